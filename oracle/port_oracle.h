@@ -1,0 +1,80 @@
+/* port_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE ONLY; never linked into the product).
+ *
+ * A plain-C, 64-bit-index restatement of the reference's stochastic-global hot path, used by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the *checker* for the HIP
+ * path.  Each function cites the reference file:line it follows.  Pinned against the real
+ * reference (oracle/_ref/libnlopt_ref.so, built by `make ref`) and against the golden vectors in
+ * tests/golden/ by tests/test_oracle_pins.py.
+ *
+ * Naming: orc_* .  The product library (nlopt_amd/lib/libnlopt_amd.so) exports nlopt_* / nla_*
+ * and shares no object code with this directory (objfuncs.h, the objective formulae, is the one
+ * shared *source* header — SURVEY.md §7.1 step 1 requires identical objective C on both sides).
+ */
+#ifndef PORT_ORACLE_H
+#define PORT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double (*orc_func)(unsigned n, const double *x, double *grad, void *data);
+typedef void (*orc_mfunc)(unsigned m, double *result, unsigned n, const double *x, double *grad, void *data);
+
+/* result codes = nlopt_result values (src/api/nlopt.h:162-176) */
+enum { ORC_FAILURE = -1, ORC_INVALID_ARGS = -2, ORC_OUT_OF_MEMORY = -3, ORC_ROUNDOFF_LIMITED = -4,
+       ORC_FORCED_STOP = -5, ORC_SUCCESS = 1, ORC_STOPVAL_REACHED = 2, ORC_FTOL_REACHED = 3,
+       ORC_XTOL_REACHED = 4, ORC_MAXEVAL_REACHED = 5, ORC_MAXTIME_REACHED = 6 };
+
+/* ---- MT19937 (src/util/mt19937ar.c) ---------------------------------------------------------- */
+void orc_srand(unsigned long seed);                 /* nlopt_init_genrand :80-93 */
+uint32_t orc_genrand_int32(void);                   /* :97-131 */
+double orc_urand(double a, double b);               /* :194-206 */
+int orc_iurand(int n);                              /* :209-212 */
+double orc_nrand(double mean, double stddev);       /* :216-232 */
+void orc_mt_get_state(uint32_t mt[624], int *mti);
+void orc_mt_set_state(const uint32_t mt[624], int mti);
+uint64_t orc_mt_words_drawn(void);                  /* words drawn since the last orc_srand */
+
+/* ---- stopping (src/util/stop.c:81-159, nlopt-util.h:79-91) ----------------------------------- */
+typedef struct {
+    unsigned n;
+    double minf_max, ftol_rel, ftol_abs, xtol_rel;
+    const double *xtol_abs, *x_weights;
+    long nevals, maxeval;
+    double maxtime, start;
+    int force_stop;
+} orc_stop;
+void orc_stop_default(orc_stop *s, unsigned n);
+int orc_stop_ftol(const orc_stop *s, double f, double oldf);
+int orc_stop_f(const orc_stop *s, double f, double oldf);
+int orc_stop_x(const orc_stop *s, const double *x, const double *oldx);
+int orc_stop_dx(const orc_stop *s, const double *x, const double *dx);
+int orc_stop_evals(const orc_stop *s);
+int orc_stop_time(const orc_stop *s);
+double orc_seconds(void);
+
+/* ---- per-evaluation trace --------------------------------------------------------------------
+ * kind: 0 = init row, 1 = reflection trial (T), 2 = local mutation (M)
+ * row : init -> the row written; accepted trial -> the row replaced (the then-worst); else -1 */
+typedef struct { double f; int64_t row; int32_t kind; int32_t accepted; } orc_trace_rec;
+typedef struct { orc_trace_rec *rec; size_t cap, len; } orc_trace;
+
+/* ---- CRS2_LM (src/algs/crs/crs.c) ------------------------------------------------------------ */
+int orc_crs_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub,
+                     double *x, double *minf, orc_stop *stop, long population, orc_trace *trace);
+
+/* ---- objective zoo callbacks (objfuncs.h compiled for the host) ------------------------------ */
+orc_func orc_objective(int id);                     /* f_data ignored */
+double orc_con_blocksum(unsigned n, const double *x, double *grad, void *data); /* data -> unsigned[2]={q,Q} */
+
+/* recording wrapper: calls inner, appends f to buf (for pinning against the real reference) */
+typedef struct { orc_func inner; void *inner_data; double *fbuf; uint64_t *xhash; size_t cap, len; } orc_recorder;
+double orc_recording_callback(unsigned n, const double *x, double *grad, void *data);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

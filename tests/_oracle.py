@@ -1,0 +1,204 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so = the port, oracle/_ref/libnlopt_ref.so =
+the real reference compiled by oracle/Makefile).  TEST INFRASTRUCTURE: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+
+FUNC = C.CFUNCTYPE(C.c_double, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+OBJ = {"rastrigin": 0, "ackley": 1, "griewank": 2, "rosenbrock": 3, "levy": 4, "sphere": 5}
+
+
+class OrcStop(C.Structure):
+    _fields_ = [("n", C.c_uint), ("minf_max", C.c_double), ("ftol_rel", C.c_double), ("ftol_abs", C.c_double),
+                ("xtol_rel", C.c_double), ("xtol_abs", C.POINTER(C.c_double)), ("x_weights", C.POINTER(C.c_double)),
+                ("nevals", C.c_long), ("maxeval", C.c_long), ("maxtime", C.c_double), ("start", C.c_double),
+                ("force_stop", C.c_int)]
+
+
+class TraceRec(C.Structure):
+    _fields_ = [("f", C.c_double), ("row", C.c_int64), ("kind", C.c_int32), ("accepted", C.c_int32)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("rec", C.POINTER(TraceRec)), ("cap", C.c_size_t), ("len", C.c_size_t)]
+
+
+class Recorder(C.Structure):
+    _fields_ = [("inner", C.c_void_p), ("inner_data", C.c_void_p), ("fbuf", C.POINTER(C.c_double)),
+                ("xhash", C.POINTER(C.c_uint64)), ("cap", C.c_size_t), ("len", C.c_size_t)]
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORC_DIR, "port"], check=True)
+    if os.path.isdir("/root/reference/src"):
+        if not os.path.exists(os.path.join(ORC_DIR, "_ref", "libnlopt_ref.so")):
+            subprocess.run(["make", "-s", "-C", ORC_DIR, "ref"], check=True)
+
+
+_port = None
+_ref = None
+
+
+def port():
+    global _port
+    if _port is None:
+        path = os.path.join(ORC_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        L.orc_urand.restype = C.c_double
+        L.orc_urand.argtypes = [C.c_double, C.c_double]
+        L.orc_nrand.restype = C.c_double
+        L.orc_nrand.argtypes = [C.c_double, C.c_double]
+        L.orc_iurand.argtypes = [C.c_int]
+        L.orc_genrand_int32.restype = C.c_uint32
+        L.orc_srand.argtypes = [C.c_ulong]
+        L.orc_mt_words_drawn.restype = C.c_uint64
+        L.orc_objective.restype = C.c_void_p
+        L.orc_objective.argtypes = [C.c_int]
+        L.orc_stop_default.argtypes = [C.POINTER(OrcStop), C.c_uint]
+        L.orc_crs_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OrcStop), C.c_long,
+                                       C.POINTER(Trace)]
+        L.orc_hash_doubles.restype = C.c_uint64
+        L.orc_hash_doubles.argtypes = [C.POINTER(C.c_double), C.c_uint]
+        L.orc_obj_box.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _port = L
+    return _port
+
+
+def have_ref():
+    return os.path.exists(os.path.join(ORC_DIR, "_ref", "libnlopt_ref.so"))
+
+
+def ref():
+    """the real reference library (NLopt 2.11.0 compiled from /root/reference by oracle/Makefile)"""
+    global _ref
+    if _ref is None:
+        L = C.CDLL(os.path.join(ORC_DIR, "_ref", "libnlopt_ref.so"))
+        L.nlopt_create.restype = C.c_void_p
+        L.nlopt_create.argtypes = [C.c_int, C.c_uint]
+        L.nlopt_destroy.argtypes = [C.c_void_p]
+        L.nlopt_srand.argtypes = [C.c_ulong]
+        L.nlopt_optimize.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.nlopt_set_min_objective.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nlopt_set_max_objective.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        for nm in ("nlopt_set_lower_bounds", "nlopt_set_upper_bounds", "nlopt_set_xtol_abs"):
+            getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        for nm in ("nlopt_set_stopval", "nlopt_set_ftol_rel", "nlopt_set_ftol_abs", "nlopt_set_xtol_rel",
+                   "nlopt_set_maxtime", "nlopt_set_xtol_abs1"):
+            getattr(L, nm).argtypes = [C.c_void_p, C.c_double]
+        L.nlopt_set_maxeval.argtypes = [C.c_void_p, C.c_int]
+        L.nlopt_set_population.argtypes = [C.c_void_p, C.c_uint]
+        L.nlopt_get_numevals.argtypes = [C.c_void_p]
+        L.nlopt_add_inequality_constraint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        L.nlopt_add_equality_constraint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        L.nlopt_set_local_optimizer.argtypes = [C.c_void_p, C.c_void_p]
+        L.nlopt_urand.restype = C.c_double
+        L.nlopt_urand.argtypes = [C.c_double, C.c_double]
+        L.nlopt_nrand.restype = C.c_double
+        L.nlopt_nrand.argtypes = [C.c_double, C.c_double]
+        L.nlopt_iurand.argtypes = [C.c_int]
+        _ref = L
+    return _ref
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def golden_x0(obj, n):
+    """non-special start point: x0_i = lb + (ub-lb)*frac((i+1)*phi)"""
+    lo, hi = C.c_double(), C.c_double()
+    port().orc_obj_box(OBJ[obj], C.byref(lo), C.byref(hi))
+    i = np.arange(1, n + 1, dtype=np.float64)
+    fr = np.modf(i * 0.6180339887498949)[0]
+    return lo.value + (hi.value - lo.value) * fr, lo.value, hi.value
+
+
+def run_port_crs(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0,
+                 trace_cap=0, record=False):
+    """run the port's CRS2_LM; returns dict(ret, minf, x, nevals, trace, words[, fseq, xhash])"""
+    L = port()
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lb = np.full(n, lo)
+    ub = np.full(n, hi)
+    st = OrcStop()
+    L.orc_stop_default(C.byref(st), n)
+    st.maxeval = maxeval
+    st.ftol_rel, st.ftol_abs, st.xtol_rel = ftol_rel, ftol_abs, xtol_rel
+    if stopval is not None:
+        st.minf_max = stopval
+    tr = Trace()
+    recs = (TraceRec * max(trace_cap, 1))()
+    tr.rec, tr.cap, tr.len = recs, trace_cap, 0
+    f = L.orc_objective(OBJ[obj])
+    fdata = None
+    rec = None
+    if record:
+        cap = (maxeval or 100000) + 2 * n + 1000
+        fbuf = np.zeros(cap)
+        hbuf = np.zeros(cap, dtype=np.uint64)
+        rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
+        f = C.cast(L.orc_recording_callback, C.c_void_p).value
+        fdata = C.cast(C.pointer(rec), C.c_void_p)
+    minf = C.c_double()
+    L.orc_srand(seed)
+    ret = L.orc_crs_minimize(n, f, fdata, dptr(lb), dptr(ub), dptr(x), C.byref(minf), C.byref(st), pop, C.byref(tr))
+    out = dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, words=L.orc_mt_words_drawn())
+    k = min(tr.len, trace_cap)
+    out["trace"] = np.array([(recs[i].f, recs[i].row, recs[i].kind, recs[i].accepted) for i in range(k)],
+                            dtype=[("f", "f8"), ("row", "i8"), ("kind", "i4"), ("accepted", "i4")])
+    if record:
+        out["fseq"] = fbuf[:rec.len].copy()
+        out["xhash"] = hbuf[:rec.len].copy()
+    return out
+
+
+def run_ref(alg, obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0,
+            record=True, setup=None):
+    """run the REAL reference through its public C API with the zoo objective as host callback"""
+    R, L = ref(), port()
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lb = np.full(n, lo)
+    ub = np.full(n, hi)
+    opt = R.nlopt_create(alg, n)
+    R.nlopt_set_lower_bounds(opt, dptr(lb))
+    R.nlopt_set_upper_bounds(opt, dptr(ub))
+    f = L.orc_objective(OBJ[obj])
+    cap = (maxeval or 100000) + 2 * n + 1000
+    fbuf = np.zeros(cap)
+    hbuf = np.zeros(cap, dtype=np.uint64)
+    rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
+    R.nlopt_set_min_objective(opt, C.cast(L.orc_recording_callback, C.c_void_p).value,
+                              C.cast(C.pointer(rec), C.c_void_p))
+    if pop:
+        R.nlopt_set_population(opt, pop)
+    if maxeval:
+        R.nlopt_set_maxeval(opt, maxeval)
+    if stopval is not None:
+        R.nlopt_set_stopval(opt, stopval)
+    if ftol_rel:
+        R.nlopt_set_ftol_rel(opt, ftol_rel)
+    if ftol_abs:
+        R.nlopt_set_ftol_abs(opt, ftol_abs)
+    if xtol_rel:
+        R.nlopt_set_xtol_rel(opt, xtol_rel)
+    keep = setup(R, opt) if setup else None
+    minf = C.c_double()
+    R.nlopt_srand(seed)
+    ret = R.nlopt_optimize(opt, dptr(x), C.byref(minf))
+    out = dict(ret=ret, minf=minf.value, x=x, nevals=R.nlopt_get_numevals(opt), fseq=fbuf[:rec.len].copy(),
+               xhash=hbuf[:rec.len].copy())
+    R.nlopt_destroy(opt)
+    del keep
+    return out
