@@ -1,0 +1,162 @@
+/* nlopt_amd.h — additive extension of the NLopt C API plus the kernel-level C-ABI of libnlopt_amd.
+ *
+ * Part 1 (user-facing): the device-objective registry the reference cannot have (its objective
+ *   is a host callback, src/api/nlopt.h:60-62; SURVEY.md §8b "required extension"), run
+ *   statistics and the per-evaluation trace used by the parity tests.  All symbols are new
+ *   (nlopt_amd_*), none changes the reference ABI.
+ *
+ * Part 2 (nla_k_*): one `extern "C"` launcher per HIP kernel.  Plain pointers and sizes only;
+ *   every pointer is a DEVICE pointer unless its name starts with h_; `stream` is a hipStream_t
+ *   passed as void*; return value 0 = launched, otherwise the hipError_t.  These are what a
+ *   maintainer of the reference would bind to replace the CPU loops listed in SURVEY.md §2.3
+ *   (each launcher cites the loop it replaces).  The parity tests call through them.
+ */
+#ifndef NLOPT_AMD_H
+#define NLOPT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "nlopt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1 — extension API
+ * ---------------------------------------------------------------------------------------------- */
+#define NLOPT_AMD_OBJ_RASTRIGIN  0
+#define NLOPT_AMD_OBJ_ACKLEY     1
+#define NLOPT_AMD_OBJ_GRIEWANK   2   /* test/testfuncs.c:250-266 */
+#define NLOPT_AMD_OBJ_ROSENBROCK 3   /* test/testfuncs.c:124-140, n-general */
+#define NLOPT_AMD_OBJ_LEVY       4   /* test/testfuncs.c:218-240 */
+#define NLOPT_AMD_OBJ_SPHERE     5
+#define NLOPT_AMD_OBJ_COUNT      6
+
+/* Host callback (sequential, same formulae) for device objective `id`; passing exactly this
+ * pointer to nlopt_set_min/max_objective selects the HIP evaluator (pointer identity). */
+nlopt_func nlopt_amd_objective(int id);
+int nlopt_amd_objective_id(nlopt_func f);              /* -1: not a device objective */
+const char *nlopt_amd_objective_name(int id);
+void nlopt_amd_objective_box(int id, double *lo, double *hi);
+
+/* block-sum inequality constraint g(x) = sum_{i in block q of Q} x_i - 1 <= 0 (ISRES config,
+ * SURVEY.md §8d); func_data must point at `unsigned qQ[2] = {q, Q}` that outlives the run. */
+nlopt_func nlopt_amd_constraint_blocksum(void);
+
+int nlopt_amd_device_count(void);                      /* visible HIP devices (0 => optimize fails loudly) */
+
+/* per-evaluation trace (same record as the oracle's): kind 0 = initial row, 1 = reflection trial,
+ * 2 = local mutation; row = row written (init / accepted) or -1. */
+typedef struct { double f; int64_t row; int32_t kind; int32_t accepted; } nlopt_amd_trace_rec;
+nlopt_result nlopt_amd_set_trace(nlopt_opt opt, nlopt_amd_trace_rec *buf, size_t cap);
+size_t nlopt_amd_trace_len(const nlopt_opt opt);       /* records produced by the last nlopt_optimize */
+
+typedef struct {
+    uint64_t rounds;            /* speculate/commit rounds */
+    uint64_t slots_launched;    /* speculative reflection trials computed on the device */
+    uint64_t slots_used;        /* ... consumed by the in-order commit walk */
+    uint64_t slots_invalid;     /* ... discarded: read a row overwritten earlier in the same round */
+    uint64_t slots_newbest;     /* ... discarded: the best point changed earlier in the same round */
+    uint64_t slots_role;        /* ... discarded: their block was consumed as a mutation block */
+    uint64_t evals_init, evals_trial, evals_mutation;
+    uint64_t accepted;
+    uint64_t mt_words;          /* MT19937 words consumed (== the reference's count) */
+    double t_init_s, t_trial_s; /* wall seconds in the two phases */
+    double t_gather_ms;         /* sum of device time of the gather kernel (HIP events) */
+    uint64_t gather_launches;
+    uint64_t gather_bytes;      /* algorithmic bytes moved by those launches: slots * 8 n (n+1) */
+} nlopt_amd_stats;
+nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2 — kernel-level C-ABI (device pointers; see file header)
+ * ---------------------------------------------------------------------------------------------- */
+#define NLA_MT_N 624
+#define NLA_MT_POLYWORDS 312           /* GF(2) polynomial of degree < 19937 as 64-bit words */
+#define NLA_MT_SEG_REGENS 1024         /* one stream segment = 1024 regenerations */
+#define NLA_MT_SEG_WORDS (624ULL * NLA_MT_SEG_REGENS)
+
+/* replaces: the serial generator src/util/mt19937ar.c:102-120 advanced J words.
+ * dst[i] (624 words) = block array `J` words after src[i], g = t^J mod phi (312 u64). */
+int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src_states, uint32_t *dst_states, int count, void *stream);
+
+/* replaces: nlopt_genrand_int32, src/util/mt19937ar.c:97-131, called count times.
+ * out[i] = tempered stream word g_first+i; seg_states + 624*s = block array at the start of
+ * segment seg_first+s; the nseg segments must cover [g_first, g_first+count). */
+int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg,
+                      uint64_t g_first, uint64_t count, uint32_t *out, void *stream);
+
+/* replaces: crs_init's row loop, src/algs/crs/crs.c:211-226 (K1+K2 of SURVEY.md §2.3).
+ * rows row_first .. row_first+nrows-1 of X (leading dimension ld) := lb + (ub-lb)*res53(words),
+ * row r uses words[(r-row_first)*2n ...]; F[r] := objective(X[r]). obj < 0: skip evaluation. */
+int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, const double *ub, const uint32_t *words,
+                        int64_t row_first, int64_t nrows, double *X, double *F, void *stream);
+
+/* replaces: one objective call per candidate (crs.c:133,205,220; isres.c:138; mlsl.c:335,360).
+ * F[c] = objective(P + c*ld), c < count; one wavefront per candidate. */
+int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F, void *stream);
+
+/* replaces: the Vitter method-A chain of random_trial, crs.c:89-109 (K3), for nblocks
+ * consecutive 2n-word blocks of the stream, one lane per block.  Outputs per block b:
+ *   jn[b]          which pick is reflected (crs.c:72)
+ *   pos[b*n + t]   t < n-1: position of pick t among the N-1 non-best rows ("reduced" index,
+ *                  the actual row is r + (r >= i0)); pos[b*n + n-1] = reduced position from
+ *                  which the last pick jumps
+ *   last[b]        d = iurand(Nleft) of the last pick (crs.c:109), resolved against i0 at use. */
+int nla_k_crs_vitter(int n, int64_t N, const uint32_t *words, int nblocks,
+                     int32_t *jn, int32_t *pos, int32_t *last, void *stream);
+
+/* replaces: the centroid/reflection gather-sum of random_trial, crs.c:101-120 (K4), for K
+ * speculative trials at once against one population snapshot.  Slot s uses block s of
+ * jn/pos/last; TX[s*ld + k] = clamp((best_k + sum ...) * 2/n).  Row order, one accumulator per
+ * coordinate, no FMA: bit-identical to the reference's x. */
+int nla_k_crs_gather(int n, int ld, const double *X, int64_t i0, const int32_t *jn, const int32_t *pos,
+                     const int32_t *last, int K, const double *lb, const double *ub, double *TX, void *stream);
+
+/* replaces: the evaluation of the trial (crs.c:133), the local mutation + its evaluation
+ * (crs.c:139-146, K5) and the information the in-order commit needs (K6):
+ *   fT[s] = f(TX[s]);  TM[s] = clamp(best*(1+w) - w*TX[s]) with w from stream block s+1
+ *   (words_next = words of block first+1), fM[s] = f(TM[s]);
+ *   minhz[s] = smallest rank r < nW with W[r] among the rows slot s read (INT32_MAX if none).
+ * obj < 0: no evaluation / no mutation (host-callback mode). */
+int nla_k_crs_post(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                   const uint32_t *words_next, int K, const int64_t *W, int nW,
+                   const int32_t *pos, const int32_t *last, const double *lb, const double *ub,
+                   double *fT, double *fM, int32_t *minhz, void *stream);
+
+/* replaces: memcpy(worst->k, d->p, ...) at crs.c:153 for a batch of accepted candidates.
+ * X[row[c]] := (kind[c] == 1 ? TX : TM)[slot[c]];  rows must be distinct within one call. */
+int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
+                     const int32_t *slot, const int32_t *kind, const int64_t *row, void *stream);
+
+/* single local mutation of one candidate in place (host-callback mode, crs.c:139-146) */
+int nla_k_crs_mutate(int n, const double *best, double *p, const uint32_t *words,
+                     const double *lb, const double *ub, void *stream);
+
+/* thin device-runtime layer the C host code uses (no HIP types cross the boundary) */
+int nla_dev_count(void);
+int nla_dev_set(int dev);
+void *nla_dev_malloc(size_t bytes);
+void nla_dev_free(void *p);
+void *nla_host_malloc(size_t bytes);            /* pinned */
+void nla_host_free(void *p);
+int nla_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream);
+int nla_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream);
+int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int nla_memset(void *dst, int value, size_t bytes, void *stream);
+void *nla_stream_create(void);
+void nla_stream_destroy(void *stream);
+int nla_stream_sync(void *stream);
+void *nla_event_create(void);
+void nla_event_destroy(void *ev);
+int nla_event_record(void *ev, void *stream);
+int nla_event_sync(void *ev);
+float nla_event_elapsed_ms(void *ev0, void *ev1);
+int nla_stream_wait_event(void *stream, void *ev);
+const char *nla_dev_error_string(int err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLOPT_AMD_H */

@@ -1,0 +1,64 @@
+"""Build libnlopt_amd.so in-tree: HIP kernels with hipcc for gfx950, C host code with gcc, one shared
+library exporting the NLopt C API (include/nlopt.h) + the extension / kernel-level C-ABI
+(include/nlopt_amd.h).  hipcc cross-compiles without a GPU, so this runs on the build container;
+the .so travels to the GPU box with the snapshot (git-ignored, not gpurun-ignored)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libnlopt_amd.so")
+
+HIP_SRC = ["hip/devrt.hip", "hip/mt_kernels.hip", "hip/crs_kernels.hip"]
+C_SRC = ["mt_host.c", "mtstream.c", "stopping.c", "objfuncs.c", "api_general.c", "api_options.c", "api_optimize.c",
+         "crs_driver.c", "crs_engine.c"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off everywhere: population rows and trial points must be bit-identical to the
+# reference, which is built with it (CMakeLists.txt:280-284).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
+C_FLAGS = ["-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-fvisibility=default"]
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src,) + tuple(extra))
+
+
+def _headers():
+    hs = []
+    for root in (CSRC, os.path.join(CSRC, "hip"), os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith(".h"):
+                hs.append(os.path.join(root, f))
+    return tuple(hs)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    objs = []
+    relink = force
+    for rel in HIP_SRC + C_SRC:
+        src = os.path.join(CSRC, rel)
+        obj = os.path.join(OBJ, os.path.basename(rel).rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj, hdrs):
+            cmd = ([HIPCC] + HIP_FLAGS if rel.endswith(".hip") else ["gcc"] + C_FLAGS) + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            relink = True
+    if relink or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lm"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

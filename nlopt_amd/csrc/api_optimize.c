@@ -1,0 +1,120 @@
+/* api_optimize.c — nlopt_optimize and the dispatcher for the algorithms this library provides.
+ * Follows the control flow of the reference's src/api/optimize.c: nlopt_optimize :991-1083
+ * (force_stop reset, maximisation by sign flip), nlopt_optimize_ :514-959 (n == 0 shortcut, RNG
+ * seeding, bounds check, nlopt_stopping setup, switch on the algorithm) and
+ * nlopt_optimize_limited :1087-1113.  Cases outside the stochastic-global hot path are not
+ * provided and say so in errmsg.  The elimdim wrapper (:219-445) for lb[i]==ub[i] coordinates is
+ * listed as "next" in SURVEY.md §8f and is not applied. */
+#include "nla_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define POP(opt, dflt) ((opt)->stochastic_population > 0 ? (int) (opt)->stochastic_population : \
+                        (nla_stochastic_population > 0 ? nla_stochastic_population : (dflt)))   /* optimize.c:511 */
+
+static int finite_domain(unsigned n, const double *lb, const double *ub)     /* optimize.c:187-194 */
+{
+    unsigned i;
+    for (i = 0; i < n; ++i) if (nla_isinf(ub[i] - lb[i])) return 0;
+    return 1;
+}
+
+typedef struct { nlopt_func f; nlopt_precond pre; void *f_data; } flip_data;
+static double flipped_objective(unsigned n, const double *x, double *grad, void *data)   /* optimize.c:970-980 */
+{
+    flip_data *d = (flip_data *) data;
+    double v = d->f(n, x, grad, d->f_data);
+    if (grad) { unsigned i; for (i = 0; i < n; ++i) grad[i] = -grad[i]; }
+    return -v;
+}
+static void flipped_precond(unsigned n, const double *x, const double *v, double *vpre, void *data)
+{
+    flip_data *d = (flip_data *) data;
+    unsigned i;
+    d->pre(n, x, v, vpre, d->f_data);
+    for (i = 0; i < n; ++i) vpre[i] = -vpre[i];
+}
+
+static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
+{
+    nla_stopping stop;
+    unsigned n, i;
+    if (!opt || !x || !minf || !opt->f || opt->maximize) { if (opt) nla_set_errmsg(opt, "NULL args to nlopt_optimize_"); return NLOPT_INVALID_ARGS; }
+    n = opt->n;
+    if (n == 0) { *minf = opt->f(n, x, NULL, opt->f_data); return NLOPT_SUCCESS; }    /* optimize.c:536-539 */
+    *minf = HUGE_VAL;
+    nla_srand_time_default();                                                            /* optimize.c:544 */
+    for (i = 0; i < n; ++i)
+        if (opt->lb[i] > opt->ub[i] || x[i] < opt->lb[i] || x[i] > opt->ub[i]) {
+            nla_set_errmsg(opt, "bounds %d fail %g <= %g <= %g", i, opt->lb[i], x[i], opt->ub[i]);
+            return NLOPT_INVALID_ARGS;
+        }
+    stop.n = n;
+    stop.minf_max = opt->stopval;
+    stop.ftol_rel = opt->ftol_rel; stop.ftol_abs = opt->ftol_abs;
+    stop.xtol_rel = opt->xtol_rel; stop.xtol_abs = opt->xtol_abs; stop.x_weights = opt->x_weights;
+    opt->numevals = 0;
+    stop.nevals_p = &opt->numevals;
+    stop.maxeval = opt->maxeval; stop.maxtime = opt->maxtime;
+    stop.start = nla_seconds();
+    stop.force_stop = &opt->force_stop;
+    stop.stop_msg = &opt->errmsg;
+    opt->trace_len = 0;
+    memset(&opt->stats, 0, sizeof opt->stats);
+
+    switch (opt->algorithm) {
+    case NLOPT_GN_CRS2_LM:                                                               /* optimize.c:744-747 */
+        if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
+        return nla_crs_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, POP(opt, 0));
+    default:
+        nla_set_errmsg(opt, "algorithm %s is not provided by libnlopt_amd (stochastic-global hot path only)",
+                       nlopt_algorithm_to_string(opt->algorithm));
+        return NLOPT_INVALID_ARGS;
+    }
+}
+
+nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
+{
+    nlopt_func f; void *f_data; nlopt_precond pre;
+    flip_data fd;
+    int maximize;
+    nlopt_result ret;
+    nla_unset_errmsg(opt);
+    if (!opt || !opt_f || !opt->f) { if (opt) nla_set_errmsg(opt, "NULL args to nlopt_optimize"); return NLOPT_INVALID_ARGS; }
+    f = opt->f; f_data = opt->f_data; pre = opt->pre;
+    nlopt_set_force_stop(opt, 0);
+    opt->force_stop_child = NULL;
+    if ((maximize = opt->maximize)) {          /* minimise -f (optimize.c:1014-1024) */
+        fd.f = f; fd.f_data = f_data; fd.pre = pre;
+        opt->f = flipped_objective; opt->f_data = &fd;
+        if (opt->pre) opt->pre = flipped_precond;
+        opt->stopval = -opt->stopval;
+        opt->maximize = 0;
+    }
+    ret = minimize_dispatch(opt, x, opt_f);
+    if (maximize) {
+        opt->maximize = maximize;
+        opt->stopval = -opt->stopval;
+        opt->f = f; opt->f_data = f_data; opt->pre = pre;
+        *opt_f = -*opt_f;
+    }
+    return ret;
+}
+
+nlopt_result nla_optimize_limited(nlopt_opt opt, double *x, double *minf, int maxeval, double maxtime)   /* optimize.c:1087-1113 */
+{
+    int save_maxeval;
+    double save_maxtime;
+    nlopt_result ret;
+    nla_unset_errmsg(opt);
+    if (!opt) return NLOPT_INVALID_ARGS;
+    save_maxeval = nlopt_get_maxeval(opt);
+    save_maxtime = nlopt_get_maxtime(opt);
+    if (save_maxeval <= 0 || (maxeval > 0 && maxeval < save_maxeval)) nlopt_set_maxeval(opt, maxeval);
+    if (save_maxtime <= 0 || (maxtime > 0 && maxtime < save_maxtime)) nlopt_set_maxtime(opt, maxtime);
+    ret = nlopt_optimize(opt, x, minf);
+    nlopt_set_maxeval(opt, save_maxeval);
+    nlopt_set_maxtime(opt, save_maxtime);
+    return ret;
+}

@@ -1,0 +1,79 @@
+/* devrt.hip — the thin C-ABI device-runtime layer under the C host code: memory, streams, events.
+ * No HIP type crosses the boundary (streams/events travel as void*), so the host side stays
+ * plain C compiled by gcc, as north_star asks ("host code in C calling HIP through a thin C-ABI
+ * layer").  There is no CPU fallback anywhere: with no visible device nla_dev_count() returns 0
+ * and the optimisers fail with NLOPT_FAILURE and an errmsg. */
+#include <hip/hip_runtime.h>
+#include "../../../include/nlopt_amd.h"
+
+extern "C" int nla_dev_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return c;
+}
+extern "C" int nla_dev_set(int dev) { return (int) hipSetDevice(dev); }
+
+extern "C" void *nla_dev_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void nla_dev_free(void *p) { if (p) (void) hipFree(p); }
+
+extern "C" void *nla_host_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void nla_host_free(void *p) { if (p) (void) hipHostFree(p); }
+
+extern "C" int nla_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream)
+{
+    if (!bytes) return 0;
+    return (int) hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t) stream);
+}
+extern "C" int nla_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream)
+{
+    if (!bytes) return 0;
+    return (int) hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream);
+}
+extern "C" int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!bytes) return 0;
+    return (int) hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream);
+}
+extern "C" int nla_memset(void *dst, int value, size_t bytes, void *stream)
+{
+    if (!bytes) return 0;
+    return (int) hipMemsetAsync(dst, value, bytes, (hipStream_t) stream);
+}
+
+extern "C" void *nla_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return (void *) s;
+}
+extern "C" void nla_stream_destroy(void *stream) { if (stream) (void) hipStreamDestroy((hipStream_t) stream); }
+extern "C" int nla_stream_sync(void *stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
+
+extern "C" void *nla_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return (void *) e;
+}
+extern "C" void nla_event_destroy(void *ev) { if (ev) (void) hipEventDestroy((hipEvent_t) ev); }
+extern "C" int nla_event_record(void *ev, void *stream) { return (int) hipEventRecord((hipEvent_t) ev, (hipStream_t) stream); }
+extern "C" int nla_event_sync(void *ev) { return (int) hipEventSynchronize((hipEvent_t) ev); }
+extern "C" float nla_event_elapsed_ms(void *ev0, void *ev1)
+{
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t) ev0, (hipEvent_t) ev1) != hipSuccess) { (void) hipGetLastError(); return -1.f; }
+    return ms;
+}
+extern "C" int nla_stream_wait_event(void *stream, void *ev) { return (int) hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) ev, 0); }
+extern "C" const char *nla_dev_error_string(int err) { return hipGetErrorString((hipError_t) err); }

@@ -1,0 +1,129 @@
+/* mt_kernels.hip — the MT19937 word stream on gfx950.
+ *
+ * The reference draws every random number from one serial generator (src/util/mt19937ar.c).
+ * Here the same word stream is produced in parallel: the stream is cut into segments of
+ * NLA_MT_SEG_REGENS regenerations (638,976 words); the block array at the start of every segment
+ * is obtained by GF(2) jump-ahead (mt_jump_kernel, polynomials from ../mt_host.c) in log2(#seg)
+ * doubling rounds, then one wavefront per segment regenerates its 1024 blocks out of LDS and
+ * writes the tempered words with coalesced 256-byte stores (mt_generate_kernel).
+ *
+ * Bound: integer VALU + LDS latency (3 dependent phases of 227 words per regeneration,
+ * mt19937ar.c:108-117); HBM traffic is 4 B/word written once.
+ */
+#include "dev_common.h"
+#include "../../../include/nlopt_amd.h"
+
+#define MT_N 624
+#define MT_M 397
+#define MT_DEG 19937
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t hi, uint32_t lo, uint32_t far)
+{
+    uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)       /* mt19937ar.c:125-128 */
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* one wavefront (= one 64-thread workgroup) per segment */
+__global__ __launch_bounds__(64) void mt_generate_kernel(const uint32_t *__restrict__ seg_states, uint64_t seg_first,
+                                                          uint64_t g_first, uint64_t count, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t mt[MT_N];
+    const int lane = threadIdx.x;
+    const uint64_t seg = seg_first + blockIdx.x;
+    const uint64_t g_end = g_first + count;
+    const uint64_t g0 = seg * NLA_MT_SEG_WORDS;
+
+    for (int i = lane; i < MT_N; i += 64) mt[i] = seg_states[(size_t) blockIdx.x * MT_N + i];
+    __syncthreads();
+
+    for (int r = 0; r < NLA_MT_SEG_REGENS; ++r) {
+        const uint64_t gb = g0 + (uint64_t) r * MT_N;
+        if (gb >= g_end) break;
+        if (gb + MT_N > g_first) {
+            for (int i = lane; i < MT_N; i += 64) {
+                const uint64_t g = gb + i;
+                if (g >= g_first && g < g_end) out[g - g_first] = mt_temper(mt[i]);
+            }
+        }
+        /* regenerate in place: three phases whose inputs are all older than their outputs */
+        for (int k = lane; k < MT_N - MT_M; k += 64) {                       /* 0 .. 226 */
+            uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k + MT_M]);
+            mt[k] = v;      /* lanes read before any lane of this step writes (lockstep); k+1 of
+                               the last lane of a step is written only by the next step */
+        }
+        __syncthreads();
+        for (int k = MT_N - MT_M + lane; k < 2 * (MT_N - MT_M); k += 64) {     /* 227 .. 453 */
+            uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]);
+            mt[k] = v;
+        }
+        __syncthreads();
+        for (int k = 2 * (MT_N - MT_M) + lane; k < MT_N - 1; k += 64) {        /* 454 .. 622 */
+            uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]);
+            mt[k] = v;
+        }
+        __syncthreads();
+        if (lane == 0) mt[MT_N - 1] = mt_twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+        __syncthreads();
+    }
+}
+
+/* dst = block array J words after src, g = t^J mod phi.  One 640-thread workgroup per state:
+ * (a) extend src to the 33*624 consecutive untempered words x[0 .. 20591] in LDS (88 dependent
+ * steps of 227 words), (b) thread j < 624 forms y_j = XOR_{i : g_i} x[i+j]; g is wave-uniform so
+ * the bit test is a scalar branch and the LDS reads of a wavefront are 64 consecutive words. */
+#define JUMP_BLOCKS 33
+#define JUMP_WORDS (JUMP_BLOCKS * MT_N)
+__global__ __launch_bounds__(640) void mt_jump_kernel(const uint64_t *__restrict__ poly, const uint32_t *__restrict__ src,
+                                                       uint32_t *__restrict__ dst)
+{
+    __shared__ uint32_t x[JUMP_WORDS];
+    const int tid = threadIdx.x;
+    const uint32_t *s = src + (size_t) blockIdx.x * MT_N;
+    if (tid < MT_N) x[tid] = s[tid];
+    __syncthreads();
+    /* x[m+624] = x[m+397] ^ A(x[m] upper | x[m+1] lower); chunk c produces words 624+227c .. */
+    for (int base = MT_N; base < JUMP_WORDS; base += (MT_N - MT_M)) {
+        int j = base + tid;
+        if (tid < (MT_N - MT_M) && j < JUMP_WORDS) x[j] = mt_twist(x[j - MT_N], x[j - MT_N + 1], x[j - (MT_N - MT_M)]);
+        __syncthreads();
+    }
+    if (tid < MT_N) {
+        uint32_t acc = 0;
+        for (int w = 0; w < NLA_MT_POLYWORDS; ++w) {
+            uint64_t gw = poly[w];                       /* uniform -> scalar load */
+            const uint32_t *xw = x + w * 64 + tid;
+            while (gw) {
+                int b = __builtin_ctzll(gw);
+                gw &= gw - 1;
+                acc ^= xw[b];
+            }
+        }
+        dst[(size_t) blockIdx.x * MT_N + tid] = acc;
+    }
+}
+
+extern "C" int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src_states, uint32_t *dst_states, int count, void *stream)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(mt_jump_kernel, dim3(count), dim3(640), 0, (hipStream_t) stream, poly, src_states, dst_states);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg,
+                                 uint64_t g_first, uint64_t count, uint32_t *out, void *stream)
+{
+    if (nseg <= 0 || count == 0) return 0;
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(nseg), dim3(64), 0, (hipStream_t) stream,
+                       seg_states, seg_first, g_first, count, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

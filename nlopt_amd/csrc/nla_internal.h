@@ -1,0 +1,174 @@
+/* nla_internal.h — internal declarations of libnlopt_amd's C host side.
+ * Mirrors the roles of the reference's src/api/nlopt-internal.h (struct nlopt_opt_s :40-88) and
+ * src/util/nlopt-util.h (nlopt_stopping :79-91, nlopt_constraint :119-126); own layout. */
+#ifndef NLA_INTERNAL_H
+#define NLA_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/nlopt.h"
+#include "../../include/nlopt_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLA_MT_M 397
+#define NLA_MT_DEG 19937
+#define NLA_MT_MAXPOW2 48
+
+#define NLA_VERSION_MAJOR 2     /* API level of the reference this library is a drop-in for */
+#define NLA_VERSION_MINOR 11
+#define NLA_VERSION_BUGFIX 0
+
+/* ---- stopping criteria (reference: nlopt-util.h:79-91, stop.c:81-159) ------------------------ */
+typedef struct {
+    unsigned n;
+    double minf_max, ftol_rel, ftol_abs, xtol_rel;
+    const double *xtol_abs, *x_weights;
+    int *nevals_p, maxeval;
+    double maxtime, start;
+    int *force_stop;
+    char **stop_msg;
+} nla_stopping;
+
+int nla_stop_ftol(const nla_stopping *s, double f, double oldf);
+int nla_stop_f(const nla_stopping *s, double f, double oldf);
+int nla_stop_x(const nla_stopping *s, const double *x, const double *oldx);
+int nla_stop_dx(const nla_stopping *s, const double *x, const double *dx);
+int nla_stop_evals(const nla_stopping *s);
+int nla_stop_time(const nla_stopping *s);
+int nla_stop_forced(const nla_stopping *s);
+void nla_stop_msg(const nla_stopping *s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int nla_isinf(double x);
+int nla_istiny(double x);
+double nla_seconds(void);
+unsigned long nla_time_seed(void);
+long nla_thread_id(void);
+
+/* ---- constraints (reference: nlopt-util.h:119-126) ------------------------------------------- */
+typedef struct {
+    unsigned m;
+    nlopt_func f;
+    nlopt_mfunc mf;
+    nlopt_precond pre;
+    void *f_data;
+    double *tol;
+} nla_constraint;
+
+typedef struct { char *name; double val; } nla_param;
+
+/* ---- the optimiser object (reference: nlopt-internal.h:40-88) -------------------------------- */
+struct nlopt_opt_s {
+    nlopt_algorithm algorithm;
+    unsigned n;
+    nlopt_func f; void *f_data; nlopt_precond pre; int maximize;
+    nla_param *params; unsigned nparams;
+    double *lb, *ub;
+    unsigned m, m_alloc; nla_constraint *fc;
+    unsigned p, p_alloc; nla_constraint *h;
+    nlopt_munge munge_on_destroy, munge_on_copy;
+    double stopval, ftol_rel, ftol_abs, xtol_rel, *xtol_abs, *x_weights;
+    int maxeval, numevals;
+    double maxtime;
+    int force_stop;
+    struct nlopt_opt_s *force_stop_child;
+    nlopt_opt local_opt;
+    unsigned stochastic_population;
+    double *dx;
+    unsigned vector_storage;
+    char *errmsg;
+    /* --- libnlopt_amd additions (not in the reference) --- */
+    nlopt_amd_trace_rec *trace; size_t trace_cap, trace_len;
+    nlopt_amd_stats stats;
+};
+
+const char *nla_set_errmsg(nlopt_opt opt, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void nla_unset_errmsg(nlopt_opt opt);
+char *nla_vsprintf(char *p, const char *fmt, __builtin_va_list ap);
+
+extern int nla_stochastic_population;                 /* deprecated.c:61 semantics */
+extern nlopt_algorithm nla_local_search_alg_deriv, nla_local_search_alg_nonderiv;
+extern int nla_local_search_maxeval;
+
+nlopt_result nla_optimize_limited(nlopt_opt opt, double *x, double *minf, int maxeval, double maxtime);
+
+/* ---- MT19937 host side (mt_host.c) ------------------------------------------------------------ */
+void nla_mt_seed_array(uint32_t mt[NLA_MT_N], unsigned long seed);
+void nla_mt_regen(uint32_t mt[NLA_MT_N]);
+uint32_t nla_mt_temper(uint32_t y);
+uint32_t nla_genrand_int32(void);
+double nlopt_urand(double a, double b);
+int nlopt_iurand(int n);
+double nlopt_nrand(double mean, double stddev);
+void nla_srand_time_default(void);
+void nla_mt_export(uint32_t mt[NLA_MT_N], int *consumed);
+void nla_mt_import(const uint32_t mt[NLA_MT_N], int consumed);
+int nla_mt_charpoly_terms(const int **exps);
+void nla_mt_jump_poly_words(uint64_t J, uint64_t g[NLA_MT_POLYWORDS]);
+const uint64_t *nla_mt_jump_poly_pow2(int k);
+void nla_mt_apply_jump_host(const uint64_t g[NLA_MT_POLYWORDS], const uint32_t src[NLA_MT_N], uint32_t dst[NLA_MT_N]);
+void nla_mt_advance_blocks_host(const uint32_t src[NLA_MT_N], uint64_t regens, uint32_t dst[NLA_MT_N]);
+
+/* ---- device word stream (mtstream.c): the host generator continued on the GPU ---------------- */
+typedef struct nla_mtstream nla_mtstream;
+nla_mtstream *nla_mtstream_create(void *stream);     /* snapshots the calling thread's generator */
+void nla_mtstream_destroy(nla_mtstream *s);
+uint64_t nla_mtstream_origin(const nla_mtstream *s); /* global index of the first unconsumed word */
+/* out[i] = stream word (origin + rel_first + i), i < count; device pointer, async on `stream` */
+int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint32_t *d_out);
+/* leave the calling thread's generator as if it had drawn `consumed` words since create */
+int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed);
+
+/* ---- CRS engine interface (the device work the algorithm driver asks for) --------------------
+ * The driver (crs_driver.c) owns the algorithm: ordered set, accept/reject chain, stopping.
+ * The engine owns device memory and kernels.  `kind`: 1 = reflection trial, 2 = mutation. */
+typedef struct {
+    /* population rows 1..N-1 from the stream (2n words each), row 0 = x0; F[0..N-1] on the host.
+     * obj < 0 (host-callback mode): rows generated but not evaluated. */
+    int (*init_population)(void *e, const double *x0, double *F);
+    /* how many consecutive blocks starting at `first_block` can be speculated in one call */
+    int (*max_slots)(void *e, uint64_t first_block);
+    /* speculate K reflection trials (stream blocks first_block .. +K-1) against the current
+     * population with best row i0; W[0..nW) = rows that may be overwritten this round, worst first.
+     * Out: fT[K], fM[K] (mutation of slot s uses block first_block+s+1), minhz[K]. */
+    int (*speculate)(void *e, uint64_t first_block, int K, int64_t i0, const int64_t *W, int nW,
+                     double *fT, double *fM, int32_t *minhz);
+    int (*commit)(void *e, int ncommit, const int32_t *slot, const int32_t *kind, const int64_t *row);
+    int (*read_slot)(void *e, int slot, int kind, double *x);
+    int (*read_row)(void *e, int64_t row, double *x);
+    /* host-callback mode: mutate slot's trial in place with block `block` (kind-1 buffer) */
+    int (*mutate_slot)(void *e, int slot, uint64_t block, int64_t i0);
+    const char *(*last_error)(void *e);
+} nla_crs_engine_ops;
+
+typedef struct {
+    int n; int64_t N;
+    const double *lb, *ub;
+    int obj;                        /* device objective id, or -1: call f on the host */
+    nlopt_func f; void *f_data;
+    nla_stopping *stop;
+    nlopt_amd_trace_rec *trace; size_t trace_cap, *trace_len;
+    nlopt_amd_stats *stats;
+    int max_spec;                   /* cap on slots per round (0 = default) */
+} nla_crs_problem;
+
+/* the algorithm; *words_used = stream words consumed (2n per row / block) */
+nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *engine, const nla_crs_problem *pb,
+                         double *x, double *minf, uint64_t *words_used);
+
+/* HIP engine (crs_engine.c) */
+typedef struct nla_crs_hip_engine nla_crs_hip_engine;
+nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj,
+                                              nlopt_amd_stats *stats, char **errmsg);
+void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used);
+extern const nla_crs_engine_ops nla_crs_hip_ops;
+
+/* reference-shaped entry (src/algs/crs/crs.h:34-40) */
+nlopt_result nla_crs_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,
+                              double *x, double *minf, nla_stopping *stop, int population);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

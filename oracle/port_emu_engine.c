@@ -1,0 +1,138 @@
+/* port_emu_engine.c — CPU ORACLE (test infrastructure): a CPU stand-in for the HIP engine, built
+ * from the per-kernel statements of port_kernels.c, so that the product's *host-side* CRS logic
+ * (nlopt_amd/csrc/crs_driver.c: ordered set, speculation validity, in-order commit, stopping
+ * quirks) can be tested against the oracle and the real reference on machines without a GPU.
+ * Lives in oracle/libemu.so, which links the product library only to call nla_crs_run(); the
+ * product never links or loads this file, and nlopt_optimize() has no path to it. */
+#include "port_oracle.h"
+#include "../nlopt_amd/csrc/nla_internal.h"
+#include "objfuncs.h"
+#include <stdlib.h>
+#include <string.h>
+
+void orc_k_words(uint64_t count, uint32_t *out);
+void orc_k_init_rows(int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t nrows, double *X);
+void orc_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F);
+void orc_k_vitter(int n, int64_t N, const uint32_t *words, int nblocks, int32_t *jn, int32_t *pos, int32_t *last);
+void orc_k_gather(int n, int ld, const double *X, int64_t i0, const int32_t *jn, const int32_t *pos, const int32_t *last,
+                  int K, const double *lb, const double *ub, double *TX);
+void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *words, const double *lb, const double *ub, double *out);
+void orc_k_minhz(int n, int64_t i0, const int32_t *pos, const int32_t *last, int K, const int64_t *W, int nW, int32_t *minhz);
+
+typedef struct {
+    int n, ld, obj, cap; int64_t N;
+    const double *lb, *ub;
+    double *X, *TX, *TM;
+    uint32_t *tw; uint64_t tw_blocks;       /* trial-phase words generated so far (blocks of 2n) */
+    int32_t *jn, *pos, *last;               /* of the last speculate */
+    int max_slots;
+} emu;
+
+static void need_blocks(emu *e, uint64_t upto)     /* the oracle generator is sequential: extend on demand */
+{
+    if (upto <= e->tw_blocks) return;
+    e->tw = (uint32_t *) realloc(e->tw, sizeof(uint32_t) * 2 * (size_t) e->n * (size_t) upto);
+    orc_k_words((upto - e->tw_blocks) * 2 * (uint64_t) e->n, e->tw + e->tw_blocks * 2 * (uint64_t) e->n);
+    e->tw_blocks = upto;
+}
+
+static int emu_init(void *ve, const double *x0, double *F)
+{
+    emu *e = (emu *) ve;
+    size_t nw = 2 * (size_t) e->n * (size_t) (e->N - 1);
+    uint32_t *w = (uint32_t *) malloc(sizeof(uint32_t) * (nw ? nw : 1));
+    memcpy(e->X, x0, sizeof(double) * (size_t) e->n);
+    orc_k_words(nw, w);
+    orc_k_init_rows(e->n, e->ld, e->lb, e->ub, w, e->N - 1, e->X + e->ld);
+    free(w);
+    if (e->obj >= 0) orc_k_eval(e->obj, e->n, e->ld, e->X, e->N, F);
+    return 0;
+}
+static int emu_max_slots(void *ve, uint64_t first_block) { (void) first_block; return ((emu *) ve)->max_slots; }
+static int emu_speculate(void *ve, uint64_t first, int K, int64_t i0, const int64_t *W, int nW, double *fT, double *fM, int32_t *minhz)
+{
+    emu *e = (emu *) ve;
+    const int n = e->n;
+    if (K > e->cap) return -1;
+    need_blocks(e, first + (uint64_t) K + 1);
+    orc_k_vitter(n, e->N, e->tw + first * 2 * (uint64_t) n, K, e->jn, e->pos, e->last);
+    orc_k_gather(n, e->ld, e->X, i0, e->jn, e->pos, e->last, K, e->lb, e->ub, e->TX);
+    orc_k_minhz(n, i0, e->pos, e->last, K, W, nW, minhz);
+    if (e->obj >= 0) {
+        orc_k_eval(e->obj, n, e->ld, e->TX, K, fT);
+        for (int s = 0; s < K; ++s)
+            orc_k_mutate(n, e->X + (size_t) i0 * e->ld, e->TX + (size_t) s * e->ld,
+                         e->tw + (first + (uint64_t) s + 1) * 2 * (uint64_t) n, e->lb, e->ub, e->TM + (size_t) s * e->ld);
+        orc_k_eval(e->obj, n, e->ld, e->TM, K, fM);
+    }
+    return 0;
+}
+static int emu_commit(void *ve, int nc, const int32_t *slot, const int32_t *kind, const int64_t *row)
+{
+    emu *e = (emu *) ve;
+    for (int c = 0; c < nc; ++c)
+        memcpy(e->X + (size_t) row[c] * e->ld, (kind[c] == 1 ? e->TX : e->TM) + (size_t) slot[c] * e->ld, sizeof(double) * (size_t) e->n);
+    return 0;
+}
+static int emu_read_slot(void *ve, int slot, int kind, double *x)
+{
+    emu *e = (emu *) ve;
+    memcpy(x, (kind == 1 ? e->TX : e->TM) + (size_t) slot * e->ld, sizeof(double) * (size_t) e->n);
+    return 0;
+}
+static int emu_read_row(void *ve, int64_t row, double *x)
+{
+    emu *e = (emu *) ve;
+    memcpy(x, e->X + (size_t) row * e->ld, sizeof(double) * (size_t) e->n);
+    return 0;
+}
+static int emu_mutate_slot(void *ve, int slot, uint64_t block, int64_t i0)
+{
+    emu *e = (emu *) ve;
+    double *p = e->TX + (size_t) slot * e->ld;
+    need_blocks(e, block + 1);
+    orc_k_mutate(e->n, e->X + (size_t) i0 * e->ld, p, e->tw + block * 2 * (uint64_t) e->n, e->lb, e->ub, p);
+    return 0;
+}
+static const char *emu_err(void *ve) { (void) ve; return "emu"; }
+
+static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_speculate, emu_commit, emu_read_slot,
+                                            emu_read_row, emu_mutate_slot, emu_err };
+
+/* Run the PRODUCT's CRS driver over the emulated engine.  RNG = the oracle generator (orc_srand
+ * beforehand).  host_eval != 0 exercises the host-callback path with the zoo callback. */
+int orc_emu_crs(int obj, int n, long N, const double *lb, const double *ub, double *x, double *minf,
+                long maxeval, double stopval, double ftol_rel, double ftol_abs, double xtol_rel, const double *xtol_abs,
+                int max_slots, int max_spec, int host_eval,
+                nlopt_amd_trace_rec *trace, size_t trace_cap, size_t *trace_len, nlopt_amd_stats *stats,
+                int *nevals_out, unsigned long long *words_out)
+{
+    emu e;
+    nla_stopping stop;
+    nla_crs_problem pb;
+    int nevals = 0, force = 0, ret;
+    uint64_t words = 0;
+    char *msg = NULL;
+    memset(&e, 0, sizeof e);
+    e.n = n; e.ld = (n + 1) & ~1; e.N = N; e.obj = host_eval ? -1 : obj; e.lb = lb; e.ub = ub; e.cap = 1024;
+    e.max_slots = max_slots > 0 ? max_slots : 1024;
+    e.X = (double *) calloc((size_t) e.ld * (size_t) N, sizeof(double));
+    e.TX = (double *) calloc((size_t) e.ld * (size_t) e.cap, sizeof(double));
+    e.TM = (double *) calloc((size_t) e.ld * (size_t) e.cap, sizeof(double));
+    e.jn = (int32_t *) malloc(sizeof(int32_t) * (size_t) e.cap);
+    e.last = (int32_t *) malloc(sizeof(int32_t) * (size_t) e.cap);
+    e.pos = (int32_t *) malloc(sizeof(int32_t) * (size_t) e.cap * (size_t) n);
+    memset(&stop, 0, sizeof stop);
+    stop.n = (unsigned) n; stop.minf_max = stopval; stop.ftol_rel = ftol_rel; stop.ftol_abs = ftol_abs;
+    stop.xtol_rel = xtol_rel; stop.xtol_abs = xtol_abs; stop.nevals_p = &nevals; stop.maxeval = (int) maxeval;
+    stop.maxtime = 0; stop.start = 0; stop.force_stop = &force; stop.stop_msg = &msg;
+    memset(&pb, 0, sizeof pb);
+    pb.n = n; pb.N = N; pb.lb = lb; pb.ub = ub; pb.obj = e.obj;
+    pb.f = (nlopt_func) orc_objective(obj); pb.f_data = NULL; pb.stop = &stop;
+    pb.trace = trace; pb.trace_cap = trace_cap; pb.trace_len = trace_len; pb.stats = stats; pb.max_spec = max_spec;
+    if (trace_len) *trace_len = 0;
+    ret = (int) nla_crs_run(&emu_ops, &e, &pb, x, minf, &words);
+    *nevals_out = nevals; *words_out = words;
+    free(e.X); free(e.TX); free(e.TM); free(e.jn); free(e.last); free(e.pos); free(e.tw); free(msg);
+    return ret;
+}

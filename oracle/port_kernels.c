@@ -1,0 +1,114 @@
+/* port_kernels.c — CPU ORACLE (test infrastructure): plain-C statements of what each HIP kernel
+ * must compute, used (a) by the -m gpu parity tests as the per-kernel checker and (b) by
+ * port_emu_engine.c to exercise the product's host-side speculate/commit logic on machines
+ * without a GPU.  Each follows the reference lines it cites; none is linked into the product. */
+#include "port_oracle.h"
+#include "objfuncs.h"
+#include <limits.h>
+#include <string.h>
+
+/* tempered stream words of a generator state, in order (mt19937ar.c:97-131) */
+void orc_k_words(uint64_t count, uint32_t *out)
+{
+    for (uint64_t i = 0; i < count; ++i) out[i] = orc_genrand_int32();
+}
+
+static double res53w(uint32_t w0, uint32_t w1)                 /* mt19937ar.c:194-198 */
+{
+    uint32_t a = w0 >> 5, b = w1 >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+}
+
+/* crs.c:216-218: row r coordinate j = lb[j] + (ub[j]-lb[j]) * res53(words of (r,j)) */
+void orc_k_init_rows(int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t nrows, double *X)
+{
+    for (int64_t r = 0; r < nrows; ++r)
+        for (int j = 0; j < n; ++j) {
+            const uint32_t *w = words + ((size_t) r * (size_t) n + (size_t) j) * 2;
+            X[(size_t) r * (size_t) ld + j] = lb[j] + (ub[j] - lb[j]) * res53w(w[0], w[1]);
+        }
+}
+
+void orc_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F)
+{
+    for (int64_t c = 0; c < count; ++c) F[c] = nla_obj_eval_seq(obj, (unsigned) n, P + (size_t) c * (size_t) ld, NULL);
+}
+
+/* crs.c:72,89-109 on one 2n-word block, positions in reduced space (best row removed) */
+void orc_k_vitter(int n, int64_t N, const uint32_t *words, int nblocks, int32_t *jn, int32_t *pos, int32_t *last)
+{
+    for (int b = 0; b < nblocks; ++b) {
+        const uint32_t *w = words + (size_t) b * 2 * (size_t) n;
+        int32_t *out = pos + (size_t) b * (size_t) n;
+        int Nleft = (int) (N - 1), nleft = n, Nfree = Nleft - nleft, i = 0, t = 0, wi = 1;
+        jn[b] = (int32_t) (w[0] % (uint32_t) n);
+        while (nleft > 1) {
+            double q = ((double) Nfree) / Nleft;
+            double v = res53w(w[wi], w[wi + 1]);
+            wi += 2;
+            while (q > v) { ++i; --Nfree; --Nleft; q = (q * Nfree) / Nleft; }
+            out[t++] = i;
+            ++i; --Nleft; --nleft;
+        }
+        out[n - 1] = i;
+        last[b] = (int32_t) (w[2 * n - 1] % (uint32_t) Nleft);
+    }
+}
+
+/* actual row of pick t of a block, given the best row i0 (the `i += i == i0` skipping, crs.c:92,97,106,109) */
+static int64_t pick_row(int n, const int32_t *pos, int32_t last, int64_t i0, int t)
+{
+    if (t < n - 1) { int64_t r = pos[t]; return r + (r >= i0); }
+    {
+        int64_t rb = pos[n - 1], a = rb + (rb >= i0) + last;
+        a += (a == i0);
+        return a;
+    }
+}
+
+/* crs.c:69,101-120 for K slots */
+void orc_k_gather(int n, int ld, const double *X, int64_t i0, const int32_t *jn, const int32_t *pos, const int32_t *last,
+                  int K, const double *lb, const double *ub, double *TX)
+{
+    for (int s = 0; s < K; ++s) {
+        double *x = TX + (size_t) s * (size_t) ld;
+        const int32_t *p = pos + (size_t) s * (size_t) n;
+        memcpy(x, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) n);
+        for (int t = 0; t < n; ++t) {
+            const double *xi = X + (size_t) pick_row(n, p, last[s], i0, t) * (size_t) ld;
+            if (t == jn[s]) for (int k = 0; k < n; ++k) x[k] -= xi[k] * (0.5 * n);
+            else            for (int k = 0; k < n; ++k) x[k] += xi[k];
+        }
+        for (int k = 0; k < n; ++k) {
+            x[k] *= 2.0 / n;
+            if (x[k] > ub[k]) x[k] = ub[k];
+            else if (x[k] < lb[k]) x[k] = lb[k];
+        }
+    }
+}
+
+/* crs.c:140-145: out = clamp(best(1+w) - w p), w from the block's n urands */
+void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *words, const double *lb, const double *ub,
+                  double *out)
+{
+    for (int i = 0; i < n; ++i) {
+        double w = 0. + (1. - 0.) * res53w(words[2 * i], words[2 * i + 1]);
+        double v = best[i] * (1 + w) - w * p[i];
+        if (v > ub[i]) v = ub[i];
+        else if (v < lb[i]) v = lb[i];
+        out[i] = v;
+    }
+}
+
+/* smallest rank r with W[r] among the rows slot s sampled (INT_MAX if none) */
+void orc_k_minhz(int n, int64_t i0, const int32_t *pos, const int32_t *last, int K, const int64_t *W, int nW, int32_t *minhz)
+{
+    for (int s = 0; s < K; ++s) {
+        const int32_t *p = pos + (size_t) s * (size_t) n;
+        int best = INT_MAX;
+        for (int r = 0; r < nW && best == INT_MAX; ++r)
+            for (int t = 0; t < n; ++t)
+                if (pick_row(n, p, last[s], i0, t) == W[r]) { best = r; break; }
+        minhz[s] = best;
+    }
+}

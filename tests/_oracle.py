@@ -202,3 +202,62 @@ def run_ref(alg, obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0
     R.nlopt_destroy(opt)
     del keep
     return out
+
+
+class TraceRecP(C.Structure):
+    _fields_ = [("f", C.c_double), ("row", C.c_int64), ("kind", C.c_int32), ("accepted", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("rounds", "slots_launched", "slots_used", "slots_invalid", "slots_newbest",
+                                           "slots_role", "evals_init", "evals_trial", "evals_mutation", "accepted",
+                                           "mt_words")] + \
+               [("t_init_s", C.c_double), ("t_trial_s", C.c_double), ("t_gather_ms", C.c_double),
+                ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+TRACE_DT = [("f", "f8"), ("row", "i8"), ("kind", "i4"), ("accepted", "i4")]
+
+_emu = None
+
+
+def emu():
+    """the product's host-side CRS driver over the CPU emulation of the device engine (oracle/libemu.so)"""
+    global _emu
+    if _emu is None:
+        path = os.path.join(ORC_DIR, "libemu.so")
+        subprocess.run(["make", "-s", "-C", ORC_DIR, "port", "emu"], check=True)
+        port()
+        L = C.CDLL(path)
+        L.orc_emu_crs.argtypes = [C.c_int, C.c_int, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_long, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        _emu = L
+    return _emu
+
+
+def run_emu_crs(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0,
+                trace_cap=0, max_slots=0, max_spec=0, host_eval=False):
+    E, L = emu(), port()
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lb = np.full(n, lo)
+    ub = np.full(n, hi)
+    tr = np.zeros(max(trace_cap, 1), dtype=TRACE_DT)
+    tlen = C.c_size_t(0)
+    st = Stats()
+    minf = C.c_double()
+    nev = C.c_int()
+    words = C.c_ulonglong()
+    L.orc_srand(seed)
+    ret = E.orc_emu_crs(OBJ[obj], n, pop, dptr(lb), dptr(ub), dptr(x), C.byref(minf), maxeval,
+                        -np.inf if stopval is None else stopval, ftol_rel, ftol_abs, xtol_rel, None,
+                        max_slots, max_spec, int(host_eval), tr.ctypes.data, trace_cap, C.byref(tlen), C.byref(st),
+                        C.byref(nev), C.byref(words))
+    return dict(ret=ret, minf=minf.value, x=x, nevals=nev.value, words=words.value,
+                trace=tr[:min(tlen.value, trace_cap)].copy(), trace_len=tlen.value, stats=st.asdict())
