@@ -69,6 +69,17 @@ typedef struct {
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 
+/* Stepwise CRS2_LM: the same run as nlopt_optimize(), paused between speculation rounds (used by
+ * bench.py to time exactly K steps, and by callers that want to poll).  open() performs the
+ * population initialisation (crs_init, crs.c:165-229); step() runs until the algorithm stops or at
+ * least `eval_budget` more objective evaluations were made (<=0: until it stops); close() writes
+ * the best point to the x/minf given to open(), advances the thread's RNG exactly as a full
+ * nlopt_optimize() would have, and returns the final nlopt_result. */
+typedef struct nlopt_amd_crs_session nlopt_amd_crs_session;
+nlopt_amd_crs_session *nlopt_amd_crs_open(nlopt_opt opt, double *x, double *minf, nlopt_result *ret);
+nlopt_result nlopt_amd_crs_step(nlopt_amd_crs_session *s, long eval_budget);
+nlopt_result nlopt_amd_crs_close(nlopt_amd_crs_session *s);
+
 /* ------------------------------------------------------------------------------------------------
  * Part 2 — kernel-level C-ABI (device pointers; see file header)
  * ---------------------------------------------------------------------------------------------- */

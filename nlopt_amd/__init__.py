@@ -1,0 +1,379 @@
+"""nlopt_amd — Python face of libnlopt_amd.so, the MI355X-native drop-in for NLopt's stochastic
+population-based global optimisers (CRS2_LM / ISRES / MLSL).
+
+The product is the C-ABI shared library (include/nlopt.h + include/nlopt_amd.h); this module only
+loads it with ctypes and mirrors the object-oriented surface of the reference's SWIG binding
+(`nlopt.opt`: set_min_objective, set_lower_bounds, optimize, last_optimize_result, ... —
+src/swig/nlopt-python.i) so the parity tests read like the reference's own (test/t_python.py).
+There is no CPU implementation behind it: without a visible HIP device `optimize` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnlopt_amd.so")
+
+# nlopt_algorithm values (include/nlopt.h; ABI)
+GN_CRS2_LM, GN_MLSL, GD_MLSL, GN_MLSL_LDS, GD_MLSL_LDS = 19, 20, 21, 22, 23
+LD_LBFGS, GN_ISRES, G_MLSL, G_MLSL_LDS = 11, 35, 38, 39
+# nlopt_result values
+FAILURE, INVALID_ARGS, OUT_OF_MEMORY, ROUNDOFF_LIMITED, FORCED_STOP = -1, -2, -3, -4, -5
+SUCCESS, STOPVAL_REACHED, FTOL_REACHED, XTOL_REACHED, MAXEVAL_REACHED, MAXTIME_REACHED = 1, 2, 3, 4, 5, 6
+
+OBJECTIVES = {"rastrigin": 0, "ackley": 1, "griewank": 2, "rosenbrock": 3, "levy": 4, "sphere": 5}
+
+NLOPT_FUNC = C.CFUNCTYPE(C.c_double, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+TRACE_DTYPE = np.dtype([("f", "f8"), ("row", "i8"), ("kind", "i4"), ("accepted", "i4")])
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("rounds", "slots_launched", "slots_used", "slots_invalid", "slots_newbest",
+                                           "slots_role", "evals_init", "evals_trial", "evals_mutation", "accepted",
+                                           "mt_words")] + \
+               [("t_init_s", C.c_double), ("t_trial_s", C.c_double), ("t_gather_ms", C.c_double),
+                ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    from . import _build as _b
+    return _b.build(force=force, verbose=verbose)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def lib():
+    """the loaded C-ABI library with argtypes set; raises if it has not been built"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libnlopt_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, dbl, dpp = C.c_void_p, C.c_double, C.POINTER(C.c_double)
+    L.nlopt_create.restype = vp
+    L.nlopt_create.argtypes = [C.c_int, C.c_uint]
+    L.nlopt_copy.restype = vp
+    L.nlopt_copy.argtypes = [vp]
+    L.nlopt_destroy.argtypes = [vp]
+    L.nlopt_destroy.restype = None
+    L.nlopt_optimize.argtypes = [vp, dpp, dpp]
+    for nm in ("nlopt_set_min_objective", "nlopt_set_max_objective"):
+        getattr(L, nm).argtypes = [vp, vp, vp]
+    for nm in ("nlopt_set_lower_bounds", "nlopt_set_upper_bounds", "nlopt_get_lower_bounds", "nlopt_get_upper_bounds",
+               "nlopt_set_xtol_abs", "nlopt_get_xtol_abs", "nlopt_set_x_weights", "nlopt_get_x_weights",
+               "nlopt_set_initial_step"):
+        getattr(L, nm).argtypes = [vp, dpp]
+    for nm in ("nlopt_set_lower_bounds1", "nlopt_set_upper_bounds1", "nlopt_set_stopval", "nlopt_set_ftol_rel",
+               "nlopt_set_ftol_abs", "nlopt_set_xtol_rel", "nlopt_set_xtol_abs1", "nlopt_set_x_weights1",
+               "nlopt_set_maxtime", "nlopt_set_initial_step1"):
+        getattr(L, nm).argtypes = [vp, dbl]
+    for nm in ("nlopt_get_stopval", "nlopt_get_ftol_rel", "nlopt_get_ftol_abs", "nlopt_get_xtol_rel", "nlopt_get_maxtime"):
+        getattr(L, nm).argtypes = [vp]
+        getattr(L, nm).restype = dbl
+    L.nlopt_set_lower_bound.argtypes = [vp, C.c_int, dbl]
+    L.nlopt_set_upper_bound.argtypes = [vp, C.c_int, dbl]
+    L.nlopt_set_maxeval.argtypes = [vp, C.c_int]
+    for nm in ("nlopt_get_maxeval", "nlopt_get_numevals", "nlopt_get_force_stop", "nlopt_force_stop", "nlopt_get_algorithm"):
+        getattr(L, nm).argtypes = [vp]
+    L.nlopt_set_force_stop.argtypes = [vp, C.c_int]
+    L.nlopt_get_dimension.argtypes = [vp]
+    L.nlopt_get_dimension.restype = C.c_uint
+    L.nlopt_set_population.argtypes = [vp, C.c_uint]
+    L.nlopt_get_population.argtypes = [vp]
+    L.nlopt_get_population.restype = C.c_uint
+    L.nlopt_set_vector_storage.argtypes = [vp, C.c_uint]
+    L.nlopt_get_vector_storage.argtypes = [vp]
+    L.nlopt_get_vector_storage.restype = C.c_uint
+    L.nlopt_set_local_optimizer.argtypes = [vp, vp]
+    L.nlopt_get_errmsg.argtypes = [vp]
+    L.nlopt_get_errmsg.restype = C.c_char_p
+    L.nlopt_set_param.argtypes = [vp, C.c_char_p, dbl]
+    L.nlopt_get_param.argtypes = [vp, C.c_char_p, dbl]
+    L.nlopt_get_param.restype = dbl
+    L.nlopt_has_param.argtypes = [vp, C.c_char_p]
+    L.nlopt_num_params.argtypes = [vp]
+    L.nlopt_num_params.restype = C.c_uint
+    L.nlopt_nth_param.argtypes = [vp, C.c_uint]
+    L.nlopt_nth_param.restype = C.c_char_p
+    for nm in ("nlopt_add_inequality_constraint", "nlopt_add_equality_constraint"):
+        getattr(L, nm).argtypes = [vp, vp, vp, dbl]
+    for nm in ("nlopt_remove_inequality_constraints", "nlopt_remove_equality_constraints"):
+        getattr(L, nm).argtypes = [vp]
+    L.nlopt_srand.argtypes = [C.c_ulong]
+    L.nlopt_srand.restype = None
+    L.nlopt_algorithm_name.argtypes = [C.c_int]
+    L.nlopt_algorithm_name.restype = C.c_char_p
+    L.nlopt_algorithm_to_string.argtypes = [C.c_int]
+    L.nlopt_algorithm_to_string.restype = C.c_char_p
+    L.nlopt_algorithm_from_string.argtypes = [C.c_char_p]
+    L.nlopt_result_to_string.argtypes = [C.c_int]
+    L.nlopt_result_to_string.restype = C.c_char_p
+    L.nlopt_result_from_string.argtypes = [C.c_char_p]
+    L.nlopt_version.argtypes = [C.POINTER(C.c_int)] * 3
+    L.nlopt_urand.argtypes = [dbl, dbl]
+    L.nlopt_urand.restype = dbl
+    L.nlopt_nrand.argtypes = [dbl, dbl]
+    L.nlopt_nrand.restype = dbl
+    L.nlopt_iurand.argtypes = [C.c_int]
+    L.nla_genrand_int32.restype = C.c_uint32
+    # extension
+    L.nlopt_amd_objective.argtypes = [C.c_int]
+    L.nlopt_amd_objective.restype = vp
+    L.nlopt_amd_objective_id.argtypes = [vp]
+    L.nlopt_amd_objective_name.argtypes = [C.c_int]
+    L.nlopt_amd_objective_name.restype = C.c_char_p
+    L.nlopt_amd_objective_box.argtypes = [C.c_int, dpp, dpp]
+    L.nlopt_amd_objective_box.restype = None
+    L.nlopt_amd_constraint_blocksum.restype = vp
+    L.nlopt_amd_set_trace.argtypes = [vp, vp, C.c_size_t]
+    L.nlopt_amd_trace_len.argtypes = [vp]
+    L.nlopt_amd_trace_len.restype = C.c_size_t
+    L.nlopt_amd_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.nlopt_amd_crs_open.argtypes = [vp, dpp, dpp, C.POINTER(C.c_int)]
+    L.nlopt_amd_crs_open.restype = vp
+    L.nlopt_amd_crs_step.argtypes = [vp, C.c_long]
+    L.nlopt_amd_crs_close.argtypes = [vp]
+    # device runtime + kernel-level C-ABI
+    L.nla_dev_malloc.argtypes = [C.c_size_t]
+    L.nla_dev_malloc.restype = vp
+    L.nla_dev_free.argtypes = [vp]
+    L.nla_dev_free.restype = None
+    for nm in ("nla_memcpy_h2d", "nla_memcpy_d2h", "nla_memcpy_d2d"):
+        getattr(L, nm).argtypes = [vp, vp, C.c_size_t, vp]
+    L.nla_stream_create.restype = vp
+    L.nla_stream_destroy.argtypes = [vp]
+    L.nla_stream_sync.argtypes = [vp]
+    L.nla_event_create.restype = vp
+    L.nla_event_destroy.argtypes = [vp]
+    L.nla_event_record.argtypes = [vp, vp]
+    L.nla_event_sync.argtypes = [vp]
+    L.nla_event_elapsed_ms.argtypes = [vp, vp]
+    L.nla_event_elapsed_ms.restype = C.c_float
+    L.nla_dev_error_string.argtypes = [C.c_int]
+    L.nla_dev_error_string.restype = C.c_char_p
+    L.nla_mtstream_create.argtypes = [vp]
+    L.nla_mtstream_create.restype = vp
+    L.nla_mtstream_destroy.argtypes = [vp]
+    L.nla_mtstream_destroy.restype = None
+    L.nla_mtstream_fill.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+    L.nla_mtstream_finish.argtypes = [vp, C.c_uint64]
+    L.nla_k_mt_jump.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.nla_k_mt_generate.argtypes = [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, vp, vp]
+    L.nla_k_crs_init_rows.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
+    L.nla_k_eval.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
+    L.nla_k_crs_vitter.argtypes = [C.c_int, C.c_int64, vp, C.c_int, vp, vp, vp, vp]
+    L.nla_k_crs_gather.argtypes = [C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.nla_k_crs_post.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp,
+                                 vp, vp, vp, vp, vp, vp]
+    L.nla_k_crs_commit.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.nla_k_crs_mutate.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
+    L.nla_mt_jump_poly_words.argtypes = [C.c_uint64, vp]
+    L.nla_mt_jump_poly_words.restype = None
+    L.nla_mt_jump_poly_pow2.argtypes = [C.c_int]
+    L.nla_mt_jump_poly_pow2.restype = vp
+    L.nla_mt_apply_jump_host.argtypes = [vp, vp, vp]
+    L.nla_mt_apply_jump_host.restype = None
+    L.nla_mt_advance_blocks_host.argtypes = [vp, C.c_uint64, vp]
+    L.nla_mt_advance_blocks_host.restype = None
+    L.nla_mt_export.argtypes = [vp, C.POINTER(C.c_int)]
+    L.nla_mt_export.restype = None
+    L.nla_mt_import.argtypes = [vp, C.c_int]
+    L.nla_mt_import.restype = None
+    L.nla_mt_charpoly_terms.argtypes = [C.POINTER(C.POINTER(C.c_int))]
+    _lib = L
+    return L
+
+
+def device_count():
+    return lib().nlopt_amd_device_count()
+
+
+def srand(seed):
+    lib().nlopt_srand(seed)
+
+
+def objective(name_or_id):
+    """the registered host callback for a device objective (pass it to set_min_objective)"""
+    i = OBJECTIVES[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+    return lib().nlopt_amd_objective(i)
+
+
+def objective_box(name_or_id):
+    i = OBJECTIVES[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+    lo, hi = C.c_double(), C.c_double()
+    lib().nlopt_amd_objective_box(i, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class DevBuf:
+    """a device allocation owned by libnlopt_amd's runtime layer, with numpy staging"""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().nla_dev_malloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("nla_dev_malloc(%d) failed" % self.nbytes)
+
+    @classmethod
+    def from_array(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(max(a.nbytes, 1))
+        L = lib()
+        rc = L.nla_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes, None) or L.nla_stream_sync(None)
+        if rc:
+            raise RuntimeError("H2D failed: %s" % L.nla_dev_error_string(rc))
+        return b
+
+    def to_array(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        L = lib()
+        rc = L.nla_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None) or L.nla_stream_sync(None)
+        if rc:
+            raise RuntimeError("D2H failed: %s" % L.nla_dev_error_string(rc))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().nla_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Opt:
+    """Mirror of the reference's `nlopt.opt` Python class over the C API (subset used by the hot path)."""
+
+    def __init__(self, algorithm, n):
+        self._L = lib()
+        self._h = self._L.nlopt_create(int(algorithm), int(n))
+        if not self._h:
+            raise ValueError("nlopt_create failed (bad algorithm?)")
+        self.n = int(n)
+        self._keep = []
+        self._trace = None
+        self._last = None
+        self._minf = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.nlopt_destroy(h)
+
+    def _ck(self, ret):
+        if ret < 0:
+            msg = self._L.nlopt_get_errmsg(self._h)
+            raise RuntimeError("nlopt error %d (%s)%s" % (ret, self._L.nlopt_result_to_string(ret).decode(),
+                                                          ": " + msg.decode() if msg else ""))
+        return ret
+
+    # -- objective / bounds / constraints --
+    def _fptr(self, f):
+        if isinstance(f, int):
+            return f
+        cb = NLOPT_FUNC(lambda n, x, g, d: float(f(np.ctypeslib.as_array(x, shape=(n,)),
+                                                    np.ctypeslib.as_array(g, shape=(n,)) if g else np.empty(0))))
+        self._keep.append(cb)
+        return C.cast(cb, C.c_void_p).value
+
+    def set_min_objective(self, f, f_data=None):
+        self._ck(self._L.nlopt_set_min_objective(self._h, self._fptr(f), f_data))
+
+    def set_max_objective(self, f, f_data=None):
+        self._ck(self._L.nlopt_set_max_objective(self._h, self._fptr(f), f_data))
+
+    def set_lower_bounds(self, lb):
+        if np.isscalar(lb):
+            self._ck(self._L.nlopt_set_lower_bounds1(self._h, float(lb)))
+        else:
+            self._ck(self._L.nlopt_set_lower_bounds(self._h, _dp(np.ascontiguousarray(lb, dtype=np.float64))))
+
+    def set_upper_bounds(self, ub):
+        if np.isscalar(ub):
+            self._ck(self._L.nlopt_set_upper_bounds1(self._h, float(ub)))
+        else:
+            self._ck(self._L.nlopt_set_upper_bounds(self._h, _dp(np.ascontiguousarray(ub, dtype=np.float64))))
+
+    def get_lower_bounds(self):
+        a = np.empty(self.n)
+        self._ck(self._L.nlopt_get_lower_bounds(self._h, _dp(a)))
+        return a
+
+    def get_upper_bounds(self):
+        a = np.empty(self.n)
+        self._ck(self._L.nlopt_get_upper_bounds(self._h, _dp(a)))
+        return a
+
+    def add_inequality_constraint(self, fc, tol=0.0, f_data=None):
+        return self._L.nlopt_add_inequality_constraint(self._h, self._fptr(fc), f_data, float(tol))
+
+    def add_equality_constraint(self, h, tol=0.0, f_data=None):
+        return self._L.nlopt_add_equality_constraint(self._h, self._fptr(h), f_data, float(tol))
+
+    # -- stopping criteria & parameters --
+    def set_stopval(self, v): self._ck(self._L.nlopt_set_stopval(self._h, float(v)))
+    def set_ftol_rel(self, v): self._ck(self._L.nlopt_set_ftol_rel(self._h, float(v)))
+    def set_ftol_abs(self, v): self._ck(self._L.nlopt_set_ftol_abs(self._h, float(v)))
+    def set_xtol_rel(self, v): self._ck(self._L.nlopt_set_xtol_rel(self._h, float(v)))
+    def set_xtol_abs(self, v):
+        if np.isscalar(v):
+            self._ck(self._L.nlopt_set_xtol_abs1(self._h, float(v)))
+        else:
+            self._ck(self._L.nlopt_set_xtol_abs(self._h, _dp(np.ascontiguousarray(v, dtype=np.float64))))
+    def set_maxeval(self, v): self._ck(self._L.nlopt_set_maxeval(self._h, int(v)))
+    def set_maxtime(self, v): self._ck(self._L.nlopt_set_maxtime(self._h, float(v)))
+    def set_population(self, v): self._ck(self._L.nlopt_set_population(self._h, int(v)))
+    def set_param(self, name, v): self._ck(self._L.nlopt_set_param(self._h, name.encode(), float(v)))
+    def get_numevals(self): return self._L.nlopt_get_numevals(self._h)
+    def get_errmsg(self):
+        m = self._L.nlopt_get_errmsg(self._h)
+        return m.decode() if m else None
+    def force_stop(self): self._L.nlopt_force_stop(self._h)
+
+    # -- libnlopt_amd additions --
+    def enable_trace(self, cap):
+        self._trace = np.zeros(int(cap), dtype=TRACE_DTYPE)
+        self._L.nlopt_amd_set_trace(self._h, self._trace.ctypes.data, int(cap))
+
+    def trace(self):
+        k = min(self._L.nlopt_amd_trace_len(self._h), len(self._trace))
+        return self._trace[:k].copy()
+
+    def trace_len(self):
+        return self._L.nlopt_amd_trace_len(self._h)
+
+    def stats(self):
+        s = Stats()
+        self._L.nlopt_amd_get_stats(self._h, C.byref(s))
+        return s.asdict()
+
+    # -- run --
+    def optimize_raw(self, x0):
+        """returns (x, minf, nlopt_result) without raising on negative results"""
+        x = np.array(x0, dtype=np.float64)
+        minf = C.c_double()
+        ret = self._L.nlopt_optimize(self._h, _dp(x), C.byref(minf))
+        self._last, self._minf = ret, minf.value
+        return x, minf.value, ret
+
+    def optimize(self, x0):
+        x, _, ret = self.optimize_raw(x0)
+        self._ck(ret)
+        return x
+
+    def last_optimum_value(self): return self._minf
+    def last_optimize_result(self): return self._last

@@ -36,13 +36,13 @@ static void flipped_precond(unsigned n, const double *x, const double *v, double
     for (i = 0; i < n; ++i) vpre[i] = -vpre[i];
 }
 
-static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
+/* common prologue of a run: argument and bounds checks, RNG seeding, nlopt_stopping setup
+ * (optimize.c:514-566).  Returns NLOPT_SUCCESS when the algorithm may start. */
+nlopt_result nla_setup_run(nlopt_opt opt, double *x, double *minf, nla_stopping *stop)
 {
-    nla_stopping stop;
     unsigned n, i;
     if (!opt || !x || !minf || !opt->f || opt->maximize) { if (opt) nla_set_errmsg(opt, "NULL args to nlopt_optimize_"); return NLOPT_INVALID_ARGS; }
     n = opt->n;
-    if (n == 0) { *minf = opt->f(n, x, NULL, opt->f_data); return NLOPT_SUCCESS; }    /* optimize.c:536-539 */
     *minf = HUGE_VAL;
     nla_srand_time_default();                                                            /* optimize.c:544 */
     for (i = 0; i < n; ++i)
@@ -50,18 +50,30 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
             nla_set_errmsg(opt, "bounds %d fail %g <= %g <= %g", i, opt->lb[i], x[i], opt->ub[i]);
             return NLOPT_INVALID_ARGS;
         }
-    stop.n = n;
-    stop.minf_max = opt->stopval;
-    stop.ftol_rel = opt->ftol_rel; stop.ftol_abs = opt->ftol_abs;
-    stop.xtol_rel = opt->xtol_rel; stop.xtol_abs = opt->xtol_abs; stop.x_weights = opt->x_weights;
+    stop->n = n;
+    stop->minf_max = opt->stopval;
+    stop->ftol_rel = opt->ftol_rel; stop->ftol_abs = opt->ftol_abs;
+    stop->xtol_rel = opt->xtol_rel; stop->xtol_abs = opt->xtol_abs; stop->x_weights = opt->x_weights;
     opt->numevals = 0;
-    stop.nevals_p = &opt->numevals;
-    stop.maxeval = opt->maxeval; stop.maxtime = opt->maxtime;
-    stop.start = nla_seconds();
-    stop.force_stop = &opt->force_stop;
-    stop.stop_msg = &opt->errmsg;
+    stop->nevals_p = &opt->numevals;
+    stop->maxeval = opt->maxeval; stop->maxtime = opt->maxtime;
+    stop->start = nla_seconds();
+    stop->force_stop = &opt->force_stop;
+    stop->stop_msg = &opt->errmsg;
     opt->trace_len = 0;
     memset(&opt->stats, 0, sizeof opt->stats);
+    return NLOPT_SUCCESS;
+}
+
+static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
+{
+    nla_stopping stop;
+    unsigned n;
+    nlopt_result pre;
+    if (!opt || !x || !minf || !opt->f || opt->maximize) { if (opt) nla_set_errmsg(opt, "NULL args to nlopt_optimize_"); return NLOPT_INVALID_ARGS; }
+    n = opt->n;
+    if (n == 0) { *minf = opt->f(n, x, NULL, opt->f_data); return NLOPT_SUCCESS; }    /* optimize.c:536-539 */
+    if ((pre = nla_setup_run(opt, x, minf, &stop)) != NLOPT_SUCCESS) return pre;
 
     switch (opt->algorithm) {
     case NLOPT_GN_CRS2_LM:                                                               /* optimize.c:744-747 */

@@ -158,87 +158,139 @@ static int after_accept(run_state *rs, int slot, int kind)
     return 0;
 }
 
-nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *e, const nla_crs_problem *pb,
-                         double *x, double *minf, uint64_t *words_used)
+/* ---- resumable run: begin (= crs_init), advance (= rounds of the trial loop), end -------------- */
+struct nla_crs_session {
+    run_state rs;
+    nla_crs_problem pb;
+    nlopt_result ret;
+    uint64_t block, init_words;
+    int Kmax, host_eval;
+    double runlen;
+    double *fT, *fM;
+    int32_t *minhz, *cslot, *ckind;
+    int64_t *W, *crow;
+};
+
+static void session_free(nla_crs_session *S)
+{
+    if (!S) return;
+    free(S->rs.F); free(S->rs.os.heap); free(S->rs.os.cand); free(S->rs.xtmp);
+    free(S->fT); free(S->fM); free(S->minhz); free(S->W); free(S->cslot); free(S->ckind); free(S->crow);
+    free(S);
+}
+
+static void engine_failed(nla_crs_session *S)
+{
+    nla_stopping *stop = S->pb.stop;
+    if (stop->stop_msg && S->rs.ops->last_error) nla_stop_msg(stop, "device engine: %s", S->rs.ops->last_error(S->rs.e));
+    S->ret = NLOPT_FAILURE;
+}
+
+/* crs_init (crs.c:165-229) + the first assignments of crs_minimize (crs.c:246-248).  On return
+ * *ret_out is NLOPT_SUCCESS if the trial loop may start, else the final result. */
+nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla_crs_problem *pb,
+                               double *x, double *minf, nlopt_result *ret_out)
 {
     const int n = pb->n;
     const int64_t N = pb->N;
     nla_stopping *stop = pb->stop;
     nlopt_amd_stats *st = pb->stats;
-    run_state rs;
+    nla_crs_session *S = (nla_crs_session *) calloc(1, sizeof *S);
+    run_state *rs;
     nlopt_result ret = NLOPT_SUCCESS;
     int64_t rows_done = 0, i;
-    uint64_t block = 0;
-    const int host_eval = pb->obj < 0;
-    int Kmax = pb->max_spec > 0 ? pb->max_spec : 1024;
-    double runlen = 4.0;
-    double *fT = NULL, *fM = NULL;
-    int32_t *minhz = NULL, *cslot = NULL, *ckind = NULL;
-    int64_t *W = NULL, *crow = NULL;
     double t0 = nla_seconds();
+    if (!S) { *ret_out = NLOPT_OUT_OF_MEMORY; return NULL; }
+    rs = &S->rs;
+    S->pb = *pb;
+    S->host_eval = pb->obj < 0;
+    S->Kmax = pb->max_spec > 0 ? pb->max_spec : 1024;
+    if (S->Kmax > 1024) S->Kmax = 1024;
+    if (S->host_eval) S->Kmax = 1;
+    S->runlen = 4.0;
+    rs->ops = ops; rs->e = e; rs->pb = &S->pb; rs->x = x; rs->minf = minf;
+    rs->need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);
 
-    memset(&rs, 0, sizeof rs);
-    rs.ops = ops; rs.e = e; rs.pb = pb; rs.x = x; rs.minf = minf;
-    rs.need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);
-    *words_used = 0;
-    if (host_eval) Kmax = 1;
-
-    rs.F = (double *) malloc(sizeof(double) * (size_t) N);
-    rs.os.heap = (int64_t *) malloc(sizeof(int64_t) * (size_t) N);
-    rs.os.cand = (int64_t *) malloc(sizeof(int64_t) * (size_t) (2 * Kmax + 8));
-    rs.xtmp = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
-    fT = (double *) malloc(sizeof(double) * (size_t) Kmax);
-    fM = (double *) malloc(sizeof(double) * (size_t) Kmax);
-    minhz = (int32_t *) malloc(sizeof(int32_t) * (size_t) Kmax);
-    W = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax);
-    cslot = (int32_t *) malloc(sizeof(int32_t) * (size_t) Kmax);
-    ckind = (int32_t *) malloc(sizeof(int32_t) * (size_t) Kmax);
-    crow = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax);
-    if (!rs.F || !rs.os.heap || !rs.os.cand || !rs.xtmp || !fT || !fM || !minhz || !W || !cslot || !ckind || !crow) {
-        ret = NLOPT_OUT_OF_MEMORY;
-        goto done;
+    rs->F = (double *) malloc(sizeof(double) * (size_t) N);
+    rs->os.heap = (int64_t *) malloc(sizeof(int64_t) * (size_t) N);
+    rs->os.cand = (int64_t *) malloc(sizeof(int64_t) * (size_t) (2 * S->Kmax + 8));
+    rs->xtmp = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+    S->fT = (double *) malloc(sizeof(double) * (size_t) S->Kmax);
+    S->fM = (double *) malloc(sizeof(double) * (size_t) S->Kmax);
+    S->minhz = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
+    S->W = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
+    S->cslot = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
+    S->ckind = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
+    S->crow = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
+    if (!rs->F || !rs->os.heap || !rs->os.cand || !rs->xtmp || !S->fT || !S->fM || !S->minhz || !S->W || !S->cslot ||
+        !S->ckind || !S->crow) {
+        session_free(S);
+        *ret_out = NLOPT_OUT_OF_MEMORY;
+        return NULL;
     }
-    rs.os.F = rs.F;
+    rs->os.F = rs->F;
 
-    /* ---- crs_init (crs.c:203-226): the device generates and (if it can) evaluates all N rows;
-     * the stop tests of the reference run after *every* evaluation, so replay them in row order
-     * and forget the rows past the first stop. ------------------------------------------------ */
-    if (ops->init_population(e, x, rs.F)) { ret = NLOPT_FAILURE; goto fail_engine; }
+    /* the device generates and (if it can) evaluates all N rows; the reference's stop tests run
+     * after *every* evaluation, so replay them in row order and forget rows past the first stop */
+    if (ops->init_population(e, x, rs->F)) { engine_failed(S); *ret_out = S->ret; return S; }
     for (i = 0; i < N && ret == NLOPT_SUCCESS; ++i) {
-        if (host_eval) {
-            if (i == 0) rs.F[0] = pb->f((unsigned) n, x, NULL, pb->f_data);
+        if (S->host_eval) {
+            if (i == 0) rs->F[0] = pb->f((unsigned) n, x, NULL, pb->f_data);
             else {
-                if (ops->read_row(e, i, rs.xtmp)) { ret = NLOPT_FAILURE; goto fail_engine; }
-                rs.F[i] = pb->f((unsigned) n, rs.xtmp, NULL, pb->f_data);
+                if (ops->read_row(e, i, rs->xtmp)) { engine_failed(S); *ret_out = S->ret; return S; }
+                rs->F[i] = pb->f((unsigned) n, rs->xtmp, NULL, pb->f_data);
             }
         }
         ++*stop->nevals_p;
         if (st) ++st->evals_init;
-        os_push(&rs.os, i);
-        trace_add(pb, rs.F[i], i, 0, 1);
+        os_push(&rs->os, i);
+        trace_add(pb, rs->F[i], i, 0, 1);
         rows_done = i + 1;
-        if (rs.F[i] < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
+        if (rs->F[i] < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
         else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
         else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
     }
-    *words_used = 2ULL * (uint64_t) n * (uint64_t) (rows_done - 1);
-    *minf = rs.F[rs.os.best];                               /* crs.c:246-248 */
-    if (ops->read_row(e, rs.os.best, x)) { ret = NLOPT_FAILURE; goto fail_engine; }
+    S->init_words = 2ULL * (uint64_t) n * (uint64_t) (rows_done - 1);
+    *minf = rs->F[rs->os.best];                               /* crs.c:246-248 */
+    if (ops->read_row(e, rs->os.best, x)) { engine_failed(S); *ret_out = S->ret; return S; }
     if (st) st->t_init_s = nla_seconds() - t0;
-    t0 = nla_seconds();
+    S->ret = ret;
+    *ret_out = ret;
+    return S;
+}
 
-    /* ---- the trial loop (crs.c:250-270) ----------------------------------------------------- */
+/* Run rounds of the trial loop (crs.c:250-270) until the algorithm stops or at least
+ * `eval_budget` more evaluations have been made (<= 0: no budget).  Pausing between rounds does
+ * not change the sequence: a round boundary is only a speculation boundary. */
+nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
+{
+    run_state *rs = &S->rs;
+    const nla_crs_engine_ops *ops = rs->ops;
+    void *e = rs->e;
+    const nla_crs_problem *pb = &S->pb;
+    nla_stopping *stop = pb->stop;
+    nlopt_amd_stats *st = pb->stats;
+    const int n = pb->n, host_eval = S->host_eval;
+    const int64_t N = pb->N;
+    double *fT = S->fT, *fM = S->fM;
+    int32_t *minhz = S->minhz, *cslot = S->cslot, *ckind = S->ckind;
+    int64_t *W = S->W, *crow = S->crow;
+    nlopt_result ret = S->ret;
+    const int evals_at_entry = *stop->nevals_p;
+    double t0 = nla_seconds();
+
     while (ret == NLOPT_SUCCESS) {
         int K, nW, j = 0, c = 0, ncommit = 0, best_changed = 0, cap;
-        cap = ops->max_slots(e, block);
-        if (cap <= 0) { ret = NLOPT_FAILURE; goto fail_engine; }
-        K = (int) ceil(1.25 * runlen) + 1;
-        if (K > Kmax) K = Kmax;
+        if (eval_budget > 0 && (int64_t) (*stop->nevals_p - evals_at_entry) >= eval_budget) break;
+        cap = ops->max_slots(e, S->block);
+        if (cap <= 0) { engine_failed(S); return S->ret; }
+        K = (int) ceil(1.25 * S->runlen) + 1;
+        if (K > S->Kmax) K = S->Kmax;
         if (K > cap) K = cap;
         if (K < 1) K = 1;
         nW = K < N ? K : (int) N;
-        nW = os_topk(&rs.os, nW, W);
-        if (ops->speculate(e, block, K, rs.os.best, W, nW, fT, fM, minhz)) { ret = NLOPT_FAILURE; goto fail_engine; }
+        nW = os_topk(&rs->os, nW, W);
+        if (ops->speculate(e, S->block, K, rs->os.best, W, nW, fT, fM, minhz)) { engine_failed(S); return S->ret; }
         if (st) { ++st->rounds; st->slots_launched += (uint64_t) K; }
 
         while (j < K && ret == NLOPT_SUCCESS) {
@@ -248,17 +300,17 @@ nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *e, const nla_crs_p
             if (best_changed) { if (st) st->slots_newbest += (uint64_t) (K - j); break; }
             if (minhz[j] < c) { if (st) ++st->slots_invalid; break; }
             if (st) ++st->slots_used;
-            worst = rs.os.heap[0];
+            worst = rs->os.heap[0];
             /* reflection trial of block+j */
             if (host_eval) {
-                if (ops->read_slot(e, j, 1, rs.xtmp)) { ret = NLOPT_FAILURE; goto fail_engine; }
-                fT[j] = pb->f((unsigned) n, rs.xtmp, NULL, pb->f_data);
+                if (ops->read_slot(e, j, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
+                fT[j] = pb->f((unsigned) n, rs->xtmp, NULL, pb->f_data);
             }
             fcand = fT[j];
             ++*stop->nevals_p;
             if (st) ++st->evals_trial;
             if (nla_stop_forced(stop)) { trace_add(pb, fcand, -1, 1, 0); ret = NLOPT_FORCED_STOP; ++j; break; }
-            if (fcand < rs.F[worst]) accepted = 1;
+            if (fcand < rs->F[worst]) accepted = 1;
             else {
                 trace_add(pb, fcand, -1, 1, 0);
                 if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; ++j; break; }   /* only after a rejection */
@@ -266,15 +318,15 @@ nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *e, const nla_crs_p
                 /* local mutation: consumes block+j+1 (crs.c:139-146) */
                 kind = 2;
                 if (host_eval) {
-                    if (ops->mutate_slot(e, j, block + (uint64_t) j + 1, rs.os.best) ||
-                        ops->read_slot(e, j, 1, rs.xtmp)) { ret = NLOPT_FAILURE; goto fail_engine; }
-                    fM[j] = pb->f((unsigned) n, rs.xtmp, NULL, pb->f_data);
+                    if (ops->mutate_slot(e, j, S->block + (uint64_t) j + 1, rs->os.best) ||
+                        ops->read_slot(e, j, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
+                    fM[j] = pb->f((unsigned) n, rs->xtmp, NULL, pb->f_data);
                 }
                 fcand = fM[j];
                 ++*stop->nevals_p;
                 if (st) { ++st->evals_mutation; if (j + 1 < K) ++st->slots_role; }
                 if (nla_stop_forced(stop)) { trace_add(pb, fcand, -1, 2, 0); ret = NLOPT_FORCED_STOP; j += 2; break; }
-                if (fcand < rs.F[worst]) accepted = 1;
+                if (fcand < rs->F[worst]) accepted = 1;
                 else {
                     trace_add(pb, fcand, -1, 2, 0);
                     if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; j += 2; break; }
@@ -284,22 +336,22 @@ nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *e, const nla_crs_p
             if (accepted) {
                 /* memcpy(worst->k, d->p) + resort (crs.c:153-154); the row write is deferred */
                 if (c < nW && W[c] == worst) ++c;            /* else: a row of the prefix, again */
-                rs.F[worst] = fcand;
-                os_top_changed(&rs.os);
+                rs->F[worst] = fcand;
+                os_top_changed(&rs->os);
                 trace_add(pb, fcand, worst, kind, 1);
                 if (st) ++st->accepted;
                 cslot[ncommit] = j; ckind[ncommit] = host_eval ? 1 : kind; crow[ncommit] = worst; ++ncommit;
-                if (key_less(rs.F, worst, rs.os.best)) { rs.os.best = worst; best_changed = 1; }
-                if (after_accept(&rs, j, host_eval ? 1 : kind)) { ret = NLOPT_FAILURE; goto fail_engine; }
-                ret = rs.ret;
+                if (key_less(rs->F, worst, rs->os.best)) { rs->os.best = worst; best_changed = 1; }
+                if (after_accept(rs, j, host_eval ? 1 : kind)) { engine_failed(S); return S->ret; }
+                ret = rs->ret;
             }
             j += (kind == 2) ? 2 : 1;
         }
-        block += (uint64_t) j;
+        S->block += (uint64_t) j;
         {   /* adapt the speculation depth to the observed usable run length */
             double obs = (j >= K) ? 2.0 * K : (double) j;
-            runlen = 0.7 * runlen + 0.3 * obs;
-            if (runlen < 1.0) runlen = 1.0;
+            S->runlen = 0.7 * S->runlen + 0.3 * obs;
+            if (S->runlen < 1.0) S->runlen = 1.0;
         }
         if (ncommit > 0) {
             /* a row replaced twice in one round keeps only its last content */
@@ -309,18 +361,35 @@ nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *e, const nla_crs_p
                 for (q = k + 1; q < ncommit; ++q) if (crow[q] == crow[k]) { later = 1; break; }
                 if (!later) { cslot[m] = cslot[k]; ckind[m] = ckind[k]; crow[m] = crow[k]; ++m; }
             }
-            if (ops->commit(e, m, cslot, ckind, crow)) { ret = NLOPT_FAILURE; goto fail_engine; }
+            if (ops->commit(e, m, cslot, ckind, crow)) { engine_failed(S); return S->ret; }
         }
     }
-    *words_used += 2ULL * (uint64_t) n * block;
-    if (ops->read_row(e, rs.os.best, x)) { ret = NLOPT_FAILURE; goto fail_engine; }
-    if (st) st->t_trial_s = nla_seconds() - t0;
-    goto done;
-
-fail_engine:
-    if (stop->stop_msg && ops->last_error) nla_stop_msg(stop, "device engine: %s", ops->last_error(e));
-done:
-    free(rs.F); free(rs.os.heap); free(rs.os.cand); free(rs.xtmp);
-    free(fT); free(fM); free(minhz); free(W); free(cslot); free(ckind); free(crow);
+    if (st) st->t_trial_s += nla_seconds() - t0;
+    S->ret = ret;
     return ret;
+}
+
+/* final x (crs.c:258 keeps x = best point), stream accounting, release */
+nlopt_result nla_crs_end(nla_crs_session *S, uint64_t *words_used)
+{
+    nlopt_result ret;
+    if (!S) return NLOPT_INVALID_ARGS;
+    ret = S->ret;
+    if (words_used) *words_used = S->init_words + 2ULL * (uint64_t) S->pb.n * S->block;
+    if (ret != NLOPT_FAILURE && S->rs.os.nheap > 0 && S->rs.ops->read_row(S->rs.e, S->rs.os.best, S->rs.x)) {
+        engine_failed(S);
+        ret = S->ret;
+    }
+    session_free(S);
+    return ret;
+}
+
+nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *e, const nla_crs_problem *pb,
+                         double *x, double *minf, uint64_t *words_used)
+{
+    nlopt_result ret;
+    nla_crs_session *S = nla_crs_begin(ops, e, pb, x, minf, &ret);
+    if (!S) return ret;
+    if (ret == NLOPT_SUCCESS) nla_crs_advance(S, 0);
+    return nla_crs_end(S, words_used);
 }

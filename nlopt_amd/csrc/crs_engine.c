@@ -313,6 +313,36 @@ const nla_crs_engine_ops nla_crs_hip_ops = {
     op_init_population, op_max_slots, op_speculate, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
 };
 
+static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,
+                                    nla_stopping *stop, int population, nla_crs_problem *pb, nla_crs_hip_engine **eout)
+{
+    int64_t N = population ? (int64_t) population : 10 * ((int64_t) n + 1);     /* crs.c:172-179 */
+    *eout = NULL;
+    if (N < n + 1) {                                                            /* crs.c:180-184 */
+        nla_stop_msg(stop, "population %d should be >= dimension + 1 = %d", (int) N, n + 1);
+        return NLOPT_INVALID_ARGS;
+    }
+    memset(pb, 0, sizeof *pb);
+    pb->n = n; pb->N = N; pb->lb = lb; pb->ub = ub; pb->f = f; pb->f_data = f_data; pb->stop = stop;
+    pb->obj = nlopt_amd_objective_id(f);
+    if (opt) {
+        pb->trace = opt->trace; pb->trace_cap = opt->trace_cap; pb->trace_len = &opt->trace_len;
+        pb->stats = &opt->stats;
+        pb->max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
+        if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
+    }
+    if (nla_dev_count() <= 0) {
+        nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
+        return NLOPT_FAILURE;
+    }
+    *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->stats, NULL);
+    if (!*eout) {
+        nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
+        return NLOPT_OUT_OF_MEMORY;
+    }
+    return NLOPT_SUCCESS;
+}
+
 /* reference-shaped entry point: crs_minimize(n, f, f_data, lb, ub, x, minf, stop, population, lds=0)
  * (src/algs/crs/crs.h:34-40; called from the dispatcher as at src/api/optimize.c:744-747) */
 nlopt_result nla_crs_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,
@@ -322,31 +352,66 @@ nlopt_result nla_crs_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, 
     nla_crs_hip_engine *e;
     nlopt_result ret;
     uint64_t words = 0;
-    int64_t N = population ? (int64_t) population : 10 * ((int64_t) n + 1);     /* crs.c:172-179 */
-    if (N < n + 1) {                                                            /* crs.c:180-184 */
-        nla_stop_msg(stop, "population %d should be >= dimension + 1 = %d", (int) N, n + 1);
-        return NLOPT_INVALID_ARGS;
-    }
-    memset(&pb, 0, sizeof pb);
-    pb.n = n; pb.N = N; pb.lb = lb; pb.ub = ub; pb.f = f; pb.f_data = f_data; pb.stop = stop;
-    pb.obj = nlopt_amd_objective_id(f);
-    if (opt) {
-        pb.trace = opt->trace; pb.trace_cap = opt->trace_cap; pb.trace_len = &opt->trace_len;
-        pb.stats = &opt->stats;
-        pb.max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
-        if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb.obj = -1;   /* force the host-callback path */
-    }
-    if (nla_dev_count() <= 0) {
-        nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
-        return NLOPT_FAILURE;
-    }
-    e = nla_crs_hip_engine_create(n, N, lb, ub, pb.obj, pb.stats, NULL);
-    if (!e) {
-        nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
-        return NLOPT_OUT_OF_MEMORY;
-    }
+    ret = crs_open_common(opt, n, f, f_data, lb, ub, stop, population, &pb, &e);
+    if (ret != NLOPT_SUCCESS) return ret;
     ret = nla_crs_run(&nla_crs_hip_ops, e, &pb, x, minf, &words);
     if (pb.stats) pb.stats->mt_words = words;
     nla_crs_hip_engine_destroy(e, words);
+    return ret;
+}
+
+/* ---- stepwise sessions (nlopt_amd.h): the same run, paused between speculation rounds ---------- */
+struct nlopt_amd_crs_session {
+    nlopt_opt opt;
+    nla_stopping stop;
+    nla_crs_problem pb;
+    nla_crs_hip_engine *e;
+    nla_crs_session *S;
+    nlopt_result ret;
+};
+
+nlopt_result nla_setup_run(nlopt_opt opt, double *x, double *minf, nla_stopping *stop);
+
+nlopt_amd_crs_session *nlopt_amd_crs_open(nlopt_opt opt, double *x, double *minf, nlopt_result *ret_out)
+{
+    nlopt_amd_crs_session *h;
+    nlopt_result ret;
+    int pop;
+    nla_unset_errmsg(opt);
+    if (!opt || opt->algorithm != NLOPT_GN_CRS2_LM || opt->maximize) { if (ret_out) *ret_out = NLOPT_INVALID_ARGS; return NULL; }
+    h = (nlopt_amd_crs_session *) calloc(1, sizeof *h);
+    if (!h) { if (ret_out) *ret_out = NLOPT_OUT_OF_MEMORY; return NULL; }
+    h->opt = opt;
+    nlopt_set_force_stop(opt, 0);
+    ret = nla_setup_run(opt, x, minf, &h->stop);
+    if (ret == NLOPT_SUCCESS) {
+        pop = opt->stochastic_population > 0 ? (int) opt->stochastic_population
+                                             : (nla_stochastic_population > 0 ? nla_stochastic_population : 0);
+        ret = crs_open_common(opt, (int) opt->n, opt->f, opt->f_data, opt->lb, opt->ub, &h->stop, pop, &h->pb, &h->e);
+    }
+    if (ret != NLOPT_SUCCESS) { if (ret_out) *ret_out = ret; free(h); return NULL; }
+    h->S = nla_crs_begin(&nla_crs_hip_ops, h->e, &h->pb, x, minf, &ret);
+    h->ret = ret;
+    if (ret_out) *ret_out = ret;
+    if (!h->S) { nla_crs_hip_engine_destroy(h->e, 0); free(h); return NULL; }
+    return h;
+}
+
+nlopt_result nlopt_amd_crs_step(nlopt_amd_crs_session *h, long eval_budget)
+{
+    if (!h || !h->S) return NLOPT_INVALID_ARGS;
+    if (h->ret == NLOPT_SUCCESS) h->ret = nla_crs_advance(h->S, (int64_t) eval_budget);
+    return h->ret;
+}
+
+nlopt_result nlopt_amd_crs_close(nlopt_amd_crs_session *h)
+{
+    nlopt_result ret;
+    uint64_t words = 0;
+    if (!h) return NLOPT_INVALID_ARGS;
+    ret = nla_crs_end(h->S, &words);
+    if (h->pb.stats) h->pb.stats->mt_words = words;
+    nla_crs_hip_engine_destroy(h->e, words);
+    free(h);
     return ret;
 }

@@ -153,7 +153,13 @@ typedef struct {
     int max_spec;                   /* cap on slots per round (0 = default) */
 } nla_crs_problem;
 
-/* the algorithm; *words_used = stream words consumed (2n per row / block) */
+/* the algorithm, resumable between speculation rounds (bench steps, sessions);
+ * *words_used = stream words consumed (2n per row / block) */
+typedef struct nla_crs_session nla_crs_session;
+nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *engine, const nla_crs_problem *pb,
+                               double *x, double *minf, nlopt_result *ret_out);
+nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget);
+nlopt_result nla_crs_end(nla_crs_session *S, uint64_t *words_used);
 nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *engine, const nla_crs_problem *pb,
                          double *x, double *minf, uint64_t *words_used);
 

@@ -113,6 +113,8 @@ int orc_emu_crs(int obj, int n, long N, const double *lb, const double *ub, doub
     int nevals = 0, force = 0, ret;
     uint64_t words = 0;
     char *msg = NULL;
+    if (N == 0) N = 10 * ((long) n + 1);          /* crs.c:172-179, done by nla_crs_minimize in the product */
+    if (N < n + 1) return -2;
     memset(&e, 0, sizeof e);
     e.n = n; e.ld = (n + 1) & ~1; e.N = N; e.obj = host_eval ? -1 : obj; e.lb = lb; e.ub = ub; e.cap = 1024;
     e.max_slots = max_slots > 0 ? max_slots : 1024;

@@ -55,3 +55,20 @@ double orc_recording_callback(unsigned n, const double *x, double *grad, void *d
     ++r->len;
     return f;
 }
+
+/* timing wrapper for the cpu_baseline leg of bench.py: wall-clock stamps at evaluation #mark and
+ * at the last evaluation, so the trial phase can be timed without the init phase */
+#include <sys/time.h>
+typedef struct { orc_func inner; void *inner_data; long mark, count; double t_first, t_mark, t_last; } orc_timer;
+static double now_s(void) { struct timeval tv; gettimeofday(&tv, NULL); return (double) tv.tv_sec + 1e-6 * (double) tv.tv_usec; }
+double orc_timing_callback(unsigned n, const double *x, double *grad, void *data)
+{
+    orc_timer *t = (orc_timer *) data;
+    double f = t->inner(n, x, grad, t->inner_data);
+    double now = now_s();
+    if (t->count == 0) t->t_first = now;
+    ++t->count;
+    if (t->count == t->mark) t->t_mark = now;
+    t->t_last = now;
+    return f;
+}

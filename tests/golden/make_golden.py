@@ -1,0 +1,56 @@
+"""Generate tests/golden/crs_golden.json from the REAL reference (oracle/_ref/libnlopt_ref.so, built
+from /root/reference by oracle/Makefile).  Run in the build container only:
+    python tests/golden/make_golden.py
+Each case records what a later run (port or HIP path) must reproduce: nlopt_result, numevals, minf
+(hex, bit-exact for the CPU port; 1e-10 relative for the device objective), the argmin x (hex),
+and the full per-evaluation f sequence compressed to a hash + the first/last few values."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _oracle as O  # noqa: E402
+
+CASES = [
+    # (name, obj, n, pop, seed, kwargs)  — kwargs go to both the reference and the candidates
+    ("cfg1_rosenbrock_n10_pop100", "rosenbrock", 10, 100, 42, dict(maxeval=10000)),
+    ("rastrigin_n10_pop100_ftol1e-4", "rastrigin", 10, 100, 42, dict(ftol_rel=1e-4)),
+    ("rastrigin_n10_pop100_ftol1e-8", "rastrigin", 10, 100, 42, dict(ftol_rel=1e-8)),
+    ("griewank_n8_pop50", "griewank", 8, 50, 42, dict(maxeval=5002)),
+    ("griewank_n10_default_pop", "griewank", 10, 0, 12345, dict(maxeval=3000)),
+    ("levy_n4_default_pop", "levy", 4, 0, 12345, dict(maxeval=3000)),
+    ("ackley_n16_pop400", "ackley", 16, 400, 7, dict(maxeval=6000)),
+    ("rastrigin_n64_pop2000", "rastrigin", 64, 2000, 42, dict(maxeval=12000)),
+    ("sphere_n3_pop4_stopval", "sphere", 3, 4, 3, dict(stopval=1e-3, maxeval=4000)),
+    ("sphere_n3_pop40_stopval_hit", "sphere", 3, 40, 3, dict(stopval=1e-2, maxeval=4000)),
+    ("rastrigin_n10_stopval_in_init", "rastrigin", 10, 100, 42, dict(stopval=120.0)),
+    ("rastrigin_n10_maxeval_in_init", "rastrigin", 10, 100, 42, dict(maxeval=37)),
+    ("rosenbrock_n5_xtol", "rosenbrock", 5, 60, 9, dict(xtol_rel=1e-3, maxeval=20000)),
+    ("rastrigin_n257_pop600_odd_n", "rastrigin", 257, 600, 5, dict(maxeval=1500)),
+    ("griewank_n512_pop3000", "griewank", 512, 3000, 42, dict(maxeval=5000)),
+]
+
+
+def fhash(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+def main():
+    out = {}
+    for name, obj, n, pop, seed, kw in CASES:
+        r = O.run_ref(19, obj, n, pop, seed, **kw)
+        out[name] = dict(obj=obj, n=n, pop=pop, seed=seed, kwargs=kw, ret=int(r["ret"]), nevals=int(r["nevals"]),
+                         minf=float(r["minf"]).hex(), x=[float(v).hex() for v in r["x"]],
+                         fseq_sha256=fhash(r["fseq"]), xhash_sha256=hashlib.sha256(r["xhash"].tobytes()).hexdigest(),
+                         fseq_head=[float(v).hex() for v in r["fseq"][:8]], fseq_tail=[float(v).hex() for v in r["fseq"][-8:]])
+        print(name, r["ret"], r["nevals"], r["minf"])
+    with open(os.path.join(HERE, "crs_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,211 @@
+"""-m gpu: CRS2_LM end to end through the public C API (nlopt_create / nlopt_set_min_objective /
+nlopt_optimize of libnlopt_amd.so) against the CPU oracle and the golden vectors generated from
+the real reference.  Bar (BASELINE.json north_star): bit-exact candidate indices (which
+evaluations were accepted and which row each replaced), f within 1e-10 relative, same numevals /
+result code / RNG consumption; x of the optimum bit-exact."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import nlopt_amd
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "crs_golden.json")))
+RTOL = 1e-10
+
+
+def run_amd(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0, trace_cap=0,
+            params=None, host_callback=None):
+    assert nlopt_amd.device_count() > 0, "no HIP device: the product has no CPU fallback"
+    xs, lo, hi = O.golden_x0(obj, n)
+    o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
+    o.set_lower_bounds(lo)
+    o.set_upper_bounds(hi)
+    o.set_min_objective(host_callback if host_callback is not None else nlopt_amd.objective(obj))
+    if pop:
+        o.set_population(pop)
+    if maxeval:
+        o.set_maxeval(maxeval)
+    if stopval is not None:
+        o.set_stopval(stopval)
+    if ftol_rel:
+        o.set_ftol_rel(ftol_rel)
+    if ftol_abs:
+        o.set_ftol_abs(ftol_abs)
+    if xtol_rel:
+        o.set_xtol_rel(xtol_rel)
+    for k, v in (params or {}).items():
+        o.set_param(k, v)
+    if trace_cap:
+        o.enable_trace(trace_cap)
+    nlopt_amd.srand(seed)
+    x, minf, ret = o.optimize_raw(xs if x0 is None else x0)
+    return dict(ret=ret, minf=minf, x=x, nevals=o.get_numevals(), trace=o.trace() if trace_cap else None,
+                stats=o.stats(), err=o.get_errmsg(), opt=o)
+
+
+def assert_same_run(a, p, check_trace=True):
+    """a = libnlopt_amd result, p = oracle port result"""
+    assert a["ret"] == p["ret"], (a["ret"], p["ret"], a["err"])
+    assert a["nevals"] == p["nevals"]
+    assert abs(a["minf"] - p["minf"]) <= RTOL * max(abs(p["minf"]), 1e-300) or abs(a["minf"] - p["minf"]) <= RTOL * np.abs(p["trace"]["f"]).mean()
+    assert np.array_equal(a["x"], p["x"])                      # bit-exact argmin
+    assert a["stats"]["mt_words"] == p["words"]
+    if check_trace:
+        ta, tp = a["trace"], p["trace"]
+        assert len(ta) == len(tp)
+        assert np.array_equal(ta["row"], tp["row"])            # bit-exact candidate / replaced-row indices
+        assert np.array_equal(ta["kind"], tp["kind"])
+        assert np.array_equal(ta["accepted"], tp["accepted"])
+        scale = np.abs(tp["f"]).mean()
+        assert np.all(np.abs(ta["f"] - tp["f"]) <= RTOL * np.maximum(np.abs(tp["f"]), scale))
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_crs_matches_golden_and_oracle(name):
+    g = GOLD[name]
+    kw = dict(g["kwargs"])
+    a = run_amd(g["obj"], g["n"], g["pop"], g["seed"], trace_cap=200000, **kw)
+    p = O.run_port_crs(g["obj"], g["n"], g["pop"], g["seed"], trace_cap=200000, **kw)
+    assert_same_run(a, p)
+    # the committed golden vector generated from the real reference
+    assert a["ret"] == g["ret"] and a["nevals"] == g["nevals"]
+    gm = float.fromhex(g["minf"])
+    assert abs(a["minf"] - gm) <= RTOL * max(abs(gm), np.abs(p["trace"]["f"]).mean())
+    assert [float(v).hex() for v in a["x"]] == g["x"]
+
+
+def test_speculation_depth_does_not_change_the_sequence():
+    base = None
+    for spec in (1, 2, 16, 0):
+        a = run_amd("rastrigin", 64, 2000, 42, maxeval=9000, trace_cap=20000, params={"amd_max_spec": spec})
+        if base is None:
+            base = a
+        else:
+            assert np.array_equal(a["trace"]["row"], base["trace"]["row"])
+            assert np.array_equal(a["trace"]["f"], base["trace"]["f"])       # same device, same kernels: bit-identical
+            assert np.array_equal(a["x"], base["x"]) and a["minf"] == base["minf"]
+    assert base["stats"]["slots_launched"] == base["stats"]["slots_used"]     # depth 1 never wastes a slot
+
+
+def test_rng_continues_where_the_reference_would():
+    """after nlopt_optimize the thread's generator must stand where the serial reference's stands"""
+    P, L = O.port(), nlopt_amd.lib()
+    a = run_amd("griewank", 8, 50, 42, maxeval=5002)
+    after = [L.nla_genrand_int32() for _ in range(1500)]
+    p = O.run_port_crs("griewank", 8, 50, 42, maxeval=5002)
+    assert a["stats"]["mt_words"] == p["words"] == 80016
+    ref_after = [P.orc_genrand_int32() for _ in range(1500)]
+    assert after == ref_after
+
+
+def test_generic_host_callback_takes_the_exact_serial_path():
+    calls = []
+
+    def f(x, grad):
+        calls.append(x.copy())
+        return float(np.sum((x - 0.5) ** 2) + np.sum(np.cos(3 * x)))
+
+    n, pop, seed, me = 6, 70, 11, 900
+    a = run_amd("sphere", n, pop, seed, maxeval=me, trace_cap=2000, host_callback=f)
+    # the reference with the same Python-level objective (through ctypes callbacks)
+    if O.have_ref():
+        R = O.ref()
+        xs, lo, hi = O.golden_x0("sphere", n)
+        rcalls = []
+        cb = nlopt_amd.NLOPT_FUNC(lambda nn, x, g, d: (rcalls.append(np.ctypeslib.as_array(x, shape=(nn,)).copy()),
+                                                       float(np.sum((rcalls[-1] - 0.5) ** 2) + np.sum(np.cos(3 * rcalls[-1]))))[1])
+        opt = R.nlopt_create(19, n)
+        lb, ub = np.full(n, lo), np.full(n, hi)
+        R.nlopt_set_lower_bounds(opt, O.dptr(lb))
+        R.nlopt_set_upper_bounds(opt, O.dptr(ub))
+        R.nlopt_set_min_objective(opt, C.cast(cb, C.c_void_p).value, None)
+        R.nlopt_set_population(opt, pop)
+        R.nlopt_set_maxeval(opt, me)
+        x = np.array(xs)
+        mf = C.c_double()
+        R.nlopt_srand(seed)
+        ret = R.nlopt_optimize(opt, O.dptr(x), C.byref(mf))
+        assert ret == a["ret"] and R.nlopt_get_numevals(opt) == a["nevals"] == len(calls)
+        assert mf.value == a["minf"] and np.array_equal(x, a["x"])
+        assert all(np.array_equal(u, v) for u, v in zip(calls, rcalls))       # same x, same order, one at a time
+        R.nlopt_destroy(opt)
+    assert a["stats"]["slots_launched"] == a["stats"]["slots_used"]
+
+
+def test_maximisation_flips_signs_like_the_reference():
+    # maximise -sphere == minimise sphere; device objective is not recognised through the flip wrapper,
+    # so this also exercises the host-callback path through f_max (optimize.c:970-980,1014-1024)
+    n = 4
+    o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
+    o.set_lower_bounds(-3.0)
+    o.set_upper_bounds(2.0)
+    o.set_max_objective(lambda x, g: -float(np.sum(x * x)))
+    o.set_population(40)
+    o.set_maxeval(1500)
+    nlopt_amd.srand(5)
+    x, maxf, ret = o.optimize_raw(np.full(n, 1.0))
+    assert ret == 5 and maxf <= 0 and maxf > -0.5
+
+
+@pytest.mark.parametrize("n,N", [(4096, 20000)])
+def test_large_n_prefix_against_oracle(n, N):
+    """n = 4096 (the metric's dimension): the first ~300 trial evaluations after a 2e4-row init,
+    compared with the CPU oracle evaluation by evaluation (about 15 s of CPU)."""
+    me = N + 300
+    a = run_amd("griewank", n, N, 42, maxeval=me, trace_cap=me + 100)
+    p = O.run_port_crs("griewank", n, N, 42, maxeval=me, trace_cap=me + 100)
+    assert_same_run(a, p)
+
+
+def test_full_size_invariants_at_the_metric_configuration():
+    """CRS2_LM Griewank n=4096 pop=1e5 (BASELINE.json metric config): too big for a CPU replay in a
+    test, so check size-independent properties of the run: evaluation accounting, stream
+    accounting, every accepted f below the f it replaced, final minf == min over the trace, and the
+    trace is unchanged when the same run is repeated with a different speculation depth."""
+    n, N, extra = 4096, 100000, 1500
+    a = run_amd("griewank", n, N, 42, maxeval=N + extra, trace_cap=N + extra + 64)
+    t = a["trace"]
+    st = a["stats"]
+    assert a["ret"] == 5 and a["nevals"] >= N + extra
+    assert st["evals_init"] == N and st["evals_init"] + st["evals_trial"] + st["evals_mutation"] == a["nevals"]
+    assert st["mt_words"] == 2 * n * (N - 1) + 2 * n * (a["nevals"] - N)
+    assert np.all(t["kind"][:N] == 0) and np.array_equal(t["row"][:N], np.arange(N))
+    F = t["f"][:N].copy()
+    for rec in t[N:]:
+        if rec["accepted"]:
+            assert rec["f"] < F[rec["row"]] and F[rec["row"]] == F.max()       # replaced the current worst
+            F[rec["row"]] = rec["f"]
+        else:
+            assert rec["f"] >= F.max()
+    assert a["minf"] == F.min()
+    lo, hi = nlopt_amd.objective_box("griewank")
+    assert np.all(a["x"] >= lo) and np.all(a["x"] <= hi)
+    b = run_amd("griewank", n, N, 42, maxeval=N + extra, trace_cap=N + extra + 64, params={"amd_max_spec": 3})
+    assert np.array_equal(b["trace"]["row"], t["row"]) and np.array_equal(b["trace"]["f"], t["f"])
+    assert np.array_equal(a["x"], b["x"])
+
+
+def test_stepwise_session_equals_one_shot():
+    L = nlopt_amd.lib()
+    n, N = 32, 500
+    one = run_amd("ackley", n, N, 8, maxeval=3000, trace_cap=4000)
+    xs, lo, hi = O.golden_x0("ackley", n)
+    o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
+    o.set_lower_bounds(lo); o.set_upper_bounds(hi)
+    o.set_min_objective(nlopt_amd.objective("ackley"))
+    o.set_population(N); o.set_maxeval(3000); o.enable_trace(4000)
+    nlopt_amd.srand(8)
+    x = np.array(xs)
+    mf, ret = C.c_double(), C.c_int()
+    s = L.nlopt_amd_crs_open(o._h, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(mf), C.byref(ret))
+    assert s and ret.value == 1
+    while L.nlopt_amd_crs_step(s, 100) == 1:
+        pass
+    assert L.nlopt_amd_crs_close(s) == one["ret"]
+    assert o.get_numevals() == one["nevals"] and mf.value == one["minf"] and np.array_equal(x, one["x"])
+    assert np.array_equal(o.trace()["row"], one["trace"]["row"])

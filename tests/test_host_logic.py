@@ -1,0 +1,113 @@
+"""Host-side logic of the product, testable without a GPU:
+ * the speculate/commit CRS driver (nlopt_amd/csrc/crs_driver.c) run over a CPU emulation of the
+   device engine (oracle/port_emu_engine.c) must reproduce the oracle's serial trace exactly, for
+   any speculation depth;
+ * MT19937 host generator + GF(2) jump-ahead machinery (nlopt_amd/csrc/mt_host.c)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import nlopt_amd
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "crs_golden.json")))
+TR = ("f", "row", "kind", "accepted")
+
+
+def same_trace(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[k], b[k]) for k in TR)
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_driver_over_emulated_engine_matches_golden(name):
+    g = GOLD[name]
+    kw = dict(g["kwargs"])
+    r = O.run_emu_crs(g["obj"], g["n"], g["pop"], g["seed"], trace_cap=200000, **kw)
+    assert r["ret"] == g["ret"] and r["nevals"] == g["nevals"]
+    assert float(r["minf"]).hex() == g["minf"]
+    assert [float(v).hex() for v in r["x"]] == g["x"]
+    p = O.run_port_crs(g["obj"], g["n"], g["pop"], g["seed"], trace_cap=200000, **kw)
+    assert same_trace(p["trace"], r["trace"])
+    assert p["words"] == r["words"]
+
+
+@pytest.mark.parametrize("max_slots,max_spec", [(1, 0), (3, 0), (0, 1), (0, 2), (0, 37), (5, 1024), (0, 0)])
+def test_trace_is_invariant_under_speculation_depth(max_slots, max_spec):
+    base = O.run_port_crs("rastrigin", 24, 300, 17, maxeval=4000, trace_cap=10000)
+    r = O.run_emu_crs("rastrigin", 24, 300, 17, maxeval=4000, trace_cap=10000, max_slots=max_slots, max_spec=max_spec)
+    assert r["ret"] == base["ret"] and r["nevals"] == base["nevals"]
+    assert same_trace(base["trace"], r["trace"])
+    assert np.array_equal(base["x"], r["x"]) and base["minf"] == r["minf"]
+    st = r["stats"]
+    assert st["evals_init"] + st["evals_trial"] + st["evals_mutation"] == r["nevals"]
+    assert st["slots_launched"] >= st["slots_used"]
+
+
+def test_host_callback_path_matches_serial_reference_order():
+    base = O.run_port_crs("levy", 6, 80, 3, maxeval=2500, trace_cap=5000)
+    r = O.run_emu_crs("levy", 6, 80, 3, maxeval=2500, trace_cap=5000, host_eval=True)
+    assert same_trace(base["trace"], r["trace"]) and r["stats"]["slots_launched"] == r["stats"]["slots_used"]
+
+
+def test_tiny_population_where_worst_list_covers_everything():
+    # N = n+1 = 4: the per-round worst list is the whole population, the best row included
+    base = O.run_port_crs("sphere", 3, 4, 5, maxeval=600, trace_cap=2000)
+    r = O.run_emu_crs("sphere", 3, 4, 5, maxeval=600, trace_cap=2000)
+    assert same_trace(base["trace"], r["trace"]) and np.array_equal(base["x"], r["x"])
+
+
+# ---- MT19937 host side -------------------------------------------------------------------------
+def test_product_generator_matches_oracle_generator():
+    L, P = nlopt_amd.lib(), O.port()
+    L.nlopt_srand(20240922)
+    P.orc_srand(20240922)
+    for i in range(5000):
+        assert L.nla_genrand_int32() == P.orc_genrand_int32()
+    for i in range(500):
+        assert L.nlopt_urand(-1.0, 3.0) == P.orc_urand(-1.0, 3.0)
+        assert L.nlopt_iurand(4097) == P.orc_iurand(4097)
+        assert L.nlopt_nrand(0.0, 1.0) == P.orc_nrand(0.0, 1.0)
+
+
+def test_characteristic_polynomial_has_the_known_weight():
+    L = nlopt_amd.lib()
+    exps = C.POINTER(C.c_int)()
+    nterms = L.nla_mt_charpoly_terms(C.byref(exps))
+    e = [exps[i] for i in range(nterms)]
+    assert nterms == 135 and e[0] == 0 and e[-1] == 19937        # weight of MT19937's characteristic polynomial
+
+
+def _regen_ref(mt, times):
+    L = nlopt_amd.lib()
+    a = mt.copy()
+    L.nla_mt_regen.argtypes = [C.c_void_p]
+    for _ in range(times):
+        L.nla_mt_regen(a.ctypes.data)
+    return a
+
+
+def test_jump_polynomials_equal_plain_regeneration():
+    L = nlopt_amd.lib()
+    L.nlopt_srand(777)
+    mt = np.zeros(624, dtype=np.uint32)
+    cons = C.c_int()
+    L.nla_mt_export(mt.ctypes.data, C.byref(cons))
+    assert cons.value == 0
+    out = np.zeros(624, dtype=np.uint32)
+    # pow2 table entry k jumps 2^k regenerations
+    for k in (0, 1, 5):
+        L.nla_mt_apply_jump_host(L.nla_mt_jump_poly_pow2(k), mt.ctypes.data, out.ctypes.data)
+        assert np.array_equal(out, _regen_ref(mt, 1 << k))
+    # arbitrary word offset, not a multiple of 624: compare word windows
+    J = 624 * 3 + 77
+    g = np.zeros(312, dtype=np.uint64)
+    L.nla_mt_jump_poly_words(J, g.ctypes.data)
+    L.nla_mt_apply_jump_host(g.ctypes.data, mt.ctypes.data, out.ctypes.data)
+    seq = np.concatenate([_regen_ref(mt, r) for r in range(6)])
+    assert np.array_equal(out, seq[J:J + 624])
+    # binary decomposition with plain regeneration for the low bits
+    L.nla_mt_advance_blocks_host(mt.ctypes.data, 4096 + 3, out.ctypes.data)
+    assert np.array_equal(out, _regen_ref(mt, 4099))

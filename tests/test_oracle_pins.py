@@ -1,0 +1,90 @@
+"""Pin the CPU oracle (oracle/port_*.c) — the checker every GPU parity test relies on:
+(1) MT19937 against the published known-answer values and, word for word, against the real
+reference's samplers; (2) CRS2_LM evaluation-by-evaluation against the real reference
+(oracle/_ref/libnlopt_ref.so, when present); (3) against the committed golden vectors that were
+generated from the real reference (tests/golden/make_golden.py)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "crs_golden.json")))
+need_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
+
+
+def test_mt19937_known_answers():
+    L = O.port()
+    L.orc_srand(5489)
+    first = [L.orc_genrand_int32() for _ in range(5)]
+    # published MT19937 outputs for the default seed 5489
+    assert first == [3499211612, 581869302, 3890346734, 3586334585, 545404204]
+    for _ in range(10000 - 5 - 1):
+        L.orc_genrand_int32()
+    assert L.orc_genrand_int32() == 4123659995      # the 10000th output (C++11 [rand.predef] check value)
+
+
+@need_ref
+def test_samplers_match_reference_word_for_word():
+    L, R = O.port(), O.ref()
+    for seed in (0, 1, 42, 2**31 + 5):
+        L.orc_srand(seed)
+        R.nlopt_srand(seed)
+        for i in range(3000):
+            k = i % 4
+            if k == 0:
+                assert L.orc_urand(-3.5, 7.25) == R.nlopt_urand(-3.5, 7.25)
+            elif k == 1:
+                assert L.orc_iurand(977) == R.nlopt_iurand(977)
+            elif k == 2:
+                assert L.orc_nrand(1.5, 2.0) == R.nlopt_nrand(1.5, 2.0)
+            else:
+                assert L.orc_urand(0.0, 1.0) == R.nlopt_urand(0.0, 1.0)
+
+
+def _fhash(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_port_crs_matches_golden(name):
+    g = GOLD[name]
+    r = O.run_port_crs(g["obj"], g["n"], g["pop"], g["seed"], record=True, **g["kwargs"])
+    assert r["ret"] == g["ret"]
+    assert r["nevals"] == g["nevals"]
+    assert float(r["minf"]).hex() == g["minf"]
+    assert [float(v).hex() for v in r["x"]] == g["x"]
+    assert _fhash(r["fseq"]) == g["fseq_sha256"]
+    assert hashlib.sha256(r["xhash"].tobytes()).hexdigest() == g["xhash_sha256"]
+
+
+@need_ref
+@pytest.mark.parametrize("obj,n,pop,seed,kw", [
+    ("rastrigin", 32, 400, 11, dict(maxeval=5000)),
+    ("ackley", 12, 0, 99, dict(maxeval=4000)),
+    ("levy", 7, 90, 5, dict(ftol_abs=1e-6, maxeval=30000)),
+    ("rosenbrock", 2, 3, 1, dict(maxeval=500)),          # N == n+1: every trial uses every other row
+])
+def test_port_crs_matches_reference_live(obj, n, pop, seed, kw):
+    a = O.run_port_crs(obj, n, pop, seed, record=True, **kw)
+    b = O.run_ref(19, obj, n, pop, seed, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert a["minf"] == b["minf"]
+    assert np.array_equal(a["x"], b["x"])
+    assert np.array_equal(a["fseq"], b["fseq"])
+    assert np.array_equal(a["xhash"], b["xhash"])
+
+
+def test_port_crs_rejects_small_population():
+    r = O.run_port_crs("sphere", 5, 5, 1, maxeval=100)     # N < n+1 (crs.c:180-184)
+    assert r["ret"] == -2
+
+
+def test_word_accounting_matches_survey_appendix_a():
+    # CRS2_LM n=8, N=50, 5002 evals consumes 2n(N-1) + 2n(evals-N) = 80016 words
+    r = O.run_port_crs("griewank", 8, 50, 42, maxeval=5002)
+    assert r["nevals"] == 5002 and r["words"] == 80016
