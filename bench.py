@@ -17,8 +17,10 @@ own GPU with its own seed ("replicas only", scaling = weak, no data-path collect
 the sum over ranks.  See DESIGN.md §multi-GPU for what comes next.
 
 Output: ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     — dominant kernel (crs_gather_kernel): algorithmic bytes 8 n (n+1) per trial x trials
-                 per launch / HIP-event time of those launches on their own stream, vs 8 TB/s HBM
+  roofline     — dominant kernel (crs_advance_kernel, the resumable gather-sum): algorithmic bytes
+                 = 8n per population row summed (n+1 rows = 8 n (n+1) B per trial), counted per
+                 launch from the slots' progress / HIP-event time of those launches on their own
+                 stream, vs 8 TB/s HBM
   cpu_baseline — the real reference NLopt (oracle/_ref, kind "reference") or the C port (kind
                  "port") timed single-threaded on this host on a bounded sample of the same workload
   gens_to_ftol — numevals/pop at NLOPT_FTOL_REACHED on the small configuration where the CPU
@@ -51,6 +53,7 @@ def parse():
     ap.add_argument("--evals-per-step", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--max-spec", type=int, default=0)
+    ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pop", type=int, default=20000)
     ap.add_argument("--cpu-sample-trials", type=int, default=400)
@@ -154,6 +157,8 @@ def main():
     o.set_population(pop)
     if a.max_spec:
         o.set_param("amd_max_spec", a.max_spec)
+    if a.gather_variant:
+        o.set_param("amd_gather_variant", a.gather_variant)
     nlopt_amd.srand(a.seed + rank)
     x = np.array(xs)
     minf, ret = C.c_double(), C.c_int()
@@ -211,14 +216,14 @@ def main():
                                    % (a.obj, n, pop, a.seed, a.evals_per_step,
                                       "" if world == 1 else "; %d independent replicas (seed+rank)" % world),
                        "evals_timed": int(evals_all), "evals_per_step_requested": a.evals_per_step},
-            "roofline": {"bound": "hbm", "kernel": "crs_gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "crs_advance_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "launches": int(g_launch), "avg_launch_ms": (g_ms / g_launch) if g_launch else None,
                          "algorithmic_bytes_per_trial": 8 * n * (n + 1),
-                         "avg_trials_per_launch": (slots / g_launch) if g_launch else None},
-            "speculation": {"slots_launched": int(slots), "slots_used": int(used),
+                         "avg_algorithmic_MB_per_launch": (g_bytes / 1e6 / g_launch) if g_launch else None,
+                         "avg_trials_consumed_per_launch": (used / g_launch) if g_launch else None},
+            "window": {"slots_started": int(slots), "slots_used": int(used),
                             "useful_frac": (used / slots) if slots else None,
-                            "invalid": int(st1["slots_invalid"] - st0["slots_invalid"]),
                             "newbest": int(st1["slots_newbest"] - st0["slots_newbest"]),
                             "role": int(st1["slots_role"] - st0["slots_role"]),
                             "accepted": int(st1["accepted"] - st0["accepted"])},

@@ -53,23 +53,23 @@ nlopt_result nlopt_amd_set_trace(nlopt_opt opt, nlopt_amd_trace_rec *buf, size_t
 size_t nlopt_amd_trace_len(const nlopt_opt opt);       /* records produced by the last nlopt_optimize */
 
 typedef struct {
-    uint64_t rounds;            /* speculate/commit rounds */
-    uint64_t slots_launched;    /* speculative reflection trials computed on the device */
+    uint64_t rounds;            /* advance/commit passes */
+    uint64_t slots_launched;    /* stream blocks started on the device as reflection trials */
     uint64_t slots_used;        /* ... consumed by the in-order commit walk */
-    uint64_t slots_invalid;     /* ... discarded: read a row overwritten earlier in the same round */
-    uint64_t slots_newbest;     /* ... discarded: the best point changed earlier in the same round */
-    uint64_t slots_role;        /* ... discarded: their block was consumed as a mutation block */
+    uint64_t slots_invalid;     /* always 0: a slot never reads a row that can still change (kept for layout) */
+    uint64_t slots_newbest;     /* ... discarded in flight: the best point changed */
+    uint64_t slots_role;        /* ... discarded in flight: their block was consumed as a mutation block */
     uint64_t evals_init, evals_trial, evals_mutation;
     uint64_t accepted;
     uint64_t mt_words;          /* MT19937 words consumed (== the reference's count) */
     double t_init_s, t_trial_s; /* wall seconds in the two phases */
-    double t_gather_ms;         /* sum of device time of the gather kernel (HIP events) */
+    double t_gather_ms;         /* sum of device time of the gather-sum (advance) kernel (HIP events) */
     uint64_t gather_launches;
-    uint64_t gather_bytes;      /* algorithmic bytes moved by those launches: slots * 8 n (n+1) */
+    uint64_t gather_bytes;      /* algorithmic bytes those launches summed: 8n per row, n+1 rows per trial */
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 
-/* Stepwise CRS2_LM: the same run as nlopt_optimize(), paused between speculation rounds (used by
+/* Stepwise CRS2_LM: the same run as nlopt_optimize(), paused between passes (used by
  * bench.py to time exactly K steps, and by callers that want to poll).  open() performs the
  * population initialisation (crs_init, crs.c:165-229); step() runs until the algorithm stops or at
  * least `eval_budget` more objective evaluations were made (<=0: until it stops); close() writes
@@ -118,23 +118,34 @@ int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F
 int nla_k_crs_vitter(int n, int64_t N, const uint32_t *words, int nblocks,
                      int32_t *jn, int32_t *pos, int32_t *last, void *stream);
 
-/* replaces: the centroid/reflection gather-sum of random_trial, crs.c:101-120 (K4), for K
- * speculative trials at once against one population snapshot.  Slot s uses block s of
- * jn/pos/last; TX[s*ld + k] = clamp((best_k + sum ...) * 2/n).  Row order, one accumulator per
- * coordinate, no FMA: bit-identical to the reference's x. */
-int nla_k_crs_gather(int n, int ld, const double *X, int64_t i0, const int32_t *jn, const int32_t *pos,
-                     const int32_t *last, int K, const double *lb, const double *ub, double *TX, void *stream);
+/* status of one window slot after a pass (read back by the host's in-order commit walk) */
+typedef struct { double fT, fM; int32_t t, pad; } nla_crs_slot_status;
 
-/* replaces: the evaluation of the trial (crs.c:133), the local mutation + its evaluation
- * (crs.c:139-146, K5) and the information the in-order commit needs (K6):
- *   fT[s] = f(TX[s]);  TM[s] = clamp(best*(1+w) - w*TX[s]) with w from stream block s+1
- *   (words_next = words of block first+1), fM[s] = f(TM[s]);
- *   minhz[s] = smallest rank r < nW with W[r] among the rows slot s read (INT32_MAX if none).
- * obj < 0: no evaluation / no mutation (host-callback mode). */
-int nla_k_crs_post(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
-                   const uint32_t *words_next, int K, const int64_t *W, int nW,
-                   const int32_t *pos, const int32_t *last, const double *lb, const double *ub,
-                   double *fT, double *fM, int32_t *minhz, void *stream);
+/* replaces: the centroid/reflection gather-sum of random_trial, crs.c:69,101-120 (K4), as a
+ * resumable operation on a window of K consecutive stream blocks first_block .. first_block+K-1.
+ * Block b uses entry b % ring_blocks of jn_ring/pos_ring/last_ring (as written by
+ * nla_k_crs_vitter) and slot q = b & slot_mask of TX.  Slot state: picks [0,t) are summed into
+ * TX[q] (t == n: TX[q] is the finished trial point x, scaled and clamped; row order, one
+ * accumulator per coordinate, no FMA: bit-identical to the reference's x).  Window slot a
+ * (block first_block+a) resumes at t_in[a] and advances to the first pick whose row is among
+ * W[0 .. min(a,nW)) — the rows that may be overwritten before the slot's turn — or to n;
+ * t_out[a] = new t.  t_in and t_out must be different arrays.  variant 0 = automatic tiling. */
+int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                      const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                      uint64_t first_block, int K, const int64_t *W, int nW,
+                      const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                      double *TX, int variant, void *stream);
+
+/* replaces: the evaluation of the trial (crs.c:133) and the local mutation + its evaluation
+ * (crs.c:139-146, K5) for the slots completed by the preceding nla_k_crs_advance (same window):
+ * fT_ring[q] = f(TX[q]); TM[q] = clamp(best*(1+w) - w*TX[q]), w from the words of block b+1
+ * (words_ring entry (b+1) % ring_blocks); fM_ring[q] = f(TM[q]); status[a] = (fT, fM, t) of
+ * window slot a for all a < K.  obj < 0: no evaluation / no mutation (host-callback mode). */
+int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                     const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                     const int32_t *t_in, const int32_t *t_out, int slot_mask,
+                     const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                     nla_crs_slot_status *status, void *stream);
 
 /* replaces: memcpy(worst->k, d->p, ...) at crs.c:153 for a batch of accepted candidates.
  * X[row[c]] := (kind[c] == 1 ? TX : TM)[slot[c]];  rows must be distinct within one call. */

@@ -173,9 +173,10 @@ def lib():
     L.nla_k_crs_init_rows.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.nla_k_eval.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
     L.nla_k_crs_vitter.argtypes = [C.c_int, C.c_int64, vp, C.c_int, vp, vp, vp, vp]
-    L.nla_k_crs_gather.argtypes = [C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_int, vp, vp, vp, vp]
-    L.nla_k_crs_post.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp,
-                                 vp, vp, vp, vp, vp, vp]
+    L.nla_k_crs_advance.argtypes = [C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, C.c_int,
+                                    vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]
+    L.nla_k_crs_finish.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int,
+                                   vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.nla_k_crs_commit.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_mutate.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
     L.nla_mt_jump_poly_words.argtypes = [C.c_uint64, vp]

@@ -1,27 +1,32 @@
-/* crs_driver.c — CRS2_LM, the algorithm side: speculate on the device, commit in program order.
+/* crs_driver.c — CRS2_LM, the algorithm side: a window of stream blocks in flight on the device,
+ * committed in program order on the host.
  *
  * The reference (src/algs/crs/crs.c) is one serial chain: build ONE trial point from the current
  * best + n random rows, evaluate it, accept it over the current worst or reject it, maybe mutate,
  * repeat (crs_trial :125-156, crs_minimize :250-270).  Its only data parallelism is inside a
- * trial.  To feed a GPU we exploit two facts:
- *   (i)  every reflection trial and every mutation consumes exactly one 2n-word block of the MT
- *        stream, so the random content of block m is known before its role is;
- *   (ii) a block is a mutation iff the previous block was a rejected reflection (:129-151), and
- *        acceptance is the common case, so "every block is a reflection trial" is a good guess.
- * Each round the engine computes K consecutive blocks as reflection trials against one snapshot
- * of the population (plus, for each, the mutation that would follow its rejection), and this file
- * then replays the reference's accept/reject chain over the results *in block order*: a
- * speculative trial is used only if nothing it read has changed since the snapshot —
- *   (a) its block still has the reflection role,
- *   (b) the best row is still the same row,
- *   (c) none of the rows it sampled was overwritten by an earlier commit of the same round.
- * Since every commit overwrites the then-worst row, the rows overwritten so far always form a
- * prefix of the round's initial worst-first list W; (c) is therefore one integer compare against
- * the smallest W-rank the trial touched (computed on the device).  The first unusable slot ends
- * the round; the next round starts at that block.  The result is the reference's exact sequence
- * of (candidate, accept/reject, replaced row), including its quirks: maxeval is only tested
- * after a rejection (:136-137), ftol compares successive bests (:256), ties in f break by row
- * index (:51-56, here in key_less), and a reached tolerance is overridden by MAXEVAL (:263-268).
+ * trial.  To feed a GPU we exploit:
+ *   (i)   every reflection trial and every mutation consumes exactly one 2n-word block of the MT
+ *         stream, so the random content of block m is known before its role is;
+ *   (ii)  a block is a mutation iff the previous block was a rejected reflection (:129-151), and
+ *         acceptance is the common case, so "every block is a reflection trial" is a good guess;
+ *   (iii) a trial's gather-sum visits its n rows in ascending row order, and between "now" and the
+ *         trial's own turn the only rows that can change are the ones the intervening blocks may
+ *         commit to: each block commits at most once and every commit overwrites the then-worst
+ *         row, so after d more blocks the overwritten rows are a subset of the current d worst.
+ * The device keeps a window of K consecutive blocks in flight, each as a *resumable* gather-sum
+ * (picks summed so far + accumulator).  One pass (ops->advance) pushes every slot forward until
+ * its next pick is one of the rows in its hazard prefix W[0..d) — never across it — so no row is
+ * read before its content is final for that slot, no byte is read twice and no finished trial is
+ * ever thrown away because of a write hazard.  The front slot has d = 0 and always finishes.  This
+ * file then replays the reference's accept/reject chain over the finished slots at the window
+ * front *in block order*, until it meets an unfinished one; commits are written back and the next
+ * pass recomputes W from the updated order.  What is still discarded (and counted in the stats):
+ *   (a) a slot whose block turned out to be a mutation block (its predecessor was rejected),
+ *   (b) everything in flight when the best point changes (the sum starts from the best row).
+ * The result is the reference's exact sequence of (candidate, accept/reject, replaced row),
+ * including its quirks: maxeval is only tested after a rejection (:136-137), ftol compares
+ * successive bests (:256), ties in f break by row index (:51-56, here in key_less), and a reached
+ * tolerance is overridden by MAXEVAL (:263-268).
  */
 #include "nla_internal.h"
 #include <limits.h>
@@ -133,8 +138,9 @@ static void trace_add(const nla_crs_problem *pb, double f, int64_t row, int kind
 }
 
 /* crs_minimize's bookkeeping after an accepted replacement (crs.c:252-269).  The accepted point
- * sits in speculation slot `slot` (buffer `kind`); it has not been written to the population yet. */
-static int after_accept(run_state *rs, int slot, int kind)
+ * sits in the slot of stream block `block` (buffer `kind`); it has not been written to the
+ * population yet. */
+static int after_accept(run_state *rs, uint64_t block, int kind)
 {
     const nla_crs_problem *pb = rs->pb;
     nla_stopping *stop = pb->stop;
@@ -144,7 +150,7 @@ static int after_accept(run_state *rs, int slot, int kind)
         if (rs->F[b] < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
         else if (nla_stop_f(stop, rs->F[b], *rs->minf)) ret = NLOPT_FTOL_REACHED;
         else if (rs->need_x) {
-            if (rs->ops->read_slot(rs->e, slot, kind, rs->xtmp)) return -1;
+            if (rs->ops->read_slot(rs->e, block, kind, rs->xtmp)) return -1;
             if (nla_stop_x(stop, rs->xtmp, rs->x)) ret = NLOPT_XTOL_REACHED;
             memcpy(rs->x, rs->xtmp, sizeof(double) * (size_t) pb->n);
         }
@@ -159,15 +165,21 @@ static int after_accept(run_state *rs, int slot, int kind)
 }
 
 /* ---- resumable run: begin (= crs_init), advance (= rounds of the trial loop), end -------------- */
+#define TRING 2048                 /* host mirror of per-slot progress, indexed by block % TRING */
+
 struct nla_crs_session {
     run_state rs;
     nla_crs_problem pb;
     nlopt_result ret;
-    uint64_t block, init_words;
+    uint64_t block;                /* first stream block not yet consumed by the chain */
+    uint64_t fresh_from;           /* blocks >= this have no device state yet */
+    uint64_t init_words;
     int Kmax, host_eval;
     double runlen;
-    double *fT, *fM;
-    int32_t *minhz, *cslot, *ckind;
+    nla_crs_slot_status *status;
+    int32_t *tprev;                /* picks already summed, per in-flight block (stats only) */
+    uint64_t *cblock;
+    int32_t *ckind;
     int64_t *W, *crow;
 };
 
@@ -175,7 +187,7 @@ static void session_free(nla_crs_session *S)
 {
     if (!S) return;
     free(S->rs.F); free(S->rs.os.heap); free(S->rs.os.cand); free(S->rs.xtmp);
-    free(S->fT); free(S->fM); free(S->minhz); free(S->W); free(S->cslot); free(S->ckind); free(S->crow);
+    free(S->status); free(S->tprev); free(S->W); free(S->cblock); free(S->ckind); free(S->crow);
     free(S);
 }
 
@@ -204,7 +216,7 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     rs = &S->rs;
     S->pb = *pb;
     S->host_eval = pb->obj < 0;
-    S->Kmax = pb->max_spec > 0 ? pb->max_spec : 1024;
+    S->Kmax = pb->max_spec > 0 ? pb->max_spec : 256;
     if (S->Kmax > 1024) S->Kmax = 1024;
     if (S->host_eval) S->Kmax = 1;
     S->runlen = 4.0;
@@ -215,14 +227,13 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     rs->os.heap = (int64_t *) malloc(sizeof(int64_t) * (size_t) N);
     rs->os.cand = (int64_t *) malloc(sizeof(int64_t) * (size_t) (2 * S->Kmax + 8));
     rs->xtmp = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
-    S->fT = (double *) malloc(sizeof(double) * (size_t) S->Kmax);
-    S->fM = (double *) malloc(sizeof(double) * (size_t) S->Kmax);
-    S->minhz = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
+    S->status = (nla_crs_slot_status *) malloc(sizeof(nla_crs_slot_status) * (size_t) S->Kmax);
+    S->tprev = (int32_t *) calloc(TRING, sizeof(int32_t));
     S->W = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
-    S->cslot = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
+    S->cblock = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) S->Kmax);
     S->ckind = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
     S->crow = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
-    if (!rs->F || !rs->os.heap || !rs->os.cand || !rs->xtmp || !S->fT || !S->fM || !S->minhz || !S->W || !S->cslot ||
+    if (!rs->F || !rs->os.heap || !rs->os.cand || !rs->xtmp || !S->status || !S->tprev || !S->W || !S->cblock ||
         !S->ckind || !S->crow) {
         session_free(S);
         *ret_out = NLOPT_OUT_OF_MEMORY;
@@ -259,9 +270,9 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     return S;
 }
 
-/* Run rounds of the trial loop (crs.c:250-270) until the algorithm stops or at least
- * `eval_budget` more evaluations have been made (<= 0: no budget).  Pausing between rounds does
- * not change the sequence: a round boundary is only a speculation boundary. */
+/* Run passes of the trial loop (crs.c:250-270) until the algorithm stops or at least
+ * `eval_budget` more evaluations have been made (<= 0: no budget).  Pausing between passes does
+ * not change the sequence: the in-flight slots simply stay in flight. */
 nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
 {
     run_state *rs = &S->rs;
@@ -272,41 +283,60 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
     nlopt_amd_stats *st = pb->stats;
     const int n = pb->n, host_eval = S->host_eval;
     const int64_t N = pb->N;
-    double *fT = S->fT, *fM = S->fM;
-    int32_t *minhz = S->minhz, *cslot = S->cslot, *ckind = S->ckind;
+    nla_crs_slot_status *status = S->status;
+    uint64_t *cblock = S->cblock;
+    int32_t *ckind = S->ckind;
     int64_t *W = S->W, *crow = S->crow;
     nlopt_result ret = S->ret;
     const int evals_at_entry = *stop->nevals_p;
     double t0 = nla_seconds();
 
     while (ret == NLOPT_SUCCESS) {
-        int K, nW, j = 0, c = 0, ncommit = 0, best_changed = 0, cap;
+        int K, nW, j = 0, ncommit = 0, best_changed = 0, cap, a;
+        uint64_t wend;
         if (eval_budget > 0 && (int64_t) (*stop->nevals_p - evals_at_entry) >= eval_budget) break;
         cap = ops->max_slots(e, S->block);
         if (cap <= 0) { engine_failed(S); return S->ret; }
-        K = (int) ceil(1.25 * S->runlen) + 1;
+        K = (int) ceil(3.0 * S->runlen) + 4;
         if (K > S->Kmax) K = S->Kmax;
         if (K > cap) K = cap;
         if (K < 1) K = 1;
+        /* never shrink the window below what is already in flight (their state would be lost) */
+        if (S->fresh_from > S->block && (uint64_t) K < S->fresh_from - S->block && S->fresh_from - S->block <= (uint64_t) cap &&
+            S->fresh_from - S->block <= (uint64_t) S->Kmax)
+            K = (int) (S->fresh_from - S->block);
         nW = K < N ? K : (int) N;
         nW = os_topk(&rs->os, nW, W);
-        if (ops->speculate(e, S->block, K, rs->os.best, W, nW, fT, fM, minhz)) { engine_failed(S); return S->ret; }
-        if (st) { ++st->rounds; st->slots_launched += (uint64_t) K; }
+        if (ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status)) { engine_failed(S); return S->ret; }
+        wend = S->block + (uint64_t) K;
+        if (st) {
+            ++st->rounds;
+            for (a = 0; a < K; ++a) {          /* algorithmic bytes this pass moved: 8n per row summed */
+                const uint64_t b = S->block + (uint64_t) a;
+                const int32_t told = b >= S->fresh_from ? 0 : S->tprev[b % TRING];
+                const int32_t tnew = status[a].t;
+                if (b >= S->fresh_from) ++st->slots_launched;
+                if (tnew > told) st->gather_bytes += 8ULL * (uint64_t) n * (uint64_t) (tnew - told + (told == 0 ? 1 : 0));
+                S->tprev[b % TRING] = tnew;
+            }
+        }
+        if (wend > S->fresh_from) S->fresh_from = wend;
 
         while (j < K && ret == NLOPT_SUCCESS) {
             int64_t worst;
             int kind = 1, accepted = 0;
             double fcand;
-            if (best_changed) { if (st) st->slots_newbest += (uint64_t) (K - j); break; }
-            if (minhz[j] < c) { if (st) ++st->slots_invalid; break; }
+            const uint64_t blk = S->block + (uint64_t) j;
+            if (best_changed) break;
+            if (status[j].t < n) break;             /* not finished yet: next pass */
             if (st) ++st->slots_used;
             worst = rs->os.heap[0];
-            /* reflection trial of block+j */
+            /* reflection trial of block blk */
             if (host_eval) {
-                if (ops->read_slot(e, j, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
-                fT[j] = pb->f((unsigned) n, rs->xtmp, NULL, pb->f_data);
+                if (ops->read_slot(e, blk, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
+                status[j].fT = pb->f((unsigned) n, rs->xtmp, NULL, pb->f_data);
             }
-            fcand = fT[j];
+            fcand = status[j].fT;
             ++*stop->nevals_p;
             if (st) ++st->evals_trial;
             if (nla_stop_forced(stop)) { trace_add(pb, fcand, -1, 1, 0); ret = NLOPT_FORCED_STOP; ++j; break; }
@@ -315,16 +345,15 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 trace_add(pb, fcand, -1, 1, 0);
                 if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; ++j; break; }   /* only after a rejection */
                 if (nla_stop_time(stop)) { ret = NLOPT_MAXTIME_REACHED; ++j; break; }
-                /* local mutation: consumes block+j+1 (crs.c:139-146) */
+                /* local mutation: consumes block blk+1 (crs.c:139-146) */
                 kind = 2;
                 if (host_eval) {
-                    if (ops->mutate_slot(e, j, S->block + (uint64_t) j + 1, rs->os.best) ||
-                        ops->read_slot(e, j, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
-                    fM[j] = pb->f((unsigned) n, rs->xtmp, NULL, pb->f_data);
+                    if (ops->mutate_slot(e, blk, rs->os.best) || ops->read_slot(e, blk, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
+                    status[j].fM = pb->f((unsigned) n, rs->xtmp, NULL, pb->f_data);
                 }
-                fcand = fM[j];
+                fcand = status[j].fM;
                 ++*stop->nevals_p;
-                if (st) { ++st->evals_mutation; if (j + 1 < K) ++st->slots_role; }
+                if (st) { ++st->evals_mutation; if (blk + 1 < S->fresh_from) ++st->slots_role; }
                 if (nla_stop_forced(stop)) { trace_add(pb, fcand, -1, 2, 0); ret = NLOPT_FORCED_STOP; j += 2; break; }
                 if (fcand < rs->F[worst]) accepted = 1;
                 else {
@@ -335,33 +364,38 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             }
             if (accepted) {
                 /* memcpy(worst->k, d->p) + resort (crs.c:153-154); the row write is deferred */
-                if (c < nW && W[c] == worst) ++c;            /* else: a row of the prefix, again */
                 rs->F[worst] = fcand;
                 os_top_changed(&rs->os);
                 trace_add(pb, fcand, worst, kind, 1);
                 if (st) ++st->accepted;
-                cslot[ncommit] = j; ckind[ncommit] = host_eval ? 1 : kind; crow[ncommit] = worst; ++ncommit;
+                cblock[ncommit] = blk; ckind[ncommit] = host_eval ? 1 : kind; crow[ncommit] = worst; ++ncommit;
                 if (key_less(rs->F, worst, rs->os.best)) { rs->os.best = worst; best_changed = 1; }
-                if (after_accept(rs, j, host_eval ? 1 : kind)) { engine_failed(S); return S->ret; }
+                if (after_accept(rs, blk, host_eval ? 1 : kind)) { engine_failed(S); return S->ret; }
                 ret = rs->ret;
             }
             j += (kind == 2) ? 2 : 1;
         }
         S->block += (uint64_t) j;
-        {   /* adapt the speculation depth to the observed usable run length */
+        if (best_changed) {
+            /* every slot in flight started from the old best row: forget them all */
+            if (st && S->fresh_from > S->block) st->slots_newbest += S->fresh_from - S->block;
+            S->fresh_from = S->block;
+        }
+        if (S->fresh_from < S->block) S->fresh_from = S->block;   /* a mutation consumed the block past the window */
+        {   /* adapt the window to the observed number of blocks consumed per pass */
             double obs = (j >= K) ? 2.0 * K : (double) j;
             S->runlen = 0.7 * S->runlen + 0.3 * obs;
             if (S->runlen < 1.0) S->runlen = 1.0;
         }
         if (ncommit > 0) {
-            /* a row replaced twice in one round keeps only its last content */
+            /* a row replaced twice in one pass keeps only its last content */
             int k, m = 0;
             for (k = 0; k < ncommit; ++k) {
                 int later = 0, q;
                 for (q = k + 1; q < ncommit; ++q) if (crow[q] == crow[k]) { later = 1; break; }
-                if (!later) { cslot[m] = cslot[k]; ckind[m] = ckind[k]; crow[m] = crow[k]; ++m; }
+                if (!later) { cblock[m] = cblock[k]; ckind[m] = ckind[k]; crow[m] = crow[k]; ++m; }
             }
-            if (ops->commit(e, m, cslot, ckind, crow)) { engine_failed(S); return S->ret; }
+            if (ops->commit(e, m, cblock, ckind, crow)) { engine_failed(S); return S->ret; }
         }
     }
     if (st) st->t_trial_s += nla_seconds() - t0;

@@ -2,13 +2,16 @@
  * sequencing.  Plain C over the C-ABI launchers of include/nlopt_amd.h (no HIP types here).
  *
  * Memory (all HBM, sized for one MI355X; N=1e5, n=4096 is 3.3 GB, N=1e6 33 GB of 288 GB):
- *   X        N x ld fp64 population                 (the reference's ps matrix without the f column)
- *   batch[2] stream blocks pre-digested ahead of use: words (B+1 blocks x 2n u32),
- *            jn/last (B i32), pos (B x n i32)        — double-buffered, filled on the rng stream
- *   TX, TM   Kcap x ld fp64 speculative trial / mutation points, fT/fM/minhz their results
- * Streams: `main` runs gather -> post -> D2H -> commit each round; `rng` runs the MT generator,
- * the GF(2) jumps and the Vitter kernel for the *next* batch of blocks concurrently (VALU-bound
- * work hiding under the HBM-bound gather); an event per batch orders main after rng.
+ *   X          N x ld fp64 population              (the reference's ps matrix without the f column)
+ *   block ring 2B stream blocks pre-digested ahead of use, block b at entry b % 2B:
+ *              words (2n u32), jn/last (i32), pos (n i32); filled one half (= one batch of B
+ *              blocks) at a time on the rng stream
+ *   slot ring  KCAP slots, block b at slot b & (KCAP-1): TX (partial sum, then the finished trial
+ *              point), TM (its mutation), fT/fM
+ * Streams: `main` runs upload -> advance -> finish -> status D2H -> (host walk) -> commit each
+ * pass; `rng` runs the MT generator, the GF(2) jumps and the Vitter kernel for the *next* batch of
+ * blocks concurrently (VALU-bound work hiding under the HBM-bound gather); an event per batch
+ * orders main after rng.
  */
 #include "nla_internal.h"
 #include <stdio.h>
@@ -16,35 +19,38 @@
 #include <string.h>
 
 #define INIT_CHUNK_WORDS (1ULL << 28)      /* 1 GiB of stream words per init pass */
-#define KCAP 1024
+#define KCAP 1024                          /* slot ring (power of two) */
 
 typedef struct {
     int64_t index;                 /* batch number (blocks [index*B, (index+1)*B)), -1 = empty */
-    uint32_t *d_words;             /* (B+1) * 2n */
-    int32_t *d_jn, *d_pos, *d_last;
     void *ev_ready;
     int waited;                    /* main stream already ordered after ev_ready */
 } crs_batch;
 
+typedef struct { int64_t W[KCAP]; int32_t t_in[KCAP]; } crs_upload;   /* one H2D per pass */
+
 struct nla_crs_hip_engine {
     int n, ld, obj;
     int64_t N;
-    int B;                         /* blocks per batch */
+    int B;                         /* blocks per batch; the block ring holds 2B */
+    int variant;                   /* advance-kernel tiling override (0 = automatic) */
     void *main, *rng;
     nla_mtstream *mts;
     double *d_lb, *d_ub, *d_X, *d_F;
     uint32_t *d_initwords; size_t initwords_cap;
     crs_batch bat[2];
+    uint32_t *d_words;             /* 2B x 2n */
+    int32_t *d_jn, *d_pos, *d_last;
     double *d_TX, *d_TM, *d_fT, *d_fM;
-    int32_t *d_minhz, *d_cslot, *d_ckind;
-    int64_t *d_W, *d_crow;
-    /* pinned staging */
-    double *h_f;                   /* fT[KCAP] | fM[KCAP] */
-    int32_t *h_minhz, *h_cslot, *h_ckind;
-    int64_t *h_W, *h_crow;
+    crs_upload *d_up, *h_up;
+    int32_t *d_tout, *d_cslot, *d_ckind;
+    nla_crs_slot_status *d_status, *h_status;
+    int64_t *d_crow;
+    int32_t h_t[KCAP];             /* picks summed so far, per slot (host-authoritative) */
+    int32_t *h_cslot, *h_ckind;
+    int64_t *h_crow;
     void *ev0, *ev1;
     nlopt_amd_stats *stats;
-    int lastK;
     char err[256];
 };
 
@@ -55,28 +61,31 @@ static uint64_t trial_word0(const nla_crs_hip_engine *e) { return 2ULL * (uint64
 
 static int prepare_batch(nla_crs_hip_engine *e, crs_batch *b, int64_t index)
 {
+    const size_t half = (size_t) (index & 1) * (size_t) e->B;
     const uint64_t w0 = trial_word0(e) + 2ULL * (uint64_t) e->n * (uint64_t) index * (uint64_t) e->B;
+    uint32_t *words = e->d_words + half * 2 * (size_t) e->n;
     b->index = index;
     b->waited = 0;
-    if (nla_mtstream_fill(e->mts, w0, 2ULL * (uint64_t) e->n * (uint64_t) (e->B + 1), b->d_words))
+    if (nla_mtstream_fill(e->mts, w0, 2ULL * (uint64_t) e->n * (uint64_t) e->B, words))
         FAIL(e, "MT stream fill failed for batch %lld", (long long) index);
-    CK(e, nla_k_crs_vitter(e->n, e->N, b->d_words, e->B, b->d_jn, b->d_pos, b->d_last, e->rng));
+    CK(e, nla_k_crs_vitter(e->n, e->N, words, e->B, e->d_jn + half, e->d_pos + half * (size_t) e->n, e->d_last + half, e->rng));
     CK(e, nla_event_record(b->ev_ready, e->rng));
     return 0;
 }
 
-static crs_batch *batch_for(nla_crs_hip_engine *e, uint64_t block)
+/* make the batches holding blocks [first, last] usable on the main stream (last < first + 2B - B
+ * is guaranteed by op_max_slots: a window never reaches past the batch after first's) */
+static int ensure_blocks(nla_crs_hip_engine *e, uint64_t first, uint64_t last)
 {
-    const int64_t index = (int64_t) (block / (uint64_t) e->B);
-    crs_batch *cur = &e->bat[index & 1], *nxt = &e->bat[(index + 1) & 1];
-    if (cur->index != index && prepare_batch(e, cur, index)) return NULL;
-    /* prefetch the following batch: everything that used the other buffer has been synchronised */
-    if (nxt->index != index + 1 && prepare_batch(e, nxt, index + 1)) return NULL;
-    if (!cur->waited) {
-        if (nla_stream_wait_event(e->main, cur->ev_ready)) return NULL;
-        cur->waited = 1;
-    }
-    return cur;
+    const int64_t i0 = (int64_t) (first / (uint64_t) e->B), i1 = (int64_t) (last / (uint64_t) e->B);
+    crs_batch *cur = &e->bat[i0 & 1], *nxt = &e->bat[(i0 + 1) & 1];
+    if (i1 > i0 + 1) FAIL(e, "window reaches past the prepared batches");
+    /* everything that used the half being overwritten has been consumed: blocks < first are done */
+    if (cur->index != i0 && prepare_batch(e, cur, i0)) return -1;
+    if (nxt->index != i0 + 1 && prepare_batch(e, nxt, i0 + 1)) return -1;
+    if (!cur->waited) { CK(e, nla_stream_wait_event(e->main, cur->ev_ready)); cur->waited = 1; }
+    if (i1 > i0 && !nxt->waited) { CK(e, nla_stream_wait_event(e->main, nxt->ev_ready)); nxt->waited = 1; }
+    return 0;
 }
 
 void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
@@ -85,16 +94,14 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     if (e->main) nla_stream_sync(e->main);
     if (e->rng) nla_stream_sync(e->rng);
     if (e->mts) { nla_mtstream_finish(e->mts, words_used); nla_mtstream_destroy(e->mts); }
-    for (int i = 0; i < 2; ++i) {
-        nla_dev_free(e->bat[i].d_words); nla_dev_free(e->bat[i].d_jn); nla_dev_free(e->bat[i].d_pos);
-        nla_dev_free(e->bat[i].d_last); nla_event_destroy(e->bat[i].ev_ready);
-    }
+    for (int i = 0; i < 2; ++i) nla_event_destroy(e->bat[i].ev_ready);
+    nla_dev_free(e->d_words); nla_dev_free(e->d_jn); nla_dev_free(e->d_pos); nla_dev_free(e->d_last);
     nla_dev_free(e->d_lb); nla_dev_free(e->d_ub); nla_dev_free(e->d_X); nla_dev_free(e->d_F);
     nla_dev_free(e->d_initwords);
     nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
-    nla_dev_free(e->d_minhz); nla_dev_free(e->d_cslot); nla_dev_free(e->d_ckind); nla_dev_free(e->d_W); nla_dev_free(e->d_crow);
-    nla_host_free(e->h_f); nla_host_free(e->h_minhz); nla_host_free(e->h_cslot); nla_host_free(e->h_ckind);
-    nla_host_free(e->h_W); nla_host_free(e->h_crow);
+    nla_dev_free(e->d_up); nla_dev_free(e->d_tout); nla_dev_free(e->d_status);
+    nla_dev_free(e->d_cslot); nla_dev_free(e->d_ckind); nla_dev_free(e->d_crow);
+    nla_host_free(e->h_up); nla_host_free(e->h_status); nla_host_free(e->h_cslot); nla_host_free(e->h_ckind); nla_host_free(e->h_crow);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
     nla_stream_destroy(e->main); nla_stream_destroy(e->rng);
     free(e);
@@ -114,7 +121,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->bat[0].index = e->bat[1].index = -1;
     B = (size_t) ((1ULL << 25) / (2ULL * (uint64_t) n));
     if (B > 65536) B = 65536;
-    if (B < 1024) B = 1024;
+    if (B < 2 * KCAP) B = 2 * KCAP;
     e->B = (int) B;
     e->main = nla_stream_create();
     e->rng = nla_stream_create();
@@ -125,34 +132,34 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld);
     e->d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * (size_t) N);
     e->d_F = (double *) nla_dev_malloc(sizeof(double) * (size_t) N);
+    e->d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * 2 * B);
+    e->d_jn = (int32_t *) nla_dev_malloc(sizeof(int32_t) * 2 * B);
+    e->d_last = (int32_t *) nla_dev_malloc(sizeof(int32_t) * 2 * B);
+    e->d_pos = (int32_t *) nla_dev_malloc(sizeof(int32_t) * 2 * B * (size_t) n);
     for (int i = 0; i < 2; ++i) {
-        e->bat[i].d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (B + 1));
-        e->bat[i].d_jn = (int32_t *) nla_dev_malloc(sizeof(int32_t) * B);
-        e->bat[i].d_last = (int32_t *) nla_dev_malloc(sizeof(int32_t) * B);
-        e->bat[i].d_pos = (int32_t *) nla_dev_malloc(sizeof(int32_t) * B * (size_t) n);
         e->bat[i].ev_ready = nla_event_create();
-        if (!e->bat[i].d_words || !e->bat[i].d_jn || !e->bat[i].d_last || !e->bat[i].d_pos || !e->bat[i].ev_ready) goto fail;
+        if (!e->bat[i].ev_ready) goto fail;
     }
     e->d_TX = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_TM = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_fT = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP);
     e->d_fM = e->d_fT ? e->d_fT + KCAP : NULL;
-    e->d_minhz = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
+    e->d_up = (crs_upload *) nla_dev_malloc(sizeof(crs_upload));
+    e->d_tout = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
+    e->d_status = (nla_crs_slot_status *) nla_dev_malloc(sizeof(nla_crs_slot_status) * KCAP);
     e->d_cslot = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
     e->d_ckind = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
-    e->d_W = (int64_t *) nla_dev_malloc(sizeof(int64_t) * KCAP);
     e->d_crow = (int64_t *) nla_dev_malloc(sizeof(int64_t) * KCAP);
-    e->h_f = (double *) nla_host_malloc(sizeof(double) * 2 * KCAP);
-    e->h_minhz = (int32_t *) nla_host_malloc(sizeof(int32_t) * KCAP);
+    e->h_up = (crs_upload *) nla_host_malloc(sizeof(crs_upload));
+    e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * KCAP);
     e->h_cslot = (int32_t *) nla_host_malloc(sizeof(int32_t) * KCAP);
     e->h_ckind = (int32_t *) nla_host_malloc(sizeof(int32_t) * KCAP);
-    e->h_W = (int64_t *) nla_host_malloc(sizeof(int64_t) * KCAP);
     e->h_crow = (int64_t *) nla_host_malloc(sizeof(int64_t) * KCAP);
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
-    if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_TX || !e->d_TM || !e->d_fT || !e->d_minhz || !e->d_cslot ||
-        !e->d_ckind || !e->d_W || !e->d_crow || !e->h_f || !e->h_minhz || !e->h_cslot || !e->h_ckind || !e->h_W ||
-        !e->h_crow || !e->ev0 || !e->ev1) goto fail;
+    if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
+        !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->d_cslot || !e->d_ckind || !e->d_crow ||
+        !e->h_up || !e->h_status || !e->h_cslot || !e->h_ckind || !e->h_crow || !e->ev0 || !e->ev1) goto fail;
     if (nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
         nla_memcpy_h2d(e->d_ub, ub, sizeof(double) * (size_t) n, e->main) || nla_stream_sync(e->main)) goto fail;
     return e;
@@ -209,78 +216,72 @@ static int op_init_population(void *ve, const double *x0, double *F)
     }
     nla_dev_free(e->d_initwords); e->d_initwords = NULL; e->initwords_cap = 0;
     /* start digesting the first batch of trial blocks while the host builds its ordered set */
-    if (!batch_for(e, 0)) return -1;
+    if (ensure_blocks(e, 0, 0)) return -1;
     return 0;
 }
 
 static int op_max_slots(void *ve, uint64_t first_block)
 {
+    /* the window and the block after it (mutation words) must lie in first_block's batch or the next */
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const uint64_t B = (uint64_t) e->B;
-    uint64_t rem = B - first_block % B;
+    uint64_t rem = (first_block / B + 2) * B - 1 - first_block;
     return (int) (rem < KCAP ? rem : KCAP);
 }
 
-static int op_speculate(void *ve, uint64_t first_block, int K, int64_t i0, const int64_t *W, int nW,
-                        double *fT, double *fM, int32_t *minhz)
+static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
+                      nla_crs_slot_status *status)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const int n = e->n;
-    crs_batch *b = batch_for(e, first_block);
-    size_t off;
-    if (!b) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
-    if (K < 1 || K > KCAP || nW > KCAP) FAIL(e, "bad speculation size K=%d nW=%d", K, nW);
-    off = (size_t) (first_block - (uint64_t) b->index * (uint64_t) e->B);
-    if (off + (size_t) K > (size_t) e->B) FAIL(e, "speculation crosses a batch boundary");
-    memcpy(e->h_W, W, sizeof(int64_t) * (size_t) nW);
-    CK(e, nla_memcpy_h2d(e->d_W, e->h_W, sizeof(int64_t) * (size_t) nW, e->main));
+    const uint32_t ring = 2u * (uint32_t) e->B;
+    if (K < 1 || K > KCAP || nW > KCAP || nW < 0) FAIL(e, "bad window K=%d nW=%d", K, nW);
+    if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
+    if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
+    memcpy(e->h_up->W, W, sizeof(int64_t) * (size_t) nW);
+    for (int a = 0; a < K; ++a) {
+        const uint64_t b = first_block + (uint64_t) a;
+        e->h_up->t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
+    }
+    CK(e, nla_memcpy_h2d(e->d_up, e->h_up, sizeof(crs_upload), e->main));
     CK(e, nla_event_record(e->ev0, e->main));
-    CK(e, nla_k_crs_gather(n, e->ld, e->d_X, i0, b->d_jn + off, b->d_pos + off * (size_t) n, b->d_last + off, K,
-                           e->d_lb, e->d_ub, e->d_TX, e->main));
+    CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, e->d_up->W, nW,
+                            e->d_up->t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
     CK(e, nla_event_record(e->ev1, e->main));
-    CK(e, nla_k_crs_post(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, b->d_words + (off + 1) * 2 * (size_t) n, K,
-                         e->d_W, nW, b->d_pos + off * (size_t) n, b->d_last + off, e->d_lb, e->d_ub,
-                         e->d_fT, e->d_fM, e->d_minhz, e->main));
-    if (e->obj >= 0) {
-        CK(e, nla_memcpy_d2h(e->h_f, e->d_fT, sizeof(double) * (size_t) K, e->main));
-        CK(e, nla_memcpy_d2h(e->h_f + KCAP, e->d_fM, sizeof(double) * (size_t) K, e->main));
-    }
-    CK(e, nla_memcpy_d2h(e->h_minhz, e->d_minhz, sizeof(int32_t) * (size_t) K, e->main));
+    CK(e, nla_k_crs_finish(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
+                           e->d_up->t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
+    CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * (size_t) K, e->main));
     CK(e, nla_stream_sync(e->main));
-    if (e->obj >= 0) {
-        memcpy(fT, e->h_f, sizeof(double) * (size_t) K);
-        memcpy(fM, e->h_f + KCAP, sizeof(double) * (size_t) K);
-    }
-    memcpy(minhz, e->h_minhz, sizeof(int32_t) * (size_t) K);
-    e->lastK = K;
+    memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
+    for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = status[a].t;
     if (e->stats) {
         float ms = nla_event_elapsed_ms(e->ev0, e->ev1);
         if (ms >= 0) e->stats->t_gather_ms += ms;
         e->stats->gather_launches += 1;
-        e->stats->gather_bytes += (uint64_t) K * 8ULL * (uint64_t) n * (uint64_t) (n + 1);
     }
     return 0;
 }
 
-static int op_commit(void *ve, int ncommit, const int32_t *slot, const int32_t *kind, const int64_t *row)
+static int op_commit(void *ve, int ncommit, const uint64_t *block, const int32_t *kind, const int64_t *row)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     if (ncommit <= 0) return 0;
     if (ncommit > KCAP) FAIL(e, "too many commits");
-    memcpy(e->h_cslot, slot, sizeof(int32_t) * (size_t) ncommit);
+    for (int c = 0; c < ncommit; ++c) e->h_cslot[c] = (int32_t) (block[c] & (KCAP - 1));
     memcpy(e->h_ckind, kind, sizeof(int32_t) * (size_t) ncommit);
     memcpy(e->h_crow, row, sizeof(int64_t) * (size_t) ncommit);
     CK(e, nla_memcpy_h2d(e->d_cslot, e->h_cslot, sizeof(int32_t) * (size_t) ncommit, e->main));
     CK(e, nla_memcpy_h2d(e->d_ckind, e->h_ckind, sizeof(int32_t) * (size_t) ncommit, e->main));
     CK(e, nla_memcpy_h2d(e->d_crow, e->h_crow, sizeof(int64_t) * (size_t) ncommit, e->main));
     CK(e, nla_k_crs_commit(e->n, e->ld, e->d_X, e->d_TX, e->d_TM, ncommit, e->d_cslot, e->d_ckind, e->d_crow, e->main));
+    /* no sync: the pinned staging arrays are next written after the following pass has synchronised */
     return 0;
 }
 
-static int op_read_slot(void *ve, int slot, int kind, double *x)
+static int op_read_slot(void *ve, uint64_t block, int kind, double *x)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
-    const double *src = (kind == 1 ? e->d_TX : e->d_TM) + (size_t) slot * (size_t) e->ld;
+    const double *src = (kind == 1 ? e->d_TX : e->d_TM) + (size_t) (block & (KCAP - 1)) * (size_t) e->ld;
     CK(e, nla_memcpy_d2h(x, src, sizeof(double) * (size_t) e->n, e->main));
     CK(e, nla_stream_sync(e->main));
     return 0;
@@ -294,23 +295,20 @@ static int op_read_row(void *ve, int64_t row, double *x)
     return 0;
 }
 
-static int op_mutate_slot(void *ve, int slot, uint64_t block, int64_t i0)
+static int op_mutate_slot(void *ve, uint64_t block, int64_t i0)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
-    /* `block` is at most one past the batch of the slot's own block: the batch holds B+1 blocks of words */
-    crs_batch *b = batch_for(e, block > 0 ? block - 1 : 0);
-    size_t off;
-    if (!b) return -1;
-    off = (size_t) (block - (uint64_t) b->index * (uint64_t) e->B);
-    CK(e, nla_k_crs_mutate(e->n, e->d_X + (size_t) i0 * (size_t) e->ld, e->d_TX + (size_t) slot * (size_t) e->ld,
-                           b->d_words + off * 2 * (size_t) e->n, e->d_lb, e->d_ub, e->main));
+    const uint32_t ring = 2u * (uint32_t) e->B;
+    if (ensure_blocks(e, block, block + 1)) return -1;
+    CK(e, nla_k_crs_mutate(e->n, e->d_X + (size_t) i0 * (size_t) e->ld, e->d_TX + (size_t) (block & (KCAP - 1)) * (size_t) e->ld,
+                           e->d_words + (size_t) ((block + 1) % ring) * 2 * (size_t) e->n, e->d_lb, e->d_ub, e->main));
     return 0;
 }
 
 static const char *op_last_error(void *ve) { return ((nla_crs_hip_engine *) ve)->err; }
 
 const nla_crs_engine_ops nla_crs_hip_ops = {
-    op_init_population, op_max_slots, op_speculate, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
+    op_init_population, op_max_slots, op_advance, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
 };
 
 static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,
@@ -340,6 +338,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
         return NLOPT_OUT_OF_MEMORY;
     }
+    if (opt) (*eout)->variant = (int) nlopt_get_param(opt, "amd_gather_variant", 0);
     return NLOPT_SUCCESS;
 }
 

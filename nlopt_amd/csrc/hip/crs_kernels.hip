@@ -104,11 +104,7 @@ __global__ __launch_bounds__(64) void crs_vitter_kernel(int n, int64_t N, const 
     last[b] = (int32_t) (w[2 * n - 1] % (uint32_t) Nleft);       /* nlopt_iurand(Nleft), crs.c:109 */
 }
 
-/* ------------------------------------------------------------------------------------------------
- * K4: the gather-sum.  grid = K slots x wps wavefronts; wavefront `chunk` of a slot owns
- * coordinates [chunk*64*VEC, (chunk+1)*64*VEC).  Row indices are wave-uniform (scalar loads);
- * U row segments are requested before the first is accumulated.
- * ---------------------------------------------------------------------------------------------- */
+/* vector width helpers for the gather-sum */
 template <int VEC> struct VecT;
 template <> struct VecT<1> { typedef double T; };
 template <> struct VecT<2> { typedef double2 T; };
@@ -118,132 +114,208 @@ __device__ __forceinline__ typename VecT<VEC>::T ldv(const double *p);
 template <> __device__ __forceinline__ double ldv<1>(const double *p) { return *p; }
 template <> __device__ __forceinline__ double2 ldv<2>(const double *p) { return *reinterpret_cast<const double2 *>(p); }
 
+__device__ __forceinline__ void add_row(double &a, double v) { a = a + v; }
+__device__ __forceinline__ void add_row(double2 &a, double2 v) { a.x = a.x + v.x; a.y = a.y + v.y; }
 __device__ __forceinline__ void acc_row(double &a, double v, double m) { a = a + v * m; }
 __device__ __forceinline__ void acc_row(double2 &a, double2 v, double m) { a.x = a.x + v.x * m; a.y = a.y + v.y * m; }
 
-template <int VEC, int U>
-__global__ __launch_bounds__(256) void crs_gather_kernel(int n, int ld, const double *__restrict__ X, int64_t i0,
-                                                          const int32_t *__restrict__ jn_arr, const int32_t *__restrict__ pos,
-                                                          const int32_t *__restrict__ last, int K, int wps,
-                                                          const double *__restrict__ lb, const double *__restrict__ ub,
-                                                          double *__restrict__ TX)
+/* ------------------------------------------------------------------------------------------------
+ * K4': resumable gather-sum ("advance").  The reference accumulates the n sampled rows of a trial
+ * in ascending row order into one accumulator per coordinate (crs.c:101-114); fp64 addition is
+ * not associative, so that order is the contract.  A slot (= one stream block speculated as a
+ * reflection trial) carries (t, acc): picks [0,t) are already summed into acc (kept in its TX
+ * row).  One pass advances every slot of the window from its t to
+ *     e = the first pick >= t whose row may still be overwritten before the slot's turn,
+ * i.e. a row among W[0..d), the d worst rows at the time of the pass, d = the slot's distance
+ * from the front of the window (each earlier block commits at most once, and every commit
+ * overwrites the then-worst row, so the rows overwritten before the slot's turn are a subset of
+ * that prefix).  Picks < e read rows whose content is already final for this slot, so no byte is
+ * read twice and nothing speculative is ever discarded because of a write hazard.
+ *
+ * grid = window slots x coordinate chunks; one workgroup of WAVES wavefronts per (slot, chunk).
+ * The per-coordinate chain is serial, the loads are not: the WAVES wavefronts take the batches of
+ * U rows round-robin, each keeps its next batch in flight (U x 16 B per lane) while the
+ * accumulator travels through LDS from wavefront to wavefront in batch order (one s_barrier per
+ * batch) — WAVES*U rows of one chunk are in flight instead of U.
+ * ---------------------------------------------------------------------------------------------- */
+/* LDS-only barrier: orders this wavefront's LDS traffic, leaves its global loads in flight
+ * (__syncthreads() carries a workgroup release fence that drains vmcnt). */
+__device__ __forceinline__ void nla_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define NLA_ADV_RCAP 8192               /* picks staged in LDS per segment (32 KB) */
+
+template <int VEC, int U, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
+    int n, int ld, const double *__restrict__ X, int64_t i0, const int32_t *__restrict__ jn_ring,
+    const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, uint32_t ring_blocks,
+    uint64_t first_block, const int64_t *__restrict__ W, int nW,
+    const int32_t *__restrict__ t_in, int32_t *__restrict__ t_out, int slot_mask, int chunks,
+    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX)
 {
     typedef typename VecT<VEC>::T V;
+    static_assert(U <= 64, "one lane per row of a batch");
+    __shared__ V sacc[64];
+    __shared__ int32_t srow[NLA_ADV_RCAP];
+    __shared__ int s_e;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
-    const int slot = wave / wps;
-    if (slot >= K) return;
-    const int chunk = wave - slot * wps;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int a = blockIdx.x / chunks, chunk = blockIdx.x - a * chunks;
+    const uint64_t block = first_block + (uint64_t) a;
+    const uint32_t rb = (uint32_t) (block % ring_blocks);
+    const int q = (int) (block & (uint64_t) slot_mask);
+    const int32_t *p = pos_ring + (size_t) rb * (size_t) n;
+    const int jn = jn_ring[rb];
+    const int t0 = t_in[a];
+    /* last pick: i += iurand(Nleft); i += i == i0  (crs.c:109) */
+    const int64_t rbase = p[n - 1];
+    int64_t al = rbase + (rbase >= i0 ? 1 : 0) + (int64_t) last_ring[rb];
+    al += (al == i0) ? 1 : 0;
+
+    if (wave == 0) {                        /* plan: where must this slot stop in this pass? */
+        int e = n;
+        const int nun = a < nW ? a : nW;
+        for (int j = lane; j < nun; j += 64) {
+            const int64_t r = W[j];
+            if (r == i0) continue;          /* the best row is never sampled */
+            if (r == al) { e = e < n - 1 ? e : n - 1; continue; }
+            const int32_t rho = (int32_t) (r - (r > i0 ? 1 : 0));
+            int lo = t0, hi = n - 2;        /* binary search in the ascending picks not yet summed */
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const int32_t pv = p[mid];
+                if (pv == rho) { e = e < mid ? e : mid; break; }
+                if (pv < rho) lo = mid + 1; else hi = mid - 1;
+            }
+        }
+        e = nla_wave_min_i32(e);
+        if (e < t0) e = t0;
+        if (lane == 0) s_e = e;
+    }
+    __syncthreads();
+    const int e = s_e;
+    if (e == t0) {
+        if (chunk == 0 && threadIdx.x == 0) t_out[a] = t0;
+        return;
+    }
     const int col = (chunk * 64 + lane) * VEC;
     const bool active = col < n;
     const size_t colc = active ? (size_t) col : 0;
-    const int32_t *p = pos + (size_t) slot * (size_t) n;
-    const int jn = jn_arr[slot];
-    const double hneg = -(0.5 * n);      /* x -= xi*(0.5*n)  ==  x += xi*(-(0.5*n)), exactly */
     const double *Xc = X + colc;
+    double *accrow = TX + (size_t) q * (size_t) ld + colc;
+    if (wave == 0)                          /* x := best (crs.c:69), or resume */
+        sacc[lane] = (t0 == 0) ? ldv<VEC>(Xc + (size_t) i0 * (size_t) ld) : ldv<VEC>(accrow);
 
-    V acc = ldv<VEC>(Xc + (size_t) i0 * (size_t) ld);      /* x := best (crs.c:69) */
-
-    const int nmain = n - 1;             /* picks 0..n-2 come from pos[]; pick n-1 is the jump */
-    int t0 = 0;
-    for (; t0 + U <= nmain; t0 += U) {
-        V v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t r = p[t0 + u];
-            const int64_t a = r + (r >= i0 ? 1 : 0);        /* i += i == i0 skipping, crs.c:92,97,106 */
-            v[u] = ldv<VEC>(Xc + (size_t) a * (size_t) ld);
+    const double hneg = -(0.5 * n);         /* x -= xi*(0.5*n)  ==  x += xi*(-(0.5*n)), exactly */
+    const uint32_t lane_off = (uint32_t) (colc * sizeof(double));
+    V v[U];
+    for (int seg0 = t0; seg0 < e; seg0 += NLA_ADV_RCAP) {
+        const int cnt = (e - seg0 < NLA_ADV_RCAP) ? e - seg0 : NLA_ADV_RCAP;
+        nla_lds_barrier();                  /* the previous segment's row list is no longer needed */
+        for (int i = threadIdx.x; i < cnt; i += WAVES * 64) {   /* actual rows of picks seg0 .. seg0+cnt-1 */
+            const int t = seg0 + i;
+            int64_t r;
+            if (t < n - 1) { r = p[t]; r += (r >= i0 ? 1 : 0); } else r = al;
+            srow[i] = (int32_t) r;
         }
+        nla_lds_barrier();
+        const int nb = (cnt + U - 1) / U;
+        auto issue = [&](int b) {
+            const int base = b * U;
+            const int mine = base + lane < cnt ? base + lane : cnt - 1;
+            const int32_t myrow = srow[mine];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc_row(acc, v[u], (t0 + u == jn) ? hneg : 1.0);
+            for (int u = 0; u < U; ++u) {        /* unconditional: lanes past the end hold the last row */
+                const int64_t r = (int64_t) __builtin_amdgcn_readlane(myrow, u);
+                const char *rowp = reinterpret_cast<const char *>(X + (size_t) r * (size_t) ld);   /* wave-uniform */
+                v[u] = *reinterpret_cast<const V *>(rowp + lane_off);
+            }
+        };
+        if (wave < nb) issue(wave);
+        for (int ph = 0; ph < nb; ++ph) {
+            nla_lds_barrier();
+            if (ph % WAVES == wave) {
+                V acc = sacc[lane];
+                const int base = ph * U, tb = seg0 + base;
+                if (base + U <= cnt && !(jn >= tb && jn < tb + U)) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) add_row(acc, v[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (base + u < cnt) acc_row(acc, v[u], (tb + u == jn) ? hneg : 1.0);
+                }
+                sacc[lane] = acc;
+                if (ph + WAVES < nb) issue(ph + WAVES);
+            }
+        }
     }
-    for (; t0 < nmain; ++t0) {
-        const int64_t r = p[t0];
-        const int64_t a = r + (r >= i0 ? 1 : 0);
-        acc_row(acc, ldv<VEC>(Xc + (size_t) a * (size_t) ld), (t0 == jn) ? hneg : 1.0);
-    }
-    {   /* last pick: i += iurand(Nleft); i += i == i0  (crs.c:109) */
-        const int64_t rb = p[n - 1];
-        int64_t a = rb + (rb >= i0 ? 1 : 0) + (int64_t) last[slot];
-        a += (a == i0) ? 1 : 0;
-        acc_row(acc, ldv<VEC>(Xc + (size_t) a * (size_t) ld), (n - 1 == jn) ? hneg : 1.0);
-    }
-    if (active) {
-        const double s = 2.0 / n;        /* x[k] *= 2.0 / n, then clamp (crs.c:116-120) */
-        double *o = TX + (size_t) slot * (size_t) ld + col;
-        if constexpr (VEC == 1) {
-            double a0 = *reinterpret_cast<double *>(&acc);
-            o[0] = nla_clamp_box(a0 * s, lb[col], ub[col]);
+    nla_lds_barrier();
+    if (wave == 0 && active) {
+        V acc = sacc[lane];
+        if (e == n) {                       /* x[k] *= 2.0 / n, then clamp (crs.c:116-120) */
+            const double s = 2.0 / n;
+            if constexpr (VEC == 1) {
+                double a0 = *reinterpret_cast<double *>(&acc);
+                *accrow = nla_clamp_box(a0 * s, lb[col], ub[col]);
+            } else {
+                double2 a2 = *reinterpret_cast<double2 *>(&acc), r2;
+                r2.x = nla_clamp_box(a2.x * s, lb[col], ub[col]);
+                r2.y = nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]);
+                *reinterpret_cast<double2 *>(accrow) = r2;
+            }
         } else {
-            double2 a2 = *reinterpret_cast<double2 *>(&acc);
-            double2 r2;
-            r2.x = nla_clamp_box(a2.x * s, lb[col], ub[col]);
-            r2.y = nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]);
-            *reinterpret_cast<double2 *>(o) = r2;
+            *reinterpret_cast<V *>(accrow) = acc;
         }
     }
+    if (chunk == 0 && threadIdx.x == 0) t_out[a] = e;
 }
 
-/* ------------------------------------------------------------------------------------------------
- * post kernel: 3K single-wavefront tasks — [0,K) evaluate the trial, [K,2K) local mutation of the
- * trial (as if it will be rejected) + its evaluation, [2K,3K) hazard rank of the slot.
- * ---------------------------------------------------------------------------------------------- */
+/* finish kernel: for every slot of the window that became complete in this pass, f of the trial
+ * and the local mutation that would follow its rejection (crs.c:139-146; w from the NEXT stream
+ * block) with its f; for every slot, its status record for the host's in-order walk. */
 template <int OBJ>
-__global__ __launch_bounds__(64) void crs_post_kernel(int n, int ld, const double *__restrict__ X, int64_t i0,
-                                                       const double *__restrict__ TX, double *__restrict__ TM,
-                                                       const uint32_t *__restrict__ words_next, int K,
-                                                       const int64_t *__restrict__ W, int nW,
-                                                       const int32_t *__restrict__ pos, const int32_t *__restrict__ last,
-                                                       const double *__restrict__ lb, const double *__restrict__ ub,
-                                                       double *__restrict__ fT, double *__restrict__ fM,
-                                                       int32_t *__restrict__ minhz)
+__global__ __launch_bounds__(64) void crs_finish_kernel(
+    int n, int ld, const double *__restrict__ X, int64_t i0, const double *__restrict__ TX, double *__restrict__ TM,
+    const uint32_t *__restrict__ words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+    const int32_t *__restrict__ t_in, const int32_t *__restrict__ t_out, int slot_mask,
+    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ fT_ring,
+    double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status)
 {
     const int lane = threadIdx.x;
-    const int task = blockIdx.x / K, s = blockIdx.x - task * K;
+    const int task = blockIdx.x / K, a = blockIdx.x - task * K;
+    const uint64_t block = first_block + (uint64_t) a;
+    const int q = (int) (block & (uint64_t) slot_mask);
+    const int t1 = t_out[a];
+    const bool was_done = t_in[a] == n;
+    const bool newly = (t1 == n) && !was_done;
+    const double *x = TX + (size_t) q * (size_t) ld;
     if (task == 0) {
-        if (OBJ < 0) return;
-        const double *x = TX + (size_t) s * (size_t) ld;
-        double f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, [&](int i) { return x[i]; });
-        if (lane == 0) fT[s] = f;
-    } else if (task == 1) {
-        if (OBJ < 0) return;
-        const double *x = TX + (size_t) s * (size_t) ld;
-        const double *xb = X + (size_t) i0 * (size_t) ld;
-        const uint32_t *w = words_next + (size_t) s * 2 * (size_t) n;
-        double *m = TM + (size_t) s * (size_t) ld;
-        auto mut = [&](int i) {            /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
-            const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
-            const double wv = nla_urand_from(0., 1., ww.x, ww.y);
-            return nla_clamp_box(xb[i] * (1 + wv) - wv * x[i], lb[i], ub[i]);
-        };
-        for (int i = lane; i < n; i += 64) m[i] = mut(i);
-        double f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, mut);
-        if (lane == 0) fM[s] = f;
-    } else {
-        /* which of the rows that can be overwritten this round (W, worst first) did slot s read? */
-        const int32_t *p = pos + (size_t) s * (size_t) n;
-        const int64_t rb = p[n - 1];
-        int64_t al = rb + (rb >= i0 ? 1 : 0) + (int64_t) last[s];
-        al += (al == i0) ? 1 : 0;
-        int best = INT_MAX;
-        for (int r = lane; r < nW; r += 64) {
-            const int64_t a = W[r];
-            if (a == i0) continue;                       /* the best row is never sampled */
-            bool hit = (a == al);
-            if (!hit && n > 1) {
-                const int32_t rho = (int32_t) (a - (a > i0 ? 1 : 0));
-                int lo = 0, hi = n - 2;                  /* binary search in the ascending picks */
-                while (lo <= hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const int32_t pv = p[mid];
-                    if (pv == rho) { hit = true; break; }
-                    if (pv < rho) lo = mid + 1; else hi = mid - 1;
-                }
-            }
-            if (hit && r < best) best = r;
+        double f = 0;
+        if (OBJ >= 0) {
+            if (newly) {
+                f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, [&](int i) { return x[i]; });
+                if (lane == 0) fT_ring[q] = f;
+            } else if (t1 == n) f = fT_ring[q];
         }
-        best = nla_wave_min_i32(best);
-        if (lane == 0) minhz[s] = best;
+        if (lane == 0) { status[a].fT = f; status[a].t = t1; }
+    } else {
+        double f = 0;
+        if (OBJ >= 0) {
+            if (newly) {
+                const double *xb = X + (size_t) i0 * (size_t) ld;
+                const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n;
+                double *m = TM + (size_t) q * (size_t) ld;
+                auto mut = [&](int i) {        /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
+                    const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
+                    const double wv = nla_urand_from(0., 1., ww.x, ww.y);
+                    return nla_clamp_box(xb[i] * (1 + wv) - wv * x[i], lb[i], ub[i]);
+                };
+                for (int i = lane; i < n; i += 64) m[i] = mut(i);
+                f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, mut);
+                if (lane == 0) fM_ring[q] = f;
+            } else if (t1 == n) f = fM_ring[q];
+        }
+        if (lane == 0) status[a].fM = f;
     }
 }
 
@@ -311,48 +383,6 @@ extern "C" int nla_k_crs_vitter(int n, int64_t N, const uint32_t *words, int nbl
     return 0;
 }
 
-extern "C" int nla_k_crs_gather(int n, int ld, const double *X, int64_t i0, const int32_t *jn, const int32_t *pos,
-                                const int32_t *last, int K, const double *lb, const double *ub, double *TX, void *stream)
-{
-    if (K <= 0) return 0;
-    hipStream_t st = (hipStream_t) stream;
-    const bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
-    const int cpw = vec2 ? 128 : 64;                        /* coordinates per wavefront */
-    const int wps = (n + cpw - 1) / cpw;
-    const long waves = (long) wps * K;
-    const dim3 grid((unsigned) ((waves + 3) / 4)), block(256);
-    /* few wavefronts in flight => deeper per-lane load pipelines */
-    if (vec2) {
-        if (waves <= 2048)
-            hipLaunchKernelGGL((crs_gather_kernel<2, 32>), grid, block, 0, st, n, ld, X, i0, jn, pos, last, K, wps, lb, ub, TX);
-        else
-            hipLaunchKernelGGL((crs_gather_kernel<2, 16>), grid, block, 0, st, n, ld, X, i0, jn, pos, last, K, wps, lb, ub, TX);
-    } else {
-        hipLaunchKernelGGL((crs_gather_kernel<1, 16>), grid, block, 0, st, n, ld, X, i0, jn, pos, last, K, wps, lb, ub, TX);
-    }
-    NLA_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int nla_k_crs_post(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
-                              const uint32_t *words_next, int K, const int64_t *W, int nW,
-                              const int32_t *pos, const int32_t *last, const double *lb, const double *ub,
-                              double *fT, double *fM, int32_t *minhz, void *stream)
-{
-    if (K <= 0) return 0;
-    const dim3 grid((unsigned) (3 * K)), block(64);
-    hipStream_t st = (hipStream_t) stream;
-    if (obj < 0) {
-        hipLaunchKernelGGL((crs_post_kernel<-1>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_next, K, W, nW, pos, last, lb, ub, fT, fM, minhz);
-    } else {
-#define CALL(O) hipLaunchKernelGGL((crs_post_kernel<O>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_next, K, W, nW, pos, last, lb, ub, fT, fM, minhz)
-        NLA_OBJ_DISPATCH(obj, CALL)
-#undef CALL
-    }
-    NLA_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
                                 const int32_t *slot, const int32_t *kind, const int64_t *row, void *stream)
 {
@@ -368,6 +398,71 @@ extern "C" int nla_k_crs_mutate(int n, const double *best, double *p, const uint
 {
     hipLaunchKernelGGL(crs_mutate_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
                        n, best, p, words, lb, ub);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+/* variant: 0 = automatic; otherwise WAVES*100 + U (tuning / microbenchmarks) */
+extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                                 const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                                 uint64_t first_block, int K, const int64_t *W, int nW,
+                                 const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                                 double *TX, int variant, void *stream)
+{
+    if (K <= 0) return 0;
+    hipStream_t st = (hipStream_t) stream;
+    const bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    const int cpw = vec2 ? 128 : 64;
+    const int chunks = (n + cpw - 1) / cpw;
+    const dim3 grid((unsigned) ((long) chunks * K));
+    if (variant == 0) variant = n >= 2048 ? 816 : (n >= 512 ? 416 : (n >= 128 ? 216 : 116));
+#define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, n, ld, X, i0, jn_ring, \
+        pos_ring, last_ring, ring_blocks, first_block, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX)
+    if (vec2) {
+        switch (variant) {
+        case 116: ADV(2, 16, 1); break;
+        case 132: ADV(2, 32, 1); break;
+        case 216: ADV(2, 16, 2); break;
+        case 416: ADV(2, 16, 4); break;
+        case 432: ADV(2, 32, 4); break;
+        case 816: ADV(2, 16, 8); break;
+        case 832: ADV(2, 32, 8); break;
+        case 1616: ADV(2, 16, 16); break;
+        case 1632: ADV(2, 32, 16); break;
+        default: return (int) hipErrorInvalidValue;
+        }
+    } else {
+        switch (variant) {
+        case 116: ADV(1, 16, 1); break;
+        case 216: ADV(1, 16, 2); break;
+        case 416: ADV(1, 16, 4); break;
+        case 832: ADV(1, 32, 8); break;
+        default: ADV(1, 16, 4); break;
+        }
+    }
+#undef ADV
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                                const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                                const int32_t *t_in, const int32_t *t_out, int slot_mask,
+                                const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                                nla_crs_slot_status *status, void *stream)
+{
+    if (K <= 0) return 0;
+    const dim3 grid((unsigned) (2 * K)), block(64);
+    hipStream_t st = (hipStream_t) stream;
+    if (obj < 0) {
+        hipLaunchKernelGGL((crs_finish_kernel<-1>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
+                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status);
+    } else {
+#define CALL(O) hipLaunchKernelGGL((crs_finish_kernel<O>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks, \
+                                   first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status)
+        NLA_OBJ_DISPATCH(obj, CALL)
+#undef CALL
+    }
     NLA_LAUNCH_CHECK();
     return 0;
 }

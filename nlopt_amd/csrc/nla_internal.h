@@ -122,23 +122,27 @@ int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed);
 
 /* ---- CRS engine interface (the device work the algorithm driver asks for) --------------------
  * The driver (crs_driver.c) owns the algorithm: ordered set, accept/reject chain, stopping.
- * The engine owns device memory and kernels.  `kind`: 1 = reflection trial, 2 = mutation. */
+ * The engine owns device memory and kernels.  A *slot* is one 2n-word stream block speculated as a
+ * reflection trial; it is named by its block index.  `kind`: 1 = reflection trial, 2 = mutation. */
 typedef struct {
     /* population rows 1..N-1 from the stream (2n words each), row 0 = x0; F[0..N-1] on the host.
      * obj < 0 (host-callback mode): rows generated but not evaluated. */
     int (*init_population)(void *e, const double *x0, double *F);
-    /* how many consecutive blocks starting at `first_block` can be speculated in one call */
+    /* how many consecutive blocks starting at `first_block` one window may hold */
     int (*max_slots)(void *e, uint64_t first_block);
-    /* speculate K reflection trials (stream blocks first_block .. +K-1) against the current
-     * population with best row i0; W[0..nW) = rows that may be overwritten this round, worst first.
-     * Out: fT[K], fM[K] (mutation of slot s uses block first_block+s+1), minhz[K]. */
-    int (*speculate)(void *e, uint64_t first_block, int K, int64_t i0, const int64_t *W, int nW,
-                     double *fT, double *fM, int32_t *minhz);
-    int (*commit)(void *e, int ncommit, const int32_t *slot, const int32_t *kind, const int64_t *row);
-    int (*read_slot)(void *e, int slot, int kind, double *x);
+    /* one pass over the window of K blocks first_block .. first_block+K-1 (see nla_k_crs_advance):
+     * blocks >= fresh_from have no state yet (start at pick 0); every slot advances its gather-sum
+     * to its first pick among W[0..d), d = its distance from the window front, W = the nW rows
+     * that may be overwritten next, worst first.  status[a] = (f of the finished trial, f of the
+     * mutation that would follow its rejection (w from block+1), picks summed so far). */
+    int (*advance)(void *e, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
+                   nla_crs_slot_status *status);
+    /* X[row[c]] := point of slot block[c] (kind[c]: 1 trial, 2 its mutation); rows distinct */
+    int (*commit)(void *e, int ncommit, const uint64_t *block, const int32_t *kind, const int64_t *row);
+    int (*read_slot)(void *e, uint64_t block, int kind, double *x);
     int (*read_row)(void *e, int64_t row, double *x);
-    /* host-callback mode: mutate slot's trial in place with block `block` (kind-1 buffer) */
-    int (*mutate_slot)(void *e, int slot, uint64_t block, int64_t i0);
+    /* host-callback mode: mutate the slot's finished trial in place with the words of block+1 */
+    int (*mutate_slot)(void *e, uint64_t block, int64_t i0);
     const char *(*last_error)(void *e);
 } nla_crs_engine_ops;
 

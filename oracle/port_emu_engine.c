@@ -1,6 +1,6 @@
 /* port_emu_engine.c — CPU ORACLE (test infrastructure): a CPU stand-in for the HIP engine, built
  * from the per-kernel statements of port_kernels.c, so that the product's *host-side* CRS logic
- * (nlopt_amd/csrc/crs_driver.c: ordered set, speculation validity, in-order commit, stopping
+ * (nlopt_amd/csrc/crs_driver.c: ordered set, window of resumable slots, in-order commit, stopping
  * quirks) can be tested against the oracle and the real reference on machines without a GPU.
  * Lives in oracle/libemu.so, which links the product library only to call nla_crs_run(); the
  * product never links or loads this file, and nlopt_optimize() has no path to it. */
@@ -17,14 +17,17 @@ void orc_k_vitter(int n, int64_t N, const uint32_t *words, int nblocks, int32_t 
 void orc_k_gather(int n, int ld, const double *X, int64_t i0, const int32_t *jn, const int32_t *pos, const int32_t *last,
                   int K, const double *lb, const double *ub, double *TX);
 void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *words, const double *lb, const double *ub, double *out);
-void orc_k_minhz(int n, int64_t i0, const int32_t *pos, const int32_t *last, int K, const int64_t *W, int nW, int32_t *minhz);
+int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
+                       const int64_t *W, int nun, int t0, const double *lb, const double *ub, double *acc);
+
+#define ECAP 1024                           /* slot ring, block b at slot b % ECAP */
 
 typedef struct {
     int n, ld, obj, cap; int64_t N;
     const double *lb, *ub;
-    double *X, *TX, *TM;
+    double *X, *TX, *TM, *fT, *fM;
     uint32_t *tw; uint64_t tw_blocks;       /* trial-phase words generated so far (blocks of 2n) */
-    int32_t *jn, *pos, *last;               /* of the last speculate */
+    int32_t *jn, *pos, *last, *t;           /* per ring slot */
     int max_slots;
 } emu;
 
@@ -49,35 +52,50 @@ static int emu_init(void *ve, const double *x0, double *F)
     return 0;
 }
 static int emu_max_slots(void *ve, uint64_t first_block) { (void) first_block; return ((emu *) ve)->max_slots; }
-static int emu_speculate(void *ve, uint64_t first, int K, int64_t i0, const int64_t *W, int nW, double *fT, double *fM, int32_t *minhz)
+static int emu_advance(void *ve, uint64_t first, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
+                       nla_crs_slot_status *status)
 {
     emu *e = (emu *) ve;
     const int n = e->n;
     if (K > e->cap) return -1;
     need_blocks(e, first + (uint64_t) K + 1);
-    orc_k_vitter(n, e->N, e->tw + first * 2 * (uint64_t) n, K, e->jn, e->pos, e->last);
-    orc_k_gather(n, e->ld, e->X, i0, e->jn, e->pos, e->last, K, e->lb, e->ub, e->TX);
-    orc_k_minhz(n, i0, e->pos, e->last, K, W, nW, minhz);
-    if (e->obj >= 0) {
-        orc_k_eval(e->obj, n, e->ld, e->TX, K, fT);
-        for (int s = 0; s < K; ++s)
-            orc_k_mutate(n, e->X + (size_t) i0 * e->ld, e->TX + (size_t) s * e->ld,
-                         e->tw + (first + (uint64_t) s + 1) * 2 * (uint64_t) n, e->lb, e->ub, e->TM + (size_t) s * e->ld);
-        orc_k_eval(e->obj, n, e->ld, e->TM, K, fM);
+    for (int a = 0; a < K; ++a) {
+        const uint64_t b = first + (uint64_t) a;
+        const int q = (int) (b % ECAP);
+        double *acc = e->TX + (size_t) q * e->ld;
+        int t0, t1;
+        if (b >= fresh_from) {          /* a block seen for the first time: digest its words (crs.c:72,89-109) */
+            orc_k_vitter(n, e->N, e->tw + b * 2 * (uint64_t) n, 1, e->jn + q, e->pos + (size_t) q * n, e->last + q);
+            e->t[q] = 0;
+        }
+        t0 = e->t[q];
+        t1 = orc_k_advance_slot(n, e->ld, e->X, i0, e->jn[q], e->pos + (size_t) q * n, e->last[q], W, a < nW ? a : nW, t0,
+                                e->lb, e->ub, acc);
+        e->t[q] = t1;
+        if (t1 == n && t0 < n && e->obj >= 0) {
+            double *m = e->TM + (size_t) q * e->ld;
+            orc_k_eval(e->obj, n, e->ld, acc, 1, e->fT + q);
+            orc_k_mutate(n, e->X + (size_t) i0 * e->ld, acc, e->tw + (b + 1) * 2 * (uint64_t) n, e->lb, e->ub, m);
+            orc_k_eval(e->obj, n, e->ld, m, 1, e->fM + q);
+        }
+        status[a].t = t1; status[a].pad = 0;
+        status[a].fT = t1 == n ? e->fT[q] : 0;
+        status[a].fM = t1 == n ? e->fM[q] : 0;
     }
     return 0;
 }
-static int emu_commit(void *ve, int nc, const int32_t *slot, const int32_t *kind, const int64_t *row)
+static int emu_commit(void *ve, int nc, const uint64_t *block, const int32_t *kind, const int64_t *row)
 {
     emu *e = (emu *) ve;
     for (int c = 0; c < nc; ++c)
-        memcpy(e->X + (size_t) row[c] * e->ld, (kind[c] == 1 ? e->TX : e->TM) + (size_t) slot[c] * e->ld, sizeof(double) * (size_t) e->n);
+        memcpy(e->X + (size_t) row[c] * e->ld, (kind[c] == 1 ? e->TX : e->TM) + (size_t) (block[c] % ECAP) * e->ld,
+               sizeof(double) * (size_t) e->n);
     return 0;
 }
-static int emu_read_slot(void *ve, int slot, int kind, double *x)
+static int emu_read_slot(void *ve, uint64_t block, int kind, double *x)
 {
     emu *e = (emu *) ve;
-    memcpy(x, (kind == 1 ? e->TX : e->TM) + (size_t) slot * e->ld, sizeof(double) * (size_t) e->n);
+    memcpy(x, (kind == 1 ? e->TX : e->TM) + (size_t) (block % ECAP) * e->ld, sizeof(double) * (size_t) e->n);
     return 0;
 }
 static int emu_read_row(void *ve, int64_t row, double *x)
@@ -86,17 +104,17 @@ static int emu_read_row(void *ve, int64_t row, double *x)
     memcpy(x, e->X + (size_t) row * e->ld, sizeof(double) * (size_t) e->n);
     return 0;
 }
-static int emu_mutate_slot(void *ve, int slot, uint64_t block, int64_t i0)
+static int emu_mutate_slot(void *ve, uint64_t block, int64_t i0)
 {
     emu *e = (emu *) ve;
-    double *p = e->TX + (size_t) slot * e->ld;
-    need_blocks(e, block + 1);
-    orc_k_mutate(e->n, e->X + (size_t) i0 * e->ld, p, e->tw + block * 2 * (uint64_t) e->n, e->lb, e->ub, p);
+    double *p = e->TX + (size_t) (block % ECAP) * e->ld;
+    need_blocks(e, block + 2);
+    orc_k_mutate(e->n, e->X + (size_t) i0 * e->ld, p, e->tw + (block + 1) * 2 * (uint64_t) e->n, e->lb, e->ub, p);
     return 0;
 }
 static const char *emu_err(void *ve) { (void) ve; return "emu"; }
 
-static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_speculate, emu_commit, emu_read_slot,
+static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_advance, emu_commit, emu_read_slot,
                                             emu_read_row, emu_mutate_slot, emu_err };
 
 /* Run the PRODUCT's CRS driver over the emulated engine.  RNG = the oracle generator (orc_srand
@@ -116,11 +134,14 @@ int orc_emu_crs(int obj, int n, long N, const double *lb, const double *ub, doub
     if (N == 0) N = 10 * ((long) n + 1);          /* crs.c:172-179, done by nla_crs_minimize in the product */
     if (N < n + 1) return -2;
     memset(&e, 0, sizeof e);
-    e.n = n; e.ld = (n + 1) & ~1; e.N = N; e.obj = host_eval ? -1 : obj; e.lb = lb; e.ub = ub; e.cap = 1024;
+    e.n = n; e.ld = (n + 1) & ~1; e.N = N; e.obj = host_eval ? -1 : obj; e.lb = lb; e.ub = ub; e.cap = ECAP;
     e.max_slots = max_slots > 0 ? max_slots : 1024;
     e.X = (double *) calloc((size_t) e.ld * (size_t) N, sizeof(double));
     e.TX = (double *) calloc((size_t) e.ld * (size_t) e.cap, sizeof(double));
     e.TM = (double *) calloc((size_t) e.ld * (size_t) e.cap, sizeof(double));
+    e.fT = (double *) calloc((size_t) e.cap, sizeof(double));
+    e.fM = (double *) calloc((size_t) e.cap, sizeof(double));
+    e.t = (int32_t *) calloc((size_t) e.cap, sizeof(int32_t));
     e.jn = (int32_t *) malloc(sizeof(int32_t) * (size_t) e.cap);
     e.last = (int32_t *) malloc(sizeof(int32_t) * (size_t) e.cap);
     e.pos = (int32_t *) malloc(sizeof(int32_t) * (size_t) e.cap * (size_t) n);
@@ -135,6 +156,6 @@ int orc_emu_crs(int obj, int n, long N, const double *lb, const double *ub, doub
     if (trace_len) *trace_len = 0;
     ret = (int) nla_crs_run(&emu_ops, &e, &pb, x, minf, &words);
     *nevals_out = nevals; *words_out = words;
-    free(e.X); free(e.TX); free(e.TM); free(e.jn); free(e.last); free(e.pos); free(e.tw); free(msg);
+    free(e.X); free(e.TX); free(e.TM); free(e.fT); free(e.fM); free(e.t); free(e.jn); free(e.last); free(e.pos); free(e.tw); free(msg);
     return ret;
 }

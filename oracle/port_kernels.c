@@ -100,15 +100,30 @@ void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *wo
     }
 }
 
-/* smallest rank r with W[r] among the rows slot s sampled (INT_MAX if none) */
-void orc_k_minhz(int n, int64_t i0, const int32_t *pos, const int32_t *last, int K, const int64_t *W, int nW, int32_t *minhz)
+/* resumable gather-sum for one slot (crs.c:69,101-120 in pieces): picks [t0, return value) are
+ * added to acc (n doubles; initialised from the best row when t0 == 0), stopping before the first
+ * pick >= t0 whose row is among W[0..nun); when the sum completes (returns n) acc is scaled by
+ * 2/n and clamped, i.e. becomes the trial point x. */
+int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
+                       const int64_t *W, int nun, int t0, const double *lb, const double *ub, double *acc)
 {
-    for (int s = 0; s < K; ++s) {
-        const int32_t *p = pos + (size_t) s * (size_t) n;
-        int best = INT_MAX;
-        for (int r = 0; r < nW && best == INT_MAX; ++r)
-            for (int t = 0; t < n; ++t)
-                if (pick_row(n, p, last[s], i0, t) == W[r]) { best = r; break; }
-        minhz[s] = best;
+    int e = n, t;
+    for (t = t0; t < n && e == n; ++t) {
+        const int64_t r = pick_row(n, pos, last, i0, t);
+        for (int j = 0; j < nun; ++j) if (W[j] == r) { e = t; break; }
     }
+    if (e == t0) return e;
+    if (t0 == 0) memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) n);
+    for (t = t0; t < e; ++t) {
+        const double *xi = X + (size_t) pick_row(n, pos, last, i0, t) * (size_t) ld;
+        if (t == jn) for (int k = 0; k < n; ++k) acc[k] -= xi[k] * (0.5 * n);
+        else         for (int k = 0; k < n; ++k) acc[k] += xi[k];
+    }
+    if (e == n)
+        for (int k = 0; k < n; ++k) {
+            acc[k] *= 2.0 / n;
+            if (acc[k] > ub[k]) acc[k] = ub[k];
+            else if (acc[k] < lb[k]) acc[k] = lb[k];
+        }
+    return e;
 }

@@ -131,64 +131,121 @@ def _spec_inputs(n, N, K, seed, obj):
     return ld, lb, ub, X, w, jn, pos, last
 
 
-@pytest.mark.parametrize("obj,n,N,K,i0", [("rastrigin", 10, 100, 7, 0), ("rastrigin", 10, 11, 5, 10), ("griewank", 64, 500, 33, 250),
-                                          ("ackley", 257, 600, 9, 599), ("levy", 128, 300, 4, 17), ("rosenbrock", 512, 2000, 6, 3),
-                                          ("griewank", 4096, 4200, 3, 4199), ("sphere", 1, 9, 8, 4)])
-def test_gather_and_post_kernels(L, obj, n, N, K, i0):
+class SlotStatus(C.Structure):
+    _fields_ = [("fT", C.c_double), ("fM", C.c_double), ("t", C.c_int32), ("pad", C.c_int32)]
+
+
+@pytest.mark.parametrize("obj,n,N,K,i0,variant", [("rastrigin", 10, 100, 7, 0, 0), ("rastrigin", 10, 11, 5, 10, 0),
+                                                  ("griewank", 64, 500, 33, 250, 0), ("ackley", 257, 600, 9, 599, 0),
+                                                  ("levy", 128, 300, 4, 17, 0), ("rosenbrock", 512, 2000, 6, 3, 0),
+                                                  ("griewank", 4096, 4200, 3, 4199, 0), ("sphere", 1, 9, 8, 4, 0),
+                                                  ("griewank", 2048, 3000, 5, 77, 832), ("griewank", 1024, 3000, 5, 77, 1616),
+                                                  ("ackley", 300, 700, 6, 5, 132), ("ackley", 9000, 9100, 2, 5, 416)])
+def test_advance_finish_commit_kernels(L, obj, n, N, K, i0, variant):
+    """the resumable gather-sum in two passes (first one stopped by a hazard list), evaluation and
+    mutation of the finished slots, and the commit: bit-exact x / partial sums / t, f within 1e-10"""
     P = O.port()
-    ld, lb, ub, X, w, jn, pos, last = _spec_inputs(n, N, K, 31 + n, obj)
+    ring = K + 1                      # block b at ring entry b % ring; the window starts at block `first`
+    first = 3 * ring + 2              # exercises the ring wrap and the slot mask
+    mask = 63
+    ld, lb, ub, X, w0, jn0, pos0, last0 = _spec_inputs(n, N, ring, 31 + n, obj)
     oid = O.OBJ[obj]
-    # oracle
-    TXr = np.zeros((K, ld))
-    P.orc_k_gather.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                               C.c_void_p, C.c_void_p, C.c_void_p]
-    P.orc_k_gather(n, ld, X.ctypes.data, i0, jn.ctypes.data, pos.ctypes.data, last.ctypes.data, K, lb.ctypes.data,
-                   ub.ctypes.data, TXr.ctypes.data)
+    # ring layout: entry (first+a) % ring holds what the oracle digested for window slot a
+    ent = [(first + a) % ring for a in range(ring)]
+    w = np.zeros(2 * n * ring, np.uint32)
+    jn, pos, last = np.zeros(ring, np.int32), np.zeros(ring * n, np.int32), np.zeros(ring, np.int32)
+    for a in range(ring):
+        w[ent[a] * 2 * n:(ent[a] + 1) * 2 * n] = w0[a * 2 * n:(a + 1) * 2 * n]
+        jn[ent[a]], last[ent[a]] = jn0[a], last0[a]
+        pos[ent[a] * n:(ent[a] + 1) * n] = pos0[a * n:(a + 1) * n]
+    # hazard list: W[a-1] = a row sampled by slot a (so slot a must stop there or earlier), plus the best row
+    P.orc_k_advance_slot.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5 + n)
+    W = np.zeros(max(K, 1), np.int64)
+    for a in range(1, K):
+        t = int(rng.integers(0, n))
+        if t < n - 1:
+            r = int(pos0[a * n + t]); r += (r >= i0)
+        else:
+            r = int(pos0[a * n + n - 1]); r += (r >= i0); r += int(last0[a]); r += (r == i0)
+        W[a - 1] = r
+    if K >= 3:
+        W[K - 2] = i0                 # the best row in the list must be ignored
+    nW = K - 1
+    # oracle, pass 1 and pass 2
+    acc = np.zeros((K, ld))
+    t1r, t2r = np.zeros(K, np.int32), np.zeros(K, np.int32)
+    for a in range(K):
+        t1r[a] = P.orc_k_advance_slot(n, ld, X.ctypes.data, i0, int(jn0[a]), pos0[a * n:].ctypes.data, int(last0[a]),
+                                      W.ctypes.data, min(a, nW), 0, lb.ctypes.data, ub.ctypes.data, acc[a].ctypes.data)
+    acc1 = acc.copy()
+    for a in range(K):
+        t2r[a] = P.orc_k_advance_slot(n, ld, X.ctypes.data, i0, int(jn0[a]), pos0[a * n:].ctypes.data, int(last0[a]),
+                                      W.ctypes.data, 0, int(t1r[a]), lb.ctypes.data, ub.ctypes.data, acc[a].ctypes.data)
+    assert np.all(t2r == n)
+    TXr = acc
     TMr = np.zeros((K, ld))
     P.orc_k_mutate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    for s in range(K):
-        P.orc_k_mutate(n, X[i0].ctypes.data, TXr[s].ctypes.data, w[(s + 1) * 2 * n:].ctypes.data, lb.ctypes.data,
-                       ub.ctypes.data, TMr[s].ctypes.data)
+    for a in range(K):
+        P.orc_k_mutate(n, X[i0].ctypes.data, TXr[a].ctypes.data, w0[(a + 1) * 2 * n:].ctypes.data, lb.ctypes.data,
+                       ub.ctypes.data, TMr[a].ctypes.data)
     fTr, fMr = np.zeros(K), np.zeros(K)
     P.orc_k_eval.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     P.orc_k_eval(oid, n, ld, TXr.ctypes.data, K, fTr.ctypes.data)
     P.orc_k_eval(oid, n, ld, TMr.ctypes.data, K, fMr.ctypes.data)
-    # a worst-list that contains rows the slots did and did not read, the best row, and duplicates of nothing
-    rng = np.random.default_rng(5)
-    nW = min(N, 40)
-    W = rng.permutation(N)[:nW].astype(np.int64)
-    W[nW // 2] = i0 if i0 not in W else W[nW // 2]
-    mhr = np.zeros(K, np.int32)
-    P.orc_k_minhz.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-    P.orc_k_minhz(n, i0, pos.ctypes.data, last.ctypes.data, K, W.ctypes.data, nW, mhr.ctypes.data)
     # device
     dX, dlb, dub, dw = DevBuf.from_array(X), DevBuf.from_array(lb), DevBuf.from_array(ub), DevBuf.from_array(w)
     dj, dp, dl, dW = DevBuf.from_array(jn), DevBuf.from_array(pos), DevBuf.from_array(last), DevBuf.from_array(W)
-    dTX, dTM = DevBuf(8 * ld * K), DevBuf(8 * ld * K)
-    dfT, dfM, dmh = DevBuf(8 * K), DevBuf(8 * K), DevBuf(4 * K)
-    assert L.nla_k_crs_gather(n, ld, dX.ptr, i0, dj.ptr, dp.ptr, dl.ptr, K, dlb.ptr, dub.ptr, dTX.ptr, None) == 0
-    assert L.nla_k_crs_post(oid, n, ld, dX.ptr, i0, dTX.ptr, dTM.ptr, dw.ptr + 4 * 2 * n, K, dW.ptr, nW, dp.ptr, dl.ptr,
-                            dlb.ptr, dub.ptr, dfT.ptr, dfM.ptr, dmh.ptr, None) == 0
-    assert L.nla_stream_sync(None) == 0
-    TX = dTX.to_array(np.float64, K * ld).reshape(K, ld)[:, :n]
-    TM = dTM.to_array(np.float64, K * ld).reshape(K, ld)[:, :n]
+    nslot = mask + 1
+    dTX, dTM = DevBuf(8 * ld * nslot), DevBuf(8 * ld * nslot)
+    dfT, dfM, dst = DevBuf(8 * nslot), DevBuf(8 * nslot), DevBuf(C.sizeof(SlotStatus) * K)
+    dt0, dt1, dt2 = DevBuf.from_array(np.zeros(K, np.int32)), DevBuf(4 * K), DevBuf(4 * K)
+    q = [(first + a) & mask for a in range(K)]
+
+    def status():
+        raw = dst.to_array(np.uint8, C.sizeof(SlotStatus) * K)
+        return np.frombuffer(raw.tobytes(), dtype=[("fT", "f8"), ("fM", "f8"), ("t", "i4"), ("pad", "i4")])
+
+    def run(t_in, t_out, nw):
+        assert L.nla_k_crs_advance(n, ld, dX.ptr, i0, dj.ptr, dp.ptr, dl.ptr, ring, first, K, dW.ptr, nw, t_in.ptr, t_out.ptr,
+                                   mask, dlb.ptr, dub.ptr, dTX.ptr, variant, None) == 0
+        assert L.nla_k_crs_finish(oid, n, ld, dX.ptr, i0, dTX.ptr, dTM.ptr, dw.ptr, ring, first, K, t_in.ptr, t_out.ptr, mask,
+                                  dlb.ptr, dub.ptr, dfT.ptr, dfM.ptr, dst.ptr, None) == 0
+        assert L.nla_stream_sync(None) == 0
+
+    run(dt0, dt1, nW)
+    st1 = status()
+    assert np.array_equal(dt1.to_array(np.int32, K), t1r) and np.array_equal(st1["t"], t1r)
+    TX1 = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)
+    for a in range(K):
+        if t1r[a] > 0:
+            assert np.array_equal(TX1[q[a], :n], acc1[a, :n]), a        # partial sums are bit-exact too
+    scale = np.abs(np.concatenate([fTr, fMr])).mean()
+    done1 = t1r == n
+    assert close(st1["fT"][done1], fTr[done1], scale) and close(st1["fM"][done1], fMr[done1], scale)
+    run(dt1, dt2, 0)
+    st2 = status()
+    assert np.all(dt2.to_array(np.int32, K) == n) and np.all(st2["t"] == n)
+    TX = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)[q][:, :n]
+    TM = dTM.to_array(np.float64, nslot * ld).reshape(nslot, ld)[q][:, :n]
     assert np.array_equal(TX, TXr[:, :n])          # bit-exact trial points (row order, no FMA)
     assert np.array_equal(TM, TMr[:, :n])          # bit-exact mutations
-    scale = np.abs(np.concatenate([fTr, fMr])).mean()
-    assert close(dfT.to_array(np.float64, K), fTr, scale)
-    assert close(dfM.to_array(np.float64, K), fMr, scale)
-    assert np.array_equal(dmh.to_array(np.int32, K), mhr)
+    assert close(st2["fT"], fTr, scale) and close(st2["fM"], fMr, scale)
+    # slots finished in pass 1 keep their first-pass results (not recomputed)
+    assert np.array_equal(st2["fT"][done1], st1["fT"][done1])
     # commit kernel: write two candidates back and read the population
-    slot = np.array([0, K - 1], np.int32)
+    slot = np.array([q[0], q[K - 1]], np.int32)
     kind = np.array([1, 2], np.int32)
     rows = np.array([1 if i0 != 1 else 2, N - 1 if i0 != N - 1 else N - 2], np.int64)
+    src = [0, K - 1]
     if K == 1:
-        slot, kind, rows = slot[:1], kind[:1], rows[:1]
+        slot, kind, rows, src = slot[:1], kind[:1], rows[:1], src[:1]
     ds, dk, dr = DevBuf.from_array(slot), DevBuf.from_array(kind), DevBuf.from_array(rows)
     assert L.nla_k_crs_commit(n, ld, dX.ptr, dTX.ptr, dTM.ptr, len(slot), ds.ptr, dk.ptr, dr.ptr, None) == 0
     assert L.nla_stream_sync(None) == 0
     X2 = dX.to_array(np.float64, N * ld).reshape(N, ld)
     Xe = X.copy()
-    for s, k, r in zip(slot, kind, rows):
-        Xe[r, :n] = (TXr if k == 1 else TMr)[s, :n]
+    for a, k, r in zip(src, kind, rows):
+        Xe[r, :n] = (TXr if k == 1 else TMr)[a, :n]
     assert np.array_equal(X2[:, :n], Xe[:, :n])
