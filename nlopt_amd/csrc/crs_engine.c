@@ -8,8 +8,8 @@
  *              blocks) at a time on the rng stream
  *   slot ring  KCAP slots, block b at slot b & (KCAP-1): TX (partial sum, then the finished trial
  *              point), TM (its mutation), fT/fM
- * Streams: `main` runs upload -> advance -> finish -> status D2H -> (host walk) -> commit each
- * pass; `rng` runs the MT generator, the GF(2) jumps and the Vitter kernel for the *next* batch of
+ * Streams: `main` runs [upload + commit of the previous pass's accepts] -> advance -> finish ->
+ * status D2H -> (host walk) each pass; `rng` runs the MT generator, the GF(2) jumps and the Vitter kernel for the *next* batch of
  * blocks concurrently (VALU-bound work hiding under the HBM-bound gather); an event per batch
  * orders main after rng.
  */
@@ -27,7 +27,8 @@ typedef struct {
     int waited;                    /* main stream already ordered after ev_ready */
 } crs_batch;
 
-typedef struct { int64_t W[KCAP]; int32_t t_in[KCAP]; } crs_upload;   /* one H2D per pass */
+/* one H2D per pass, packed: [W: nW i64][crow: nc i64][t_in: K i32][cslot: nc i32][ckind: nc i32] */
+#define UPLOAD_BYTES (KCAP * (8 + 8 + 4 + 4 + 4))
 
 struct nla_crs_hip_engine {
     int n, ld, obj;
@@ -42,13 +43,13 @@ struct nla_crs_hip_engine {
     uint32_t *d_words;             /* 2B x 2n */
     int32_t *d_jn, *d_pos, *d_last;
     double *d_TX, *d_TM, *d_fT, *d_fM;
-    crs_upload *d_up, *h_up;
-    int32_t *d_tout, *d_cslot, *d_ckind;
+    char *d_up, *h_up;
+    int32_t *d_tout;
     nla_crs_slot_status *d_status, *h_status;
-    int64_t *d_crow;
     int32_t h_t[KCAP];             /* picks summed so far, per slot (host-authoritative) */
-    int32_t *h_cslot, *h_ckind;
-    int64_t *h_crow;
+    int npending;                  /* commits staged on the host, not yet written to X */
+    int32_t pend_slot[KCAP], pend_kind[KCAP];
+    int64_t pend_row[KCAP];
     void *ev0, *ev1;
     nlopt_amd_stats *stats;
     char err[256];
@@ -100,8 +101,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_initwords);
     nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
     nla_dev_free(e->d_up); nla_dev_free(e->d_tout); nla_dev_free(e->d_status);
-    nla_dev_free(e->d_cslot); nla_dev_free(e->d_ckind); nla_dev_free(e->d_crow);
-    nla_host_free(e->h_up); nla_host_free(e->h_status); nla_host_free(e->h_cslot); nla_host_free(e->h_ckind); nla_host_free(e->h_crow);
+    nla_host_free(e->h_up); nla_host_free(e->h_status);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
     nla_stream_destroy(e->main); nla_stream_destroy(e->rng);
     free(e);
@@ -144,22 +144,15 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->d_TM = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_fT = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP);
     e->d_fM = e->d_fT ? e->d_fT + KCAP : NULL;
-    e->d_up = (crs_upload *) nla_dev_malloc(sizeof(crs_upload));
+    e->d_up = (char *) nla_dev_malloc(UPLOAD_BYTES);
     e->d_tout = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
     e->d_status = (nla_crs_slot_status *) nla_dev_malloc(sizeof(nla_crs_slot_status) * KCAP);
-    e->d_cslot = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
-    e->d_ckind = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
-    e->d_crow = (int64_t *) nla_dev_malloc(sizeof(int64_t) * KCAP);
-    e->h_up = (crs_upload *) nla_host_malloc(sizeof(crs_upload));
+    e->h_up = (char *) nla_host_malloc(UPLOAD_BYTES);
     e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * KCAP);
-    e->h_cslot = (int32_t *) nla_host_malloc(sizeof(int32_t) * KCAP);
-    e->h_ckind = (int32_t *) nla_host_malloc(sizeof(int32_t) * KCAP);
-    e->h_crow = (int64_t *) nla_host_malloc(sizeof(int64_t) * KCAP);
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
-        !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->d_cslot || !e->d_ckind || !e->d_crow ||
-        !e->h_up || !e->h_status || !e->h_cslot || !e->h_ckind || !e->h_crow || !e->ev0 || !e->ev1) goto fail;
+        !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1) goto fail;
     if (nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
         nla_memcpy_h2d(e->d_ub, ub, sizeof(double) * (size_t) n, e->main) || nla_stream_sync(e->main)) goto fail;
     return e;
@@ -229,27 +222,66 @@ static int op_max_slots(void *ve, uint64_t first_block)
     return (int) (rem < KCAP ? rem : KCAP);
 }
 
+/* upload W / t_in of the coming pass (K may be 0: commits only) together with the staged commits
+ * in ONE copy, and write the commits to X before anything else runs on the main stream */
+static int upload_and_commit(nla_crs_hip_engine *e, const int64_t *W, int nW, const int32_t *t_in, int K,
+                             const int64_t **d_W, const int32_t **d_tin)
+{
+    const int nc = e->npending;
+    size_t oW = 0, oR = oW + 8 * (size_t) nW, oT = oR + 8 * (size_t) nc, oS = oT + 4 * (size_t) K, oK = oS + 4 * (size_t) nc;
+    const size_t total = oK + 4 * (size_t) nc;
+    if (total == 0) return 0;
+    if (nW) memcpy(e->h_up + oW, W, 8 * (size_t) nW);
+    if (nc) {
+        memcpy(e->h_up + oR, e->pend_row, 8 * (size_t) nc);
+        memcpy(e->h_up + oS, e->pend_slot, 4 * (size_t) nc);
+        memcpy(e->h_up + oK, e->pend_kind, 4 * (size_t) nc);
+    }
+    if (K) memcpy(e->h_up + oT, t_in, 4 * (size_t) K);
+    CK(e, nla_memcpy_h2d(e->d_up, e->h_up, total, e->main));
+    if (nc) {
+        CK(e, nla_k_crs_commit(e->n, e->ld, e->d_X, e->d_TX, e->d_TM, nc, (const int32_t *) (e->d_up + oS),
+                               (const int32_t *) (e->d_up + oK), (const int64_t *) (e->d_up + oR), e->main));
+        e->npending = 0;
+    }
+    if (d_W) *d_W = (const int64_t *) (e->d_up + oW);
+    if (d_tin) *d_tin = (const int32_t *) (e->d_up + oT);
+    return 0;
+}
+
+/* the pinned upload buffer is rewritten by the next pass: callers that do not synchronise
+ * themselves must do so before the host touches it again (every pass ends with a sync) */
+static int flush_commits(nla_crs_hip_engine *e)
+{
+    if (!e->npending) return 0;
+    if (upload_and_commit(e, NULL, 0, NULL, 0, NULL, NULL)) return -1;
+    CK(e, nla_stream_sync(e->main));
+    return 0;
+}
+
 static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
                       nla_crs_slot_status *status)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const int n = e->n;
     const uint32_t ring = 2u * (uint32_t) e->B;
+    int32_t t_in[KCAP];
+    const int64_t *d_W = NULL;
+    const int32_t *d_tin = NULL;
     if (K < 1 || K > KCAP || nW > KCAP || nW < 0) FAIL(e, "bad window K=%d nW=%d", K, nW);
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
     if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
-    memcpy(e->h_up->W, W, sizeof(int64_t) * (size_t) nW);
     for (int a = 0; a < K; ++a) {
         const uint64_t b = first_block + (uint64_t) a;
-        e->h_up->t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
+        t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
     }
-    CK(e, nla_memcpy_h2d(e->d_up, e->h_up, sizeof(crs_upload), e->main));
+    if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin)) return -1;
     CK(e, nla_event_record(e->ev0, e->main));
-    CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, e->d_up->W, nW,
-                            e->d_up->t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
+    CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
+                            d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
     CK(e, nla_event_record(e->ev1, e->main));
     CK(e, nla_k_crs_finish(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
-                           e->d_up->t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
+                           d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
     CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * (size_t) K, e->main));
     CK(e, nla_stream_sync(e->main));
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
@@ -262,19 +294,19 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     return 0;
 }
 
+/* staged; written to X by the next pass's single upload (or by a flush when something reads X) */
 static int op_commit(void *ve, int ncommit, const uint64_t *block, const int32_t *kind, const int64_t *row)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     if (ncommit <= 0) return 0;
+    if (e->npending && flush_commits(e)) return -1;
     if (ncommit > KCAP) FAIL(e, "too many commits");
-    for (int c = 0; c < ncommit; ++c) e->h_cslot[c] = (int32_t) (block[c] & (KCAP - 1));
-    memcpy(e->h_ckind, kind, sizeof(int32_t) * (size_t) ncommit);
-    memcpy(e->h_crow, row, sizeof(int64_t) * (size_t) ncommit);
-    CK(e, nla_memcpy_h2d(e->d_cslot, e->h_cslot, sizeof(int32_t) * (size_t) ncommit, e->main));
-    CK(e, nla_memcpy_h2d(e->d_ckind, e->h_ckind, sizeof(int32_t) * (size_t) ncommit, e->main));
-    CK(e, nla_memcpy_h2d(e->d_crow, e->h_crow, sizeof(int64_t) * (size_t) ncommit, e->main));
-    CK(e, nla_k_crs_commit(e->n, e->ld, e->d_X, e->d_TX, e->d_TM, ncommit, e->d_cslot, e->d_ckind, e->d_crow, e->main));
-    /* no sync: the pinned staging arrays are next written after the following pass has synchronised */
+    for (int c = 0; c < ncommit; ++c) {
+        e->pend_slot[c] = (int32_t) (block[c] & (KCAP - 1));
+        e->pend_kind[c] = kind[c];
+        e->pend_row[c] = row[c];
+    }
+    e->npending = ncommit;
     return 0;
 }
 
@@ -282,6 +314,7 @@ static int op_read_slot(void *ve, uint64_t block, int kind, double *x)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const double *src = (kind == 1 ? e->d_TX : e->d_TM) + (size_t) (block & (KCAP - 1)) * (size_t) e->ld;
+    if (flush_commits(e)) return -1;
     CK(e, nla_memcpy_d2h(x, src, sizeof(double) * (size_t) e->n, e->main));
     CK(e, nla_stream_sync(e->main));
     return 0;
@@ -290,6 +323,7 @@ static int op_read_slot(void *ve, uint64_t block, int kind, double *x)
 static int op_read_row(void *ve, int64_t row, double *x)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
+    if (flush_commits(e)) return -1;
     CK(e, nla_memcpy_d2h(x, e->d_X + (size_t) row * (size_t) e->ld, sizeof(double) * (size_t) e->n, e->main));
     CK(e, nla_stream_sync(e->main));
     return 0;
@@ -299,7 +333,7 @@ static int op_mutate_slot(void *ve, uint64_t block, int64_t i0)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const uint32_t ring = 2u * (uint32_t) e->B;
-    if (ensure_blocks(e, block, block + 1)) return -1;
+    if (ensure_blocks(e, block, block + 1) || flush_commits(e)) return -1;
     CK(e, nla_k_crs_mutate(e->n, e->d_X + (size_t) i0 * (size_t) e->ld, e->d_TX + (size_t) (block & (KCAP - 1)) * (size_t) e->ld,
                            e->d_words + (size_t) ((block + 1) % ring) * 2 * (size_t) e->n, e->d_lb, e->d_ub, e->main));
     return 0;

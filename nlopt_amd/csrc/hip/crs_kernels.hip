@@ -135,8 +135,9 @@ __device__ __forceinline__ void acc_row(double2 &a, double2 v, double m) { a.x =
  * grid = window slots x coordinate chunks; one workgroup of WAVES wavefronts per (slot, chunk).
  * The per-coordinate chain is serial, the loads are not: the WAVES wavefronts take the batches of
  * U rows round-robin, each keeps its next batch in flight (U x 16 B per lane) while the
- * accumulator travels through LDS from wavefront to wavefront in batch order (one s_barrier per
- * batch) — WAVES*U rows of one chunk are in flight instead of U.
+ * accumulator travels through LDS from wavefront to wavefront in batch order as a token (an LDS
+ * turn counter; only the 2U fp64 adds of a batch and the hand-off are on the serial path) —
+ * WAVES*U rows of one chunk are in flight instead of U.
  * ---------------------------------------------------------------------------------------------- */
 /* LDS-only barrier: orders this wavefront's LDS traffic, leaves its global loads in flight
  * (__syncthreads() carries a workgroup release fence that drains vmcnt). */
@@ -148,7 +149,7 @@ template <int VEC, int U, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     int n, int ld, const double *__restrict__ X, int64_t i0, const int32_t *__restrict__ jn_ring,
     const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, uint32_t ring_blocks,
-    uint64_t first_block, const int64_t *__restrict__ W, int nW,
+    uint64_t first_block, int K, const int64_t *__restrict__ W, int nW,
     const int32_t *__restrict__ t_in, int32_t *__restrict__ t_out, int slot_mask, int chunks,
     const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX)
 {
@@ -157,9 +158,14 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     __shared__ V sacc[64];
     __shared__ int32_t srow[NLA_ADV_RCAP];
     __shared__ int s_e;
+    __shared__ int s_turn;
+    /* polled through an explicit LDS-address-space pointer: volatile accesses through a generic
+     * pointer become flat loads, whose waits would also drain the global loads in flight */
+    volatile __attribute__((address_space(3))) int *turn = (volatile __attribute__((address_space(3))) int *) &s_turn;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int a = blockIdx.x / chunks, chunk = blockIdx.x - a * chunks;
+    /* back of the window first: fresh slots have the longest pieces, the front ones the shortest */
+    const int a = K - 1 - (int) (blockIdx.x / chunks), chunk = blockIdx.x % chunks;
     const uint64_t block = first_block + (uint64_t) a;
     const uint32_t rb = (uint32_t) (block % ring_blocks);
     const int q = (int) (block & (uint64_t) slot_mask);
@@ -171,20 +177,40 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     int64_t al = rbase + (rbase >= i0 ? 1 : 0) + (int64_t) last_ring[rb];
     al += (al == i0) ? 1 : 0;
 
+    /* actual rows of picks t0 .. t0+cnt0-1 into LDS (ascending): one coalesced read of the pick
+     * list serves both the plan below and the first segment of the sum */
+    auto pick_row = [&](int t) -> int32_t {
+        int64_t r;
+        if (t < n - 1) { r = p[t]; r += (r >= i0 ? 1 : 0); } else r = al;
+        return (int32_t) r;
+    };
+    const int cnt0 = (n - t0 < NLA_ADV_RCAP) ? n - t0 : NLA_ADV_RCAP;
+    for (int i = threadIdx.x; i < cnt0; i += WAVES * 64) srow[i] = pick_row(t0 + i);
+    __syncthreads();
     if (wave == 0) {                        /* plan: where must this slot stop in this pass? */
         int e = n;
         const int nun = a < nW ? a : nW;
         for (int j = lane; j < nun; j += 64) {
             const int64_t r = W[j];
             if (r == i0) continue;          /* the best row is never sampled */
-            if (r == al) { e = e < n - 1 ? e : n - 1; continue; }
-            const int32_t rho = (int32_t) (r - (r > i0 ? 1 : 0));
-            int lo = t0, hi = n - 2;        /* binary search in the ascending picks not yet summed */
+            int lo = 0, hi = cnt0 - 1;      /* binary search among the staged picks */
+            bool found = false;
             while (lo <= hi) {
                 const int mid = (lo + hi) >> 1;
-                const int32_t pv = p[mid];
-                if (pv == rho) { e = e < mid ? e : mid; break; }
-                if (pv < rho) lo = mid + 1; else hi = mid - 1;
+                const int32_t pv = srow[mid];
+                if (pv == (int32_t) r) { e = e < t0 + mid ? e : t0 + mid; found = true; break; }
+                if (pv < (int32_t) r) lo = mid + 1; else hi = mid - 1;
+            }
+            if (!found && t0 + cnt0 < n) {  /* very long pick lists: the rest straight from memory */
+                if (r == al) { e = e < n - 1 ? e : n - 1; continue; }
+                const int32_t rho = (int32_t) (r - (r > i0 ? 1 : 0));
+                lo = t0 + cnt0; hi = n - 2;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int32_t pv = p[mid];
+                    if (pv == rho) { e = e < mid ? e : mid; break; }
+                    if (pv < rho) lo = mid + 1; else hi = mid - 1;
+                }
             }
         }
         e = nla_wave_min_i32(e);
@@ -211,12 +237,9 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     for (int seg0 = t0; seg0 < e; seg0 += NLA_ADV_RCAP) {
         const int cnt = (e - seg0 < NLA_ADV_RCAP) ? e - seg0 : NLA_ADV_RCAP;
         nla_lds_barrier();                  /* the previous segment's row list is no longer needed */
-        for (int i = threadIdx.x; i < cnt; i += WAVES * 64) {   /* actual rows of picks seg0 .. seg0+cnt-1 */
-            const int t = seg0 + i;
-            int64_t r;
-            if (t < n - 1) { r = p[t]; r += (r >= i0 ? 1 : 0); } else r = al;
-            srow[i] = (int32_t) r;
-        }
+        if (seg0 != t0)                     /* (the first segment was staged for the plan) */
+            for (int i = threadIdx.x; i < cnt; i += WAVES * 64) srow[i] = pick_row(seg0 + i);
+        if (threadIdx.x == 0) *turn = 0;
         nla_lds_barrier();
         const int nb = (cnt + U - 1) / U;
         auto issue = [&](int b) {
@@ -230,26 +253,33 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
                 v[u] = *reinterpret_cast<const V *>(rowp + lane_off);
             }
         };
+        /* The accumulator is a token: batch ph may only be added by its wavefront once batch ph-1 has
+         * been (turn == ph).  Only the adds are on the serial path; a wavefront issues the loads of
+         * its next batch after it has passed the token on. */
         if (wave < nb) issue(wave);
-        for (int ph = 0; ph < nb; ++ph) {
-            nla_lds_barrier();
-            if (ph % WAVES == wave) {
-                V acc = sacc[lane];
-                const int base = ph * U, tb = seg0 + base;
-                if (base + U <= cnt && !(jn >= tb && jn < tb + U)) {
+        for (int ph = wave; ph < nb; ph += WAVES) {
+            while (*turn != ph) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            V acc = sacc[lane];
+            const int base = ph * U, tb = seg0 + base;
+            if (base + U <= cnt && !(jn >= tb && jn < tb + U)) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) add_row(acc, v[u]);
-                } else {
+                for (int u = 0; u < U; ++u) add_row(acc, v[u]);
+            } else {
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (base + u < cnt) acc_row(acc, v[u], (tb + u == jn) ? hneg : 1.0);
-                }
-                sacc[lane] = acc;
-                if (ph + WAVES < nb) issue(ph + WAVES);
+                for (int u = 0; u < U; ++u)
+                    if (base + u < cnt) acc_row(acc, v[u], (tb + u == jn) ? hneg : 1.0);
             }
+            sacc[lane] = acc;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *turn = ph + 1;
+            if (ph + WAVES < nb) issue(ph + WAVES);
+        }
+        if (wave == 0) {                    /* the segment is summed when the token has left its last batch */
+            while (*turn != nb) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
         }
     }
-    nla_lds_barrier();
     if (wave == 0 && active) {
         V acc = sacc[lane];
         if (e == n) {                       /* x[k] *= 2.0 / n, then clamp (crs.c:116-120) */
@@ -273,31 +303,33 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
 /* finish kernel: for every slot of the window that became complete in this pass, f of the trial
  * and the local mutation that would follow its rejection (crs.c:139-146; w from the NEXT stream
  * block) with its f; for every slot, its status record for the host's in-order walk. */
+#define NLA_FIN_WAVES 8
 template <int OBJ>
-__global__ __launch_bounds__(64) void crs_finish_kernel(
+__global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
     int n, int ld, const double *__restrict__ X, int64_t i0, const double *__restrict__ TX, double *__restrict__ TM,
     const uint32_t *__restrict__ words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
     const int32_t *__restrict__ t_in, const int32_t *__restrict__ t_out, int slot_mask,
     const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ fT_ring,
     double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status)
 {
-    const int lane = threadIdx.x;
+    __shared__ double scratch[2 * NLA_FIN_WAVES];
+    const int tid = threadIdx.x;
     const int task = blockIdx.x / K, a = blockIdx.x - task * K;
     const uint64_t block = first_block + (uint64_t) a;
     const int q = (int) (block & (uint64_t) slot_mask);
     const int t1 = t_out[a];
     const bool was_done = t_in[a] == n;
-    const bool newly = (t1 == n) && !was_done;
+    const bool newly = (t1 == n) && !was_done;          /* uniform over the workgroup */
     const double *x = TX + (size_t) q * (size_t) ld;
     if (task == 0) {
         double f = 0;
         if (OBJ >= 0) {
             if (newly) {
-                f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, [&](int i) { return x[i]; });
-                if (lane == 0) fT_ring[q] = f;
+                f = nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, [&](int i) { return x[i]; }, scratch);
+                if (tid == 0) fT_ring[q] = f;
             } else if (t1 == n) f = fT_ring[q];
         }
-        if (lane == 0) { status[a].fT = f; status[a].t = t1; }
+        if (tid == 0) { status[a].fT = f; status[a].t = t1; }
     } else {
         double f = 0;
         if (OBJ >= 0) {
@@ -310,12 +342,12 @@ __global__ __launch_bounds__(64) void crs_finish_kernel(
                     const double wv = nla_urand_from(0., 1., ww.x, ww.y);
                     return nla_clamp_box(xb[i] * (1 + wv) - wv * x[i], lb[i], ub[i]);
                 };
-                for (int i = lane; i < n; i += 64) m[i] = mut(i);
-                f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, mut);
-                if (lane == 0) fM_ring[q] = f;
+                for (int i = tid; i < n; i += NLA_FIN_WAVES * 64) m[i] = mut(i);
+                f = nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, mut, scratch);
+                if (tid == 0) fM_ring[q] = f;
             } else if (t1 == n) f = fM_ring[q];
         }
-        if (lane == 0) status[a].fM = f;
+        if (tid == 0) status[a].fM = f;
     }
 }
 
@@ -411,13 +443,16 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
 {
     if (K <= 0) return 0;
     hipStream_t st = (hipStream_t) stream;
-    const bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    /* variant = [1 if thin][WAVES][U as two digits]; thin = one coordinate per lane (64-coordinate chunks:
+     * twice the workgroups per slot, for when few slots must spread over the whole chip) */
+    bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    if (variant == 0) variant = n >= 2048 ? 832 : (n >= 512 ? 416 : (n >= 128 ? 216 : 116));
+    if (variant >= 10000) { vec2 = false; variant -= 10000; }
     const int cpw = vec2 ? 128 : 64;
     const int chunks = (n + cpw - 1) / cpw;
     const dim3 grid((unsigned) ((long) chunks * K));
-    if (variant == 0) variant = n >= 2048 ? 816 : (n >= 512 ? 416 : (n >= 128 ? 216 : 116));
 #define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, n, ld, X, i0, jn_ring, \
-        pos_ring, last_ring, ring_blocks, first_block, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX)
+        pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX)
     if (vec2) {
         switch (variant) {
         case 116: ADV(2, 16, 1); break;
@@ -428,7 +463,6 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
         case 816: ADV(2, 16, 8); break;
         case 832: ADV(2, 32, 8); break;
         case 1616: ADV(2, 16, 16); break;
-        case 1632: ADV(2, 32, 16); break;
         default: return (int) hipErrorInvalidValue;
         }
     } else {
@@ -436,7 +470,11 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
         case 116: ADV(1, 16, 1); break;
         case 216: ADV(1, 16, 2); break;
         case 416: ADV(1, 16, 4); break;
+        case 432: ADV(1, 32, 4); break;
+        case 816: ADV(1, 16, 8); break;
         case 832: ADV(1, 32, 8); break;
+        case 864: ADV(1, 64, 8); break;
+        case 1632: ADV(1, 32, 16); break;
         default: ADV(1, 16, 4); break;
         }
     }
@@ -452,7 +490,7 @@ extern "C" int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t
                                 nla_crs_slot_status *status, void *stream)
 {
     if (K <= 0) return 0;
-    const dim3 grid((unsigned) (2 * K)), block(64);
+    const dim3 grid((unsigned) (2 * K)), block(NLA_FIN_WAVES * 64);
     hipStream_t st = (hipStream_t) stream;
     if (obj < 0) {
         hipLaunchKernelGGL((crs_finish_kernel<-1>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,

@@ -62,42 +62,98 @@ __device__ __forceinline__ double nla_clamp_box(double v, double lo, double hi)
     return v;
 }
 
-/* Objective of one candidate by one wavefront.  `get(i)` returns coordinate i (a load, or a value
- * recomputed on the fly); every lane returns the full f. */
+/* Objective of one candidate, data-parallel over its coordinates.  Every objective of the zoo is
+ * (sum a, second sum or product b) over per-coordinate terms plus a scalar finish, so a partial
+ * result is the pair (a, b); partials combine by (+, + or *).  Thread `first` of `stride`
+ * accumulates coordinates first, first+stride, ... in that order; the 64 partials of a wavefront
+ * combine with a xor-butterfly, the wavefronts of a workgroup in wavefront order through LDS. */
+struct nla_obj_part { double a, b; };
+
+template <int OBJ>
+__device__ __forceinline__ nla_obj_part nla_obj_combine(nla_obj_part x, nla_obj_part y)
+{
+    nla_obj_part r;
+    r.a = x.a + y.a;
+    r.b = (OBJ == NLA_OBJ_GRIEWANK) ? x.b * y.b : x.b + y.b;
+    return r;
+}
+
+template <int OBJ, class Get>
+__device__ __forceinline__ nla_obj_part nla_obj_partial(int n, int first, int stride, Get get)
+{
+    nla_obj_part r;
+    r.a = 0;
+    r.b = (OBJ == NLA_OBJ_GRIEWANK) ? 1 : 0;
+    if (OBJ == NLA_OBJ_RASTRIGIN) {
+        for (int i = first; i < n; i += stride) r.a += nla_rastrigin_term(get(i));
+    } else if (OBJ == NLA_OBJ_ACKLEY) {
+        for (int i = first; i < n; i += stride) { double x = get(i); r.a += nla_sqr(x); r.b += nla_ackley_cos_term(x); }
+    } else if (OBJ == NLA_OBJ_GRIEWANK) {
+        for (int i = first; i < n; i += stride) {
+            double x = get(i);
+            r.a += nla_griewank_sum_term(x);
+            r.b *= nla_griewank_prod_term(x, (unsigned) i);
+        }
+    } else if (OBJ == NLA_OBJ_ROSENBROCK) {
+        for (int i = first; i + 1 < n; i += stride) r.a += nla_rosenbrock_term(get(i), get(i + 1));
+    } else if (OBJ == NLA_OBJ_LEVY) {
+        for (int i = first; i + 1 < n; i += stride) r.a += nla_levy_term(get(i), get(i + 1));
+    } else { /* NLA_OBJ_SPHERE */
+        for (int i = first; i < n; i += stride) r.a += nla_sqr(get(i));
+    }
+    return r;
+}
+
+template <int OBJ, class Get>
+__device__ __forceinline__ double nla_obj_finish(int n, nla_obj_part t, Get get)
+{
+    if (OBJ == NLA_OBJ_RASTRIGIN) return 10.0 * n + t.a;
+    if (OBJ == NLA_OBJ_ACKLEY) return nla_ackley_finish(t.a, t.b, (unsigned) n);
+    if (OBJ == NLA_OBJ_GRIEWANK) return (1.0 + t.a) - t.b;
+    if (OBJ == NLA_OBJ_LEVY) return nla_levy_head(get(0), get(n - 1)) + t.a;
+    return t.a;
+}
+
+template <int OBJ>
+__device__ __forceinline__ nla_obj_part nla_obj_wave_reduce(nla_obj_part t)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        nla_obj_part o;
+        o.a = __shfl_xor(t.a, m, NLA_WAVE);
+        o.b = __shfl_xor(t.b, m, NLA_WAVE);
+        t = nla_obj_combine<OBJ>(t, o);
+    }
+    return t;
+}
+
+/* one wavefront per candidate; `get(i)` returns coordinate i (a load, or a value recomputed on the
+ * fly); every lane returns the full f */
 template <int OBJ, class Get>
 __device__ __forceinline__ double nla_wave_objective(int n, Get get)
 {
     const int lane = threadIdx.x & (NLA_WAVE - 1);
-    if (OBJ == NLA_OBJ_RASTRIGIN) {
-        double s = 0;
-        for (int i = lane; i < n; i += NLA_WAVE) s += nla_rastrigin_term(get(i));
-        return 10.0 * n + nla_wave_sum(s);
-    } else if (OBJ == NLA_OBJ_ACKLEY) {
-        double s = 0, c = 0;
-        for (int i = lane; i < n; i += NLA_WAVE) { double x = get(i); s += nla_sqr(x); c += nla_ackley_cos_term(x); }
-        return nla_ackley_finish(nla_wave_sum(s), nla_wave_sum(c), (unsigned) n);
-    } else if (OBJ == NLA_OBJ_GRIEWANK) {
-        double s = 0, p = 1;
-        for (int i = lane; i < n; i += NLA_WAVE) {
-            double x = get(i);
-            s += nla_griewank_sum_term(x);
-            p *= nla_griewank_prod_term(x, (unsigned) i);
-        }
-        return (1.0 + nla_wave_sum(s)) - nla_wave_prod(p);
-    } else if (OBJ == NLA_OBJ_ROSENBROCK) {
-        double s = 0;
-        for (int i = lane; i + 1 < n; i += NLA_WAVE) s += nla_rosenbrock_term(get(i), get(i + 1));
-        return nla_wave_sum(s);
-    } else if (OBJ == NLA_OBJ_LEVY) {
-        double s = 0;
-        for (int i = lane; i + 1 < n; i += NLA_WAVE) s += nla_levy_term(get(i), get(i + 1));
-        double head = nla_levy_head(get(0), get(n - 1));
-        return head + nla_wave_sum(s);
-    } else { /* NLA_OBJ_SPHERE */
-        double s = 0;
-        for (int i = lane; i < n; i += NLA_WAVE) s += nla_sqr(get(i));
-        return nla_wave_sum(s);
+    return nla_obj_finish<OBJ>(n, nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, lane, NLA_WAVE, get)), get);
+}
+
+/* one workgroup of WAVES wavefronts per candidate (blockDim.x == 64*WAVES, all threads call);
+ * `scratch` = 2*WAVES doubles of LDS; every thread returns the full f */
+template <int OBJ, int WAVES, class Get>
+__device__ __forceinline__ double nla_block_objective(int n, Get get, double *scratch)
+{
+    const int lane = threadIdx.x & (NLA_WAVE - 1), wave = threadIdx.x >> 6;
+    nla_obj_part t = nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, (int) threadIdx.x, NLA_WAVE * WAVES, get));
+    __syncthreads();                      /* scratch may still be read from a previous call */
+    if (lane == 0) { scratch[2 * wave] = t.a; scratch[2 * wave + 1] = t.b; }
+    __syncthreads();
+    t.a = scratch[0]; t.b = scratch[1];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) {
+        nla_obj_part o;
+        o.a = scratch[2 * w]; o.b = scratch[2 * w + 1];
+        t = nla_obj_combine<OBJ>(t, o);
     }
+    return nla_obj_finish<OBJ>(n, t, get);
 }
 
 #define NLA_OBJ_DISPATCH(obj, CALL)                                   \

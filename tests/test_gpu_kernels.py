@@ -140,7 +140,8 @@ class SlotStatus(C.Structure):
                                                   ("levy", 128, 300, 4, 17, 0), ("rosenbrock", 512, 2000, 6, 3, 0),
                                                   ("griewank", 4096, 4200, 3, 4199, 0), ("sphere", 1, 9, 8, 4, 0),
                                                   ("griewank", 2048, 3000, 5, 77, 832), ("griewank", 1024, 3000, 5, 77, 1616),
-                                                  ("ackley", 300, 700, 6, 5, 132), ("ackley", 9000, 9100, 2, 5, 416)])
+                                                  ("ackley", 300, 700, 6, 5, 132), ("ackley", 9000, 9100, 2, 5, 416),
+                                                  ("griewank", 2048, 3000, 5, 77, 10816), ("ackley", 300, 700, 6, 5, 10432)])
 def test_advance_finish_commit_kernels(L, obj, n, N, K, i0, variant):
     """the resumable gather-sum in two passes (first one stopped by a hazard list), evaluation and
     mutation of the finished slots, and the commit: bit-exact x / partial sums / t, f within 1e-10"""

@@ -15,6 +15,7 @@ int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 4096;
     const int64_t N = argc > 2 ? atoll(argv[2]) : 100000;
+    const int mode = argc > 3 ? atoi(argv[3]) : 0;   /* 1: consecutive rows (locality probe) */
     const int KMAX = 64, ld = (n + 1) & ~1, reps = 5;
     const int64_t i0 = N / 3;
     void *st;
@@ -49,6 +50,7 @@ int main(int argc, char **argv)
         int32_t *p = h_pos + (size_t) s * n;
         char *mark = calloc((size_t) N, 1);
         int got = 0;
+        if (mode == 1) { int32_t r0 = (int32_t) (xr() % (uint64_t) (N - 2 - n)); for (got = 0; got < n; ++got) p[got] = r0 + got; }
         while (got < n) { int32_t r = (int32_t) (xr() % (uint64_t) (N - 2)); if (!mark[r]) { mark[r] = 1; p[got++] = r; } }
         free(mark);
         qsort(p, (size_t) n, 4, cmp32);
@@ -59,8 +61,8 @@ int main(int argc, char **argv)
     nla_memcpy_h2d(d_jn, h_jn, 4 * KMAX, st); nla_memcpy_h2d(d_last, h_last, 4 * KMAX, st);
     nla_memcpy_h2d(d_pos, h_pos, 4 * (size_t) KMAX * n, st); nla_stream_sync(st);
 
-    static const int Ks[] = { 1, 2, 4, 6, 8, 12, 16, 24, 32, 64 };
-    static const int variants[] = { 132, 416, 432, 816, 832, 1616 };
+    static const int Ks[] = { 1, 2, 4, 6, 8, 16 };
+    static const int variants[] = { 416, 432, 816, 832, 1616, 10832, 10864 };
     printf("n=%d N=%lld  bytes/trial=%.2f MB\n", n, (long long) N, 8.0 * n * (n + 1) / 1e6);
     for (size_t ki = 0; ki < sizeof Ks / sizeof *Ks; ++ki) {
         const int K = Ks[ki];
