@@ -66,6 +66,13 @@ typedef struct { orc_trace_rec *rec; size_t cap, len; } orc_trace;
 int orc_crs_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub,
                      double *x, double *minf, orc_stop *stop, long population, orc_trace *trace);
 
+/* ---- ISRES (src/algs/isres/isres.c) ---------------------------------------------------------- */
+typedef struct { orc_func f; void *f_data; double tol; } orc_constraint;      /* scalar, nlopt-util.h:119-126 */
+typedef struct { double *f, *pen; size_t cap, len; long generations; } orc_isres_trace;   /* per evaluation */
+int orc_isres_minimize(int n, orc_func f, void *f_data, int m, const orc_constraint *fc, int p, const orc_constraint *h,
+                       const double *lb, const double *ub, double *x, double *minf, orc_stop *stop, long population,
+                       orc_isres_trace *trace);
+
 /* ---- objective zoo callbacks (objfuncs.h compiled for the host) ------------------------------ */
 orc_func orc_objective(int id);                     /* f_data ignored */
 double orc_con_blocksum(unsigned n, const double *x, double *grad, void *data); /* data -> unsigned[2]={q,Q} */

@@ -261,3 +261,74 @@ def run_emu_crs(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.
                         C.byref(nev), C.byref(words))
     return dict(ret=ret, minf=minf.value, x=x, nevals=nev.value, words=words.value,
                 trace=tr[:min(tlen.value, trace_cap)].copy(), trace_len=tlen.value, stats=st.asdict())
+
+
+# ---- ISRES ------------------------------------------------------------------------------------
+class OrcConstraint(C.Structure):
+    _fields_ = [("f", C.c_void_p), ("f_data", C.c_void_p), ("tol", C.c_double)]
+
+
+class IsresTrace(C.Structure):
+    _fields_ = [("f", C.POINTER(C.c_double)), ("pen", C.POINTER(C.c_double)), ("cap", C.c_size_t), ("len", C.c_size_t),
+                ("generations", C.c_long)]
+
+
+def blocksum_data(ncon, q0=0):
+    """func_data of the block-sum constraints q0..q0+ncon-1 of Q = ncon blocks: unsigned[2] = {q, Q} each"""
+    arr = (C.c_uint * (2 * max(ncon, 1)))()
+    for q in range(ncon):
+        arr[2 * q], arr[2 * q + 1] = q, ncon
+    return arr
+
+
+def run_port_isres(obj, n, pop, seed, nineq=0, neq=0, tol=1e-8, maxeval=0, x0=None, stopval=None, ftol_rel=0.0,
+                   ftol_abs=0.0, xtol_rel=0.0, record=True):
+    """the port's ISRES with `nineq` block-sum inequality and `neq` block-sum equality constraints"""
+    L = port()
+    L.orc_isres_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OrcConstraint), C.c_int,
+                                     C.POINTER(OrcConstraint), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OrcStop), C.c_long,
+                                     C.POINTER(IsresTrace)]
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lb, ub = np.full(n, lo), np.full(n, hi)
+    st = OrcStop()
+    L.orc_stop_default(C.byref(st), n)
+    st.maxeval = maxeval
+    st.ftol_rel, st.ftol_abs, st.xtol_rel = ftol_rel, ftol_abs, xtol_rel
+    if stopval is not None:
+        st.minf_max = stopval
+    con = C.cast(L.orc_con_blocksum, C.c_void_p).value
+    di, de = blocksum_data(nineq), blocksum_data(neq)
+    fc = (OrcConstraint * max(nineq, 1))(*[OrcConstraint(con, C.addressof(di) + 8 * q, tol) for q in range(nineq)])
+    hc = (OrcConstraint * max(neq, 1))(*[OrcConstraint(con, C.addressof(de) + 8 * q, tol) for q in range(neq)])
+    f = L.orc_objective(OBJ[obj])
+    cap = (maxeval or 200000) + 16
+    fbuf = np.zeros(cap)
+    hbuf = np.zeros(cap, dtype=np.uint64)
+    rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
+    fcb = C.cast(L.orc_recording_callback, C.c_void_p).value
+    tf, tp = np.zeros(cap), np.zeros(cap)
+    tr = IsresTrace(dptr(tf), dptr(tp), cap, 0, 0)
+    minf = C.c_double()
+    L.orc_srand(seed)
+    ret = L.orc_isres_minimize(n, fcb, C.cast(C.pointer(rec), C.c_void_p), nineq, fc, neq, hc, dptr(lb), dptr(ub), dptr(x),
+                               C.byref(minf), C.byref(st), pop, C.byref(tr))
+    k = min(tr.len, cap)
+    return dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, words=L.orc_mt_words_drawn(), fseq=fbuf[:rec.len].copy(),
+                xhash=hbuf[:rec.len].copy(), ftrace=tf[:k].copy(), pentrace=tp[:k].copy(), generations=tr.generations)
+
+
+def run_ref_isres(obj, n, pop, seed, nineq=0, neq=0, tol=1e-8, **kw):
+    """the REAL reference's NLOPT_GN_ISRES (35) with the same block-sum constraints"""
+    L = port()
+    con = C.cast(L.orc_con_blocksum, C.c_void_p).value
+    di, de = blocksum_data(nineq), blocksum_data(neq)
+
+    def setup(R, opt):
+        for q in range(nineq):
+            assert R.nlopt_add_inequality_constraint(opt, con, C.addressof(di) + 8 * q, tol) > 0
+        for q in range(neq):
+            assert R.nlopt_add_equality_constraint(opt, con, C.addressof(de) + 8 * q, tol) > 0
+        return (di, de)
+    return run_ref(35, obj, n, pop, seed, setup=setup, **kw)

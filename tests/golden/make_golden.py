@@ -1,4 +1,4 @@
-"""Generate tests/golden/crs_golden.json from the REAL reference (oracle/_ref/libnlopt_ref.so, built
+"""Generate tests/golden/crs_golden.json and isres_golden.json from the REAL reference (oracle/_ref/libnlopt_ref.so, built
 from /root/reference by oracle/Makefile).  Run in the build container only:
     python tests/golden/make_golden.py
 Each case records what a later run (port or HIP path) must reproduce: nlopt_result, numevals, minf
@@ -39,6 +39,34 @@ def fhash(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
 
 
+ISRES_CASES = [
+    # (name, obj, n, pop, seed, nineq, neq, kwargs)
+    ("isres_rastrigin_n8_pop40_uncon", "rastrigin", 8, 40, 42, 0, 0, dict(maxeval=2000)),
+    ("isres_rastrigin_n12_pop60_4ineq", "rastrigin", 12, 60, 42, 4, 0, dict(maxeval=3000)),
+    ("isres_griewank_n6_defaultpop_2ineq_1eq", "griewank", 6, 0, 7, 2, 1, dict(maxeval=2500)),
+    ("isres_sphere_n5_pop30_ftolabs", "sphere", 5, 30, 3, 1, 0, dict(ftol_abs=1e-9, maxeval=20000)),
+    ("isres_rosenbrock_n4_pop35_xtol", "rosenbrock", 4, 35, 11, 0, 0, dict(xtol_rel=1e-4, maxeval=20000)),
+    ("isres_levy_n3_pop7_2eq", "levy", 3, 7, 5, 0, 2, dict(maxeval=700)),
+    ("isres_sphere_n4_pop50_stopval", "sphere", 4, 50, 9, 2, 0, dict(stopval=0.05, maxeval=20000)),
+    ("isres_rastrigin_n32_pop700_4ineq", "rastrigin", 32, 700, 42, 4, 0, dict(maxeval=7000)),
+    ("isres_ackley_n64_pop300_uncon", "ackley", 64, 300, 5, 0, 0, dict(maxeval=3000)),
+    ("isres_rastrigin_n10_maxeval_midgen", "rastrigin", 10, 100, 42, 2, 0, dict(maxeval=257)),
+]
+
+
+def main_isres():
+    out = {}
+    for name, obj, n, pop, seed, nineq, neq, kw in ISRES_CASES:
+        r = O.run_ref_isres(obj, n, pop, seed, nineq, neq, **kw)
+        out[name] = dict(obj=obj, n=n, pop=pop, seed=seed, nineq=nineq, neq=neq, kwargs=kw, ret=int(r["ret"]),
+                         nevals=int(r["nevals"]), minf=float(r["minf"]).hex(), x=[float(v).hex() for v in r["x"]],
+                         fseq_sha256=fhash(r["fseq"]), xhash_sha256=hashlib.sha256(r["xhash"].tobytes()).hexdigest(),
+                         fseq_head=[float(v).hex() for v in r["fseq"][:8]], fseq_tail=[float(v).hex() for v in r["fseq"][-8:]])
+        print(name, r["ret"], r["nevals"], r["minf"])
+    with open(os.path.join(HERE, "isres_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
     out = {}
     for name, obj, n, pop, seed, kw in CASES:
@@ -53,4 +81,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "isres" in sys.argv[1:] or len(sys.argv) == 1:
+        main_isres()
+    if "crs" in sys.argv[1:] or len(sys.argv) == 1:
+        main()

@@ -88,3 +88,38 @@ def test_word_accounting_matches_survey_appendix_a():
     # CRS2_LM n=8, N=50, 5002 evals consumes 2n(N-1) + 2n(evals-N) = 80016 words
     r = O.run_port_crs("griewank", 8, 50, 42, maxeval=5002)
     assert r["nevals"] == 5002 and r["words"] == 80016
+
+
+# ---- ISRES ------------------------------------------------------------------------------------
+@need_ref
+@pytest.mark.parametrize("obj,n,pop,seed,nineq,neq,kw", [
+    ("rastrigin", 8, 40, 42, 0, 0, dict(maxeval=2000)),          # unconstrained: qsort ranking path
+    ("rastrigin", 12, 60, 42, 4, 0, dict(maxeval=3000)),         # stochastic ranking, 4 inequality constraints
+    ("griewank", 6, 0, 7, 2, 1, dict(maxeval=2500)),             # default population, inequality + equality
+    ("sphere", 5, 30, 3, 1, 0, dict(ftol_abs=1e-9, maxeval=20000)),
+    ("rosenbrock", 4, 35, 11, 0, 0, dict(xtol_rel=1e-4, maxeval=20000)),
+    ("levy", 3, 7, 5, 0, 2, dict(maxeval=700)),                  # pop=7: survivors = 1 (last-survivor mutation only)
+    ("sphere", 4, 50, 9, 2, 0, dict(stopval=0.05, maxeval=20000)),
+])
+def test_port_isres_matches_reference_live(obj, n, pop, seed, nineq, neq, kw):
+    a = O.run_port_isres(obj, n, pop, seed, nineq, neq, **kw)
+    b = O.run_ref_isres(obj, n, pop, seed, nineq, neq, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert a["minf"] == b["minf"]
+    assert np.array_equal(a["x"], b["x"])
+    assert np.array_equal(a["fseq"], b["fseq"])
+    assert np.array_equal(a["xhash"], b["xhash"])
+
+
+IGOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "isres_golden.json")))
+
+
+@pytest.mark.parametrize("name", sorted(IGOLD))
+def test_port_isres_matches_golden(name):
+    g = IGOLD[name]
+    r = O.run_port_isres(g["obj"], g["n"], g["pop"], g["seed"], g["nineq"], g["neq"], **g["kwargs"])
+    assert r["ret"] == g["ret"] and r["nevals"] == g["nevals"]
+    assert float(r["minf"]).hex() == g["minf"]
+    assert [float(v).hex() for v in r["x"]] == g["x"]
+    assert _fhash(r["fseq"]) == g["fseq_sha256"]
+    assert hashlib.sha256(r["xhash"].tobytes()).hexdigest() == g["xhash_sha256"]
