@@ -43,6 +43,7 @@ void nlopt_amd_objective_box(int id, double *lo, double *hi);
 /* block-sum inequality constraint g(x) = sum_{i in block q of Q} x_i - 1 <= 0 (ISRES config,
  * SURVEY.md §8d); func_data must point at `unsigned qQ[2] = {q, Q}` that outlives the run. */
 nlopt_func nlopt_amd_constraint_blocksum(void);
+int nlopt_amd_constraint_id(nlopt_func f);             /* 0: block sum, -1: not a device constraint */
 
 int nlopt_amd_device_count(void);                      /* visible HIP devices (0 => optimize fails loudly) */
 
@@ -66,6 +67,9 @@ typedef struct {
     double t_gather_ms;         /* sum of device time of the gather-sum (advance) kernel (HIP events) */
     uint64_t gather_launches;
     uint64_t gather_bytes;      /* algorithmic bytes those launches summed: 8n per row, n+1 rows per trial */
+    /* ISRES (evals are counted in evals_trial) */
+    uint64_t generations, rank_sweeps;
+    double t_eval_s, t_rank_s, t_evolve_s, t_rng_s;   /* wall seconds per phase; t_rng_s = stream-word generation inside rank/evolve */
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 
@@ -155,6 +159,56 @@ int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *T
 /* single local mutation of one candidate in place (host-callback mode, crs.c:139-146) */
 int nla_k_crs_mutate(int n, const double *best, double *p, const uint32_t *words,
                      const double *lb, const double *ub, void *stream);
+
+/* ---- ISRES (src/algs/isres/isres.c) --------------------------------------------------------------
+ * X, S (step sizes): pop x ld fp64 row-major; F/PEN/GPEN: pop fp64; FEAS: pop i32. */
+
+/* a constraint the device can evaluate; type 0 = block sum  sum_{i in block q of Q} x_i - 1 */
+typedef struct { int32_t type; uint32_t q, Q; int32_t pad; double tol; } nla_dev_constraint;
+
+/* replaces: the initial population, isres.c:122-128, for individuals k_first .. k_first+count-1
+ * (xs k-major from the stream: `words` starts at individual k_first, coordinate j of individual
+ * k uses words 2((k-k_first)n+j),+1; sigma = (ub-lb)/sqrt(n); individual 0 := x0). */
+int nla_k_isres_init(int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t k_first,
+                     int64_t count, const double *x0, double *X, double *S, void *stream);
+
+/* replaces: f and the constraint penalties of every candidate, isres.c:138-166.  con[0..m) are the
+ * inequality, con[m..m+p) the equality constraints.  PEN = sum max(g,0)^2 + sum h^2 in constraint
+ * order, GPEN = the inequality part, FEAS = every g <= tol and |h| <= tol. */
+int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t pop, int m, int p, const nla_dev_constraint *con,
+                     double *F, double *PEN, double *GPEN, int32_t *FEAS, void *stream);
+
+/* replaces: nlopt_qsort_r(irank, ..., fval, key_compare), isres.c:204 (sorted[pos] = individual,
+ * stable), and prepares the stochastic ranking: elems[k] = individual k packed with the dense ranks
+ * of its fval and penalty (layout in isres_kernels.hip).  pop <= 2^20. */
+int nla_k_isres_rank_count(int64_t pop, const double *F, const double *PEN, uint64_t *elems, int32_t *sorted, void *stream);
+
+/* replaces: u = nlopt_urand(0,1) of every ranking step, isres.c:210, reduced to the bit u < PF.
+ * words = stream words of sweeps row_first .. row_first+nrows-1 (2(pop-1) words per sweep);
+ * bits row i = ceil((pop-1)/64) u64, bit j = (u_{i,j} < 0.45). */
+int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_t pop, uint64_t *bits, void *stream);
+
+/* replaces: the stochastic ranking sweeps, isres.c:206-228, as a systolic pipeline of nsweeps
+ * stages.  streams: (ceil(nsweeps/64)+1) x pop u64, streams[0..pop) = the packed elements in
+ * initial order; progress: one int per stream (progress[0] = pop, others 0); *ticket = 0.
+ * Out: swapped[i] = sweep i exchanged something; irank[pos] = individual. */
+int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
+                          int *ticket, uint8_t *swapped, int32_t *irank, void *stream);
+
+/* replaces: nlopt_nrand(0,1), mt19937ar.c:216-232, for a run of 4-word attempts: appends the
+ * accepted deviates of attempts [attempt_base, attempt_base+nattempts) (words = their words) to
+ * z[zbase ...], zatt = their attempt indices; *ztotal += number appended.  counts: scratch,
+ * ceil(nattempts/1024) ints. */
+int nla_k_isres_nrand(const uint32_t *words, int64_t nattempts, int64_t attempt_base, int32_t *counts, int64_t *ztotal,
+                      int64_t zbase, double *z, int64_t *zatt, void *stream);
+
+/* replaces: the standard mutation (phase 0, isres.c:234-252) / differential variation (phase 1,
+ * :253-280) loops, consuming the deviates z[state[1] ...] in the reference's order.
+ * state = {next individual, next deviate, ran-out flag}; scratch = 3*ld doubles that persist
+ * between calls of one generation. */
+int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                       const double *lb, const double *ub, const double *z, const int32_t *irank, double *X, double *S,
+                       double *scratch, int64_t *state, void *stream);
 
 /* thin device-runtime layer the C host code uses (no HIP types cross the boundary) */
 int nla_dev_count(void);

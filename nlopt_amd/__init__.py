@@ -34,7 +34,9 @@ class Stats(C.Structure):
                                            "slots_role", "evals_init", "evals_trial", "evals_mutation", "accepted",
                                            "mt_words")] + \
                [("t_init_s", C.c_double), ("t_trial_s", C.c_double), ("t_gather_ms", C.c_double),
-                ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64)]
+                ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64), ("generations", C.c_uint64),
+                ("rank_sweeps", C.c_uint64), ("t_eval_s", C.c_double), ("t_rank_s", C.c_double), ("t_evolve_s", C.c_double),
+                ("t_rng_s", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -177,6 +179,9 @@ def lib():
                                     vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]
     L.nla_k_crs_finish.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int,
                                    vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.nla_k_isres_rank_count.argtypes = [C.c_int64, vp, vp, vp, vp, vp]
+    L.nla_k_isres_bits.argtypes = [vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
+    L.nla_k_isres_stochrank.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     L.nla_k_crs_commit.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_mutate.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
     L.nla_mt_jump_poly_words.argtypes = [C.c_uint64, vp]
@@ -324,6 +329,16 @@ class Opt:
 
     def add_equality_constraint(self, h, tol=0.0, f_data=None):
         return self._L.nlopt_add_equality_constraint(self._h, self._fptr(h), f_data, float(tol))
+
+    def add_blocksum_constraints(self, count, tol=1e-8, equality=False):
+        """`count` device constraints g_q(x) = sum_{i in block q of `count`} x_i - 1 (<= 0, or == 0)"""
+        data = (C.c_uint * (2 * max(count, 1)))()
+        self._keep.append(data)
+        cb = C.cast(self._L.nlopt_amd_constraint_blocksum(), C.c_void_p).value
+        add = self._L.nlopt_add_equality_constraint if equality else self._L.nlopt_add_inequality_constraint
+        for q in range(count):
+            data[2 * q], data[2 * q + 1] = q, count
+            self._ck(add(self._h, cb, C.addressof(data) + 8 * q, float(tol)))
 
     # -- stopping criteria & parameters --
     def set_stopval(self, v): self._ck(self._L.nlopt_set_stopval(self._h, float(v)))

@@ -1,0 +1,391 @@
+/* isres_driver.c — NLOPT_GN_ISRES behind the reference's entry point
+ *   isres_minimize(n, f, f_data, m, fc, p, h, lb, ub, x, minf, stop, population)   (isres.h:34-41),
+ * host side: the generation loop, the best-point/stop bookkeeping the reference runs after EVERY
+ * candidate (isres.c:168-198, replayed in candidate order over the device's f/penalty arrays), the
+ * stream accounting, and the kernel sequencing through the C-ABI launchers of include/nlopt_amd.h.
+ *
+ * One generation on the device (isres_kernels.hip):
+ *   eval      f + penalties of all pop candidates                       (isres.c:134-166)
+ *   rank      all feasible: stable sort by f (counting ranks)            (:204)
+ *             else: MT words -> "u < PF" bits -> systolic stochastic ranking; the reference's
+ *             early exit after a sweep without exchange (:227) is honoured by checking the
+ *             per-sweep flags and, if it ever fires, re-running with exactly that many sweeps
+ *   evolve    MT words -> accepted normal deviates in order -> the serial mutation / variation
+ *             chain (:234-280)
+ * The MT19937 stream position after the run equals the reference's: 2 pop n words for the initial
+ * population, 2 per ranking step actually taken, 4 per Box-Muller attempt up to the last deviate
+ * consumed.
+ *
+ * Device objective + device constraints (pointer identity, nlopt_amd.h part 1) run entirely on the
+ * GPU.  Any other callback takes the host-callback path: X is copied back and f / constraints are
+ * called on the caller's thread in the reference's order (:137-165); ranking and evolution still
+ * run on the device.  There is no CPU fallback for the device work.
+ */
+#include "nla_internal.h"
+#include "objfuncs.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define WORD_CHUNK (1ULL << 28)            /* stream words generated per pass (1 GiB) */
+
+typedef struct {
+    int n, ld, m, p, obj, dev_eval;
+    int64_t pop, survivors, units, rowwords;
+    void *st;
+    nla_mtstream *mts;
+    uint64_t words_used;
+    double *d_lb, *d_ub, *d_X, *d_S, *d_F, *d_PEN, *d_GPEN, *d_scratch, *d_z;
+    int32_t *d_FEAS, *d_irank, *d_counts;
+    int *d_progress, *d_ticket;
+    uint8_t *d_swapped;
+    uint64_t *d_streams, *d_bits;
+    int64_t *d_zatt, *d_ztotal, *d_state;
+    uint32_t *d_words;
+    nla_dev_constraint *d_con;
+    int64_t zcap;
+    double *h_F, *h_PEN, *h_GPEN, *h_X;
+    int32_t *h_FEAS;
+    uint8_t *h_swapped;
+    int *h_progress;
+    char err[200];
+} isres_dev;
+
+#define DFAIL(d, ...) do { snprintf((d)->err, sizeof (d)->err, __VA_ARGS__); return -1; } while (0)
+#define DCK(d, call) do { int rc_ = (call); if (rc_) DFAIL(d, "%s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
+
+static void dev_free_all(isres_dev *d)
+{
+    if (d->st) nla_stream_sync(d->st);
+    if (d->mts) { nla_mtstream_finish(d->mts, d->words_used); nla_mtstream_destroy(d->mts); }
+    nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_X); nla_dev_free(d->d_S); nla_dev_free(d->d_F);
+    nla_dev_free(d->d_PEN); nla_dev_free(d->d_GPEN); nla_dev_free(d->d_scratch); nla_dev_free(d->d_z); nla_dev_free(d->d_FEAS);
+    nla_dev_free(d->d_irank); nla_dev_free(d->d_counts); nla_dev_free(d->d_progress); nla_dev_free(d->d_ticket);
+    nla_dev_free(d->d_swapped); nla_dev_free(d->d_streams); nla_dev_free(d->d_bits); nla_dev_free(d->d_zatt);
+    nla_dev_free(d->d_ztotal); nla_dev_free(d->d_state); nla_dev_free(d->d_words); nla_dev_free(d->d_con);
+    nla_host_free(d->h_F); nla_host_free(d->h_PEN); nla_host_free(d->h_GPEN); nla_host_free(d->h_X); nla_host_free(d->h_FEAS);
+    nla_host_free(d->h_swapped); nla_host_free(d->h_progress);
+    if (d->st) nla_stream_destroy(d->st);
+}
+
+static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla_dev_constraint *con)
+{
+    const size_t pop = (size_t) d->pop, ld = (size_t) d->ld, n = (size_t) d->n;
+    int ok = 1;
+    d->units = (d->pop + 63) / 64;
+    d->rowwords = (d->pop - 1 + 63) / 64;
+    if (d->rowwords < 1) d->rowwords = 1;
+    d->zcap = 4 * d->pop * (1 + 2 * (int64_t) d->n) + 4096;
+    d->st = nla_stream_create();
+    if (!d->st) return -1;
+    d->mts = nla_mtstream_create(d->st);
+    if (!d->mts) return -1;
+#define A(ptr, T, count) do { d->ptr = (T *) nla_dev_malloc(sizeof(T) * (size_t) (count)); if (!d->ptr) ok = 0; } while (0)
+    A(d_lb, double, ld); A(d_ub, double, ld); A(d_X, double, pop * ld); A(d_S, double, pop * ld);
+    A(d_F, double, pop); A(d_PEN, double, pop); A(d_GPEN, double, pop); A(d_FEAS, int32_t, pop);
+    A(d_irank, int32_t, pop); A(d_scratch, double, 3 * ld);
+    A(d_streams, uint64_t, (size_t) (d->units + 1) * pop); A(d_progress, int, d->units + 1); A(d_ticket, int, 1);
+    A(d_swapped, uint8_t, pop); A(d_bits, uint64_t, pop * (size_t) d->rowwords);
+    A(d_words, uint32_t, WORD_CHUNK); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
+    A(d_counts, int32_t, WORD_CHUNK / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
+    A(d_con, nla_dev_constraint, d->m + d->p + 1);
+#undef A
+    d->h_F = (double *) nla_host_malloc(sizeof(double) * pop);
+    d->h_PEN = (double *) nla_host_malloc(sizeof(double) * pop);
+    d->h_GPEN = (double *) nla_host_malloc(sizeof(double) * pop);
+    d->h_FEAS = (int32_t *) nla_host_malloc(sizeof(int32_t) * pop);
+    d->h_swapped = (uint8_t *) nla_host_malloc(pop);
+    d->h_progress = (int *) nla_host_malloc(sizeof(int) * (size_t) (d->units + 1));
+    d->h_X = (double *) nla_host_malloc(sizeof(double) * (d->dev_eval ? n : pop * ld));
+    if (!ok || !d->h_F || !d->h_PEN || !d->h_GPEN || !d->h_FEAS || !d->h_swapped || !d->h_progress || !d->h_X) return -1;
+    if (nla_memcpy_h2d(d->d_lb, lb, sizeof(double) * n, d->st) || nla_memcpy_h2d(d->d_ub, ub, sizeof(double) * n, d->st)) return -1;
+    if (d->m + d->p > 0 && d->dev_eval && nla_memcpy_h2d(d->d_con, con, sizeof(nla_dev_constraint) * (size_t) (d->m + d->p), d->st)) return -1;
+    d->h_progress[0] = (int) d->pop;
+    for (int64_t u = 1; u <= d->units; ++u) d->h_progress[u] = 0;
+    return nla_stream_sync(d->st) ? -1 : 0;
+}
+
+/* initial population (isres.c:122-128): 2 pop n stream words, in passes of WORD_CHUNK */
+static int dev_init_population(isres_dev *d, const double *x0)
+{
+    const uint64_t wpi = 2ULL * (uint64_t) d->n;
+    int64_t per = (int64_t) (WORD_CHUNK / wpi), k0;
+    if (per < 1) DFAIL(d, "dimension too large for the word buffer");
+    DCK(d, nla_memcpy_h2d(d->d_scratch, x0, sizeof(double) * (size_t) d->n, d->st));
+    for (k0 = 0; k0 < d->pop; k0 += per) {
+        const int64_t cnt = d->pop - k0 < per ? d->pop - k0 : per;
+        if (nla_mtstream_fill(d->mts, d->words_used + wpi * (uint64_t) k0, wpi * (uint64_t) cnt, d->d_words)) DFAIL(d, "MT stream fill failed");
+        DCK(d, nla_k_isres_init(d->n, d->ld, d->d_lb, d->d_ub, d->d_words, k0, cnt, d->d_scratch, d->d_X, d->d_S, d->st));
+        DCK(d, nla_stream_sync(d->st));
+    }
+    d->words_used += wpi * (uint64_t) d->pop;
+    return 0;
+}
+
+/* selection (isres.c:202-229); *sweeps_out = ranking sweeps actually taken (0 on the sort path) */
+static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double *t_rng)
+{
+    const int64_t pop = d->pop, popm1 = pop - 1;
+    int64_t nsweeps = pop, rows_per, r0, i;
+    double t0;
+    *sweeps_out = 0;
+    DCK(d, nla_k_isres_rank_count(pop, d->d_F, d->d_PEN, d->d_streams, d->d_irank, d->st));
+    if (all_feasible || popm1 <= 0) return 0;      /* irank = stable sort by f (or the single individual) */
+    /* the uniforms of all pop sweeps, reduced to bits, generated in whole-sweep passes */
+    t0 = nla_seconds();
+    rows_per = (int64_t) (WORD_CHUNK / (2ULL * (uint64_t) popm1));
+    if (rows_per < 1) DFAIL(d, "population too large for the word buffer");
+    for (r0 = 0; r0 < pop; r0 += rows_per) {
+        const int64_t nr = pop - r0 < rows_per ? pop - r0 : rows_per;
+        if (nla_mtstream_fill(d->mts, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) r0, 2ULL * (uint64_t) popm1 * (uint64_t) nr, d->d_words))
+            DFAIL(d, "MT stream fill failed");
+        DCK(d, nla_k_isres_bits(d->d_words, r0, (int) nr, pop, d->d_bits, d->st));
+    }
+    DCK(d, nla_stream_sync(d->st));
+    *t_rng += nla_seconds() - t0;
+    for (;;) {
+        DCK(d, nla_memcpy_h2d(d->d_progress, d->h_progress, sizeof(int) * (size_t) (d->units + 1), d->st));
+        DCK(d, nla_memset(d->d_ticket, 0, sizeof(int), d->st));
+        DCK(d, nla_k_isres_stochrank(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank, d->st));
+        DCK(d, nla_memcpy_d2h(d->h_swapped, d->d_swapped, (size_t) nsweeps, d->st));
+        DCK(d, nla_stream_sync(d->st));
+        for (i = 0; i < nsweeps; ++i) if (!d->h_swapped[i]) break;      /* `if (!swapped) break;` isres.c:227 */
+        if (i >= nsweeps - 1) break;               /* no early exit, or it was the last sweep anyway */
+        nsweeps = i + 1;                           /* the reference stopped after sweep i: redo exactly that */
+    }
+    *sweeps_out = nsweeps;
+    d->words_used += 2ULL * (uint64_t) popm1 * (uint64_t) nsweeps;
+    return 0;
+}
+
+/* append the accepted deviates of `nattempts` further attempts of the evolve phase */
+static int dev_more_deviates(isres_dev *d, uint64_t phase_word0, int64_t *attempts_done, int64_t nattempts, int64_t *zcount)
+{
+    while (nattempts > 0) {
+        int64_t a = nattempts < (int64_t) (WORD_CHUNK / 4) ? nattempts : (int64_t) (WORD_CHUNK / 4), zt;
+        if (*zcount + a > d->zcap) a = d->zcap - *zcount;
+        if (a <= 0) DFAIL(d, "deviate buffer exhausted");
+        if (nla_mtstream_fill(d->mts, phase_word0 + 4ULL * (uint64_t) *attempts_done, 4ULL * (uint64_t) a, d->d_words)) DFAIL(d, "MT stream fill failed");
+        DCK(d, nla_k_isres_nrand(d->d_words, a, *attempts_done, d->d_counts, d->d_ztotal, *zcount, d->d_z, d->d_zatt, d->st));
+        DCK(d, nla_memcpy_d2h(&zt, d->d_ztotal, sizeof zt, d->st));
+        DCK(d, nla_stream_sync(d->st));
+        *zcount = zt;
+        *attempts_done += a;
+        nattempts -= a;
+    }
+    return 0;
+}
+
+/* mutation + variation (isres.c:234-280) */
+static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
+{
+    const uint64_t word0 = d->words_used;
+    const int64_t expect = d->pop * (1 + 2 * (int64_t) d->n);
+    int64_t attempts_done = 0, zcount = 0, state[16] = { 0 }, last_att;
+    double t0 = nla_seconds();
+    int phase;
+    DCK(d, nla_memset(d->d_ztotal, 0, sizeof(int64_t), d->st));
+    if (dev_more_deviates(d, word0, &attempts_done, (int64_t) (1.35 * (double) expect / 0.785) + 4096, &zcount)) return -1;
+    *t_rng += nla_seconds() - t0;
+    for (phase = 0; phase < 2; ++phase) {
+        state[0] = phase == 0 ? d->survivors : 0;
+        state[2] = 0;
+        DCK(d, nla_memcpy_h2d(d->d_state, state, sizeof state, d->st));
+        DCK(d, nla_stream_sync(d->st));
+        for (;;) {
+            DCK(d, nla_k_isres_evolve(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z, d->d_irank,
+                                      d->d_X, d->d_S, d->d_scratch, d->d_state, d->st));
+            DCK(d, nla_memcpy_d2h(state, d->d_state, sizeof state, d->st));
+            DCK(d, nla_stream_sync(d->st));
+            if (!state[2]) break;
+            t0 = nla_seconds();
+            if (dev_more_deviates(d, word0, &attempts_done, (int64_t) (0.5 * (double) expect / 0.785) + 4096, &zcount)) return -1;
+            *t_rng += nla_seconds() - t0;
+        }
+    }
+    if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve: fixpoint rounds %lld for %lld individuals, deviates %lld; cycles stage %lld eval %lld scan %lld fin %lld all %lld\n", (long long) state[3], (long long) d->pop, (long long) state[1], (long long) state[4], (long long) state[5], (long long) state[6], (long long) state[7], (long long) state[8]);
+    if (state[1] <= 0) DFAIL(d, "evolve consumed no deviates");
+    DCK(d, nla_memcpy_d2h(&last_att, d->d_zatt + (state[1] - 1), sizeof last_att, d->st));
+    DCK(d, nla_stream_sync(d->st));
+    d->words_used += 4ULL * (uint64_t) (last_att + 1);
+    return 0;
+}
+
+static int con_eval_host(const nla_constraint *c, unsigned n, const double *x, double *res)
+{
+    if (c->f) res[0] = c->f(n, x, NULL, c->f_data);
+    else c->mf(c->m, res, n, x, NULL, c->f_data);
+    return 0;
+}
+
+nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, int m, nla_constraint *fc, int p, nla_constraint *h,
+                                const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, int population)
+{
+    const double PHI = 1.0, SURVIVOR = 1.0 / 7.0;                 /* isres.c:71-73 */
+    isres_dev D;
+    nlopt_result ret = NLOPT_SUCCESS;
+    nla_dev_constraint *con = NULL;
+    nlopt_amd_stats *st = opt ? &opt->stats : NULL;
+    double minf_penalty = HUGE_VAL, minf_gpenalty = HUGE_VAL, taup, tau, *results = NULL;
+    unsigned maxdim = 1;
+    int j, c, dev_eval;
+    const int need_x = stop->xtol_rel > 0 || stop->xtol_abs != NULL;
+    int64_t k;
+
+    *minf = HUGE_VAL;
+    if (!population) population = 20 * (n + 1);                                        /* :88 */
+    if (population < 1) { nla_stop_msg(stop, "population %d is too small", population); return NLOPT_INVALID_ARGS; }
+    taup = PHI / sqrt(2 * n);
+    tau = PHI / sqrt(2 * sqrt(n));
+    for (j = 0; j < n; ++j)
+        if (nla_isinf(lb[j]) || nla_isinf(ub[j])) { nla_stop_msg(stop, "isres requires a finite search region"); return NLOPT_INVALID_ARGS; }
+    if (nla_dev_count() <= 0) {
+        nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
+        return NLOPT_FAILURE;
+    }
+    if (population > (1 << 20)) { nla_stop_msg(stop, "nlopt_amd: ISRES populations above 2^20 are not supported"); return NLOPT_INVALID_ARGS; }
+
+    /* can everything be evaluated on the device? */
+    memset(&D, 0, sizeof D);
+    D.obj = nlopt_amd_objective_id(f);
+    dev_eval = D.obj >= 0 && !(opt && nlopt_get_param(opt, "amd_host_eval", 0) != 0);
+    con = (nla_dev_constraint *) calloc((size_t) (m + p + 1), sizeof *con);
+    if (!con) return NLOPT_OUT_OF_MEMORY;
+    for (c = 0; c < m + p; ++c) {
+        const nla_constraint *cc = c < m ? fc + c : h + (c - m);
+        if (cc->m > maxdim) maxdim = cc->m;
+        if (cc->f && cc->m == 1 && nlopt_amd_constraint_id(cc->f) == NLA_CON_BLOCKSUM && cc->f_data) {
+            const unsigned *qQ = (const unsigned *) cc->f_data;
+            con[c].type = NLA_CON_BLOCKSUM; con[c].q = qQ[0]; con[c].Q = qQ[1]; con[c].tol = cc->tol[0];
+            if (qQ[1] == 0 || qQ[0] >= qQ[1]) dev_eval = 0;
+        } else dev_eval = 0;
+    }
+    results = (double *) malloc(sizeof(double) * maxdim);
+    if (!results) { free(con); return NLOPT_OUT_OF_MEMORY; }
+
+    D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
+    D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */
+    if (dev_alloc(&D, lb, ub, con)) {
+        nla_stop_msg(stop, "nlopt_amd: could not create the ISRES device state (out of device memory?)");
+        dev_free_all(&D); free(con); free(results);
+        return NLOPT_OUT_OF_MEMORY;
+    }
+#define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
+    if (dev_init_population(&D, x)) DEVFAIL();
+
+    for (;;) {                                       /* each loop body = one generation (isres.c:130) */
+        int all_feasible = 1;
+        int64_t kbest = -1, sweeps = 0;
+        double t0 = nla_seconds(), t_rng = 0;
+        if (dev_eval) {
+            if (nla_k_isres_eval(D.obj, n, D.ld, D.d_X, D.pop, m, p, D.d_con, D.d_F, D.d_PEN, D.d_GPEN, D.d_FEAS, D.st) ||
+                nla_memcpy_d2h(D.h_F, D.d_F, sizeof(double) * (size_t) D.pop, D.st) ||
+                nla_memcpy_d2h(D.h_PEN, D.d_PEN, sizeof(double) * (size_t) D.pop, D.st) ||
+                nla_memcpy_d2h(D.h_GPEN, D.d_GPEN, sizeof(double) * (size_t) D.pop, D.st) ||
+                nla_memcpy_d2h(D.h_FEAS, D.d_FEAS, sizeof(int32_t) * (size_t) D.pop, D.st) || nla_stream_sync(D.st)) {
+                snprintf(D.err, sizeof D.err, "evaluation pass failed");
+                DEVFAIL();
+            }
+        } else if (nla_memcpy_d2h(D.h_X, D.d_X, sizeof(double) * (size_t) D.pop * (size_t) D.ld, D.st) || nla_stream_sync(D.st)) {
+            snprintf(D.err, sizeof D.err, "population read-back failed");
+            DEVFAIL();
+        }
+        if (st) st->t_eval_s += nla_seconds() - t0;
+
+        /* the reference's per-candidate bookkeeping, in candidate order (isres.c:134-199) */
+        for (k = 0; k < D.pop; ++k) {
+            int feasible = 1;
+            double gpenalty, fk, pk;
+            const double *xk = NULL;
+            ++*stop->nevals_p;
+            if (dev_eval) { fk = D.h_F[k]; pk = D.h_PEN[k]; gpenalty = D.h_GPEN[k]; feasible = D.h_FEAS[k]; }
+            else {
+                unsigned ires;
+                xk = D.h_X + (size_t) k * (size_t) D.ld;
+                fk = f((unsigned) n, xk, NULL, f_data);
+                if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; goto done; }
+                pk = 0;
+                for (c = 0; c < m; ++c) {
+                    con_eval_host(fc + c, (unsigned) n, xk, results);
+                    if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; goto done; }
+                    for (ires = 0; ires < fc[c].m; ++ires) {
+                        double gval = results[ires];
+                        if (gval > fc[c].tol[ires]) feasible = 0;
+                        if (gval < 0) gval = 0;
+                        pk += gval * gval;
+                    }
+                }
+                gpenalty = pk;
+                for (c = 0; c < p; ++c) {
+                    con_eval_host(h + c, (unsigned) n, xk, results);
+                    if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; goto done; }
+                    for (ires = 0; ires < h[c].m; ++ires) {
+                        double hval = results[ires];
+                        if (fabs(hval) > h[c].tol[ires]) feasible = 0;
+                        pk += hval * hval;
+                    }
+                }
+                D.h_F[k] = fk; D.h_PEN[k] = pk;
+            }
+            if (st) ++st->evals_trial;
+            if (opt && opt->trace) {
+                if (opt->trace_len < opt->trace_cap) {
+                    nlopt_amd_trace_rec *r = opt->trace + opt->trace_len;
+                    r->f = fk; r->row = k; r->kind = 3; r->accepted = feasible;
+                }
+                ++opt->trace_len;
+            }
+            if (pk > 0) all_feasible = 0;
+            if ((pk <= minf_penalty || feasible) && (fk <= *minf || minf_gpenalty > 0)
+                && ((feasible ? 0 : pk) != minf_penalty || fk != *minf)) {                       /* :174-177 */
+                if (dev_eval && need_x) {          /* nlopt_stop_x / later comparisons need this candidate: fetch it (rare) */
+                    if (nla_memcpy_d2h(D.h_X, D.d_X + (size_t) k * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) {
+                        snprintf(D.err, sizeof D.err, "candidate read-back failed");
+                        DEVFAIL();
+                    }
+                    xk = D.h_X;
+                }
+                if (fk < stop->minf_max && feasible) ret = NLOPT_MINF_MAX_REACHED;
+                else if (!nla_isinf(*minf)) {
+                    if (nla_stop_f(stop, fk, *minf) && nla_stop_f(stop, feasible ? 0 : pk, minf_penalty)) ret = NLOPT_FTOL_REACHED;
+                    else if (need_x && nla_stop_x(stop, xk, x)) ret = NLOPT_XTOL_REACHED;
+                }
+                if (xk) { memcpy(x, xk, sizeof(double) * (size_t) n); kbest = -1; }   /* memcpy(x, xs+k*n), isres.c:188 */
+                else kbest = k;                                                     /* ... deferred to one read-back per generation */
+                *minf = fk;
+                minf_penalty = feasible ? 0 : pk;
+                minf_gpenalty = feasible ? 0 : gpenalty;
+                if (ret != NLOPT_SUCCESS) break;
+            }
+            if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP;
+            else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
+            else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
+            if (ret != NLOPT_SUCCESS) break;
+        }
+        if (kbest >= 0) {                          /* the last accepted best of this generation -> x */
+            if (nla_memcpy_d2h(x, D.d_X + (size_t) kbest * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) {
+                snprintf(D.err, sizeof D.err, "best-point read-back failed");
+                DEVFAIL();
+            }
+        }
+        if (ret != NLOPT_SUCCESS) goto done;
+        if (!dev_eval) {                           /* the ranking kernels read f / penalty from the device */
+            if (nla_memcpy_h2d(D.d_F, D.h_F, sizeof(double) * (size_t) D.pop, D.st) ||
+                nla_memcpy_h2d(D.d_PEN, D.h_PEN, sizeof(double) * (size_t) D.pop, D.st)) { snprintf(D.err, sizeof D.err, "upload failed"); DEVFAIL(); }
+        }
+
+        t0 = nla_seconds();
+        if (dev_rank(&D, all_feasible, &sweeps, &t_rng)) DEVFAIL();
+        if (st) { st->t_rank_s += nla_seconds() - t0; st->rank_sweeps += (uint64_t) sweeps; }
+        t0 = nla_seconds();
+        if (dev_evolve(&D, taup, tau, &t_rng)) DEVFAIL();
+        if (st) { st->t_evolve_s += nla_seconds() - t0; st->t_rng_s += t_rng; ++st->generations; st->mt_words = D.words_used; }
+    }
+done:
+    if (st) st->mt_words = D.words_used;
+    dev_free_all(&D);
+    free(con);
+    free(results);
+    return ret;
+}

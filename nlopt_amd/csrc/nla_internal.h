@@ -167,6 +167,10 @@ nlopt_result nla_crs_end(nla_crs_session *S, uint64_t *words_used);
 nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *engine, const nla_crs_problem *pb,
                          double *x, double *minf, uint64_t *words_used);
 
+/* reference-shaped entry (src/algs/isres/isres.h:34-41) */
+nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, int m, nla_constraint *fc, int p, nla_constraint *h,
+                                const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, int population);
+
 /* HIP engine (crs_engine.c) */
 typedef struct nla_crs_hip_engine nla_crs_hip_engine;
 nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj,

@@ -36,5 +36,6 @@ static double cb_blocksum(unsigned n, const double *x, double *grad, void *data)
     return nla_con_blocksum_seq(n, x, grad, qQ[0], qQ[1]);
 }
 nlopt_func nlopt_amd_constraint_blocksum(void) { return cb_blocksum; }
+int nlopt_amd_constraint_id(nlopt_func f) { return f == cb_blocksum ? NLA_CON_BLOCKSUM : -1; }
 
 int nlopt_amd_device_count(void) { return nla_dev_count(); }

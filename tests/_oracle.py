@@ -213,7 +213,9 @@ class Stats(C.Structure):
                                            "slots_role", "evals_init", "evals_trial", "evals_mutation", "accepted",
                                            "mt_words")] + \
                [("t_init_s", C.c_double), ("t_trial_s", C.c_double), ("t_gather_ms", C.c_double),
-                ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64)]
+                ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64), ("generations", C.c_uint64),
+                ("rank_sweeps", C.c_uint64), ("t_eval_s", C.c_double), ("t_rank_s", C.c_double), ("t_evolve_s", C.c_double),
+                ("t_rng_s", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

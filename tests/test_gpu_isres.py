@@ -1,0 +1,170 @@
+"""-m gpu: NLOPT_GN_ISRES end to end through the public C API of libnlopt_amd.so against the CPU
+oracle (oracle/port_isres.c, pinned to the real reference) and the golden vectors generated from the
+real reference.  Bar: the same evaluation sequence — f and penalty of every candidate of every
+generation within 1e-10 relative (device libm vs glibc in cos/exp/log), which implies the same
+rank order, the same redraw counts and the same parents — the same numevals / result code and the
+same MT19937 consumption (exact), the argmin within 1e-9 relative."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import nlopt_amd
+
+pytestmark = pytest.mark.gpu
+IGOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "isres_golden.json")))
+RTOL = 1e-10
+
+
+def run_amd(obj, n, pop, seed, nineq=0, neq=0, tol=1e-8, maxeval=0, stopval=None, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0,
+            params=None, host_callback=None, trace_cap=None):
+    assert nlopt_amd.device_count() > 0, "no HIP device: the product has no CPU fallback"
+    xs, lo, hi = O.golden_x0(obj, n)
+    o = nlopt_amd.Opt(nlopt_amd.GN_ISRES, n)
+    o.set_lower_bounds(lo)
+    o.set_upper_bounds(hi)
+    o.set_min_objective(host_callback if host_callback is not None else nlopt_amd.objective(obj))
+    o.add_blocksum_constraints(nineq, tol)
+    o.add_blocksum_constraints(neq, tol, equality=True)
+    if pop:
+        o.set_population(pop)
+    if maxeval:
+        o.set_maxeval(maxeval)
+    if stopval is not None:
+        o.set_stopval(stopval)
+    if ftol_rel:
+        o.set_ftol_rel(ftol_rel)
+    if ftol_abs:
+        o.set_ftol_abs(ftol_abs)
+    if xtol_rel:
+        o.set_xtol_rel(xtol_rel)
+    for k, v in (params or {}).items():
+        o.set_param(k, v)
+    cap = trace_cap or (maxeval or 200000) + 16
+    o.enable_trace(cap)
+    nlopt_amd.srand(seed)
+    x, minf, ret = o.optimize_raw(xs)
+    return dict(ret=ret, minf=minf, x=x, nevals=o.get_numevals(), trace=o.trace(), stats=o.stats(), err=o.get_errmsg())
+
+
+def assert_same_run(a, p, exact=False):
+    assert a["ret"] == p["ret"], (a["ret"], p["ret"], a["err"])
+    assert a["nevals"] == p["nevals"]
+    fa, fp = a["trace"]["f"], p["ftrace"]
+    assert len(fa) == len(fp)
+    scale = max(np.abs(fp).mean(), 1e-300)
+    bad = np.nonzero(np.abs(fa - fp) > RTOL * np.maximum(np.abs(fp), scale))[0]
+    assert len(bad) == 0, "first differing evaluation: %d of %d (%r vs %r)" % (bad[0], len(fp), fa[bad[0]], fp[bad[0]])
+    assert abs(a["minf"] - p["minf"]) <= RTOL * max(abs(p["minf"]), scale)
+    assert np.allclose(a["x"], p["x"], rtol=1e-9, atol=1e-9 * np.abs(p["x"]).max())
+    assert a["stats"]["mt_words"] == p["words"]          # same stream position: ranking sweeps and redraw counts agree
+    if exact:
+        assert np.array_equal(fa, fp) and np.array_equal(a["x"], p["x"])
+
+
+@pytest.mark.parametrize("name", sorted(IGOLD))
+def test_isres_matches_oracle_on_golden_cases(name):
+    g = IGOLD[name]
+    a = run_amd(g["obj"], g["n"], g["pop"], g["seed"], g["nineq"], g["neq"], **g["kwargs"])
+    p = O.run_port_isres(g["obj"], g["n"], g["pop"], g["seed"], g["nineq"], g["neq"], **g["kwargs"])
+    assert_same_run(a, p)
+    assert a["ret"] == g["ret"] and a["nevals"] == g["nevals"]
+    assert abs(a["minf"] - float.fromhex(g["minf"])) <= RTOL * max(abs(float.fromhex(g["minf"])), 1e-300) or a["ret"] == 2
+
+
+@pytest.mark.parametrize("obj,n,pop,seed,nineq,neq,kw", [
+    ("rastrigin", 64, 1400, 42, 4, 0, dict(maxeval=7000)),        # 5 generations, stochastic ranking, n = one lane chunk
+    ("rastrigin", 256, 700, 7, 4, 0, dict(maxeval=3500)),         # the config-3 shape at small population
+    ("griewank", 130, 300, 3, 0, 3, dict(maxeval=2400)),          # equality constraints, odd chunking (n = 130)
+    ("ackley", 20, 129, 11, 0, 0, dict(maxeval=1290)),            # unconstrained: sort path; pop = 2*64+1
+    ("sphere", 3, 65, 5, 1, 0, dict(maxeval=1300)),               # tiny n: large step sizes -> many redraws
+    ("rastrigin", 2, 64, 9, 1, 0, dict(maxeval=1920)),
+    ("sphere", 2100, 40, 3, 2, 0, dict(maxeval=200)),             # n beyond the LDS-staged evolve kernel: generic path
+    ("rastrigin", 1150, 30, 3, 0, 1, dict(maxeval=120)),          # largest n of the LDS-staged kernel
+])
+def test_isres_matches_oracle_larger(obj, n, pop, seed, nineq, neq, kw):
+    a = run_amd(obj, n, pop, seed, nineq, neq, **kw)
+    p = O.run_port_isres(obj, n, pop, seed, nineq, neq, **kw)
+    assert_same_run(a, p)
+    assert a["stats"]["generations"] >= 1
+
+
+def test_isres_host_callback_path_is_exact():
+    """a user callback the library does not know: f and the constraints run on the host in the
+    reference's order; ranking and evolution on the device.  f sequence bit-exact."""
+    P = O.port()
+    f = P.orc_objective(O.OBJ["rastrigin"])
+    a = run_amd("rastrigin", 12, 60, 42, 4, 0, maxeval=1500, host_callback=f, params={})
+    p = O.run_port_isres("rastrigin", 12, 60, 42, 4, 0, maxeval=1500)
+    assert_same_run(a, p)
+    assert np.array_equal(a["trace"]["f"][:60], p["ftrace"][:60])     # host arithmetic for f: generation 0 is bit-exact
+    # forcing the host path for a device objective gives the same run
+    b = run_amd("rastrigin", 12, 60, 42, 4, 0, maxeval=1500, params={"amd_host_eval": 1})
+    assert_same_run(b, p)
+
+
+def test_isres_argument_errors():
+    o = nlopt_amd.Opt(nlopt_amd.GN_ISRES, 3)
+    o.set_min_objective(nlopt_amd.objective("sphere"))
+    x, minf, ret = o.optimize_raw(np.zeros(3))
+    assert ret == nlopt_amd.INVALID_ARGS and "finite domain" in o.get_errmsg()
+
+
+def _serial_stochrank(f, pen, bits_fn, pop, nsweeps):
+    irank = list(range(pop))
+    sweeps = 0
+    for i in range(nsweeps):
+        swapped = False
+        for j in range(pop - 1):
+            a, b = irank[j], irank[j + 1]
+            if bits_fn(i, j) or (pen[a] == 0 and pen[b] == 0):
+                sw = f[a] > f[b]
+            else:
+                sw = pen[a] > pen[b]
+            if sw:
+                irank[j], irank[j + 1] = b, a
+                swapped = True
+        sweeps += 1
+        if not swapped:
+            break
+    return irank, sweeps
+
+
+@pytest.mark.parametrize("pop,seed", [(2, 1), (5, 2), (64, 3), (65, 4), (130, 5), (300, 6)])
+def test_stochastic_ranking_kernels_against_serial_loop(pop, seed):
+    """bits + systolic ranking vs the reference's double loop written out in Python (isres.c:206-228)"""
+    from nlopt_amd import DevBuf
+    L = nlopt_amd.lib()
+    rng = np.random.default_rng(seed)
+    f = rng.integers(0, pop // 2 + 2, pop).astype(np.float64)               # many ties
+    pen = np.where(rng.random(pop) < 0.4, 0.0, rng.integers(1, 6, pop).astype(np.float64))
+    words = rng.integers(0, 2**32, 2 * pop * (pop - 1), dtype=np.uint64).astype(np.uint32)
+    u = ((words[0::2] >> 5).astype(np.float64) * 67108864.0 + (words[1::2] >> 6).astype(np.float64)) * (1.0 / 9007199254740992.0)
+    low = (0.0 + (1.0 - 0.0) * u) < 0.45
+    ref, sweeps = _serial_stochrank(f, pen, lambda i, j: bool(low[i * (pop - 1) + j]), pop, pop)
+    units = (pop + 63) // 64
+    roww = max((pop - 1 + 63) // 64, 1)
+    dF, dP, dW = DevBuf.from_array(f), DevBuf.from_array(pen), DevBuf.from_array(words)
+    dstreams, dsorted = DevBuf(8 * (units + 1) * pop), DevBuf(4 * pop)
+    dbits, dsw, dirank = DevBuf(8 * pop * roww), DevBuf(pop), DevBuf(4 * pop)
+    prog = np.zeros(units + 1, np.int32)
+    prog[0] = pop
+    dprog, dticket = DevBuf.from_array(prog), DevBuf.from_array(np.zeros(1, np.int32))
+    assert L.nla_k_isres_rank_count(pop, dF.ptr, dP.ptr, dstreams.ptr, dsorted.ptr, None) == 0
+    assert L.nla_k_isres_bits(dW.ptr, 0, pop, pop, dbits.ptr, None) == 0
+    assert L.nla_k_isres_stochrank(pop, pop, dstreams.ptr, dprog.ptr, dbits.ptr, dticket.ptr, dsw.ptr, dirank.ptr, None) == 0
+    assert L.nla_stream_sync(None) == 0
+    sw = dsw.to_array(np.uint8, pop)
+    first_quiet = next((i for i in range(pop) if not sw[i]), pop)
+    assert first_quiet + 1 == sweeps or (first_quiet == pop and sweeps == pop)
+    if sweeps < pop:                   # the reference stopped early: rerun with exactly that many sweeps
+        dprog2, dticket2 = DevBuf.from_array(prog), DevBuf.from_array(np.zeros(1, np.int32))
+        assert L.nla_k_isres_stochrank(pop, sweeps, dstreams.ptr, dprog2.ptr, dbits.ptr, dticket2.ptr, dsw.ptr, dirank.ptr, None) == 0
+        assert L.nla_stream_sync(None) == 0
+    assert list(dirank.to_array(np.int32, pop)) == ref
+    # the stable sort by f used when everything is feasible
+    order = sorted(range(pop), key=lambda k: (f[k], k))
+    assert list(dsorted.to_array(np.int32, pop)) == order
