@@ -73,6 +73,10 @@ int orc_isres_minimize(int n, orc_func f, void *f_data, int m, const orc_constra
                        const double *lb, const double *ub, double *x, double *minf, orc_stop *stop, long population,
                        orc_isres_trace *trace);
 
+/* ---- LD_LBFGS (src/algs/luksan/plis.c) -------------------------------------------------------- */
+int orc_lbfgs_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+                       orc_stop *stop, int mf, double tolg);
+
 /* ---- objective zoo callbacks (objfuncs.h compiled for the host) ------------------------------ */
 orc_func orc_objective(int id);                     /* f_data ignored */
 double orc_con_blocksum(unsigned n, const double *x, double *grad, void *data); /* data -> unsigned[2]={q,Q} */

@@ -334,3 +334,42 @@ def run_ref_isres(obj, n, pop, seed, nineq=0, neq=0, tol=1e-8, **kw):
             assert R.nlopt_add_equality_constraint(opt, con, C.addressof(de) + 8 * q, tol) > 0
         return (di, de)
     return run_ref(35, obj, n, pop, seed, setup=setup, **kw)
+
+
+# ---- LD_LBFGS ---------------------------------------------------------------------------------
+def run_port_lbfgs(obj, n, seed=None, x0=None, maxeval=0, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0, stopval=None, mf=0, tolg=0.0,
+                   lb=None, ub=None):
+    L = port()
+    L.orc_lbfgs_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OrcStop), C.c_int, C.c_double]
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lbv = np.full(n, lo) if lb is None else np.array(lb, dtype=np.float64)
+    ubv = np.full(n, hi) if ub is None else np.array(ub, dtype=np.float64)
+    st = OrcStop()
+    L.orc_stop_default(C.byref(st), n)
+    st.maxeval = maxeval
+    st.ftol_rel, st.ftol_abs, st.xtol_rel = ftol_rel, ftol_abs, xtol_rel
+    if stopval is not None:
+        st.minf_max = stopval
+    f = L.orc_objective(OBJ[obj])
+    cap = (maxeval or 100000) + 16
+    fbuf = np.zeros(cap)
+    hbuf = np.zeros(cap, dtype=np.uint64)
+    rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
+    minf = C.c_double()
+    ret = L.orc_lbfgs_minimize(n, C.cast(L.orc_recording_callback, C.c_void_p).value, C.cast(C.pointer(rec), C.c_void_p),
+                               dptr(lbv), dptr(ubv), dptr(x), C.byref(minf), C.byref(st), mf, tolg)
+    return dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, fseq=fbuf[:rec.len].copy(), xhash=hbuf[:rec.len].copy())
+
+
+def run_ref_lbfgs(obj, n, x0=None, mf=0, lb=None, ub=None, **kw):
+    def setup(R, opt):
+        R.nlopt_set_vector_storage.argtypes = [C.c_void_p, C.c_uint]
+        if mf:
+            R.nlopt_set_vector_storage(opt, mf)
+        if lb is not None:
+            R.nlopt_set_lower_bounds(opt, dptr(np.array(lb, dtype=np.float64)))
+        if ub is not None:
+            R.nlopt_set_upper_bounds(opt, dptr(np.array(ub, dtype=np.float64)))
+    return run_ref(11, obj, n, 0, 0, x0=x0, setup=setup, **kw)

@@ -123,3 +123,43 @@ def test_port_isres_matches_golden(name):
     assert [float(v).hex() for v in r["x"]] == g["x"]
     assert _fhash(r["fseq"]) == g["fseq_sha256"]
     assert hashlib.sha256(r["xhash"].tobytes()).hexdigest() == g["xhash_sha256"]
+
+
+# ---- LD_LBFGS ---------------------------------------------------------------------------------
+@need_ref
+@pytest.mark.parametrize("obj,n,kw", [
+    ("sphere", 8, dict()),
+    ("rosenbrock", 10, dict(maxeval=2000)),
+    ("rosenbrock", 2, dict(ftol_rel=1e-10)),
+    ("ackley", 30, dict(ftol_rel=1e-8)),
+    ("rastrigin", 20, dict(ftol_rel=1e-8)),
+    ("griewank", 12, dict(xtol_rel=1e-6)),
+    ("levy", 7, dict(ftol_abs=1e-12)),
+    ("ackley", 200, dict(ftol_rel=1e-8, mf=5)),
+    ("rastrigin", 64, dict(maxeval=37)),
+    ("sphere", 6, dict(stopval=1e-3)),
+])
+def test_port_lbfgs_matches_reference_live(obj, n, kw):
+    a = O.run_port_lbfgs(obj, n, **kw)
+    b = O.run_ref_lbfgs(obj, n, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+    assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
+
+
+@need_ref
+def test_port_lbfgs_active_bounds_match_reference():
+    """start points and boxes that put coordinates on their bounds: projection, active set, release"""
+    rng = np.random.default_rng(3)
+    for n, obj in ((9, "sphere"), (14, "rastrigin"), (6, "rosenbrock")):
+        lb = -rng.uniform(0.1, 2.0, n)
+        ub = rng.uniform(0.1, 2.0, n)
+        lb[::3] = 0.3          # the unconstrained minimiser (0 or 1) lies outside on these coordinates
+        ub[::3] = 2.5
+        x0 = np.clip(rng.uniform(-2, 2, n), lb, ub)
+        x0[1] = ub[1]
+        a = O.run_port_lbfgs(obj, n, x0=x0, lb=lb, ub=ub, ftol_rel=1e-10)
+        b = O.run_ref_lbfgs(obj, n, x0=x0, lb=lb, ub=ub, ftol_rel=1e-10)
+        assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+        assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+        assert np.array_equal(a["x"], b["x"])
