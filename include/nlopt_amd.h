@@ -210,6 +210,21 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
                        const double *lb, const double *ub, const double *z, const int32_t *irank, double *X, double *S,
                        double *scratch, int64_t *state, void *stream);
 
+/* ---- LD_LBFGS (src/algs/luksan/plis.c), batched ----------------------------------------------------- */
+typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, tolg; int32_t maxeval, pad; } nla_lbfgs_params;
+typedef struct { double f; int32_t ret, nevals, iterm, pad; } nla_lbfgs_result;
+size_t nla_lbfgs_work_doubles(int ld, int mf, int count);     /* doubles of `work` */
+size_t nla_lbfgs_hist_doubles(int ld, int mf, int count);     /* doubles of `hist` */
+
+/* replaces: luksan_plis (plis.c:420-510) for `count` independent starts at once, one workgroup per
+ * start, the whole optimisation loop on the device.  X: count x ld, start points in, minimisers
+ * out; lb/ub: the box (n); mf: history pairs kept (plis.c:441-445 computed by the caller); work /
+ * iwork (count*ld ints) / hist: scratch sized by the helpers above; out[i] = (f, nlopt_result,
+ * evaluations, PLIS termination code) of start i. */
+int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
+                      double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
+                      void *stream);
+
 /* thin device-runtime layer the C host code uses (no HIP types cross the boundary) */
 int nla_dev_count(void);
 int nla_dev_set(int dev);

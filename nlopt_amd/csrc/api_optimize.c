@@ -79,6 +79,9 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
     case NLOPT_GN_CRS2_LM:                                                               /* optimize.c:744-747 */
         if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
         return nla_crs_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, POP(opt, 0));
+    case NLOPT_LD_LBFGS:                                                                 /* optimize.c:716-718 */
+        return nla_lbfgs_minimize((int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, (int) opt->vector_storage,
+                                  nlopt_get_param(opt, "tolg", 0.));
     case NLOPT_GN_ISRES:                                                                 /* optimize.c:941-944 */
         if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
         return nla_isres_minimize(opt, (int) n, opt->f, opt->f_data, (int) opt->m, opt->fc, (int) opt->p, opt->h, opt->lb, opt->ub,

@@ -1,0 +1,387 @@
+/* lbfgs_kernels.hip — batched NLOPT_LD_LBFGS (Luksan's PLIS, src/algs/luksan/plis.c:106-417) on gfx950:
+ * one workgroup per local search, the whole optimisation loop on the device.
+ *
+ * Reference loops replaced: the Strang recurrences mxdrcb / mxdrcf over the k <= mf history pairs
+ * (mssubs.c:353-441: k sequential dot + axpy pairs each), the masked vector kernels mxudot /
+ * mxudir / mxuneg (mssubs.c:601-790), the bound handling pcbs04 / pyadc0 / pyrmc0 / pytrcg /
+ * pytrcs / pytrcd (pssubs.c), and the objective + gradient evaluation.  The scalar control flow —
+ * line search PS1L01 / PNINT1 and the termination test PYFUT1 — is the shared source
+ * ../lbfgs_scalar.h, executed redundantly by every thread on workgroup-uniform values, so a local
+ * search needs no host round trip at all.
+ *
+ * Roofline: HBM/L2 traffic of the history, 32 k n bytes per iteration (k columns, two matrices, a
+ * dot and an axpy pass each); one workgroup streams its own 2 x mf x n history (21 MB at n = 4096),
+ * the batch keeps every CU busy.  History layout: per instance mf columns of ld doubles for the
+ * x-differences, then mf for the g-differences; the reference shifts all columns every iteration
+ * (mxdrsu, mssubs.c:503-524) — here column "i-th newest" is ring-indexed, same numbers.
+ *
+ * Numerics: per-element formulas and the order of the scalar logic are the reference's; dot
+ * products are workgroup reductions (fixed tree: thread-strided partials, xor-butterfly per
+ * wavefront, wavefronts in order), so sums differ from the reference's sequential ones by
+ * rounding only.
+ */
+#include "dev_common.h"
+#include <limits.h>
+#include "../lbfgs_scalar.h"
+#include "../../../include/nlopt_amd.h"
+
+#define LB_T 256
+#define LB_W (LB_T / 64)
+
+struct lb_shared {
+    double red[2 * LB_W];
+    int ired[2 * LB_W];
+};
+
+__device__ __forceinline__ double lb_wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double lb_block_sum(double v, lb_shared &S)
+{
+    v = lb_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = S.red[0];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) t += S.red[w];
+    return t;
+}
+__device__ __forceinline__ double lb_block_max(double v, lb_shared &S)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = S.red[0];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) t = S.red[w] > t ? S.red[w] : t;
+    return t;
+}
+__device__ __forceinline__ double lb_block_min(double v, lb_shared &S) { return -lb_block_max(-v, S); }
+__device__ __forceinline__ int lb_block_isum(int v, lb_shared &S)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) S.ired[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = S.ired[0];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) t += S.ired[w];
+    return t;
+}
+
+/* masked dot product (mxudot, job > 0): coordinates on an active bound (ix < 0) are skipped */
+__device__ __forceinline__ double lb_mdot(int n, const double *x, const double *y, const int *ix, lb_shared &S)
+{
+    double t = 0;
+    for (int i = threadIdx.x; i < n; i += LB_T) if (ix[i] >= 0) t += x[i] * y[i];
+    return lb_block_sum(t, S);
+}
+
+/* objective and gradient of one point by the workgroup (same per-element formulas as the host
+ * callbacks in ../objfuncs.h nla_obj_eval_seq) */
+template <int OBJ>
+__device__ __forceinline__ double lb_objgrad(int n, const double *x, double *g, lb_shared &S, double *scratch)
+{
+    const int tid = threadIdx.x;
+    nla_obj_part t = nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, tid, LB_T, [&](int i) { return x[i]; }));
+    __syncthreads();
+    if ((tid & 63) == 0) { scratch[2 * (tid >> 6)] = t.a; scratch[2 * (tid >> 6) + 1] = t.b; }
+    __syncthreads();
+    t.a = scratch[0]; t.b = scratch[1];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) { nla_obj_part o; o.a = scratch[2 * w]; o.b = scratch[2 * w + 1]; t = nla_obj_combine<OBJ>(t, o); }
+    const double f = nla_obj_finish<OBJ>(n, t, [&](int i) { return x[i]; });
+    if (OBJ == NLA_OBJ_RASTRIGIN) {
+        for (int i = tid; i < n; i += LB_T) g[i] = 2 * x[i] + 10.0 * NLA_PI2 * sin(NLA_PI2 * x[i]);
+    } else if (OBJ == NLA_OBJ_ACKLEY) {
+        const double r = sqrt(t.a / (unsigned) n), e1 = exp(-0.2 * r), e2 = exp(t.b / (unsigned) n);
+        for (int i = tid; i < n; i += LB_T) {
+            double gi = e2 * NLA_PI2 * sin(NLA_PI2 * x[i]) / (unsigned) n;
+            if (r > 0) gi += 4.0 * e1 * x[i] / ((unsigned) n * r);
+            g[i] = gi;
+        }
+    } else if (OBJ == NLA_OBJ_GRIEWANK) {
+        for (int i = tid; i < n; i += LB_T) {
+            const double sq = sqrt(i + 1.);
+            g[i] = x[i] * 0.0005 + t.b * tan(x[i] / sq) / sq;
+        }
+    } else if (OBJ == NLA_OBJ_ROSENBROCK) {
+        for (int i = tid; i < n; i += LB_T) {
+            double gi = 0;
+            if (i > 0) { const double a = x[i] - x[i - 1] * x[i - 1]; gi = 200 * a; }
+            if (i + 1 < n) { const double a = x[i + 1] - x[i] * x[i], b = 1 - x[i]; gi += -400 * a * x[i] - 2 * b; }
+            g[i] = gi;
+        }
+    } else if (OBJ == NLA_OBJ_LEVY) {
+        for (int i = tid; i < n; i += LB_T) {
+            double gi = 0;
+            if (i == 0) gi = 2 * NLA_PI3 * sin(NLA_PI3 * x[0]) * cos(NLA_PI3 * x[0]);
+            if (i == n - 1) {
+                const double a = x[n - 1] - 1, b = 1 + nla_sqr(sin(NLA_PI2 * x[n - 1]));
+                gi += b + a * 2 * NLA_PI2 * sin(NLA_PI2 * x[n - 1]) * cos(NLA_PI2 * x[n - 1]);
+            }
+            if (i + 1 < n) { const double a = x[i] - 1, b = 1 + nla_sqr(sin(NLA_PI3 * x[i + 1])); gi += 2 * a * b; }
+            if (i > 0) { const double a = x[i - 1] - 1; gi += 2 * NLA_PI3 * nla_sqr(a) * sin(NLA_PI3 * x[i]) * cos(NLA_PI3 * x[i]); }
+            g[i] = gi;
+        }
+    } else {
+        for (int i = tid; i < n; i += LB_T) g[i] = 2 * x[i];
+    }
+    __syncthreads();
+    return f;
+}
+
+__device__ __forceinline__ void lb_project(int n, double *x, const int *ix, const double *xl, const double *xu, double eps9)   /* pcbs04 */
+{
+    for (int i = threadIdx.x; i < n; i += LB_T) {
+        const int t = ix[i] < 0 ? -ix[i] : ix[i];
+        double v = x[i];
+        if ((t == 1 || t == 3 || t == 4) && v <= xl[i] + eps9 * LB_MAX(fabs(xl[i]), 1.)) v = xl[i];
+        if ((t == 2 || t == 3 || t == 4) && v >= xu[i] - eps9 * LB_MAX(fabs(xu[i]), 1.)) v = xu[i];
+        x[i] = v;
+    }
+}
+__device__ __forceinline__ void lb_add_active(int n, double *x, int *ix, const double *xl, const double *xu)                 /* pyadc0 */
+{
+    for (int i = threadIdx.x; i < n; i += LB_T) {
+        const int ii = ix[i], t = ii < 0 ? -ii : ii;
+        if (t >= 5) ix[i] = -t;
+        else if ((t == 1 || t == 3 || t == 4) && x[i] <= xl[i]) { x[i] = xl[i]; ix[i] = (t == 4) ? -3 : -t; }
+        else if ((t == 2 || t == 3 || t == 4) && x[i] >= xu[i]) { x[i] = xu[i]; ix[i] = (t == 3) ? -4 : -t; }
+    }
+}
+
+template <int OBJ>
+__global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf, int count, const double *__restrict__ lb,
+                                                            const double *__restrict__ ub, double *__restrict__ X,
+                                                            double *__restrict__ work, int *__restrict__ iwork,
+                                                            double *__restrict__ hist, nla_lbfgs_params P,
+                                                            nla_lbfgs_result *__restrict__ out)
+{
+    __shared__ lb_shared S;
+    __shared__ double oscratch[2 * LB_W];
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    if (inst >= count) return;
+    double *x = X + (size_t) inst * ld;
+    double *gf = work + (size_t) inst * 4 * ld, *s = gf + ld, *xl = s + ld, *xu = xl + ld;
+    int *ix = iwork + (size_t) inst * ld;
+    double *hx = hist + (size_t) inst * 2 * (size_t) mf * ld, *hg = hx + (size_t) mf * ld;
+    /* per-column scalars u, v live behind the instance's vectors */
+    double *ucol = work + (size_t) count * 4 * ld + (size_t) inst * 2 * mf, *vcol = ucol + mf;
+    int head = 0;
+#define COLX(i) (hx + (size_t) ((head + (i) - 1) % mf) * ld)
+#define COLG(i) (hg + (size_t) ((head + (i) - 1) % mf) * ld)
+#define COLU(i) (ucol[(head + (i) - 1) % mf])
+
+    lb_ls_state lss;
+    lb_ls_io q;
+    lb_counters c;
+    lb_stop ls;
+    double gmax = 0, umax = 0, fval, fo, p = 0, po = 0, a, b, gnorm, snorm = 0, rmax, rmin = 0;
+    const double eta9 = 1e120, eps8 = 1., eps9 = 1e-8, alf1 = 1e-10, alf2 = 1e10, told = 1e-4, xmax = 1e16, maxf = 1e20,
+                 minf_est = -HUGE_VAL;
+    int kd = 1, ld_ = -1, nred = 0, maxst = 0, xstop = 0, nevals = 0, k;
+    double xtol_rel = P.xtol_rel, tolg = P.tolg;
+    (void) ld_;
+
+    for (int i = tid; i < n; i += LB_T) {                                    /* plis.c:463-469 */
+        const int lbu = lb[i] <= -0.99 * HUGE_VAL, ubu = ub[i] >= 0.99 * HUGE_VAL;
+        int t = lbu ? (ubu ? 0 : 2) : (ubu ? 1 : (lb[i] == ub[i] ? 5 : 3));
+        double l = lb[i], u = ub[i];
+        if ((t == 3 || t == 4) && u <= l) { u = l; t = 5; }                  /* plis.c:232-241 */
+        else if (t == 5 || t == 6) { l = x[i]; u = x[i]; t = 5; }
+        ix[i] = t; xl[i] = l; xu[i] = u;
+    }
+    if (xtol_rel <= 0.) xtol_rel = 1e-16;                                    /* plis.c:202-214 */
+    ls.minf_max = P.minf_max; ls.ftol_rel = P.ftol_rel <= 0. ? 1e-14 : P.ftol_rel; ls.ftol_abs = P.ftol_abs; ls.maxeval = P.maxeval;
+    if (tolg <= 0.) tolg = 1e-8;
+    memset(&c, 0, sizeof c);
+    memset(&lss, 0, sizeof lss);
+    memset(&q, 0, sizeof q);
+    c.ites = 1; c.mtesx = 2; c.mtesf = 2; c.iters = 2; c.ires1 = 999; c.ires2 = 0; c.kd = 1;
+    c.mit = INT_MAX; c.mfg = P.maxeval > 0 ? P.maxeval : INT_MAX;
+    c.kit = -(c.ires1 * n + c.ires2);
+    rmax = eta9;
+    fo = minf_est;
+    __syncthreads();
+    lb_project(n, x, ix, xl, xu, eps9);
+    __syncthreads();
+    lb_add_active(n, x, ix, xl, xu);
+    __syncthreads();
+    fval = lb_objgrad<OBJ>(n, x, gf, S, oscratch);
+    ++nevals; ++c.nfg;
+
+    for (;;) {
+        /* pytrcg: largest free gradient component, largest wrong-signed multiplier on an active bound */
+        {
+            double gm = 0, um = 0;
+            for (int i = tid; i < n; i += LB_T) {
+                const double t = gf[i];
+                const int ii = ix[i];
+                if (ii >= 0) gm = LB_MAX(gm, fabs(t));
+                else if (ii <= -5) { }
+                else if (ii == -1 || ii == -3) { if (-t > um) um = -t; }
+                else if (ii == -2 || ii == -4) { if (t > um) um = t; }
+            }
+            gmax = lb_block_max(gm, S);
+            umax = lb_block_max(um, S);
+        }
+        c.kd = kd;
+        lb_pyfut1(n, fval, &fo, umax, gmax, xstop, &ls, 0, nevals, tolg, &c);
+        if (c.iterm != 0) break;
+        if (rmax > 0. && umax > eps8 * gmax) {                               /* pyrmc0: release wrong-signed active bounds */
+            int rel = 0;
+            for (int i = tid; i < n; i += LB_T) {
+                const int t = ix[i];
+                if (t >= 0 || t <= -5) continue;
+                if ((t == -1 || t == -3) && -gf[i] <= 0.) continue;
+                if ((t == -2 || t == -4) && gf[i] <= 0.) continue;
+                ++rel;
+                ix[i] = LB_MIN(-t, 3);
+            }
+            if (lb_block_isum(rel, S) > 1) c.irest = LB_MAX(c.irest, 1);
+        }
+        __syncthreads();
+    direction:
+        gnorm = sqrt(lb_mdot(n, gf, gf, ix, S));
+        if (c.irest == 0) {
+            k = LB_MIN(c.nit - c.kit, mf);
+            if (k <= 0) c.irest = LB_MAX(c.irest, 1);
+            else {
+                b = lb_mdot(n, COLX(1), COLG(1), ix, S);
+                if (b <= 0.) c.irest = LB_MAX(c.irest, 1);
+                else {
+                    if (tid == 0) COLU(1) = 1. / b;
+                    for (int i = tid; i < n; i += LB_T) s[i] = ix[i] >= 0 ? -gf[i] : 0.;      /* mxuneg */
+                    __syncthreads();
+                    for (int j = 1; j <= k; ++j) {                           /* mxdrcb */
+                        const double *cx = COLX(j), *cg = COLG(j);
+                        const double v = COLU(j) * lb_mdot(n, s, cx, ix, S);
+                        if (tid == 0) vcol[j - 1] = v;
+                        for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + (-v) * cg[i];
+                        __syncthreads();
+                    }
+                    a = lb_mdot(n, COLG(1), COLG(1), ix, S);
+                    if (a > 0.) { const double sc = b / a; for (int i = tid; i < n; i += LB_T) s[i] = s[i] * sc; __syncthreads(); }
+                    for (int j = k; j >= 1; --j) {                           /* mxdrcf */
+                        const double *cx = COLX(j), *cg = COLG(j);
+                        const double t = COLU(j) * lb_mdot(n, s, cg, ix, S);
+                        const double w = vcol[j - 1] - t;
+                        for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + w * cx[i];
+                        __syncthreads();
+                    }
+                    snorm = sqrt(lb_mdot(n, s, s, ix, S));
+                    head = (head + mf - 1) % mf;                             /* mxdrsu: every column one older */
+                }
+            }
+        }
+        if (c.irest != 0) {                                                  /* steepest descent */
+            for (int i = tid; i < n; i += LB_T) s[i] = ix[i] >= 0 ? -gf[i] : 0.;
+            __syncthreads();
+            snorm = gnorm;
+            if (c.kit < c.nit) c.kit = c.nit;
+            else { c.iterm = -10; if (c.iters < 0) c.iterm = c.iters - 5; }
+        }
+        if (kd > 0) p = lb_mdot(n, gf, s, ix, S);
+        if (snorm <= 0.) c.irest = LB_MAX(c.irest, 1);
+        else if (p + told * gnorm * snorm <= 0.) c.irest = 0;
+        else c.irest = LB_MAX(c.irest, 1);
+        if (c.irest == 0) {
+            nred = 0;
+            rmin = alf1 * gnorm / snorm;
+            rmax = LB_MIN(alf2 * gnorm / snorm, xmax / snorm);
+        }
+        if (c.iterm != 0) break;
+        if (c.irest != 0) goto direction;
+        /* pytrcs: save x, g in column 1; zero s on active bounds; largest step inside the box */
+        q.fp = fo; fo = fval; po = p;
+        {
+            double *cx = COLX(1), *cg = COLG(1);
+            double rm = rmax;
+            for (int i = tid; i < n; i += LB_T) {
+                cx[i] = x[i]; cg[i] = gf[i];
+                if (ix[i] < 0) s[i] = 0.;
+                else {
+                    if ((ix[i] == 1 || ix[i] >= 3) && s[i] < -1. / eta9) rm = LB_MIN(rm, (xl[i] - x[i]) / s[i]);
+                    if ((ix[i] == 2 || ix[i] >= 3) && s[i] > 1. / eta9) rm = LB_MIN(rm, (xu[i] - x[i]) / s[i]);
+                }
+            }
+            rmax = lb_block_min(rm, S);
+        }
+        if (rmax != 0.) {
+            q.f = fval; q.fo = fo; q.p = p; q.po = po; q.minf_est = minf_est; q.maxf = maxf; q.rmin = rmin; q.rmax = rmax;
+            q.tols = 1e-4; q.tolp = .8; q.kd = kd; q.ld = -1; q.nit = c.nit; q.kit = c.kit; q.nred = nred; q.mred = 10;
+            q.maxst = maxst; q.iest = 0; q.inits = 2; q.iters = c.iters; q.kters = 3; q.mes = 4; q.isys = 0;
+            for (;;) {
+                lb_ps1l01(&q, &lss);
+                if (q.isys == 0) break;
+                {
+                    const double *xs = COLX(1);
+                    for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) x[i] = xs[i] + q.r * s[i];
+                }
+                __syncthreads();
+                lb_project(n, x, ix, xl, xu, eps9);
+                __syncthreads();
+                q.f = lb_objgrad<OBJ>(n, x, gf, S, oscratch);
+                ++nevals; ++c.nfg;
+                q.p = lb_mdot(n, gf, s, ix, S);
+            }
+            fval = q.f; p = q.p; kd = q.kd; nred = q.nred; maxst = q.maxst; c.iters = q.iters;
+            if (c.iters <= 0) {                                              /* zero step: restore and restart */
+                fval = fo; p = po;
+                const double *cx = COLX(1), *cg = COLG(1);
+                for (int i = tid; i < n; i += LB_T) { x[i] = cx[i]; gf[i] = cg[i]; }
+                __syncthreads();
+                c.irest = LB_MAX(c.irest, 1);
+                goto direction;
+            }
+            /* pytrcd: column 1 := differences (zero on active coordinates); nlopt_stop_dx(x, dx) */
+            {
+                double *dx = COLX(1), *dg = COLG(1);
+                double nx = 0, ndx = 0;
+                for (int i = tid; i < n; i += LB_T) {
+                    double ddx = x[i] - dx[i], ddg = gf[i] - dg[i];
+                    if (ix[i] < 0) { ddx = 0.; ddg = 0.; }
+                    dx[i] = ddx; dg[i] = ddg;
+                    nx += fabs(x[i]); ndx += fabs(ddx);
+                }
+                po = q.r * po; p = q.r * p;
+                nx = lb_block_sum(nx, S);
+                ndx = lb_block_sum(ndx, S);
+                xstop = ndx < xtol_rel * nx;                                  /* stop.c:110-120, no xtol_abs / weights on this path */
+            }
+        }
+        for (int i = tid; i < n; i += LB_T) if (ix[i] < 0) ix[i] = -ix[i];   /* mxvine */
+        __syncthreads();
+        lb_add_active(n, x, ix, xl, xu);
+        __syncthreads();
+    }
+    if (tid == 0) { out[inst].f = fval; out[inst].ret = lb_result_of_iterm(c.iterm); out[inst].nevals = nevals; out[inst].iterm = c.iterm; }
+#undef COLX
+#undef COLG
+#undef COLU
+}
+
+extern "C" size_t nla_lbfgs_work_doubles(int ld, int mf, int count) { return (size_t) count * (4 * (size_t) ld + 2 * (size_t) mf); }
+extern "C" size_t nla_lbfgs_hist_doubles(int ld, int mf, int count) { return (size_t) count * 2 * (size_t) mf * (size_t) ld; }
+
+extern "C" int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
+                                 double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
+                                 void *stream)
+{
+    if (count <= 0) return 0;
+    hipStream_t st = (hipStream_t) stream;
+    const nla_lbfgs_params P = *params;
+#define CALL(O) hipLaunchKernelGGL((lbfgs_batch_kernel<O>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, iwork, hist, P, out)
+    NLA_OBJ_DISPATCH(obj, CALL)
+#undef CALL
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,88 @@
+/* lbfgs_driver.c — NLOPT_LD_LBFGS behind the reference's entry point luksan_plis (plis.c:420-510):
+ * argument handling on the host, the optimisation itself in one launch of the batched device
+ * kernel (hip/lbfgs_kernels.hip) — used directly by nlopt_optimize(LD_LBFGS) with count = 1 and by
+ * MLSL (mlsl_driver.c) with one workgroup per start point.
+ *
+ * Provided for device objectives (nlopt_amd_objective): the objective and its gradient are
+ * evaluated inside the kernel.  A host callback would need a PCIe round trip per evaluation; that
+ * path is not provided and says so. */
+#include "nla_internal.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MEMAVAIL 1310720                       /* luksan.h:149 */
+
+int nla_lbfgs_default_mf(int n, int mf, int maxeval)        /* plis.c:441-445 */
+{
+    if (mf <= 0) {
+        mf = MEMAVAIL / n > 10 ? MEMAVAIL / n : 10;
+        if (maxeval > 0 && maxeval <= mf) mf = maxeval > 1 ? maxeval : 1;
+    }
+    return mf;
+}
+
+/* `count` local searches from the rows of h_X (count x n, host), results back in h_X / res */
+int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
+                        const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen)
+{
+    const int ld = (n + 1) & ~1;
+    void *st = nla_stream_create();
+    double *d_lb = NULL, *d_ub = NULL, *d_X = NULL, *d_work = NULL, *d_hist = NULL;
+    int *d_iwork = NULL, rc = -1, i;
+    nla_lbfgs_result *d_res = NULL;
+    if (!st) { snprintf(err, errlen, "stream creation failed"); return -1; }
+    d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld);
+    d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld);
+    d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld * (size_t) count);
+    d_work = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_work_doubles(ld, mf, count));
+    d_iwork = (int *) nla_dev_malloc(sizeof(int) * (size_t) ld * (size_t) count);
+    d_hist = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_hist_doubles(ld, mf, count));
+    d_res = (nla_lbfgs_result *) nla_dev_malloc(sizeof(nla_lbfgs_result) * (size_t) count);
+    if (!d_lb || !d_ub || !d_X || !d_work || !d_iwork || !d_hist || !d_res) { snprintf(err, errlen, "out of device memory"); goto done; }
+    if (nla_memcpy_h2d(d_lb, lb, sizeof(double) * (size_t) n, st) || nla_memcpy_h2d(d_ub, ub, sizeof(double) * (size_t) n, st) ||
+        nla_memset(d_hist, 0, sizeof(double) * nla_lbfgs_hist_doubles(ld, mf, count), st)) { snprintf(err, errlen, "upload failed"); goto done; }
+    for (i = 0; i < count; ++i)
+        if (nla_memcpy_h2d(d_X + (size_t) i * ld, h_X + (size_t) i * n, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "upload failed"); goto done; }
+    if ((i = nla_k_lbfgs_batch(obj, n, ld, mf, count, d_lb, d_ub, d_X, d_work, d_iwork, d_hist, prm, d_res, st))) {
+        snprintf(err, errlen, "L-BFGS launch failed: %s", nla_dev_error_string(i));
+        goto done;
+    }
+    for (i = 0; i < count; ++i)
+        if (nla_memcpy_d2h(h_X + (size_t) i * n, d_X + (size_t) i * ld, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "read-back failed"); goto done; }
+    if (nla_memcpy_d2h(res, d_res, sizeof(nla_lbfgs_result) * (size_t) count, st) || (i = nla_stream_sync(st))) {
+        snprintf(err, errlen, "L-BFGS kernel failed: %s", nla_dev_error_string(i));
+        goto done;
+    }
+    rc = 0;
+done:
+    nla_dev_free(d_lb); nla_dev_free(d_ub); nla_dev_free(d_X); nla_dev_free(d_work); nla_dev_free(d_iwork); nla_dev_free(d_hist);
+    nla_dev_free(d_res);
+    nla_stream_destroy(st);
+    return rc;
+}
+
+/* reference-shaped entry: luksan_plis(n, f, f_data, lb, ub, x, minf, stop, mf, tolg) (plis.c:420-426) */
+nlopt_result nla_lbfgs_minimize(int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+                                nla_stopping *stop, int mf, double tolg)
+{
+    const int obj = nlopt_amd_objective_id(f);
+    nla_lbfgs_params prm;
+    nla_lbfgs_result res;
+    char err[200];
+    (void) f_data;
+    if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
+    if (obj < 0) {
+        nla_stop_msg(stop, "nlopt_amd: LD_LBFGS is provided for device objectives (nlopt_amd_objective) only");
+        return NLOPT_INVALID_ARGS;
+    }
+    if (stop->xtol_abs) { nla_stop_msg(stop, "nlopt_amd: LD_LBFGS on the device does not take xtol_abs"); return NLOPT_INVALID_ARGS; }
+    memset(&prm, 0, sizeof prm);
+    prm.minf_max = stop->minf_max; prm.ftol_rel = stop->ftol_rel; prm.ftol_abs = stop->ftol_abs; prm.xtol_rel = stop->xtol_rel;
+    prm.tolg = tolg; prm.maxeval = stop->maxeval;
+    mf = nla_lbfgs_default_mf(n, mf, stop->maxeval);
+    if (nla_lbfgs_run_batch(obj, n, 1, lb, ub, x, mf, &prm, &res, err, sizeof err)) { nla_stop_msg(stop, "device engine: %s", err); return NLOPT_FAILURE; }
+    *minf = res.f;
+    *stop->nevals_p += res.nevals;
+    return (nlopt_result) res.ret;
+}

@@ -171,6 +171,13 @@ nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *engine, const nla_
 nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, int m, nla_constraint *fc, int p, nla_constraint *h,
                                 const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, int population);
 
+/* LD_LBFGS (lbfgs_driver.c) */
+int nla_lbfgs_default_mf(int n, int mf, int maxeval);
+int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
+                        const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen);
+nlopt_result nla_lbfgs_minimize(int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+                                nla_stopping *stop, int mf, double tolg);
+
 /* HIP engine (crs_engine.c) */
 typedef struct nla_crs_hip_engine nla_crs_hip_engine;
 nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj,
