@@ -77,6 +77,12 @@ int orc_isres_minimize(int n, orc_func f, void *f_data, int m, const orc_constra
 int orc_lbfgs_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                        orc_stop *stop, int mf, double tolg);
 
+/* ---- MLSL (src/algs/mlsl/mlsl.c) with LD_LBFGS as the local optimiser ------------------------- */
+typedef struct { double ftol_rel, ftol_abs, xtol_rel, tolg; long maxeval; int mf; } orc_local_params;
+typedef struct { double *fsamp, *floc; int *eloc; size_t cap, nsamp, nloc; long iterations; } orc_mlsl_trace;
+int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+                      orc_stop *stop, int Nsamples, const orc_local_params *loc, orc_mlsl_trace *trace);
+
 /* ---- objective zoo callbacks (objfuncs.h compiled for the host) ------------------------------ */
 orc_func orc_objective(int id);                     /* f_data ignored */
 double orc_con_blocksum(unsigned n, const double *x, double *grad, void *data); /* data -> unsigned[2]={q,Q} */

@@ -373,3 +373,65 @@ def run_ref_lbfgs(obj, n, x0=None, mf=0, lb=None, ub=None, **kw):
         if ub is not None:
             R.nlopt_set_upper_bounds(opt, dptr(np.array(ub, dtype=np.float64)))
     return run_ref(11, obj, n, 0, 0, x0=x0, setup=setup, **kw)
+
+
+# ---- MLSL + LD_LBFGS ----------------------------------------------------------------------------
+class OrcLocal(C.Structure):
+    _fields_ = [("ftol_rel", C.c_double), ("ftol_abs", C.c_double), ("xtol_rel", C.c_double), ("tolg", C.c_double),
+                ("maxeval", C.c_long), ("mf", C.c_int)]
+
+
+class MlslTrace(C.Structure):
+    _fields_ = [("fsamp", C.POINTER(C.c_double)), ("floc", C.POINTER(C.c_double)), ("eloc", C.POINTER(C.c_int)),
+                ("cap", C.c_size_t), ("nsamp", C.c_size_t), ("nloc", C.c_size_t), ("iterations", C.c_long)]
+
+
+def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0,
+                  local_maxeval=0, mf=0, x0=None, record=True):
+    L = port()
+    L.orc_mlsl_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OrcStop), C.c_int,
+                                    C.POINTER(OrcLocal), C.POINTER(MlslTrace)]
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lb, ub = np.full(n, lo), np.full(n, hi)
+    st = OrcStop()
+    L.orc_stop_default(C.byref(st), n)
+    st.maxeval = maxeval
+    if stopval is not None:
+        st.minf_max = stopval
+    loc = OrcLocal(local_ftol_rel, local_ftol_abs, local_xtol_rel, 0.0, local_maxeval, mf)
+    f = L.orc_objective(OBJ[obj])
+    cap = (maxeval or 400000) + 4096
+    fbuf = np.zeros(cap)
+    hbuf = np.zeros(cap, dtype=np.uint64)
+    rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
+    fs, fl, el = np.zeros(cap), np.zeros(cap), np.zeros(cap, dtype=np.int32)
+    tr = MlslTrace(dptr(fs), dptr(fl), el.ctypes.data_as(C.POINTER(C.c_int)), cap, 0, 0, 0)
+    minf = C.c_double()
+    L.orc_srand(seed)
+    ret = L.orc_mlsl_minimize(n, C.cast(L.orc_recording_callback, C.c_void_p).value, C.cast(C.pointer(rec), C.c_void_p),
+                              dptr(lb), dptr(ub), dptr(x), C.byref(minf), C.byref(st), nsamples, C.byref(loc), C.byref(tr))
+    return dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, words=L.orc_mt_words_drawn(), fseq=fbuf[:rec.len].copy(),
+                xhash=hbuf[:rec.len].copy(), fsamp=fs[:tr.nsamp].copy(), floc=fl[:tr.nloc].copy(), eloc=el[:tr.nloc].copy(),
+                iterations=tr.iterations)
+
+
+def run_ref_mlsl(obj, n, nsamples, seed, alg=38, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0, local_maxeval=0, mf=0, **kw):
+    """the REAL reference's G_MLSL (38) with an LD_LBFGS (11) local optimiser"""
+    def setup(R, opt):
+        R.nlopt_set_vector_storage.argtypes = [C.c_void_p, C.c_uint]
+        loc = R.nlopt_create(11, n)
+        if local_ftol_rel:
+            R.nlopt_set_ftol_rel(loc, local_ftol_rel)
+        if local_ftol_abs:
+            R.nlopt_set_ftol_abs(loc, local_ftol_abs)
+        if local_xtol_rel:
+            R.nlopt_set_xtol_rel(loc, local_xtol_rel)
+        if local_maxeval:
+            R.nlopt_set_maxeval(loc, local_maxeval)
+        if mf:
+            R.nlopt_set_vector_storage(loc, mf)
+        assert R.nlopt_set_local_optimizer(opt, loc) > 0
+        R.nlopt_destroy(loc)           # set_local_optimizer copies it (options.c:824-846)
+    return run_ref(alg, obj, n, nsamples, seed, setup=setup, **kw)

@@ -163,3 +163,22 @@ def test_port_lbfgs_active_bounds_match_reference():
         assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
         assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
         assert np.array_equal(a["x"], b["x"])
+
+
+# ---- MLSL + LD_LBFGS ----------------------------------------------------------------------------
+@need_ref
+@pytest.mark.parametrize("obj,n,ns,seed,kw", [
+    ("rastrigin", 4, 10, 42, dict(maxeval=3000)),
+    ("ackley", 6, 25, 7, dict(maxeval=5000)),
+    ("griewank", 5, 0, 3, dict(maxeval=2500)),                     # default 4 samples per iteration
+    ("levy", 3, 8, 11, dict(maxeval=2000, local_xtol_rel=1e-6, local_ftol_rel=0.0)),
+    ("rastrigin", 8, 40, 5, dict(maxeval=6000, local_maxeval=30)),
+    ("sphere", 5, 6, 2, dict(stopval=1e-9, maxeval=5000)),
+    ("rosenbrock", 4, 12, 9, dict(maxeval=4000, mf=3)),
+])
+def test_port_mlsl_matches_reference_live(obj, n, ns, seed, kw):
+    a = O.run_port_mlsl(obj, n, ns, seed, **kw)
+    b = O.run_ref_mlsl(obj, n, ns, seed, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+    assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
