@@ -225,6 +225,15 @@ int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *l
                       double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
                       void *stream);
 
+/* ---- MLSL (src/algs/mlsl/mlsl.c) ------------------------------------------------------------------- */
+/* replaces: distance2 (mlsl.c:118-127) for all pairs: D[i*nb + j] = |A_i - B_j|^2, A: na x ld, B: nb x ld
+ * (summed over k ascending without FMA: bit-identical to the reference's loop). */
+int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream);
+/* replaces: find_closest_pt / find_closest_lm (mlsl.c:131-155): out[i] = min(init[i], min_j {D[i*ldd+j] : FB[j] < FA[i]}) */
+int nla_k_mlsl_rowmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const double *init, double *out, void *stream);
+/* replaces: pts_update_newpt (mlsl.c:162-173): inout[j] = min(inout[j], min_i {D[i][j] : FA[i] < FB[j]}) where skip[j] == 0 */
+int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const int32_t *skip, double *inout, void *stream);
+
 /* thin device-runtime layer the C host code uses (no HIP types cross the boundary) */
 int nla_dev_count(void);
 int nla_dev_set(int dev);

@@ -82,6 +82,38 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
     case NLOPT_LD_LBFGS:                                                                 /* optimize.c:716-718 */
         return nla_lbfgs_minimize((int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, (int) opt->vector_storage,
                                   nlopt_get_param(opt, "tolg", 0.));
+    case NLOPT_G_MLSL: case NLOPT_G_MLSL_LDS: case NLOPT_GN_MLSL: case NLOPT_GD_MLSL:
+    case NLOPT_GN_MLSL_LDS: case NLOPT_GD_MLSL_LDS: {                                    /* optimize.c:748-793 */
+        nlopt_opt local_opt = opt->local_opt;
+        nlopt_algorithm alg = opt->algorithm;
+        nlopt_result ret;
+        unsigned i;
+        int own = 0;
+        if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
+        if (!local_opt && (alg == NLOPT_G_MLSL || alg == NLOPT_G_MLSL_LDS)) { nla_set_errmsg(opt, "local optimizer must be specified for G_MLSL"); return NLOPT_INVALID_ARGS; }
+        if (!local_opt) {                                                               /* the reference's default local optimiser */
+            nlopt_algorithm local_alg = (alg == NLOPT_GN_MLSL || alg == NLOPT_GN_MLSL_LDS) ? nla_local_search_alg_nonderiv : nla_local_search_alg_deriv;
+            if (local_alg >= NLOPT_GN_MLSL && local_alg <= NLOPT_GD_MLSL_LDS)
+                local_alg = (alg == NLOPT_GN_MLSL || alg == NLOPT_GN_MLSL_LDS) ? NLOPT_LN_COBYLA : NLOPT_LD_MMA;
+            local_opt = nlopt_create(local_alg, n);
+            if (!local_opt) { nla_set_errmsg(opt, "failed to create local_opt"); return NLOPT_FAILURE; }
+            own = 1;
+            nlopt_set_ftol_rel(local_opt, opt->ftol_rel); nlopt_set_ftol_abs(local_opt, opt->ftol_abs);
+            nlopt_set_xtol_rel(local_opt, opt->xtol_rel); nlopt_set_xtol_abs(local_opt, opt->xtol_abs);
+            nlopt_set_maxeval(local_opt, nla_local_search_maxeval);
+        }
+        for (i = 0; i < n && stop.xtol_abs && stop.xtol_abs[i] > 0; ++i) { }
+        if (local_opt->ftol_rel <= 0 && local_opt->ftol_abs <= 0 && local_opt->xtol_rel <= 0 && i < n) {
+            nlopt_set_ftol_rel(local_opt, 1e-15);                                        /* optimize.c:781-786 */
+            nlopt_set_xtol_rel(local_opt, 1e-7);
+        }
+        opt->force_stop_child = local_opt;
+        ret = nla_mlsl_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, local_opt, POP(opt, 0),
+                                alg >= NLOPT_GN_MLSL_LDS && alg != NLOPT_G_MLSL);
+        opt->force_stop_child = NULL;
+        if (own) nlopt_destroy(local_opt);
+        return ret;
+    }
     case NLOPT_GN_ISRES:                                                                 /* optimize.c:941-944 */
         if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
         return nla_isres_minimize(opt, (int) n, opt->f, opt->f_data, (int) opt->m, opt->fc, (int) opt->p, opt->h, opt->lb, opt->ub,

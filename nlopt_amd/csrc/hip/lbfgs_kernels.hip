@@ -198,6 +198,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
         if ((t == 3 || t == 4) && u <= l) { u = l; t = 5; }                  /* plis.c:232-241 */
         else if (t == 5 || t == 6) { l = x[i]; u = x[i]; t = 5; }
         ix[i] = t; xl[i] = l; xu[i] = u;
+        hx[i] = 0.; hg[i] = 0.;               /* the reference zero-fills xo (plis.c:475); column 1 is read before it is written */
     }
     if (xtol_rel <= 0.) xtol_rel = 1e-16;                                    /* plis.c:202-214 */
     ls.minf_max = P.minf_max; ls.ftol_rel = P.ftol_rel <= 0. ? 1e-14 : P.ftol_rel; ls.ftol_abs = P.ftol_abs; ls.maxeval = P.maxeval;

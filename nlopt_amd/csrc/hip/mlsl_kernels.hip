@@ -1,0 +1,90 @@
+/* mlsl_kernels.hip — Multi-Level Single-Linkage (src/algs/mlsl/mlsl.c) device work besides the
+ * batched local searches (lbfgs_kernels.hip) and the sample generation + evaluation (the
+ * row-from-stream kernel of crs_kernels.hip):
+ *
+ *   dist2        |a_i - b_j|^2 for all pairs of two point sets — the reference's distance2
+ *                (mlsl.c:118-127) inside find_closest_pt / find_closest_lm / pts_update_newpt /
+ *                pts_update_newlm (:131-194), N_new x |pts| x n flops per iteration, the sampling
+ *                phase's hot spot.  LDS-tiled 16x16 pairs per workgroup; every pair is summed by one
+ *                thread over k in ascending order without FMA, i.e. in the reference's order:
+ *                distances are bit-identical to the CPU's.
+ *   masked mins  closest_pt_d / closest_lm_d updates: min over the partner set restricted to
+ *                partners with strictly smaller f (mlsl.c:133,147,164,184).
+ */
+#include "dev_common.h"
+#include "../../../include/nlopt_amd.h"
+
+#define DT 16          /* pairs tile edge */
+#define DK 64          /* coordinates per LDS tile */
+
+__global__ __launch_bounds__(DT * DT) void mlsl_dist2_kernel(int n, int ld, const double *__restrict__ A, int na,
+                                                             const double *__restrict__ B, int nb, double *__restrict__ D)
+{
+    __shared__ double sa[DT][DK + 1], sb[DT][DK + 1];
+    const int tx = threadIdx.x % DT, ty = threadIdx.x / DT;     /* pair (i0+ty, j0+tx) */
+    const int i0 = blockIdx.y * DT, j0 = blockIdx.x * DT;
+    double d = 0.;
+    for (int k0 = 0; k0 < n; k0 += DK) {
+        const int kc = n - k0 < DK ? n - k0 : DK;
+        __syncthreads();
+        for (int e = threadIdx.x; e < DT * DK; e += DT * DT) {
+            const int r = e / DK, k = e - r * DK;
+            sa[r][k] = (i0 + r < na && k < kc) ? A[(size_t) (i0 + r) * ld + k0 + k] : 0.;
+            sb[r][k] = (j0 + r < nb && k < kc) ? B[(size_t) (j0 + r) * ld + k0 + k] : 0.;
+        }
+        __syncthreads();
+        for (int k = 0; k < kc; ++k) { const double dx = sa[ty][k] - sb[tx][k]; d += dx * dx; }
+    }
+    if (i0 + ty < na && j0 + tx < nb) D[(size_t) (i0 + ty) * nb + j0 + tx] = d;
+}
+
+/* out[i] = min(init[i], min_j { D[i][j] : FB[j] < FA[i] })        (one wavefront per row i) */
+__global__ __launch_bounds__(256) void mlsl_rowmin_kernel(const double *__restrict__ D, int ldd, int na, int nb, const double *__restrict__ FA,
+                                                          const double *__restrict__ FB, const double *__restrict__ init,
+                                                          double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= na) return;
+    const double fi = FA[i];
+    double m = HUGE_VAL;
+    for (int j = lane; j < nb; j += 64) if (FB[j] < fi) { const double d = D[(size_t) i * ldd + j]; m = d < m ? d : m; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { const double o = __shfl_xor(m, s, 64); m = o < m ? o : m; }
+    if (lane == 0) { const double b = init ? init[i] : HUGE_VAL; out[i] = m < b ? m : b; }
+}
+
+/* inout[j] = min(inout[j], min_i { D[i][j] : FA[i] < FB[j] }) for j with skip[j] == 0 (one thread per column j) */
+__global__ __launch_bounds__(256) void mlsl_colmin_kernel(const double *__restrict__ D, int ldd, int na, int nb, const double *__restrict__ FA,
+                                                          const double *__restrict__ FB, const int32_t *__restrict__ skip,
+                                                          double *__restrict__ inout)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nb || (skip && skip[j])) return;
+    const double fj = FB[j];
+    double m = inout[j];
+    for (int i = 0; i < na; ++i) if (FA[i] < fj) { const double d = D[(size_t) i * ldd + j]; m = d < m ? d : m; }
+    inout[j] = m;
+}
+
+extern "C" int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream)
+{
+    if (na <= 0 || nb <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_dist2_kernel, dim3((unsigned) ((nb + DT - 1) / DT), (unsigned) ((na + DT - 1) / DT)), dim3(DT * DT), 0,
+                       (hipStream_t) stream, n, ld, A, na, B, nb, D);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int nla_k_mlsl_rowmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const double *init, double *out, void *stream)
+{
+    if (na <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_rowmin_kernel, dim3((unsigned) ((na + 3) / 4)), dim3(256), 0, (hipStream_t) stream, D, ldd, na, nb, FA, FB, init, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const int32_t *skip, double *inout, void *stream)
+{
+    if (nb <= 0 || na <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_colmin_kernel, dim3((unsigned) ((nb + 255) / 256)), dim3(256), 0, (hipStream_t) stream, D, ldd, na, nb, FA, FB, skip, inout);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

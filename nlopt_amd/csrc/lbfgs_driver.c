@@ -22,42 +22,74 @@ int nla_lbfgs_default_mf(int n, int mf, int maxeval)        /* plis.c:441-445 */
     return mf;
 }
 
+/* a reusable batch: device buffers for up to `cap` simultaneous local searches */
+struct nla_lbfgs_ctx {
+    int obj, n, ld, cap, mf;
+    void *st;
+    const double *d_lb, *d_ub;
+    double *d_X, *d_work, *d_hist;
+    int *d_iwork;
+    nla_lbfgs_result *d_res;
+};
+
+void nla_lbfgs_ctx_destroy(nla_lbfgs_ctx *c)
+{
+    if (!c) return;
+    nla_dev_free(c->d_X); nla_dev_free(c->d_work); nla_dev_free(c->d_iwork); nla_dev_free(c->d_hist); nla_dev_free(c->d_res);
+    free(c);
+}
+
+nla_lbfgs_ctx *nla_lbfgs_ctx_create(int obj, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream)
+{
+    nla_lbfgs_ctx *c = (nla_lbfgs_ctx *) calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->obj = obj; c->n = n; c->ld = (n + 1) & ~1; c->cap = cap; c->mf = mf; c->st = stream; c->d_lb = d_lb; c->d_ub = d_ub;
+    c->d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld * (size_t) cap);
+    c->d_work = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_work_doubles(c->ld, mf, cap));
+    c->d_iwork = (int *) nla_dev_malloc(sizeof(int) * (size_t) c->ld * (size_t) cap);
+    c->d_hist = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_hist_doubles(c->ld, mf, cap));
+    c->d_res = (nla_lbfgs_result *) nla_dev_malloc(sizeof(nla_lbfgs_result) * (size_t) cap);
+    if (!c->d_X || !c->d_work || !c->d_iwork || !c->d_hist || !c->d_res) { nla_lbfgs_ctx_destroy(c); return NULL; }
+    return c;
+}
+
+double *nla_lbfgs_ctx_X(nla_lbfgs_ctx *c) { return c->d_X; }
+
+/* run `count` searches from the rows already in ctx X; minimisers stay there, results come to the host */
+int nla_lbfgs_ctx_run(nla_lbfgs_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res)
+{
+    int rc;
+    if (count > c->cap) return -1;
+    if ((rc = nla_k_lbfgs_batch(c->obj, c->n, c->ld, c->mf, count, c->d_lb, c->d_ub, c->d_X, c->d_work, c->d_iwork, c->d_hist, prm, c->d_res, c->st))) return rc;
+    if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
+    return nla_stream_sync(c->st);
+}
+
 /* `count` local searches from the rows of h_X (count x n, host), results back in h_X / res */
 int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
                         const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen)
 {
     const int ld = (n + 1) & ~1;
     void *st = nla_stream_create();
-    double *d_lb = NULL, *d_ub = NULL, *d_X = NULL, *d_work = NULL, *d_hist = NULL;
-    int *d_iwork = NULL, rc = -1, i;
-    nla_lbfgs_result *d_res = NULL;
+    double *d_lb = NULL, *d_ub = NULL;
+    nla_lbfgs_ctx *c = NULL;
+    int rc = -1, i;
     if (!st) { snprintf(err, errlen, "stream creation failed"); return -1; }
     d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld);
     d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld);
-    d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld * (size_t) count);
-    d_work = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_work_doubles(ld, mf, count));
-    d_iwork = (int *) nla_dev_malloc(sizeof(int) * (size_t) ld * (size_t) count);
-    d_hist = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_hist_doubles(ld, mf, count));
-    d_res = (nla_lbfgs_result *) nla_dev_malloc(sizeof(nla_lbfgs_result) * (size_t) count);
-    if (!d_lb || !d_ub || !d_X || !d_work || !d_iwork || !d_hist || !d_res) { snprintf(err, errlen, "out of device memory"); goto done; }
-    if (nla_memcpy_h2d(d_lb, lb, sizeof(double) * (size_t) n, st) || nla_memcpy_h2d(d_ub, ub, sizeof(double) * (size_t) n, st) ||
-        nla_memset(d_hist, 0, sizeof(double) * nla_lbfgs_hist_doubles(ld, mf, count), st)) { snprintf(err, errlen, "upload failed"); goto done; }
+    if (d_lb && d_ub) c = nla_lbfgs_ctx_create(obj, n, count, mf, d_lb, d_ub, st);
+    if (!c) { snprintf(err, errlen, "out of device memory"); goto done; }
+    if (nla_memcpy_h2d(d_lb, lb, sizeof(double) * (size_t) n, st) || nla_memcpy_h2d(d_ub, ub, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "upload failed"); goto done; }
     for (i = 0; i < count; ++i)
-        if (nla_memcpy_h2d(d_X + (size_t) i * ld, h_X + (size_t) i * n, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "upload failed"); goto done; }
-    if ((i = nla_k_lbfgs_batch(obj, n, ld, mf, count, d_lb, d_ub, d_X, d_work, d_iwork, d_hist, prm, d_res, st))) {
-        snprintf(err, errlen, "L-BFGS launch failed: %s", nla_dev_error_string(i));
-        goto done;
-    }
+        if (nla_memcpy_h2d(c->d_X + (size_t) i * ld, h_X + (size_t) i * n, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "upload failed"); goto done; }
+    if ((i = nla_lbfgs_ctx_run(c, count, prm, res))) { snprintf(err, errlen, "L-BFGS batch failed: %s", nla_dev_error_string(i)); goto done; }
     for (i = 0; i < count; ++i)
-        if (nla_memcpy_d2h(h_X + (size_t) i * n, d_X + (size_t) i * ld, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "read-back failed"); goto done; }
-    if (nla_memcpy_d2h(res, d_res, sizeof(nla_lbfgs_result) * (size_t) count, st) || (i = nla_stream_sync(st))) {
-        snprintf(err, errlen, "L-BFGS kernel failed: %s", nla_dev_error_string(i));
-        goto done;
-    }
+        if (nla_memcpy_d2h(h_X + (size_t) i * n, c->d_X + (size_t) i * ld, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "read-back failed"); goto done; }
+    if ((i = nla_stream_sync(st))) { snprintf(err, errlen, "read-back failed: %s", nla_dev_error_string(i)); goto done; }
     rc = 0;
 done:
-    nla_dev_free(d_lb); nla_dev_free(d_ub); nla_dev_free(d_X); nla_dev_free(d_work); nla_dev_free(d_iwork); nla_dev_free(d_hist);
-    nla_dev_free(d_res);
+    nla_lbfgs_ctx_destroy(c);
+    nla_dev_free(d_lb); nla_dev_free(d_ub);
     nla_stream_destroy(st);
     return rc;
 }

@@ -1,0 +1,382 @@
+/* mlsl_driver.c — Multi-Level Single-Linkage behind the reference's entry point
+ *   mlsl_minimize(n, f, f_data, lb, ub, x, minf, stop, local_opt, Nsamples, lds)   (mlsl.h:34-41),
+ * host side: the point / local-minimum bookkeeping of mlsl.c:251-438 (ordered by f, the trees'
+ * tie rule kept), stop tests in the reference's order, stream accounting; device side through
+ * the C-ABI launchers of include/nlopt_amd.h:
+ *
+ *   sampling phase (mlsl.c:349-374)   the N samples of an iteration are generated from the stream
+ *       and evaluated in one launch; all pair distances new x (old + new) and new x minima in one
+ *       tiled kernel (bit-identical distances); closest_pt_d / closest_lm_d by masked min kernels.
+ *       The reference interleaves these per sample; the values it reads later (only in the local
+ *       phase) are mins over the same pair sets, so batching changes nothing.
+ *   local phase (mlsl.c:380-428)      the walk over the best ceil(gamma |pts|) points is serial in the
+ *       reference because a new minimum can disqualify later candidates (closest_lm_d only ever
+ *       decreases).  Here the next batch of currently-potential candidates is minimised
+ *       concurrently — one workgroup each in the batched L-BFGS kernel — and committed in walk
+ *       order; a candidate that an earlier commit of the same batch disqualified is dropped
+ *       (its start point stays un-minimised, exactly as if it had never been started).
+ *
+ * Provided: local optimiser NLOPT_LD_LBFGS with a device objective; pseudo-random sampling (all
+ * MLSL variants for n > 1111, where the reference's Sobol generator is NULL too — sobolseq.c — and
+ * the non-LDS variants for any n).  Sobol sampling for n <= 1111 is not provided and says so.
+ */
+#include "nla_internal.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define K2PI (6.2831853071795864769252867665590057683943388)
+#define MLSL_SIGMA 2.
+#define MLSL_GAMMA 0.3
+#define BATCH_MAX 64
+#define SOBOL_MAXDIM 1111
+
+static double gam(int n) { double z = n / 2; return sqrt(pow(K2PI * z, 1.0 / n) * z) * exp(-0.5); }   /* mlsl.c:227-237 */
+
+typedef struct {
+    int n, ld, obj, N;
+    void *st;
+    nla_mtstream *mts;
+    uint64_t words_used;
+    /* points: row id = insertion order */
+    size_t npts, cap;
+    double *F, *cpd, *cld;          /* host */
+    int32_t *minimized;
+    size_t *ord;                    /* row ids sorted by f, equal keys newest first (redblack.c:120) */
+    size_t nlms, lcap;
+    double *LF; size_t *lord;
+    double *d_lb, *d_ub, *d_P, *d_F, *d_cpd, *d_LM, *d_LF, *d_D, *d_tmp;
+    int32_t *d_min;
+    uint32_t *d_words;
+    size_t dcap;                    /* doubles in d_D */
+    nla_lbfgs_ctx *lb;
+    double *h_D;                    /* pinned: batch x npts distances */
+    size_t hcap;
+    char err[200];
+} mlsl_dev;
+
+#define MFAIL(d, ...) do { snprintf((d)->err, sizeof (d)->err, __VA_ARGS__); return -1; } while (0)
+#define MCK(d, call) do { int rc_ = (call); if (rc_) MFAIL(d, "%s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
+
+static void mfree(mlsl_dev *d)
+{
+    if (d->st) nla_stream_sync(d->st);
+    if (d->mts) { nla_mtstream_finish(d->mts, d->words_used); nla_mtstream_destroy(d->mts); }
+    nla_lbfgs_ctx_destroy(d->lb);
+    free(d->F); free(d->cpd); free(d->cld); free(d->minimized); free(d->ord); free(d->LF); free(d->lord);
+    nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd);
+    nla_dev_free(d->d_LM); nla_dev_free(d->d_LF); nla_dev_free(d->d_D); nla_dev_free(d->d_tmp); nla_dev_free(d->d_min);
+    nla_dev_free(d->d_words);
+    nla_host_free(d->h_D);
+    if (d->st) nla_stream_destroy(d->st);
+}
+
+static int grow_pts(mlsl_dev *d, size_t need)
+{
+    size_t ncap = d->cap ? d->cap : 1024;
+    double *nP, *nF, *nC;
+    int32_t *nM;
+    if (need <= d->cap) return 0;
+    while (ncap < need) ncap *= 2;
+    d->F = (double *) realloc(d->F, sizeof(double) * ncap);
+    d->cpd = (double *) realloc(d->cpd, sizeof(double) * ncap);
+    d->cld = (double *) realloc(d->cld, sizeof(double) * ncap);
+    d->minimized = (int32_t *) realloc(d->minimized, sizeof(int32_t) * ncap);
+    d->ord = (size_t *) realloc(d->ord, sizeof(size_t) * ncap);
+    nP = (double *) nla_dev_malloc(sizeof(double) * ncap * (size_t) d->ld);
+    nF = (double *) nla_dev_malloc(sizeof(double) * ncap);
+    nC = (double *) nla_dev_malloc(sizeof(double) * ncap);
+    nM = (int32_t *) nla_dev_malloc(sizeof(int32_t) * ncap);
+    if (!d->F || !d->cpd || !d->cld || !d->minimized || !d->ord || !nP || !nF || !nC || !nM) MFAIL(d, "out of memory growing the point set");
+    if (d->npts) {
+        MCK(d, nla_memcpy_d2d(nP, d->d_P, sizeof(double) * d->npts * (size_t) d->ld, d->st));
+        MCK(d, nla_memcpy_d2d(nF, d->d_F, sizeof(double) * d->npts, d->st));
+        MCK(d, nla_stream_sync(d->st));
+    }
+    nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd); nla_dev_free(d->d_min);
+    d->d_P = nP; d->d_F = nF; d->d_cpd = nC; d->d_min = nM;
+    d->cap = ncap;
+    return 0;
+}
+
+static int grow_lms(mlsl_dev *d, size_t need)
+{
+    size_t ncap = d->lcap ? d->lcap : 256;
+    double *nL, *nF;
+    if (need <= d->lcap) return 0;
+    while (ncap < need) ncap *= 2;
+    d->LF = (double *) realloc(d->LF, sizeof(double) * ncap);
+    d->lord = (size_t *) realloc(d->lord, sizeof(size_t) * ncap);
+    nL = (double *) nla_dev_malloc(sizeof(double) * ncap * (size_t) d->ld);
+    nF = (double *) nla_dev_malloc(sizeof(double) * ncap);
+    if (!d->LF || !d->lord || !nL || !nF) MFAIL(d, "out of memory growing the local-minimum set");
+    if (d->nlms) {
+        MCK(d, nla_memcpy_d2d(nL, d->d_LM, sizeof(double) * d->nlms * (size_t) d->ld, d->st));
+        MCK(d, nla_memcpy_d2d(nF, d->d_LF, sizeof(double) * d->nlms, d->st));
+        MCK(d, nla_stream_sync(d->st));
+    }
+    nla_dev_free(d->d_LM); nla_dev_free(d->d_LF);
+    d->d_LM = nL; d->d_LF = nF; d->lcap = ncap;
+    return 0;
+}
+
+static int need_D(mlsl_dev *d, size_t doubles)
+{
+    if (doubles <= d->dcap) return 0;
+    nla_dev_free(d->d_D);
+    d->d_D = (double *) nla_dev_malloc(sizeof(double) * doubles);
+    d->dcap = d->d_D ? doubles : 0;
+    if (!d->d_D) MFAIL(d, "out of device memory (distance matrix)");
+    return 0;
+}
+
+/* insert row id `r` (value f) into an order array: before the first element that is not smaller */
+static void ord_insert(size_t *ord, size_t cnt, const double *F, size_t r)
+{
+    size_t lo = 0, hi = cnt;
+    const double f = F[r];
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (F[ord[mid]] < f) lo = mid + 1; else hi = mid; }
+    memmove(ord + lo + 1, ord + lo, (cnt - lo) * sizeof *ord);
+    ord[lo] = r;
+}
+
+nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
+                               double *minf, nla_stopping *stop, nlopt_opt local_opt, int Nsamples, int lds)
+{
+    mlsl_dev D;
+    nlopt_result ret = NLOPT_SUCCESS;
+    nlopt_amd_stats *st = opt ? &opt->stats : NULL;
+    nla_lbfgs_params prm;
+    nla_lbfgs_result res[BATCH_MAX];
+    size_t cand[BATCH_MAX];
+    double R_prefactor, *Fnew = NULL, *rowbuf = NULL, best_f = HUGE_VAL;
+    const double dlm = 1.0, dbound = 1e-6;
+    const double *lbh = lb, *ubh = ub;
+    int i, j, mf, best_is_lm = 0, loc_maxeval;
+    size_t best_row = 0;
+    (void) f_data;
+
+    memset(&D, 0, sizeof D);
+    D.N = Nsamples ? Nsamples : 4;                                             /* mlsl.c:283-286 */
+    if (D.N < 1) { nla_stop_msg(stop, "population %d is too small", D.N); return NLOPT_INVALID_ARGS; }
+    if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
+    D.obj = nlopt_amd_objective_id(f);
+    if (D.obj < 0) { nla_stop_msg(stop, "nlopt_amd: MLSL is provided for device objectives (nlopt_amd_objective) only"); return NLOPT_INVALID_ARGS; }
+    if (!local_opt || local_opt->algorithm != NLOPT_LD_LBFGS) {
+        nla_stop_msg(stop, "nlopt_amd: MLSL is provided with NLOPT_LD_LBFGS as the local optimizer only");
+        return NLOPT_INVALID_ARGS;
+    }
+    if (lds && n <= SOBOL_MAXDIM) {
+        nla_stop_msg(stop, "nlopt_amd: Sobol sampling (MLSL_LDS with n <= %d) is not provided; use the non-LDS variant", SOBOL_MAXDIM);
+        return NLOPT_INVALID_ARGS;
+    }
+    if (local_opt->xtol_abs) { nla_stop_msg(stop, "nlopt_amd: LD_LBFGS on the device does not take xtol_abs"); return NLOPT_INVALID_ARGS; }
+    D.n = n; D.ld = (n + 1) & ~1;
+    R_prefactor = sqrt(2. / K2PI) * pow(gam(n) * MLSL_SIGMA, 1.0 / n);            /* mlsl.c:313-317 */
+    for (i = 0; i < n; ++i) R_prefactor *= pow(ub[i] - lb[i], 1.0 / n);
+
+    /* the local optimiser as nlopt_optimize_limited(local_opt, ...) would configure it (mlsl.c:303-306,404-407) */
+    memset(&prm, 0, sizeof prm);
+    prm.minf_max = stop->minf_max; prm.ftol_rel = local_opt->ftol_rel; prm.ftol_abs = local_opt->ftol_abs;
+    prm.xtol_rel = local_opt->xtol_rel; prm.tolg = nlopt_get_param(local_opt, "tolg", 0.);
+    loc_maxeval = local_opt->maxeval;
+    mf = nla_lbfgs_default_mf(n, (int) local_opt->vector_storage, 0);
+
+    D.st = nla_stream_create();
+    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { mfree(&D); return NLOPT_OUT_OF_MEMORY; }
+    D.d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
+    D.d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
+    D.d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (size_t) D.N);
+    D.d_tmp = (double *) nla_dev_malloc(sizeof(double) * (size_t) (D.N > BATCH_MAX ? D.N : BATCH_MAX));
+    Fnew = (double *) malloc(sizeof(double) * (size_t) D.N);
+    if (!D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !Fnew || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+        nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
+        nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
+        mfree(&D); free(Fnew);
+        return NLOPT_OUT_OF_MEMORY;
+    }
+    D.lb = nla_lbfgs_ctx_create(D.obj, n, BATCH_MAX, mf, D.d_lb, D.d_ub, D.st);
+    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (L-BFGS batch)"); mfree(&D); free(Fnew); return NLOPT_OUT_OF_MEMORY; }
+#define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
+#define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
+#define STOPS(fv) do { if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP; else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED; \
+        else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED; else if ((fv) < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED; } while (0)
+#define GET_MINF() do { if (D.npts) { best_f = D.F[D.ord[0]]; best_row = D.ord[0]; best_is_lm = 0; } \
+        if (D.nlms && D.LF[D.lord[0]] < best_f) { best_f = D.LF[D.lord[0]]; best_row = D.lord[0]; best_is_lm = 1; } } while (0)
+
+    /* the starting guess is the first point (mlsl.c:326-340) */
+    if (nla_memcpy_h2d(D.d_P, x, sizeof(double) * (size_t) n, D.st) || nla_k_eval(D.obj, n, D.ld, D.d_P, 1, D.d_F, D.st) ||
+        nla_memcpy_d2h(D.F, D.d_F, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "first evaluation failed"); DEVFAIL(); }
+    ++*stop->nevals_p;
+    NEWPT(0);
+    STOPS(D.F[0]);
+
+    while (ret == NLOPT_SUCCESS) {
+        double R, t0 = nla_seconds();
+        size_t old = D.npts, used = 0, idx;
+        int remaining;
+        GET_MINF();                                                            /* mlsl.c:347 */
+
+        /* ---- sampling phase (mlsl.c:349-374) ---- */
+        if (grow_pts(&D, old + (size_t) D.N)) DEVFAIL();
+        if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
+        if (nla_k_crs_init_rows(D.obj, n, D.ld, D.d_lb, D.d_ub, D.d_words, (int64_t) old, D.N, D.d_P, D.d_F, D.st) ||
+            nla_memcpy_d2h(Fnew, D.d_F + old, sizeof(double) * (size_t) D.N, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+        for (i = 0; i < D.N && ret == NLOPT_SUCCESS; ++i) {
+            D.F[old + (size_t) i] = Fnew[i];
+            ++*stop->nevals_p;
+            if (st) ++st->evals_trial;
+            NEWPT(old + (size_t) i);
+            used = (size_t) i + 1;
+            if (opt && opt->trace) {
+                if (opt->trace_len < opt->trace_cap) { nlopt_amd_trace_rec *tr = opt->trace + opt->trace_len; tr->f = Fnew[i]; tr->row = (int64_t) (old + (size_t) i); tr->kind = 3; tr->accepted = 0; }
+                ++opt->trace_len;
+            }
+            STOPS(Fnew[i]);
+        }
+        D.words_used += 2ULL * (uint64_t) n * (uint64_t) used;
+        if (ret != NLOPT_SUCCESS) break;
+        {
+            const int na = D.N, nb = (int) D.npts;
+            if (need_D(&D, (size_t) na * (size_t) nb)) DEVFAIL();
+            /* closest_pt_d of the new points: over every point with smaller f; of the old, not yet
+             * minimised points: over the new points with smaller f (find_closest_pt + pts_update_newpt) */
+            if (nla_memcpy_h2d(D.d_cpd, D.cpd, sizeof(double) * D.npts, D.st) ||
+                nla_memcpy_h2d(D.d_min, D.minimized, sizeof(int32_t) * D.npts, D.st) ||
+                nla_k_mlsl_dist2(n, D.ld, D.d_P + old * (size_t) D.ld, na, D.d_P, nb, D.d_D, D.st) ||
+                nla_k_mlsl_rowmin(D.d_D, nb, na, nb, D.d_F + old, D.d_F, NULL, D.d_cpd + old, D.st) ||
+                nla_k_mlsl_colmin(D.d_D, nb, na, (int) old, D.d_F + old, D.d_F, D.d_min, D.d_cpd, D.st) ||
+                nla_memcpy_d2h(D.cpd, D.d_cpd, sizeof(double) * D.npts, D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+            if (D.nlms) {                                                      /* find_closest_lm */
+                if (need_D(&D, (size_t) na * D.nlms)) DEVFAIL();
+                if (nla_k_mlsl_dist2(n, D.ld, D.d_P + old * (size_t) D.ld, na, D.d_LM, (int) D.nlms, D.d_D, D.st) ||
+                    nla_k_mlsl_rowmin(D.d_D, (int) D.nlms, na, (int) D.nlms, D.d_F + old, D.d_LF, NULL, D.d_tmp, D.st) ||
+                    nla_memcpy_d2h(D.cld + old, D.d_tmp, sizeof(double) * (size_t) na, D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+            }
+            if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+        }
+        if (st) st->t_eval_s += nla_seconds() - t0;
+
+        /* ---- local phase (mlsl.c:377-428) ---- */
+        t0 = nla_seconds();
+        R = R_prefactor * pow(log((double) D.npts) / D.npts, 1.0 / n);
+        idx = 0;
+        remaining = (int) (ceil(MLSL_GAMMA * D.npts) + 0.5);
+        while (idx < D.npts && remaining > 0 && ret == NLOPT_SUCCESS) {
+            int nb = 0, c;
+            size_t scan = idx;
+            int rem = remaining, eff;
+            long limited;
+            /* the next candidates that are potential minimisers right now (is_potential_minimizer, :196-221) */
+            while (scan < D.npts && rem > 0 && nb < BATCH_MAX) {
+                const size_t r = D.ord[scan];
+                ++scan; --rem;
+                if (D.minimized[r] || D.cpd[r] <= R * R || D.cld[r] <= (dlm * R) * (dlm * R)) continue;
+                cand[nb++] = scan - 1;
+            }
+            if (nb == 0) { idx = scan; remaining = rem; break; }
+            /* bound test needs the coordinates: done on the start rows after they are gathered (below) */
+            for (c = 0; c < nb; ++c)
+                if (nla_memcpy_d2d(nla_lbfgs_ctx_X(D.lb) + (size_t) c * D.ld, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+            if (!rowbuf) rowbuf = (double *) malloc(sizeof(double) * (size_t) n * BATCH_MAX);
+            for (c = 0; c < nb; ++c)
+                if (nla_memcpy_d2h(rowbuf + (size_t) c * n, nla_lbfgs_ctx_X(D.lb) + (size_t) c * D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+            if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+            /* local searches of the whole batch, then the distances of their minimisers to every point */
+            limited = (long) stop->maxeval - (long) *stop->nevals_p;             /* nlopt_optimize_limited, optimize.c:1097-1100 */
+            eff = loc_maxeval;
+            if (loc_maxeval <= 0 || (limited > 0 && limited < loc_maxeval)) eff = (int) limited;
+            prm.maxeval = eff;
+            if (nla_lbfgs_ctx_run(D.lb, nb, &prm, res)) { snprintf(D.err, sizeof D.err, "L-BFGS batch failed"); DEVFAIL(); }
+            if (need_D(&D, (size_t) nb * D.npts)) DEVFAIL();
+            if ((size_t) nb * D.npts > D.hcap) {
+                nla_host_free(D.h_D);
+                D.hcap = 2 * (size_t) BATCH_MAX * D.npts;
+                D.h_D = (double *) nla_host_malloc(sizeof(double) * D.hcap);
+                if (!D.h_D) { D.hcap = 0; snprintf(D.err, sizeof D.err, "out of pinned memory"); DEVFAIL(); }
+            }
+            if (nla_k_mlsl_dist2(n, D.ld, nla_lbfgs_ctx_X(D.lb), nb, D.d_P, (int) D.npts, D.d_D, D.st) ||
+                nla_memcpy_d2h(D.h_D, D.d_D, sizeof(double) * (size_t) nb * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+            /* commit in walk order */
+            for (c = 0; c < nb && ret == NLOPT_SUCCESS; ++c) {
+                const size_t r = D.ord[cand[c]];
+                const double *xr = rowbuf + (size_t) c * n;
+                int pot = !(D.cld[r] <= (dlm * R) * (dlm * R));               /* may have changed since the batch was formed */
+                double lf;
+                size_t lrow, k;
+                /* nodes between the previous candidate and this one were visited and skipped */
+                remaining -= (int) (cand[c] + 1 - idx);
+                idx = cand[c] + 1;
+                if (pot) for (j = 0; j < n; ++j)
+                    if ((xr[j] - lb[j] <= dbound * R || ub[j] - xr[j] <= dbound * R) && ub[j] - lb[j] > dbound * R) { pot = 0; break; }
+                if (!pot) continue;
+                if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; break; }
+                if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; break; }
+                if (stop->maxtime > 0 && nla_seconds() - stop->start >= stop->maxtime) { ret = NLOPT_MAXTIME_REACHED; break; }
+                /* did this search run under the evaluation limit it would have had in the serial order? */
+                limited = (long) stop->maxeval - (long) *stop->nevals_p;
+                eff = loc_maxeval;
+                if (loc_maxeval <= 0 || (limited > 0 && limited < loc_maxeval)) eff = (int) limited;
+                if (eff > 0 && eff != prm.maxeval && res[c].nevals >= eff) {
+                    /* the limit binds differently than assumed: redo this one search alone with the exact limit */
+                    nla_lbfgs_params p1 = prm;
+                    nla_lbfgs_result r1;
+                    p1.maxeval = eff;
+                    if (nla_memcpy_d2d(nla_lbfgs_ctx_X(D.lb), D.d_P + r * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
+                        nla_lbfgs_ctx_run(D.lb, 1, &p1, &r1) ||
+                        nla_k_mlsl_dist2(n, D.ld, nla_lbfgs_ctx_X(D.lb), 1, D.d_P, (int) D.npts, D.d_D, D.st) ||
+                        nla_memcpy_d2h(D.h_D + (size_t) c * D.npts, D.d_D, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "L-BFGS rerun failed"); DEVFAIL(); }
+                    res[c] = r1;
+                    /* the rest of the batch was computed from slot rows that this rerun overwrote in slot 0 only */
+                    if (c != 0 && nb > 1) { /* slot 0's minimiser was already committed or dropped */ }
+                    lrow = 0;
+                } else lrow = (size_t) c;
+                *stop->nevals_p += res[c].nevals;                               /* fcount, mlsl.c:246-251 */
+                if (st) { st->evals_mutation += (uint64_t) res[c].nevals; ++st->accepted; }
+                D.minimized[r] = 1;
+                if (opt && opt->trace) {
+                    if (opt->trace_len < opt->trace_cap) { nlopt_amd_trace_rec *tr = opt->trace + opt->trace_len; tr->f = res[c].f; tr->row = (int64_t) r; tr->kind = 4; tr->accepted = res[c].nevals; }
+                    ++opt->trace_len;
+                }
+                if (res[c].ret < 0) { ret = (nlopt_result) res[c].ret; goto done_noget; }
+                lf = res[c].f;
+                if (grow_lms(&D, D.nlms + 1)) DEVFAIL();
+                if (nla_memcpy_d2d(D.d_LM + D.nlms * (size_t) D.ld, nla_lbfgs_ctx_X(D.lb) + lrow * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
+                    nla_memcpy_h2d(D.d_LF + D.nlms, &res[c].f, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
+                D.LF[D.nlms] = lf;
+                ord_insert(D.lord, D.nlms, D.LF, D.nlms);
+                ++D.nlms;
+                if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP;
+                else if (lf < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
+                else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
+                else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
+                else {
+                    const double *dr = D.h_D + (size_t) c * D.npts;              /* pts_update_newlm, mlsl.c:180-194 */
+                    for (k = 0; k < D.npts; ++k)
+                        if (D.F[k] > lf && !D.minimized[k] && dr[k] < D.cld[k]) D.cld[k] = dr[k];
+                }
+            }
+            if (ret == NLOPT_SUCCESS && c == nb) {
+                /* nodes scanned after the last candidate of the batch (none qualified) are visited too */
+                remaining -= (int) (scan - idx);
+                idx = scan;
+            }
+        }
+        if (st) { st->t_evolve_s += nla_seconds() - t0; ++st->generations; }
+    }
+    GET_MINF();                                                                /* mlsl.c:431 */
+done_noget:
+    if (ret != NLOPT_FAILURE || best_f < HUGE_VAL) {
+        const double *src = best_is_lm ? D.d_LM + best_row * (size_t) D.ld : D.d_P + best_row * (size_t) D.ld;
+        if (best_f < HUGE_VAL) {
+            *minf = best_f;
+            if (nla_memcpy_d2h(x, src, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) { nla_stop_msg(stop, "device engine: result read-back failed"); ret = NLOPT_FAILURE; }
+        }
+    }
+done:
+    if (st) st->mt_words = D.words_used;
+    mfree(&D);
+    free(Fnew); free(rowbuf);
+    return ret;
+}

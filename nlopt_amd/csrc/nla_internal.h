@@ -173,10 +173,19 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
 
 /* LD_LBFGS (lbfgs_driver.c) */
 int nla_lbfgs_default_mf(int n, int mf, int maxeval);
+typedef struct nla_lbfgs_ctx nla_lbfgs_ctx;
+nla_lbfgs_ctx *nla_lbfgs_ctx_create(int obj, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream);
+void nla_lbfgs_ctx_destroy(nla_lbfgs_ctx *c);
+double *nla_lbfgs_ctx_X(nla_lbfgs_ctx *c);
+int nla_lbfgs_ctx_run(nla_lbfgs_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res);
 int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
                         const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen);
 nlopt_result nla_lbfgs_minimize(int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                                 nla_stopping *stop, int mf, double tolg);
+
+/* reference-shaped entry (src/algs/mlsl/mlsl.h:34-41) */
+nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
+                               double *minf, nla_stopping *stop, nlopt_opt local_opt, int Nsamples, int lds);
 
 /* HIP engine (crs_engine.c) */
 typedef struct nla_crs_hip_engine nla_crs_hip_engine;
