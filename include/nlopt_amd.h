@@ -73,6 +73,29 @@ typedef struct {
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 
+/* ---- multi-GPU (one process per GPU): the collective the sharded runs use --------------------------
+ * Every rank creates the same optimiser, seeds the same nlopt_srand() and calls nlopt_optimize() with
+ * the same arguments; the library partitions the data-parallel device work of each step over the
+ * ranks and exchanges results with an ALL-GATHER: ISRES — the candidates' f/penalty;
+ * MLSL — the minimisers found by the local searches dealt to each rank; CRS2_LM — the rows of the
+ * initial population.  Every rank returns the same x, f and nlopt_result.  Without a communicator
+ * (default) the run is single-process.
+ *   RCCL transport: the id comes from nlopt_amd_rccl_unique_id() on rank 0 and reaches the other ranks
+ *   through the launcher (torch.distributed / MPI broadcast, a file, ...); create after hipSetDevice.
+ *   Host transport: an all-gather on host buffers supplied by the caller (MPI_Allgather, gloo, ...):
+ *   h_recv[r*bytes ..] := rank r's h_send[0..bytes), return 0 on success. */
+typedef struct nlopt_amd_comm_s nlopt_amd_comm;
+typedef int (*nlopt_amd_allgather_fn)(void *ctx, const void *h_send, void *h_recv, size_t bytes);
+int nlopt_amd_rccl_unique_id(void *id128);                                   /* 0 = ok */
+nlopt_amd_comm *nlopt_amd_comm_create_rccl(int rank, int world, const void *id128);
+nlopt_amd_comm *nlopt_amd_comm_create_host(int rank, int world, nlopt_amd_allgather_fn fn, void *ctx);
+void nlopt_amd_comm_destroy(nlopt_amd_comm *c);
+int nlopt_amd_comm_rank(const nlopt_amd_comm *c);
+int nlopt_amd_comm_world(const nlopt_amd_comm *c);
+const char *nlopt_amd_comm_error(const nlopt_amd_comm *c);
+void nlopt_amd_comm_counters(const nlopt_amd_comm *c, uint64_t *calls, uint64_t *bytes);   /* collectives issued / bytes gathered */
+nlopt_result nlopt_amd_set_comm(nlopt_opt opt, nlopt_amd_comm *c);            /* borrowed, not copied; NULL = single process */
+
 /* Stepwise CRS2_LM: the same run as nlopt_optimize(), paused between passes (used by
  * bench.py to time exactly K steps, and by callers that want to poll).  open() performs the
  * population initialisation (crs_init, crs.c:165-229); step() runs until the algorithm stops or at

@@ -197,6 +197,26 @@ def lib():
     L.nla_mt_import.argtypes = [vp, C.c_int]
     L.nla_mt_import.restype = None
     L.nla_mt_charpoly_terms.argtypes = [C.POINTER(C.POINTER(C.c_int))]
+    # multi-GPU collectives (comm.c)
+    L.nlopt_amd_rccl_unique_id.argtypes = [vp]
+    L.nlopt_amd_comm_create_rccl.argtypes = [C.c_int, C.c_int, vp]
+    L.nlopt_amd_comm_create_rccl.restype = vp
+    L.nlopt_amd_comm_create_host.argtypes = [C.c_int, C.c_int, vp, vp]
+    L.nlopt_amd_comm_create_host.restype = vp
+    L.nlopt_amd_comm_destroy.argtypes = [vp]
+    L.nlopt_amd_comm_destroy.restype = None
+    L.nlopt_amd_comm_rank.argtypes = [vp]
+    L.nlopt_amd_comm_world.argtypes = [vp]
+    L.nlopt_amd_comm_error.argtypes = [vp]
+    L.nlopt_amd_comm_error.restype = C.c_char_p
+    L.nlopt_amd_comm_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.nlopt_amd_comm_counters.restype = None
+    L.nlopt_amd_set_comm.argtypes = [vp, vp]
+    L.nla_comm_allgather_host.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.nla_comm_allgather_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.nla_comm_partition.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.nla_comm_partition.restype = None
+    L.nla_dev_set.argtypes = [C.c_int]
     _lib = L
     return L
 
@@ -259,6 +279,104 @@ class DevBuf:
             self.free()
         except Exception:
             pass
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class Comm:
+    """The communicator of a multi-GPU run (include/nlopt_amd.h, comm.c): one process per GPU, every rank
+    builds the same Opt, calls srand() with the same seed and optimize() with the same arguments."""
+
+    def __init__(self, handle, keep=None):
+        self._L = lib()
+        self._h = handle
+        self._keep = keep
+        if not handle:
+            raise RuntimeError("could not create the communicator")
+
+    @classmethod
+    def rccl(cls, rank, world, uid):
+        """RCCL over xGMI; `uid` = the 128 bytes of rccl_unique_id() made on rank 0. Call after selecting the device."""
+        buf = C.create_string_buffer(bytes(uid), 128)
+        return cls(lib().nlopt_amd_comm_create_rccl(int(rank), int(world), C.cast(buf, C.c_void_p)))
+
+    @classmethod
+    def host(cls, rank, world, allgather):
+        """host transport: allgather(send: bytes) -> bytes of length world*len(send), rank-major"""
+        def _cb(ctx, send, recv, nbytes):
+            try:
+                out = allgather(C.string_at(send, nbytes))
+                if len(out) != nbytes * world:
+                    return 2
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:           # must not propagate through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = ALLGATHER_FN(_cb)
+        return cls(lib().nlopt_amd_comm_create_host(int(rank), int(world), C.cast(fn, C.c_void_p), None), keep=fn)
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        """communicator over an initialised torch.distributed process group: backend nccl (= RCCL on ROCm)
+        -> the library's own RCCL communicator (the unique id is broadcast through the group); gloo ->
+        host transport through dist.all_gather_into_tensor on CPU tensors."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if dist.get_backend(group) == "nccl":
+            uid = [rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, group=group)
+            return cls.rccl(rank, world, uid[0])
+
+        def allgather(b):
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+            out = torch.empty(world * t.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, t, group=group)
+            return out.numpy().tobytes()
+        return cls.host(rank, world, allgather)
+
+    @property
+    def rank(self): return self._L.nlopt_amd_comm_rank(self._h)
+
+    @property
+    def world(self): return self._L.nlopt_amd_comm_world(self._h)
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._L.nlopt_amd_comm_counters(self._h, C.byref(a), C.byref(b))
+        return dict(collectives=a.value, bytes=b.value)
+
+    def error(self):
+        return self._L.nlopt_amd_comm_error(self._h).decode()
+
+    def allgather_host(self, a):
+        """all-gather of a numpy array over the communicator's host path (tests)"""
+        a = np.ascontiguousarray(a)
+        out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+        rc = self._L.nla_comm_allgather_host(self._h, a.ctypes.data, out.ctypes.data, a.nbytes, None)
+        if rc:
+            raise RuntimeError("all-gather failed: " + self.error())
+        return out
+
+    def partition(self, count):
+        per, first, mine = C.c_int64(), C.c_int64(), C.c_int64()
+        self._L.nla_comm_partition(self._h, count, C.byref(per), C.byref(first), C.byref(mine))
+        return per.value, first.value, mine.value
+
+    def destroy(self):
+        h, self._h = self._h, None
+        if h:
+            self._L.nlopt_amd_comm_destroy(h)
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    if lib().nlopt_amd_rccl_unique_id(C.cast(buf, C.c_void_p)) != 0:
+        raise RuntimeError("RCCL is not available (librccl.so could not be loaded)")
+    return buf.raw
 
 
 class Opt:
@@ -353,6 +471,12 @@ class Opt:
     def set_maxeval(self, v): self._ck(self._L.nlopt_set_maxeval(self._h, int(v)))
     def set_maxtime(self, v): self._ck(self._L.nlopt_set_maxtime(self._h, float(v)))
     def set_population(self, v): self._ck(self._L.nlopt_set_population(self._h, int(v)))
+
+    def set_comm(self, comm):
+        """multi-GPU run over `comm` (a Comm, kept alive by this object); None = single process"""
+        self._comm = comm
+        self._ck(self._L.nlopt_amd_set_comm(self._h, comm._h if comm is not None else None))
+
     def set_param(self, name, v): self._ck(self._L.nlopt_set_param(self._h, name.encode(), float(v)))
     def get_numevals(self): return self._L.nlopt_get_numevals(self._h)
     def get_errmsg(self):

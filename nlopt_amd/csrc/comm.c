@@ -1,0 +1,188 @@
+/* comm.c — the collective layer of the multi-GPU runs: one process per GPU, every rank runs the same
+ * deterministic host driver on the same MT19937 stream and the data-parallel device work of a step
+ * is partitioned over the ranks; the only exchange the algorithms need is an ALL-GATHER (SURVEY.md
+ * §8e: f / penalty of the candidates, rows of new population members, local minima).
+ *
+ * Two transports behind one interface:
+ *   RCCL   ncclAllGather on device buffers over xGMI.  librccl is dlopen()ed on first use so that
+ *          single-GPU programs never load or initialise it; the 128-byte unique id is created on
+ *          rank 0 (nlopt_amd_rccl_unique_id) and handed to every rank by the launcher.
+ *   host   a user-supplied all-gather on host buffers (MPI, gloo, ...); device data are staged
+ *          through pinned memory.  This is what the world_size-2 tests use.
+ *
+ * The reference has no counterpart (it is single-threaded).
+ */
+#include "nla_internal.h"
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { char internal[128]; } rccl_uid;              /* ncclUniqueId, NCCL_UNIQUE_ID_BYTES = 128 */
+typedef int (*fn_get_uid)(rccl_uid *);
+typedef int (*fn_init_rank)(void **comm, int nranks, rccl_uid id, int rank);
+typedef int (*fn_allgather)(const void *send, void *recv, size_t count, int dtype, void *comm, void *stream);
+typedef int (*fn_destroy)(void *comm);
+typedef const char *(*fn_errstr)(int);
+#define RCCL_UINT8 1                                          /* ncclUint8 */
+
+static struct {
+    void *dl;
+    fn_get_uid get_uid; fn_init_rank init_rank; fn_allgather allgather; fn_destroy destroy; fn_errstr errstr;
+} R;
+
+static int rccl_load(void)
+{
+    if (R.dl) return 0;
+    R.dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.dl) R.dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.dl) R.dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.dl) return -1;
+    R.get_uid = (fn_get_uid) dlsym(R.dl, "ncclGetUniqueId");
+    R.init_rank = (fn_init_rank) dlsym(R.dl, "ncclCommInitRank");
+    R.allgather = (fn_allgather) dlsym(R.dl, "ncclAllGather");
+    R.destroy = (fn_destroy) dlsym(R.dl, "ncclCommDestroy");
+    R.errstr = (fn_errstr) dlsym(R.dl, "ncclGetErrorString");
+    if (!R.get_uid || !R.init_rank || !R.allgather || !R.destroy) { dlclose(R.dl); R.dl = NULL; return -1; }
+    return 0;
+}
+
+struct nlopt_amd_comm_s {
+    int rank, world;
+    void *rccl;                         /* ncclComm_t, or NULL: host transport */
+    nlopt_amd_allgather_fn fn; void *ctx;
+    void *h_send, *h_recv; size_t h_cap;          /* pinned staging (host transport / host data over RCCL) */
+    void *d_send, *d_recv; size_t d_cap;          /* device staging for host data over RCCL */
+    uint64_t calls, bytes;
+    char err[160];
+};
+
+int nlopt_amd_rccl_unique_id(void *id128)
+{
+    rccl_uid id;
+    if (!id128 || rccl_load()) return -1;
+    if (R.get_uid(&id)) return -2;
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+nlopt_amd_comm *nlopt_amd_comm_create_rccl(int rank, int world, const void *id128)
+{
+    nlopt_amd_comm *c;
+    rccl_uid id;
+    if (world < 1 || rank < 0 || rank >= world || !id128 || rccl_load()) return NULL;
+    c = (nlopt_amd_comm *) calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->rank = rank; c->world = world;
+    memcpy(&id, id128, sizeof id);
+    if (R.init_rank(&c->rccl, world, id, rank) || !c->rccl) { free(c); return NULL; }
+    return c;
+}
+
+nlopt_amd_comm *nlopt_amd_comm_create_host(int rank, int world, nlopt_amd_allgather_fn fn, void *ctx)
+{
+    nlopt_amd_comm *c;
+    if (world < 1 || rank < 0 || rank >= world || (!fn && world > 1)) return NULL;
+    c = (nlopt_amd_comm *) calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->rank = rank; c->world = world; c->fn = fn; c->ctx = ctx;
+    return c;
+}
+
+void nlopt_amd_comm_destroy(nlopt_amd_comm *c)
+{
+    if (!c) return;
+    if (c->rccl) R.destroy(c->rccl);
+    nla_host_free(c->h_send); nla_host_free(c->h_recv);
+    nla_dev_free(c->d_send); nla_dev_free(c->d_recv);
+    free(c);
+}
+
+int nlopt_amd_comm_rank(const nlopt_amd_comm *c) { return c ? c->rank : 0; }
+int nlopt_amd_comm_world(const nlopt_amd_comm *c) { return c ? c->world : 1; }
+const char *nlopt_amd_comm_error(const nlopt_amd_comm *c) { return c ? c->err : ""; }
+void nlopt_amd_comm_counters(const nlopt_amd_comm *c, uint64_t *calls, uint64_t *bytes)
+{
+    if (calls) *calls = c ? c->calls : 0;
+    if (bytes) *bytes = c ? c->bytes : 0;
+}
+
+nlopt_result nlopt_amd_set_comm(nlopt_opt opt, nlopt_amd_comm *c)
+{
+    if (!opt) return NLOPT_INVALID_ARGS;
+    opt->comm = c;
+    return NLOPT_SUCCESS;
+}
+
+static int need_host(nlopt_amd_comm *c, size_t bytes)
+{
+    if (bytes * (size_t) c->world <= c->h_cap) return 0;
+    nla_host_free(c->h_send); nla_host_free(c->h_recv);
+    c->h_cap = 2 * bytes * (size_t) c->world;
+    c->h_send = nla_host_malloc(c->h_cap / (size_t) c->world);
+    c->h_recv = nla_host_malloc(c->h_cap);
+    if (!c->h_send || !c->h_recv) { c->h_cap = 0; snprintf(c->err, sizeof c->err, "out of pinned memory for the collective staging"); return -1; }
+    return 0;
+}
+static int need_dev(nlopt_amd_comm *c, size_t bytes)
+{
+    if (bytes * (size_t) c->world <= c->d_cap) return 0;
+    nla_dev_free(c->d_send); nla_dev_free(c->d_recv);
+    c->d_cap = 2 * bytes * (size_t) c->world;
+    c->d_send = nla_dev_malloc(c->d_cap / (size_t) c->world);
+    c->d_recv = nla_dev_malloc(c->d_cap);
+    if (!c->d_send || !c->d_recv) { c->d_cap = 0; snprintf(c->err, sizeof c->err, "out of device memory for the collective staging"); return -1; }
+    return 0;
+}
+
+/* device buffers: d_recv (world*bytes, rank-major) := all-gather of every rank's d_send (bytes).
+ * RCCL: enqueued on `stream` (asynchronous).  Host transport: synchronises `stream`. */
+int nla_comm_allgather_dev(nlopt_amd_comm *c, const void *d_send, void *d_recv, size_t bytes, void *stream)
+{
+    int rc;
+    /* a 1-rank RCCL communicator still goes through ncclAllGather (that is how a 1-GPU box exercises the transport) */
+    if (!c || (c->world == 1 && !c->rccl)) return (bytes && d_recv != d_send) ? nla_memcpy_d2d(d_recv, d_send, bytes, stream) : 0;
+    ++c->calls; c->bytes += bytes * (size_t) c->world;
+    if (c->rccl) {
+        rc = R.allgather(d_send, d_recv, bytes, RCCL_UINT8, c->rccl, stream);
+        if (rc) snprintf(c->err, sizeof c->err, "ncclAllGather failed: %s", R.errstr ? R.errstr(rc) : "?");
+        return rc;
+    }
+    if (need_host(c, bytes)) return -1;
+    if (nla_memcpy_d2h(c->h_send, d_send, bytes, stream) || nla_stream_sync(stream)) { snprintf(c->err, sizeof c->err, "staging copy failed"); return -1; }
+    if ((rc = c->fn(c->ctx, c->h_send, c->h_recv, bytes))) { snprintf(c->err, sizeof c->err, "host all-gather callback failed (%d)", rc); return rc; }
+    if (nla_memcpy_h2d(d_recv, c->h_recv, bytes * (size_t) c->world, stream) || nla_stream_sync(stream)) { snprintf(c->err, sizeof c->err, "staging copy failed"); return -1; }
+    return 0;
+}
+
+/* host buffers (small control data); synchronous */
+int nla_comm_allgather_host(nlopt_amd_comm *c, const void *h_send, void *h_recv, size_t bytes, void *stream)
+{
+    int rc;
+    if (!c || (c->world == 1 && !c->rccl)) { memmove(h_recv, h_send, bytes); return 0; }
+    ++c->calls; c->bytes += bytes * (size_t) c->world;
+    if (!c->rccl) {
+        if ((rc = c->fn(c->ctx, h_send, h_recv, bytes))) snprintf(c->err, sizeof c->err, "host all-gather callback failed (%d)", rc);
+        return rc;
+    }
+    if (need_dev(c, bytes)) return -1;
+    if (nla_memcpy_h2d(c->d_send, h_send, bytes, stream)) return -1;
+    rc = R.allgather(c->d_send, c->d_recv, bytes, RCCL_UINT8, c->rccl, stream);
+    if (rc) { snprintf(c->err, sizeof c->err, "ncclAllGather failed: %s", R.errstr ? R.errstr(rc) : "?"); return rc; }
+    if (nla_memcpy_d2h(h_recv, c->d_recv, bytes * (size_t) c->world, stream) || nla_stream_sync(stream)) return -1;
+    return 0;
+}
+
+/* block partition of `count` units: every rank owns `per` = ceil(count/world) slots (all-gather wants
+ * equal contributions); rank r's real units are [first, first+mine). */
+void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, int64_t *first, int64_t *mine)
+{
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    const int64_t p = (count + world - 1) / world;
+    int64_t f = p * rank, m;
+    if (f > count) f = count;
+    m = count - f < p ? count - f : p;
+    if (per) *per = p;
+    if (first) *first = f;
+    if (mine) *mine = m;
+}

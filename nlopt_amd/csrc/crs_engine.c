@@ -20,6 +20,7 @@
 
 #define INIT_CHUNK_WORDS (1ULL << 28)      /* 1 GiB of stream words per init pass */
 #define KCAP 1024                          /* slot ring (power of two) */
+#define ROWPAD 64                          /* spare rows behind X / F: the init all-gather wants equal blocks per rank (world <= 64) */
 
 typedef struct {
     int64_t index;                 /* batch number (blocks [index*B, (index+1)*B)), -1 = empty */
@@ -52,6 +53,7 @@ struct nla_crs_hip_engine {
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
     nlopt_amd_stats *stats;
+    nlopt_amd_comm *comm;          /* multi-GPU: initial rows are generated in rank blocks and all-gathered; NULL = single process */
     char err[256];
 };
 
@@ -130,8 +132,8 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     if (!e->mts) goto fail;
     e->d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld);
     e->d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld);
-    e->d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * (size_t) N);
-    e->d_F = (double *) nla_dev_malloc(sizeof(double) * (size_t) N);
+    e->d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * (size_t) (N + ROWPAD));
+    e->d_F = (double *) nla_dev_malloc(sizeof(double) * (size_t) (N + ROWPAD));
     e->d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * 2 * B);
     e->d_jn = (int32_t *) nla_dev_malloc(sizeof(int32_t) * 2 * B);
     e->d_last = (int32_t *) nla_dev_malloc(sizeof(int32_t) * 2 * B);
@@ -162,17 +164,26 @@ fail:
 }
 
 /* ---- ops ------------------------------------------------------------------------------------ */
+/* crs_init's row loop (crs.c:211-226).  Row i >= 1 owns stream words [2n(i-1), 2n i), so any block of
+ * rows can be produced independently: with a communicator, rank r generates and evaluates rows
+ * [1 + r*per, 1 + (r+1)*per) and the rows and their f are ALL-GATHERED in place ("CRS
+ * init"); every rank then holds the whole population and runs the identical trial chain. */
 static int op_init_population(void *ve, const double *x0, double *F)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const int n = e->n;
+    const int world = nlopt_amd_comm_world(e->comm), rank = nlopt_amd_comm_rank(e->comm);
     const uint64_t wpr = 2ULL * (uint64_t) n;            /* words per row */
+    const int64_t per = (e->N - 1 + world - 1) / world;  /* rows per rank */
+    const int64_t first = 1 + per * rank;
+    const int64_t last = first + per < e->N ? first + per : e->N;     /* this rank's rows: [first, last) */
     int64_t rows_per_chunk = (int64_t) (INIT_CHUNK_WORDS / wpr), r0;
     void *ev = nla_event_create();
     if (!ev) FAIL(e, "event create failed");
+    if (world > ROWPAD) { nla_event_destroy(ev); FAIL(e, "more than %d ranks are not supported", ROWPAD); }
     if (rows_per_chunk < 1) rows_per_chunk = 1;
-    if (rows_per_chunk > e->N - 1) rows_per_chunk = e->N - 1;
-    if (e->N > 1) {
+    if (rows_per_chunk > per) rows_per_chunk = per;
+    if (last > first) {
         size_t need = (size_t) (rows_per_chunk * (int64_t) wpr);
         if (need > e->initwords_cap) {
             nla_dev_free(e->d_initwords);
@@ -184,11 +195,11 @@ static int op_init_population(void *ve, const double *x0, double *F)
     /* row 0 = the caller's starting guess (crs.c:204) */
     if (nla_memcpy_h2d(e->d_X, x0, sizeof(double) * (size_t) n, e->main)) { nla_event_destroy(ev); FAIL(e, "H2D x0 failed"); }
     if (e->obj >= 0 && nla_k_eval(e->obj, n, e->ld, e->d_X, 1, e->d_F, e->main)) { nla_event_destroy(ev); FAIL(e, "eval launch failed"); }
-    for (r0 = 1; r0 < e->N; r0 += rows_per_chunk) {
-        int64_t nr = e->N - r0 < rows_per_chunk ? e->N - r0 : rows_per_chunk;
+    for (r0 = first; r0 < last; r0 += rows_per_chunk) {
+        int64_t nr = last - r0 < rows_per_chunk ? last - r0 : rows_per_chunk;
         /* the words buffer is reused: the generator must not overwrite it before the previous
          * chunk's init kernel has consumed it */
-        if (r0 > 1) {
+        if (r0 > first) {
             if (nla_event_record(ev, e->main) || nla_stream_wait_event(e->rng, ev)) { nla_event_destroy(ev); FAIL(e, "event failed"); }
         }
         if (nla_mtstream_fill(e->mts, wpr * (uint64_t) (r0 - 1), wpr * (uint64_t) nr, e->d_initwords)) {
@@ -197,6 +208,13 @@ static int op_init_population(void *ve, const double *x0, double *F)
         if (nla_event_record(ev, e->rng) || nla_stream_wait_event(e->main, ev)) { nla_event_destroy(ev); FAIL(e, "event failed"); }
         if (nla_k_crs_init_rows(e->obj, n, e->ld, e->d_lb, e->d_ub, e->d_initwords, r0, nr, e->d_X, e->d_F, e->main)) {
             nla_event_destroy(ev); FAIL(e, "init kernel launch failed");
+        }
+    }
+    if (world > 1) {
+        if (nla_comm_allgather_dev(e->comm, e->d_X + (size_t) first * (size_t) e->ld, e->d_X + (size_t) e->ld,
+                                   sizeof(double) * (size_t) per * (size_t) e->ld, e->main) ||
+            (e->obj >= 0 && nla_comm_allgather_dev(e->comm, e->d_F + first, e->d_F + 1, sizeof(double) * (size_t) per, e->main))) {
+            nla_event_destroy(ev); FAIL(e, "all-gather of the initial population failed: %s", nlopt_amd_comm_error(e->comm));
         }
     }
     if (e->obj >= 0) {
@@ -372,7 +390,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
         return NLOPT_OUT_OF_MEMORY;
     }
-    if (opt) (*eout)->variant = (int) nlopt_get_param(opt, "amd_gather_variant", 0);
+    if (opt) { (*eout)->variant = (int) nlopt_get_param(opt, "amd_gather_variant", 0); (*eout)->comm = opt->comm; }
     return NLOPT_SUCCESS;
 }
 

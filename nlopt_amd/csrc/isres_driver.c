@@ -17,7 +17,11 @@
  * consumed.
  *
  * Device objective + device constraints (pointer identity, nlopt_amd.h part 1) run entirely on the
- * GPU.  Any other callback takes the host-callback path: X is copied back and f / constraints are
+ * GPU.  Multi-GPU (nlopt_amd_set_comm): the candidates are block-partitioned over the
+ * ranks for the evaluation and (f, penalty, inequality penalty, feasibility) are ALL-GATHERED — the one
+ * exchange a generation needs; selection and evolution are one serial chain through the stream position
+ * and run replicated, so every rank holds the whole population and no rows travel.
+ * Any other callback takes the host-callback path: X is copied back and f / constraints are
  * called on the caller's thread in the reference's order (:137-165); ranking and evolution still
  * run on the device.  There is no CPU fallback for the device work.
  */
@@ -33,6 +37,8 @@
 typedef struct {
     int n, ld, m, p, obj, dev_eval;
     int64_t pop, survivors, units, rowwords;
+    nlopt_amd_comm *comm;
+    int64_t per, popcap;            /* candidates per rank, per * world >= pop (all-gather wants equal blocks) */
     void *st;
     nla_mtstream *mts;
     uint64_t words_used;
@@ -73,6 +79,8 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
 {
     const size_t pop = (size_t) d->pop, ld = (size_t) d->ld, n = (size_t) d->n;
     int ok = 1;
+    d->per = (d->pop + nlopt_amd_comm_world(d->comm) - 1) / nlopt_amd_comm_world(d->comm);
+    d->popcap = d->per * nlopt_amd_comm_world(d->comm);
     d->units = (d->pop + 63) / 64;
     d->rowwords = (d->pop - 1 + 63) / 64;
     if (d->rowwords < 1) d->rowwords = 1;
@@ -83,7 +91,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     if (!d->mts) return -1;
 #define A(ptr, T, count) do { d->ptr = (T *) nla_dev_malloc(sizeof(T) * (size_t) (count)); if (!d->ptr) ok = 0; } while (0)
     A(d_lb, double, ld); A(d_ub, double, ld); A(d_X, double, pop * ld); A(d_S, double, pop * ld);
-    A(d_F, double, pop); A(d_PEN, double, pop); A(d_GPEN, double, pop); A(d_FEAS, int32_t, pop);
+    A(d_F, double, d->popcap); A(d_PEN, double, d->popcap); A(d_GPEN, double, d->popcap); A(d_FEAS, int32_t, d->popcap);
     A(d_irank, int32_t, pop); A(d_scratch, double, 3 * ld);
     A(d_streams, uint64_t, (size_t) (d->units + 1) * pop); A(d_progress, int, d->units + 1); A(d_ticket, int, 1);
     A(d_swapped, uint8_t, pop); A(d_bits, uint64_t, pop * (size_t) d->rowwords);
@@ -265,6 +273,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     if (!results) { free(con); return NLOPT_OUT_OF_MEMORY; }
 
     D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
+    D.comm = opt ? opt->comm : NULL;
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */
     if (dev_alloc(&D, lb, ub, con)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the ISRES device state (out of device memory?)");
@@ -279,7 +288,15 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         int64_t kbest = -1, sweeps = 0;
         double t0 = nla_seconds(), t_rng = 0;
         if (dev_eval) {
-            if (nla_k_isres_eval(D.obj, n, D.ld, D.d_X, D.pop, m, p, D.d_con, D.d_F, D.d_PEN, D.d_GPEN, D.d_FEAS, D.st) ||
+            /* this rank's block of candidates, then the all-gather (in place: block r sits at r * per) */
+            const int64_t first = D.per * nlopt_amd_comm_rank(D.comm);
+            const int64_t mine = first >= D.pop ? 0 : (D.pop - first < D.per ? D.pop - first : D.per);
+            if (nla_k_isres_eval(D.obj, n, D.ld, D.d_X + (size_t) first * (size_t) D.ld, mine, m, p, D.d_con, D.d_F + first, D.d_PEN + first,
+                                 D.d_GPEN + first, D.d_FEAS + first, D.st) ||
+                nla_comm_allgather_dev(D.comm, D.d_F + first, D.d_F, sizeof(double) * (size_t) D.per, D.st) ||
+                nla_comm_allgather_dev(D.comm, D.d_PEN + first, D.d_PEN, sizeof(double) * (size_t) D.per, D.st) ||
+                nla_comm_allgather_dev(D.comm, D.d_GPEN + first, D.d_GPEN, sizeof(double) * (size_t) D.per, D.st) ||
+                nla_comm_allgather_dev(D.comm, D.d_FEAS + first, D.d_FEAS, sizeof(int32_t) * (size_t) D.per, D.st) ||
                 nla_memcpy_d2h(D.h_F, D.d_F, sizeof(double) * (size_t) D.pop, D.st) ||
                 nla_memcpy_d2h(D.h_PEN, D.d_PEN, sizeof(double) * (size_t) D.pop, D.st) ||
                 nla_memcpy_d2h(D.h_GPEN, D.d_GPEN, sizeof(double) * (size_t) D.pop, D.st) ||

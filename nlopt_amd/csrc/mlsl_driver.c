@@ -15,6 +15,11 @@
  *       concurrently — one workgroup each in the batched L-BFGS kernel — and committed in walk
  *       order; a candidate that an earlier commit of the same batch disqualified is dropped
  *       (its start point stays un-minimised, exactly as if it had never been started).
+ *   multi-GPU (nlopt_amd_set_comm)    every rank runs this same driver on the same stream (sampling and
+ *       bookkeeping are replicated, they are cheap); the candidates of a batch are dealt round-robin over
+ *       the ranks — candidate c is minimised by rank c mod world — and the minimisers + their results
+ *       are ALL-GATHERED (SURVEY.md §8e "all-gather of local minima"), after which every rank commits
+ *       the whole batch in walk order.  world x BATCH_MAX searches are in flight per batch.
  *
  * Provided: local optimiser NLOPT_LD_LBFGS with a device objective; pseudo-random sampling (all
  * MLSL variants for n > 1111, where the reference's Sobol generator is NULL too — sobolseq.c — and
@@ -29,7 +34,7 @@
 #define K2PI (6.2831853071795864769252867665590057683943388)
 #define MLSL_SIGMA 2.
 #define MLSL_GAMMA 0.3
-#define BATCH_MAX 64
+#define BATCH_MAX 128                  /* local searches in flight per rank (one workgroup each) */
 #define SOBOL_MAXDIM 1111
 
 static double gam(int n) { double z = n / 2; return sqrt(pow(K2PI * z, 1.0 / n) * z) * exp(-0.5); }   /* mlsl.c:227-237 */
@@ -47,6 +52,8 @@ typedef struct {
     size_t nlms, lcap;
     double *LF; size_t *lord;
     double *d_lb, *d_ub, *d_P, *d_F, *d_cpd, *d_LM, *d_LF, *d_D, *d_tmp;
+    double *d_LX;                   /* gathered minimisers of a batch: world x per rows of ld */
+    nlopt_amd_comm *comm; int world, rank;
     int32_t *d_min;
     uint32_t *d_words;
     size_t dcap;                    /* doubles in d_D */
@@ -67,7 +74,7 @@ static void mfree(mlsl_dev *d)
     free(d->F); free(d->cpd); free(d->cld); free(d->minimized); free(d->ord); free(d->LF); free(d->lord);
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd);
     nla_dev_free(d->d_LM); nla_dev_free(d->d_LF); nla_dev_free(d->d_D); nla_dev_free(d->d_tmp); nla_dev_free(d->d_min);
-    nla_dev_free(d->d_words);
+    nla_dev_free(d->d_words); nla_dev_free(d->d_LX);
     nla_host_free(d->h_D);
     if (d->st) nla_stream_destroy(d->st);
 }
@@ -148,8 +155,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     nlopt_result ret = NLOPT_SUCCESS;
     nlopt_amd_stats *st = opt ? &opt->stats : NULL;
     nla_lbfgs_params prm;
-    nla_lbfgs_result res[BATCH_MAX];
-    size_t cand[BATCH_MAX];
+    nla_lbfgs_result *res = NULL, *res_mine = NULL;
+    size_t *cand = NULL;
+    int bmax;
     double R_prefactor, *Fnew = NULL, *rowbuf = NULL, best_f = HUGE_VAL;
     const double dlm = 1.0, dbound = 1e-6;
     const double *lbh = lb, *ubh = ub;
@@ -173,6 +181,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     }
     if (local_opt->xtol_abs) { nla_stop_msg(stop, "nlopt_amd: LD_LBFGS on the device does not take xtol_abs"); return NLOPT_INVALID_ARGS; }
     D.n = n; D.ld = (n + 1) & ~1;
+    D.comm = opt ? opt->comm : NULL;
+    D.world = nlopt_amd_comm_world(D.comm); D.rank = nlopt_amd_comm_rank(D.comm);
+    bmax = BATCH_MAX * D.world;
     R_prefactor = sqrt(2. / K2PI) * pow(gam(n) * MLSL_SIGMA, 1.0 / n);            /* mlsl.c:313-317 */
     for (i = 0; i < n; ++i) R_prefactor *= pow(ub[i] - lb[i], 1.0 / n);
 
@@ -188,16 +199,20 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (size_t) D.N);
-    D.d_tmp = (double *) nla_dev_malloc(sizeof(double) * (size_t) (D.N > BATCH_MAX ? D.N : BATCH_MAX));
+    D.d_tmp = (double *) nla_dev_malloc(sizeof(double) * (size_t) (D.N > bmax ? D.N : bmax));
+    D.d_LX = (double *) nla_dev_malloc(sizeof(double) * (size_t) bmax * (size_t) D.ld);
     Fnew = (double *) malloc(sizeof(double) * (size_t) D.N);
-    if (!D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !Fnew || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
+    res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
+    cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
+    if (!D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
-        mfree(&D); free(Fnew);
+        mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
         return NLOPT_OUT_OF_MEMORY;
     }
     D.lb = nla_lbfgs_ctx_create(D.obj, n, BATCH_MAX, mf, D.d_lb, D.d_ub, D.st);
-    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (L-BFGS batch)"); mfree(&D); free(Fnew); return NLOPT_OUT_OF_MEMORY; }
+    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (L-BFGS batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
 #define STOPS(fv) do { if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP; else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED; \
@@ -264,47 +279,59 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         idx = 0;
         remaining = (int) (ceil(MLSL_GAMMA * D.npts) + 0.5);
         while (idx < D.npts && remaining > 0 && ret == NLOPT_SUCCESS) {
-            int nb = 0, c;
+            int nb = 0, c, per, mine = 0;
             size_t scan = idx;
             int rem = remaining, eff;
             long limited;
             /* the next candidates that are potential minimisers right now (is_potential_minimizer, :196-221) */
-            while (scan < D.npts && rem > 0 && nb < BATCH_MAX) {
+            while (scan < D.npts && rem > 0 && nb < bmax) {
                 const size_t r = D.ord[scan];
                 ++scan; --rem;
                 if (D.minimized[r] || D.cpd[r] <= R * R || D.cld[r] <= (dlm * R) * (dlm * R)) continue;
                 cand[nb++] = scan - 1;
             }
             if (nb == 0) { idx = scan; remaining = rem; break; }
-            /* bound test needs the coordinates: done on the start rows after they are gathered (below) */
+            /* candidate c is minimised by rank c mod world in its slot c / world; gathered row of c: GI(c) */
+            per = (nb + D.world - 1) / D.world;
+#define GI(c) ((size_t) ((c) % D.world) * (size_t) per + (size_t) ((c) / D.world))
+            for (c = D.rank; c < nb; c += D.world, ++mine)
+                if (nla_memcpy_d2d(nla_lbfgs_ctx_X(D.lb) + (size_t) mine * D.ld, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+            /* the bound test needs the start coordinates on the host (every rank: all candidates) */
+            if (!rowbuf) rowbuf = (double *) malloc(sizeof(double) * (size_t) n * (size_t) bmax);
+            if (!rowbuf) { snprintf(D.err, sizeof D.err, "out of memory"); DEVFAIL(); }
             for (c = 0; c < nb; ++c)
-                if (nla_memcpy_d2d(nla_lbfgs_ctx_X(D.lb) + (size_t) c * D.ld, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
-            if (!rowbuf) rowbuf = (double *) malloc(sizeof(double) * (size_t) n * BATCH_MAX);
-            for (c = 0; c < nb; ++c)
-                if (nla_memcpy_d2h(rowbuf + (size_t) c * n, nla_lbfgs_ctx_X(D.lb) + (size_t) c * D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+                if (nla_memcpy_d2h(rowbuf + (size_t) c * n, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
             if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
-            /* local searches of the whole batch, then the distances of their minimisers to every point */
+            /* local searches of this rank's share, all-gather of the minimisers, then their distances to every point */
             limited = (long) stop->maxeval - (long) *stop->nevals_p;             /* nlopt_optimize_limited, optimize.c:1097-1100 */
             eff = loc_maxeval;
             if (loc_maxeval <= 0 || (limited > 0 && limited < loc_maxeval)) eff = (int) limited;
             prm.maxeval = eff;
-            if (nla_lbfgs_ctx_run(D.lb, nb, &prm, res)) { snprintf(D.err, sizeof D.err, "L-BFGS batch failed"); DEVFAIL(); }
-            if (need_D(&D, (size_t) nb * D.npts)) DEVFAIL();
-            if ((size_t) nb * D.npts > D.hcap) {
-                nla_host_free(D.h_D);
-                D.hcap = 2 * (size_t) BATCH_MAX * D.npts;
-                D.h_D = (double *) nla_host_malloc(sizeof(double) * D.hcap);
-                if (!D.h_D) { D.hcap = 0; snprintf(D.err, sizeof D.err, "out of pinned memory"); DEVFAIL(); }
+            if (mine > 0 && nla_lbfgs_ctx_run(D.lb, mine, &prm, res_mine)) { snprintf(D.err, sizeof D.err, "L-BFGS batch failed"); DEVFAIL(); }
+            if (nla_comm_allgather_dev(D.comm, nla_lbfgs_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st) ||
+                nla_comm_allgather_host(D.comm, res_mine, res, sizeof *res * (size_t) per, D.st)) {
+                snprintf(D.err, sizeof D.err, "all-gather of the local minima failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL();
             }
-            if (nla_k_mlsl_dist2(n, D.ld, nla_lbfgs_ctx_X(D.lb), nb, D.d_P, (int) D.npts, D.d_D, D.st) ||
-                nla_memcpy_d2h(D.h_D, D.d_D, sizeof(double) * (size_t) nb * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+            {
+                const size_t na = (size_t) per * (size_t) D.world;
+                if (need_D(&D, na * D.npts)) DEVFAIL();
+                if (na * D.npts > D.hcap) {
+                    nla_host_free(D.h_D);
+                    D.hcap = 2 * (size_t) bmax * D.npts;
+                    D.h_D = (double *) nla_host_malloc(sizeof(double) * D.hcap);
+                    if (!D.h_D) { D.hcap = 0; snprintf(D.err, sizeof D.err, "out of pinned memory"); DEVFAIL(); }
+                }
+                if (nla_k_mlsl_dist2(n, D.ld, D.d_LX, (int) na, D.d_P, (int) D.npts, D.d_D, D.st) ||
+                    nla_memcpy_d2h(D.h_D, D.d_D, sizeof(double) * na * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+            }
             /* commit in walk order */
             for (c = 0; c < nb && ret == NLOPT_SUCCESS; ++c) {
                 const size_t r = D.ord[cand[c]];
                 const double *xr = rowbuf + (size_t) c * n;
                 int pot = !(D.cld[r] <= (dlm * R) * (dlm * R));               /* may have changed since the batch was formed */
                 double lf;
-                size_t lrow, k;
+                const size_t g = GI(c);
+                size_t k;
                 /* nodes between the previous candidate and this one were visited and skipped */
                 remaining -= (int) (cand[c] + 1 - idx);
                 idx = cand[c] + 1;
@@ -318,32 +345,31 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 limited = (long) stop->maxeval - (long) *stop->nevals_p;
                 eff = loc_maxeval;
                 if (loc_maxeval <= 0 || (limited > 0 && limited < loc_maxeval)) eff = (int) limited;
-                if (eff > 0 && eff != prm.maxeval && res[c].nevals >= eff) {
-                    /* the limit binds differently than assumed: redo this one search alone with the exact limit */
+                if (eff > 0 && eff != prm.maxeval && res[g].nevals >= eff) {
+                    /* the limit binds differently than assumed: redo this one search alone with the exact limit
+                     * (every rank does, identically; the gathered rows of the other candidates are untouched) */
                     nla_lbfgs_params p1 = prm;
                     nla_lbfgs_result r1;
                     p1.maxeval = eff;
                     if (nla_memcpy_d2d(nla_lbfgs_ctx_X(D.lb), D.d_P + r * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
                         nla_lbfgs_ctx_run(D.lb, 1, &p1, &r1) ||
-                        nla_k_mlsl_dist2(n, D.ld, nla_lbfgs_ctx_X(D.lb), 1, D.d_P, (int) D.npts, D.d_D, D.st) ||
-                        nla_memcpy_d2h(D.h_D + (size_t) c * D.npts, D.d_D, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "L-BFGS rerun failed"); DEVFAIL(); }
-                    res[c] = r1;
-                    /* the rest of the batch was computed from slot rows that this rerun overwrote in slot 0 only */
-                    if (c != 0 && nb > 1) { /* slot 0's minimiser was already committed or dropped */ }
-                    lrow = 0;
-                } else lrow = (size_t) c;
-                *stop->nevals_p += res[c].nevals;                               /* fcount, mlsl.c:246-251 */
-                if (st) { st->evals_mutation += (uint64_t) res[c].nevals; ++st->accepted; }
+                        nla_memcpy_d2d(D.d_LX + g * (size_t) D.ld, nla_lbfgs_ctx_X(D.lb), sizeof(double) * (size_t) n, D.st) ||
+                        nla_k_mlsl_dist2(n, D.ld, D.d_LX + g * (size_t) D.ld, 1, D.d_P, (int) D.npts, D.d_D, D.st) ||
+                        nla_memcpy_d2h(D.h_D + g * D.npts, D.d_D, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "L-BFGS rerun failed"); DEVFAIL(); }
+                    res[g] = r1;
+                }
+                *stop->nevals_p += res[g].nevals;                               /* fcount, mlsl.c:246-251 */
+                if (st) { st->evals_mutation += (uint64_t) res[g].nevals; ++st->accepted; }
                 D.minimized[r] = 1;
                 if (opt && opt->trace) {
-                    if (opt->trace_len < opt->trace_cap) { nlopt_amd_trace_rec *tr = opt->trace + opt->trace_len; tr->f = res[c].f; tr->row = (int64_t) r; tr->kind = 4; tr->accepted = res[c].nevals; }
+                    if (opt->trace_len < opt->trace_cap) { nlopt_amd_trace_rec *tr = opt->trace + opt->trace_len; tr->f = res[g].f; tr->row = (int64_t) r; tr->kind = 4; tr->accepted = res[g].nevals; }
                     ++opt->trace_len;
                 }
-                if (res[c].ret < 0) { ret = (nlopt_result) res[c].ret; goto done_noget; }
-                lf = res[c].f;
+                if (res[g].ret < 0) { ret = (nlopt_result) res[g].ret; goto done_noget; }
+                lf = res[g].f;
                 if (grow_lms(&D, D.nlms + 1)) DEVFAIL();
-                if (nla_memcpy_d2d(D.d_LM + D.nlms * (size_t) D.ld, nla_lbfgs_ctx_X(D.lb) + lrow * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
-                    nla_memcpy_h2d(D.d_LF + D.nlms, &res[c].f, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
+                if (nla_memcpy_d2d(D.d_LM + D.nlms * (size_t) D.ld, D.d_LX + g * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
+                    nla_memcpy_h2d(D.d_LF + D.nlms, &res[g].f, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
                 D.LF[D.nlms] = lf;
                 ord_insert(D.lord, D.nlms, D.LF, D.nlms);
                 ++D.nlms;
@@ -352,7 +378,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
                 else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
                 else {
-                    const double *dr = D.h_D + (size_t) c * D.npts;              /* pts_update_newlm, mlsl.c:180-194 */
+                    const double *dr = D.h_D + g * D.npts;              /* pts_update_newlm, mlsl.c:180-194 */
                     for (k = 0; k < D.npts; ++k)
                         if (D.F[k] > lf && !D.minimized[k] && dr[k] < D.cld[k]) D.cld[k] = dr[k];
                 }
@@ -377,6 +403,6 @@ done_noget:
 done:
     if (st) st->mt_words = D.words_used;
     mfree(&D);
-    free(Fnew); free(rowbuf);
+    free(Fnew); free(rowbuf); free(res); free(res_mine); free(cand);
     return ret;
 }

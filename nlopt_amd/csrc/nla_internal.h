@@ -81,6 +81,7 @@ struct nlopt_opt_s {
     /* --- libnlopt_amd additions (not in the reference) --- */
     nlopt_amd_trace_rec *trace; size_t trace_cap, trace_len;
     nlopt_amd_stats stats;
+    nlopt_amd_comm *comm;           /* multi-GPU run: borrowed communicator (comm.c), NULL = single process */
 };
 
 const char *nla_set_errmsg(nlopt_opt opt, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -92,6 +93,11 @@ extern nlopt_algorithm nla_local_search_alg_deriv, nla_local_search_alg_nonderiv
 extern int nla_local_search_maxeval;
 
 nlopt_result nla_optimize_limited(nlopt_opt opt, double *x, double *minf, int maxeval, double maxtime);
+
+/* ---- collectives (comm.c) ---------------------------------------------------------------------- */
+int nla_comm_allgather_dev(nlopt_amd_comm *c, const void *d_send, void *d_recv, size_t bytes, void *stream);
+int nla_comm_allgather_host(nlopt_amd_comm *c, const void *h_send, void *h_recv, size_t bytes, void *stream);
+void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, int64_t *first, int64_t *mine);
 
 /* ---- MT19937 host side (mt_host.c) ------------------------------------------------------------ */
 void nla_mt_seed_array(uint32_t mt[NLA_MT_N], unsigned long seed);

@@ -39,13 +39,37 @@ static void need_blocks(emu *e, uint64_t upto)     /* the oracle generator is se
     e->tw_blocks = upto;
 }
 
+/* world_size-2 tests of the product's collective layer (comm.c) without a GPU: the initial rows are
+ * produced in rank blocks and all-gathered over the communicator's host transport, the way
+ * crs_engine.c's op_init_population does it on the device. */
+static nlopt_amd_comm *emu_comm = NULL;
+void orc_emu_set_comm(void *comm) { emu_comm = (nlopt_amd_comm *) comm; }
+
 static int emu_init(void *ve, const double *x0, double *F)
 {
     emu *e = (emu *) ve;
     size_t nw = 2 * (size_t) e->n * (size_t) (e->N - 1);
     uint32_t *w = (uint32_t *) malloc(sizeof(uint32_t) * (nw ? nw : 1));
     memcpy(e->X, x0, sizeof(double) * (size_t) e->n);
-    orc_k_words(nw, w);
+    orc_k_words(nw, w);                 /* the oracle generator is sequential: every rank draws the whole stream */
+    if (nlopt_amd_comm_world(emu_comm) > 1) {
+        int64_t per, first, mine;
+        const size_t rowbytes = sizeof(double) * (size_t) e->ld;
+        double *mineX, *allX, *mineF, *allF;
+        nla_comm_partition(emu_comm, e->N - 1, &per, &first, &mine);
+        mineX = (double *) calloc((size_t) per * e->ld, sizeof(double));
+        allX = (double *) calloc((size_t) per * e->ld * (size_t) nlopt_amd_comm_world(emu_comm), sizeof(double));
+        mineF = (double *) calloc((size_t) per, sizeof(double));
+        allF = (double *) calloc((size_t) per * (size_t) nlopt_amd_comm_world(emu_comm), sizeof(double));
+        orc_k_init_rows(e->n, e->ld, e->lb, e->ub, w + 2 * (size_t) e->n * (size_t) first, mine, mineX);
+        if (e->obj >= 0) orc_k_eval(e->obj, e->n, e->ld, mineX, mine, mineF);
+        if (nla_comm_allgather_host(emu_comm, mineX, allX, rowbytes * (size_t) per, NULL) ||
+            nla_comm_allgather_host(emu_comm, mineF, allF, sizeof(double) * (size_t) per, NULL)) return -1;
+        memcpy(e->X + e->ld, allX, rowbytes * (size_t) (e->N - 1));
+        if (e->obj >= 0) { orc_k_eval(e->obj, e->n, e->ld, e->X, 1, F); memcpy(F + 1, allF, sizeof(double) * (size_t) (e->N - 1)); }
+        free(mineX); free(allX); free(mineF); free(allF); free(w);
+        return 0;
+    }
     orc_k_init_rows(e->n, e->ld, e->lb, e->ub, w, e->N - 1, e->X + e->ld);
     free(w);
     if (e->obj >= 0) orc_k_eval(e->obj, e->n, e->ld, e->X, e->N, F);

@@ -1,0 +1,103 @@
+"""Multi-process runs on the GPU: N ranks, the library's communicator over gloo (host
+transport; the GPU box has one GPU, so the ranks share HIP device 0 — partitioning, all-gathers and the
+replicated commit logic are exactly those of the one-rank-per-GPU run), compared with the single-process
+run of the same problem: every rank must produce the identical evaluation sequence and result.  Plus the RCCL
+transport itself on a 1-rank communicator."""
+import numpy as np
+import pytest
+
+import nlopt_amd
+import _oracle as O
+from _mp_launch import run_world
+
+pytestmark = pytest.mark.gpu
+
+
+def single(case, a):
+    obj, n, seed = a["obj"], a["n"], a["seed"]
+    xs, lo, hi = O.golden_x0(obj, n)
+    alg = {"gpu_crs": nlopt_amd.GN_CRS2_LM, "gpu_isres": nlopt_amd.GN_ISRES, "gpu_mlsl": nlopt_amd.G_MLSL}[case]
+    o = nlopt_amd.Opt(alg, n)
+    o.set_lower_bounds(lo)
+    o.set_upper_bounds(hi)
+    o.set_min_objective(nlopt_amd.objective(obj))
+    if a.get("pop"):
+        o.set_population(a["pop"])
+    o.set_maxeval(a["maxeval"])
+    if case == "gpu_isres" and a.get("ncon"):
+        o.add_blocksum_constraints(a["ncon"], 1e-8)
+    if case == "gpu_mlsl":
+        loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, n)
+        loc.set_ftol_rel(1e-8)
+        nlopt_amd.lib().nlopt_set_local_optimizer(o._h, loc._h)
+    o.enable_trace(a["maxeval"] + 4096)
+    nlopt_amd.srand(seed)
+    x, minf, ret = o.optimize_raw(xs)
+    t = o.trace()
+    return dict(ret=ret, minf=minf, x=x, nevals=o.get_numevals(), f=t["f"].copy(), row=t["row"].copy(), kind=t["kind"].copy(),
+                accepted=t["accepted"].copy(), after=nlopt_amd.lib().nla_genrand_int32())
+
+
+def same(d, s):
+    assert d["ret"][0] == s["ret"] and d["nevals"][0] == s["nevals"]
+    assert np.array_equal(d["f"], s["f"]) and np.array_equal(d["row"], s["row"]) and np.array_equal(d["accepted"], s["accepted"])
+    assert np.array_equal(d["kind"], s["kind"])
+    assert d["minf"][0] == s["minf"] and np.array_equal(d["x"], s["x"])
+    assert int(d["after"][0]) == s["after"]            # the thread's generator is left at the same stream position
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_crs_sharded_init(world):
+    a = dict(obj="rastrigin", n=96, pop=1501, seed=11, maxeval=4000)
+    s = single("gpu_crs", a)
+    for d in run_world("gpu_crs", a, world=world):
+        same(d, s)
+        assert d["collectives"][0] == 2                # rows, f
+
+
+@pytest.mark.parametrize("world,ncon", [(2, 4), (3, 0)])
+def test_isres_sharded_eval(world, ncon):
+    a = dict(obj="rastrigin", n=24, pop=301, seed=5, maxeval=4 * 301, ncon=ncon)
+    s = single("gpu_isres", a)
+    for d in run_world("gpu_isres", a, world=world):
+        same(d, s)
+        assert d["collectives"][0] == 4 * 4            # (f, penalty, inequality penalty, feasible) per generation
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mlsl_sharded_local_searches(world):
+    a = dict(obj="griewank", n=6, pop=40, seed=3, maxeval=6000)
+    s = single("gpu_mlsl", a)
+    res = run_world("gpu_mlsl", a, world=world)
+    for d in res:
+        same(d, s)
+        assert d["collectives"][0] >= 2
+    assert (s["kind"] == 4).sum() >= 3                  # several local searches were committed
+
+
+def test_rccl_transport_one_rank():
+    """ncclCommInitRank / ncclAllGather through the library's dlopen()ed RCCL on a 1-rank communicator"""
+    import ctypes as C
+    L = nlopt_amd.lib()
+    c = nlopt_amd.Comm.rccl(0, 1, nlopt_amd.rccl_unique_id())
+    a = np.arange(1000, dtype=np.float64)
+    src, dst = nlopt_amd.DevBuf.from_array(a), nlopt_amd.DevBuf(a.nbytes)
+    assert L.nla_comm_allgather_dev(c._h, src.ptr, dst.ptr, a.nbytes, None) == 0
+    assert L.nla_stream_sync(None) == 0
+    assert np.array_equal(dst.to_array(np.float64, 1000), a)
+    assert np.array_equal(c.allgather_host(a[:7]), a[None, :7])
+    assert c.counters()["collectives"] == 2
+    # a whole ISRES run over the RCCL communicator == the run without one
+    args = dict(obj="rastrigin", n=16, pop=120, seed=9, maxeval=480, ncon=2)
+    s = single("gpu_isres", args)
+    xs, lo, hi = O.golden_x0("rastrigin", 16)
+    o = nlopt_amd.Opt(nlopt_amd.GN_ISRES, 16)
+    o.set_lower_bounds(lo); o.set_upper_bounds(hi)
+    o.set_min_objective(nlopt_amd.objective("rastrigin"))
+    o.set_population(120); o.set_maxeval(480); o.add_blocksum_constraints(2, 1e-8)
+    o.set_comm(c)
+    nlopt_amd.srand(9)
+    x, minf, ret = o.optimize_raw(xs)
+    assert ret == s["ret"] and minf == s["minf"] and np.array_equal(x, s["x"])
+    assert c.counters()["collectives"] == 2 + 4 * 4
+    c.destroy()
