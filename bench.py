@@ -1,30 +1,39 @@
 #!/usr/bin/env python
-"""bench.py — the headline benchmark of BASELINE.json on MI355X.
+"""bench.py — the benchmarks of BASELINE.json on MI355X.
 
-Metric: candidate-evals/sec (+ gens-to-ftol), NLOPT_GN_CRS2_LM, Griewank n=4096, pop=1e5
-(BASELINE.json "metric"; the configuration fits one GPU: 3.3 GB of 288 GB).
+Default workload (`--workload crs`) is the headline metric: candidate-evals/sec (+ gens-to-ftol),
+NLOPT_GN_CRS2_LM, Griewank n=4096, pop=1e5 (the configuration fits one GPU: 3.3 GB of 288 GB).
+A *step* is one pass of the hot path over one batch of work: `--evals-per-step` candidate evaluations of
+the CRS2_LM trial loop (reflection gather-sum + objective + in-order commit, src/algs/crs/crs.c:125-156) on a
+population that is already resident in HBM.  The population initialisation (crs_init) happens before the
+timed region and is reported separately (`init`).  W warm-up steps, then EXACTLY K timed steps bracketed by
+a barrier and a device synchronisation; value = evaluations made in the K steps / wall time, max over ranks.
 
-A *step* is one pass of the hot path over one batch of work: `--evals-per-step` candidate
-evaluations of the CRS2_LM trial loop (reflection gather-sum + objective + in-order commit,
-src/algs/crs/crs.c:125-156) on a population that is already resident in HBM.  The population
-initialisation (crs_init) happens before the timed region and is reported separately
-(`init_evals_per_s`).  W warm-up steps, then EXACTLY K timed steps bracketed by a barrier and a
-device synchronisation; value = evaluations made in the K steps / wall time, max over ranks.
+Other workloads (BASELINE.json configs 3 and 4; parity for them is in tests/):
+  --workload isres   NLOPT_GN_ISRES, Rastrigin n=256 + 4 block-sum inequality constraints, pop=5e4;
+                     a step = one generation (pop evaluations + selection + evolution, isres.c:130-281)
+  --workload mlsl    NLOPT_G_MLSL_LDS + LD_LBFGS(ftol_rel 1e-8), Ackley n=4096, 1000 samples per iteration;
+                     a step = one MLSL iteration (sampling + the local searches it starts, mlsl.c:345-429)
+For these the K timed steps are bracketed inside one nlopt_optimize() call by the library's generation hook
+(nlopt_amd_set_progress): barrier + sync at the start of step W, again at the start of step W+K, where the
+run is force-stopped.
 
-N > 1 (launched by torchrun, one rank per GPU): the CRS2_LM trial loop is one serial accept/reject
-chain — in this round each rank runs an independent replica of the workload on its
-own GPU with its own seed ("replicas only", scaling = weak, no data-path collective); `value` is
-the sum over ranks.  See DESIGN.md §multi-GPU for what comes next.
+N > 1 (launched by torchrun, one rank per GPU; SURVEY.md §8e / DESIGN.md §6):
+  crs    the trial loop is one serial accept/reject chain — each rank runs an independent replica (seed+rank),
+         no data-path collective, scaling = weak, value = sum over ranks
+  isres  one job over all ranks (library communicator = RCCL): evaluation sharded, (f, penalty) all-gathered
+         each generation; scaling = strong
+  mlsl   one job over all ranks: the local searches of a batch are dealt over the ranks and the minimisers
+         all-gathered; scaling = strong
 
 Output: ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     — dominant kernel (crs_advance_kernel, the resumable gather-sum): algorithmic bytes
-                 = 8n per population row summed (n+1 rows = 8 n (n+1) B per trial), counted per
-                 launch from the slots' progress / HIP-event time of those launches on their own
-                 stream, vs 8 TB/s HBM
-  cpu_baseline — the real reference NLopt (oracle/_ref, kind "reference") or the C port (kind
-                 "port") timed single-threaded on this host on a bounded sample of the same workload
-  gens_to_ftol — numevals/pop at NLOPT_FTOL_REACHED on the small configuration where the CPU
-                 reference can reach it, with the reference's golden value beside it.
+  roofline     — dominant kernel of the workload: algorithmic bytes per launch / HIP-event time of the launches
+                 on the stream they run on, vs 8 TB/s HBM; `traffic` = HBM bytes per launch from the committed
+                 rocprofv3 PMC summaries of the same command (profiles/), corrected as MI355X_MICROARCH.md says
+  cpu_baseline — the real reference NLopt (oracle/_ref, kind "reference") or the C port (kind "port") timed
+                 single-threaded on this host on a bounded sample of the same workload
+  gens_to_ftol — (crs) numevals/pop at NLOPT_FTOL_REACHED on the small configuration where the CPU reference can
+                 reach it, with the reference's golden value beside it.
 """
 import argparse
 import ctypes as C
@@ -47,20 +56,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--pop", type=int, default=100000)
-    ap.add_argument("--obj", default="griewank")
+    ap.add_argument("--workload", choices=("crs", "isres", "mlsl"), default="crs")
+    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--pop", type=int, default=0)
+    ap.add_argument("--obj", default="")
     ap.add_argument("--evals-per-step", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--max-spec", type=int, default=0)
     ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pop", type=int, default=20000)
+    ap.add_argument("--cpu-sample-pop", type=int, default=0)
     ap.add_argument("--cpu-sample-trials", type=int, default=400)
-    return ap.parse_args()
+    a = ap.parse_args()
+    dflt = {"crs": (4096, 100000, "griewank"), "isres": (256, 50000, "rastrigin"), "mlsl": (4096, 1000, "ackley")}[a.workload]
+    a.n = a.n or dflt[0]
+    a.pop = a.pop or dflt[1]
+    a.obj = a.obj or dflt[2]
+    return a
 
 
-def cpu_baseline(obj, n, pop_sample, trials, seed):
+# ------------------------------------------------------------------------------------------------
+# CPU baselines: the real reference (oracle/_ref) on a bounded sample of the same workload
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline_crs(obj, n, pop_sample, trials, seed):
     """single-thread CPU reference on a bounded sample: init (untimed) + `trials` trial-phase
     evaluations of the same workload at the same n (the trial-phase rate does not depend on pop:
     SURVEY.md §6, 49.9 vs 50.3 evals/s at pop 2e4 vs 1e5)."""
@@ -106,6 +124,40 @@ def cpu_baseline(obj, n, pop_sample, trials, seed):
                 init_evals_per_s=tm.mark / max(tm.t_mark - tm.t_first, 1e-9))
 
 
+def cpu_baseline_isres(obj, n, pop_sample, seed, ncon=4):
+    """ISRES on the CPU is dominated by the O(pop^2) stochastic ranking (isres.c:207-228), so evals/s falls ~1/pop:
+    the sample runs 2 generations at a smaller population and reports that rate plus its pop-scaled estimate."""
+    import _oracle as O
+    gens = 2
+    t0 = time.perf_counter()
+    if O.have_ref():
+        r = O.run_ref_isres(obj, n, pop_sample, seed, nineq=ncon, maxeval=gens * pop_sample, record=False)
+        kind = "reference"
+    else:
+        r = O.run_port_isres(obj, n, pop_sample, seed, nineq=ncon, maxeval=gens * pop_sample, record=False)
+        kind = "port"
+    dt = time.perf_counter() - t0
+    return dict(value=r["nevals"] / dt, unit="evals/s", cores=1, kind=kind,
+                sample="NLOPT_GN_ISRES %s n=%d + %d inequality constraints at pop=%d (NOT the benchmark's pop): %d evals = %d generations "
+                       "in %.1f s, 1 thread; ranking work per generation grows as pop^2" % (obj, n, ncon, pop_sample, r["nevals"], gens, dt),
+                sample_pop=pop_sample)
+
+
+def cpu_baseline_mlsl(obj, n, nsamples, seed, maxeval):
+    import _oracle as O
+    t0 = time.perf_counter()
+    if O.have_ref():
+        r = O.run_ref_mlsl(obj, n, nsamples, seed, alg=39, maxeval=maxeval, record=False)
+        kind = "reference"
+    else:
+        r = O.run_port_mlsl(obj, n, nsamples, seed, maxeval=maxeval, record=False)
+        kind = "port"
+    dt = time.perf_counter() - t0
+    return dict(value=r["nevals"] / dt, unit="evals/s", cores=1, kind=kind,
+                sample="NLOPT_G_MLSL_LDS + LD_LBFGS(ftol_rel 1e-8) %s n=%d, %d samples/iteration, the first %d evaluations of the same run "
+                       "in %.1f s, 1 thread" % (obj, n, nsamples, r["nevals"], dt))
+
+
 def gens_to_ftol():
     """gens-to-ftol on the configuration where the reference can reach it:
     CRS2_LM Rastrigin n=10 pop=100 ftol_rel=1e-4, seed 42 — golden: 5385 evals = 53.85 'generations'."""
@@ -126,6 +178,35 @@ def gens_to_ftol():
                 reference_value=gold["nevals"] / 100.0, reference_minf=float.fromhex(gold["minf"]))
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of `kernel_prefix` from the newest committed rocprofv3 PMC summaries under profiles/
+    (separate FETCH_SIZE / WRITE_SIZE passes of this command, values in KiB per dispatch).  Correction per
+    MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half of a wide coalesced read -> doubled."""
+    import glob
+    out = {}
+    for counter, fac in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s*.csv" % counter.split("_")[0].lower())))
+        for path in reversed(files):
+            best = None
+            for line in open(path):
+                parts = line.rstrip("\n").split(",")
+                if len(parts) >= 5 and parts[-4] == counter and kernel_prefix in line:
+                    try:
+                        cand = (float(parts[-2]), float(parts[-1]))
+                    except ValueError:
+                        continue
+                    if best is None or cand[0] > best[0]:
+                        best = cand
+            if best:
+                out[counter] = dict(bytes_per_launch=best[1] * 1024.0 * fac, source=os.path.relpath(path, ROOT))
+                break
+    if "FETCH_SIZE" not in out:
+        return None, None
+    total = out["FETCH_SIZE"]["bytes_per_launch"] + out.get("WRITE_SIZE", {}).get("bytes_per_launch", 0.0)
+    return total, {k: v["source"] for k, v in out.items()}
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -142,11 +223,38 @@ def main():
     L = nlopt_amd.lib()
     if nlopt_amd.device_count() <= 0:
         raise SystemExit("bench.py: no HIP device visible (libnlopt_amd has no CPU fallback)")
-    L.nla_dev_set.argtypes = [C.c_int]
     L.nla_dev_set(local_rank)
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
+    def sync_all():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        L.nla_stream_sync(None)
+        if dist is not None:
+            dist.barrier()
+
+    def reduce(dt, evals, sum_evals):
+        if dist is None:
+            return dt, float(evals)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        te = torch.tensor([float(evals)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.SUM if sum_evals else dist.ReduceOp.MAX)
+        return float(tt.item()), float(te.item())
+
+    if a.workload == "crs":
+        out = bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce)
+    else:
+        out = bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     import _oracle as O
     n, pop = a.n, a.pop
     xs, lo, hi = O.golden_x0(a.obj, n)
@@ -167,14 +275,6 @@ def main():
     t_init = time.perf_counter() - t0
     if not s or ret.value != 1:
         raise SystemExit("bench.py: crs_open failed: ret=%d %s" % (ret.value, o.get_errmsg()))
-
-    def sync_all():
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        L.nla_stream_sync(None)
-        if dist is not None:
-            dist.barrier()
-
     for _ in range(a.warmup):
         if L.nlopt_amd_crs_step(s, a.evals_per_step) != 1:
             raise SystemExit("bench.py: the run stopped during warm-up")
@@ -188,63 +288,140 @@ def main():
     dt = time.perf_counter() - t0
     st1, ev1 = o.stats(), o.get_numevals()
     fret = L.nlopt_amd_crs_close(s)
-    evals = ev1 - ev0
-
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_max = float(tt.item())
-        te = torch.tensor([float(evals)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.SUM)
-        evals_all = float(te.item())
-    else:
-        dt_max, evals_all = dt, float(evals)
-
-    if rank == 0:
-        g_ms = st1["t_gather_ms"] - st0["t_gather_ms"]
-        g_bytes = st1["gather_bytes"] - st0["gather_bytes"]
-        g_launch = st1["gather_launches"] - st0["gather_launches"]
-        achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
-        slots = st1["slots_launched"] - st0["slots_launched"]
-        used = st1["slots_used"] - st0["slots_used"]
-        out = {
-            "metric": "candidate-evals/sec, CRS2_LM n=%d pop=%d (trial phase)" % (n, pop),
-            "value": evals_all / dt_max, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt_max / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "NLOPT_GN_CRS2_LM %s n=%d pop=%d seed=%d, %d candidate evals per step, population resident in HBM%s"
-                                   % (a.obj, n, pop, a.seed, a.evals_per_step,
-                                      "" if world == 1 else "; %d independent replicas (seed+rank)" % world),
-                       "evals_timed": int(evals_all), "evals_per_step_requested": a.evals_per_step},
-            "roofline": {"bound": "hbm", "kernel": "crs_advance_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "launches": int(g_launch), "avg_launch_ms": (g_ms / g_launch) if g_launch else None,
-                         "algorithmic_bytes_per_trial": 8 * n * (n + 1),
-                         "avg_algorithmic_MB_per_launch": (g_bytes / 1e6 / g_launch) if g_launch else None,
-                         "avg_trials_consumed_per_launch": (used / g_launch) if g_launch else None},
-            "window": {"slots_started": int(slots), "slots_used": int(used),
-                            "useful_frac": (used / slots) if slots else None,
-                            "newbest": int(st1["slots_newbest"] - st0["slots_newbest"]),
-                            "role": int(st1["slots_role"] - st0["slots_role"]),
-                            "accepted": int(st1["accepted"] - st0["accepted"])},
-            "init": {"evals": pop, "seconds": t_init, "init_evals_per_s": pop / t_init},
-            "final_result": int(fret), "minf": minf.value,
-        }
+    dt_max, evals_all = reduce(dt, ev1 - ev0, True)
+    if rank != 0:
+        return None
+    g_ms = st1["t_gather_ms"] - st0["t_gather_ms"]
+    g_bytes = st1["gather_bytes"] - st0["gather_bytes"]
+    g_launch = st1["gather_launches"] - st0["gather_launches"]
+    achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
+    slots = st1["slots_launched"] - st0["slots_launched"]
+    used = st1["slots_used"] - st0["slots_used"]
+    traffic, traffic_src = pmc_traffic("crs_advance_kernel") if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
+    out = {
+        "metric": "candidate-evals/sec, CRS2_LM n=%d pop=%d (trial phase)" % (n, pop),
+        "value": evals_all / dt_max, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt_max / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "NLOPT_GN_CRS2_LM %s n=%d pop=%d seed=%d, %d candidate evals per step, population resident in HBM%s"
+                               % (a.obj, n, pop, a.seed, a.evals_per_step,
+                                  "" if world == 1 else "; %d independent replicas (seed+rank)" % world),
+                   "evals_timed": int(evals_all), "evals_per_step_requested": a.evals_per_step},
+        "roofline": {"bound": "hbm", "kernel": "crs_advance_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                     "launches": int(g_launch), "avg_launch_ms": (g_ms / g_launch) if g_launch else None,
+                     "algorithmic_bytes_per_trial": 8 * n * (n + 1),
+                     "avg_algorithmic_bytes_per_launch": (g_bytes / g_launch) if g_launch else None,
+                     "avg_trials_consumed_per_launch": (used / g_launch) if g_launch else None},
+        "window": {"slots_started": int(slots), "slots_used": int(used),
+                   "useful_frac": (used / slots) if slots else None,
+                   "newbest": int(st1["slots_newbest"] - st0["slots_newbest"]),
+                   "role": int(st1["slots_role"] - st0["slots_role"]),
+                   "accepted": int(st1["accepted"] - st0["accepted"])},
+        "init": {"evals": pop, "seconds": t_init, "init_evals_per_s": pop / t_init},
+        "final_result": int(fret), "minf": minf.value,
+    }
+    try:
+        out["gens_to_ftol"] = gens_to_ftol()
+    except Exception as e:        # the headline line must still be printed
+        out["gens_to_ftol"] = {"error": repr(e)}
+    if not a.no_cpu_baseline:
         try:
-            out["gens_to_ftol"] = gens_to_ftol()
-        except Exception as e:        # the headline line must still be printed
-            out["gens_to_ftol"] = {"error": repr(e)}
-        if not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(a.obj, n, a.cpu_sample_pop, a.cpu_sample_trials, a.seed)
-                if out["cpu_baseline"]["value"]:
-                    out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
-            except Exception as e:
-                out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            out["cpu_baseline"] = cpu_baseline_crs(a.obj, n, a.cpu_sample_pop or 20000, a.cpu_sample_trials, a.seed)
+            if out["cpu_baseline"]["value"]:
+                out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
+    """isres / mlsl: K generations of ONE nlopt_optimize() call, bracketed by the generation hook"""
+    import _oracle as O
+    n, pop, W, K = a.n, a.pop, a.warmup, a.steps
+    xs, lo, hi = O.golden_x0(a.obj, n)
+    comm = None
+    if a.workload == "isres":
+        o = nlopt_amd.Opt(nlopt_amd.GN_ISRES, n)
+        ncon = 4
+    else:
+        o = nlopt_amd.Opt(nlopt_amd.G_MLSL_LDS, n)
+        loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, n)
+        loc.set_ftol_rel(1e-8)
+        L.nlopt_set_local_optimizer(o._h, loc._h)
+    o.set_lower_bounds(lo)
+    o.set_upper_bounds(hi)
+    o.set_min_objective(nlopt_amd.objective(a.obj))
+    o.set_population(pop)
+    if a.workload == "isres":
+        o.add_blocksum_constraints(ncon, 1e-8)
+    if world > 1:
+        comm = nlopt_amd.Comm.from_torch_distributed()       # nccl group -> the library's own RCCL communicator
+        o.set_comm(comm)
+    marks = {}
+
+    def hook(gens_done, numevals):
+        if gens_done == W or gens_done == W + K:
+            sync_all()
+            marks[gens_done] = (time.perf_counter(), numevals, o.stats())
+            if gens_done == W + K:
+                o.force_stop()
+    o.set_progress(hook)
+    nlopt_amd.srand(a.seed)                                   # every rank: the same stream (one job)
+    t_start = time.perf_counter()
+    x, minf, ret = o.optimize_raw(xs)
+    t_total = time.perf_counter() - t_start
+    if W not in marks or W + K not in marks:
+        raise SystemExit("bench.py: the run ended before %d generations (result %d: %s)" % (W + K, ret, o.get_errmsg()))
+    (t0, ev0, st0), (t1, ev1, st1) = marks[W], marks[W + K]
+    dt_max, evals_all = reduce(t1 - t0, ev1 - ev0, False)
+    if rank != 0:
+        return None
+    d = {k: st1[k] - st0[k] for k in st1}
+    if a.workload == "isres":
+        # dominant kernel: the evolve chain (isres.c:234-280); algorithmic bytes per candidate per generation = 40 n (SURVEY.md §8d)
+        t_dom = d["t_evolve_s"]
+        bytes_dom = 40.0 * n * pop * K
+        kern, launches = "isres_evolve_lds_kernel (+ nrand compaction)", K
+        metric = "candidate-evals/sec, ISRES n=%d pop=%d, %d inequality constraints" % (n, pop, ncon)
+        wl = "NLOPT_GN_ISRES %s n=%d pop=%d + %d block-sum inequality constraints, seed=%d; step = 1 generation" % (a.obj, n, pop, ncon, a.seed)
+        phases = {"eval_s_per_gen": d["t_eval_s"] / K, "rank_s_per_gen": d["t_rank_s"] / K, "evolve_s_per_gen": d["t_evolve_s"] / K,
+                  "rng_s_per_gen_inside_rank_and_evolve": d["t_rng_s"] / K, "rank_sweeps_per_gen": d["rank_sweeps"] / K}
+    else:
+        t_dom = d["t_lbfgs_ms"] / 1e3
+        bytes_dom = float(d["lbfgs_bytes"])
+        kern, launches = "lbfgs_batch_kernel", int(d["lbfgs_launches"])
+        metric = "candidate-evals/sec, G_MLSL_LDS + LD_LBFGS n=%d, %d samples per iteration" % (n, pop)
+        wl = "NLOPT_G_MLSL_LDS + NLOPT_LD_LBFGS(ftol_rel 1e-8) %s n=%d, %d samples/iteration, seed=%d; step = 1 MLSL iteration" % (a.obj, n, pop, a.seed)
+        phases = {"sampling_s_per_iter": d["t_eval_s"] / K, "local_phase_s_per_iter": d["t_evolve_s"] / K,
+                  "local_searches": int(d["accepted"]), "sample_evals": int(d["evals_trial"]), "local_evals": int(d["evals_mutation"])}
+    achieved = (bytes_dom / 1e9) / t_dom if t_dom > 0 else None
+    out = {
+        "metric": metric, "value": evals_all / dt_max, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": wl + ("" if world == 1 else "; ONE job over %d ranks (library communicator over RCCL)" % world),
+                   "evals_timed": int(evals_all)},
+        "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None, "launches": launches,
+                     "avg_launch_ms": 1e3 * t_dom / launches if launches else None,
+                     "avg_algorithmic_bytes_per_launch": bytes_dom / launches if launches else None},
+        "phases": phases, "total_seconds_incl_setup": t_total, "final_result": int(ret), "minf": minf,
+    }
+    if comm is not None:
+        out["collectives"] = comm.counters()
+    if not a.no_cpu_baseline:
+        try:
+            if a.workload == "isres":
+                out["cpu_baseline"] = cpu_baseline_isres(a.obj, n, a.cpu_sample_pop or 10000, a.seed, ncon)
+                out["cpu_baseline"]["estimate_at_benchmark_pop"] = out["cpu_baseline"]["value"] * out["cpu_baseline"]["sample_pop"] / pop
+            else:
+                out["cpu_baseline"] = cpu_baseline_mlsl(a.obj, n, pop, a.seed, 30000)
+            if out["cpu_baseline"]["value"]:
+                out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
 
 
 if __name__ == "__main__":

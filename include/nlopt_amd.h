@@ -70,8 +70,18 @@ typedef struct {
     /* ISRES (evals are counted in evals_trial) */
     uint64_t generations, rank_sweeps;
     double t_eval_s, t_rank_s, t_evolve_s, t_rng_s;   /* wall seconds per phase; t_rng_s = stream-word generation inside rank/evolve */
+    /* batched L-BFGS inside MLSL: launches of lbfgs_batch_kernel, their device time (HIP events) and the algorithmic
+     * bytes they streamed: 32 n per history column used (two matrices, a dot and an axpy pass each) + 16 n per f/grad evaluation */
+    uint64_t lbfgs_launches, lbfgs_bytes;
+    double t_lbfgs_ms;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
+
+/* generation hook: called on the caller's thread by ISRES at the start of every generation (isres.c:130) and by
+ * MLSL at the start of every iteration (mlsl.c:345) — the device is idle at those points — with the number of
+ * generations completed and the evaluations made so far.  bench.py times exactly K generations with it. */
+typedef void (*nlopt_amd_progress_fn)(void *data, long generations_done, long numevals);
+nlopt_result nlopt_amd_set_progress(nlopt_opt opt, nlopt_amd_progress_fn fn, void *data);
 
 /* ---- multi-GPU (one process per GPU): the collective the sharded runs use --------------------------
  * Every rank creates the same optimiser, seeds the same nlopt_srand() and calls nlopt_optimize() with
@@ -235,7 +245,7 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
 
 /* ---- LD_LBFGS (src/algs/luksan/plis.c), batched ----------------------------------------------------- */
 typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, tolg; int32_t maxeval, pad; } nla_lbfgs_params;
-typedef struct { double f; int32_t ret, nevals, iterm, pad; } nla_lbfgs_result;
+typedef struct { double f; int32_t ret, nevals, iterm, cols; } nla_lbfgs_result;   /* cols = history columns streamed: sum over iterations of k */
 size_t nla_lbfgs_work_doubles(int ld, int mf, int count);     /* doubles of `work` */
 size_t nla_lbfgs_hist_doubles(int ld, int mf, int count);     /* doubles of `hist` */
 

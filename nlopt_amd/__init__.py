@@ -36,7 +36,7 @@ class Stats(C.Structure):
                [("t_init_s", C.c_double), ("t_trial_s", C.c_double), ("t_gather_ms", C.c_double),
                 ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64), ("generations", C.c_uint64),
                 ("rank_sweeps", C.c_uint64), ("t_eval_s", C.c_double), ("t_rank_s", C.c_double), ("t_evolve_s", C.c_double),
-                ("t_rng_s", C.c_double)]
+                ("t_rng_s", C.c_double), ("lbfgs_launches", C.c_uint64), ("lbfgs_bytes", C.c_uint64), ("t_lbfgs_ms", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -212,6 +212,7 @@ def lib():
     L.nlopt_amd_comm_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.nlopt_amd_comm_counters.restype = None
     L.nlopt_amd_set_comm.argtypes = [vp, vp]
+    L.nlopt_amd_set_progress.argtypes = [vp, vp, vp]
     L.nla_comm_allgather_host.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.nla_comm_allgather_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.nla_comm_partition.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -281,6 +282,7 @@ class DevBuf:
             pass
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_long)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
@@ -471,6 +473,12 @@ class Opt:
     def set_maxeval(self, v): self._ck(self._L.nlopt_set_maxeval(self._h, int(v)))
     def set_maxtime(self, v): self._ck(self._L.nlopt_set_maxtime(self._h, float(v)))
     def set_population(self, v): self._ck(self._L.nlopt_set_population(self._h, int(v)))
+
+    def set_progress(self, fn):
+        """fn(generations_done, numevals) at the start of every ISRES generation / MLSL iteration"""
+        cb = PROGRESS_FN(lambda d, g, e: fn(g, e)) if fn else None
+        self._progress = cb
+        self._ck(self._L.nlopt_amd_set_progress(self._h, C.cast(cb, C.c_void_p) if cb else None, None))
 
     def set_comm(self, comm):
         """multi-GPU run over `comm` (a Comm, kept alive by this object); None = single process"""

@@ -114,6 +114,13 @@ nlopt_result nlopt_amd_set_comm(nlopt_opt opt, nlopt_amd_comm *c)
     return NLOPT_SUCCESS;
 }
 
+nlopt_result nlopt_amd_set_progress(nlopt_opt opt, nlopt_amd_progress_fn fn, void *data)
+{
+    if (!opt) return NLOPT_INVALID_ARGS;
+    opt->progress = fn; opt->progress_data = data;
+    return NLOPT_SUCCESS;
+}
+
 static int need_host(nlopt_amd_comm *c, size_t bytes)
 {
     if (bytes * (size_t) c->world <= c->h_cap) return 0;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
     double gmax = 0, umax = 0, fval, fo, p = 0, po = 0, a, b, gnorm, snorm = 0, rmax, rmin = 0;
     const double eta9 = 1e120, eps8 = 1., eps9 = 1e-8, alf1 = 1e-10, alf2 = 1e10, told = 1e-4, xmax = 1e16, maxf = 1e20,
                  minf_est = -HUGE_VAL;
-    int kd = 1, ld_ = -1, nred = 0, maxst = 0, xstop = 0, nevals = 0, k;
+    int kd = 1, ld_ = -1, nred = 0, maxst = 0, xstop = 0, nevals = 0, k, cols = 0;
     double xtol_rel = P.xtol_rel, tolg = P.tolg;
     (void) ld_;
 
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
                 if (b <= 0.) c.irest = LB_MAX(c.irest, 1);
                 else {
                     if (tid == 0) COLU(1) = 1. / b;
+                    cols += k;
                     for (int i = tid; i < n; i += LB_T) s[i] = ix[i] >= 0 ? -gf[i] : 0.;      /* mxuneg */
                     __syncthreads();
                     for (int j = 1; j <= k; ++j) {                           /* mxdrcb */
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
         lb_add_active(n, x, ix, xl, xu);
         __syncthreads();
     }
-    if (tid == 0) { out[inst].f = fval; out[inst].ret = lb_result_of_iterm(c.iterm); out[inst].nevals = nevals; out[inst].iterm = c.iterm; }
+    if (tid == 0) { out[inst].f = fval; out[inst].ret = lb_result_of_iterm(c.iterm); out[inst].nevals = nevals; out[inst].iterm = c.iterm; out[inst].cols = cols; }
 #undef COLX
 #undef COLG
 #undef COLU

@@ -286,7 +286,9 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     for (;;) {                                       /* each loop body = one generation (isres.c:130) */
         int all_feasible = 1;
         int64_t kbest = -1, sweeps = 0;
-        double t0 = nla_seconds(), t_rng = 0;
+        double t0, t_rng = 0;
+        if (opt && opt->progress) opt->progress(opt->progress_data, st ? (long) st->generations : 0, (long) *stop->nevals_p);
+        t0 = nla_seconds();
         if (dev_eval) {
             /* this rank's block of candidates, then the all-gather (in place: block r sits at r * per) */
             const int64_t first = D.per * nlopt_amd_comm_rank(D.comm);

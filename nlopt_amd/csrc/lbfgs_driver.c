@@ -30,12 +30,15 @@ struct nla_lbfgs_ctx {
     double *d_X, *d_work, *d_hist;
     int *d_iwork;
     nla_lbfgs_result *d_res;
+    void *ev0, *ev1;
+    nlopt_amd_stats *stats;        /* optional: device time / algorithmic bytes of the launches are added here */
 };
 
 void nla_lbfgs_ctx_destroy(nla_lbfgs_ctx *c)
 {
     if (!c) return;
     nla_dev_free(c->d_X); nla_dev_free(c->d_work); nla_dev_free(c->d_iwork); nla_dev_free(c->d_hist); nla_dev_free(c->d_res);
+    nla_event_destroy(c->ev0); nla_event_destroy(c->ev1);
     free(c);
 }
 
@@ -49,20 +52,31 @@ nla_lbfgs_ctx *nla_lbfgs_ctx_create(int obj, int n, int cap, int mf, const doubl
     c->d_iwork = (int *) nla_dev_malloc(sizeof(int) * (size_t) c->ld * (size_t) cap);
     c->d_hist = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_hist_doubles(c->ld, mf, cap));
     c->d_res = (nla_lbfgs_result *) nla_dev_malloc(sizeof(nla_lbfgs_result) * (size_t) cap);
-    if (!c->d_X || !c->d_work || !c->d_iwork || !c->d_hist || !c->d_res) { nla_lbfgs_ctx_destroy(c); return NULL; }
+    c->ev0 = nla_event_create(); c->ev1 = nla_event_create();
+    if (!c->d_X || !c->d_work || !c->d_iwork || !c->d_hist || !c->d_res || !c->ev0 || !c->ev1) { nla_lbfgs_ctx_destroy(c); return NULL; }
     return c;
 }
+void nla_lbfgs_ctx_set_stats(nla_lbfgs_ctx *c, nlopt_amd_stats *stats) { if (c) c->stats = stats; }
 
 double *nla_lbfgs_ctx_X(nla_lbfgs_ctx *c) { return c->d_X; }
 
 /* run `count` searches from the rows already in ctx X; minimisers stay there, results come to the host */
 int nla_lbfgs_ctx_run(nla_lbfgs_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res)
 {
-    int rc;
+    int rc, i;
     if (count > c->cap) return -1;
+    nla_event_record(c->ev0, c->st);
     if ((rc = nla_k_lbfgs_batch(c->obj, c->n, c->ld, c->mf, count, c->d_lb, c->d_ub, c->d_X, c->d_work, c->d_iwork, c->d_hist, prm, c->d_res, c->st))) return rc;
+    nla_event_record(c->ev1, c->st);
     if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
-    return nla_stream_sync(c->st);
+    if ((rc = nla_stream_sync(c->st))) return rc;
+    if (c->stats) {
+        ++c->stats->lbfgs_launches;
+        c->stats->t_lbfgs_ms += (double) nla_event_elapsed_ms(c->ev0, c->ev1);
+        for (i = 0; i < count; ++i)
+            c->stats->lbfgs_bytes += (uint64_t) c->n * (32ULL * (uint64_t) h_res[i].cols + 16ULL * (uint64_t) h_res[i].nevals);
+    }
+    return 0;
 }
 
 /* `count` local searches from the rows of h_X (count x n, host), results back in h_X / res */

@@ -213,6 +213,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     }
     D.lb = nla_lbfgs_ctx_create(D.obj, n, BATCH_MAX, mf, D.d_lb, D.d_ub, D.st);
     if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (L-BFGS batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
+    nla_lbfgs_ctx_set_stats(D.lb, st);
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
 #define STOPS(fv) do { if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP; else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED; \
@@ -232,6 +233,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         size_t old = D.npts, used = 0, idx;
         int remaining;
         GET_MINF();                                                            /* mlsl.c:347 */
+        if (opt && opt->progress) { opt->progress(opt->progress_data, st ? (long) st->generations : 0, (long) *stop->nevals_p); t0 = nla_seconds(); }
 
         /* ---- sampling phase (mlsl.c:349-374) ---- */
         if (grow_pts(&D, old + (size_t) D.N)) DEVFAIL();

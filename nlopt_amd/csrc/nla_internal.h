@@ -81,6 +81,7 @@ struct nlopt_opt_s {
     /* --- libnlopt_amd additions (not in the reference) --- */
     nlopt_amd_trace_rec *trace; size_t trace_cap, trace_len;
     nlopt_amd_stats stats;
+    nlopt_amd_progress_fn progress; void *progress_data;
     nlopt_amd_comm *comm;           /* multi-GPU run: borrowed communicator (comm.c), NULL = single process */
 };
 
@@ -183,6 +184,7 @@ typedef struct nla_lbfgs_ctx nla_lbfgs_ctx;
 nla_lbfgs_ctx *nla_lbfgs_ctx_create(int obj, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream);
 void nla_lbfgs_ctx_destroy(nla_lbfgs_ctx *c);
 double *nla_lbfgs_ctx_X(nla_lbfgs_ctx *c);
+void nla_lbfgs_ctx_set_stats(nla_lbfgs_ctx *c, nlopt_amd_stats *stats);
 int nla_lbfgs_ctx_run(nla_lbfgs_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res);
 int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
                         const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen);

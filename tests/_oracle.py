@@ -208,18 +208,17 @@ class TraceRecP(C.Structure):
     _fields_ = [("f", C.c_double), ("row", C.c_int64), ("kind", C.c_int32), ("accepted", C.c_int32)]
 
 
-class Stats(C.Structure):
-    _fields_ = [(k, C.c_uint64) for k in ("rounds", "slots_launched", "slots_used", "slots_invalid", "slots_newbest",
-                                           "slots_role", "evals_init", "evals_trial", "evals_mutation", "accepted",
-                                           "mt_words")] + \
-               [("t_init_s", C.c_double), ("t_trial_s", C.c_double), ("t_gather_ms", C.c_double),
-                ("gather_launches", C.c_uint64), ("gather_bytes", C.c_uint64), ("generations", C.c_uint64),
-                ("rank_sweeps", C.c_uint64), ("t_eval_s", C.c_double), ("t_rank_s", C.c_double), ("t_evolve_s", C.c_double),
-                ("t_rng_s", C.c_double)]
+def _stats_type():
+    import nlopt_amd
+    return nlopt_amd.Stats          # one definition of nlopt_amd_stats' layout (include/nlopt_amd.h)
 
-    def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
 
+class _StatsProxy:
+    def __call__(self):
+        return _stats_type()()
+
+
+Stats = _StatsProxy()
 
 TRACE_DT = [("f", "f8"), ("row", "i8"), ("kind", "i4"), ("accepted", "i4")]
 
@@ -237,7 +236,7 @@ def emu():
         L.orc_emu_crs.argtypes = [C.c_int, C.c_int, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_long, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
-                                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats),
+                                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_stats_type()),
                                   C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
         _emu = L
     return _emu
