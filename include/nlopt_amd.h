@@ -259,6 +259,11 @@ int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *l
                       void *stream);
 
 /* ---- MLSL (src/algs/mlsl/mlsl.c) ------------------------------------------------------------------- */
+/* replaces: nlopt_sobol_next (sobolseq.c:236-242) for `count` consecutive points: row r of P (count x ld) := point number
+ * index_first + r (1-based call count of the reference's generator) scaled to [lb, ub]; V = 32 x n direction numbers as
+ * 32-bit fractions (nla_sobol_directions).  Bit-identical to the reference's stateful Gray-code walk. */
+int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const double *ub, const uint32_t *V, uint32_t index_first,
+                          int count, double *P, void *stream);
 /* replaces: distance2 (mlsl.c:118-127) for all pairs: D[i*nb + j] = |A_i - B_j|^2, A: na x ld, B: nb x ld
  * (summed over k ascending without FMA: bit-identical to the reference's loop). */
 int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream);

@@ -66,6 +66,32 @@ __global__ __launch_bounds__(256) void mlsl_colmin_kernel(const double *__restri
     inout[j] = m;
 }
 
+/* Sobol points by index (nlopt_sobol_next, sobolseq.c:236-242; see ../sobol.c for why a point is a pure function
+ * of its index): row r of P := lb + (ub - lb) * (x_k / 2^32), k = index_first + r, x_k = XOR of V[c] over the set
+ * bits c of gray(k).  One thread per (point, coordinate); V is 32 x n u32, coalesced over the coordinate. */
+__global__ __launch_bounds__(256) void mlsl_sobol_rows_kernel(int n, int ld, const double *__restrict__ lb, const double *__restrict__ ub,
+                                                              const uint32_t *__restrict__ V, uint32_t index_first, int count,
+                                                              double *__restrict__ P)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (i >= n || r >= count) return;
+    const uint32_t k = index_first + (uint32_t) r;
+    uint32_t g = k ^ (k >> 1), acc = 0;
+    while (g) { const int c = __builtin_ctz(g); acc ^= V[(size_t) c * n + i]; g &= g - 1; }
+    const double u = (double) acc / 4294967296.0;
+    P[(size_t) r * ld + i] = lb[i] + (ub[i] - lb[i]) * u;
+}
+
+extern "C" int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const double *ub, const uint32_t *V, uint32_t index_first,
+                                     int count, double *P, void *stream)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_sobol_rows_kernel, dim3((n + 255) / 256, count), dim3(256), 0, (hipStream_t) stream, n, ld, lb, ub, V,
+                       index_first, count, P);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream)
 {
     if (na <= 0 || nb <= 0) return 0;

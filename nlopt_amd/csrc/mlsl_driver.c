@@ -21,9 +21,10 @@
  *       are ALL-GATHERED (SURVEY.md §8e "all-gather of local minima"), after which every rank commits
  *       the whole batch in walk order.  world x BATCH_MAX searches are in flight per batch.
  *
- * Provided: local optimiser NLOPT_LD_LBFGS with a device objective; pseudo-random sampling (all
- * MLSL variants for n > 1111, where the reference's Sobol generator is NULL too — sobolseq.c — and
- * the non-LDS variants for any n).  Sobol sampling for n <= 1111 is not provided and says so.
+ * Provided: local optimiser NLOPT_LD_LBFGS with a device objective; pseudo-random sampling (the non-LDS
+ * variants, and the LDS variants for n > 1111 where the reference's Sobol generator is NULL — sobolseq.c:143
+ * — and mlsl.c:355-359 falls back to nlopt_urand) and Sobol sampling (LDS variants, n <= 1111; points by
+ * index, sobol.c; no MT words are drawn in that mode).
  */
 #include "nla_internal.h"
 #include <math.h>
@@ -35,7 +36,6 @@
 #define MLSL_SIGMA 2.
 #define MLSL_GAMMA 0.3
 #define BATCH_MAX 128                  /* local searches in flight per rank (one workgroup each) */
-#define SOBOL_MAXDIM 1111
 
 static double gam(int n) { double z = n / 2; return sqrt(pow(K2PI * z, 1.0 / n) * z) * exp(-0.5); }   /* mlsl.c:227-237 */
 
@@ -56,6 +56,7 @@ typedef struct {
     nlopt_amd_comm *comm; int world, rank;
     int32_t *d_min;
     uint32_t *d_words;
+    uint32_t *d_V; uint32_t sobol_next;   /* LDS mode: direction table on the device, index of the next point (1-based) */
     size_t dcap;                    /* doubles in d_D */
     nla_lbfgs_ctx *lb;
     double *h_D;                    /* pinned: batch x npts distances */
@@ -74,7 +75,7 @@ static void mfree(mlsl_dev *d)
     free(d->F); free(d->cpd); free(d->cld); free(d->minimized); free(d->ord); free(d->LF); free(d->lord);
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd);
     nla_dev_free(d->d_LM); nla_dev_free(d->d_LF); nla_dev_free(d->d_D); nla_dev_free(d->d_tmp); nla_dev_free(d->d_min);
-    nla_dev_free(d->d_words); nla_dev_free(d->d_LX);
+    nla_dev_free(d->d_words); nla_dev_free(d->d_LX); nla_dev_free(d->d_V);
     nla_host_free(d->h_D);
     if (d->st) nla_stream_destroy(d->st);
 }
@@ -175,10 +176,6 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         nla_stop_msg(stop, "nlopt_amd: MLSL is provided with NLOPT_LD_LBFGS as the local optimizer only");
         return NLOPT_INVALID_ARGS;
     }
-    if (lds && n <= SOBOL_MAXDIM) {
-        nla_stop_msg(stop, "nlopt_amd: Sobol sampling (MLSL_LDS with n <= %d) is not provided; use the non-LDS variant", SOBOL_MAXDIM);
-        return NLOPT_INVALID_ARGS;
-    }
     if (local_opt->xtol_abs) { nla_stop_msg(stop, "nlopt_amd: LD_LBFGS on the device does not take xtol_abs"); return NLOPT_INVALID_ARGS; }
     D.n = n; D.ld = (n + 1) & ~1;
     D.comm = opt ? opt->comm : NULL;
@@ -211,6 +208,19 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
         return NLOPT_OUT_OF_MEMORY;
     }
+    if (lds) {                                                                 /* d.s = nlopt_sobol_create(n), mlsl.c:306 */
+        uint32_t *V = (uint32_t *) malloc(sizeof(uint32_t) * 32 * (size_t) n);
+        if (V && nla_sobol_directions((unsigned) n, V)) {
+            D.d_V = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 32 * (size_t) n);
+            if (!D.d_V || nla_memcpy_h2d(D.d_V, V, sizeof(uint32_t) * 32 * (size_t) n, D.st) || nla_stream_sync(D.st)) {
+                nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
+                free(V); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
+                return NLOPT_OUT_OF_MEMORY;
+            }
+            D.sobol_next = nla_sobol_skip_count((unsigned) (10 * n + D.N)) + 1;  /* nlopt_sobol_skip(d.s, 10n+N, .), mlsl.c:332 */
+        }                                                                      /* else: NULL generator -> nlopt_urand, as the reference */
+        free(V);
+    }
     D.lb = nla_lbfgs_ctx_create(D.obj, n, BATCH_MAX, mf, D.d_lb, D.d_ub, D.st);
     if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (L-BFGS batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_lbfgs_ctx_set_stats(D.lb, st);
@@ -237,8 +247,15 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 
         /* ---- sampling phase (mlsl.c:349-374) ---- */
         if (grow_pts(&D, old + (size_t) D.N)) DEVFAIL();
-        if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
-        if (nla_k_crs_init_rows(D.obj, n, D.ld, D.d_lb, D.d_ub, D.d_words, (int64_t) old, D.N, D.d_P, D.d_F, D.st) ||
+        if (D.d_V) {                                                           /* nlopt_sobol_next, mlsl.c:355 */
+            if ((uint64_t) D.sobol_next + (uint64_t) D.N >= 4294967295ULL) { snprintf(D.err, sizeof D.err, "Sobol sequence exhausted (2^32-1 points)"); DEVFAIL(); }
+            if (nla_k_mlsl_sobol_rows(n, D.ld, D.d_lb, D.d_ub, D.d_V, D.sobol_next, D.N, D.d_P + old * (size_t) D.ld, D.st) ||
+                nla_k_eval(D.obj, n, D.ld, D.d_P + old * (size_t) D.ld, D.N, D.d_F + old, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+        } else {
+            if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
+            if (nla_k_crs_init_rows(D.obj, n, D.ld, D.d_lb, D.d_ub, D.d_words, (int64_t) old, D.N, D.d_P, D.d_F, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+        }
+        if (
             nla_memcpy_d2h(Fnew, D.d_F + old, sizeof(double) * (size_t) D.N, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         for (i = 0; i < D.N && ret == NLOPT_SUCCESS; ++i) {
             D.F[old + (size_t) i] = Fnew[i];
@@ -252,7 +269,8 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             }
             STOPS(Fnew[i]);
         }
-        D.words_used += 2ULL * (uint64_t) n * (uint64_t) used;
+        if (D.d_V) D.sobol_next += (uint32_t) used;
+        else D.words_used += 2ULL * (uint64_t) n * (uint64_t) used;
         if (ret != NLOPT_SUCCESS) break;
         {
             const int na = D.N, nb = (int) D.npts;

@@ -191,6 +191,11 @@ int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const doubl
 nlopt_result nla_lbfgs_minimize(int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                                 nla_stopping *stop, int mf, double tolg);
 
+/* Sobol LDS (sobol.c; src/util/sobolseq.c) */
+int nla_sobol_directions(unsigned sdim, uint32_t *V);      /* V: 32*sdim u32; 0 = no generator for this dimension */
+uint32_t nla_sobol_skip_count(unsigned n);
+void nla_sobol_point01(unsigned sdim, const uint32_t *V, uint32_t index, double *x);
+
 /* reference-shaped entry (src/algs/mlsl/mlsl.h:34-41) */
 nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
                                double *minf, nla_stopping *stop, nlopt_opt local_opt, int Nsamples, int lds);

@@ -38,6 +38,10 @@ static double distance2(int n, const double *a, const double *b)              /*
 #define K2PI (6.2831853071795864769252867665590057683943388)
 static double gam(int n) { double z = n / 2; return sqrt(pow(K2PI * z, 1.0 / n) * z) * exp(-0.5); }   /* mlsl.c:227-237, integer n/2 */
 
+/* lds != 0: NLOPT_G*_MLSL_LDS — Sobol points instead of urand when a generator exists for this n (mlsl.c:306,332,355-359) */
+static int mlsl_lds = 0;
+void orc_mlsl_set_lds(int lds) { mlsl_lds = lds; }
+
 int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                       orc_stop *stop, int Nsamples, const orc_local_params *loc, orc_mlsl_trace *trace)
 {
@@ -47,7 +51,8 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
     lm_t *lms = NULL; size_t nlms = 0, caplms = 0;
     double R_prefactor;
     counted cnt;
-    if (N < 1) return ORC_INVALID_ARGS;
+    orc_sobol *sob = mlsl_lds ? orc_sobol_create((unsigned) n) : NULL;
+    if (N < 1) { orc_sobol_destroy(sob); return ORC_INVALID_ARGS; }
     cnt.n = n; cnt.f = f; cnt.f_data = f_data; cnt.stop = stop;
     R_prefactor = sqrt(2. / K2PI) * pow(gam(n) * MLSL_SIGMA, 1.0 / n);
     for (i = 0; i < n; ++i) R_prefactor *= pow(ub[i] - lb[i], 1.0 / n);
@@ -65,6 +70,7 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
     {
         pt *p;
         NEWPT(p);
+        orc_sobol_skip(sob, (unsigned) (10 * n + N), p->x);                  /* mlsl.c:332 */
         memcpy(p->x, x, sizeof(double) * (size_t) n);
         p->f = f((unsigned) n, x, NULL, f_data);
         ++stop->nevals;
@@ -79,7 +85,8 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
             pt *p;
             size_t k;
             NEWPT(p);
-            for (j = 0; j < n; ++j) p->x[j] = orc_urand(lb[j], ub[j]);
+            if (sob) orc_sobol_next(sob, p->x, lb, ub);
+            else for (j = 0; j < n; ++j) p->x[j] = orc_urand(lb[j], ub[j]);
             p->f = f((unsigned) n, p->x, NULL, f_data);
             ++stop->nevals;
             if (trace && trace->nsamp < trace->cap) trace->fsamp[trace->nsamp] = p->f;
@@ -154,6 +161,6 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
 done:
     for (size_t k = 0; k < npts; ++k) { free(pts[k]->x); free(pts[k]); }
     for (size_t k = 0; k < nlms; ++k) free(lms[k].x);
-    free(pts); free(lms);
+    free(pts); free(lms); orc_sobol_destroy(sob);
     return ret;
 }

@@ -80,6 +80,14 @@ int orc_lbfgs_minimize(int n, orc_func f, void *f_data, const double *lb, const 
 /* ---- MLSL (src/algs/mlsl/mlsl.c) with LD_LBFGS as the local optimiser ------------------------- */
 typedef struct { double ftol_rel, ftol_abs, xtol_rel, tolg; long maxeval; int mf; } orc_local_params;
 typedef struct { double *fsamp, *floc; int *eloc; size_t cap, nsamp, nloc; long iterations; } orc_mlsl_trace;
+/* Sobol LDS (port_sobol.c; sobolseq.c:109-264) */
+typedef struct orc_sobol_s orc_sobol;
+orc_sobol *orc_sobol_create(unsigned sdim);
+void orc_sobol_destroy(orc_sobol *s);
+void orc_sobol_next(orc_sobol *s, double *x, const double *lb, const double *ub);
+void orc_sobol_next01(orc_sobol *s, double *x);
+void orc_sobol_skip(orc_sobol *s, unsigned n, double *x);
+
 int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                       orc_stop *stop, int Nsamples, const orc_local_params *loc, orc_mlsl_trace *trace);
 

@@ -386,8 +386,9 @@ class MlslTrace(C.Structure):
 
 
 def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0,
-                  local_maxeval=0, mf=0, x0=None, record=True):
+                  local_maxeval=0, mf=0, x0=None, record=True, lds=False):
     L = port()
+    L.orc_mlsl_set_lds(int(lds))
     L.orc_mlsl_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OrcStop), C.c_int,
                                     C.POINTER(OrcLocal), C.POINTER(MlslTrace)]
@@ -411,9 +412,59 @@ def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_re
     L.orc_srand(seed)
     ret = L.orc_mlsl_minimize(n, C.cast(L.orc_recording_callback, C.c_void_p).value, C.cast(C.pointer(rec), C.c_void_p),
                               dptr(lb), dptr(ub), dptr(x), C.byref(minf), C.byref(st), nsamples, C.byref(loc), C.byref(tr))
+    L.orc_mlsl_set_lds(0)
     return dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, words=L.orc_mt_words_drawn(), fseq=fbuf[:rec.len].copy(),
                 xhash=hbuf[:rec.len].copy(), fsamp=fs[:tr.nsamp].copy(), floc=fl[:tr.nloc].copy(), eloc=el[:tr.nloc].copy(),
                 iterations=tr.iterations)
+
+
+def port_sobol_points(sdim, skip_n, count, lb=None, ub=None):
+    """`count` points of the oracle's stateful Sobol generator after nlopt_sobol_skip(s, skip_n, .) (skip_n = 0: no skip);
+    None if there is no generator for this dimension"""
+    L = port()
+    L.orc_sobol_create.restype = C.c_void_p
+    L.orc_sobol_create.argtypes = [C.c_uint]
+    L.orc_sobol_destroy.argtypes = [C.c_void_p]
+    L.orc_sobol_next01.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.orc_sobol_next.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_sobol_skip.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_double)]
+    s = L.orc_sobol_create(sdim)
+    if not s:
+        return None
+    out = np.zeros((count, sdim))
+    if skip_n:
+        L.orc_sobol_skip(s, skip_n, dptr(out[0]))
+    for i in range(count):
+        if lb is None:
+            L.orc_sobol_next01(s, dptr(out[i]))
+        else:
+            L.orc_sobol_next(s, dptr(out[i]), dptr(lb), dptr(ub))
+    L.orc_sobol_destroy(s)
+    return out
+
+
+def ref_sobol_points(sdim, skip_n, count, lb=None, ub=None):
+    """the same from the REAL reference (src/util/sobolseq.c through oracle/_ref)"""
+    R = ref()
+    R.nlopt_sobol_create.restype = C.c_void_p
+    R.nlopt_sobol_create.argtypes = [C.c_uint]
+    R.nlopt_sobol_destroy.argtypes = [C.c_void_p]
+    R.nlopt_sobol_next01.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    R.nlopt_sobol_next.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    R.nlopt_sobol_skip.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_double)]
+    s = R.nlopt_sobol_create(sdim)
+    if not s:
+        return None
+    out = np.zeros((count, sdim))
+    if skip_n:
+        R.nlopt_sobol_skip(s, skip_n, dptr(out[0]))
+    for i in range(count):
+        if lb is None:
+            R.nlopt_sobol_next01(s, dptr(out[i]))
+        else:
+            R.nlopt_sobol_next(s, dptr(out[i]), dptr(lb), dptr(ub))
+    R.nlopt_sobol_destroy(s)
+    return out
 
 
 def run_ref_mlsl(obj, n, nsamples, seed, alg=38, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0, local_maxeval=0, mf=0, **kw):

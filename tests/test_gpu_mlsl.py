@@ -112,27 +112,46 @@ def test_mlsl_argument_errors():
     o2.set_min_objective(nlopt_amd.objective("sphere"))
     loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, 3)
     nlopt_amd.lib().nlopt_set_local_optimizer(o2._h, loc._h)
+    o2.set_maxeval(200)
     x, minf, ret = o2.optimize_raw(np.zeros(3))
-    assert ret == nlopt_amd.INVALID_ARGS and "Sobol" in o2.get_errmsg()
+    assert ret == nlopt_amd.MAXEVAL_REACHED          # Sobol sampling (n <= 1111) is served
 
 
-def test_distance_kernel_is_bit_identical_to_the_sequential_sum():
-    from nlopt_amd import DevBuf
+def test_sobol_rows_kernel_is_bit_identical_to_the_stateful_generator():
     L = nlopt_amd.lib()
-    rng = np.random.default_rng(1)
-    for n, na, nb in ((3, 5, 7), (64, 17, 33), (257, 40, 19), (4096, 20, 50)):
+    L.nla_sobol_directions.argtypes = [C.c_uint, C.c_void_p]
+    L.nla_k_mlsl_sobol_rows.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    L.nla_sobol_skip_count.argtypes = [C.c_uint]
+    L.nla_sobol_skip_count.restype = C.c_uint32
+    for n, count, skip_n in ((3, 100, 0), (37, 300, 10 * 37 + 50), (1111, 64, 11114)):
         ld = (n + 1) & ~1
-        A, B = np.zeros((na, ld)), np.zeros((nb, ld))
-        A[:, :n], B[:, :n] = rng.normal(size=(na, n)), rng.normal(size=(nb, n))
-        ref = np.zeros((na, nb))
-        for i in range(na):
-            for j in range(nb):
-                d = 0.0
-                for dx in (A[i, :n] - B[j, :n]):
-                    d += dx * dx
-                ref[i, j] = d
-        dA, dB, dD = DevBuf.from_array(A), DevBuf.from_array(B), DevBuf(8 * na * nb)
-        L.nla_k_mlsl_dist2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        assert L.nla_k_mlsl_dist2(n, ld, dA.ptr, na, dB.ptr, nb, dD.ptr, None) == 0
+        V = np.zeros(32 * n, dtype=np.uint32)
+        assert L.nla_sobol_directions(n, V.ctypes.data) == 1
+        lb, ub = np.linspace(-5, -1, n), np.linspace(0.5, 9, n)
+        dV, dlb, dub = nlopt_amd.DevBuf.from_array(V), nlopt_amd.DevBuf.from_array(lb), nlopt_amd.DevBuf.from_array(ub)
+        dP = nlopt_amd.DevBuf(8 * ld * count)
+        first = (L.nla_sobol_skip_count(skip_n) if skip_n else 0) + 1
+        assert L.nla_k_mlsl_sobol_rows(n, ld, dlb.ptr, dub.ptr, dV.ptr, first, count, dP.ptr, None) == 0
         assert L.nla_stream_sync(None) == 0
-        assert np.array_equal(dD.to_array(np.float64, na * nb).reshape(na, nb), ref)
+        got = dP.to_array(np.float64, ld * count).reshape(count, ld)[:, :n]
+        assert np.array_equal(got, O.port_sobol_points(n, skip_n, count, lb, ub))
+
+
+@pytest.mark.parametrize("obj,n,ns,seed,kw", [
+    ("sphere", 5, 6, 2, dict(stopval=1e-9, maxeval=5000)),
+    ("rastrigin", 4, 10, 42, dict(stopval=1e-6, maxeval=100000)),
+    ("rosenbrock", 4, 12, 9, dict(stopval=1e-10, maxeval=100000, mf=3)),
+    ("ackley", 30, 50, 1, dict(maxeval=4000)),
+])
+def test_mlsl_lds_sobol_sampling_matches_the_oracle(obj, n, ns, seed, kw):
+    """G_MLSL_LDS with a live Sobol generator (n <= 1111): the same samples in order (bit-identical x), no MT word drawn"""
+    a = run_amd(obj, n, ns, seed, alg=nlopt_amd.G_MLSL_LDS, **kw)
+    p = O.run_port_mlsl(obj, n, ns, seed, lds=True, **kw)
+    assert a["ret"] == p["ret"], (a["err"], p["ret"])
+    assert a["stats"]["mt_words"] == 0 and p["words"] == 0
+    assert abs(a["minf"] - p["minf"]) <= 1e-7 * max(abs(p["minf"]), 1.0)
+    fs = a["trace"][a["trace"]["kind"] == 3]["f"]
+    if p["ret"] != nlopt_amd.MAXEVAL_REACHED:
+        assert len(fs) == len(p["fsamp"])
+    m = min(len(fs), len(p["fsamp"]), ns or 4)          # the first iteration's samples do not depend on any local search
+    assert np.all(np.abs(fs[:m] - p["fsamp"][:m]) <= 1e-10 * np.maximum(np.abs(p["fsamp"][:m]), 1.0))

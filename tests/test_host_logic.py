@@ -111,3 +111,32 @@ def test_jump_polynomials_equal_plain_regeneration():
     # binary decomposition with plain regeneration for the low bits
     L.nla_mt_advance_blocks_host(mt.ctypes.data, 4096 + 3, out.ctypes.data)
     assert np.array_equal(out, _regen_ref(mt, 4099))
+
+
+def test_sobol_points_by_index_equal_the_stateful_walk():
+    """the product computes Sobol point k directly from gray(k) (nlopt_amd/csrc/sobol.c); the oracle walks the
+    reference's stateful generator (oracle/port_sobol.c, pinned to the real one): same doubles"""
+    import ctypes as C
+    import nlopt_amd
+    L = nlopt_amd.lib()
+    L.nla_sobol_directions.argtypes = [C.c_uint, C.c_void_p]
+    L.nla_sobol_point01.argtypes = [C.c_uint, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
+    L.nla_sobol_skip_count.argtypes = [C.c_uint]
+    L.nla_sobol_skip_count.restype = C.c_uint32
+    for sdim, count in ((1, 70), (5, 600), (1111, 130)):
+        V = np.zeros(32 * sdim, dtype=np.uint32)
+        assert L.nla_sobol_directions(sdim, V.ctypes.data) == 1
+        want = O.port_sobol_points(sdim, 0, count)
+        x = np.zeros(sdim)
+        for k in (1, 2, 3, 4, 7, 8, 63, 64, count - 1, count):
+            L.nla_sobol_point01(sdim, V.ctypes.data, k, O.dptr(x))
+            assert np.array_equal(x, want[k - 1]), (sdim, k)
+    # after nlopt_sobol_skip(s, n, .) the next point is number skip_count(n) + 1
+    for n_skip in (1, 2, 3, 17, 64, 65, 10 * 30 + 50):
+        k = L.nla_sobol_skip_count(n_skip)
+        V = np.zeros(32 * 3, dtype=np.uint32)
+        L.nla_sobol_directions(3, V.ctypes.data)
+        x = np.zeros(3)
+        L.nla_sobol_point01(3, V.ctypes.data, k + 1, O.dptr(x))
+        assert np.array_equal(x, O.port_sobol_points(3, n_skip, 1)[0])
+    assert L.nla_sobol_directions(1112, np.zeros(32 * 1112, dtype=np.uint32).ctypes.data) == 0

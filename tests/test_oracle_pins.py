@@ -182,3 +182,43 @@ def test_port_mlsl_matches_reference_live(obj, n, ns, seed, kw):
     assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
     assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
     assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
+
+
+# ---- Sobol LDS (a19) -----------------------------------------------------------------------------
+@need_ref
+@pytest.mark.parametrize("sdim,skip_n,count", [(1, 0, 300), (2, 0, 1025), (7, 110, 200), (40, 1000, 300), (1111, 11114, 40)])
+def test_port_sobol_matches_reference(sdim, skip_n, count):
+    a = O.port_sobol_points(sdim, skip_n, count)
+    b = O.ref_sobol_points(sdim, skip_n, count)
+    assert np.array_equal(a, b)
+    lb, ub = np.linspace(-3, -1, sdim), np.linspace(2, 7, sdim)
+    assert np.array_equal(O.port_sobol_points(sdim, skip_n, 50, lb, ub), O.ref_sobol_points(sdim, skip_n, 50, lb, ub))
+
+
+@need_ref
+def test_sobol_has_no_generator_above_1111_dimensions():
+    assert O.port_sobol_points(1112, 0, 1) is None and O.ref_sobol_points(1112, 0, 1) is None
+    assert O.port_sobol_points(0, 0, 1) is None and O.ref_sobol_points(0, 0, 1) is None
+
+
+def test_sobol_first_points_known_answers():
+    """the classic start of the sequence: 1/2; (3/4, 1/4); (1/4, 3/4); ... in Gray-code order"""
+    p = O.port_sobol_points(2, 0, 3)
+    assert np.array_equal(p, np.array([[0.5, 0.5], [0.75, 0.25], [0.25, 0.75]]))
+
+
+@need_ref
+@pytest.mark.parametrize("obj,n,ns,seed,kw", [
+    ("rastrigin", 4, 10, 42, dict(maxeval=3000)),
+    ("ackley", 6, 25, 7, dict(maxeval=4000)),
+    ("levy", 3, 0, 11, dict(maxeval=1500)),
+    ("griewank", 30, 50, 1, dict(maxeval=6000)),
+])
+def test_port_mlsl_lds_matches_reference_live(obj, n, ns, seed, kw):
+    """G_MLSL_LDS (39) with a live Sobol generator: every evaluation identical, and no MT word drawn"""
+    a = O.run_port_mlsl(obj, n, ns, seed, lds=True, **kw)
+    b = O.run_ref_mlsl(obj, n, ns, seed, alg=39, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+    assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
+    assert a["words"] == 0
