@@ -243,6 +243,20 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
                        const double *lb, const double *ub, const double *z, const int32_t *irank, double *X, double *S,
                        double *scratch, int64_t *state, void *stream);
 
+/* the same two loops, parallel over individuals (hip/isres_evolve2.hip: stage / multi-start scan / chain look-up /
+ * write, `rounds` times; each round resolves up to 256 consecutive individuals).  state as above plus [9] individuals
+ * resolved by the last round, [10] = 1: the next individual needs the serial kernel (nla_k_isres_evolve with
+ * state[14] = index to stop before), [14] serial stop index; rho: 4 doubles of running redraw statistics (zero at
+ * first use, kept between generations); inv: inverse of irank (nla_k_isres_inverse); x0c: copy of X row 0 taken
+ * before phase 1; ws: nla_isres_evolve2_ws_bytes(n) bytes.  n <= 1150 (nla_isres_evolve2_supported). */
+size_t nla_isres_evolve2_ws_bytes(int n);
+int nla_isres_evolve2_supported(int n);
+int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *inv, void *stream);
+int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                              const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
+                              double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
+                              void *stream);
+
 /* ---- LD_LBFGS (src/algs/luksan/plis.c), batched ----------------------------------------------------- */
 typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, tolg; int32_t maxeval, pad; } nla_lbfgs_params;
 typedef struct { double f; int32_t ret, nevals, iterm, cols; } nla_lbfgs_result;   /* cols = history columns streamed: sum over iterations of k */

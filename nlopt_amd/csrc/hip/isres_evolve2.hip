@@ -1,0 +1,347 @@
+/* isres_evolve2.hip — the ISRES evolve phase (mutation isres.c:234-252, differential variation :253-280) in
+ * parallel over individuals.
+ *
+ * Why it is hard: every draw is an nlopt_nrand taken from ONE stream, and how many deviates individual k consumes
+ * (1 + 2 per mutated coordinate + one more per out-of-bounds redraw, :245-248,270-273) depends on the deviates it
+ * meets — so where individual k+1 starts reading depends on everything before it.  isres_kernels.hip walks that
+ * chain with one workgroup (kept as the fallback); here the chain is cut open by MULTI-START LOOK-UP:
+ *
+ *   stage   (one workgroup per individual of a block of EVM consecutive individuals)  everything that does not
+ *           depend on the stream position: parent rows, the differential step and which coordinates mutate
+ *           (variation), compacted into a workspace.
+ *   scan    (one workgroup per individual, one LANE per candidate start)  individual i's start is predicted from the
+ *           block's exactly known first position, the deviates the individuals before it consume at least, and the
+ *           running redraw rate; for EACH of the EVD stream positions around the prediction a lane walks the
+ *           individual's coordinates sequentially (parent data broadcast from LDS, the deviate window shared) and
+ *           records how many deviates the individual would consume FROM THAT START: E[i][d], plus the redraw count
+ *           at every 1/64 of the coordinates (T) so that the write pass can start all of its lanes at once.
+ *   chain   (one thread, tables in LDS)  start_0 is exact; start_{i+1} = start_i + E[i][start_i - base_i] — a table
+ *           look-up per individual instead of the individual's whole arithmetic.  The walk stops where the true start
+ *           leaves the predicted window (the next round re-anchors there), where a variation individual needs a row
+ *           that an earlier individual of the same block rewrites (isres.c:260 reads the CURRENT physical row k+1),
+ *           or where the deviates generated so far run out.
+ *   write   (one wavefront per resolved individual)  the same arithmetic once more from the now exact start, lanes on
+ *           contiguous coordinate chunks whose stream offsets come from T, producing the child's x and sigma rows.
+ *
+ * Everything is exact: the same expressions in the same order as the serial kernel (sigma' = sigma exp(taup z_k +
+ * tau z), capped; x = x_parent + sigma' z redrawn while out of bounds; sigma_new = sigma + 0.2 (sigma' - sigma));
+ * a wrong prediction costs a shorter round, never a different result.  Work is EVD x the serial arithmetic, spread
+ * over EVM x EVD lanes per round.
+ */
+#include "dev_common.h"
+#include "../../../include/nlopt_amd.h"
+
+#define EVD 256                 /* candidate starts per individual (window of stream positions) */
+#define EVM 256                 /* individuals per round */
+#define EV2_MAXN 1150           /* LDS staging limit (same as the serial LDS kernel) */
+#define EV2_ZW(n) (EVD + 3 * (n) + 65)      /* deviates staged per individual: window + 1 + 2n + room for n + 64 redraws */
+
+struct ev2_args {
+    int n, ld, phase;
+    int64_t pop, survivors, zcount;
+    double taup, tau;
+    const double *lb, *ub, *z;
+    const int32_t *irank, *inv;         /* inv[irank[k]] = k */
+    double *X, *S;
+    const double *x0c;                  /* copy of physical row 0 taken before the variation loop (isres.c:253) */
+    int64_t *state;                     /* [0] next individual, [1] next deviate, [2] deviates ran out, [9] resolved in the last round,
+                                           [10] stuck (fallback needed), [11] rounds, [12] first individual of the last round */
+    double *rho;                        /* [2*phase] decayed redraw sum, [2*phase+1] decayed mutated-coordinate sum */
+    int32_t *ws_nact, *ws_act;          /* per block slot: number of mutated coordinates (-1: past the end), their indices */
+    double *ws_xi, *ws_sg, *ws_xpre;    /* parent x / sigma of the mutated coordinates (compacted); x of the others */
+    int16_t *T;                         /* EVM x 64 x EVD: redraws before coordinate chunk c when starting at d */
+    int16_t *E;                         /* EVM x EVD: deviates consumed from candidate start d, -1 window exceeded, -2 deviates ran out */
+    int64_t *ws_base, *ws_start;        /* window origin / exact start per slot */
+};
+
+/* ---- stage ------------------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void ev2_stage_kernel(ev2_args A)
+{
+    __shared__ int s_cnt[4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
+    const int n = A.n, ld = A.ld;
+    if (A.state[2] || A.state[10]) return;
+    const int64_t k = A.state[0] + i, kend = A.phase == 0 ? A.pop : A.survivors;
+    if (k >= kend) { if (tid == 0) A.ws_nact[i] = -1; return; }
+    const int64_t rk = A.irank[k];
+    int32_t *act = A.ws_act + (size_t) i * n;
+    double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n, *wpre = A.ws_xpre + (size_t) i * n;
+    if (A.phase == 0) {                                        /* standard mutation: child k from parent irank[k % survivors], every coordinate */
+        const int64_t ri = A.irank[k % A.survivors];
+        const double *xr = A.X + (size_t) ri * ld, *sr = A.S + (size_t) ri * ld;
+        for (int j = tid; j < n; j += 256) { wxi[j] = xr[j]; wsg[j] = sr[j]; act[j] = j; }
+        if (tid == 0) A.ws_nact[i] = n;
+        return;
+    }
+    /* differential variation of survivor k, in place: x + 0.85 (x0 - physical row k+1) unless it is the last survivor;
+     * coordinates that leave the box (or all of them, for the last survivor) are mutated from the survivor's own x, sigma */
+    const double GAMMA = 0.85;
+    const bool lastsurv = (k + 1 == A.survivors), self = (k + 1 == rk);
+    const double *xr = A.X + (size_t) rk * ld, *sr = A.S + (size_t) rk * ld, *kr = A.X + (size_t) (k + 1) * ld;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        double xv = 0, sv = 0, xnew = 0;
+        bool mut = false;
+        if (j < n) {
+            xv = xr[j]; sv = sr[j];
+            xnew = xv;
+            if (!lastsurv) xnew = xv + GAMMA * (A.x0c[j] - (self ? xv : kr[j]));
+            mut = lastsurv || xnew < A.lb[j] || xnew > A.ub[j];
+            wpre[j] = xnew;
+        }
+        const unsigned long long bal = __ballot(mut);
+        if (lane == 0) s_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base + __popcll(bal & ((1ull << lane) - 1));
+        for (int w = 0; w < wave; ++w) off += s_cnt[w];
+        if (mut) { act[off] = j; wxi[off] = xv; wsg[off] = sv; }
+        __syncthreads();
+        if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) A.ws_nact[i] = s_base;
+}
+
+/* ---- scan -------------------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
+{
+    extern __shared__ double sm[];
+    __shared__ long long s_red[4];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
+    const int n = A.n;
+    if (A.state[2] || A.state[10]) return;
+    const int na = A.ws_nact[i];
+    if (na < 0) return;
+    const double sa_ = A.rho[2 * A.phase + 1];
+    const double rhoc = sa_ > 0 ? A.rho[2 * A.phase] / sa_ : 0.0;
+    /* predicted start: the exact start of the block + what the individuals before this one consume at least
+     * (1 + 2 per mutated coordinate) + the expected redraws */
+    {
+        long long acc = 0;
+        for (int q = tid; q < i; q += 256) acc += A.ws_nact[q];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (lane == 0) s_red[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const long long ab = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+            s_base = A.state[1] + i + 2 * ab + (long long) floor(rhoc * (double) ab) - EVD / 2;
+            A.ws_base[i] = s_base;
+        }
+        __syncthreads();
+    }
+    const int64_t base = s_base;
+    double *xi = sm, *sg = sm + n, *lo = sm + 2 * n, *hi = sm + 3 * n, *smax = sm + 4 * n, *zw = sm + 5 * n;
+    const double sqn = sqrt((double) n);
+    const int32_t *act = A.ws_act + (size_t) i * n;
+    const double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n;
+    for (int a = tid; a < na; a += 256) {
+        const int j = act[a];
+        xi[a] = wxi[a]; sg[a] = wsg[a]; lo[a] = A.lb[j]; hi[a] = A.ub[j]; smax[a] = (A.ub[j] - A.lb[j]) / sqn;
+    }
+    const int ZW = EVD + 3 * na + 65;
+    const int64_t avail = A.zcount - base;
+    const int zwlen = (int) (avail < ZW ? (avail < 0 ? 0 : avail) : ZW);
+    const bool zw_cut = avail < ZW;
+    for (int q = tid; q < zwlen; q += 256) { const int64_t g = base + q; zw[q] = g >= 0 ? A.z[g] : 0.0; }
+    __syncthreads();
+    /* lane = candidate start d: the coordinates one after the other, exactly the serial loop (isres.c:236-251,266-277) */
+    {
+        const int d = tid;                                      /* blockDim.x == EVD */
+        const int chunk = (na + 63) >> 6;
+        int16_t *Ti = A.T + (size_t) i * 64 * EVD;
+        int res = 0;
+        if (base + d < 0 || d >= zwlen) res = zw_cut && base + d >= 0 ? -2 : -1;
+        const double taup_rand = res == 0 ? A.taup * zw[d] : 0.0;
+        int cur = d + 1, red = 0, cnext = 0, c = 0;
+        for (int a = 0; a < na; ++a) {
+            if (a == cnext) { if (c < 64) Ti[(size_t) c * EVD + d] = (int16_t) red; ++c; cnext += chunk; }
+            if (res != 0) continue;
+            if (cur + 1 >= zwlen) { res = zw_cut ? -2 : -1; continue; }
+            double s2 = sg[a] * exp(taup_rand + A.tau * zw[cur]);
+            if (s2 > smax[a]) s2 = smax[a];
+            const double xa = xi[a], l = lo[a], h = hi[a];
+            int t = 1;
+            for (;;) {
+                const double xn = xa + s2 * zw[cur + t];
+                if (!(xn < l || xn > h)) break;
+                ++t;
+                if (cur + t >= zwlen) { res = zw_cut ? -2 : -1; break; }
+            }
+            cur += 1 + t; red += t - 1;
+        }
+        const int e = res != 0 ? res : 1 + 2 * na + red;
+        A.E[(size_t) i * EVD + d] = (int16_t) (e > 32767 ? -1 : e);
+    }
+}
+
+/* ---- chain ------------------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void ev2_chain_kernel(ev2_args A)
+{
+    extern __shared__ int16_t sE[];                            /* EVM x EVD */
+    __shared__ int s_na[EVM];
+    __shared__ long long s_b[EVM];
+    const int tid = threadIdx.x;
+    if (A.state[2] || A.state[10]) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing: its write kernel idles */
+    const int64_t k0 = A.state[0], kend = A.phase == 0 ? A.pop : A.survivors;
+    if (k0 >= kend) { if (tid == 0) A.state[9] = 0; return; }
+    for (int q = tid; q < EVM; q += 256) { s_na[q] = A.ws_nact[q]; s_b[q] = A.ws_base[q]; }
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(A.E);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(sE);
+        for (int q = tid; q < EVM * EVD / 2; q += 256) dst[q] = src[q];
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    long long pos = A.state[1], rsum = 0, asum = 0;
+    int r = 0, ranout = 0;
+    for (int i = 0; i < EVM; ++i) {
+        const int na = s_na[i];
+        if (na < 0) break;
+        const long long k = k0 + i;
+        if (A.phase == 1 && k + 1 < A.pop) {                   /* the row isres.c:260 reads must not be rewritten inside this block before k */
+            const long long o = A.inv[k + 1];
+            if (o >= k0 && o < k) break;
+        }
+        const long long d = pos - s_b[i];
+        if (d < 0 || d >= EVD) break;
+        const int e = sE[i * EVD + (int) d];
+        if (e == -2) { ranout = 1; break; }
+        if (e < 0) break;
+        A.ws_start[i] = pos;
+        pos += e; rsum += e - 1 - 2 * na; asum += na;
+        ++r;
+    }
+    A.state[12] = k0;
+    A.state[0] = k0 + r;
+    A.state[1] = pos;
+    A.state[9] = r;
+    A.state[11] += 1;
+    if (ranout) A.state[2] = 1;
+    else if (r == 0) A.state[10] = 1;                           /* not even the exactly-started first individual resolved: serial fallback */
+    A.rho[2 * A.phase] = 0.9 * A.rho[2 * A.phase] + (double) rsum;
+    A.rho[2 * A.phase + 1] = 0.9 * A.rho[2 * A.phase + 1] + (double) asum;
+}
+
+/* ---- write ------------------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(64) void ev2_write_kernel(ev2_args A)
+{
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x, i = blockIdx.x;
+    const int n = A.n, ld = A.ld;
+    /* state[9] / [12] were written by the chain kernel of this round; a round that was skipped leaves state[9] = 0 */
+    if (i >= A.state[9]) return;
+    const int64_t k = A.state[12] + i, rk = A.irank[k];
+    const int na = A.ws_nact[i];
+    const int64_t start = A.ws_start[i];
+    double *xi = sm, *sg = sm + n, *lo = sm + 2 * n, *hi = sm + 3 * n, *smax = sm + 4 * n, *xo = sm + 5 * n, *so = sm + 6 * n, *zw = sm + 7 * n;
+    const double sqn = sqrt((double) n);
+    const int32_t *act = A.ws_act + (size_t) i * n;
+    const double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n, *wpre = A.ws_xpre + (size_t) i * n;
+    for (int a = lane; a < na; a += 64) {
+        const int j = act[a];
+        xi[a] = wxi[a]; sg[a] = wsg[a]; lo[a] = A.lb[j]; hi[a] = A.ub[j]; smax[a] = (A.ub[j] - A.lb[j]) / sqn;
+    }
+    const int ZW = EVD + 3 * na + 65;                         /* as long as the longest window the scan had for this individual */
+    const int64_t avail = A.zcount - start;
+    const int zwlen = (int) (avail < ZW ? avail : ZW);
+    for (int q = lane; q < zwlen; q += 64) zw[q] = A.z[start + q];
+    __syncthreads();
+    {
+        /* the exact start is candidate dtrue of the scan's window: its lane left the redraw count before every chunk in T */
+        const double ALPHA = 0.2;
+        const int dtrue = (int) (start - A.ws_base[i]);
+        const int chunk = (na + 63) >> 6;
+        const int a0 = lane * chunk < na ? lane * chunk : na, a1 = a0 + chunk < na ? a0 + chunk : na;
+        const double taup_rand = A.taup * zw[0];
+        int cur = 1 + 2 * a0 + (a0 < na ? (int) A.T[((size_t) i * 64 + lane) * EVD + dtrue] : 0);
+        for (int a = a0; a < a1; ++a) {
+            const double xa = xi[a], sa = sg[a], l = lo[a], h = hi[a];
+            double s2 = sa * exp(taup_rand + A.tau * zw[cur]);
+            if (s2 > smax[a]) s2 = smax[a];
+            int t = 1;
+            double xn;
+            for (;;) { xn = xa + s2 * zw[cur + t]; if (!(xn < l || xn > h)) break; ++t; }
+            xo[a] = xn; so[a] = sa + ALPHA * (s2 - sa);
+            cur += 1 + t;
+        }
+    }
+    __syncthreads();
+    double *xw = A.X + (size_t) rk * ld, *sw = A.S + (size_t) rk * ld;
+    if (A.phase == 1) for (int j = lane; j < n; j += 64) xw[j] = wpre[j];      /* coordinates that stayed inside the box; sigma unchanged */
+    __syncthreads();
+    for (int a = lane; a < na; a += 64) { const int j = act[a]; xw[j] = xo[a]; sw[j] = so[a]; }
+}
+
+/* inverse of the ranking permutation (variation's dependency test) */
+__global__ __launch_bounds__(256) void ev2_inverse_kernel(int64_t pop, const int32_t *__restrict__ irank, int32_t *__restrict__ inv)
+{
+    const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (k < pop) inv[irank[k]] = (int32_t) k;
+}
+
+/* ---- launchers --------------------------------------------------------------------------------------------------- */
+extern "C" size_t nla_isres_evolve2_ws_bytes(int n)
+{
+    /* nact | act | xi | sg | xpre | E | T | base | start, each region 256-byte aligned */
+    size_t b = 0;
+    auto add = [&](size_t x) { b += (x + 255) & ~(size_t) 255; };
+    add(sizeof(int32_t) * EVM); add(sizeof(int32_t) * EVM * (size_t) n);
+    add(sizeof(double) * EVM * (size_t) n); add(sizeof(double) * EVM * (size_t) n); add(sizeof(double) * EVM * (size_t) n);
+    add(sizeof(int16_t) * EVM * EVD); add(sizeof(int16_t) * EVM * 64 * EVD); add(sizeof(int64_t) * EVM); add(sizeof(int64_t) * EVM);
+    return b;
+}
+extern "C" int nla_isres_evolve2_supported(int n) { return n >= 1 && n <= EV2_MAXN; }
+
+extern "C" int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *inv, void *stream)
+{
+    if (pop <= 0) return 0;
+    hipLaunchKernelGGL(ev2_inverse_kernel, dim3((unsigned) ((pop + 255) / 256)), dim3(256), 0, (hipStream_t) stream, pop, irank, inv);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                                         const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
+                                         double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
+                                         void *stream)
+{
+    if (!nla_isres_evolve2_supported(n)) return (int) hipErrorInvalidValue;
+    ev2_args A;
+    A.n = n; A.ld = ld; A.phase = phase; A.pop = pop; A.survivors = survivors; A.zcount = zcount; A.taup = taup; A.tau = tau;
+    A.lb = lb; A.ub = ub; A.z = z; A.irank = irank; A.inv = inv; A.X = X; A.S = S; A.x0c = x0c; A.state = state; A.rho = rho;
+    char *p = (char *) ws;
+    auto take = [&](size_t x) { char *q = p; p += (x + 255) & ~(size_t) 255; return q; };
+    A.ws_nact = (int32_t *) take(sizeof(int32_t) * EVM);
+    A.ws_act = (int32_t *) take(sizeof(int32_t) * EVM * (size_t) n);
+    A.ws_xi = (double *) take(sizeof(double) * EVM * (size_t) n);
+    A.ws_sg = (double *) take(sizeof(double) * EVM * (size_t) n);
+    A.ws_xpre = (double *) take(sizeof(double) * EVM * (size_t) n);
+    A.E = (int16_t *) take(sizeof(int16_t) * EVM * EVD);
+    A.T = (int16_t *) take(sizeof(int16_t) * EVM * 64 * EVD);
+    A.ws_base = (int64_t *) take(sizeof(int64_t) * EVM);
+    A.ws_start = (int64_t *) take(sizeof(int64_t) * EVM);
+    const size_t lds_scan = sizeof(double) * (size_t) (5 * n + EV2_ZW(n));
+    const size_t lds_write = sizeof(double) * (size_t) (7 * n + EV2_ZW(n));
+    const size_t lds_chain = sizeof(int16_t) * EVM * EVD;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void) hipGetLastError();
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t) stream;
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(ev2_stage_kernel, dim3(EVM), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(ev2_scan_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);
+        hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(256), lds_chain, st, A);
+        hipLaunchKernelGGL(ev2_write_kernel, dim3(EVM), dim3(64), lds_write, st, A);
+    }
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

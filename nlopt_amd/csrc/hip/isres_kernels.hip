@@ -375,7 +375,8 @@ __global__ __launch_bounds__(64) void isres_evolve_kernel(isres_evolve_args A)
     volatile double *Xv = A.X;
     volatile double *Sv = A.S;
     int64_t k = A.state[0], pos = A.state[1];
-    const int64_t kend = A.phase == 0 ? A.pop : A.survivors;
+    int64_t kend = A.phase == 0 ? A.pop : A.survivors;
+    if (A.state[14] > 0 && A.state[14] < kend) kend = A.state[14];      /* stop before this individual (fallback use) */
     if (A.phase == 1 && k == 0) {           /* memcpy(x0, xs, n) before the first survivor (isres.c:253) */
         for (int j = lane; j < n; j += 64) x0c[j] = Xv[j];
         __threadfence();
@@ -501,7 +502,8 @@ __global__ __launch_bounds__(EV_T) void isres_evolve_lds_kernel(isres_evolve_arg
     double *xp = sm, *sp = sm + n, *xo = sm + 2 * n, *so = sm + 3 * n, *x0c = sm + 4 * n, *xk1 = sm + 5 * n, *lbs = sm + 6 * n,
            *ubs = sm + 7 * n, *smax = sm + 8 * n, *zw = sm + 9 * n, *gw = sm + 9 * n + ZW;
     int64_t k = A.state[0], pos = A.state[1];
-    const int64_t kend = A.phase == 0 ? A.pop : A.survivors;
+    int64_t kend = A.phase == 0 ? A.pop : A.survivors;
+    if (A.state[14] > 0 && A.state[14] < kend) kend = A.state[14];      /* stop before this individual (fallback use) */
     for (int j = tid; j < n; j += EV_T) { lbs[j] = A.lb[j]; ubs[j] = A.ub[j]; smax[j] = (A.ub[j] - A.lb[j]) / sqn; }
     if (A.phase == 1) {                     /* memcpy(x0, xs, n) before the first survivor (isres.c:253); kept for resumes */
         if (k == 0) for (int j = tid; j < n; j += EV_T) A.scratch[j] = A.X[j];

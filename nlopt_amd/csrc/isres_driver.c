@@ -43,7 +43,10 @@ typedef struct {
     nla_mtstream *mts;
     uint64_t words_used;
     double *d_lb, *d_ub, *d_X, *d_S, *d_F, *d_PEN, *d_GPEN, *d_scratch, *d_z;
-    int32_t *d_FEAS, *d_irank, *d_counts;
+    int32_t *d_FEAS, *d_irank, *d_counts, *d_inv;
+    double *d_rho; void *d_ws;           /* parallel evolve (hip/isres_evolve2.hip): redraw statistics, block workspace */
+    int parallel_evolve;
+    uint64_t ev_rounds, ev_fallbacks;
     int *d_progress, *d_ticket;
     uint8_t *d_swapped;
     uint64_t *d_streams, *d_bits;
@@ -59,7 +62,7 @@ typedef struct {
 } isres_dev;
 
 #define DFAIL(d, ...) do { snprintf((d)->err, sizeof (d)->err, __VA_ARGS__); return -1; } while (0)
-#define DCK(d, call) do { int rc_ = (call); if (rc_) DFAIL(d, "%s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
+#define DCK(d, call) do { int rc_ = (call); if (rc_) DFAIL(d, "%.90s failed: %.60s", #call, nla_dev_error_string(rc_)); } while (0)
 
 static void dev_free_all(isres_dev *d)
 {
@@ -70,6 +73,7 @@ static void dev_free_all(isres_dev *d)
     nla_dev_free(d->d_irank); nla_dev_free(d->d_counts); nla_dev_free(d->d_progress); nla_dev_free(d->d_ticket);
     nla_dev_free(d->d_swapped); nla_dev_free(d->d_streams); nla_dev_free(d->d_bits); nla_dev_free(d->d_zatt);
     nla_dev_free(d->d_ztotal); nla_dev_free(d->d_state); nla_dev_free(d->d_words); nla_dev_free(d->d_con);
+    nla_dev_free(d->d_inv); nla_dev_free(d->d_rho); nla_dev_free(d->d_ws);
     nla_host_free(d->h_F); nla_host_free(d->h_PEN); nla_host_free(d->h_GPEN); nla_host_free(d->h_X); nla_host_free(d->h_FEAS);
     nla_host_free(d->h_swapped); nla_host_free(d->h_progress);
     if (d->st) nla_stream_destroy(d->st);
@@ -98,6 +102,12 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     A(d_words, uint32_t, WORD_CHUNK); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
     A(d_counts, int32_t, WORD_CHUNK / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
     A(d_con, nla_dev_constraint, d->m + d->p + 1);
+    d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !getenv("NLA_ISRES_EVOLVE_SERIAL");
+    if (d->parallel_evolve) {
+        A(d_inv, int32_t, pop); A(d_rho, double, 4);
+        d->d_ws = nla_dev_malloc(nla_isres_evolve2_ws_bytes(d->n));
+        if (!d->d_ws || (d->d_rho && nla_memset(d->d_rho, 0, sizeof(double) * 4, d->st))) ok = 0;
+    }
 #undef A
     d->h_F = (double *) nla_host_malloc(sizeof(double) * pop);
     d->h_PEN = (double *) nla_host_malloc(sizeof(double) * pop);
@@ -196,22 +206,53 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
     DCK(d, nla_memset(d->d_ztotal, 0, sizeof(int64_t), d->st));
     if (dev_more_deviates(d, word0, &attempts_done, (int64_t) (1.35 * (double) expect / 0.785) + 4096, &zcount)) return -1;
     *t_rng += nla_seconds() - t0;
+    if (d->parallel_evolve) DCK(d, nla_k_isres_inverse(d->pop, d->d_irank, d->d_inv, d->st));
     for (phase = 0; phase < 2; ++phase) {
+        const int64_t kend = phase == 0 ? d->pop : d->survivors;
         state[0] = phase == 0 ? d->survivors : 0;
-        state[2] = 0;
+        state[2] = 0; state[9] = 0; state[10] = 0; state[14] = 0;
         DCK(d, nla_memcpy_h2d(d->d_state, state, sizeof state, d->st));
+        if (d->parallel_evolve && phase == 1)                  /* memcpy(x0, xs, n) before the variation loop (isres.c:253) */
+            DCK(d, nla_memcpy_d2d(d->d_scratch, d->d_X, sizeof(double) * (size_t) d->n, d->st));
         DCK(d, nla_stream_sync(d->st));
         for (;;) {
-            DCK(d, nla_k_isres_evolve(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z, d->d_irank,
-                                      d->d_X, d->d_S, d->d_scratch, d->d_state, d->st));
+            if (d->parallel_evolve) {
+                /* a round resolves up to 256 individuals (fewer when the predicted windows are left): enqueue several, then look */
+                const int64_t left = kend - state[0];
+                int rounds = (int) (left / 96) + 1;
+                if (rounds > 24) rounds = 24;
+                DCK(d, nla_k_isres_evolve_rounds(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z,
+                                                 d->d_irank, d->d_inv, d->d_X, d->d_S, d->d_scratch, d->d_state, d->d_rho, d->d_ws, rounds, d->st));
+                d->ev_rounds += (uint64_t) rounds;
+            } else
+                DCK(d, nla_k_isres_evolve(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z, d->d_irank,
+                                          d->d_X, d->d_S, d->d_scratch, d->d_state, d->st));
             DCK(d, nla_memcpy_d2h(state, d->d_state, sizeof state, d->st));
             DCK(d, nla_stream_sync(d->st));
-            if (!state[2]) break;
-            t0 = nla_seconds();
-            if (dev_more_deviates(d, word0, &attempts_done, (int64_t) (0.5 * (double) expect / 0.785) + 4096, &zcount)) return -1;
-            *t_rng += nla_seconds() - t0;
+            if (state[2]) {                                    /* the deviates generated so far ran out */
+                t0 = nla_seconds();
+                if (dev_more_deviates(d, word0, &attempts_done, (int64_t) (0.5 * (double) expect / 0.785) + 4096, &zcount)) return -1;
+                *t_rng += nla_seconds() - t0;
+                state[2] = 0;
+                DCK(d, nla_memcpy_h2d(d->d_state, state, sizeof state, d->st));
+                DCK(d, nla_stream_sync(d->st));
+                continue;
+            }
+            if (d->parallel_evolve && state[10]) {             /* one individual the look-up could not resolve: the serial kernel takes it */
+                state[10] = 0; state[14] = state[0] + 1;
+                DCK(d, nla_memcpy_h2d(d->d_state, state, sizeof state, d->st));
+                DCK(d, nla_k_isres_evolve(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z, d->d_irank,
+                                          d->d_X, d->d_S, d->d_scratch, d->d_state, d->st));
+                DCK(d, nla_memcpy_d2h(state, d->d_state, sizeof state, d->st));
+                DCK(d, nla_stream_sync(d->st));
+                ++d->ev_fallbacks;
+                if (!state[2]) { state[14] = 0; DCK(d, nla_memcpy_h2d(d->d_state, state, sizeof state, d->st)); DCK(d, nla_stream_sync(d->st)); }
+                else { state[14] = 0; state[10] = 1; continue; }     /* ran out inside the serial step: refill above, then retry it */
+            }
+            if (!d->parallel_evolve || state[0] >= kend) break;
         }
     }
+    if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve2: rounds enqueued %llu, serial fallbacks %llu\n", (unsigned long long) d->ev_rounds, (unsigned long long) d->ev_fallbacks);
     if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve: fixpoint rounds %lld for %lld individuals, deviates %lld; cycles stage %lld eval %lld scan %lld fin %lld all %lld\n", (long long) state[3], (long long) d->pop, (long long) state[1], (long long) state[4], (long long) state[5], (long long) state[6], (long long) state[7], (long long) state[8]);
     if (state[1] <= 0) DFAIL(d, "evolve consumed no deviates");
     DCK(d, nla_memcpy_d2h(&last_att, d->d_zatt + (state[1] - 1), sizeof last_att, d->st));
