@@ -35,7 +35,7 @@
 #define K2PI (6.2831853071795864769252867665590057683943388)
 #define MLSL_SIGMA 2.
 #define MLSL_GAMMA 0.3
-#define BATCH_MAX 128                  /* local searches in flight per rank (one workgroup each) */
+#define BATCH_MAX 320                  /* local searches in flight per rank (one workgroup each) */
 
 static double gam(int n) { double z = n / 2; return sqrt(pow(K2PI * z, 1.0 / n) * z) * exp(-0.5); }   /* mlsl.c:227-237 */
 
