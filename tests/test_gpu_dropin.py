@@ -1,0 +1,68 @@
+"""-m gpu: the drop-in boundary at the C ABI.  tests/dropin/dropin_demo.c is a plain NLopt client; the
+same executable is run against the REAL reference library (oracle/_ref/libnlopt_ref.so) and against libnlopt_amd.so and
+must print the same line: same result code, same minimum bit for bit, same number of evaluations, and — through the
+hash of every x handed to its callback — the same candidates in the same order."""
+import os
+import subprocess
+
+import pytest
+
+import _oracle as O
+import nlopt_amd
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "dropin", "dropin_demo.c")
+EXE = os.path.join(HERE, "dropin", "dropin_demo")
+REF = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libnlopt_ref.so")
+
+
+def build():
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(SRC):
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", EXE, SRC, "-ldl", "-lm"], check=True)
+    return EXE
+
+
+def run(lib, *args):
+    r = subprocess.run([build(), lib] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout.strip()
+
+
+def fields(line):
+    return dict(p.strip().split(" ", 1) for p in line.split(":", 1)[1].split(","))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,pop,maxeval,seed", [(12, 150, 3000, 42), (40, 0, 2500, 7), (3, 0, 800, 1)])
+def test_crs_same_client_same_output_against_reference_and_amd(n, pop, maxeval, seed):
+    """NLOPT_GN_CRS2_LM (19): nothing on the path to x involves libm, so the two runs agree bit for bit"""
+    ref = run(REF, 19, n, pop, maxeval, seed)
+    amd = run(nlopt_amd.LIB_PATH, 19, n, pop, maxeval, seed)
+    assert ref == amd, "\nreference: %s\nnlopt_amd: %s" % (ref, amd)
+    assert fields(amd)["callbacks"] == fields(amd)["numevals"]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("n,pop,maxeval,seed", [(10, 60, 1200, 5), (6, 0, 1500, 11)])
+def test_isres_same_client_against_reference_and_amd(n, pop, maxeval, seed):
+    """NLOPT_GN_ISRES (35): the mutation step sizes go through exp() — device libm vs glibc differ in the last bit, so x
+    agrees to rounding, not bit for bit: same result / evaluation count / callback count, minimum within 1e-9 relative"""
+    rf = fields(run(REF, 35, n, pop, maxeval, seed))
+    af = fields(run(nlopt_amd.LIB_PATH, 35, n, pop, maxeval, seed))
+    assert (rf["result"], rf["numevals"], rf["callbacks"]) == (af["result"], af["numevals"], af["callbacks"])
+    assert abs(float(rf["minf"]) - float(af["minf"])) <= 1e-9 * abs(float(rf["minf"]))
+    assert abs(float(rf["x[0]"]) - float(af["x[0]"])) <= 1e-9 * max(1.0, abs(float(rf["x[0]"])))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_device_objective_reaches_the_reference_result():
+    """the fully-on-device path (registered objective) against the reference running the client's C callback:
+    same result code / evaluation count, minimum within the f tolerance (device libm + reduction order)"""
+    ref = run(REF, 19, 64, 2000, 6000, 42)
+    amd = run(nlopt_amd.LIB_PATH, 19, 64, 2000, 6000, 42, "device")
+    rf, af = fields(ref), fields(amd)
+    assert rf["result"] == af["result"] and rf["numevals"] == af["numevals"]
+    assert abs(float(rf["minf"]) - float(af["minf"])) <= 1e-10 * abs(float(rf["minf"]))
+    assert rf["x[0]"] == af["x[0]"] and rf["x[n-1]"] == af["x[n-1]"]          # the argmin is bit-identical
+    assert af["callbacks"] == "0"
