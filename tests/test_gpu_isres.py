@@ -84,12 +84,27 @@ def test_isres_matches_oracle_on_golden_cases(name):
     ("rastrigin", 2, 64, 9, 1, 0, dict(maxeval=1920)),
     ("sphere", 2100, 40, 3, 2, 0, dict(maxeval=200)),             # n beyond the LDS-staged evolve kernel: generic path
     ("rastrigin", 1150, 30, 3, 0, 1, dict(maxeval=120)),          # largest n of the LDS-staged kernel
+    ("rastrigin", 256, 5000, 42, 4, 0, dict(maxeval=10000)),      # config-3 shape, 2 generations: many look-up rounds per phase
+    ("griewank", 48, 3000, 2, 2, 1, dict(maxeval=12000)),         # variation blocks cut by in-block row dependencies
 ])
 def test_isres_matches_oracle_larger(obj, n, pop, seed, nineq, neq, kw):
     a = run_amd(obj, n, pop, seed, nineq, neq, **kw)
     p = O.run_port_isres(obj, n, pop, seed, nineq, neq, **kw)
     assert_same_run(a, p)
     assert a["stats"]["generations"] >= 1
+
+
+def test_full_size_config3_parallel_evolve_equals_the_serial_chain(monkeypatch):
+    """BASELINE config 3 at full size (n = 256, pop = 5e4, 4 inequality constraints; the CPU reference needs ~86 s per
+    generation there): the multi-start look-up evolve (hip/isres_evolve2.hip) and the serial chain kernel must give the
+    same population trajectory — same f of every candidate, same best point, same stream position."""
+    kw = dict(maxeval=150000)
+    a = run_amd("rastrigin", 256, 50000, 42, 4, 0, **kw)
+    monkeypatch.setenv("NLA_ISRES_EVOLVE_SERIAL", "1")
+    b = run_amd("rastrigin", 256, 50000, 42, 4, 0, **kw)
+    assert a["ret"] == b["ret"] and a["nevals"] == b["nevals"] == 150000
+    assert np.array_equal(a["trace"]["f"], b["trace"]["f"]) and np.array_equal(a["x"], b["x"]) and a["minf"] == b["minf"]
+    assert a["stats"]["mt_words"] == b["stats"]["mt_words"] and a["stats"]["rank_sweeps"] == 2 * 50000
 
 
 def test_isres_host_callback_path_is_exact():
