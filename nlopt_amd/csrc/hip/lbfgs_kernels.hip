@@ -27,6 +27,7 @@
 
 #define LB_T 256
 #define LB_W (LB_T / 64)
+#define LB_EPT 16                  /* coordinates per thread held in registers by the direction loops (n <= 4096) */
 
 struct lb_shared {
     double red[2 * LB_W];
@@ -261,25 +262,91 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
                 else {
                     if (tid == 0) COLU(1) = 1. / b;
                     cols += k;
-                    for (int i = tid; i < n; i += LB_T) s[i] = ix[i] >= 0 ? -gf[i] : 0.;      /* mxuneg */
-                    __syncthreads();
-                    for (int j = 1; j <= k; ++j) {                           /* mxdrcb */
-                        const double *cx = COLX(j), *cg = COLG(j);
-                        const double v = COLU(j) * lb_mdot(n, s, cx, ix, S);
-                        if (tid == 0) vcol[j - 1] = v;
-                        for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + (-v) * cg[i];
+                    if (n <= LB_T * LB_EPT) {
+                        /* the two Strang loops with s held in registers (thread t owns coordinates t, t+256, ...: the same
+                         * partial-sum order as lb_mdot) and the next history column prefetched while the current dot
+                         * product is being reduced — one barrier pair per column, no s traffic */
+                        double sr[LB_EPT], c1[LB_EPT], c2[LB_EPT], n1[LB_EPT], n2[LB_EPT];
+                        unsigned live = 0;
+                        const int ept = (n + LB_T - 1) / LB_T;
+#pragma unroll
+                        for (int e = 0; e < LB_EPT; ++e) {
+                            const int i = tid + e * LB_T;
+                            sr[e] = 0.; c1[e] = 0.; c2[e] = 0.; n1[e] = 0.; n2[e] = 0.;
+                            if (e < ept && i < n && ix[i] >= 0) { live |= 1u << e; sr[e] = -gf[i]; }     /* mxuneg */
+                        }
+                        __syncthreads();                       /* COLU(1) visible */
+                        auto load_col = [&](int j, double *px, double *pg) {
+                            const double *cx = COLX(j), *cg = COLG(j);
+#pragma unroll
+                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { px[e] = cx[tid + e * LB_T]; pg[e] = cg[tid + e * LB_T]; }
+                        };
+                        load_col(1, c1, c2);
+                        for (int j = 1; j <= k; ++j) {                       /* mxdrcb */
+                            if (j < k) load_col(j + 1, n1, n2);
+                            double t = 0;
+#pragma unroll
+                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c1[e];
+                            const double v = COLU(j) * lb_block_sum(t, S);
+                            if (tid == 0) vcol[j - 1] = v;
+#pragma unroll
+                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + (-v) * c2[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
+                        }
+                        {
+                            double t = 0;
+                            const double *cg = COLG(1);
+#pragma unroll
+                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { const double gv = cg[tid + e * LB_T]; t += gv * gv; }
+                            a = lb_block_sum(t, S);
+                            if (a > 0.) {
+                                const double sc = b / a;
+#pragma unroll
+                                for (int e = 0; e < LB_EPT; ++e) sr[e] = sr[e] * sc;
+                            }
+                        }
+                        load_col(k, c1, c2);
+                        for (int j = k; j >= 1; --j) {                       /* mxdrcf */
+                            if (j > 1) load_col(j - 1, n1, n2);
+                            double t = 0;
+#pragma unroll
+                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c2[e];
+                            const double tt = COLU(j) * lb_block_sum(t, S);
+                            const double w = vcol[j - 1] - tt;
+#pragma unroll
+                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + w * c1[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
+                        }
+                        {
+                            double t = 0;
+#pragma unroll
+                            for (int e = 0; e < LB_EPT; ++e) {
+                                const int i = tid + e * LB_T;
+                                if (e < ept && i < n) s[i] = sr[e];
+                                if (live & (1u << e)) t += sr[e] * sr[e];
+                            }
+                            snorm = sqrt(lb_block_sum(t, S));
+                        }
                         __syncthreads();
-                    }
-                    a = lb_mdot(n, COLG(1), COLG(1), ix, S);
-                    if (a > 0.) { const double sc = b / a; for (int i = tid; i < n; i += LB_T) s[i] = s[i] * sc; __syncthreads(); }
-                    for (int j = k; j >= 1; --j) {                           /* mxdrcf */
-                        const double *cx = COLX(j), *cg = COLG(j);
-                        const double t = COLU(j) * lb_mdot(n, s, cg, ix, S);
-                        const double w = vcol[j - 1] - t;
-                        for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + w * cx[i];
+                    } else {
+                        for (int i = tid; i < n; i += LB_T) s[i] = ix[i] >= 0 ? -gf[i] : 0.;      /* mxuneg */
                         __syncthreads();
+                        for (int j = 1; j <= k; ++j) {                           /* mxdrcb */
+                            const double *cx = COLX(j), *cg = COLG(j);
+                            const double v = COLU(j) * lb_mdot(n, s, cx, ix, S);
+                            if (tid == 0) vcol[j - 1] = v;
+                            for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + (-v) * cg[i];
+                            __syncthreads();
+                        }
+                        a = lb_mdot(n, COLG(1), COLG(1), ix, S);
+                        if (a > 0.) { const double sc = b / a; for (int i = tid; i < n; i += LB_T) s[i] = s[i] * sc; __syncthreads(); }
+                        for (int j = k; j >= 1; --j) {                           /* mxdrcf */
+                            const double *cx = COLX(j), *cg = COLG(j);
+                            const double t = COLU(j) * lb_mdot(n, s, cg, ix, S);
+                            const double w = vcol[j - 1] - t;
+                            for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + w * cx[i];
+                            __syncthreads();
+                        }
+                        snorm = sqrt(lb_mdot(n, s, s, ix, S));
                     }
-                    snorm = sqrt(lb_mdot(n, s, s, ix, S));
                     head = (head + mf - 1) % mf;                             /* mxdrsu: every column one older */
                 }
             }
