@@ -32,12 +32,13 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define WORD_CHUNK (1ULL << 28)            /* stream words generated per pass (1 GiB) */
+#define WORD_CHUNK_MAX (1ULL << 30)        /* stream words generated per pass: at most 4 GiB of the 288 (~1700 generator wavefronts per launch) */
 
 typedef struct {
     int n, ld, m, p, obj, dev_eval;
     int64_t pop, survivors, units, rowwords;
     nlopt_amd_comm *comm;
+    uint64_t wchunk;                /* words per generator pass: what the largest phase needs, up to WORD_CHUNK_MAX */
     int64_t per, popcap;            /* candidates per rank, per * world >= pop (all-gather wants equal blocks) */
     void *st;
     nla_mtstream *mts;
@@ -89,6 +90,14 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     d->rowwords = (d->pop - 1 + 63) / 64;
     if (d->rowwords < 1) d->rowwords = 1;
     d->zcap = 4 * d->pop * (1 + 2 * (int64_t) d->n) + 4096;
+    {
+        const uint64_t init_w = 2ULL * (uint64_t) d->pop * (uint64_t) d->n, rank_w = 2ULL * (uint64_t) d->pop * (uint64_t) d->pop,
+                       evo_w = 8ULL * (uint64_t) d->pop * (1 + 2 * (uint64_t) d->n);
+        uint64_t need = init_w > rank_w ? init_w : rank_w;
+        if (evo_w > need) need = evo_w;
+        d->wchunk = 1ULL << 22;
+        while (d->wchunk < need && d->wchunk < WORD_CHUNK_MAX) d->wchunk <<= 1;
+    }
     d->st = nla_stream_create();
     if (!d->st) return -1;
     d->mts = nla_mtstream_create(d->st);
@@ -99,8 +108,8 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     A(d_irank, int32_t, pop); A(d_scratch, double, 3 * ld);
     A(d_streams, uint64_t, (size_t) (d->units + 1) * pop); A(d_progress, int, d->units + 1); A(d_ticket, int, 1);
     A(d_swapped, uint8_t, pop); A(d_bits, uint64_t, pop * (size_t) d->rowwords);
-    A(d_words, uint32_t, WORD_CHUNK); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
-    A(d_counts, int32_t, WORD_CHUNK / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
+    A(d_words, uint32_t, d->wchunk); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
+    A(d_counts, int32_t, d->wchunk / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
     A(d_con, nla_dev_constraint, d->m + d->p + 1);
     d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !getenv("NLA_ISRES_EVOLVE_SERIAL");
     if (d->parallel_evolve) {
@@ -124,11 +133,11 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     return nla_stream_sync(d->st) ? -1 : 0;
 }
 
-/* initial population (isres.c:122-128): 2 pop n stream words, in passes of WORD_CHUNK */
+/* initial population (isres.c:122-128): 2 pop n stream words, in passes of d->wchunk */
 static int dev_init_population(isres_dev *d, const double *x0)
 {
     const uint64_t wpi = 2ULL * (uint64_t) d->n;
-    int64_t per = (int64_t) (WORD_CHUNK / wpi), k0;
+    int64_t per = (int64_t) (d->wchunk / wpi), k0;
     if (per < 1) DFAIL(d, "dimension too large for the word buffer");
     DCK(d, nla_memcpy_h2d(d->d_scratch, x0, sizeof(double) * (size_t) d->n, d->st));
     for (k0 = 0; k0 < d->pop; k0 += per) {
@@ -152,7 +161,7 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
     if (all_feasible || popm1 <= 0) return 0;      /* irank = stable sort by f (or the single individual) */
     /* the uniforms of all pop sweeps, reduced to bits, generated in whole-sweep passes */
     t0 = nla_seconds();
-    rows_per = (int64_t) (WORD_CHUNK / (2ULL * (uint64_t) popm1));
+    rows_per = (int64_t) (d->wchunk / (2ULL * (uint64_t) popm1));
     if (rows_per < 1) DFAIL(d, "population too large for the word buffer");
     for (r0 = 0; r0 < pop; r0 += rows_per) {
         const int64_t nr = pop - r0 < rows_per ? pop - r0 : rows_per;
@@ -181,7 +190,7 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
 static int dev_more_deviates(isres_dev *d, uint64_t phase_word0, int64_t *attempts_done, int64_t nattempts, int64_t *zcount)
 {
     while (nattempts > 0) {
-        int64_t a = nattempts < (int64_t) (WORD_CHUNK / 4) ? nattempts : (int64_t) (WORD_CHUNK / 4), zt;
+        int64_t a = nattempts < (int64_t) (d->wchunk / 4) ? nattempts : (int64_t) (d->wchunk / 4), zt;
         if (*zcount + a > d->zcap) a = d->zcap - *zcount;
         if (a <= 0) DFAIL(d, "deviate buffer exhausted");
         if (nla_mtstream_fill(d->mts, phase_word0 + 4ULL * (uint64_t) *attempts_done, 4ULL * (uint64_t) a, d->d_words)) DFAIL(d, "MT stream fill failed");
