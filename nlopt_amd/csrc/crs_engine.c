@@ -122,6 +122,10 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->ld = (n + 1) & ~1;
     e->bat[0].index = e->bat[1].index = -1;
     B = (size_t) ((1ULL << 25) / (2ULL * (uint64_t) n));
+    /* the Vitter kernel walks all N rows per block, one lane per block (a serial fp64 chain): its time per launch grows
+     * with N, not with the blocks in it — large populations digest proportionally more blocks per launch so that the
+     * digestion keeps ahead of the trial loop (N = 1e6, n = 4096: 205 ms per launch whatever the batch) */
+    B *= (size_t) (1 + N / 250000);
     if (B > 65536) B = 65536;
     if (B < 2 * KCAP) B = 2 * KCAP;
     e->B = (int) B;
