@@ -254,20 +254,20 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
+def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, sync_all, max_spec=0, variant=0):
+    """open a CRS2_LM run (population initialisation untimed), W warm-up steps, K timed steps; returns the raw numbers"""
     import _oracle as O
-    n, pop = a.n, a.pop
-    xs, lo, hi = O.golden_x0(a.obj, n)
+    xs, lo, hi = O.golden_x0(obj, n)
     o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
     o.set_lower_bounds(lo)
     o.set_upper_bounds(hi)
-    o.set_min_objective(nlopt_amd.objective(a.obj))
+    o.set_min_objective(nlopt_amd.objective(obj))
     o.set_population(pop)
-    if a.max_spec:
-        o.set_param("amd_max_spec", a.max_spec)
-    if a.gather_variant:
-        o.set_param("amd_gather_variant", a.gather_variant)
-    nlopt_amd.srand(a.seed + rank)
+    if max_spec:
+        o.set_param("amd_max_spec", max_spec)
+    if variant:
+        o.set_param("amd_gather_variant", variant)
+    nlopt_amd.srand(seed)
     x = np.array(xs)
     minf, ret = C.c_double(), C.c_int()
     t0 = time.perf_counter()
@@ -275,20 +275,27 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     t_init = time.perf_counter() - t0
     if not s or ret.value != 1:
         raise SystemExit("bench.py: crs_open failed: ret=%d %s" % (ret.value, o.get_errmsg()))
-    for _ in range(a.warmup):
-        if L.nlopt_amd_crs_step(s, a.evals_per_step) != 1:
+    for _ in range(warmup):
+        if L.nlopt_amd_crs_step(s, evals_per_step) != 1:
             raise SystemExit("bench.py: the run stopped during warm-up")
     sync_all()
     st0, ev0 = o.stats(), o.get_numevals()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        if L.nlopt_amd_crs_step(s, a.evals_per_step) != 1:
+    for _ in range(steps):
+        if L.nlopt_amd_crs_step(s, evals_per_step) != 1:
             raise SystemExit("bench.py: the run stopped inside the timed region")
     sync_all()
     dt = time.perf_counter() - t0
     st1, ev1 = o.stats(), o.get_numevals()
     fret = L.nlopt_amd_crs_close(s)
-    dt_max, evals_all = reduce(dt, ev1 - ev0, True)
+    return dict(dt=dt, evals=ev1 - ev0, st0=st0, st1=st1, t_init=t_init, fret=int(fret), minf=minf.value)
+
+
+def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
+    n, pop = a.n, a.pop
+    m = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed + rank, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec, a.gather_variant)
+    dt, st0, st1, t_init, fret = m["dt"], m["st0"], m["st1"], m["t_init"], m["fret"]
+    dt_max, evals_all = reduce(dt, m["evals"], True)
     if rank != 0:
         return None
     g_ms = st1["t_gather_ms"] - st0["t_gather_ms"]
@@ -319,8 +326,29 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                    "role": int(st1["slots_role"] - st0["slots_role"]),
                    "accepted": int(st1["accepted"] - st0["accepted"])},
         "init": {"evals": pop, "seconds": t_init, "init_evals_per_s": pop / t_init},
-        "final_result": int(fret), "minf": minf.value,
+        "final_result": int(fret), "minf": m["minf"],
     }
+    if world == 1 and (n, pop, a.obj) == (4096, 100000, "griewank"):
+        # north_star asks for n in {64, 512, 4096}: the two smaller sizes (512 = BASELINE config 2), shorter runs, same contract
+        out["other_sizes"] = {}
+        for n2 in (512, 64):
+            try:
+                m2 = crs_measure(nlopt_amd, L, "rastrigin", n2, 100000, a.seed, 1, 3, 20000, sync_all)
+                s0, s1 = m2["st0"], m2["st1"]
+                gms, gb, gl = s1["t_gather_ms"] - s0["t_gather_ms"], s1["gather_bytes"] - s0["gather_bytes"], s1["gather_launches"] - s0["gather_launches"]
+                e2 = {"workload": "NLOPT_GN_CRS2_LM rastrigin n=%d pop=100000 seed=%d, 3 steps of 20000 evals" % (n2, a.seed),
+                      "value": m2["evals"] / m2["dt"], "unit": "evals/s",
+                      "roofline_frac": (gb / 1e9) / (gms / 1e3) / HBM_PEAK_GBS if gms > 0 else None,
+                      "avg_launch_ms": gms / gl if gl else None, "algorithmic_bytes_per_trial": 8 * n2 * (n2 + 1),
+                      "init_evals_per_s": 100000 / m2["t_init"]}
+                if not a.no_cpu_baseline:
+                    cb = cpu_baseline_crs("rastrigin", n2, 20000, 4000, a.seed)
+                    e2["cpu_baseline"] = cb
+                    if cb.get("value"):
+                        e2["speedup_vs_cpu_single_thread"] = e2["value"] / cb["value"]
+                out["other_sizes"]["n=%d" % n2] = e2
+            except Exception as e:
+                out["other_sizes"]["n=%d" % n2] = {"error": repr(e)}
     try:
         out["gens_to_ftol"] = gens_to_ftol()
     except Exception as e:        # the headline line must still be printed
