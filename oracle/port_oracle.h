@@ -91,6 +91,12 @@ void orc_sobol_skip(orc_sobol *s, unsigned n, double *x);
 int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                       orc_stop *stop, int Nsamples, const orc_local_params *loc, orc_mlsl_trace *trace);
 
+/* ---- ESCH (src/algs/esch/esch.c) ---------------------------------------------------------------- */
+/* np parents, no offspring (0, 0 -> 40, 60; the dispatcher passes pop and (unsigned)(pop*1.5), optimize.c:946-949);
+ * trace: one record per evaluation (kind 0 parent, 1 offspring; row = physical row) */
+int orc_esch_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf, orc_stop *stop,
+                      long np, long no, orc_trace *trace);
+
 /* ---- objective zoo callbacks (objfuncs.h compiled for the host) ------------------------------ */
 orc_func orc_objective(int id);                     /* f_data ignored */
 double orc_con_blocksum(unsigned n, const double *x, double *grad, void *data); /* data -> unsigned[2]={q,Q} */

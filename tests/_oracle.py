@@ -485,3 +485,37 @@ def run_ref_mlsl(obj, n, nsamples, seed, alg=38, local_ftol_rel=1e-8, local_xtol
         assert R.nlopt_set_local_optimizer(opt, loc) > 0
         R.nlopt_destroy(loc)           # set_local_optimizer copies it (options.c:824-846)
     return run_ref(alg, obj, n, nsamples, seed, setup=setup, **kw)
+
+
+# ---- ESCH ---------------------------------------------------------------------------------------
+def run_port_esch(obj, n, pop, seed, maxeval=0, stopval=None, x0=None, trace_cap=0):
+    """oracle/port_esch.c with np = pop, no = int(pop * 1.5) (0 -> 40 / 60), as the reference's dispatcher passes them"""
+    L = port()
+    L.orc_esch_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(OrcStop), C.c_long, C.c_long, C.POINTER(Trace)]
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lb, ub = np.full(n, lo), np.full(n, hi)
+    st = OrcStop()
+    L.orc_stop_default(C.byref(st), n)
+    st.maxeval = maxeval
+    if stopval is not None:
+        st.minf_max = stopval
+    f = L.orc_objective(OBJ[obj])
+    cap = (maxeval or 100000) + 4096
+    fbuf = np.zeros(cap)
+    hbuf = np.zeros(cap, dtype=np.uint64)
+    rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
+    tr = np.zeros(max(trace_cap, 1), dtype=TRACE_DT)
+    t = Trace(tr.ctypes.data_as(C.POINTER(TraceRec)), trace_cap, 0)
+    minf = C.c_double()
+    L.orc_srand(seed)
+    ret = L.orc_esch_minimize(n, C.cast(L.orc_recording_callback, C.c_void_p).value, C.cast(C.pointer(rec), C.c_void_p), dptr(lb), dptr(ub),
+                              dptr(x), C.byref(minf), C.byref(st), pop, int(pop * 1.5), C.byref(t) if trace_cap else None)
+    return dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, words=L.orc_mt_words_drawn(), fseq=fbuf[:rec.len].copy(),
+                xhash=hbuf[:rec.len].copy(), trace=tr[:min(t.len, trace_cap)].copy())
+
+
+def run_ref_esch(obj, n, pop, seed, **kw):
+    """the REAL reference's NLOPT_GN_ESCH (42)"""
+    return run_ref(42, obj, n, pop, seed, **kw)

@@ -222,3 +222,21 @@ def test_port_mlsl_lds_matches_reference_live(obj, n, ns, seed, kw):
     assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
     assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
     assert a["words"] == 0
+
+
+# ---- ESCH -----------------------------------------------------------------------
+@need_ref
+@pytest.mark.parametrize("obj,n,pop,seed,kw", [
+    ("rastrigin", 6, 0, 42, dict(maxeval=3000)),                    # default 40 parents / 60 offspring
+    ("griewank", 10, 50, 7, dict(maxeval=4000)),
+    ("ackley", 3, 7, 3, dict(maxeval=1500)),                        # no = 10, (no n)/10 = 3 mutations per generation
+    ("sphere", 1, 5, 5, dict(maxeval=400)),                         # n = 1: (no n)/10 = 0 -> 1 mutation
+    ("rosenbrock", 30, 200, 11, dict(maxeval=6000)),
+    ("levy", 8, 30, 1, dict(stopval=0.5, maxeval=20000)),
+])
+def test_port_esch_matches_reference_live(obj, n, pop, seed, kw):
+    a = O.run_port_esch(obj, n, pop, seed, **kw)
+    b = O.run_ref_esch(obj, n, pop, seed, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+    assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
