@@ -286,6 +286,28 @@ int nla_k_mlsl_rowmin(const double *D, int ldd, int na, int nb, const double *FA
 /* replaces: pts_update_newpt (mlsl.c:162-173): inout[j] = min(inout[j], min_i {D[i][j] : FA[i] < FB[j]}) where skip[j] == 0 */
 int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const int32_t *skip, double *inout, void *stream);
 
+/* ---- ESCH (src/algs/esch/esch.c) -------------------------------------------------------------------- */
+/* replaces: randcauchy (esch.c:28-50) called back to back: appends the accepted values (folded to [0,1], i.e. `valor` before the
+ * scaling into [lb,ub]) of attempts [attempt_base, attempt_base + nattempts) (2 words each) to v[vbase ...) (capacity vcap),
+ * vatt = their attempt indices, *vtotal += number accepted; counts: scratch, ceil(nattempts/1024) ints */
+int nla_k_esch_cauchy(const uint32_t *words, int64_t nattempts, int64_t attempt_base, int32_t *counts, int64_t *vtotal,
+                      int64_t vbase, int64_t vcap, double *v, int64_t *vatt, void *stream);
+/* replaces: the initial population loops (esch.c:133-164): element e = id*n + item of R := lb + (ub - lb) v[e - e0] */
+int nla_k_esch_fill_rows(int n, int ld, const double *lb, const double *ub, const double *v, int64_t e0, int64_t count, double *R, void *stream);
+/* replaces: crossover (esch.c:192-203): offspring id (individual np + id) from words 3 id .. 3 id + 2; slot[i] = row of individual i */
+int nla_k_esch_crossover(int n, int ld, int64_t np, int64_t no, const uint32_t *words, const int32_t *slot, double *R, void *stream);
+/* replaces: the point-mutation loop (esch.c:207-218), `total` steps from the M words W (see hip/esch_kernels.hip); last: no*n ints,
+ * scratch: nla_esch_mut_scratch_bytes(M); out (device, 2 x i64): steps the segment holds (< total: too short), words consumed */
+size_t nla_esch_mut_scratch_bytes(int64_t M);
+int nla_k_esch_mutate(const uint32_t *W, int64_t M, int64_t total, int n, int ld, int64_t np, int64_t no, const double *lb,
+                      const double *ub, const int32_t *slot, double *R, int32_t *last, void *scratch, int64_t *out, void *stream);
+/* G (count x ld) := rows of individuals i0 .. i0+count-1 */
+int nla_k_esch_gather_rows(int n, int ld, const int32_t *slot, int64_t i0, int64_t count, const double *R, double *G, void *stream);
+/* replaces: nlopt_qsort_r(estotal, ...) + the copy back (esch.c:243-251): stable sort of (slot, fit) by fit */
+size_t nla_esch_sort_scratch_bytes(int64_t count);
+int nla_k_esch_select(int64_t count, const int32_t *slot_in, const double *fit_in, int32_t *slot_out, double *fit_out,
+                      void *scratch, size_t scratch_bytes, void *stream);
+
 /* thin device-runtime layer the C host code uses (no HIP types cross the boundary) */
 int nla_dev_count(void);
 int nla_dev_set(int dev);

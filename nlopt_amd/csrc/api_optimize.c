@@ -118,6 +118,10 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
         if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
         return nla_isres_minimize(opt, (int) n, opt->f, opt->f_data, (int) opt->m, opt->fc, (int) opt->p, opt->h, opt->lb, opt->ub,
                                   x, minf, &stop, POP(opt, 0));
+    case NLOPT_GN_ESCH:                                                                  /* optimize.c:946-949 */
+        if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
+        return nla_esch_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, (unsigned) POP(opt, 0),
+                                 (unsigned) (POP(opt, 0) * 1.5));
     default:
         nla_set_errmsg(opt, "algorithm %s is not provided by libnlopt_amd (stochastic-global hot path only)",
                        nlopt_algorithm_to_string(opt->algorithm));

@@ -200,6 +200,10 @@ void nla_sobol_point01(unsigned sdim, const uint32_t *V, uint32_t index, double 
 nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
                                double *minf, nla_stopping *stop, nlopt_opt local_opt, int Nsamples, int lds);
 
+/* reference-shaped entry (src/algs/esch/esch.h) */
+nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+                               nla_stopping *stop, unsigned np, unsigned no);
+
 /* HIP engine (crs_engine.c) */
 typedef struct nla_crs_hip_engine nla_crs_hip_engine;
 nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj,
