@@ -3,8 +3,10 @@
  * (force_stop reset, maximisation by sign flip), nlopt_optimize_ :514-959 (n == 0 shortcut, RNG
  * seeding, bounds check, nlopt_stopping setup, switch on the algorithm) and
  * nlopt_optimize_limited :1087-1113.  Cases outside the stochastic-global hot path are not
- * provided and say so in errmsg.  The elimdim wrapper (:219-445) for lb[i]==ub[i] coordinates is
- * listed as "next" in SURVEY.md §8f and is not applied. */
+ * provided and say so in errmsg.  Coordinates with lb[i] == ub[i] are eliminated in front of CRS2_LM / ISRES / ESCH
+ * as the reference does (elimdim, :219-445,1038-1060): the algorithm runs on the reduced problem
+ * (its population default, stream consumption and results are those of the reduced dimension) through a wrapper
+ * objective — a host function, so such runs take the host-callback path even for a registered device objective. */
 #include "nla_internal.h"
 #include <math.h>
 #include <stdlib.h>
@@ -129,6 +131,109 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
     }
 }
 
+/* ---- elimination of fixed coordinates (reference: optimize.c:219-445) ------------------------------------------- */
+typedef struct {
+    nlopt_func f; nlopt_mfunc mf; void *f_data;
+    unsigned n;                 /* full dimension */
+    double *xfull;              /* scratch of length n, shared by the objective and the constraints of one run */
+    const double *lb, *ub;      /* the caller's bounds (length n) */
+} fixdim;
+
+static void fix_expand_into(const fixdim *d, const double *xr)
+{
+    unsigned i, j = 0;
+    for (i = 0; i < d->n; ++i) d->xfull[i] = d->lb[i] == d->ub[i] ? d->lb[i] : xr[j++];
+}
+static double fix_func(unsigned nr, const double *xr, double *grad, void *data)     /* elimdim_func; grad is never requested by CRS/ISRES/ESCH */
+{
+    const fixdim *d = (const fixdim *) data;
+    (void) nr; (void) grad;
+    fix_expand_into(d, xr);
+    return d->f(d->n, d->xfull, NULL, d->f_data);
+}
+static void fix_mfunc(unsigned m, double *result, unsigned nr, const double *xr, double *grad, void *data)   /* elimdim_mfunc */
+{
+    const fixdim *d = (const fixdim *) data;
+    (void) nr; (void) grad;
+    fix_expand_into(d, xr);
+    d->mf(m, result, d->n, d->xfull, NULL, d->f_data);
+}
+static unsigned fix_free_count(unsigned n, const double *lb, const double *ub)
+{
+    unsigned i, c = 0;
+    for (i = 0; i < n; ++i) c += lb[i] != ub[i];
+    return c;
+}
+static void fix_shrink(unsigned n, double *v, const double *lb, const double *ub)    /* elimdim_shrink */
+{
+    unsigned i, j = 0;
+    if (v) for (i = 0; i < n; ++i) if (lb[i] != ub[i]) v[j++] = v[i];
+}
+static void fix_expand(unsigned n, double *v, const double *lb, const double *ub)    /* elimdim_expand, in place from the back */
+{
+    unsigned i, j = fix_free_count(n, lb, ub);
+    if (!v) return;
+    for (i = n; i-- > 0;) v[i] = lb[i] != ub[i] ? v[--j] : lb[i];
+}
+static int fix_applies(const nlopt_opt opt)                                           /* elimdim_wrapcheck, restricted to what is provided */
+{
+    if (fix_free_count(opt->n, opt->lb, opt->ub) == opt->n) return 0;
+    return opt->algorithm == NLOPT_GN_CRS2_LM || opt->algorithm == NLOPT_GN_ISRES || opt->algorithm == NLOPT_GN_ESCH;
+}
+
+/* minimise on the reduced problem; x is shrunk on entry and expanded on return */
+static nlopt_result minimize_fixed_eliminated(nlopt_opt opt, double *x, double *minf)
+{
+    nlopt_munge save_copy = opt->munge_on_copy;
+    nlopt_opt r;
+    fixdim *dd;
+    double *xfull;
+    unsigned i, nd = 1 + opt->m + opt->p;
+    nlopt_result ret;
+    opt->munge_on_copy = NULL;                  /* an internal copy: leave f_data un-munged (optimize.c:332-335) */
+    r = nlopt_copy(opt);
+    opt->munge_on_copy = save_copy;
+    if (!r) { nla_set_errmsg(opt, "failure allocating elim_opt"); return NLOPT_OUT_OF_MEMORY; }
+    dd = (fixdim *) calloc(nd, sizeof *dd);
+    xfull = (double *) malloc(sizeof(double) * (opt->n ? opt->n : 1));
+    if (!dd || !xfull) { free(dd); free(xfull); nlopt_destroy(r); nla_set_errmsg(opt, "failure allocating elim_opt"); return NLOPT_OUT_OF_MEMORY; }
+    r->munge_on_destroy = r->munge_on_copy = NULL;
+    r->n = fix_free_count(opt->n, opt->lb, opt->ub);
+    fix_shrink(opt->n, r->lb, opt->lb, opt->ub);
+    fix_shrink(opt->n, r->ub, opt->lb, opt->ub);
+    fix_shrink(opt->n, r->xtol_abs, opt->lb, opt->ub);      /* (x_weights are NOT shrunk by the reference either, optimize.c:352-355) */
+    fix_shrink(opt->n, r->dx, opt->lb, opt->ub);
+    for (i = 0; i < nd; ++i) { dd[i].n = opt->n; dd[i].xfull = xfull; dd[i].lb = opt->lb; dd[i].ub = opt->ub; }
+    dd[0].f = opt->f; dd[0].f_data = opt->f_data;
+    r->f = fix_func; r->f_data = &dd[0];
+    for (i = 0; i < opt->m; ++i) {
+        fixdim *d = &dd[1 + i];
+        d->f = opt->fc[i].f; d->mf = opt->fc[i].mf; d->f_data = opt->fc[i].f_data;
+        r->fc[i].f = opt->fc[i].f ? fix_func : NULL; r->fc[i].mf = opt->fc[i].mf ? fix_mfunc : NULL; r->fc[i].f_data = d;
+    }
+    for (i = 0; i < opt->p; ++i) {
+        fixdim *d = &dd[1 + opt->m + i];
+        d->f = opt->h[i].f; d->mf = opt->h[i].mf; d->f_data = opt->h[i].f_data;
+        r->h[i].f = opt->h[i].f ? fix_func : NULL; r->h[i].mf = opt->h[i].mf ? fix_mfunc : NULL; r->h[i].f_data = d;
+    }
+    r->trace = opt->trace; r->trace_cap = opt->trace_cap; r->progress = opt->progress; r->progress_data = opt->progress_data;
+    fix_shrink(opt->n, x, opt->lb, opt->ub);
+    opt->force_stop_child = r;                  /* nlopt_force_stop(opt) reaches the running copy (optimize.c:1048) */
+    ret = minimize_dispatch(r, x, minf);
+    opt->force_stop_child = NULL;
+    opt->numevals = r->numevals;
+    opt->trace_len = r->trace_len;
+    opt->stats = r->stats;
+    free(opt->errmsg); opt->errmsg = r->errmsg; r->errmsg = NULL;
+    fix_expand(opt->n, x, opt->lb, opt->ub);
+    for (i = 0; i < opt->m; ++i) r->fc[i].f_data = NULL;      /* the copies' data are ours (dd), not user data to munge */
+    for (i = 0; i < opt->p; ++i) r->h[i].f_data = NULL;
+    r->f_data = NULL;
+    nlopt_destroy(r);
+    free(dd); free(xfull);
+    return ret;
+}
+
 nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
 {
     nlopt_func f; void *f_data; nlopt_precond pre;
@@ -147,7 +252,7 @@ nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
         opt->stopval = -opt->stopval;
         opt->maximize = 0;
     }
-    ret = minimize_dispatch(opt, x, opt_f);
+    ret = fix_applies(opt) ? minimize_fixed_eliminated(opt, x, opt_f) : minimize_dispatch(opt, x, opt_f);
     if (maximize) {
         opt->maximize = maximize;
         opt->stopval = -opt->stopval;

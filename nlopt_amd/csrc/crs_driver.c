@@ -124,6 +124,7 @@ typedef struct {
     double *minf;
     double *xtmp;
     int need_x;
+    int64_t xrow;         /* row whose content is the x of the last STRICT improvement of minf (crs.c:253-259), -1: rs->x holds it */
     nlopt_result ret;
 } run_state;
 
@@ -146,6 +147,7 @@ static int after_accept(run_state *rs, uint64_t block, int kind)
     nla_stopping *stop = pb->stop;
     const int64_t b = rs->os.best;
     nlopt_result ret = NLOPT_SUCCESS;
+    int have_x = 0;
     if (rs->F[b] < *rs->minf) {
         if (rs->F[b] < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
         else if (nla_stop_f(stop, rs->F[b], *rs->minf)) ret = NLOPT_FTOL_REACHED;
@@ -153,7 +155,9 @@ static int after_accept(run_state *rs, uint64_t block, int kind)
             if (rs->ops->read_slot(rs->e, block, kind, rs->xtmp)) return -1;
             if (nla_stop_x(stop, rs->xtmp, rs->x)) ret = NLOPT_XTOL_REACHED;
             memcpy(rs->x, rs->xtmp, sizeof(double) * (size_t) pb->n);
+            have_x = 1;
         }
+        rs->xrow = have_x ? -1 : b;             /* memcpy(x, best->k + 1) deferred: the row keeps this content while it is the best */
         *rs->minf = rs->F[b];
     }
     if (ret != NLOPT_SUCCESS) {                 /* quirk kept: crs.c:263-268 */
@@ -264,6 +268,7 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     S->init_words = 2ULL * (uint64_t) n * (uint64_t) (rows_done - 1);
     *minf = rs->F[rs->os.best];                               /* crs.c:246-248 */
     if (ops->read_row(e, rs->os.best, x)) { engine_failed(S); *ret_out = S->ret; return S; }
+    rs->xrow = -1;
     if (st) st->t_init_s = nla_seconds() - t0;
     S->ret = ret;
     *ret_out = ret;
@@ -363,6 +368,13 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 }
             }
             if (accepted) {
+                /* the reference's x is the point of the last strict improvement, not whatever row is best at the end (an
+                 * equal-f row with a smaller address can take over the tree's minimum without x being copied, crs.c:253):
+                 * if that row is about to be overwritten (only possible when the whole population has one f), save it now */
+                if (worst == rs->xrow) {
+                    if (ops->read_row(e, rs->xrow, rs->x)) { engine_failed(S); return S->ret; }
+                    rs->xrow = -1;
+                }
                 /* memcpy(worst->k, d->p) + resort (crs.c:153-154); the row write is deferred */
                 rs->F[worst] = fcand;
                 os_top_changed(&rs->os);
@@ -410,7 +422,7 @@ nlopt_result nla_crs_end(nla_crs_session *S, uint64_t *words_used)
     if (!S) return NLOPT_INVALID_ARGS;
     ret = S->ret;
     if (words_used) *words_used = S->init_words + 2ULL * (uint64_t) S->pb.n * S->block;
-    if (ret != NLOPT_FAILURE && S->rs.os.nheap > 0 && S->rs.ops->read_row(S->rs.e, S->rs.os.best, S->rs.x)) {
+    if (ret != NLOPT_FAILURE && S->rs.os.nheap > 0 && S->rs.xrow >= 0 && S->rs.ops->read_row(S->rs.e, S->rs.xrow, S->rs.x)) {
         engine_failed(S);
         ret = S->ret;
     }
