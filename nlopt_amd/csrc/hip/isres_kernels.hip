@@ -9,8 +9,10 @@
  * reference's offsets; the word stream is produced by mt_kernels.hip.
  *
  * Data layout in HBM: X and S (step sizes) are pop x ld fp64 row-major, ld = n rounded up to even;
- * F/PEN/GPEN/FEAS are pop-vectors.  Ranking works on 64-bit packed elements
- *   [0,20) individual | [20,40) dense rank of f | [40,60) dense rank of penalty | bit 60: penalty == 0
+ * F/PEN/GPEN/FEAS are pop-vectors.  Ranking works on 64-bit packed elements, laid out so that each of the two
+ * compares of a ranking step is one 32-bit compare after one shift / mask:
+ *   low word   [0,12) individual, low 12 bits | [12,32) dense rank of f
+ *   high word  [0,8) individual, high 8 bits  | [8,28) dense rank of penalty | bit 31: penalty == 0
  * (dense rank = number of strictly smaller values, so integer compares reproduce the reference's
  * fp64 compares including ties); populations up to 2^20.
  */
@@ -19,6 +21,12 @@
 
 #define ISRES_IDX_BITS 20
 #define ISRES_IDX_MASK 0xFFFFFu
+__host__ __device__ __forceinline__ uint64_t isres_pack(uint32_t idx, uint32_t rf, uint32_t rp, bool pzero)
+{
+    const uint32_t lo = (rf << 12) | (idx & 0xFFFu), hi = (pzero ? 0x80000000u : 0u) | (rp << 8) | (idx >> 12);
+    return ((uint64_t) hi << 32) | lo;
+}
+__host__ __device__ __forceinline__ uint32_t isres_unpack_idx(uint64_t e) { return ((uint32_t) e & 0xFFFu) | ((((uint32_t) (e >> 32)) & 0xFFu) << 12); }
 
 /* ------------------------------------------------------------------------------------------------
  * initial population (isres.c:122-128): xs[k][j] = urand(lb_j, ub_j) k-major from the stream,
@@ -121,8 +129,7 @@ __global__ __launch_bounds__(256) void isres_rank_count_kernel(int64_t pop, cons
         }
     }
     if (live) {
-        elems[k] = (uint64_t) k | ((uint64_t) rf << ISRES_IDX_BITS) | ((uint64_t) rp << (2 * ISRES_IDX_BITS)) |
-                   ((uint64_t) (pk == 0 ? 1 : 0) << (3 * ISRES_IDX_BITS));
+        elems[k] = isres_pack((uint32_t) k, rf, rp, pk == 0);
         sorted[ps] = (int32_t) k;
     }
 }
@@ -185,64 +192,71 @@ __global__ __launch_bounds__(64) void isres_stochrank_kernel(int64_t pop, int64_
     uint64_t *out = streams + (size_t) (unit + 1) * (size_t) pop;
     int *prog_in = progress + unit, *prog_out = progress + unit + 1;
     const uint64_t *brow = bits + (size_t) (active ? stage : 0) * (size_t) rowwords;
-    uint64_t carry = 0, outv = 0, inb = 0, outb = 0;
+    uint32_t c_lo = 0, c_hi = 0, o_lo = 0, o_hi = 0;         /* carry and output element of this stage, as two words */
+    uint64_t inb = 0, outb = 0;
     uint64_t cur0 = 0, cur1 = 0, nxt0 = 0, nxt1 = 0;
-    int64_t curw = 0;                       /* 64-bit word index (within the row) of cur0 */
-    int swapped = 0;
-    const int64_t t_first = 2 * lane;       /* tick of this stage's first input */
-    const int64_t nticks = pop + 128;
-    auto wordidx = [&](int64_t t) {         /* row word holding the step this lane handles at tick t */
-        int64_t j = t - t_first - 1;
+    int curw = 0;                           /* 64-bit word index (within the row) of cur0 */
+    uint32_t swapped = 0;
+    const int ipop = (int) pop;
+    const int t_first = 2 * lane;           /* tick of this stage's first input */
+    const int nticks = ipop + 128;
+    const bool lane0 = lane == 0;
+    auto wordidx = [&](int t) {             /* row word holding the step this lane handles at tick t */
+        int j = t - t_first - 1;
         if (j < 0) j = 0;
-        int64_t w = j >> 6;
-        if (w > rowwords - 1) w = rowwords - 1;
+        int w = j >> 6;
+        if (w > (int) rowwords - 1) w = (int) rowwords - 1;
         return w;
     };
-    if (active) { const int64_t w = wordidx(0); nxt0 = brow[w]; nxt1 = brow[w + 1 < rowwords ? w + 1 : w]; }
-    for (int64_t t = 0; t < nticks; ++t) {
+    if (active) { const int w = wordidx(0); nxt0 = brow[w]; nxt1 = brow[w + 1 < rowwords ? w + 1 : w]; }
+    for (int t = 0; t < nticks; ++t) {
         if ((t & 63) == 0) {
             /* bit window for ticks [t, t+64): loaded one period ago; prefetch the next one */
             cur0 = nxt0; cur1 = nxt1; curw = wordidx(t);
-            if (active) { const int64_t w = wordidx(t + 64); nxt0 = brow[w]; nxt1 = brow[w + 1 < rowwords ? w + 1 : w]; }
-            if (t < pop) {                  /* next 64 inputs of this unit */
-                const int need = (int) (t + 64 < pop ? t + 64 : pop);
+            if (active) { const int w = wordidx(t + 64); nxt0 = brow[w]; nxt1 = brow[w + 1 < rowwords ? w + 1 : w]; }
+            if (t < ipop) {                 /* next 64 inputs of this unit */
+                const int need = t + 64 < ipop ? t + 64 : ipop;
                 if (lane == 0) while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                inb = (t + lane < pop) ? in[t + lane] : 0;
+                inb = (t + lane < ipop) ? in[t + lane] : 0;
             }
         }
-        /* input of this tick: lane 0 from the unit's input stream, the others from their left neighbour */
-        const int sel = (int) (t & 63);
+        /* One tick, branch-free (the lanes of a wavefront are in different phases of their sweeps; every tick is on the
+         * serial path of the whole pipeline, so it is kept to straight-line 32-bit code).
+         * input: lane 0 from the unit's input stream, the others from their left neighbour's output */
+        const int sel = t & 63;
         const uint32_t in0lo = __builtin_amdgcn_readlane((uint32_t) inb, sel), in0hi = __builtin_amdgcn_readlane((uint32_t) (inb >> 32), sel);
-        uint32_t xlo = dpp_wave_shr1((uint32_t) outv), xhi = dpp_wave_shr1((uint32_t) (outv >> 32));
-        if (lane == 0) { xlo = in0lo; xhi = in0hi; }
-        const uint64_t x = ((uint64_t) xhi << 32) | xlo;
-        const int64_t rel = t - t_first;    /* 0: first input, 1..pop-1: compare steps, pop: flush */
-        if (rel == 0) carry = x;
-        else if (rel > 0 && rel < pop) {
-            const int64_t j = rel - 1;
-            const uint64_t bw = ((j >> 6) == curw) ? cur0 : cur1;
-            const bool ulow = (bw >> (j & 63)) & 1;
-            const uint32_t cf = (uint32_t) (carry >> ISRES_IDX_BITS) & ISRES_IDX_MASK, xf = (uint32_t) (x >> ISRES_IDX_BITS) & ISRES_IDX_MASK;
-            const uint32_t cp = (uint32_t) (carry >> (2 * ISRES_IDX_BITS)) & ISRES_IDX_MASK, xp = (uint32_t) (x >> (2 * ISRES_IDX_BITS)) & ISRES_IDX_MASK;
-            const bool bothzero = ((carry & x) >> (3 * ISRES_IDX_BITS)) & 1;
-            const bool byf = ulow || bothzero;                                   /* isres.c:211-212 */
-            const bool swap = active && (byf ? (cf > xf) : (cp > xp));           /* :213,:220 */
-            swapped |= swap;
-            outv = swap ? x : carry;
-            carry = swap ? carry : x;
-        } else if (rel == pop) outv = carry;
+        uint32_t x_lo = dpp_wave_shr1(o_lo), x_hi = dpp_wave_shr1(o_hi);
+        x_lo = lane0 ? in0lo : x_lo;
+        x_hi = lane0 ? in0hi : x_hi;
+        const int rel = t - t_first;        /* 0: first input, 1..pop-1: compare steps, pop: flush */
+        const bool is_first = rel == 0;
+        const bool is_cmp = (unsigned) (rel - 1) < (unsigned) (ipop - 1);
+        /* u < PF of this step (isres.c:210): bit j of the sweep's row */
+        const int j = rel - 1;
+        const uint64_t bw = ((j >> 6) != curw) ? cur1 : cur0;
+        const bool ulow = (bw >> (j & 63)) & 1;
+        const bool bothzero = (int32_t) (c_hi & x_hi) < 0;
+        const bool gtf = (c_lo >> 12) > (x_lo >> 12);                            /* fval[carry] > fval[x]   (isres.c:213) */
+        const bool gtp = (c_hi & 0x0FFFFF00u) > (x_hi & 0x0FFFFF00u);            /* penalty[carry] > penalty[x]  (:220) */
+        const bool swap = is_cmp && active && ((ulow || bothzero) ? gtf : gtp);  /* :211-212 */
+        swapped |= (uint32_t) swap;
+        const bool take = is_first || (is_cmp && !swap);                         /* the input becomes the carry */
+        o_lo = swap ? x_lo : c_lo;          /* emitted: the smaller of the pair, or (flush / idle) the carry */
+        o_hi = swap ? x_hi : c_hi;
+        c_lo = take ? x_lo : c_lo;
+        c_hi = take ? x_hi : c_hi;
         /* lane 63 emits output o = t - 127 of the unit's output stream */
-        const int64_t o = t - 127;
-        if (o >= 0 && o < pop) {
-            const uint32_t olo = __builtin_amdgcn_readlane((uint32_t) outv, 63), ohi = __builtin_amdgcn_readlane((uint32_t) (outv >> 32), 63);
-            if (lane == (int) (o & 63)) outb = ((uint64_t) ohi << 32) | olo;
-            if ((o & 63) == 63 || o == pop - 1) {
-                const int64_t base = o - (o & 63);
+        const int o = t - 127;
+        if (o >= 0 && o < ipop) {
+            const uint32_t olo = __builtin_amdgcn_readlane(o_lo, 63), ohi = __builtin_amdgcn_readlane(o_hi, 63);
+            if (lane == (o & 63)) outb = ((uint64_t) ohi << 32) | olo;
+            if ((o & 63) == 63 || o == ipop - 1) {
+                const int base = o - (o & 63);
                 if (base + lane <= o) out[base + lane] = outb;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(prog_out, (int) (o + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(prog_out, o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(64) void isres_stochrank_kernel(int64_t pop, int64_
 __global__ __launch_bounds__(256) void isres_unpack_kernel(int64_t pop, const uint64_t *__restrict__ stream, int32_t *__restrict__ irank)
 {
     const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (k < pop) irank[k] = (int32_t) (stream[k] & ISRES_IDX_MASK);
+    if (k < pop) irank[k] = (int32_t) isres_unpack_idx(stream[k]);
 }
 
 /* ------------------------------------------------------------------------------------------------
