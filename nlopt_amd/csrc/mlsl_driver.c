@@ -344,6 +344,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 if (nla_k_mlsl_dist2(n, D.ld, D.d_LX, (int) na, D.d_P, (int) D.npts, D.d_D, D.st) ||
                     nla_memcpy_d2h(D.h_D, D.d_D, sizeof(double) * na * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
             }
+            if (grow_lms(&D, D.nlms + (size_t) nb)) DEVFAIL();
             /* commit in walk order */
             for (c = 0; c < nb && ret == NLOPT_SUCCESS; ++c) {
                 const size_t r = D.ord[cand[c]];
@@ -387,9 +388,10 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 }
                 if (res[g].ret < 0) { ret = (nlopt_result) res[g].ret; goto done_noget; }
                 lf = res[g].f;
-                if (grow_lms(&D, D.nlms + 1)) DEVFAIL();
+                /* the minimum joins the device-side set; stream-ordered, no synchronisation per minimum (room for the whole
+                 * batch was made before the walk; res[] stays valid until the batch's closing synchronisation) */
                 if (nla_memcpy_d2d(D.d_LM + D.nlms * (size_t) D.ld, D.d_LX + g * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
-                    nla_memcpy_h2d(D.d_LF + D.nlms, &res[g].f, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
+                    nla_memcpy_h2d(D.d_LF + D.nlms, &res[g].f, sizeof(double), D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
                 D.LF[D.nlms] = lf;
                 ord_insert(D.lord, D.nlms, D.LF, D.nlms);
                 ++D.nlms;
@@ -403,6 +405,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                         if (D.F[k] > lf && !D.minimized[k] && dr[k] < D.cld[k]) D.cld[k] = dr[k];
                 }
             }
+            if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
             if (ret == NLOPT_SUCCESS && c == nb) {
                 /* nodes scanned after the last candidate of the batch (none qualified) are visited too */
                 remaining -= (int) (scan - idx);
