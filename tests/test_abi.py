@@ -1,0 +1,81 @@
+"""CPU: the drop-in boundary is a C-ABI shared library — libnlopt_amd.so loads without a GPU and exports every function that
+include/nlopt.h (the reference's public API, src/api/nlopt.h) and include/nlopt_amd.h (extension + kernel-level launchers)
+declare; enum values that are part of the reference's ABI are what the reference uses; without a HIP device the
+optimisers fail loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nlopt_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    """function names declared in a header: `NLOPT_EXTERN(type) name(` (nlopt.h) or `type name(` (nlopt_amd.h)"""
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"^\s*#[^\n]*(\\\n[^\n]*)*", " ", src, flags=re.M)
+    names = set(re.findall(r"NLOPT_EXTERN\([^)]*\)\s*(\w+)\s*\(", src))
+    src = re.sub(r"NLOPT_EXTERN\([^)]*\)", "int", src)
+    for stmt in src.split(";"):
+        stmt = " ".join(stmt.replace('extern "C" {', " ").split())
+        if not stmt or stmt.startswith("typedef") or "(" not in stmt or "{" in stmt or "}" in stmt:
+            continue
+        m = re.match(r"^(?:const\s+)?[A-Za-z_]\w*(?:\s+[A-Za-z_]\w*)*[\s\*]+(\w+)\s*\(", stmt)
+        if m:
+            names.add(m.group(1))
+    return names
+
+
+@pytest.mark.parametrize("header", ["nlopt.h", "nlopt_amd.h"])
+def test_every_declared_function_is_exported(header):
+    L = C.CDLL(nlopt_amd.LIB_PATH)
+    names = declared_functions(header)
+    assert len(names) > (60 if header == "nlopt.h" else 50), sorted(names)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, "declared in include/%s but not exported: %s" % (header, missing)
+
+
+def test_reference_abi_constants():
+    L = nlopt_amd.lib()
+    # nlopt_algorithm values of the hot path (src/api/nlopt.h:85-153) and result codes (:162-176)
+    for name, val in (("GN_CRS2_LM", 19), ("GN_MLSL", 20), ("GD_MLSL", 21), ("GN_MLSL_LDS", 22), ("GD_MLSL_LDS", 23), ("LD_LBFGS", 11),
+                      ("GN_ISRES", 35), ("G_MLSL", 38), ("G_MLSL_LDS", 39), ("GN_ESCH", 42)):
+        assert L.nlopt_algorithm_from_string(name.encode()) == val
+        assert L.nlopt_algorithm_to_string(val).decode() == name
+    for name, val in (("FAILURE", -1), ("INVALID_ARGS", -2), ("OUT_OF_MEMORY", -3), ("ROUNDOFF_LIMITED", -4), ("FORCED_STOP", -5),
+                      ("SUCCESS", 1), ("STOPVAL_REACHED", 2), ("FTOL_REACHED", 3), ("XTOL_REACHED", 4), ("MAXEVAL_REACHED", 5),
+                      ("MAXTIME_REACHED", 6)):
+        assert L.nlopt_result_from_string(name.encode()) == val
+    major, minor, bugfix = C.c_int(), C.c_int(), C.c_int()
+    L.nlopt_version(C.byref(major), C.byref(minor), C.byref(bugfix))
+    assert (major.value, minor.value) == (2, 11)
+
+
+@pytest.mark.skipif(nlopt_amd.device_count() > 0, reason="a HIP device is visible")
+@pytest.mark.parametrize("alg", [nlopt_amd.GN_CRS2_LM, nlopt_amd.GN_ISRES, nlopt_amd.GN_ESCH, nlopt_amd.LD_LBFGS, nlopt_amd.G_MLSL])
+def test_no_device_fails_loudly(alg):
+    o = nlopt_amd.Opt(alg, 4)
+    o.set_lower_bounds(-1.0)
+    o.set_upper_bounds(1.0)
+    o.set_min_objective(nlopt_amd.objective("sphere"))
+    if alg == nlopt_amd.G_MLSL:
+        loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, 4)
+        nlopt_amd.lib().nlopt_set_local_optimizer(o._h, loc._h)
+    o.set_maxeval(100)
+    x, minf, ret = o.optimize_raw(np.zeros(4))
+    assert ret == nlopt_amd.FAILURE and "no HIP device" in o.get_errmsg()
+
+
+def test_unprovided_algorithms_refuse_with_a_message():
+    o = nlopt_amd.Opt(0, 2)                    # NLOPT_GN_DIRECT
+    o.set_lower_bounds(-1.0)
+    o.set_upper_bounds(1.0)
+    o.set_min_objective(nlopt_amd.objective("sphere"))
+    x, minf, ret = o.optimize_raw(np.zeros(2))
+    assert ret == nlopt_amd.INVALID_ARGS and "not provided" in o.get_errmsg()
