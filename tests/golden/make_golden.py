@@ -1,4 +1,5 @@
-"""Generate tests/golden/crs_golden.json and isres_golden.json from the REAL reference (oracle/_ref/libnlopt_ref.so, built
+"""Generate tests/golden/crs_golden.json, isres_golden.json and rest_golden.json (LD_LBFGS, G_MLSL incl. Sobol sampling, GN_ESCH,
+the Sobol sequence) from the REAL reference (oracle/_ref/libnlopt_ref.so, built
 from /root/reference by oracle/Makefile).  Run in the build container only:
     python tests/golden/make_golden.py
 Each case records what a later run (port or HIP path) must reproduce: nlopt_result, numevals, minf
@@ -80,7 +81,63 @@ def main():
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+def record(r):
+    return dict(ret=int(r["ret"]), nevals=int(r["nevals"]), minf=float(r["minf"]).hex(), x=[float(v).hex() for v in r["x"]],
+                fseq_sha256=fhash(r["fseq"]), xhash_sha256=hashlib.sha256(r["xhash"].tobytes()).hexdigest(),
+                fseq_head=[float(v).hex() for v in r["fseq"][:8]], fseq_tail=[float(v).hex() for v in r["fseq"][-8:]])
+
+
+# the rest of the path: LD_LBFGS, G_MLSL (pseudo-random and Sobol sampling), GN_ESCH, and the Sobol sequence itself
+LBFGS_CASES = [
+    ("lbfgs_rosenbrock_n10", "rosenbrock", 10, dict(ftol_rel=1e-10, maxeval=2000)),
+    ("lbfgs_ackley_n64", "ackley", 64, dict(ftol_rel=1e-8, maxeval=500)),
+    ("lbfgs_rastrigin_n30_xtol", "rastrigin", 30, dict(xtol_rel=1e-8, maxeval=500)),
+    ("lbfgs_griewank_n200_mf5", "griewank", 200, dict(ftol_rel=1e-9, maxeval=400, mf=5)),
+]
+MLSL_CASES = [
+    ("mlsl_rastrigin_n4_ns10", "rastrigin", 4, 10, 42, 38, dict(maxeval=3000)),
+    ("mlsl_ackley_n6_ns25", "ackley", 6, 25, 7, 38, dict(maxeval=5000)),
+    ("mlsl_levy_n3_default", "levy", 3, 0, 11, 38, dict(maxeval=1500)),
+    ("mlsl_lds_rastrigin_n4_ns10_sobol", "rastrigin", 4, 10, 42, 39, dict(maxeval=3000)),
+    ("mlsl_lds_griewank_n30_ns50_sobol", "griewank", 30, 50, 1, 39, dict(maxeval=6000)),
+    ("mlsl_lds_ackley_n1200_pseudo", "ackley", 1200, 30, 4, 39, dict(maxeval=2600, local_ftol_rel=1e-6)),   # n > 1111: no Sobol generator
+]
+ESCH_CASES = [
+    ("esch_rastrigin_n6_default", "rastrigin", 6, 0, 42, dict(maxeval=3000)),
+    ("esch_griewank_n10_pop50", "griewank", 10, 50, 7, dict(maxeval=4000)),
+    ("esch_sphere_n1_pop5", "sphere", 1, 5, 5, dict(maxeval=400)),
+    ("esch_rosenbrock_n30_pop200", "rosenbrock", 30, 200, 11, dict(maxeval=6000)),
+    ("esch_levy_n8_stopval", "levy", 8, 30, 1, dict(stopval=0.5, maxeval=20000)),
+]
+SOBOL_CASES = [(1, 0, 64), (2, 0, 64), (7, 110, 32), (40, 1000, 16), (1111, 11114, 4)]
+
+
+def main_rest():
+    out = dict(lbfgs={}, mlsl={}, esch={}, sobol={})
+    for name, obj, n, kw in LBFGS_CASES:
+        r = O.run_ref_lbfgs(obj, n, **kw)
+        out["lbfgs"][name] = dict(obj=obj, n=n, kwargs=kw, **record(r))
+        print(name, r["ret"], r["nevals"], r["minf"])
+    for name, obj, n, ns, seed, alg, kw in MLSL_CASES:
+        r = O.run_ref_mlsl(obj, n, ns, seed, alg=alg, **kw)
+        out["mlsl"][name] = dict(obj=obj, n=n, ns=ns, seed=seed, alg=alg, kwargs=kw, **record(r))
+        print(name, r["ret"], r["nevals"], r["minf"])
+    for name, obj, n, pop, seed, kw in ESCH_CASES:
+        r = O.run_ref_esch(obj, n, pop, seed, **kw)
+        out["esch"][name] = dict(obj=obj, n=n, pop=pop, seed=seed, kwargs=kw, **record(r))
+        print(name, r["ret"], r["nevals"], r["minf"])
+    for sdim, skip_n, count in SOBOL_CASES:
+        pts = O.ref_sobol_points(sdim, skip_n, count)
+        out["sobol"]["sdim%d_skip%d" % (sdim, skip_n)] = dict(sdim=sdim, skip_n=skip_n, count=count, sha256=fhash(pts),
+                                                                first=[float(v).hex() for v in pts[0][:8]],
+                                                                last=[float(v).hex() for v in pts[-1][:8]])
+    with open(os.path.join(HERE, "rest_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
+    if "rest" in sys.argv[1:] or len(sys.argv) == 1:
+        main_rest()
     if "isres" in sys.argv[1:] or len(sys.argv) == 1:
         main_isres()
     if "crs" in sys.argv[1:] or len(sys.argv) == 1:

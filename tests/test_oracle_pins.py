@@ -240,3 +240,41 @@ def test_port_esch_matches_reference_live(obj, n, pop, seed, kw):
     assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
     assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
     assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
+
+
+# ---- committed golden vectors for the rest of the path (generated from the real reference by tests/golden/make_golden.py):
+# these pin the oracle where oracle/_ref is absent ---------------------------------------------------------------------
+RGOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rest_golden.json")))
+
+
+def _check(r, g):
+    assert (r["ret"], r["nevals"]) == (g["ret"], g["nevals"])
+    assert float(r["minf"]).hex() == g["minf"] and [float(v).hex() for v in r["x"]] == g["x"]
+    assert hashlib.sha256(np.ascontiguousarray(r["fseq"], dtype=np.float64).tobytes()).hexdigest() == g["fseq_sha256"]
+    assert hashlib.sha256(r["xhash"].tobytes()).hexdigest() == g["xhash_sha256"]
+
+
+@pytest.mark.parametrize("name", sorted(RGOLD["lbfgs"]))
+def test_port_lbfgs_matches_golden(name):
+    g = RGOLD["lbfgs"][name]
+    _check(O.run_port_lbfgs(g["obj"], g["n"], **g["kwargs"]), g)
+
+
+@pytest.mark.parametrize("name", sorted(RGOLD["mlsl"]))
+def test_port_mlsl_matches_golden(name):
+    g = RGOLD["mlsl"][name]
+    _check(O.run_port_mlsl(g["obj"], g["n"], g["ns"], g["seed"], lds=(g["alg"] == 39), **g["kwargs"]), g)
+
+
+@pytest.mark.parametrize("name", sorted(RGOLD["esch"]))
+def test_port_esch_matches_golden(name):
+    g = RGOLD["esch"][name]
+    _check(O.run_port_esch(g["obj"], g["n"], g["pop"], g["seed"], **g["kwargs"]), g)
+
+
+@pytest.mark.parametrize("name", sorted(RGOLD["sobol"]))
+def test_port_sobol_matches_golden(name):
+    g = RGOLD["sobol"][name]
+    pts = O.port_sobol_points(g["sdim"], g["skip_n"], g["count"])
+    assert hashlib.sha256(np.ascontiguousarray(pts, dtype=np.float64).tobytes()).hexdigest() == g["sha256"]
+    assert [float(v).hex() for v in pts[0][:8]] == g["first"] and [float(v).hex() for v in pts[-1][:8]] == g["last"]
