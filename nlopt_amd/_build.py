@@ -38,25 +38,26 @@ def _headers():
 
 
 def build(force=False, verbose=False):
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ, exist_ok=True)
     hdrs = _headers()
-    objs = []
-    relink = force
+    objs, jobs = [], []
     for rel in HIP_SRC + C_SRC:
         src = os.path.join(CSRC, rel)
         obj = os.path.join(OBJ, os.path.basename(rel).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _newer(src, obj, hdrs):
-            cmd = ([HIPCC] + HIP_FLAGS if rel.endswith(".hip") else ["gcc"] + C_FLAGS) + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
-            relink = True
-    if relink or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lm", "-ldl"]
+            jobs.append(([HIPCC] + HIP_FLAGS if rel.endswith(".hip") else ["gcc"] + C_FLAGS) + ["-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
+    if jobs:                                     # translation units are independent: compile them side by side
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lm", "-ldl"])
     return LIB
 
 
