@@ -31,6 +31,20 @@ def test_testopt_crs_identical_printout(obj, seed, maxeval):
 
 
 @need
+@pytest.mark.parametrize("alg", [19, 35, 42])
+def test_testopt_fixed_dimension(alg):
+    """-b 1: the driver equates the bounds of dimension 1 — the library eliminates it (optimize.c:1038-1060) and runs in one dimension less"""
+    a = run(AMD, "-r", 5, "-a", alg, "-o", 5, "-e", 800, "-b", 1)
+    r = run(REF, "-r", 5, "-a", alg, "-o", 5, "-e", 800, "-b", 1)
+    if alg == 19:
+        assert a == r
+    else:
+        cnt = lambda lines: [re.search(r"after (\d+) evaluations \(numevals = (\d+)\)", l).groups() for l in lines if "evaluations (numevals" in l]
+        assert cnt(a) == cnt(r) and len(cnt(a)) == 1
+        assert [l for l in a if l.startswith("return code")] == [l for l in r if l.startswith("return code")]
+
+
+@need
 @pytest.mark.parametrize("alg", [35, 42])
 @pytest.mark.parametrize("obj,seed", [(0, 0), (5, 4), (17, 9)])
 def test_testopt_isres_esch_same_result(alg, obj, seed):
