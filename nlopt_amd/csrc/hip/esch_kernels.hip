@@ -141,20 +141,30 @@ __device__ __forceinline__ int64_t esch_step(const uint32_t *__restrict__ W, int
     }
 }
 
+/* nx[p/2] = esch_step(p) for every even word position p of the segment (all step starts are even: steps have even length):
+ * the functional graph of the chain, computed once in parallel — the walks below then cost one look-up per step instead of
+ * the step's loads and tan() */
+__global__ __launch_bounds__(256) void esch_mut_next_kernel(const uint32_t *__restrict__ W, int64_t M, int32_t *__restrict__ nx)
+{
+    const int64_t h = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (h >= M / 2 + 8) return;                               /* the table has 8 entries of slack past the segment: no step starts there */
+    double v;
+    nx[h] = 2 * h < M ? (int32_t) esch_step(W, M, 2 * h, v) : -1;
+}
+
 /* for block b and entry offset o (a chain entering the block at word b*BLOCK + o): exit offset into the next block
  * and the number of steps that START inside this block */
-__global__ __launch_bounds__(ESCH_ENTRIES) void esch_mut_scan_kernel(const uint32_t *__restrict__ W, int64_t M, int32_t *__restrict__ exit_off,
+__global__ __launch_bounds__(ESCH_ENTRIES) void esch_mut_scan_kernel(const int32_t *__restrict__ nx, int64_t M, int32_t *__restrict__ exit_off,
                                                                      int32_t *__restrict__ nsteps)
 {
     const int64_t b = blockIdx.x, end = (b + 1) * ESCH_BLOCK;
     int64_t p = b * ESCH_BLOCK + threadIdx.x;
     int steps = 0;
-    bool cut = false;
-    double v;
-    while (p < end) {
-        const int64_t nx = esch_step(W, M, p, v);
-        if (nx < 0) { cut = true; break; }                    /* incomplete step: the segment is too short from here on */
-        p = nx; ++steps;
+    bool cut = (threadIdx.x & 1) || p >= M;                    /* odd offsets are never entered */
+    while (!cut && p < end) {
+        const int64_t q = p < M ? nx[p >> 1] : -1;
+        if (q < 0) { cut = true; break; }                     /* incomplete step: the segment is too short from here on */
+        p = q; ++steps;
     }
     const int64_t eo = p - end;
     exit_off[b * ESCH_ENTRIES + threadIdx.x] = (cut || eo >= ESCH_ENTRIES) ? -1 : (int32_t) eo;
@@ -163,39 +173,55 @@ __global__ __launch_bounds__(ESCH_ENTRIES) void esch_mut_scan_kernel(const uint3
 
 /* chain the blocks: entry[b] = offset at which the chain enters block b (-1: not reached / not needed), first[b] = index of
  * the first step that starts in block b; out[0] = steps found (>= total when the segment was long enough), out[1] = word
- * position after step number `total` (filled by the mark kernel) */
-__global__ void esch_mut_chain_kernel(int64_t nblocks, int64_t total, const int32_t *__restrict__ exit_off, const int32_t *__restrict__ nsteps,
-                                      int32_t *__restrict__ entry, int64_t *__restrict__ first, int64_t *__restrict__ out)
+ * position after step number `total` (filled by the mark kernel).  One workgroup: the per-block tables are brought into LDS
+ * a tile of blocks at a time (coalesced), one thread then walks the tile — a look-up per block out of LDS instead of two
+ * dependent global loads. */
+#define ESCH_CHAIN_TILE 128
+__global__ __launch_bounds__(256) void esch_mut_chain_kernel(int64_t nblocks, int64_t total, const int32_t *__restrict__ exit_off,
+                                                             const int32_t *__restrict__ nsteps, int32_t *__restrict__ entry,
+                                                             int64_t *__restrict__ first, int64_t *__restrict__ out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int64_t steps = 0;
-    int32_t o = 0;
-    int64_t b = 0;
-    for (; b < nblocks; ++b) {
-        entry[b] = o; first[b] = steps;
-        if (steps >= total) { entry[b] = -1; continue; }
-        const int32_t e = exit_off[b * ESCH_ENTRIES + o];
-        steps += nsteps[b * ESCH_ENTRIES + o];
-        if (e < 0) { ++b; break; }
-        o = e;
+    __shared__ int32_t s_exit[ESCH_CHAIN_TILE * ESCH_ENTRIES], s_steps[ESCH_CHAIN_TILE * ESCH_ENTRIES];
+    __shared__ long long s_state[3];                           /* steps so far, entry offset, chain broken */
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_state[0] = 0; s_state[1] = 0; s_state[2] = 0; }
+    for (int64_t b0 = 0; b0 < nblocks; b0 += ESCH_CHAIN_TILE) {
+        const int nb = (int) (nblocks - b0 < ESCH_CHAIN_TILE ? nblocks - b0 : ESCH_CHAIN_TILE);
+        __syncthreads();
+        for (int q = tid; q < nb * ESCH_ENTRIES; q += 256) { s_exit[q] = exit_off[b0 * ESCH_ENTRIES + q]; s_steps[q] = nsteps[b0 * ESCH_ENTRIES + q]; }
+        __syncthreads();
+        if (tid == 0) {
+            long long steps = s_state[0];
+            int o = (int) s_state[1];
+            bool broken = s_state[2] != 0;
+            for (int i = 0; i < nb; ++i) {
+                const int64_t b = b0 + i;
+                first[b] = steps;
+                if (broken || steps >= total) { entry[b] = -1; continue; }
+                entry[b] = o;
+                const int32_t e = s_exit[i * ESCH_ENTRIES + o];
+                steps += s_steps[i * ESCH_ENTRIES + o];
+                if (e < 0) broken = true; else o = e;
+            }
+            s_state[0] = steps; s_state[1] = o; s_state[2] = broken;
+        }
     }
-    for (; b < nblocks; ++b) { entry[b] = -1; first[b] = steps; }
-    out[0] = steps;
+    __syncthreads();
+    if (tid == 0) out[0] = s_state[0];
 }
 
 /* replay block b from its true entry: step c (global index) mutates element (io, ip); last[io*n + ip] = max(c + 1).
  * The step with index total - 1 also records where the chain stands afterwards. */
-__global__ __launch_bounds__(64) void esch_mut_mark_kernel(const uint32_t *__restrict__ W, int64_t M, int64_t total, int n, int64_t no,
-                                                           const int32_t *__restrict__ entry, const int64_t *__restrict__ first,
+__global__ __launch_bounds__(64) void esch_mut_mark_kernel(const uint32_t *__restrict__ W, const int32_t *__restrict__ nxt, int64_t M, int64_t total, int n,
+                                                           int64_t no, const int32_t *__restrict__ entry, const int64_t *__restrict__ first,
                                                            int32_t *__restrict__ last, int64_t *__restrict__ out)
 {
     if (threadIdx.x != 0) return;
     const int64_t b = blockIdx.x, end = (b + 1) * ESCH_BLOCK;
     if (entry[b] < 0) return;
     int64_t p = b * ESCH_BLOCK + entry[b], c = first[b];
-    double v;
     while (p < end && c < total) {
-        const int64_t nx = esch_step(W, M, p, v);
+        const int64_t nx = p < M ? nxt[p >> 1] : -1;
         if (nx < 0) break;
         const int64_t io = (int64_t) (W[p] % (uint32_t) no);
         const int ip = (int) (W[p + 1] % (uint32_t) n);
@@ -206,8 +232,9 @@ __global__ __launch_bounds__(64) void esch_mut_mark_kernel(const uint32_t *__res
     }
 }
 
-__global__ __launch_bounds__(64) void esch_mut_apply_kernel(const uint32_t *__restrict__ W, int64_t M, int64_t total, int n, int ld, int64_t np,
-                                                            int64_t no, const int32_t *__restrict__ entry, const int64_t *__restrict__ first,
+__global__ __launch_bounds__(64) void esch_mut_apply_kernel(const uint32_t *__restrict__ W, const int32_t *__restrict__ nxt, int64_t M, int64_t total, int n,
+                                                            int ld, int64_t np, int64_t no, const int32_t *__restrict__ entry,
+                                                            const int64_t *__restrict__ first,
                                                             const int32_t *__restrict__ last, const double *__restrict__ lb,
                                                             const double *__restrict__ ub, const int32_t *__restrict__ slot,
                                                             double *__restrict__ R)
@@ -217,13 +244,15 @@ __global__ __launch_bounds__(64) void esch_mut_apply_kernel(const uint32_t *__re
     if (entry[b] < 0) return;
     int64_t p = b * ESCH_BLOCK + entry[b], c = first[b];
     while (p < end && c < total) {
-        double v = 0;
-        const int64_t nx = esch_step(W, M, p, v);
+        const int64_t nx = p < M ? nxt[p >> 1] : -1;
         if (nx < 0) break;
         const int64_t io = (int64_t) (W[p] % (uint32_t) no);
         const int ip = (int) (W[p + 1] % (uint32_t) n);
-        if (last[io * n + ip] == (int32_t) (c + 1))          /* the serial loop's last write to this element */
+        if (last[io * n + ip] == (int32_t) (c + 1)) {        /* the serial loop's last write to this element */
+            double v = 0;
+            (void) esch_attempt(W[nx - 2], W[nx - 1], v);    /* the step's accepted attempt is the one that ends it */
             R[(size_t) slot[np + io] * ld + ip] = lb[ip] + (ub[ip] - lb[ip]) * v;
+        }
         p = nx;
         ++c;
     }
@@ -294,7 +323,7 @@ extern "C" int nla_k_esch_crossover(int n, int ld, int64_t np, int64_t no, const
 extern "C" size_t nla_esch_mut_scratch_bytes(int64_t M)
 {
     const size_t nb = (size_t) ((M + ESCH_BLOCK - 1) / ESCH_BLOCK) + 1;
-    return nb * ESCH_ENTRIES * 4 * 2 + nb * 4 + nb * 8 + 256;
+    return nb * ESCH_ENTRIES * 4 * 2 + nb * 4 + nb * 8 + ((size_t) M / 2 + 8) * 4 + 512;
 }
 
 /* the (no n)/10 point mutations of one generation from the M stream words W; last: no*n ints of scratch (zeroed here);
@@ -310,13 +339,16 @@ extern "C" int nla_k_esch_mutate(const uint32_t *W, int64_t M, int64_t total, in
     int32_t *exit_off = (int32_t *) p; p += (size_t) nb * ESCH_ENTRIES * 4;
     int32_t *nsteps = (int32_t *) p; p += (size_t) nb * ESCH_ENTRIES * 4;
     int32_t *entry = (int32_t *) p; p += (((size_t) nb * 4 + 7) & ~(size_t) 7);
-    int64_t *first = (int64_t *) p;
+    int64_t *first = (int64_t *) p; p += (size_t) nb * 8;
+    int32_t *nx = (int32_t *) p;
+    if (M >= (1LL << 31)) return (int) hipErrorInvalidValue;
     (void) hipMemsetAsync(last, 0, sizeof(int32_t) * (size_t) no * (size_t) n, st);
     (void) hipMemsetAsync(out, 0, 2 * sizeof(int64_t), st);
-    hipLaunchKernelGGL(esch_mut_scan_kernel, dim3((unsigned) nb), dim3(ESCH_ENTRIES), 0, st, W, M, exit_off, nsteps);
-    hipLaunchKernelGGL(esch_mut_chain_kernel, dim3(1), dim3(64), 0, st, nb, total, exit_off, nsteps, entry, first, out);
-    hipLaunchKernelGGL(esch_mut_mark_kernel, dim3((unsigned) nb), dim3(64), 0, st, W, M, total, n, no, entry, first, last, out);
-    hipLaunchKernelGGL(esch_mut_apply_kernel, dim3((unsigned) nb), dim3(64), 0, st, W, M, total, n, ld, np, no, entry, first, last, lb, ub, slot, R);
+    hipLaunchKernelGGL(esch_mut_next_kernel, dim3((unsigned) ((M / 2 + 8 + 255) / 256)), dim3(256), 0, st, W, M, nx);
+    hipLaunchKernelGGL(esch_mut_scan_kernel, dim3((unsigned) nb), dim3(ESCH_ENTRIES), 0, st, nx, M, exit_off, nsteps);
+    hipLaunchKernelGGL(esch_mut_chain_kernel, dim3(1), dim3(256), 0, st, nb, total, exit_off, nsteps, entry, first, out);
+    hipLaunchKernelGGL(esch_mut_mark_kernel, dim3((unsigned) nb), dim3(64), 0, st, W, nx, M, total, n, no, entry, first, last, out);
+    hipLaunchKernelGGL(esch_mut_apply_kernel, dim3((unsigned) nb), dim3(64), 0, st, W, nx, M, total, n, ld, np, no, entry, first, last, lb, ub, slot, R);
     NLA_LAUNCH_CHECK();
     return 0;
 }
