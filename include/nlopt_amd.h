@@ -184,6 +184,22 @@ int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const 
                      const double *lb, const double *ub, double *fT_ring, double *fM_ring,
                      nla_crs_slot_status *status, void *stream);
 
+/* nla_k_crs_advance / nla_k_crs_finish / nla_k_crs_commit with their small per-pass lists (W, t_in, the commit list; at most 96
+ * entries each) given as HOST arrays: the lists travel as kernel arguments, so a pass needs no host-to-device copy in front of it
+ * (one dependent stream operation less).  Everything else as in the pointer forms. */
+int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                           const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                           uint64_t first_block, int K, const int64_t *h_W, int nW,
+                           const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                           double *TX, int variant, void *stream);
+int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                          const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                          const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
+                          const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                          nla_crs_slot_status *status, void *stream);
+int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
+                          const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *stream);
+
 /* replaces: memcpy(worst->k, d->p, ...) at crs.c:153 for a batch of accepted candidates.
  * X[row[c]] := (kind[c] == 1 ? TX : TM)[slot[c]];  rows must be distinct within one call. */
 int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,

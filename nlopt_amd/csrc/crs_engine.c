@@ -20,6 +20,7 @@
 
 #define INIT_CHUNK_WORDS (1ULL << 28)      /* 1 GiB of stream words per init pass */
 #define KCAP 1024                          /* slot ring (power of two) */
+#define NLA_KARG_MAX 96                    /* list length that still travels as kernel arguments (hip/crs_kernels.hip NLA_KA_MAX) */
 #define ROWPAD 64                          /* spare rows behind X / F: the init all-gather wants equal blocks per rank (world <= 64) */
 
 typedef struct {
@@ -297,6 +298,21 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         const uint64_t b = first_block + (uint64_t) a;
         t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
     }
+    if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !getenv("NLA_CRS_UPLOAD")) {
+        /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
+         * front of the pass */
+        if (e->npending) {
+            CK(e, nla_k_crs_commit_args(n, e->ld, e->d_X, e->d_TX, e->d_TM, e->npending, e->pend_slot, e->pend_kind, e->pend_row, e->main));
+            e->npending = 0;
+        }
+        CK(e, nla_event_record(e->ev0, e->main));
+        CK(e, nla_k_crs_advance_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
+                                     t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
+        CK(e, nla_event_record(e->ev1, e->main));
+        CK(e, nla_k_crs_finish_args(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
+                                    t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
+        goto launched;
+    }
     if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin)) return -1;
     CK(e, nla_event_record(e->ev0, e->main));
     CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
@@ -304,6 +320,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     CK(e, nla_event_record(e->ev1, e->main));
     CK(e, nla_k_crs_finish(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                            d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
+launched:
     CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * (size_t) K, e->main));
     CK(e, nla_stream_sync(e->main));
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);

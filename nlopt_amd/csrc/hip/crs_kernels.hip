@@ -145,13 +145,19 @@ __device__ __forceinline__ void nla_lds_barrier() { asm volatile("s_waitcnt lgkm
 
 #define NLA_ADV_RCAP 8192               /* picks staged in LDS per segment (32 KB) */
 
+/* The small per-pass lists can travel as KERNEL ARGUMENTS instead of through a host-to-device copy in front of the pass
+ * (one dependent stream operation and its gap less per pass): inl != 0 -> use these, else the device pointers. */
+#define NLA_KA_MAX 96
+struct crs_lists { int inl; int32_t t_in[NLA_KA_MAX]; int64_t W[NLA_KA_MAX]; };
+struct crs_commits { int inl; int32_t slot[NLA_KA_MAX], kind[NLA_KA_MAX]; int64_t row[NLA_KA_MAX]; };
+
 template <int VEC, int U, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     int n, int ld, const double *__restrict__ X, int64_t i0, const int32_t *__restrict__ jn_ring,
     const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, uint32_t ring_blocks,
     uint64_t first_block, int K, const int64_t *__restrict__ W, int nW,
     const int32_t *__restrict__ t_in, int32_t *__restrict__ t_out, int slot_mask, int chunks,
-    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX)
+    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX, const crs_lists L)
 {
     typedef typename VecT<VEC>::T V;
     static_assert(U <= 64, "one lane per row of a batch");
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     const int q = (int) (block & (uint64_t) slot_mask);
     const int32_t *p = pos_ring + (size_t) rb * (size_t) n;
     const int jn = jn_ring[rb];
-    const int t0 = t_in[a];
+    const int t0 = L.inl ? L.t_in[a] : t_in[a];
     /* last pick: i += iurand(Nleft); i += i == i0  (crs.c:109) */
     const int64_t rbase = p[n - 1];
     int64_t al = rbase + (rbase >= i0 ? 1 : 0) + (int64_t) last_ring[rb];
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
         int e = n;
         const int nun = a < nW ? a : nW;
         for (int j = lane; j < nun; j += 64) {
-            const int64_t r = W[j];
+            const int64_t r = L.inl ? L.W[j] : W[j];
             if (r == i0) continue;          /* the best row is never sampled */
             int lo = 0, hi = cnt0 - 1;      /* binary search among the staged picks */
             bool found = false;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
     const uint32_t *__restrict__ words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
     const int32_t *__restrict__ t_in, const int32_t *__restrict__ t_out, int slot_mask,
     const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ fT_ring,
-    double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status)
+    double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status, const crs_lists L)
 {
     __shared__ double scratch[2 * NLA_FIN_WAVES];
     const int tid = threadIdx.x;
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
     const uint64_t block = first_block + (uint64_t) a;
     const int q = (int) (block & (uint64_t) slot_mask);
     const int t1 = t_out[a];
-    const bool was_done = t_in[a] == n;
+    const bool was_done = (L.inl ? L.t_in[a] : t_in[a]) == n;
     const bool newly = (t1 == n) && !was_done;          /* uniform over the workgroup */
     const double *x = TX + (size_t) q * (size_t) ld;
     if (task == 0) {
@@ -354,11 +360,13 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
 /* write accepted candidates back into the population (crs.c:153) */
 __global__ __launch_bounds__(256) void crs_commit_kernel(int n, int ld, double *__restrict__ X, const double *__restrict__ TX,
                                                           const double *__restrict__ TM, const int32_t *__restrict__ slot,
-                                                          const int32_t *__restrict__ kind, const int64_t *__restrict__ row)
+                                                          const int32_t *__restrict__ kind, const int64_t *__restrict__ row, const crs_commits C)
 {
     const int c = blockIdx.x;
-    const double *src = (kind[c] == 1 ? TX : TM) + (size_t) slot[c] * (size_t) ld;
-    double *dst = X + (size_t) row[c] * (size_t) ld;
+    const int kc = C.inl ? C.kind[c] : kind[c], sc = C.inl ? C.slot[c] : slot[c];
+    const int64_t rc = C.inl ? C.row[c] : row[c];
+    const double *src = (kc == 1 ? TX : TM) + (size_t) sc * (size_t) ld;
+    double *dst = X + (size_t) rc * (size_t) ld;
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
@@ -419,8 +427,25 @@ extern "C" int nla_k_crs_commit(int n, int ld, double *X, const double *TX, cons
                                 const int32_t *slot, const int32_t *kind, const int64_t *row, void *stream)
 {
     if (ncommit <= 0) return 0;
+    crs_commits C;
+    C.inl = 0;
     hipLaunchKernelGGL(crs_commit_kernel, dim3((unsigned) ncommit), dim3(256), 0, (hipStream_t) stream,
-                       n, ld, X, TX, TM, slot, kind, row);
+                       n, ld, X, TX, TM, slot, kind, row, C);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+/* the same with the commit list given as HOST arrays (ncommit <= 96): it travels as kernel arguments, no copy to the device */
+extern "C" int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
+                                     const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *stream)
+{
+    if (ncommit <= 0) return 0;
+    if (ncommit > NLA_KA_MAX) return (int) hipErrorInvalidValue;
+    crs_commits C;
+    C.inl = 1;
+    for (int c = 0; c < ncommit; ++c) { C.slot[c] = h_slot[c]; C.kind[c] = h_kind[c]; C.row[c] = h_row[c]; }
+    hipLaunchKernelGGL(crs_commit_kernel, dim3((unsigned) ncommit), dim3(256), 0, (hipStream_t) stream,
+                       n, ld, X, TX, TM, nullptr, nullptr, nullptr, C);
     NLA_LAUNCH_CHECK();
     return 0;
 }
@@ -435,11 +460,42 @@ extern "C" int nla_k_crs_mutate(int n, const double *best, double *p, const uint
 }
 
 /* variant: 0 = automatic; otherwise WAVES*100 + U (tuning / microbenchmarks) */
+static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                              const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                              uint64_t first_block, int K, const int64_t *W, int nW,
+                              const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                              double *TX, int variant, const crs_lists &L, void *stream);
 extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                                  const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                                  uint64_t first_block, int K, const int64_t *W, int nW,
                                  const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
                                  double *TX, int variant, void *stream)
+{
+    crs_lists L;
+    L.inl = 0;
+    return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, lb, ub,
+                              TX, variant, L, stream);
+}
+/* the same with W (nW <= 96) and t_in (K <= 96) given as HOST arrays: they travel as kernel arguments */
+extern "C" int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                                      const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                                      uint64_t first_block, int K, const int64_t *h_W, int nW,
+                                      const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                                      double *TX, int variant, void *stream)
+{
+    if (K > NLA_KA_MAX || nW > NLA_KA_MAX) return (int) hipErrorInvalidValue;
+    crs_lists L;
+    L.inl = 1;
+    for (int a = 0; a < K; ++a) L.t_in[a] = h_t_in[a];
+    for (int j = 0; j < nW; ++j) L.W[j] = h_W[j];
+    return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, nullptr, nW, nullptr, t_out, slot_mask,
+                              lb, ub, TX, variant, L, stream);
+}
+static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                              const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                              uint64_t first_block, int K, const int64_t *W, int nW,
+                              const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                              double *TX, int variant, const crs_lists &L, void *stream)
 {
     if (K <= 0) return 0;
     hipStream_t st = (hipStream_t) stream;
@@ -452,7 +508,7 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
     const int chunks = (n + cpw - 1) / cpw;
     const dim3 grid((unsigned) ((long) chunks * K));
 #define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, n, ld, X, i0, jn_ring, \
-        pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX)
+        pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX, L)
     if (vec2) {
         switch (variant) {
         case 116: ADV(2, 16, 1); break;
@@ -483,21 +539,51 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
     return 0;
 }
 
+static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                             const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                             const int32_t *t_in, const int32_t *t_out, int slot_mask,
+                             const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                             nla_crs_slot_status *status, const crs_lists &L, void *stream);
 extern "C" int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
                                 const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                                 const int32_t *t_in, const int32_t *t_out, int slot_mask,
                                 const double *lb, const double *ub, double *fT_ring, double *fM_ring,
                                 nla_crs_slot_status *status, void *stream)
 {
+    crs_lists L;
+    L.inl = 0;
+    return crs_finish_launch(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring,
+                             status, L, stream);
+}
+/* the same with t_in (K <= 96) given as a HOST array */
+extern "C" int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                                     const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                                     const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
+                                     const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                                     nla_crs_slot_status *status, void *stream)
+{
+    if (K > NLA_KA_MAX) return (int) hipErrorInvalidValue;
+    crs_lists L;
+    L.inl = 1;
+    for (int a = 0; a < K; ++a) L.t_in[a] = h_t_in[a];
+    return crs_finish_launch(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, nullptr, t_out, slot_mask, lb, ub, fT_ring,
+                             fM_ring, status, L, stream);
+}
+static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                             const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                             const int32_t *t_in, const int32_t *t_out, int slot_mask,
+                             const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                             nla_crs_slot_status *status, const crs_lists &L, void *stream)
+{
     if (K <= 0) return 0;
     const dim3 grid((unsigned) (2 * K)), block(NLA_FIN_WAVES * 64);
     hipStream_t st = (hipStream_t) stream;
     if (obj < 0) {
         hipLaunchKernelGGL((crs_finish_kernel<-1>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
-                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status);
+                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L);
     } else {
 #define CALL(O) hipLaunchKernelGGL((crs_finish_kernel<O>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks, \
-                                   first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status)
+                                   first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L)
         NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     }
