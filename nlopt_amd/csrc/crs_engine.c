@@ -53,6 +53,7 @@ struct nla_crs_hip_engine {
     int32_t pend_slot[KCAP], pend_kind[KCAP];
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
+    int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
     nlopt_amd_stats *stats;
     nlopt_amd_comm *comm;          /* multi-GPU: initial rows are generated in rank blocks and all-gathered; NULL = single process */
     char err[256];
@@ -158,6 +159,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * KCAP);
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
+    e->direct_status = !getenv("NLA_CRS_COPY_STATUS");
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1) goto fail;
     if (nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
@@ -310,7 +312,14 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
                                      t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         CK(e, nla_event_record(e->ev1, e->main));
         CK(e, nla_k_crs_finish_args(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
-                                    t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
+                                    t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM,
+                                    e->direct_status ? e->h_status : e->d_status, e->main));
+        if (e->direct_status) {
+            /* the finish kernel wrote the K records straight into the pinned host buffer (visible at kernel completion):
+             * no copy-back operation behind it either */
+            CK(e, nla_stream_sync(e->main));
+            goto have_status;
+        }
         goto launched;
     }
     if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin)) return -1;
@@ -323,6 +332,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
 launched:
     CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * (size_t) K, e->main));
     CK(e, nla_stream_sync(e->main));
+have_status:
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
     for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = status[a].t;
     if (e->stats) {
