@@ -288,6 +288,20 @@ int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *l
                       double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
                       void *stream);
 
+/* ---- LD_MMA without nonlinear constraints (src/algs/mma/mma.c), batched --------------------------- */
+/* stopping values as nlopt_stopping holds them (nlopt-util.h:79-91) + the algorithm's parameters as the dispatcher reads
+ * them (optimize.c:798-803: rho_init 1, sigma_min 0, inner_maxeval 0, inner_gradients 1, always_improve 1) */
+typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, rho_init, sigma_min;
+                 int32_t maxeval, inner_maxeval, inner_gradients, always_improve; } nla_mma_params;
+size_t nla_mma_work_doubles(int ld, int count);               /* doubles of `work` */
+
+/* replaces: mma_minimize (mma.c:146-449) with m = 0 for `count` independent starts at once, one workgroup per start, outer
+ * and inner iterations on the device (the 0-dimensional dual "solve" is dual_func's closed form, mma.c:58-137).  X: count x
+ * ld, starts in, minimisers out; sigma_init: the initial step (n, device) or NULL (mma.c:203-211); out[i] = (f,
+ * nlopt_result, evaluations counted by the algorithm, iterm = objective calls made, cols = outer iterations). */
+int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const double *ub, const double *sigma_init, double *X,
+                    double *work, const nla_mma_params *params, nla_lbfgs_result *out, void *stream);
+
 /* ---- MLSL (src/algs/mlsl/mlsl.c) ------------------------------------------------------------------- */
 /* replaces: nlopt_sobol_next (sobolseq.c:236-242) for `count` consecutive points: row r of P (count x ld) := point number
  * index_first + r (1-based call count of the reference's generator) scaled to [lb, ub]; V = 32 x n direction numbers as

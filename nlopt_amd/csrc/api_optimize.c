@@ -84,6 +84,8 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
     case NLOPT_LD_LBFGS:                                                                 /* optimize.c:716-718 */
         return nla_lbfgs_minimize((int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, (int) opt->vector_storage,
                                   nlopt_get_param(opt, "tolg", 0.));
+    case NLOPT_LD_MMA:                                                                   /* optimize.c:795-834 */
+        return nla_mma_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop);
     case NLOPT_G_MLSL: case NLOPT_G_MLSL_LDS: case NLOPT_GN_MLSL: case NLOPT_GD_MLSL:
     case NLOPT_GN_MLSL_LDS: case NLOPT_GD_MLSL_LDS: {                                    /* optimize.c:748-793 */
         nlopt_opt local_opt = opt->local_opt;

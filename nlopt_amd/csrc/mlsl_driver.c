@@ -21,7 +21,7 @@
  *       are ALL-GATHERED (SURVEY.md §8e "all-gather of local minima"), after which every rank commits
  *       the whole batch in walk order.  world x BATCH_MAX searches are in flight per batch.
  *
- * Provided: local optimiser NLOPT_LD_LBFGS with a device objective; pseudo-random sampling (the non-LDS
+ * Provided: local optimisers NLOPT_LD_LBFGS and NLOPT_LD_MMA (the GD_MLSL default) with a device objective; pseudo-random sampling (the non-LDS
  * variants, and the LDS variants for n > 1111 where the reference's Sobol generator is NULL — sobolseq.c:143
  * — and mlsl.c:355-359 falls back to nlopt_urand) and Sobol sampling (LDS variants, n <= 1111; points by
  * index, sobol.c; no MT words are drawn in that mode).
@@ -56,9 +56,10 @@ typedef struct {
     nlopt_amd_comm *comm; int world, rank;
     int32_t *d_min;
     uint32_t *d_words;
+    double *d_dx;                         /* LD_MMA local optimiser: the initial step on the device, or NULL */
     uint32_t *d_V; uint32_t sobol_next;   /* LDS mode: direction table on the device, index of the next point (1-based) */
     size_t dcap;                    /* doubles in d_D */
-    nla_lbfgs_ctx *lb;
+    nla_local_ctx *lb;
     double *h_D;                    /* pinned: batch x npts distances */
     size_t hcap;
     char err[200];
@@ -71,11 +72,11 @@ static void mfree(mlsl_dev *d)
 {
     if (d->st) nla_stream_sync(d->st);
     if (d->mts) { nla_mtstream_finish(d->mts, d->words_used); nla_mtstream_destroy(d->mts); }
-    nla_lbfgs_ctx_destroy(d->lb);
+    nla_local_ctx_destroy(d->lb);
     free(d->F); free(d->cpd); free(d->cld); free(d->minimized); free(d->ord); free(d->LF); free(d->lord);
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd);
     nla_dev_free(d->d_LM); nla_dev_free(d->d_LF); nla_dev_free(d->d_D); nla_dev_free(d->d_tmp); nla_dev_free(d->d_min);
-    nla_dev_free(d->d_words); nla_dev_free(d->d_LX); nla_dev_free(d->d_V);
+    nla_dev_free(d->d_words); nla_dev_free(d->d_LX); nla_dev_free(d->d_V); nla_dev_free(d->d_dx);
     nla_host_free(d->h_D);
     if (d->st) nla_stream_destroy(d->st);
 }
@@ -162,21 +163,28 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     double R_prefactor, *Fnew = NULL, *rowbuf = NULL, best_f = HUGE_VAL;
     const double dlm = 1.0, dbound = 1e-6;
     const double *lbh = lb, *ubh = ub;
-    int i, j, mf, best_is_lm = 0, loc_maxeval;
+    int i, j, mf, best_is_lm = 0, loc_maxeval, use_mma = 0;
+    nla_mma_params mma;
     size_t best_row = 0;
     (void) f_data;
 
     memset(&D, 0, sizeof D);
     D.N = Nsamples ? Nsamples : 4;                                             /* mlsl.c:283-286 */
     if (D.N < 1) { nla_stop_msg(stop, "population %d is too small", D.N); return NLOPT_INVALID_ARGS; }
+    if (!local_opt || (local_opt->algorithm != NLOPT_LD_LBFGS && local_opt->algorithm != NLOPT_LD_MMA)) {
+        nla_stop_msg(stop, "nlopt_amd: MLSL is provided with NLOPT_LD_LBFGS or NLOPT_LD_MMA as the local optimizer only (not %s)",
+                     local_opt ? nlopt_algorithm_name(local_opt->algorithm) : "none");
+        return NLOPT_INVALID_ARGS;
+    }
+    use_mma = local_opt->algorithm == NLOPT_LD_MMA;
+    if (local_opt->xtol_abs || (use_mma && local_opt->x_weights)) { nla_stop_msg(stop, "nlopt_amd: the local optimizer on the device does not take xtol_abs / x_weights"); return NLOPT_INVALID_ARGS; }
+    if (use_mma && (i = nla_mma_read_params(local_opt, &mma))) {
+        nla_stop_msg(stop, "%s", local_opt->errmsg ? local_opt->errmsg : "invalid LD_MMA parameter");
+        return (nlopt_result) i;
+    }
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
     D.obj = nlopt_amd_objective_id(f);
     if (D.obj < 0) { nla_stop_msg(stop, "nlopt_amd: MLSL is provided for device objectives (nlopt_amd_objective) only"); return NLOPT_INVALID_ARGS; }
-    if (!local_opt || local_opt->algorithm != NLOPT_LD_LBFGS) {
-        nla_stop_msg(stop, "nlopt_amd: MLSL is provided with NLOPT_LD_LBFGS as the local optimizer only");
-        return NLOPT_INVALID_ARGS;
-    }
-    if (local_opt->xtol_abs) { nla_stop_msg(stop, "nlopt_amd: LD_LBFGS on the device does not take xtol_abs"); return NLOPT_INVALID_ARGS; }
     D.n = n; D.ld = (n + 1) & ~1;
     D.comm = opt ? opt->comm : NULL;
     D.world = nlopt_amd_comm_world(D.comm); D.rank = nlopt_amd_comm_rank(D.comm);
@@ -221,9 +229,18 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         }                                                                      /* else: NULL generator -> nlopt_urand, as the reference */
         free(V);
     }
-    D.lb = nla_lbfgs_ctx_create(D.obj, n, BATCH_MAX, mf, D.d_lb, D.d_ub, D.st);
-    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (L-BFGS batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
-    nla_lbfgs_ctx_set_stats(D.lb, st);
+    if (use_mma && local_opt->dx) {                                            /* the initial step = MMA's sigma_init, optimize.c:829 */
+        D.d_dx = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
+        if (!D.d_dx || nla_memcpy_h2d(D.d_dx, local_opt->dx, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) {
+            nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
+            mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
+            return NLOPT_OUT_OF_MEMORY;
+        }
+    }
+    D.lb = use_mma ? nla_local_ctx_create_mma(D.obj, n, BATCH_MAX, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
+                   : nla_local_ctx_create(D.obj, n, BATCH_MAX, mf, D.d_lb, D.d_ub, D.st);
+    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
+    nla_local_ctx_set_stats(D.lb, st);
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
 #define STOPS(fv) do { if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP; else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED; \
@@ -315,7 +332,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             per = (nb + D.world - 1) / D.world;
 #define GI(c) ((size_t) ((c) % D.world) * (size_t) per + (size_t) ((c) / D.world))
             for (c = D.rank; c < nb; c += D.world, ++mine)
-                if (nla_memcpy_d2d(nla_lbfgs_ctx_X(D.lb) + (size_t) mine * D.ld, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+                if (nla_memcpy_d2d(nla_local_ctx_X(D.lb) + (size_t) mine * D.ld, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
             /* the bound test needs the start coordinates on the host (every rank: all candidates) */
             if (!rowbuf) rowbuf = (double *) malloc(sizeof(double) * (size_t) n * (size_t) bmax);
             if (!rowbuf) { snprintf(D.err, sizeof D.err, "out of memory"); DEVFAIL(); }
@@ -327,8 +344,8 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             eff = loc_maxeval;
             if (loc_maxeval <= 0 || (limited > 0 && limited < loc_maxeval)) eff = (int) limited;
             prm.maxeval = eff;
-            if (mine > 0 && nla_lbfgs_ctx_run(D.lb, mine, &prm, res_mine)) { snprintf(D.err, sizeof D.err, "L-BFGS batch failed"); DEVFAIL(); }
-            if (nla_comm_allgather_dev(D.comm, nla_lbfgs_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st) ||
+            if (mine > 0 && nla_local_ctx_run(D.lb, mine, &prm, res_mine)) { snprintf(D.err, sizeof D.err, "local-search batch failed"); DEVFAIL(); }
+            if (nla_comm_allgather_dev(D.comm, nla_local_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st) ||
                 nla_comm_allgather_host(D.comm, res_mine, res, sizeof *res * (size_t) per, D.st)) {
                 snprintf(D.err, sizeof D.err, "all-gather of the local minima failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL();
             }
@@ -351,6 +368,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 const double *xr = rowbuf + (size_t) c * n;
                 int pot = !(D.cld[r] <= (dlm * R) * (dlm * R));               /* may have changed since the batch was formed */
                 double lf;
+                int calls;
                 const size_t g = GI(c);
                 size_t k;
                 /* nodes between the previous candidate and this one were visited and skipped */
@@ -372,18 +390,19 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                     nla_lbfgs_params p1 = prm;
                     nla_lbfgs_result r1;
                     p1.maxeval = eff;
-                    if (nla_memcpy_d2d(nla_lbfgs_ctx_X(D.lb), D.d_P + r * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
-                        nla_lbfgs_ctx_run(D.lb, 1, &p1, &r1) ||
-                        nla_memcpy_d2d(D.d_LX + g * (size_t) D.ld, nla_lbfgs_ctx_X(D.lb), sizeof(double) * (size_t) n, D.st) ||
+                    if (nla_memcpy_d2d(nla_local_ctx_X(D.lb), D.d_P + r * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
+                        nla_local_ctx_run(D.lb, 1, &p1, &r1) ||
+                        nla_memcpy_d2d(D.d_LX + g * (size_t) D.ld, nla_local_ctx_X(D.lb), sizeof(double) * (size_t) n, D.st) ||
                         nla_k_mlsl_dist2(n, D.ld, D.d_LX + g * (size_t) D.ld, 1, D.d_P, (int) D.npts, D.d_D, D.st) ||
-                        nla_memcpy_d2h(D.h_D + g * D.npts, D.d_D, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "L-BFGS rerun failed"); DEVFAIL(); }
+                        nla_memcpy_d2h(D.h_D + g * D.npts, D.d_D, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "local-search rerun failed"); DEVFAIL(); }
                     res[g] = r1;
                 }
-                *stop->nevals_p += res[g].nevals;                               /* fcount, mlsl.c:246-251 */
-                if (st) { st->evals_mutation += (uint64_t) res[g].nevals; ++st->accepted; }
+                calls = use_mma ? res[g].iterm : res[g].nevals;                /* objective calls the search made (MMA: iterm) */
+                *stop->nevals_p += calls;                                       /* fcount, mlsl.c:246-251 */
+                if (st) { st->evals_mutation += (uint64_t) calls; ++st->accepted; }
                 D.minimized[r] = 1;
                 if (opt && opt->trace) {
-                    if (opt->trace_len < opt->trace_cap) { nlopt_amd_trace_rec *tr = opt->trace + opt->trace_len; tr->f = res[g].f; tr->row = (int64_t) r; tr->kind = 4; tr->accepted = res[g].nevals; }
+                    if (opt->trace_len < opt->trace_cap) { nlopt_amd_trace_rec *tr = opt->trace + opt->trace_len; tr->f = res[g].f; tr->row = (int64_t) r; tr->kind = 4; tr->accepted = calls; }
                     ++opt->trace_len;
                 }
                 if (res[g].ret < 0) { ret = (nlopt_result) res[g].ret; goto done_noget; }

@@ -180,14 +180,24 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
 
 /* LD_LBFGS (lbfgs_driver.c) */
 int nla_lbfgs_default_mf(int n, int mf, int maxeval);
-typedef struct nla_lbfgs_ctx nla_lbfgs_ctx;
-nla_lbfgs_ctx *nla_lbfgs_ctx_create(int obj, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream);
-void nla_lbfgs_ctx_destroy(nla_lbfgs_ctx *c);
-double *nla_lbfgs_ctx_X(nla_lbfgs_ctx *c);
-void nla_lbfgs_ctx_set_stats(nla_lbfgs_ctx *c, nlopt_amd_stats *stats);
-int nla_lbfgs_ctx_run(nla_lbfgs_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res);
+typedef struct nla_local_ctx nla_local_ctx;
+nla_local_ctx *nla_local_ctx_create(int obj, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream);
+nla_local_ctx *nla_local_ctx_create_mma(int obj, int n, int cap, const nla_mma_params *alg_params, const double *d_sigma_init,
+                                        const double *d_lb, const double *d_ub, void *stream);
+int nla_local_ctx_alg(const nla_local_ctx *c);
+void nla_local_ctx_destroy(nla_local_ctx *c);
+double *nla_local_ctx_X(nla_local_ctx *c);
+void nla_local_ctx_set_stats(nla_local_ctx *c, nlopt_amd_stats *stats);
+int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res);
 int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
                         const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen);
+int nla_local_run_batch(int alg, int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
+                        const nla_mma_params *mma, const double *sigma_init, const nla_lbfgs_params *prm, nla_lbfgs_result *res,
+                        char *err, size_t errlen);
+/* LD_MMA without nonlinear constraints (mma_driver.c) */
+int nla_mma_read_params(nlopt_opt opt, nla_mma_params *out);     /* optimize.c:798-815; 0 or an nlopt_result < 0 with errmsg set */
+nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
+                              double *minf, nla_stopping *stop);
 nlopt_result nla_lbfgs_minimize(int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                                 nla_stopping *stop, int mf, double tolg);
 

@@ -1,7 +1,7 @@
 /* port_mlsl.c — CPU ORACLE (test infrastructure): Multi-Level Single-Linkage global optimisation
  * (src/algs/mlsl/mlsl.c:251-438) with the pseudo-random sampler (lds = 0; the reference's LDS mode
- * silently is pseudo-random too for n > 1111) and NLOPT_LD_LBFGS as the local
- * optimiser (port_lbfgs.c), called the way nlopt_optimize_limited would call it
+ * silently is pseudo-random too for n > 1111) and NLOPT_LD_LBFGS (port_lbfgs.c) or
+ * NLOPT_LD_MMA (port_mma.c, the GD_MLSL default) as the local optimiser, called the way nlopt_optimize_limited would call it
  * (src/api/optimize.c:1087-1113, :514-566, :716-718).
  *
  * Containers: the reference keeps points and local minima in red-black trees ordered by f
@@ -134,7 +134,8 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
                 if (loc->maxeval <= 0 || (limited > 0 && limited < loc->maxeval)) ls.maxeval = limited;
                 ls.nevals = 0;
                 lf = HUGE_VAL;
-                lret = orc_lbfgs_minimize(n, fcount, &cnt, lb, ub, lx, &lf, &ls, loc->mf, loc->tolg);
+                lret = loc->alg == 1 ? orc_mma_minimize(n, fcount, &cnt, lb, ub, lx, &lf, &ls, &loc->mma)
+                                     : orc_lbfgs_minimize(n, fcount, &cnt, lb, ub, lx, &lf, &ls, loc->mf, loc->tolg);
                 p->minimized = 1;
                 if (trace && trace->nloc < trace->cap) { trace->floc[trace->nloc] = lf; trace->eloc[trace->nloc] = (int) ls.nevals; }
                 if (trace) ++trace->nloc;

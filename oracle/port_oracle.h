@@ -77,8 +77,14 @@ int orc_isres_minimize(int n, orc_func f, void *f_data, int m, const orc_constra
 int orc_lbfgs_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                        orc_stop *stop, int mf, double tolg);
 
-/* ---- MLSL (src/algs/mlsl/mlsl.c) with LD_LBFGS as the local optimiser ------------------------- */
-typedef struct { double ftol_rel, ftol_abs, xtol_rel, tolg; long maxeval; int mf; } orc_local_params;
+/* ---- LD_MMA without nonlinear constraints (src/algs/mma/mma.c) -------------------------------- */
+typedef struct { double rho_init, sigma_min; int inner_maxeval, inner_gradients, always_improve, pad;
+                 const double *sigma_init; /* the initial step (opt->dx), or NULL */ } orc_mma_params;
+int orc_mma_minimize(int n, orc_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+                     orc_stop *stop, const orc_mma_params *prm);
+
+/* ---- MLSL (src/algs/mlsl/mlsl.c) with LD_LBFGS (alg 0) or LD_MMA (alg 1) as the local optimiser - */
+typedef struct { double ftol_rel, ftol_abs, xtol_rel, tolg; long maxeval; int mf; int alg; orc_mma_params mma; } orc_local_params;
 typedef struct { double *fsamp, *floc; int *eloc; size_t cap, nsamp, nloc; long iterations; } orc_mlsl_trace;
 /* Sobol LDS (port_sobol.c; sobolseq.c:109-264) */
 typedef struct orc_sobol_s orc_sobol;

@@ -374,10 +374,72 @@ def run_ref_lbfgs(obj, n, x0=None, mf=0, lb=None, ub=None, **kw):
     return run_ref(11, obj, n, 0, 0, x0=x0, setup=setup, **kw)
 
 
-# ---- MLSL + LD_LBFGS ----------------------------------------------------------------------------
+# ---- LD_MMA (no nonlinear constraints) -----------------------------------------------------------
+class OrcMma(C.Structure):
+    _fields_ = [("rho_init", C.c_double), ("sigma_min", C.c_double), ("inner_maxeval", C.c_int), ("inner_gradients", C.c_int),
+                ("always_improve", C.c_int), ("pad", C.c_int), ("sigma_init", C.c_void_p)]
+
+
+MMA_PARAM_NAMES = ("rho_init", "sigma_min", "inner_maxeval", "inner_gradients", "always_improve")
+
+
+def mma_params(p=None):
+    """the dispatcher's defaults (optimize.c:798-803) overridden by p"""
+    d = dict(rho_init=1.0, sigma_min=0.0, inner_maxeval=0, inner_gradients=1, always_improve=1)
+    d.update(p or {})
+    return OrcMma(d["rho_init"], d["sigma_min"], d["inner_maxeval"], d["inner_gradients"], d["always_improve"], 0, None)
+
+
+def run_port_mma(obj, n, x0=None, maxeval=0, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0, stopval=None, lb=None, ub=None, params=None,
+                 step=None):
+    L = port()
+    L.orc_mma_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(OrcStop), C.POINTER(OrcMma)]
+    xs, lo, hi = golden_x0(obj, n)
+    x = np.array(xs if x0 is None else x0, dtype=np.float64)
+    lbv = np.full(n, lo) if lb is None else np.array(lb, dtype=np.float64)
+    ubv = np.full(n, hi) if ub is None else np.array(ub, dtype=np.float64)
+    st = OrcStop()
+    L.orc_stop_default(C.byref(st), n)
+    st.maxeval = maxeval
+    st.ftol_rel, st.ftol_abs, st.xtol_rel = ftol_rel, ftol_abs, xtol_rel
+    if stopval is not None:
+        st.minf_max = stopval
+    f = L.orc_objective(OBJ[obj])
+    cap = (maxeval or 200000) + 16
+    fbuf = np.zeros(cap)
+    hbuf = np.zeros(cap, dtype=np.uint64)
+    rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
+    minf = C.c_double()
+    prm = mma_params(params)
+    dx = None if step is None else np.full(n, float(step))
+    if dx is not None:
+        prm.sigma_init = dx.ctypes.data
+    ret = L.orc_mma_minimize(n, C.cast(L.orc_recording_callback, C.c_void_p).value, C.cast(C.pointer(rec), C.c_void_p),
+                             dptr(lbv), dptr(ubv), dptr(x), C.byref(minf), C.byref(st), C.byref(prm))
+    return dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, fseq=fbuf[:rec.len].copy(), xhash=hbuf[:rec.len].copy())
+
+
+def run_ref_mma(obj, n, x0=None, lb=None, ub=None, params=None, step=None, **kw):
+    """the REAL reference's NLOPT_LD_MMA (24)"""
+    def setup(R, opt):
+        R.nlopt_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        R.nlopt_set_initial_step1.argtypes = [C.c_void_p, C.c_double]
+        if step is not None:
+            assert R.nlopt_set_initial_step1(opt, float(step)) > 0
+        for k, v in (params or {}).items():
+            assert R.nlopt_set_param(opt, k.encode(), float(v)) > 0
+        if lb is not None:
+            R.nlopt_set_lower_bounds(opt, dptr(np.array(lb, dtype=np.float64)))
+        if ub is not None:
+            R.nlopt_set_upper_bounds(opt, dptr(np.array(ub, dtype=np.float64)))
+    return run_ref(24, obj, n, 0, 0, x0=x0, setup=setup, **kw)
+
+
+# ---- MLSL + LD_LBFGS / LD_MMA ---------------------------------------------------------------------
 class OrcLocal(C.Structure):
     _fields_ = [("ftol_rel", C.c_double), ("ftol_abs", C.c_double), ("xtol_rel", C.c_double), ("tolg", C.c_double),
-                ("maxeval", C.c_long), ("mf", C.c_int)]
+                ("maxeval", C.c_long), ("mf", C.c_int), ("alg", C.c_int), ("mma", OrcMma)]
 
 
 class MlslTrace(C.Structure):
@@ -386,7 +448,7 @@ class MlslTrace(C.Structure):
 
 
 def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0,
-                  local_maxeval=0, mf=0, x0=None, record=True, lds=False):
+                  local_maxeval=0, mf=0, x0=None, record=True, lds=False, local="lbfgs", local_params=None):
     L = port()
     L.orc_mlsl_set_lds(int(lds))
     L.orc_mlsl_minimize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -400,7 +462,7 @@ def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_re
     st.maxeval = maxeval
     if stopval is not None:
         st.minf_max = stopval
-    loc = OrcLocal(local_ftol_rel, local_ftol_abs, local_xtol_rel, 0.0, local_maxeval, mf)
+    loc = OrcLocal(local_ftol_rel, local_ftol_abs, local_xtol_rel, 0.0, local_maxeval, mf, 1 if local == "mma" else 0, mma_params(local_params))
     f = L.orc_objective(OBJ[obj])
     cap = (maxeval or 400000) + 4096
     fbuf = np.zeros(cap)
@@ -467,11 +529,18 @@ def ref_sobol_points(sdim, skip_n, count, lb=None, ub=None):
     return out
 
 
-def run_ref_mlsl(obj, n, nsamples, seed, alg=38, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0, local_maxeval=0, mf=0, **kw):
-    """the REAL reference's G_MLSL (38) with an LD_LBFGS (11) local optimiser"""
+def run_ref_mlsl(obj, n, nsamples, seed, alg=38, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0, local_maxeval=0, mf=0,
+                 local="lbfgs", local_params=None, **kw):
+    """the REAL reference's G_MLSL (38) with an LD_LBFGS (11) or LD_MMA (24) local optimiser; local=None: no local optimiser is
+    set and the tolerances go on the global object, from which the dispatcher builds its default (optimize.c:763-777)"""
     def setup(R, opt):
         R.nlopt_set_vector_storage.argtypes = [C.c_void_p, C.c_uint]
-        loc = R.nlopt_create(11, n)
+        R.nlopt_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        if local is None:
+            return
+        loc = R.nlopt_create(24 if local == "mma" else 11, n)
+        for k, v in (local_params or {}).items():
+            assert R.nlopt_set_param(loc, k.encode(), float(v)) > 0
         if local_ftol_rel:
             R.nlopt_set_ftol_rel(loc, local_ftol_rel)
         if local_ftol_abs:

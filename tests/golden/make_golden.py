@@ -1,4 +1,4 @@
-"""Generate tests/golden/crs_golden.json, isres_golden.json and rest_golden.json (LD_LBFGS, G_MLSL incl. Sobol sampling, GN_ESCH,
+"""Generate tests/golden/crs_golden.json, isres_golden.json and rest_golden.json (LD_LBFGS, LD_MMA, G_MLSL / GD_MLSL incl. Sobol sampling, GN_ESCH,
 the Sobol sequence) from the REAL reference (oracle/_ref/libnlopt_ref.so, built
 from /root/reference by oracle/Makefile).  Run in the build container only:
     python tests/golden/make_golden.py
@@ -109,11 +109,33 @@ ESCH_CASES = [
     ("esch_rosenbrock_n30_pop200", "rosenbrock", 30, 200, 11, dict(maxeval=6000)),
     ("esch_levy_n8_stopval", "levy", 8, 30, 1, dict(stopval=0.5, maxeval=20000)),
 ]
+MMA_CASES = [     # NLOPT_LD_MMA without nonlinear constraints (the GD_MLSL default local optimiser)
+    ("mma_rosenbrock_n10", "rosenbrock", 10, dict(maxeval=500)),
+    ("mma_ackley_n64", "ackley", 64, dict(ftol_rel=1e-8)),
+    ("mma_griewank_n12_xtol", "griewank", 12, dict(xtol_rel=1e-6)),
+    ("mma_rastrigin_n16_nograd", "rastrigin", 16, dict(ftol_rel=1e-9, params=dict(inner_gradients=0))),
+    ("mma_levy_n7_original_rule", "levy", 7, dict(ftol_abs=1e-12, params=dict(always_improve=0, rho_init=0.1))),
+    ("mma_rastrigin_n12_step", "rastrigin", 12, dict(ftol_rel=1e-9, step=0.3)),
+]
+MLSL_MMA_CASES = [   # (name, obj, n, ns, seed, alg, local, kw): local None = the dispatcher's default local optimiser
+    ("gd_mlsl_default_rastrigin_n6", "rastrigin", 6, 20, 11, 21, None, dict(maxeval=3000, ftol_rel=1e-7)),
+    ("gd_mlsl_lds_default_ackley_n10", "ackley", 10, 0, 11, 23, None, dict(maxeval=3000, ftol_rel=1e-7)),
+    ("g_mlsl_mma_griewank_n8", "griewank", 8, 0, 7, 38, "mma", dict(maxeval=2500)),
+    ("g_mlsl_mma_nograd_rastrigin_n5", "rastrigin", 5, 12, 5, 38, "mma", dict(maxeval=1500, local_params=dict(inner_gradients=0))),
+]
 SOBOL_CASES = [(1, 0, 64), (2, 0, 64), (7, 110, 32), (40, 1000, 16), (1111, 11114, 4)]
 
 
 def main_rest():
-    out = dict(lbfgs={}, mlsl={}, esch={}, sobol={})
+    out = dict(lbfgs={}, mlsl={}, esch={}, sobol={}, mma={}, mlsl_mma={})
+    for name, obj, n, kw in MMA_CASES:
+        r = O.run_ref_mma(obj, n, **kw)
+        out["mma"][name] = dict(obj=obj, n=n, kwargs=kw, **record(r))
+        print(name, r["ret"], r["nevals"], r["minf"])
+    for name, obj, n, ns, seed, alg, local, kw in MLSL_MMA_CASES:
+        r = O.run_ref_mlsl(obj, n, ns, seed, alg=alg, local=local, **kw)
+        out["mlsl_mma"][name] = dict(obj=obj, n=n, ns=ns, seed=seed, alg=alg, local=local, kwargs=kw, **record(r))
+        print(name, r["ret"], r["nevals"], r["minf"])
     for name, obj, n, kw in LBFGS_CASES:
         r = O.run_ref_lbfgs(obj, n, **kw)
         out["lbfgs"][name] = dict(obj=obj, n=n, kwargs=kw, **record(r))

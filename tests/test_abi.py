@@ -45,7 +45,7 @@ def test_reference_abi_constants():
     L = nlopt_amd.lib()
     # nlopt_algorithm values of the hot path (src/api/nlopt.h:85-153) and result codes (:162-176)
     for name, val in (("GN_CRS2_LM", 19), ("GN_MLSL", 20), ("GD_MLSL", 21), ("GN_MLSL_LDS", 22), ("GD_MLSL_LDS", 23), ("LD_LBFGS", 11),
-                      ("GN_ISRES", 35), ("G_MLSL", 38), ("G_MLSL_LDS", 39), ("GN_ESCH", 42)):
+                      ("LD_MMA", 24), ("GN_ISRES", 35), ("G_MLSL", 38), ("G_MLSL_LDS", 39), ("GN_ESCH", 42)):
         assert L.nlopt_algorithm_from_string(name.encode()) == val
         assert L.nlopt_algorithm_to_string(val).decode() == name
     for name, val in (("FAILURE", -1), ("INVALID_ARGS", -2), ("OUT_OF_MEMORY", -3), ("ROUNDOFF_LIMITED", -4), ("FORCED_STOP", -5),
@@ -58,7 +58,8 @@ def test_reference_abi_constants():
 
 
 @pytest.mark.skipif(nlopt_amd.device_count() > 0, reason="a HIP device is visible")
-@pytest.mark.parametrize("alg", [nlopt_amd.GN_CRS2_LM, nlopt_amd.GN_ISRES, nlopt_amd.GN_ESCH, nlopt_amd.LD_LBFGS, nlopt_amd.G_MLSL])
+@pytest.mark.parametrize("alg", [nlopt_amd.GN_CRS2_LM, nlopt_amd.GN_ISRES, nlopt_amd.GN_ESCH, nlopt_amd.LD_LBFGS, nlopt_amd.LD_MMA, nlopt_amd.G_MLSL,
+                                 nlopt_amd.GD_MLSL, nlopt_amd.GD_MLSL_LDS])
 def test_no_device_fails_loudly(alg):
     o = nlopt_amd.Opt(alg, 4)
     o.set_lower_bounds(-1.0)
@@ -79,3 +80,38 @@ def test_unprovided_algorithms_refuse_with_a_message():
     o.set_min_objective(nlopt_amd.objective("sphere"))
     x, minf, ret = o.optimize_raw(np.zeros(2))
     assert ret == nlopt_amd.INVALID_ARGS and "not provided" in o.get_errmsg()
+
+
+def test_argument_errors_of_the_local_optimisers_come_before_any_device_work():
+    """LD_MMA's parameters are validated as the reference's dispatcher does (optimize.c:807-815); what the device path does
+    not provide is refused by name — nonlinear constraints for LD_MMA, GN_MLSL's default local optimiser LN_COBYLA"""
+    L = nlopt_amd.lib()
+
+    def mk(alg):
+        o = nlopt_amd.Opt(alg, 3)
+        o.set_lower_bounds(-1.0)
+        o.set_upper_bounds(1.0)
+        o.set_min_objective(nlopt_amd.objective("sphere"))
+        o.set_maxeval(50)
+        return o
+    for name, val, msg in (("rho_init", -1.0, "rho_init must be positive and finite"), ("inner_gradients", 2, "inner_gradients must be 0 or 1"),
+                           ("always_improve", -1, "always_improve must be 0 or 1"), ("sigma_min", -0.5, "sigma_min must be non-negative")):
+        o = mk(nlopt_amd.LD_MMA)
+        o.set_param(name, val)
+        x, minf, ret = o.optimize_raw(np.full(3, 0.5))
+        assert ret == nlopt_amd.INVALID_ARGS and msg in o.get_errmsg()
+        g = mk(nlopt_amd.G_MLSL)                       # the same through MLSL's local optimiser
+        loc = mk(nlopt_amd.LD_MMA)
+        loc.set_param(name, val)
+        assert L.nlopt_set_local_optimizer(g._h, loc._h) > 0
+        x, minf, ret = g.optimize_raw(np.full(3, 0.5))
+        assert ret == nlopt_amd.INVALID_ARGS and msg in g.get_errmsg()
+    o = mk(nlopt_amd.LD_MMA)
+    con = nlopt_amd.NLOPT_FUNC(lambda n, x, g, d: x[0] - 0.25)
+    L.nlopt_add_inequality_constraint.argtypes = [C.c_void_p, nlopt_amd.NLOPT_FUNC, C.c_void_p, C.c_double]
+    assert L.nlopt_add_inequality_constraint(o._h, con, None, 1e-8) > 0
+    x, minf, ret = o.optimize_raw(np.full(3, 0.5))
+    assert ret == nlopt_amd.INVALID_ARGS and "without nonlinear constraints" in o.get_errmsg()
+    o = mk(nlopt_amd.GN_MLSL)
+    x, minf, ret = o.optimize_raw(np.zeros(3))
+    assert ret == nlopt_amd.INVALID_ARGS and "COBYLA" in o.get_errmsg()

@@ -184,6 +184,69 @@ def test_port_mlsl_matches_reference_live(obj, n, ns, seed, kw):
     assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
 
 
+# ---- LD_MMA without nonlinear constraints, and MLSL with it (GD_MLSL's default local optimiser) ----
+@need_ref
+@pytest.mark.parametrize("obj,n,kw", [
+    ("sphere", 8, dict(ftol_rel=1e-10)),
+    ("rosenbrock", 10, dict(maxeval=500)),
+    ("rosenbrock", 2, dict(ftol_rel=1e-10)),
+    ("ackley", 30, dict(ftol_rel=1e-8)),
+    ("rastrigin", 20, dict(ftol_rel=1e-8)),
+    ("griewank", 12, dict(xtol_rel=1e-6)),
+    ("levy", 7, dict(ftol_abs=1e-12)),
+    ("ackley", 200, dict(ftol_rel=1e-8)),
+    ("rastrigin", 64, dict(maxeval=37)),
+    ("sphere", 6, dict(stopval=1e-3)),
+    ("rastrigin", 16, dict(ftol_rel=1e-9, params=dict(inner_gradients=0))),        # calls != counted evaluations
+    ("rosenbrock", 6, dict(maxeval=3000, params=dict(always_improve=0))),
+    ("ackley", 10, dict(ftol_rel=1e-9, params=dict(inner_maxeval=2, rho_init=0.01))),
+    ("griewank", 10, dict(xtol_rel=1e-8, params=dict(sigma_min=0.5))),
+    ("rastrigin", 12, dict(ftol_rel=1e-9, step=0.3)),                                # initial step = sigma_init
+])
+def test_port_mma_matches_reference_live(obj, n, kw):
+    a = O.run_port_mma(obj, n, **kw)
+    b = O.run_ref_mma(obj, n, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+    assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
+
+
+@need_ref
+def test_port_mma_bounds_and_fixed_coordinate_match_reference():
+    n = 9
+    lb, ub = np.full(n, -2.0), np.full(n, 3.0)
+    lb[2] = 0.7
+    lb[5] = ub[5] = 1.25                     # sigma = 0 (mma.c:91-94)
+    x0 = np.linspace(0.9, 2.6, n)
+    x0[5] = 1.25
+    for obj in ("sphere", "rastrigin"):
+        a = O.run_port_mma(obj, n, x0=x0, lb=lb, ub=ub, ftol_rel=1e-10)
+        b = O.run_ref_mma(obj, n, x0=x0, lb=lb, ub=ub, ftol_rel=1e-10)
+        assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+        assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["x"], b["x"])
+
+
+@need_ref
+@pytest.mark.parametrize("alg,local,obj,n,ns,seed,kw", [
+    (38, "mma", "rastrigin", 6, 20, 7, dict(maxeval=3000)),
+    (38, "mma", "ackley", 10, 30, 7, dict(maxeval=4000)),
+    (38, "mma", "levy", 5, 16, 7, dict(maxeval=2000, local_params=dict(inner_gradients=0))),
+    (21, None, "rastrigin", 6, 20, 11, dict(maxeval=3000, ftol_rel=1e-7)),              # GD_MLSL, default local optimiser
+    (21, None, "sphere", 5, 6, 2, dict(stopval=1e-9, maxeval=5000, ftol_rel=1e-8)),
+    (23, None, "ackley", 10, 0, 11, dict(maxeval=3000, ftol_rel=1e-7)),                 # GD_MLSL_LDS, Sobol sampling
+])
+def test_port_mlsl_with_mma_matches_reference_live(alg, local, obj, n, ns, seed, kw):
+    pk = dict(kw)
+    tol = pk.pop("ftol_rel", None)
+    if tol is not None:
+        pk["local_ftol_rel"] = tol           # the dispatcher copies the global tolerances to its default local optimiser
+    a = O.run_port_mlsl(obj, n, ns, seed, local="mma", lds=(alg in (23, 39)), **pk)
+    b = O.run_ref_mlsl(obj, n, ns, seed, alg=alg, local=local, **kw)
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+    assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
+
+
 # ---- Sobol LDS (a19) -----------------------------------------------------------------------------
 @need_ref
 @pytest.mark.parametrize("sdim,skip_n,count", [(1, 0, 300), (2, 0, 1025), (7, 110, 200), (40, 1000, 300), (1111, 11114, 40)])
@@ -264,6 +327,22 @@ def test_port_lbfgs_matches_golden(name):
 def test_port_mlsl_matches_golden(name):
     g = RGOLD["mlsl"][name]
     _check(O.run_port_mlsl(g["obj"], g["n"], g["ns"], g["seed"], lds=(g["alg"] == 39), **g["kwargs"]), g)
+
+
+@pytest.mark.parametrize("name", sorted(RGOLD["mma"]))
+def test_port_mma_matches_golden(name):
+    g = RGOLD["mma"][name]
+    _check(O.run_port_mma(g["obj"], g["n"], **g["kwargs"]), g)
+
+
+@pytest.mark.parametrize("name", sorted(RGOLD["mlsl_mma"]))
+def test_port_mlsl_with_mma_matches_golden(name):
+    g = RGOLD["mlsl_mma"][name]
+    kw = dict(g["kwargs"])
+    tol = kw.pop("ftol_rel", None)
+    if tol is not None:
+        kw["local_ftol_rel"] = tol
+    _check(O.run_port_mlsl(g["obj"], g["n"], g["ns"], g["seed"], local="mma", lds=(g["alg"] in (23, 39)), **kw), g)
 
 
 @pytest.mark.parametrize("name", sorted(RGOLD["esch"]))
