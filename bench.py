@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("crs", "isres", "mlsl"), default="crs")
+    ap.add_argument("--local", choices=("lbfgs", "mma"), default="lbfgs",
+                    help="mlsl: lbfgs = G_MLSL_LDS with an explicit LD_LBFGS (config 4); mma = GD_MLSL_LDS with its default local optimiser LD_MMA")
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--pop", type=int, default=0)
     ap.add_argument("--obj", default="")
@@ -143,19 +145,23 @@ def cpu_baseline_isres(obj, n, pop_sample, seed, ncon=4):
                 sample_pop=pop_sample)
 
 
-def cpu_baseline_mlsl(obj, n, nsamples, seed, maxeval):
+def cpu_baseline_mlsl(obj, n, nsamples, seed, maxeval, local="lbfgs"):
     import _oracle as O
     t0 = time.perf_counter()
     if O.have_ref():
-        r = O.run_ref_mlsl(obj, n, nsamples, seed, alg=39, maxeval=maxeval, record=False)
+        if local == "mma":
+            r = O.run_ref_mlsl(obj, n, nsamples, seed, alg=23, local=None, ftol_rel=1e-8, maxeval=maxeval, record=False)
+        else:
+            r = O.run_ref_mlsl(obj, n, nsamples, seed, alg=39, maxeval=maxeval, record=False)
         kind = "reference"
     else:
-        r = O.run_port_mlsl(obj, n, nsamples, seed, maxeval=maxeval, record=False)
+        r = O.run_port_mlsl(obj, n, nsamples, seed, maxeval=maxeval, record=False, local=local, lds=(n <= 1111))
         kind = "port"
     dt = time.perf_counter() - t0
     return dict(value=r["nevals"] / dt, unit="evals/s", cores=1, kind=kind,
-                sample="NLOPT_G_MLSL_LDS + LD_LBFGS(ftol_rel 1e-8) %s n=%d, %d samples/iteration, the first %d evaluations of the same run "
-                       "in %.1f s, 1 thread" % (obj, n, nsamples, r["nevals"], dt))
+                sample="%s %s n=%d, %d samples/iteration, the first %d evaluations of the same run in %.1f s, 1 thread"
+                       % ("NLOPT_GD_MLSL_LDS (default local optimiser LD_MMA, ftol_rel 1e-8)" if local == "mma" else
+                          "NLOPT_G_MLSL_LDS + LD_LBFGS(ftol_rel 1e-8)", obj, n, nsamples, r["nevals"], dt))
 
 
 def gens_to_ftol():
@@ -372,6 +378,9 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
     if a.workload == "isres":
         o = nlopt_amd.Opt(nlopt_amd.GN_ISRES, n)
         ncon = 4
+    elif a.local == "mma":
+        o = nlopt_amd.Opt(nlopt_amd.GD_MLSL_LDS, n)             # no local optimiser set: the dispatcher's default, LD_MMA
+        o.set_ftol_rel(1e-8)                                     # copied to the default local optimiser (optimize.c:772)
     else:
         o = nlopt_amd.Opt(nlopt_amd.G_MLSL_LDS, n)
         loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, n)
@@ -418,9 +427,10 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
     else:
         t_dom = d["t_lbfgs_ms"] / 1e3
         bytes_dom = float(d["lbfgs_bytes"])
-        kern, launches = "lbfgs_batch_kernel", int(d["lbfgs_launches"])
-        metric = "candidate-evals/sec, G_MLSL_LDS + LD_LBFGS n=%d, %d samples per iteration" % (n, pop)
-        wl = "NLOPT_G_MLSL_LDS + NLOPT_LD_LBFGS(ftol_rel 1e-8) %s n=%d, %d samples/iteration, seed=%d; step = 1 MLSL iteration" % (a.obj, n, pop, a.seed)
+        kern, launches = ("mma_batch_kernel" if a.local == "mma" else "lbfgs_batch_kernel"), int(d["lbfgs_launches"])
+        name = "GD_MLSL_LDS + default LD_MMA" if a.local == "mma" else "G_MLSL_LDS + LD_LBFGS"
+        metric = "candidate-evals/sec, %s n=%d, %d samples per iteration" % (name, n, pop)
+        wl = "NLOPT_%s(ftol_rel 1e-8) %s n=%d, %d samples/iteration, seed=%d; step = 1 MLSL iteration" % (name.replace(" + ", " + NLOPT_").replace("default ", ""), a.obj, n, pop, a.seed)
         phases = {"sampling_s_per_iter": d["t_eval_s"] / K, "local_phase_s_per_iter": d["t_evolve_s"] / K,
                   "local_searches": int(d["accepted"]), "sample_evals": int(d["evals_trial"]), "local_evals": int(d["evals_mutation"])}
     achieved = (bytes_dom / 1e9) / t_dom if t_dom > 0 else None
@@ -444,7 +454,7 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                 out["cpu_baseline"] = cpu_baseline_isres(a.obj, n, a.cpu_sample_pop or 10000, a.seed, ncon)
                 out["cpu_baseline"]["estimate_at_benchmark_pop"] = out["cpu_baseline"]["value"] * out["cpu_baseline"]["sample_pop"] / pop
             else:
-                out["cpu_baseline"] = cpu_baseline_mlsl(a.obj, n, pop, a.seed, 30000)
+                out["cpu_baseline"] = cpu_baseline_mlsl(a.obj, n, pop, a.seed, 30000, a.local)
             if out["cpu_baseline"]["value"]:
                 out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:
