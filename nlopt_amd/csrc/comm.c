@@ -14,6 +14,7 @@
  */
 #include "nla_internal.h"
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,20 +32,24 @@ static struct {
     fn_get_uid get_uid; fn_init_rank init_rank; fn_allgather allgather; fn_destroy destroy; fn_errstr errstr;
 } R;
 
-static int rccl_load(void)
+static pthread_once_t rccl_once = PTHREAD_ONCE_INIT;
+static void rccl_load_once(void)
 {
-    if (R.dl) return 0;
     R.dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!R.dl) R.dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!R.dl) R.dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!R.dl) return -1;
+    if (!R.dl) return;
     R.get_uid = (fn_get_uid) dlsym(R.dl, "ncclGetUniqueId");
     R.init_rank = (fn_init_rank) dlsym(R.dl, "ncclCommInitRank");
     R.allgather = (fn_allgather) dlsym(R.dl, "ncclAllGather");
     R.destroy = (fn_destroy) dlsym(R.dl, "ncclCommDestroy");
     R.errstr = (fn_errstr) dlsym(R.dl, "ncclGetErrorString");
-    if (!R.get_uid || !R.init_rank || !R.allgather || !R.destroy) { dlclose(R.dl); R.dl = NULL; return -1; }
-    return 0;
+    if (!R.get_uid || !R.init_rank || !R.allgather || !R.destroy) { dlclose(R.dl); R.dl = NULL; }
+}
+static int rccl_load(void)                                    /* any thread may be the first to ask */
+{
+    pthread_once(&rccl_once, rccl_load_once);
+    return R.dl ? 0 : -1;
 }
 
 struct nlopt_amd_comm_s {
