@@ -179,6 +179,7 @@ struct nla_crs_session {
     uint64_t fresh_from;           /* blocks >= this have no device state yet */
     uint64_t init_words;
     int Kmax, host_eval;
+    double kmult;                  /* window = kmult x (blocks consumed per pass, smoothed) + 4 */
     double runlen;
     nla_crs_slot_status *status;
     int32_t *tprev;                /* picks already summed, per in-flight block (stats only) */
@@ -221,6 +222,10 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     S->pb = *pb;
     S->host_eval = pb->obj < 0;
     S->Kmax = pb->max_spec > 0 ? pb->max_spec : 256;
+    /* measured (MI355X, pop 1e5): the chain consumes the same number of blocks per pass whether the window is 1.5x or 12x
+     * that number wide — the slots behind only add workgroups, status records and hazard rows: 1.5 is as fast as 3 at
+     * n = 4096 and 3 % / 10 % faster at n = 512 / 64; 12 is 15 % slower */
+    S->kmult = pb->window_factor > 0 ? pb->window_factor : 1.5;
     if (S->Kmax > 1024) S->Kmax = 1024;
     if (S->host_eval) S->Kmax = 1;
     S->runlen = 4.0;
@@ -302,7 +307,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
         if (eval_budget > 0 && (int64_t) (*stop->nevals_p - evals_at_entry) >= eval_budget) break;
         cap = ops->max_slots(e, S->block);
         if (cap <= 0) { engine_failed(S); return S->ret; }
-        K = (int) ceil(3.0 * S->runlen) + 4;
+        K = (int) ceil(S->kmult * S->runlen) + 4;
         if (K > S->Kmax) K = S->Kmax;
         if (K > cap) K = cap;
         if (K < 1) K = 1;

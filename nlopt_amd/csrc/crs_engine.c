@@ -54,6 +54,7 @@ struct nla_crs_hip_engine {
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
+    FILE *pass_log;                /* NLA_CRS_PASS_LOG=<file>: one line per pass (development aid, see tools/pass_log_summary.py) */
     nlopt_amd_stats *stats;
     nlopt_amd_comm *comm;          /* multi-GPU: initial rows are generated in rank blocks and all-gathered; NULL = single process */
     char err[256];
@@ -99,6 +100,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     if (e->main) nla_stream_sync(e->main);
     if (e->rng) nla_stream_sync(e->rng);
     if (e->mts) { nla_mtstream_finish(e->mts, words_used); nla_mtstream_destroy(e->mts); }
+    if (e->pass_log) fclose(e->pass_log);
     for (int i = 0; i < 2; ++i) nla_event_destroy(e->bat[i].ev_ready);
     nla_dev_free(e->d_words); nla_dev_free(e->d_jn); nla_dev_free(e->d_pos); nla_dev_free(e->d_last);
     nla_dev_free(e->d_lb); nla_dev_free(e->d_ub); nla_dev_free(e->d_X); nla_dev_free(e->d_F);
@@ -131,6 +133,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     if (B > 65536) B = 65536;
     if (B < 2 * KCAP) B = 2 * KCAP;
     e->B = (int) B;
+    if (getenv("NLA_CRS_PASS_LOG")) e->pass_log = fopen(getenv("NLA_CRS_PASS_LOG"), "a");
     e->main = nla_stream_create();
     e->rng = nla_stream_create();
     if (!e->main || !e->rng) goto fail;
@@ -340,6 +343,17 @@ have_status:
         if (ms >= 0) e->stats->t_gather_ms += ms;
         e->stats->gather_launches += 1;
     }
+    if (e->pass_log) {             /* K, nW, slots already complete / fresh / stopped short, rows summed, kernel ms */
+        long rows = 0;
+        int done_in = 0, fresh = 0, stopped = 0;
+        for (int a = 0; a < K; ++a) {
+            rows += status[a].t - t_in[a];
+            done_in += t_in[a] == n;
+            fresh += t_in[a] == 0;
+            stopped += status[a].t < n;
+        }
+        fprintf(e->pass_log, "%d,%d,%d,%d,%d,%d,%ld,%.4f\n", n, K, nW, done_in, fresh, stopped, rows, (double) nla_event_elapsed_ms(e->ev0, e->ev1));
+    }
     return 0;
 }
 
@@ -410,6 +424,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         pb->trace = opt->trace; pb->trace_cap = opt->trace_cap; pb->trace_len = &opt->trace_len;
         pb->stats = &opt->stats;
         pb->max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
+        pb->window_factor = nlopt_get_param(opt, "amd_window_factor", 0);
         if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
     }
     if (nla_dev_count() <= 0) {

@@ -162,6 +162,7 @@ typedef struct {
     nlopt_amd_trace_rec *trace; size_t trace_cap, *trace_len;
     nlopt_amd_stats *stats;
     int max_spec;                   /* cap on slots per round (0 = default) */
+    double window_factor;           /* window = factor x (blocks consumed per pass, smoothed) + 4 (0 = default 1.5) */
 } nla_crs_problem;
 
 /* the algorithm, resumable between speculation rounds (bench steps, sessions);
