@@ -315,6 +315,13 @@ int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, in
 int nla_k_mlsl_rowmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const double *init, double *out, void *stream);
 /* replaces: pts_update_newpt (mlsl.c:162-173): inout[j] = min(inout[j], min_i {D[i][j] : FA[i] < FB[j]}) where skip[j] == 0 */
 int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const int32_t *skip, double *inout, void *stream);
+/* replaces: the per-point memcpy of a local search's start (mlsl.c:399-404) and of an accepted minimum (mlsl.c:410-414) for a
+ * whole batch: dst row c := src row idx[c] (idx on the device) */
+int nla_k_mlsl_gather_rows(int n, int ld, const double *src, const int64_t *idx, int count, double *dst, void *stream);
+/* replaces: the bound test of is_potential_minimizer (mlsl.c:211-218) for `count` points: flags[c] = 1 if row idx[c] of P has a
+ * coordinate within thr (= dbound R) of a bound of a box side wider than thr */
+int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, int count, const double *lb, const double *ub,
+                          double thr, int32_t *flags, void *stream);
 
 /* ---- ESCH (src/algs/esch/esch.c) -------------------------------------------------------------------- */
 /* replaces: randcauchy (esch.c:28-50) called back to back: appends the accepted values (folded to [0,1], i.e. `valor` before the

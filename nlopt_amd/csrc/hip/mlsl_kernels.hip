@@ -114,3 +114,49 @@ extern "C" int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const
     NLA_LAUNCH_CHECK();
     return 0;
 }
+
+/* rows by index: dst row c := src row idx[c] (the start points of a batch of local searches, mlsl.c:399-404; the accepted minima
+ * joining the set of local minima, mlsl.c:410-414) — one launch instead of one copy operation per row */
+__global__ __launch_bounds__(256) void mlsl_gather_rows_kernel(int n, int ld, const double *__restrict__ src, const int64_t *__restrict__ idx,
+                                                                double *__restrict__ dst)
+{
+    const double *r = src + (size_t) idx[blockIdx.x] * (size_t) ld;
+    double *g = dst + (size_t) blockIdx.x * (size_t) ld;
+    for (int j = threadIdx.x; j < n; j += 256) g[j] = r[j];
+}
+
+/* the bound test of is_potential_minimizer (mlsl.c:211-218) for `count` points at once: flags[c] = 1 if some coordinate of
+ * row idx[c] lies within thr (= dbound R) of a bound whose box side is wider than thr.  Same comparisons as the reference,
+ * on the same doubles. */
+__global__ __launch_bounds__(256) void mlsl_near_bound_kernel(int n, int ld, const double *__restrict__ P, const int64_t *__restrict__ idx,
+                                                               const double *__restrict__ lb, const double *__restrict__ ub, double thr,
+                                                               int32_t *__restrict__ flags)
+{
+    __shared__ int s_hit;
+    const double *x = P + (size_t) idx[blockIdx.x] * (size_t) ld;
+    if (threadIdx.x == 0) s_hit = 0;
+    __syncthreads();
+    int hit = 0;
+    for (int j = threadIdx.x; j < n; j += 256)
+        if ((x[j] - lb[j] <= thr || ub[j] - x[j] <= thr) && ub[j] - lb[j] > thr) hit = 1;
+    if (hit) s_hit = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = s_hit;
+}
+
+extern "C" int nla_k_mlsl_gather_rows(int n, int ld, const double *src, const int64_t *idx, int count, double *dst, void *stream)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_gather_rows_kernel, dim3((unsigned) count), dim3(256), 0, (hipStream_t) stream, n, ld, src, idx, dst);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, int count, const double *lb, const double *ub,
+                                     double thr, int32_t *flags, void *stream)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_near_bound_kernel, dim3((unsigned) count), dim3(256), 0, (hipStream_t) stream, n, ld, P, idx, lb, ub, thr, flags);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

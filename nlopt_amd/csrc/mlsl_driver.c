@@ -62,6 +62,11 @@ typedef struct {
     nla_local_ctx *lb;
     double *h_D;                    /* pinned: batch x npts distances */
     size_t hcap;
+    /* per-batch lists, pinned host side + device side: [idx of all candidates: bmax][idx of this rank's: BATCH_MAX]
+     * [gathered-row index of the accepted minima: bmax] as int64, then the accepted minima's f (bmax doubles); flags: bmax int32 */
+    int64_t *h_idx, *d_idx;
+    double *h_lf;
+    int32_t *h_flags, *d_flags;
     char err[200];
 } mlsl_dev;
 
@@ -77,7 +82,8 @@ static void mfree(mlsl_dev *d)
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd);
     nla_dev_free(d->d_LM); nla_dev_free(d->d_LF); nla_dev_free(d->d_D); nla_dev_free(d->d_tmp); nla_dev_free(d->d_min);
     nla_dev_free(d->d_words); nla_dev_free(d->d_LX); nla_dev_free(d->d_V); nla_dev_free(d->d_dx);
-    nla_host_free(d->h_D);
+    nla_host_free(d->h_D); nla_host_free(d->h_idx); nla_host_free(d->h_lf); nla_host_free(d->h_flags);
+    nla_dev_free(d->d_idx); nla_dev_free(d->d_flags);
     if (d->st) nla_stream_destroy(d->st);
 }
 
@@ -160,10 +166,10 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     nla_lbfgs_result *res = NULL, *res_mine = NULL;
     size_t *cand = NULL;
     int bmax;
-    double R_prefactor, *Fnew = NULL, *rowbuf = NULL, best_f = HUGE_VAL;
+    double R_prefactor, *Fnew = NULL, best_f = HUGE_VAL;
     const double dlm = 1.0, dbound = 1e-6;
     const double *lbh = lb, *ubh = ub;
-    int i, j, mf, best_is_lm = 0, loc_maxeval, use_mma = 0;
+    int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0;
     nla_mma_params mma;
     size_t best_row = 0;
     (void) f_data;
@@ -206,11 +212,16 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (size_t) D.N);
     D.d_tmp = (double *) nla_dev_malloc(sizeof(double) * (size_t) (D.N > bmax ? D.N : bmax));
     D.d_LX = (double *) nla_dev_malloc(sizeof(double) * (size_t) bmax * (size_t) D.ld);
+    D.h_idx = (int64_t *) nla_host_malloc(sizeof(int64_t) * (size_t) (2 * bmax + BATCH_MAX));
+    D.d_idx = (int64_t *) nla_dev_malloc(sizeof(int64_t) * (size_t) (2 * bmax + BATCH_MAX));
+    D.h_lf = (double *) nla_host_malloc(sizeof(double) * (size_t) bmax);
+    D.h_flags = (int32_t *) nla_host_malloc(sizeof(int32_t) * (size_t) bmax);
+    D.d_flags = (int32_t *) nla_dev_malloc(sizeof(int32_t) * (size_t) bmax);
     Fnew = (double *) malloc(sizeof(double) * (size_t) D.N);
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
     cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
-    if (!D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    if (!D.h_idx || !D.d_idx || !D.h_lf || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
@@ -316,8 +327,8 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         idx = 0;
         remaining = (int) (ceil(MLSL_GAMMA * D.npts) + 0.5);
         while (idx < D.npts && remaining > 0 && ret == NLOPT_SUCCESS) {
-            int nb = 0, c, per, mine = 0;
-            size_t scan = idx;
+            int nb = 0, c, per, mine = 0, nacc = 0;
+            size_t scan = idx, nlms0 = 0;
             int rem = remaining, eff;
             long limited;
             /* the next candidates that are potential minimisers right now (is_potential_minimizer, :196-221) */
@@ -331,14 +342,14 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             /* candidate c is minimised by rank c mod world in its slot c / world; gathered row of c: GI(c) */
             per = (nb + D.world - 1) / D.world;
 #define GI(c) ((size_t) ((c) % D.world) * (size_t) per + (size_t) ((c) / D.world))
-            for (c = D.rank; c < nb; c += D.world, ++mine)
-                if (nla_memcpy_d2d(nla_local_ctx_X(D.lb) + (size_t) mine * D.ld, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
-            /* the bound test needs the start coordinates on the host (every rank: all candidates) */
-            if (!rowbuf) rowbuf = (double *) malloc(sizeof(double) * (size_t) n * (size_t) bmax);
-            if (!rowbuf) { snprintf(D.err, sizeof D.err, "out of memory"); DEVFAIL(); }
-            for (c = 0; c < nb; ++c)
-                if (nla_memcpy_d2h(rowbuf + (size_t) c * n, D.d_P + D.ord[cand[c]] * (size_t) D.ld, sizeof(double) * (size_t) n, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
-            if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+            /* start points of this rank's share into the batch (one gather launch), and the bound test of every candidate
+             * (is_potential_minimizer, mlsl.c:211-218) on the device: only the flags come back */
+            for (c = 0; c < nb; ++c) D.h_idx[c] = (int64_t) D.ord[cand[c]];
+            for (c = D.rank; c < nb; c += D.world, ++mine) D.h_idx[bmax + mine] = (int64_t) D.ord[cand[c]];
+            if (nla_memcpy_h2d(D.d_idx, D.h_idx, sizeof(int64_t) * (size_t) (bmax + mine), D.st) ||
+                nla_k_mlsl_gather_rows(n, D.ld, D.d_P, D.d_idx + bmax, mine, nla_local_ctx_X(D.lb), D.st) ||
+                nla_k_mlsl_near_bound(n, D.ld, D.d_P, D.d_idx, nb, D.d_lb, D.d_ub, dbound * R, D.d_flags, D.st) ||
+                nla_memcpy_d2h(D.h_flags, D.d_flags, sizeof(int32_t) * (size_t) nb, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
             /* local searches of this rank's share, all-gather of the minimisers, then their distances to every point */
             limited = (long) stop->maxeval - (long) *stop->nevals_p;             /* nlopt_optimize_limited, optimize.c:1097-1100 */
             eff = loc_maxeval;
@@ -362,10 +373,10 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                     nla_memcpy_d2h(D.h_D, D.d_D, sizeof(double) * na * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
             }
             if (grow_lms(&D, D.nlms + (size_t) nb)) DEVFAIL();
+            nacc = 0; nlms0 = D.nlms;
             /* commit in walk order */
             for (c = 0; c < nb && ret == NLOPT_SUCCESS; ++c) {
                 const size_t r = D.ord[cand[c]];
-                const double *xr = rowbuf + (size_t) c * n;
                 int pot = !(D.cld[r] <= (dlm * R) * (dlm * R));               /* may have changed since the batch was formed */
                 double lf;
                 int calls;
@@ -374,8 +385,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 /* nodes between the previous candidate and this one were visited and skipped */
                 remaining -= (int) (cand[c] + 1 - idx);
                 idx = cand[c] + 1;
-                if (pot) for (j = 0; j < n; ++j)
-                    if ((xr[j] - lb[j] <= dbound * R || ub[j] - xr[j] <= dbound * R) && ub[j] - lb[j] > dbound * R) { pot = 0; break; }
+                if (pot && D.h_flags[c]) pot = 0;                               /* too close to a bound (mlsl.c:211-218) */
                 if (!pot) continue;
                 if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; break; }
                 if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; break; }
@@ -409,8 +419,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 lf = res[g].f;
                 /* the minimum joins the device-side set; stream-ordered, no synchronisation per minimum (room for the whole
                  * batch was made before the walk; res[] stays valid until the batch's closing synchronisation) */
-                if (nla_memcpy_d2d(D.d_LM + D.nlms * (size_t) D.ld, D.d_LX + g * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
-                    nla_memcpy_h2d(D.d_LF + D.nlms, &res[g].f, sizeof(double), D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
+                D.h_idx[bmax + BATCH_MAX + nacc] = (int64_t) g;
+                D.h_lf[nacc] = lf;
+                ++nacc;
                 D.LF[D.nlms] = lf;
                 ord_insert(D.lord, D.nlms, D.LF, D.nlms);
                 ++D.nlms;
@@ -424,6 +435,10 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                         if (D.F[k] > lf && !D.minimized[k] && dr[k] < D.cld[k]) D.cld[k] = dr[k];
                 }
             }
+            /* the batch's accepted minima join the device-side set in acceptance order: one gather launch */
+            if (nacc > 0 && (nla_memcpy_h2d(D.d_idx + bmax + BATCH_MAX, D.h_idx + bmax + BATCH_MAX, sizeof(int64_t) * (size_t) nacc, D.st) ||
+                             nla_k_mlsl_gather_rows(n, D.ld, D.d_LX, D.d_idx + bmax + BATCH_MAX, nacc, D.d_LM + nlms0 * (size_t) D.ld, D.st) ||
+                             nla_memcpy_h2d(D.d_LF + nlms0, D.h_lf, sizeof(double) * (size_t) nacc, D.st))) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
             if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
             if (ret == NLOPT_SUCCESS && c == nb) {
                 /* nodes scanned after the last candidate of the batch (none qualified) are visited too */
@@ -445,6 +460,6 @@ done_noget:
 done:
     if (st) st->mt_words = D.words_used;
     mfree(&D);
-    free(Fnew); free(rowbuf); free(res); free(res_mine); free(cand);
+    free(Fnew); free(res); free(res_mine); free(cand);
     return ret;
 }
