@@ -54,6 +54,7 @@ struct nla_crs_hip_engine {
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
+    int force_upload;              /* NLA_CRS_UPLOAD: the pass's lists through the H2D copy even when they fit the kernel arguments (A/B switch) */
     FILE *pass_log;                /* NLA_CRS_PASS_LOG=<file>: one line per pass (development aid, see tools/pass_log_summary.py) */
     nlopt_amd_stats *stats;
     nlopt_amd_comm *comm;          /* multi-GPU: initial rows are generated in rank blocks and all-gathered; NULL = single process */
@@ -163,6 +164,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
     e->direct_status = !getenv("NLA_CRS_COPY_STATUS");
+    e->force_upload = getenv("NLA_CRS_UPLOAD") != NULL;
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1) goto fail;
     if (nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
@@ -303,7 +305,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         const uint64_t b = first_block + (uint64_t) a;
         t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
     }
-    if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !getenv("NLA_CRS_UPLOAD")) {
+    if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload) {
         /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
          * front of the pass */
         if (e->npending) {
