@@ -406,7 +406,7 @@ def run_port_mma(obj, n, x0=None, maxeval=0, ftol_rel=0.0, ftol_abs=0.0, xtol_re
     if stopval is not None:
         st.minf_max = stopval
     f = L.orc_objective(OBJ[obj])
-    cap = (maxeval or 200000) + 16
+    cap = 2 * (maxeval or 200000) + 16          # inner_gradients = 0: up to two calls per counted evaluation
     fbuf = np.zeros(cap)
     hbuf = np.zeros(cap, dtype=np.uint64)
     rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)

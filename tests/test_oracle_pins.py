@@ -357,3 +357,61 @@ def test_port_sobol_matches_golden(name):
     pts = O.port_sobol_points(g["sdim"], g["skip_n"], g["count"])
     assert hashlib.sha256(np.ascontiguousarray(pts, dtype=np.float64).tobytes()).hexdigest() == g["sha256"]
     assert [float(v).hex() for v in pts[0][:8]] == g["first"] and [float(v).hex() for v in pts[-1][:8]] == g["last"]
+
+
+# ---- randomized sweep: every port against the live reference on drawn (seeded) configurations ------------------------------
+def _same(a, b):
+    assert (a["ret"], a["nevals"]) == (b["ret"], b["nevals"])
+    assert np.array_equal(a["fseq"], b["fseq"]) and np.array_equal(a["xhash"], b["xhash"])
+    assert a["minf"] == b["minf"] and np.array_equal(a["x"], b["x"])
+
+
+@need_ref
+@pytest.mark.parametrize("scale", [1, 5])
+@pytest.mark.parametrize("draw", range(40))
+def test_random_configurations_match_the_reference(draw, scale):
+    """objective, dimension, population, seed and stopping rule drawn from a fixed generator: CRS2_LM, ISRES (with and without
+    constraints), ESCH, LD_LBFGS, LD_MMA and MLSL with either local optimiser — evaluation by evaluation against the real reference"""
+    rng = np.random.default_rng(1000 * scale + draw)
+    objs = ["rastrigin", "ackley", "griewank", "rosenbrock", "levy", "sphere"]
+    obj = objs[int(rng.integers(len(objs)))]
+    n = int(rng.integers(2, 12 * scale + 1))
+    seed = int(rng.integers(1, 2 ** 31))
+    # CRS2_LM: population >= n + 1
+    pop = int(rng.integers(n + 1, 6 * n + 8))
+    kw = dict(maxeval=int(rng.integers(pop + 50, pop + 900 * scale)))
+    if rng.random() < 0.3:
+        kw["ftol_rel"] = 10.0 ** -int(rng.integers(2, 7))
+    _same(O.run_port_crs(obj, n, pop, seed, record=True, **kw), O.run_ref(19, obj, n, pop, seed, **kw))
+    # ISRES
+    ipop = int(rng.integers(8, 60))
+    nineq, neq = (int(rng.integers(0, 3)), int(rng.integers(0, 2))) if n >= 4 else (0, 0)
+    ikw = dict(maxeval=int(rng.integers(2 * ipop, 8 * ipop)))
+    _same(O.run_port_isres(obj, n, ipop, seed, nineq=nineq, neq=neq, **ikw), O.run_ref_isres(obj, n, ipop, seed, nineq=nineq, neq=neq, **ikw))
+    # ESCH
+    epop = int(rng.integers(3, 40))
+    ekw = dict(maxeval=int(rng.integers(3 * epop, 30 * epop)))
+    _same(O.run_port_esch(obj, n, epop, seed, **ekw), O.run_ref_esch(obj, n, epop, seed, **ekw))
+    # local optimisers from the golden start point
+    lkw = dict(maxeval=int(rng.integers(20, 400 * scale)))
+    if rng.random() < 0.5:
+        lkw["ftol_rel"] = 10.0 ** -int(rng.integers(4, 11))
+    else:
+        lkw["xtol_rel"] = 10.0 ** -int(rng.integers(3, 9))
+    mf = int(rng.integers(0, 8))
+    _same(O.run_port_lbfgs(obj, n, mf=mf, **lkw), O.run_ref_lbfgs(obj, n, mf=mf, **lkw))
+    mp = {}
+    if rng.random() < 0.3:
+        mp["inner_gradients"] = 0
+    if rng.random() < 0.3:
+        mp["always_improve"] = 0
+    if rng.random() < 0.3:
+        mp["rho_init"] = float(10.0 ** rng.uniform(-3, 1))
+    _same(O.run_port_mma(obj, n, params=mp, **lkw), O.run_ref_mma(obj, n, params=mp, **lkw))
+    # MLSL: pseudo-random or Sobol sampling, LD_LBFGS or LD_MMA
+    ns = int(rng.integers(0, 30))
+    lds = bool(rng.random() < 0.5)
+    local = "mma" if rng.random() < 0.5 else "lbfgs"
+    mkw = dict(maxeval=int(rng.integers(300, 2500 * scale)), local_ftol_rel=10.0 ** -int(rng.integers(4, 10)))
+    _same(O.run_port_mlsl(obj, n, ns, seed, lds=lds, local=local, **mkw),
+          O.run_ref_mlsl(obj, n, ns, seed, alg=39 if lds else 38, local=local, **mkw))
