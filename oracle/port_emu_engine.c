@@ -147,7 +147,7 @@ int orc_emu_crs(int obj, int n, long N, const double *lb, const double *ub, doub
                 long maxeval, double stopval, double ftol_rel, double ftol_abs, double xtol_rel, const double *xtol_abs,
                 int max_slots, int max_spec, int host_eval,
                 nlopt_amd_trace_rec *trace, size_t trace_cap, size_t *trace_len, nlopt_amd_stats *stats,
-                int *nevals_out, unsigned long long *words_out)
+                int *nevals_out, unsigned long long *words_out, double window_factor)
 {
     emu e;
     nla_stopping stop;
@@ -176,7 +176,7 @@ int orc_emu_crs(int obj, int n, long N, const double *lb, const double *ub, doub
     memset(&pb, 0, sizeof pb);
     pb.n = n; pb.N = N; pb.lb = lb; pb.ub = ub; pb.obj = e.obj;
     pb.f = (nlopt_func) orc_objective(obj); pb.f_data = NULL; pb.stop = &stop;
-    pb.trace = trace; pb.trace_cap = trace_cap; pb.trace_len = trace_len; pb.stats = stats; pb.max_spec = max_spec;
+    pb.trace = trace; pb.trace_cap = trace_cap; pb.trace_len = trace_len; pb.stats = stats; pb.max_spec = max_spec; pb.window_factor = window_factor;
     if (trace_len) *trace_len = 0;
     ret = (int) nla_crs_run(&emu_ops, &e, &pb, x, minf, &words);
     *nevals_out = nevals; *words_out = words;

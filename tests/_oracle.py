@@ -237,13 +237,13 @@ def emu():
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_long, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_stats_type()),
-                                  C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+                                  C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.c_double]
         _emu = L
     return _emu
 
 
 def run_emu_crs(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0,
-                trace_cap=0, max_slots=0, max_spec=0, host_eval=False):
+                trace_cap=0, max_slots=0, max_spec=0, host_eval=False, window_factor=0.0):
     E, L = emu(), port()
     xs, lo, hi = golden_x0(obj, n)
     x = np.array(xs if x0 is None else x0, dtype=np.float64)
@@ -259,7 +259,7 @@ def run_emu_crs(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.
     ret = E.orc_emu_crs(OBJ[obj], n, pop, dptr(lb), dptr(ub), dptr(x), C.byref(minf), maxeval,
                         -np.inf if stopval is None else stopval, ftol_rel, ftol_abs, xtol_rel, None,
                         max_slots, max_spec, int(host_eval), tr.ctypes.data, trace_cap, C.byref(tlen), C.byref(st),
-                        C.byref(nev), C.byref(words))
+                        C.byref(nev), C.byref(words), float(window_factor))
     return dict(ret=ret, minf=minf.value, x=x, nevals=nev.value, words=words.value,
                 trace=tr[:min(tlen.value, trace_cap)].copy(), trace_len=tlen.value, stats=st.asdict())
 

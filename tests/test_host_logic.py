@@ -46,6 +46,32 @@ def test_trace_is_invariant_under_speculation_depth(max_slots, max_spec):
     assert st["slots_launched"] >= st["slots_used"]
 
 
+@pytest.mark.parametrize("draw", range(40))
+def test_random_configurations_over_the_emulated_engine(draw):
+    """drawn objective / dimension / population / seed / stopping rule / speculation limits / window factor / host-callback mode:
+    the product's driver must replay the oracle's serial trace whatever the window does"""
+    rng = np.random.default_rng(77 + draw)
+    obj = ["rastrigin", "ackley", "griewank", "rosenbrock", "levy", "sphere"][int(rng.integers(6))]
+    n = int(rng.integers(1, 40))
+    pop = int(rng.integers(n + 1, 12 * n + 20))
+    seed = int(rng.integers(1, 2 ** 31))
+    kw = dict(maxeval=int(rng.integers(pop + 20, pop + 3000)))
+    r = rng.random()
+    if r < 0.25:
+        kw["ftol_rel"] = 10.0 ** -int(rng.integers(2, 8))
+    elif r < 0.4:
+        kw["xtol_rel"] = 10.0 ** -int(rng.integers(2, 6))
+    elif r < 0.5:
+        kw["ftol_abs"] = 10.0 ** -int(rng.integers(1, 6))
+    base = O.run_port_crs(obj, n, pop, seed, trace_cap=20000, **kw)
+    emu_kw = dict(max_slots=int(rng.choice([0, 0, 1, 2, 7, 64])), max_spec=int(rng.choice([0, 0, 1, 3, 50])),
+                  window_factor=float(rng.choice([0.0, 0.5, 1.0, 1.5, 3.0, 20.0])), host_eval=bool(rng.random() < 0.25))
+    e = O.run_emu_crs(obj, n, pop, seed, trace_cap=20000, **kw, **emu_kw)
+    assert (e["ret"], e["nevals"], e["words"]) == (base["ret"], base["nevals"], base["words"]), emu_kw
+    assert same_trace(base["trace"], e["trace"]), emu_kw
+    assert np.array_equal(base["x"], e["x"]) and base["minf"] == e["minf"]
+
+
 def test_host_callback_path_matches_serial_reference_order():
     base = O.run_port_crs("levy", 6, 80, 3, maxeval=2500, trace_cap=5000)
     r = O.run_emu_crs("levy", 6, 80, 3, maxeval=2500, trace_cap=5000, host_eval=True)
