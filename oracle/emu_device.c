@@ -1,0 +1,394 @@
+/* emu_device.c — TEST INFRASTRUCTURE: a CPU stand-in for the product's *device layer*, so that the product's host drivers
+ * (isres_driver.c, mlsl_driver.c, lbfgs_driver.c, mma_driver.c, mtstream.c, comm.c, the API shell) can be run without a GPU —
+ * in particular by the world_size-2 gloo tests of the sharded ISRES / MLSL paths (tests/test_multiproc.py).
+ *
+ * It implements the C-ABI of include/nlopt_amd.h that hip/devrt.hip and the kernel launchers export: "device" memory is host
+ * memory, streams and events are tokens, every launcher does its kernel's job with plain loops in the REFERENCE's operation
+ * order (objectives through objfuncs.h's sequential formulas, local searches through the oracle ports) — so a driver run over
+ * this layer must reproduce the oracle evaluation by evaluation, bit for bit.  The multi-start evolve of ISRES is reported as
+ * unsupported so the driver takes its serial-kernel path; CRS2_LM has its own engine emulation (port_emu_engine.c) and ESCH is
+ * not covered: their launchers here return an error.
+ *
+ * Linked with the product's C sources into oracle/libnlopt_amd_emu.so (make emudev).  The product library never sees this file;
+ * only tests load the emulated library (by path).
+ */
+#include "../nlopt_amd/csrc/nla_internal.h"
+#include "../nlopt_amd/csrc/objfuncs.h"
+#include "port_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EMU_ERR 999
+
+/* ---- runtime (hip/devrt.hip) --------------------------------------------------------------------------------------------- */
+int nla_dev_count(void) { return 1; }
+int nla_dev_set(int dev) { return dev == 0 ? 0 : EMU_ERR; }
+void *nla_dev_malloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void nla_dev_free(void *p) { free(p); }
+void *nla_host_malloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void nla_host_free(void *p) { free(p); }
+int nla_memcpy_h2d(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
+int nla_memcpy_d2h(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
+int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
+int nla_memset(void *dst, int value, size_t bytes, void *st) { (void) st; if (bytes) memset(dst, value, bytes); return 0; }
+void *nla_stream_create(void) { return malloc(1); }
+void nla_stream_destroy(void *st) { free(st); }
+int nla_stream_sync(void *st) { (void) st; return 0; }
+void *nla_event_create(void) { return malloc(1); }
+void nla_event_destroy(void *ev) { free(ev); }
+int nla_event_record(void *ev, void *st) { (void) ev; (void) st; return 0; }
+int nla_event_sync(void *ev) { (void) ev; return 0; }
+float nla_event_elapsed_ms(void *a, void *b) { (void) a; (void) b; return 0.f; }
+int nla_stream_wait_event(void *st, void *ev) { (void) st; (void) ev; return 0; }
+const char *nla_dev_error_string(int err) { return err == EMU_ERR ? "not provided by the emulated device" : "emulated device error"; }
+
+static double urand_from(double a, double b, uint32_t w0, uint32_t w1)       /* mt19937ar.c:186-206 */
+{
+    const double r = ((double) (w0 >> 5) * 67108864.0 + (double) (w1 >> 6)) * (1.0 / 9007199254740992.0);
+    return a + (b - a) * r;
+}
+
+/* ---- MT19937 word stream (hip/mt_kernels.hip) ----------------------------------------------------------------------------- */
+int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src, uint32_t *dst, int count, void *st)
+{
+    (void) st;
+    for (int i = 0; i < count; ++i) nla_mt_apply_jump_host(poly, src + (size_t) i * NLA_MT_N, dst + (size_t) i * NLA_MT_N);
+    return 0;
+}
+int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_first, uint64_t count, uint32_t *out, void *st)
+{
+    const uint64_t g_end = g_first + count;
+    (void) st;
+    for (int s = 0; s < nseg; ++s) {
+        uint32_t mt[NLA_MT_N];
+        const uint64_t g0 = (seg_first + (uint64_t) s) * NLA_MT_SEG_WORDS;
+        memcpy(mt, seg_states + (size_t) s * NLA_MT_N, sizeof mt);
+        for (int r = 0; r < NLA_MT_SEG_REGENS; ++r) {
+            const uint64_t gb = g0 + (uint64_t) r * NLA_MT_N;
+            if (gb >= g_end) break;
+            if (gb + NLA_MT_N > g_first)
+                for (int i = 0; i < NLA_MT_N; ++i) { const uint64_t g = gb + (uint64_t) i; if (g >= g_first && g < g_end) out[g - g_first] = nla_mt_temper(mt[i]); }
+            nla_mt_regen(mt);
+        }
+    }
+    return 0;
+}
+
+/* ---- rows from the stream, evaluation (hip/crs_kernels.hip: crs_init_rows_kernel, eval_kernel) ------------------------------ */
+int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t row_first,
+                        int64_t nrows, double *X, double *F, void *st)
+{
+    (void) st;
+    for (int64_t r = 0; r < nrows; ++r) {
+        double *x = X + (size_t) (row_first + r) * (size_t) ld;
+        const uint32_t *w = words + (size_t) r * 2 * (size_t) n;
+        for (int i = 0; i < n; ++i) x[i] = urand_from(lb[i], ub[i], w[2 * i], w[2 * i + 1]);
+        if (obj >= 0) F[row_first + r] = nla_obj_eval_seq(obj, (unsigned) n, x, NULL);
+    }
+    return 0;
+}
+int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F, void *st)
+{
+    (void) st;
+    for (int64_t c = 0; c < count; ++c) F[c] = nla_obj_eval_seq(obj, (unsigned) n, P + (size_t) c * (size_t) ld, NULL);
+    return 0;
+}
+
+/* ---- MLSL (hip/mlsl_kernels.hip) --------------------------------------------------------------------------------------------- */
+int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const double *ub, const uint32_t *V, uint32_t index_first, int count, double *P, void *st)
+{
+    (void) st;
+    for (int r = 0; r < count; ++r) {
+        const uint32_t k = index_first + (uint32_t) r;
+        for (int i = 0; i < n; ++i) {
+            uint32_t g = k ^ (k >> 1), acc = 0;
+            while (g) { const int c = __builtin_ctz(g); acc ^= V[(size_t) c * (size_t) n + (size_t) i]; g &= g - 1; }
+            P[(size_t) r * (size_t) ld + (size_t) i] = lb[i] + (ub[i] - lb[i]) * ((double) acc / 4294967296.0);
+        }
+    }
+    return 0;
+}
+int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *st)
+{
+    (void) st;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) {
+            double d = 0.;
+            for (int k = 0; k < n; ++k) { const double dx = A[(size_t) i * ld + k] - B[(size_t) j * ld + k]; d += dx * dx; }   /* mlsl.c:118-127 */
+            D[(size_t) i * (size_t) nb + (size_t) j] = d;
+        }
+    return 0;
+}
+int nla_k_mlsl_rowmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const double *init, double *out, void *st)
+{
+    (void) st;
+    for (int i = 0; i < na; ++i) {
+        double m = HUGE_VAL;
+        for (int j = 0; j < nb; ++j) if (FB[j] < FA[i]) { const double d = D[(size_t) i * ldd + j]; m = d < m ? d : m; }
+        { const double b = init ? init[i] : HUGE_VAL; out[i] = m < b ? m : b; }
+    }
+    return 0;
+}
+int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const int32_t *skip, double *inout, void *st)
+{
+    (void) st;
+    if (na <= 0) return 0;
+    for (int j = 0; j < nb; ++j) {
+        double m;
+        if (skip && skip[j]) continue;
+        m = inout[j];
+        for (int i = 0; i < na; ++i) if (FA[i] < FB[j]) { const double d = D[(size_t) i * ldd + j]; m = d < m ? d : m; }
+        inout[j] = m;
+    }
+    return 0;
+}
+int nla_k_mlsl_gather_rows(int n, int ld, const double *src, const int64_t *idx, int count, double *dst, void *st)
+{
+    (void) st;
+    for (int c = 0; c < count; ++c) memmove(dst + (size_t) c * ld, src + (size_t) idx[c] * (size_t) ld, sizeof(double) * (size_t) n);
+    return 0;
+}
+int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, int count, const double *lb, const double *ub, double thr,
+                          int32_t *flags, void *st)
+{
+    (void) st;
+    for (int c = 0; c < count; ++c) {
+        const double *x = P + (size_t) idx[c] * (size_t) ld;
+        int hit = 0;
+        for (int j = 0; j < n && !hit; ++j) if ((x[j] - lb[j] <= thr || ub[j] - x[j] <= thr) && ub[j] - lb[j] > thr) hit = 1;   /* mlsl.c:211-218 */
+        flags[c] = hit;
+    }
+    return 0;
+}
+
+/* ---- local optimisers: the oracle ports stand in for the batched kernels ------------------------------------------------------ */
+typedef struct { int obj; long calls; } emu_obj;
+static double emu_objective(unsigned n, const double *x, double *grad, void *p)
+{
+    emu_obj *o = (emu_obj *) p;
+    ++o->calls;
+    return nla_obj_eval_seq(o->obj, n, x, grad);
+}
+size_t nla_lbfgs_work_doubles(int ld, int mf, int count) { (void) ld; (void) mf; (void) count; return 8; }
+size_t nla_lbfgs_hist_doubles(int ld, int mf, int count) { (void) ld; (void) mf; (void) count; return 8; }
+size_t nla_mma_work_doubles(int ld, int count) { (void) ld; (void) count; return 8; }
+static void local_stop(orc_stop *s, int n, double minf_max, double ftol_rel, double ftol_abs, double xtol_rel, int maxeval)
+{
+    orc_stop_default(s, (unsigned) n);
+    s->minf_max = minf_max; s->ftol_rel = ftol_rel; s->ftol_abs = ftol_abs; s->xtol_rel = xtol_rel; s->maxeval = maxeval; s->nevals = 0;
+}
+int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X, double *work, int *iwork,
+                      double *hist, const nla_lbfgs_params *P, nla_lbfgs_result *out, void *st)
+{
+    (void) work; (void) iwork; (void) hist; (void) st;
+    for (int i = 0; i < count; ++i) {
+        emu_obj o = { obj, 0 };
+        orc_stop s;
+        double minf = HUGE_VAL;
+        local_stop(&s, n, P->minf_max, P->ftol_rel, P->ftol_abs, P->xtol_rel, P->maxeval);
+        out[i].ret = orc_lbfgs_minimize(n, emu_objective, &o, lb, ub, X + (size_t) i * ld, &minf, &s, mf, P->tolg);
+        out[i].f = minf; out[i].nevals = (int32_t) s.nevals; out[i].iterm = 0; out[i].cols = 0;
+    }
+    return 0;
+}
+int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const double *ub, const double *sigma_init, double *X, double *work,
+                    const nla_mma_params *P, nla_lbfgs_result *out, void *st)
+{
+    (void) work; (void) st;
+    for (int i = 0; i < count; ++i) {
+        emu_obj o = { obj, 0 };
+        orc_stop s;
+        orc_mma_params m;
+        double minf = HUGE_VAL;
+        local_stop(&s, n, P->minf_max, P->ftol_rel, P->ftol_abs, P->xtol_rel, P->maxeval);
+        memset(&m, 0, sizeof m);
+        m.rho_init = P->rho_init; m.sigma_min = P->sigma_min; m.inner_maxeval = P->inner_maxeval; m.inner_gradients = P->inner_gradients;
+        m.always_improve = P->always_improve; m.sigma_init = sigma_init;
+        out[i].ret = orc_mma_minimize(n, emu_objective, &o, lb, ub, X + (size_t) i * ld, &minf, &s, &m);
+        out[i].f = minf; out[i].nevals = (int32_t) s.nevals; out[i].iterm = (int32_t) o.calls; out[i].cols = 0;
+    }
+    return 0;
+}
+
+/* ---- ISRES (hip/isres_kernels.hip) ---------------------------------------------------------------------------------------------- */
+int nla_k_isres_init(int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t k_first, int64_t count,
+                     const double *x0, double *X, double *S, void *st)
+{
+    const double sq = sqrt((double) n);
+    (void) st;
+    for (int64_t kl = 0; kl < count; ++kl) {
+        const int64_t k = k_first + kl;
+        const uint32_t *w = words + (size_t) kl * 2 * (size_t) n;
+        for (int j = 0; j < n; ++j) {
+            X[(size_t) k * ld + j] = (k == 0) ? x0[j] : urand_from(lb[j], ub[j], w[2 * j], w[2 * j + 1]);
+            S[(size_t) k * ld + j] = (ub[j] - lb[j]) / sq;
+        }
+    }
+    return 0;
+}
+int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t pop, int m, int p, const nla_dev_constraint *con, double *F,
+                     double *PEN, double *GPEN, int32_t *FEAS, void *st)
+{
+    (void) st;
+    for (int64_t k = 0; k < pop; ++k) {                                       /* isres.c:138-166 */
+        const double *x = X + (size_t) k * (size_t) ld;
+        double pen = 0, gpen = 0;
+        int feas = 1;
+        F[k] = nla_obj_eval_seq(obj, (unsigned) n, x, NULL);
+        for (int c = 0; c < m + p; ++c) {
+            double g = nla_con_blocksum_seq((unsigned) n, x, NULL, con[c].q, con[c].Q);
+            if (c == m) gpen = pen;
+            if (c < m) { if (g > con[c].tol) feas = 0; if (g < 0) g = 0; pen += g * g; }
+            else { if (fabs(g) > con[c].tol) feas = 0; pen += g * g; }
+        }
+        if (p == 0) gpen = pen;
+        PEN[k] = pen; GPEN[k] = gpen; FEAS[k] = feas;
+    }
+    return 0;
+}
+/* ranking elements: own layout (rank_count and stochrank below are the only users): [63] penalty == 0 | [62:42] rank of the
+ * penalty | [41:21] rank of f | [20:0] individual */
+#define EL(idx, rf, rp, z) (((uint64_t) ((z) ? 1 : 0) << 63) | ((uint64_t) (rp) << 42) | ((uint64_t) (rf) << 21) | (uint64_t) (idx))
+#define EL_IDX(e) ((uint32_t) ((e) & 0x1FFFFFu))
+#define EL_RF(e) ((uint32_t) (((e) >> 21) & 0x1FFFFFu))
+#define EL_RP(e) ((uint32_t) (((e) >> 42) & 0x1FFFFFu))
+#define EL_Z(e) ((int) ((e) >> 63))
+int nla_k_isres_rank_count(int64_t pop, const double *F, const double *PEN, uint64_t *elems, int32_t *sorted, void *st)
+{
+    (void) st;
+    for (int64_t k = 0; k < pop; ++k) {
+        uint32_t rf = 0, rp = 0, ps = 0;
+        for (int64_t j = 0; j < pop; ++j) {
+            rf += F[j] < F[k];
+            rp += PEN[j] < PEN[k];
+            ps += (F[j] < F[k]) || (F[j] == F[k] && j < k);                   /* stable sort position (qsort_r.c:190, merge sort) */
+        }
+        elems[k] = EL((uint32_t) k, rf, rp, PEN[k] == 0);
+        sorted[ps] = (int32_t) k;
+    }
+    return 0;
+}
+int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_t pop, uint64_t *bits, void *st)
+{
+    const int64_t popm1 = pop - 1, rowwords = (popm1 + 63) / 64;
+    (void) st;
+    if (popm1 <= 0) return 0;
+    for (int r = 0; r < nrows; ++r) {
+        uint64_t *row = bits + (size_t) (row_first + r) * (size_t) rowwords;
+        const uint32_t *w = words + (size_t) r * 2 * (size_t) popm1;
+        memset(row, 0, sizeof(uint64_t) * (size_t) rowwords);
+        for (int64_t j = 0; j < popm1; ++j)
+            if (urand_from(0., 1., w[2 * j], w[2 * j + 1]) < 0.45) row[j >> 6] |= 1ULL << (j & 63);        /* PF, isres.c:72,210 */
+    }
+    return 0;
+}
+int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
+                          uint8_t *swapped, int32_t *irank, void *st)
+{
+    const int64_t rowwords = (pop - 1 + 63) / 64;
+    (void) progress; (void) ticket; (void) st;
+    for (int64_t i = 0; i < nsweeps && pop > 1; ++i) {                        /* isres.c:206-228, every sweep (the driver cuts) */
+        int sw = 0;
+        for (int64_t j = 0; j < pop - 1; ++j) {
+            const uint64_t a = streams[j], b = streams[j + 1];
+            const int ulow = (int) ((bits[(size_t) i * (size_t) rowwords + (size_t) (j >> 6)] >> (j & 63)) & 1);
+            const int gt = (ulow || (EL_Z(a) && EL_Z(b))) ? EL_RF(a) > EL_RF(b) : EL_RP(a) > EL_RP(b);
+            if (gt) { streams[j] = b; streams[j + 1] = a; sw = 1; }
+        }
+        swapped[i] = (uint8_t) sw;
+    }
+    for (int64_t k = 0; k < pop; ++k) irank[k] = (int32_t) EL_IDX(streams[k]);
+    return 0;
+}
+int nla_k_isres_nrand(const uint32_t *words, int64_t nattempts, int64_t attempt_base, int32_t *counts, int64_t *ztotal, int64_t zbase,
+                      double *z, int64_t *zatt, void *st)
+{
+    int64_t cnt = 0;
+    (void) counts; (void) st;
+    for (int64_t a = 0; a < nattempts; ++a) {                                 /* nlopt_nrand(0,1), mt19937ar.c:216-232 */
+        const uint32_t *w = words + 4 * a;
+        const double v1 = urand_from(-1., 1., w[0], w[1]), v2 = urand_from(-1., 1., w[2], w[3]);
+        const double s = v1 * v1 + v2 * v2;
+        if (s >= 1.0) continue;
+        z[zbase + cnt] = (s == 0) ? 0.0 : 0.0 + v1 * sqrt(-2 * log(s) / s) * 1.0;
+        zatt[zbase + cnt] = attempt_base + a;
+        ++cnt;
+    }
+    *ztotal += cnt;
+    return 0;
+}
+int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *inv, void *st)
+{
+    (void) st;
+    for (int64_t k = 0; k < pop; ++k) inv[irank[k]] = (int32_t) k;
+    return 0;
+}
+/* the serial evolve kernel's contract: individuals state[0].. in order, deviates from z[state[1]..); an individual whose deviates
+ * run out is not written at all and state[2] = 1 */
+int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau, const double *lb,
+                       const double *ub, const double *z, const int32_t *irank, double *X, double *S, double *scratch, int64_t *state, void *st)
+{
+    const double ALPHA = 0.2, GAMMA = 0.85, sqn = sqrt((double) n);
+    int64_t k = state[0], pos = state[1], kend = phase == 0 ? pop : survivors;
+    double *xo = (double *) malloc(sizeof(double) * 2 * (size_t) n), *so = xo + n;
+    int ranout = 0;
+    (void) st;
+    if (!xo) return EMU_ERR;
+    if (state[14] > 0 && state[14] < kend) kend = state[14];
+    if (phase == 1 && k == 0) memcpy(scratch, X, sizeof(double) * (size_t) n);           /* memcpy(x0, xs, n), isres.c:253 */
+    for (; k < kend; ++k) {
+        const int64_t rk = irank[k], ri = phase == 0 ? irank[k % survivors] : rk;
+        const int lastsurv = (k + 1 == survivors);
+        const double *xi = X + (size_t) ri * ld, *si = S + (size_t) ri * ld, *xk1 = X + (size_t) (k + 1) * ld;
+        int64_t cur;
+        double taup_rand;
+        if (pos >= zcount) { ranout = 1; break; }
+        taup_rand = taup * z[pos];
+        cur = pos + 1;
+        for (int j = 0; j < n && !ranout; ++j) {
+            double xnew = xi[j], snew = si[j];
+            int mutate = 1;
+            if (phase == 1) {
+                if (!lastsurv) xnew = xi[j] + GAMMA * (scratch[j] - xk1[j]);      /* physical row k+1, possibly rewritten (isres.c:260) */
+                mutate = lastsurv || xnew < lb[j] || xnew > ub[j];
+            }
+            if (mutate) {
+                const double sigmamax = (ub[j] - lb[j]) / sqn;
+                double sg;
+                int t = 1;
+                if (cur + 1 >= zcount) { ranout = 1; break; }
+                sg = si[j] * exp(taup_rand + tau * z[cur]);
+                if (sg > sigmamax) sg = sigmamax;
+                for (;;) {
+                    if (cur + t >= zcount) { ranout = 1; break; }
+                    xnew = xi[j] + sg * z[cur + t];
+                    if (!(xnew < lb[j] || xnew > ub[j])) break;
+                    ++t;
+                }
+                if (ranout) break;
+                snew = si[j] + ALPHA * (sg - si[j]);
+                cur += 1 + t;
+            }
+            xo[j] = xnew; so[j] = snew;
+        }
+        if (ranout) break;
+        memcpy(X + (size_t) rk * ld, xo, sizeof(double) * (size_t) n);
+        memcpy(S + (size_t) rk * ld, so, sizeof(double) * (size_t) n);
+        pos = cur;
+    }
+    free(xo);
+    state[0] = k; state[1] = pos; state[2] = ranout;
+    return 0;
+}
+int nla_isres_evolve2_supported(int n) { (void) n; return 0; }               /* the driver then takes the serial kernel above */
+size_t nla_isres_evolve2_ws_bytes(int n) { (void) n; return 16; }
+int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                              const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
+                              double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
+{
+    (void) n; (void) ld; (void) phase; (void) pop; (void) survivors; (void) zcount; (void) taup; (void) tau; (void) lb; (void) ub; (void) z;
+    (void) irank; (void) inv; (void) X; (void) S; (void) x0c; (void) state; (void) rho; (void) ws; (void) rounds; (void) st;
+    return EMU_ERR;
+}

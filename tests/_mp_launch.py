@@ -19,14 +19,14 @@ def free_port():
     return p
 
 
-def run_world(case, args=None, world=2, timeout=600):
+def run_world(case, args=None, world=2, timeout=600, extra_env=None):
     tmp = tempfile.mkdtemp(prefix="nla_mp_")
     out = os.path.join(tmp, "res")
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_mp_worker.py"), case, out, json.dumps(args or {})],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []

@@ -20,6 +20,9 @@ def main():
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import nlopt_amd
+    if os.environ.get("NLA_TEST_EMU_DEVICE"):
+        # the product's host drivers over the CPU stand-in for the device layer (oracle/emu_device.c): test-side switch only
+        nlopt_amd.LIB_PATH = os.path.join(ROOT, "oracle", "libnlopt_amd_emu.so")
     import _oracle as O
     comm = nlopt_amd.Comm.from_torch_distributed()
     res = {}
@@ -52,6 +55,10 @@ def main():
         obj, n, seed = args["obj"], args["n"], args["seed"]
         xs, lo, hi = O.golden_x0(obj, n)
         alg = {"gpu_crs": nlopt_amd.GN_CRS2_LM, "gpu_isres": nlopt_amd.GN_ISRES, "gpu_mlsl": nlopt_amd.G_MLSL}[case]
+        if case == "gpu_mlsl" and args.get("lds"):
+            alg = nlopt_amd.G_MLSL_LDS
+        if case == "gpu_mlsl" and args.get("local") == "default":      # GD_MLSL(_LDS): the dispatcher's default local optimiser
+            alg = nlopt_amd.GD_MLSL_LDS if args.get("lds") else nlopt_amd.GD_MLSL
         o = nlopt_amd.Opt(alg, n)
         o.set_lower_bounds(lo)
         o.set_upper_bounds(hi)
@@ -61,8 +68,10 @@ def main():
         o.set_maxeval(args["maxeval"])
         if case == "gpu_isres" and args.get("ncon"):
             o.add_blocksum_constraints(args["ncon"], 1e-8)
-        if case == "gpu_mlsl":
-            loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, n)
+        if case == "gpu_mlsl" and args.get("local") == "default":
+            o.set_ftol_rel(1e-8)
+        elif case == "gpu_mlsl":
+            loc = nlopt_amd.Opt(nlopt_amd.LD_MMA if args.get("local") == "mma" else nlopt_amd.LD_LBFGS, n)
             loc.set_ftol_rel(1e-8)
             nlopt_amd.lib().nlopt_set_local_optimizer(o._h, loc._h)
         if args.get("sharded", True):

@@ -42,3 +42,45 @@ def test_crs_driver_sharded_init_world2_matches_oracle(obj, n, pop, seed, maxeva
         assert np.array_equal(d["row"], p["trace"]["row"]) and np.array_equal(d["accepted"], p["trace"]["accepted"])
         assert np.array_equal(d["f"], p["trace"]["f"]) and np.array_equal(d["x"], p["x"]) and d["minf"][0] == p["minf"]
         assert d["collectives"][0] == 2         # rows + f, once
+
+
+# ---- the product's ISRES / MLSL host drivers over the CPU stand-in for the device layer (oracle/emu_device.c) -------------------
+EMU = dict(NLA_TEST_EMU_DEVICE="1")
+
+
+def _check_against_oracle(d, p, nsamp_kind=None):
+    assert d["ret"][0] == p["ret"] and d["nevals"][0] == p["nevals"]
+    assert d["minf"][0] == p["minf"] and np.array_equal(d["x"], p["x"])
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("obj,n,pop,seed,ncon,gens", [("rastrigin", 12, 60, 5, 2, 6), ("griewank", 7, 0, 11, 0, 3), ("ackley", 20, 45, 2, 3, 5)])
+def test_isres_driver_over_emulated_device_matches_oracle(world, obj, n, pop, seed, ncon, gens):
+    """ISRES, evaluation sharded over the ranks + 4 all-gathers per generation: every rank reproduces the oracle's evaluation
+    sequence (f and penalty of every candidate, bit for bit), result and stream position"""
+    effpop = pop or 20 * (n + 1)
+    a = dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=gens * effpop, ncon=ncon)
+    p = O.run_port_isres(obj, n, pop, seed, nineq=ncon, maxeval=gens * effpop)
+    for d in run_world("gpu_isres", a, world=world, extra_env=EMU):
+        _check_against_oracle(d, p)
+        assert np.array_equal(d["f"], p["ftrace"][:len(d["f"])]) and len(d["f"]) == len(p["ftrace"])
+        if world > 1:
+            assert d["collectives"][0] == 4 * gens
+
+
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("obj,n,ns,seed,local,lds,maxeval", [
+    ("rastrigin", 5, 12, 5, "lbfgs", False, 1500), ("griewank", 6, 40, 3, "lbfgs", False, 3000), ("ackley", 8, 0, 9, "mma", False, 2500),
+    ("levy", 4, 16, 7, "mma", True, 1200), ("rosenbrock", 4, 12, 9, "lbfgs", True, 2000), ("rastrigin", 6, 20, 11, "default", False, 3000),
+    ("sphere", 5, 6, 2, "default", True, 400)])
+def test_mlsl_driver_over_emulated_device_matches_oracle(world, obj, n, ns, seed, local, lds, maxeval):
+    """MLSL with LD_LBFGS / LD_MMA, pseudo-random and Sobol sampling, local searches dealt over the ranks and all-gathered: the
+    batched, speculative walk of mlsl_driver.c commits exactly what the serial reference commits — same samples, same local
+    minima with the same evaluation counts, in the same order"""
+    a = dict(obj=obj, n=n, pop=ns, seed=seed, maxeval=maxeval, local=local, lds=lds)
+    p = O.run_port_mlsl(obj, n, ns, seed, maxeval=maxeval, local="mma" if local == "default" else local, lds=lds)
+    for d in run_world("gpu_mlsl", a, world=world, extra_env=EMU):
+        _check_against_oracle(d, p)
+        samp, loc = d["kind"] == 3, d["kind"] == 4
+        assert np.array_equal(d["f"][samp], p["fsamp"][:samp.sum()]) and samp.sum() in (len(p["fsamp"]), len(p["fsamp"]) - 1)
+        assert np.array_equal(d["f"][loc], p["floc"]) and np.array_equal(d["accepted"][loc], p["eloc"])
