@@ -35,6 +35,21 @@
 /* constraint ids */
 #define NLA_CON_BLOCKSUM   0   /* g_q(x) = sum_{i in block q of Q} x_i - 1 <= 0 */
 
+/* sin / cos as the objectives call them.  On the host they go through functions the optimiser cannot look into: glibc's
+ * sincos() and cos() (or sin()) round differently for some arguments (glibc 2.35: cos(2 pi 0.5939350286162490) differs in the
+ * last bit), and whether gcc merges a sin and a cos of one argument into a sincos call depends on inlining, loop versioning and
+ * the -O level — so this same source gave f values one ulp apart in different translation units (the product's callbacks vs
+ * the oracle's).  Behind these wrappers every host build calls libm's plain cos / sin.  Device code is unaffected. */
+#if defined(__HIPCC__)
+#define NLA_COS(x) cos(x)
+#define NLA_SIN(x) sin(x)
+#else
+static __attribute__((noinline, noclone, unused)) double nla_libm_cos(double x) { return cos(x); }
+static __attribute__((noinline, noclone, unused)) double nla_libm_sin(double x) { return sin(x); }
+#define NLA_COS(x) nla_libm_cos(x)
+#define NLA_SIN(x) nla_libm_sin(x)
+#endif
+
 #define NLA_PI2 6.283185307179586   /* 2*pi, same literal as test/testfuncs.c:32 */
 #define NLA_PI3 9.424777960769379   /* 3*pi, test/testfuncs.c:33 */
 #define NLA_E   2.718281828459045
@@ -42,10 +57,10 @@
 NLA_HD double nla_sqr(double x) { return x * x; }
 
 /* ---- per-element terms (shared host/device) ------------------------------------------------- */
-NLA_HD double nla_rastrigin_term(double x) { return x * x - 10.0 * cos(NLA_PI2 * x); }
-NLA_HD double nla_ackley_cos_term(double x) { return cos(NLA_PI2 * x); }
+NLA_HD double nla_rastrigin_term(double x) { return x * x - 10.0 * NLA_COS(NLA_PI2 * x); }
+NLA_HD double nla_ackley_cos_term(double x) { return NLA_COS(NLA_PI2 * x); }
 NLA_HD double nla_griewank_sum_term(double x) { return nla_sqr(x) * 0.00025; }
-NLA_HD double nla_griewank_prod_term(double x, unsigned i) { return cos(x / sqrt(i + 1.)); }
+NLA_HD double nla_griewank_prod_term(double x, unsigned i) { return NLA_COS(x / sqrt(i + 1.)); }
 NLA_HD double nla_rosenbrock_term(double xi, double xi1)
 {
     double a = xi1 - xi * xi, b = 1 - xi;
@@ -54,14 +69,14 @@ NLA_HD double nla_rosenbrock_term(double xi, double xi1)
 /* Levy body term for i < n-1: (x_i - 1)^2 (1 + sin^2(3 pi x_{i+1})) */
 NLA_HD double nla_levy_term(double xi, double xi1)
 {
-    double a = xi - 1, b = 1 + nla_sqr(sin(NLA_PI3 * xi1));
+    double a = xi - 1, b = 1 + nla_sqr(NLA_SIN(NLA_PI3 * xi1));
     return nla_sqr(a) * b;
 }
 /* Levy head: sin^2(3 pi x_0) + (x_{n-1} - 1)(1 + sin^2(2 pi x_{n-1})) */
 NLA_HD double nla_levy_head(double x0, double xl)
 {
-    double a = xl - 1, b = 1 + nla_sqr(sin(NLA_PI2 * xl));
-    return nla_sqr(sin(NLA_PI3 * x0)) + a * b;
+    double a = xl - 1, b = 1 + nla_sqr(NLA_SIN(NLA_PI2 * xl));
+    return nla_sqr(NLA_SIN(NLA_PI3 * x0)) + a * b;
 }
 NLA_HD double nla_ackley_finish(double sumsq, double sumcos, unsigned n)
 {
@@ -91,7 +106,7 @@ static inline double nla_obj_eval_seq(int id, unsigned n, const double *x, doubl
         double f = 10.0 * n;
         for (i = 0; i < n; ++i) {
             f += nla_rastrigin_term(x[i]);
-            if (grad) grad[i] = 2 * x[i] + 10.0 * NLA_PI2 * sin(NLA_PI2 * x[i]);
+            if (grad) grad[i] = 2 * x[i] + 10.0 * NLA_PI2 * NLA_SIN(NLA_PI2 * x[i]);
         }
         return f;
     }
@@ -103,7 +118,7 @@ static inline double nla_obj_eval_seq(int id, unsigned n, const double *x, doubl
             e1 = exp(-0.2 * r);
             e2 = exp(c / n);
             for (i = 0; i < n; ++i) {
-                double g = e2 * NLA_PI2 * sin(NLA_PI2 * x[i]) / n;
+                double g = e2 * NLA_PI2 * NLA_SIN(NLA_PI2 * x[i]) / n;
                 if (r > 0) g += 4.0 * e1 * x[i] / (n * r);   /* d/dx of -20 exp(-0.2 r); r=0 guarded */
                 grad[i] = g;
             }
@@ -139,17 +154,17 @@ static inline double nla_obj_eval_seq(int id, unsigned n, const double *x, doubl
     case NLA_OBJ_LEVY: {       /* test/testfuncs.c:218-240 */
         double f = nla_levy_head(x[0], x[n - 1]);
         if (grad) {
-            double a = x[n - 1] - 1, b = 1 + nla_sqr(sin(NLA_PI2 * x[n - 1]));
+            double a = x[n - 1] - 1, b = 1 + nla_sqr(NLA_SIN(NLA_PI2 * x[n - 1]));
             for (i = 0; i < n; ++i) grad[i] = 0;
-            grad[0] = 2 * NLA_PI3 * sin(NLA_PI3 * x[0]) * cos(NLA_PI3 * x[0]);
-            grad[n - 1] += b + a * 2 * NLA_PI2 * sin(NLA_PI2 * x[n - 1]) * cos(NLA_PI2 * x[n - 1]);
+            grad[0] = 2 * NLA_PI3 * NLA_SIN(NLA_PI3 * x[0]) * NLA_COS(NLA_PI3 * x[0]);
+            grad[n - 1] += b + a * 2 * NLA_PI2 * NLA_SIN(NLA_PI2 * x[n - 1]) * NLA_COS(NLA_PI2 * x[n - 1]);
         }
         for (i = 0; i + 1 < n; ++i) {
             f += nla_levy_term(x[i], x[i + 1]);
             if (grad) {
-                double a = x[i] - 1, b = 1 + nla_sqr(sin(NLA_PI3 * x[i + 1]));
+                double a = x[i] - 1, b = 1 + nla_sqr(NLA_SIN(NLA_PI3 * x[i + 1]));
                 grad[i] += 2 * a * b;
-                grad[i + 1] += 2 * NLA_PI3 * nla_sqr(a) * sin(NLA_PI3 * x[i + 1]) * cos(NLA_PI3 * x[i + 1]);
+                grad[i + 1] += 2 * NLA_PI3 * nla_sqr(a) * NLA_SIN(NLA_PI3 * x[i + 1]) * NLA_COS(NLA_PI3 * x[i + 1]);
             }
         }
         return f;

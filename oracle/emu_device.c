@@ -288,18 +288,24 @@ int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *
                           uint8_t *swapped, int32_t *irank, void *st)
 {
     const int64_t rowwords = (pop - 1 + 63) / 64;
+    /* the kernel leaves streams[0..pop) — the elements in initial order — untouched (the driver re-runs the ranking with fewer
+     * sweeps after an early exit, isres.c:227): sweep on a copy */
+    uint64_t *cur = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (pop > 0 ? pop : 1));
     (void) progress; (void) ticket; (void) st;
+    if (!cur) return EMU_ERR;
+    memcpy(cur, streams, sizeof(uint64_t) * (size_t) pop);
     for (int64_t i = 0; i < nsweeps && pop > 1; ++i) {                        /* isres.c:206-228, every sweep (the driver cuts) */
         int sw = 0;
         for (int64_t j = 0; j < pop - 1; ++j) {
-            const uint64_t a = streams[j], b = streams[j + 1];
+            const uint64_t a = cur[j], b = cur[j + 1];
             const int ulow = (int) ((bits[(size_t) i * (size_t) rowwords + (size_t) (j >> 6)] >> (j & 63)) & 1);
             const int gt = (ulow || (EL_Z(a) && EL_Z(b))) ? EL_RF(a) > EL_RF(b) : EL_RP(a) > EL_RP(b);
-            if (gt) { streams[j] = b; streams[j + 1] = a; sw = 1; }
+            if (gt) { cur[j] = b; cur[j + 1] = a; sw = 1; }
         }
         swapped[i] = (uint8_t) sw;
     }
-    for (int64_t k = 0; k < pop; ++k) irank[k] = (int32_t) EL_IDX(streams[k]);
+    for (int64_t k = 0; k < pop; ++k) irank[k] = (int32_t) EL_IDX(cur[k]);
+    free(cur);
     return 0;
 }
 int nla_k_isres_nrand(const uint32_t *words, int64_t nattempts, int64_t attempt_base, int32_t *counts, int64_t *ztotal, int64_t zbase,

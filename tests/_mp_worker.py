@@ -83,6 +83,73 @@ def main():
         res = dict(ret=np.array([ret]), minf=np.array([minf]), x=x, nevals=np.array([o.get_numevals()]), f=t["f"], row=t["row"],
                    kind=t["kind"], accepted=t["accepted"], collectives=np.array([comm.counters()["collectives"]]),
                    gathered_bytes=np.array([comm.counters()["bytes"]]), after=np.array([nlopt_amd.lib().nla_genrand_int32()], dtype=np.uint64))
+    elif case == "emu_sweep":
+        # drawn configurations of the ISRES and MLSL host drivers over the emulated device, each checked against the oracle here
+        # (every rank runs the same draws; the multi-rank runs shard them)
+        L = nlopt_amd.lib()
+        checked = 0
+        for draw in range(args["first"], args["first"] + args["count"]):
+            rng = np.random.default_rng(4242 + draw)
+            obj = ["rastrigin", "ackley", "griewank", "rosenbrock", "levy", "sphere"][int(rng.integers(6))]
+            n = int(rng.integers(2, 16))
+            seed = int(rng.integers(1, 2 ** 31))
+            xs, lo, hi = O.golden_x0(obj, n)
+            # ISRES
+            pop = int(rng.integers(6, 70))
+            ncon = int(rng.integers(0, 3)) if n >= 4 else 0
+            neq = int(rng.integers(0, 2)) if n >= 4 else 0
+            me = int(rng.integers(pop, 9 * pop))
+            kw = {}
+            if rng.random() < 0.3:
+                kw["stopval"] = float(rng.uniform(0.5, 50.0))
+            o = nlopt_amd.Opt(nlopt_amd.GN_ISRES, n)
+            o.set_lower_bounds(lo); o.set_upper_bounds(hi); o.set_min_objective(nlopt_amd.objective(obj))
+            o.set_population(pop); o.set_maxeval(me)
+            if "stopval" in kw:
+                o.set_stopval(kw["stopval"])
+            if ncon:
+                o.add_blocksum_constraints(ncon, 1e-8)
+            if neq:
+                o.add_blocksum_constraints(neq, 1e-8, True)
+            o.set_comm(comm)
+            o.enable_trace(me + 64)
+            nlopt_amd.srand(seed)
+            x, minf, ret = o.optimize_raw(xs)
+            p = O.run_port_isres(obj, n, pop, seed, nineq=ncon, neq=neq, maxeval=me, **kw)
+            t = o.trace()
+            assert (ret, o.get_numevals(), minf) == (p["ret"], p["nevals"], p["minf"]), ("isres", draw, ret, p["ret"], o.get_numevals(), p["nevals"])
+            assert np.array_equal(x, p["x"]) and np.array_equal(t["f"], p["ftrace"]), ("isres", draw)
+            assert L.nla_genrand_int32() == O.port().orc_genrand_int32(), ("isres stream position", draw)
+            # MLSL
+            ns = int(rng.integers(0, 40))
+            lds = bool(rng.random() < 0.5)
+            local = ["lbfgs", "mma"][int(rng.integers(2))]
+            me = int(rng.integers(200, 4000))
+            tol = 10.0 ** -int(rng.integers(4, 10))
+            lme = int(rng.integers(5, 60)) if rng.random() < 0.3 else 0
+            o = nlopt_amd.Opt(nlopt_amd.G_MLSL_LDS if lds else nlopt_amd.G_MLSL, n)
+            o.set_lower_bounds(lo); o.set_upper_bounds(hi); o.set_min_objective(nlopt_amd.objective(obj))
+            loc = nlopt_amd.Opt(nlopt_amd.LD_MMA if local == "mma" else nlopt_amd.LD_LBFGS, n)
+            loc.set_ftol_rel(tol)
+            if lme:
+                loc.set_maxeval(lme)
+            L.nlopt_set_local_optimizer(o._h, loc._h)
+            if ns:
+                o.set_population(ns)
+            o.set_maxeval(me)
+            o.set_comm(comm)
+            o.enable_trace(me + 4096)
+            nlopt_amd.srand(seed)
+            x, minf, ret = o.optimize_raw(xs)
+            p = O.run_port_mlsl(obj, n, ns, seed, maxeval=me, local=local, lds=lds, local_ftol_rel=tol, local_maxeval=lme)
+            t = o.trace()
+            assert (ret, o.get_numevals(), minf) == (p["ret"], p["nevals"], p["minf"]), ("mlsl", draw, local, lds, ret, p["ret"], o.get_numevals(), p["nevals"])
+            assert np.array_equal(x, p["x"]), ("mlsl", draw)
+            locs = t[t["kind"] == 4]
+            assert np.array_equal(locs["f"], p["floc"]) and np.array_equal(locs["accepted"], p["eloc"]), ("mlsl local searches", draw)
+            assert L.nla_genrand_int32() == O.port().orc_genrand_int32(), ("mlsl stream position", draw)
+            checked += 1
+        res = dict(checked=np.array([checked]))
     else:
         raise SystemExit("unknown case " + case)
     np.savez(out + ".rank%d.npz" % rank, **res)

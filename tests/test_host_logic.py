@@ -166,3 +166,29 @@ def test_sobol_points_by_index_equal_the_stateful_walk():
         L.nla_sobol_point01(3, V.ctypes.data, k + 1, O.dptr(x))
         assert np.array_equal(x, O.port_sobol_points(3, n_skip, 1)[0])
     assert L.nla_sobol_directions(1112, np.zeros(32 * 1112, dtype=np.uint32).ctypes.data) == 0
+
+
+def test_host_callbacks_are_bit_identical_to_the_oracles():
+    """the objective zoo is one source (objfuncs.h) compiled into the product and into the oracle; glibc's sincos() rounds
+    differently from cos() / sin() for some arguments and gcc merges the calls depending on optimisation level, which once made the
+    two builds differ in the last bit (f = 100.75937443450825 vs ...823 for Rastrigin at a 4-d point).  Value and gradient, with
+    and without a gradient request, must agree exactly."""
+    FT = C.CFUNCTYPE(C.c_double, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+    L, P = nlopt_amd.lib(), O.port()
+    L.nlopt_amd_objective.restype = C.c_void_p
+    L.nlopt_amd_objective.argtypes = [C.c_int]
+    P.orc_objective.restype = C.c_void_p
+    P.orc_objective.argtypes = [C.c_int]
+    rng = np.random.default_rng(0)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    x0 = np.array([4.2152877590035569, -3.5179279536925359, 0.59393502861624903, 4.1945617962291282])
+    assert FT(L.nlopt_amd_objective(0))(4, dp(x0), None, None) == FT(P.orc_objective(0))(4, dp(x0), None, None) == 100.75937443450823
+    for oid in range(6):
+        fa, fb = FT(L.nlopt_amd_objective(oid)), FT(P.orc_objective(oid))
+        for _ in range(400):
+            n = int(rng.integers(2, 40))
+            x = rng.uniform(-6, 6, n)
+            ga, gb = np.zeros(n), np.zeros(n)
+            va, vb = fa(n, dp(x), None, None), fb(n, dp(x), None, None)
+            assert va == vb == fa(n, dp(x), dp(ga), None) == fb(n, dp(x), dp(gb), None)
+            assert np.array_equal(ga, gb)

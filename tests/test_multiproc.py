@@ -84,3 +84,13 @@ def test_mlsl_driver_over_emulated_device_matches_oracle(world, obj, n, ns, seed
         samp, loc = d["kind"] == 3, d["kind"] == 4
         assert np.array_equal(d["f"][samp], p["fsamp"][:samp.sum()]) and samp.sum() in (len(p["fsamp"]), len(p["fsamp"]) - 1)
         assert np.array_equal(d["f"][loc], p["floc"]) and np.array_equal(d["accepted"][loc], p["eloc"])
+
+
+@pytest.mark.parametrize("world,first", [(1, 0), (1, 15), (2, 30), (3, 40)])
+def test_drawn_configurations_of_the_isres_and_mlsl_drivers_over_the_emulated_device(world, first):
+    """objective, dimension, population / samples, seed, constraints, stop value, local optimiser + tolerance + its own evaluation
+    limit, Sobol or pseudo-random sampling — drawn; each run compared with the oracle inside the worker (result, evaluation count,
+    every candidate / local minimum, position of the generator afterwards)"""
+    count = 15 if world == 1 else 10
+    for d in run_world("emu_sweep", dict(first=first, count=count), world=world, extra_env=EMU, timeout=900):
+        assert d["checked"][0] == count
