@@ -6,8 +6,8 @@
  * memory, streams and events are tokens, every launcher does its kernel's job with plain loops in the REFERENCE's operation
  * order (objectives through objfuncs.h's sequential formulas, local searches through the oracle ports) — so a driver run over
  * this layer must reproduce the oracle evaluation by evaluation, bit for bit.  The multi-start evolve of ISRES is reported as
- * unsupported so the driver takes its serial-kernel path; CRS2_LM has its own engine emulation (port_emu_engine.c) and ESCH is
- * not covered: their launchers here return an error.
+ * unsupported so the driver takes its serial-kernel path; ESCH is not covered: its launchers are generated stubs that return an
+ * error.  (CRS2_LM's driver additionally has its own engine-level emulation, port_emu_engine.c.)
  *
  * Linked with the product's C sources into oracle/libnlopt_amd_emu.so (make emudev).  The product library never sees this file;
  * only tests load the emulated library (by path).
@@ -397,4 +397,86 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
     (void) n; (void) ld; (void) phase; (void) pop; (void) survivors; (void) zcount; (void) taup; (void) tau; (void) lb; (void) ub; (void) z;
     (void) irank; (void) inv; (void) X; (void) S; (void) x0c; (void) state; (void) rho; (void) ws; (void) rounds; (void) st;
     return EMU_ERR;
+}
+
+/* ---- CRS2_LM (hip/crs_kernels.hip): the per-kernel CPU references of port_kernels.c behind the launchers' ring / slot addressing,
+ * so that crs_engine.c (batches, rings, pending commits, kernel-argument lists) runs too ------------------------------------------ */
+void orc_k_vitter(int n, int64_t N, const uint32_t *words, int nblocks, int32_t *jn, int32_t *pos, int32_t *last);
+void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *words, const double *lb, const double *ub, double *out);
+int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last, const int64_t *W, int nun,
+                       int t0, const double *lb, const double *ub, double *acc);
+
+int nla_k_crs_vitter(int n, int64_t N, const uint32_t *words, int nblocks, int32_t *jn, int32_t *pos, int32_t *last, void *st)
+{
+    (void) st;
+    orc_k_vitter(n, N, words, nblocks, jn, pos, last);
+    return 0;
+}
+int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring, const int32_t *pos_ring, const int32_t *last_ring,
+                      uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W, int nW, const int32_t *t_in, int32_t *t_out,
+                      int slot_mask, const double *lb, const double *ub, double *TX, int variant, void *st)
+{
+    (void) variant; (void) st;
+    for (int a = 0; a < K; ++a) {
+        const uint64_t block = first_block + (uint64_t) a;
+        const uint32_t rb = (uint32_t) (block % ring_blocks);
+        const int q = (int) (block & (uint64_t) slot_mask);
+        t_out[a] = orc_k_advance_slot(n, ld, X, i0, jn_ring[rb], pos_ring + (size_t) rb * (size_t) n, last_ring[rb], W, a < nW ? a : nW,
+                                      t_in[a], lb, ub, TX + (size_t) q * (size_t) ld);
+    }
+    return 0;
+}
+int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring, const int32_t *pos_ring,
+                           const int32_t *last_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *h_W, int nW,
+                           const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *TX, int variant, void *st)
+{
+    return nla_k_crs_advance(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, h_W, nW, h_t_in, t_out, slot_mask, lb, ub, TX, variant, st);
+}
+int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
+                     uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
+                     const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
+{
+    (void) st;
+    for (int a = 0; a < K; ++a) {
+        const uint64_t block = first_block + (uint64_t) a;
+        const int q = (int) (block & (uint64_t) slot_mask);
+        const int t1 = t_out[a], newly = (t1 == n) && t_in[a] != n;
+        const double *x = TX + (size_t) q * (size_t) ld;
+        double fT = 0, fM = 0;
+        if (obj >= 0) {
+            if (newly) {
+                double *m = TM + (size_t) q * (size_t) ld;
+                fT = fT_ring[q] = nla_obj_eval_seq(obj, (unsigned) n, x, NULL);                       /* crs.c:133 */
+                orc_k_mutate(n, X + (size_t) i0 * (size_t) ld, x, words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n, lb, ub, m);
+                fM = fM_ring[q] = nla_obj_eval_seq(obj, (unsigned) n, m, NULL);                       /* crs.c:139-146 */
+            } else if (t1 == n) { fT = fT_ring[q]; fM = fM_ring[q]; }
+        }
+        status[a].fT = fT; status[a].fM = fM; status[a].t = t1; status[a].pad = 0;
+    }
+    return 0;
+}
+int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
+                          uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
+                          const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
+{
+    return nla_k_crs_finish(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, h_t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, st);
+}
+int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *slot, const int32_t *kind,
+                     const int64_t *row, void *st)
+{
+    (void) st;
+    for (int c = 0; c < ncommit; ++c)                                                                  /* crs.c:153 */
+        memmove(X + (size_t) row[c] * (size_t) ld, (kind[c] == 1 ? TX : TM) + (size_t) slot[c] * (size_t) ld, sizeof(double) * (size_t) n);
+    return 0;
+}
+int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *h_slot, const int32_t *h_kind,
+                          const int64_t *h_row, void *st)
+{
+    return nla_k_crs_commit(n, ld, X, TX, TM, ncommit, h_slot, h_kind, h_row, st);
+}
+int nla_k_crs_mutate(int n, const double *best, double *p, const uint32_t *words, const double *lb, const double *ub, void *st)
+{
+    (void) st;
+    orc_k_mutate(n, best, p, words, lb, ub, p);
+    return 0;
 }

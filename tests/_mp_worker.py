@@ -94,6 +94,43 @@ def main():
             n = int(rng.integers(2, 16))
             seed = int(rng.integers(1, 2 ** 31))
             xs, lo, hi = O.golden_x0(obj, n)
+            # CRS2_LM: the whole product path (crs_driver.c over crs_engine.c over the emulated launchers)
+            cn = int(rng.integers(1, 30))
+            cpop = int(rng.integers(cn + 1, 10 * cn + 30))
+            cme = int(rng.integers(cpop + 10, cpop + 2500))
+            cxs, clo, chi = O.golden_x0(obj, cn)
+            ckw = {}
+            r = rng.random()
+            if r < 0.25:
+                ckw["ftol_rel"] = 10.0 ** -int(rng.integers(2, 8))
+            elif r < 0.4:
+                ckw["xtol_rel"] = 10.0 ** -int(rng.integers(2, 6))
+            o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, cn)
+            o.set_lower_bounds(clo); o.set_upper_bounds(chi); o.set_min_objective(nlopt_amd.objective(obj))
+            o.set_population(cpop); o.set_maxeval(cme)
+            if "ftol_rel" in ckw:
+                o.set_ftol_rel(ckw["ftol_rel"])
+            if "xtol_rel" in ckw:
+                o.set_xtol_rel(ckw["xtol_rel"])
+            wf = float(rng.choice([0.0, 0.5, 1.5, 3.0, 12.0]))
+            ms = int(rng.choice([0, 0, 1, 2, 9, 200]))
+            if wf:
+                o.set_param("amd_window_factor", wf)
+            if ms:
+                o.set_param("amd_max_spec", ms)
+            if rng.random() < 0.2:
+                o.set_param("amd_host_eval", 1)
+            o.set_comm(comm)
+            o.enable_trace(cme + 64)
+            nlopt_amd.srand(seed)
+            x, minf, ret = o.optimize_raw(cxs)
+            p = O.run_port_crs(obj, cn, cpop, seed, maxeval=cme, trace_cap=cme + 64, **ckw)
+            t = o.trace()
+            assert (ret, o.get_numevals(), minf) == (p["ret"], p["nevals"], p["minf"]), ("crs", draw, cn, cpop, wf, ms, ret, p["ret"], o.get_numevals(), p["nevals"])
+            assert np.array_equal(x, p["x"]), ("crs x", draw)
+            for key in ("f", "row", "kind", "accepted"):
+                assert np.array_equal(t[key], p["trace"][key]), ("crs trace", key, draw, cn, cpop, wf, ms)
+            assert L.nla_genrand_int32() == O.port().orc_genrand_int32(), ("crs stream position", draw)
             # ISRES
             pop = int(rng.integers(6, 70))
             ncon = int(rng.integers(0, 3)) if n >= 4 else 0

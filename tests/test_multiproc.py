@@ -86,11 +86,12 @@ def test_mlsl_driver_over_emulated_device_matches_oracle(world, obj, n, ns, seed
         assert np.array_equal(d["f"][loc], p["floc"]) and np.array_equal(d["accepted"][loc], p["eloc"])
 
 
-@pytest.mark.parametrize("world,first", [(1, 0), (1, 15), (2, 30), (3, 40)])
-def test_drawn_configurations_of_the_isres_and_mlsl_drivers_over_the_emulated_device(world, first):
-    """objective, dimension, population / samples, seed, constraints, stop value, local optimiser + tolerance + its own evaluation
+@pytest.mark.parametrize("world,first,env", [(1, 0, {}), (1, 15, {"NLA_CRS_UPLOAD": "1", "NLA_CRS_COPY_STATUS": "1"}), (2, 30, {}), (3, 40, {})])
+def test_drawn_configurations_of_the_host_drivers_over_the_emulated_device(world, first, env):
+    """CRS2_LM (whole product path incl. crs_engine.c: window factor, speculation cap, host-callback mode, the alternative list /
+    status transports), ISRES and MLSL: objective, dimension, population / samples, seed, constraints, stop value, local optimiser + tolerance + its own evaluation
     limit, Sobol or pseudo-random sampling — drawn; each run compared with the oracle inside the worker (result, evaluation count,
     every candidate / local minimum, position of the generator afterwards)"""
     count = 15 if world == 1 else 10
-    for d in run_world("emu_sweep", dict(first=first, count=count), world=world, extra_env=EMU, timeout=900):
+    for d in run_world("emu_sweep", dict(first=first, count=count), world=world, extra_env=dict(EMU, **env), timeout=900):
         assert d["checked"][0] == count
