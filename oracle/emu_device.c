@@ -6,8 +6,8 @@
  * memory, streams and events are tokens, every launcher does its kernel's job with plain loops in the REFERENCE's operation
  * order (objectives through objfuncs.h's sequential formulas, local searches through the oracle ports) — so a driver run over
  * this layer must reproduce the oracle evaluation by evaluation, bit for bit.  The multi-start evolve of ISRES is reported as
- * unsupported so the driver takes its serial-kernel path; ESCH is not covered: its launchers are generated stubs that return an
- * error.  (CRS2_LM's driver additionally has its own engine-level emulation, port_emu_engine.c.)
+ * unsupported so the driver takes its serial-kernel path.  (CRS2_LM's driver additionally has its own engine-level emulation,
+ * port_emu_engine.c.)
  *
  * Linked with the product's C sources into oracle/libnlopt_amd_emu.so (make emudev).  The product library never sees this file;
  * only tests load the emulated library (by path).
@@ -478,5 +478,99 @@ int nla_k_crs_mutate(int n, const double *best, double *p, const uint32_t *words
 {
     (void) st;
     orc_k_mutate(n, best, p, words, lb, ub, p);
+    return 0;
+}
+
+/* ---- ESCH (hip/esch_kernels.hip) — the serial loops of esch.c behind the launchers' contracts ------------------------------------ */
+static int esch_attempt(uint32_t w0, uint32_t w1, double *v01)            /* one attempt of randcauchy (esch.c:28-50), folded to [0,1] */
+{
+    const double u = urand_from(0., 1., w0, w1);
+    const double c = 1.0 * tan((u - 0.5) * 3.14159265358979323846) + 0.0;
+    double f;
+    if ((c < 0.0 - (10.0 * 0.5)) || (c > 0.0 + (10.0 * 0.5))) return 0;
+    f = (c < 0) ? -c : c + (10.0 * 0.5);
+    *v01 = f / 10.0;
+    return 1;
+}
+int nla_k_esch_cauchy(const uint32_t *words, int64_t nattempts, int64_t attempt_base, int32_t *counts, int64_t *vtotal, int64_t vbase,
+                      int64_t vcap, double *v, int64_t *vatt, void *st)
+{
+    int64_t cnt = 0;
+    (void) counts; (void) st;
+    for (int64_t a = 0; a < nattempts; ++a) {
+        double val;
+        if (!esch_attempt(words[2 * a], words[2 * a + 1], &val)) continue;
+        if (vbase + cnt < vcap) { v[vbase + cnt] = val; vatt[vbase + cnt] = attempt_base + a; }
+        ++cnt;
+    }
+    *vtotal += cnt;
+    return 0;
+}
+int nla_k_esch_fill_rows(int n, int ld, const double *lb, const double *ub, const double *v, int64_t e0, int64_t count, double *R, void *st)
+{
+    (void) st;
+    for (int64_t e = e0; e < e0 + count; ++e) {
+        const int64_t id = e / n;
+        const int item = (int) (e - id * n);
+        R[(size_t) id * ld + item] = lb[item] + (ub[item] - lb[item]) * v[e - e0];
+    }
+    return 0;
+}
+int nla_k_esch_crossover(int n, int ld, int64_t np, int64_t no, const uint32_t *words, const int32_t *slot, double *R, void *st)
+{
+    (void) st;
+    for (int64_t id = 0; id < no; ++id) {                                  /* esch.c:192-203 */
+        const uint32_t *w = words + 3 * id;
+        const int64_t p1 = (int64_t) (w[0] % (uint32_t) np), p2 = (int64_t) (w[1] % (uint32_t) np);
+        const int cross = (int) (w[2] % (uint32_t) n);
+        const double *a = R + (size_t) slot[p1] * ld, *b = R + (size_t) slot[p2] * ld;
+        double *o = R + (size_t) slot[np + id] * ld;
+        for (int j = 0; j < n; ++j) o[j] = j < cross ? a[j] : b[j];
+    }
+    return 0;
+}
+size_t nla_esch_mut_scratch_bytes(int64_t M) { (void) M; return 16; }
+int nla_k_esch_mutate(const uint32_t *W, int64_t M, int64_t total, int n, int ld, int64_t np, int64_t no, const double *lb, const double *ub,
+                      const int32_t *slot, double *R, int32_t *last, void *scratch, int64_t *out, void *st)
+{
+    int64_t p = 0, c = 0;
+    (void) last; (void) scratch; (void) st;
+    out[0] = 0; out[1] = 0;
+    while (c < total) {                                                    /* esch.c:207-218: iurand(no), iurand(n), randcauchy */
+        int64_t q = p + 2;
+        double v = 0;
+        int ok = 0;
+        if (p + 1 >= M) break;
+        for (; q + 1 < M; q += 2) if (esch_attempt(W[q], W[q + 1], &v)) { ok = 1; break; }
+        if (!ok) break;                                                    /* the segment ends inside this step: the caller retries longer */
+        {
+            const int64_t io = (int64_t) (W[p] % (uint32_t) no);
+            const int ip = (int) (W[p + 1] % (uint32_t) n);
+            R[(size_t) slot[np + io] * ld + ip] = lb[ip] + (ub[ip] - lb[ip]) * v;
+        }
+        p = q + 2;
+        ++c;
+    }
+    out[0] = c; out[1] = p;
+    return 0;
+}
+int nla_k_esch_gather_rows(int n, int ld, const int32_t *slot, int64_t i0, int64_t count, const double *R, double *G, void *st)
+{
+    (void) st;
+    for (int64_t i = 0; i < count; ++i) memmove(G + (size_t) i * ld, R + (size_t) slot[i0 + i] * ld, sizeof(double) * (size_t) n);
+    return 0;
+}
+size_t nla_esch_sort_scratch_bytes(int64_t count) { (void) count; return 16; }
+int nla_k_esch_select(int64_t count, const int32_t *slot_in, const double *fit_in, int32_t *slot_out, double *fit_out, void *scratch,
+                      size_t scratch_bytes, void *st)
+{
+    /* stable ascending order by fitness (esch.c:243: nlopt_qsort_r = glibc's merge sort): insertion into the sorted prefix after
+     * every element that is not greater */
+    (void) scratch; (void) scratch_bytes; (void) st;
+    for (int64_t i = 0; i < count; ++i) {
+        int64_t k = i;
+        while (k > 0 && fit_out[k - 1] > fit_in[i]) { fit_out[k] = fit_out[k - 1]; slot_out[k] = slot_out[k - 1]; --k; }
+        fit_out[k] = fit_in[i]; slot_out[k] = slot_in[i];
+    }
     return 0;
 }

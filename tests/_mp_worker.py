@@ -131,6 +131,31 @@ def main():
             for key in ("f", "row", "kind", "accepted"):
                 assert np.array_equal(t[key], p["trace"][key]), ("crs trace", key, draw, cn, cpop, wf, ms)
             assert L.nla_genrand_int32() == O.port().orc_genrand_int32(), ("crs stream position", draw)
+            # ESCH
+            en = int(rng.integers(1, 24))
+            epop = int(rng.integers(0, 50))
+            eme = int(rng.integers(50, 3000))
+            exs, elo, ehi = O.golden_x0(obj, en)
+            ekw = {}
+            if rng.random() < 0.25:
+                ekw["stopval"] = float(rng.uniform(0.1, 30.0))
+            o = nlopt_amd.Opt(nlopt_amd.GN_ESCH, en)
+            o.set_lower_bounds(elo); o.set_upper_bounds(ehi); o.set_min_objective(nlopt_amd.objective(obj))
+            if epop:
+                o.set_population(epop)
+            o.set_maxeval(eme)
+            if "stopval" in ekw:
+                o.set_stopval(ekw["stopval"])
+            if rng.random() < 0.2:
+                o.set_param("amd_host_eval", 1)
+            o.enable_trace(eme + 64)
+            nlopt_amd.srand(seed)
+            x, minf, ret = o.optimize_raw(exs)
+            p = O.run_port_esch(obj, en, epop, seed, maxeval=eme, trace_cap=eme + 64, **ekw)
+            t = o.trace()
+            assert (ret, o.get_numevals(), minf) == (p["ret"], p["nevals"], p["minf"]), ("esch", draw, en, epop, ret, p["ret"], o.get_numevals(), p["nevals"])
+            assert np.array_equal(x, p["x"]) and np.array_equal(t["f"], p["trace"]["f"]), ("esch trace", draw)
+            assert L.nla_genrand_int32() == O.port().orc_genrand_int32(), ("esch stream position", draw)
             # ISRES
             pop = int(rng.integers(6, 70))
             ncon = int(rng.integers(0, 3)) if n >= 4 else 0
