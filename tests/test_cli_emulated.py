@@ -1,0 +1,51 @@
+"""CPU twins of tests/test_gpu_testopt_cli.py and tests/test_gpu_cpp_client.py: the reference's own command-line driver
+(test/testopt.c + test/testfuncs.c) and its own C++ client test (test/t_bounded.cxx through the generated nlopt.hpp), the
+binaries `make -C oracle cpptest` links against libnlopt_amd.so, run with the emulated library (oracle/libnlopt_amd_emu.so)
+preloaded — its nlopt_* symbols take precedence, so the product's API shell and host drivers serve the program over the CPU
+stand-in for the device layer.  Everything on that layer follows the reference's operation order with the host's libm: the
+printouts must be IDENTICAL to the reference build's for every algorithm of the path, not just to rounding."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+EMU = os.path.join(ROOT, "oracle", "libnlopt_amd_emu.so")
+need = pytest.mark.skipif(not all(os.path.exists(p) for p in (EMU, os.path.join(REFDIR, "testopt_amd"), os.path.join(REFDIR, "testopt_ref"),
+                                                             os.path.join(REFDIR, "t_bounded_amd"))), reason="oracle/_ref binaries or the emulated library not built")
+
+
+def run(exe, *args, preload=None):
+    env = dict(os.environ)
+    if preload:
+        env["LD_PRELOAD"] = preload
+    r = subprocess.run([os.path.join(REFDIR, exe)] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+    return r.returncode, [l for l in r.stdout.splitlines() if not l.startswith("finished after")], r.stderr
+
+
+@need
+@pytest.mark.parametrize("alg", [19, 35, 42])
+@pytest.mark.parametrize("obj,seed,maxeval", [(0, 0, 1000), (1, 3, 2000), (5, 7, 1500), (11, 1, 1500), (17, 2, 2500)])
+def test_testopt_identical_printout(alg, obj, seed, maxeval):
+    rc_e, out_e, err_e = run("testopt_amd", "-r", seed, "-a", alg, "-o", obj, "-e", maxeval, preload=EMU)
+    rc_r, out_r, _ = run("testopt_ref", "-r", seed, "-a", alg, "-o", obj, "-e", maxeval)
+    assert rc_e == rc_r == 0, err_e
+    assert out_e == out_r
+
+
+@need
+@pytest.mark.parametrize("alg", [19, 35, 42])
+def test_testopt_fixed_dimension_identical_printout(alg):
+    rc_e, out_e, err_e = run("testopt_amd", "-r", 5, "-a", alg, "-o", 5, "-e", 800, "-b", 1, preload=EMU)
+    rc_r, out_r, _ = run("testopt_ref", "-r", 5, "-a", alg, "-o", 5, "-e", 800, "-b", 1)
+    assert rc_e == rc_r == 0, err_e
+    assert out_e == out_r
+
+
+@need
+@pytest.mark.parametrize("alg", [19, 35, 42])
+def test_the_references_cpp_client_test_passes(alg):
+    """t_bounded.cxx: functor trampolines, munge hooks, maximisation through nlopt.hpp — exit code 0 as under ctest"""
+    rc, out, err = run("t_bounded_amd", alg, preload=EMU)
+    assert rc == 0, "\n".join(out) + err
