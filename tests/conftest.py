@@ -17,9 +17,13 @@ def pytest_configure(config):
     if not os.path.exists(lib):
         import nlopt_amd
         nlopt_amd.build()
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port", "emu"], check=True)
-    if os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libnlopt_ref.so")):
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port", "emu", "emudev"], check=True)
+    if os.path.isdir("/root/reference/src"):
+        ref = os.path.join(ROOT, "oracle", "_ref")
+        if not os.path.exists(os.path.join(ref, "libnlopt_ref.so")):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+        if not os.path.exists(os.path.join(ref, "testopt_amd")) or not os.path.exists(os.path.join(ref, "t_bounded_amd")):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "cpptest"], check=True)
 
 
 @pytest.fixture(scope="session")
