@@ -359,7 +359,7 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         out["gens_to_ftol"] = gens_to_ftol()
     except Exception as e:        # the headline line must still be printed
         out["gens_to_ftol"] = {"error": repr(e)}
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:                  # the CPU baseline is timed on rank 0 of the 1-GPU run only
         try:
             out["cpu_baseline"] = cpu_baseline_crs(a.obj, n, a.cpu_sample_pop or 20000, a.cpu_sample_trials, a.seed)
             if out["cpu_baseline"]["value"]:
@@ -448,7 +448,7 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
     }
     if comm is not None:
         out["collectives"] = comm.counters()
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:
         try:
             if a.workload == "isres":
                 out["cpu_baseline"] = cpu_baseline_isres(a.obj, n, a.cpu_sample_pop or 10000, a.seed, ncon)
