@@ -1,0 +1,50 @@
+"""bench.py's contract, checked on a machine without a GPU: the three workloads run at toy sizes with the product's host code
+over the emulated device layer (oracle/libnlopt_amd_emu.so, test-side switch) and must print ONE JSON line each carrying every
+key the driver and the judge read — incl. `roofline` and, at N = 1, `cpu_baseline`.  (The numbers mean nothing here.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "oracle", "libnlopt_amd_emu.so")
+SNIPPET = """
+import sys
+sys.path.insert(0, %r)
+import nlopt_amd
+nlopt_amd.LIB_PATH = %r
+import bench
+sys.argv = ["bench.py"] + %r
+bench.main()
+"""
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline")
+
+
+@pytest.mark.skipif(not os.path.exists(EMU), reason="emulated library not built")
+@pytest.mark.parametrize("argv", [
+    ["--n", "32", "--pop", "400", "--steps", "2", "--warmup", "1", "--evals-per-step", "150", "--cpu-sample-pop", "400", "--cpu-sample-trials", "100"],
+    ["--workload", "isres", "--n", "8", "--pop", "60", "--steps", "2", "--warmup", "1", "--cpu-sample-pop", "60"],
+    ["--workload", "mlsl", "--n", "6", "--pop", "30", "--steps", "2", "--warmup", "1"],
+    ["--workload", "mlsl", "--local", "mma", "--n", "6", "--pop", "30", "--steps", "2", "--warmup", "1"],
+])
+def test_bench_line_has_the_contracts_keys(argv):
+    r = subprocess.run([sys.executable, "-c", SNIPPET % (ROOT, EMU, argv)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["data"] == "synthetic"
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["unit"] == "evals/s" and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, (k, cb)
+    assert cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 0
