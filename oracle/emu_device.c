@@ -388,15 +388,34 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
     state[0] = k; state[1] = pos; state[2] = ranout;
     return 0;
 }
-int nla_isres_evolve2_supported(int n) { (void) n; return 0; }               /* the driver then takes the serial kernel above */
+/* The multi-start evolve (hip/isres_evolve2.hip) resolves up to 256 consecutive individuals per round and hands an individual
+ * it cannot resolve to the serial kernel (state[10] = 1).  With NLA_EMU_EVOLVE2 set the emulated device reports it as supported
+ * and plays that protocol — rounds of at most 256 individuals, an occasional forced hand-over (a fixed function of the
+ * individual's index), deviates running out mid-round — so that the driver's round / refill / fallback loop is exercised; the
+ * arithmetic is the serial routine's. */
+int nla_isres_evolve2_supported(int n) { return getenv("NLA_EMU_EVOLVE2") != NULL && n <= 1150; }
 size_t nla_isres_evolve2_ws_bytes(int n) { (void) n; return 16; }
+static int emu_forced_handover(int64_t k, int phase) { return (((uint32_t) k * 2654435761u + (uint32_t) phase * 977u) >> 7) % 53u == 0; }
 int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
                               const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
                               double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
 {
-    (void) n; (void) ld; (void) phase; (void) pop; (void) survivors; (void) zcount; (void) taup; (void) tau; (void) lb; (void) ub; (void) z;
-    (void) irank; (void) inv; (void) X; (void) S; (void) x0c; (void) state; (void) rho; (void) ws; (void) rounds; (void) st;
-    return EMU_ERR;
+    const int64_t kend = phase == 0 ? pop : survivors;
+    (void) inv; (void) rho; (void) ws;
+    for (int r = 0; r < rounds; ++r) {
+        int64_t first = state[0], limit, stop = first + 256 < kend ? first + 256 : kend;
+        int rc;
+        state[9] = 0;
+        if (state[2] || state[10] || first >= kend) continue;
+        if (emu_forced_handover(first, phase)) { state[10] = 1; continue; }
+        for (limit = first + 1; limit < stop && !emu_forced_handover(limit, phase); ++limit) { }
+        state[14] = limit;
+        rc = nla_k_isres_evolve(n, ld, phase, pop, survivors, zcount, taup, tau, lb, ub, z, irank, X, S, (double *) x0c, state, st);
+        state[14] = 0;
+        if (rc) return rc;
+        state[9] = state[0] - first;
+    }
+    return 0;
 }
 
 /* ---- CRS2_LM (hip/crs_kernels.hip): the per-kernel CPU references of port_kernels.c behind the launchers' ring / slot addressing,

@@ -86,10 +86,13 @@ def test_mlsl_driver_over_emulated_device_matches_oracle(world, obj, n, ns, seed
         assert np.array_equal(d["f"][loc], p["floc"]) and np.array_equal(d["accepted"][loc], p["eloc"])
 
 
-@pytest.mark.parametrize("world,first,env", [(1, 0, {}), (1, 15, {"NLA_CRS_UPLOAD": "1", "NLA_CRS_COPY_STATUS": "1"}), (2, 30, {}), (3, 40, {})])
+@pytest.mark.parametrize("world,first,env", [(1, 0, {}), (1, 15, {"NLA_CRS_UPLOAD": "1", "NLA_CRS_COPY_STATUS": "1"}), (2, 30, {}), (3, 40, {}),
+                                             (1, 50, {"NLA_EMU_EVOLVE2": "1"}), (2, 65, {"NLA_EMU_EVOLVE2": "1"})])
 def test_drawn_configurations_of_the_host_drivers_over_the_emulated_device(world, first, env):
     """CRS2_LM (whole product path incl. crs_engine.c: window factor, speculation cap, host-callback mode, the alternative list /
-    status transports), ISRES and MLSL: objective, dimension, population / samples, seed, constraints, stop value, local optimiser + tolerance + its own evaluation
+    status transports), ESCH, ISRES (with NLA_EMU_EVOLVE2 the emulated device plays the multi-start evolve's protocol — rounds of
+    at most 256 individuals, forced hand-overs to the serial kernel, deviates running out mid-round — so the driver's round / refill
+    / fallback loop runs) and MLSL: objective, dimension, population / samples, seed, constraints, stop value, local optimiser + tolerance + its own evaluation
     limit, Sobol or pseudo-random sampling — drawn; each run compared with the oracle inside the worker (result, evaluation count,
     every candidate / local minimum, position of the generator afterwards)"""
     count = 15 if world == 1 else 10
