@@ -117,7 +117,7 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     if (total < 1) total = 1;
 
     D.st = nla_stream_create();
-    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { efree(&D); return NLOPT_OUT_OF_MEMORY; }
+    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); efree(&D); return NLOPT_OUT_OF_MEMORY; }
     D.sscratch_bytes = nla_esch_sort_scratch_bytes(D.P);
     D.d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
@@ -144,7 +144,7 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
     {
         int32_t *ident = (int32_t *) malloc(sizeof(int32_t) * (size_t) D.P);
-        if (!ident) { efree(&D); return NLOPT_OUT_OF_MEMORY; }
+        if (!ident) { nla_stop_msg(stop, "nlopt_amd: out of memory"); efree(&D); return NLOPT_OUT_OF_MEMORY; }
         for (i = 0; i < D.P; ++i) ident[i] = (int32_t) i;
         if (nla_memcpy_h2d(D.d_lb, lb, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ub, sizeof(double) * (size_t) n, D.st) ||
             nla_memcpy_h2d(D.d_slot[0], ident, sizeof(int32_t) * (size_t) D.P, D.st) || nla_stream_sync(D.st)) {

@@ -309,7 +309,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     D.obj = nlopt_amd_objective_id(f);
     dev_eval = D.obj >= 0 && !(opt && nlopt_get_param(opt, "amd_host_eval", 0) != 0);
     con = (nla_dev_constraint *) calloc((size_t) (m + p + 1), sizeof *con);
-    if (!con) return NLOPT_OUT_OF_MEMORY;
+    if (!con) { nla_stop_msg(stop, "nlopt_amd: out of memory"); return NLOPT_OUT_OF_MEMORY; }
     for (c = 0; c < m + p; ++c) {
         const nla_constraint *cc = c < m ? fc + c : h + (c - m);
         if (cc->m > maxdim) maxdim = cc->m;
@@ -320,7 +320,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         } else dev_eval = 0;
     }
     results = (double *) malloc(sizeof(double) * maxdim);
-    if (!results) { free(con); return NLOPT_OUT_OF_MEMORY; }
+    if (!results) { nla_stop_msg(stop, "nlopt_amd: out of memory"); free(con); return NLOPT_OUT_OF_MEMORY; }
 
     D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
     D.comm = opt ? opt->comm : NULL;

@@ -103,11 +103,14 @@ static int grow_pts(mlsl_dev *d, size_t need)
     nF = (double *) nla_dev_malloc(sizeof(double) * ncap);
     nC = (double *) nla_dev_malloc(sizeof(double) * ncap);
     nM = (int32_t *) nla_dev_malloc(sizeof(int32_t) * ncap);
-    if (!d->F || !d->cpd || !d->cld || !d->minimized || !d->ord || !nP || !nF || !nC || !nM) MFAIL(d, "out of memory growing the point set");
-    if (d->npts) {
-        MCK(d, nla_memcpy_d2d(nP, d->d_P, sizeof(double) * d->npts * (size_t) d->ld, d->st));
-        MCK(d, nla_memcpy_d2d(nF, d->d_F, sizeof(double) * d->npts, d->st));
-        MCK(d, nla_stream_sync(d->st));
+    if (!d->F || !d->cpd || !d->cld || !d->minimized || !d->ord || !nP || !nF || !nC || !nM) {
+        nla_dev_free(nP); nla_dev_free(nF); nla_dev_free(nC); nla_dev_free(nM);
+        MFAIL(d, "out of memory growing the point set");
+    }
+    if (d->npts && (nla_memcpy_d2d(nP, d->d_P, sizeof(double) * d->npts * (size_t) d->ld, d->st) ||
+                    nla_memcpy_d2d(nF, d->d_F, sizeof(double) * d->npts, d->st) || nla_stream_sync(d->st))) {
+        nla_dev_free(nP); nla_dev_free(nF); nla_dev_free(nC); nla_dev_free(nM);
+        MFAIL(d, "copying the point set failed");
     }
     nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd); nla_dev_free(d->d_min);
     d->d_P = nP; d->d_F = nF; d->d_cpd = nC; d->d_min = nM;
@@ -125,11 +128,11 @@ static int grow_lms(mlsl_dev *d, size_t need)
     d->lord = (size_t *) realloc(d->lord, sizeof(size_t) * ncap);
     nL = (double *) nla_dev_malloc(sizeof(double) * ncap * (size_t) d->ld);
     nF = (double *) nla_dev_malloc(sizeof(double) * ncap);
-    if (!d->LF || !d->lord || !nL || !nF) MFAIL(d, "out of memory growing the local-minimum set");
-    if (d->nlms) {
-        MCK(d, nla_memcpy_d2d(nL, d->d_LM, sizeof(double) * d->nlms * (size_t) d->ld, d->st));
-        MCK(d, nla_memcpy_d2d(nF, d->d_LF, sizeof(double) * d->nlms, d->st));
-        MCK(d, nla_stream_sync(d->st));
+    if (!d->LF || !d->lord || !nL || !nF) { nla_dev_free(nL); nla_dev_free(nF); MFAIL(d, "out of memory growing the local-minimum set"); }
+    if (d->nlms && (nla_memcpy_d2d(nL, d->d_LM, sizeof(double) * d->nlms * (size_t) d->ld, d->st) ||
+                    nla_memcpy_d2d(nF, d->d_LF, sizeof(double) * d->nlms, d->st) || nla_stream_sync(d->st))) {
+        nla_dev_free(nL); nla_dev_free(nF);
+        MFAIL(d, "copying the local-minimum set failed");
     }
     nla_dev_free(d->d_LM); nla_dev_free(d->d_LF);
     d->d_LM = nL; d->d_LF = nF; d->lcap = ncap;
@@ -206,7 +209,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     mf = nla_lbfgs_default_mf(n, (int) local_opt->vector_storage, 0);
 
     D.st = nla_stream_create();
-    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { mfree(&D); return NLOPT_OUT_OF_MEMORY; }
+    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); mfree(&D); return NLOPT_OUT_OF_MEMORY; }
     D.d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (size_t) D.N);

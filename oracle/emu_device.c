@@ -25,19 +25,40 @@
 /* ---- runtime (hip/devrt.hip) --------------------------------------------------------------------------------------------- */
 int nla_dev_count(void) { return 1; }
 int nla_dev_set(int dev) { return dev == 0 ? 0 : EMU_ERR; }
-void *nla_dev_malloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
-void nla_dev_free(void *p) { free(p); }
-void *nla_host_malloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
-void nla_host_free(void *p) { free(p); }
+/* fault injection for the drivers' error paths: orc_emu_fail_alloc_at(k) makes the k-th allocation from now on (device or pinned
+ * host memory) fail once; 0 = never.  orc_emu_allocs() = allocations since that call. */
+static long emu_alloc_count = 0, emu_alloc_fail_at = 0, emu_live = 0;
+void orc_emu_fail_alloc_at(long k) { emu_alloc_count = 0; emu_alloc_fail_at = k; }
+long orc_emu_allocs(void) { return emu_alloc_count; }
+long orc_emu_live(void) { return emu_live; }         /* device / pinned buffers, streams and events not yet released */
+static void *emu_alloc(size_t bytes)
+{
+    void *p;
+    if (++emu_alloc_count == emu_alloc_fail_at) return NULL;
+    p = malloc(bytes ? bytes : 1);
+    if (p) ++emu_live;
+    return p;
+}
+static void emu_release(void *p) { if (p) { --emu_live; free(p); } }
+/* the same for kernel launches: the k-th nla_k_* call from now on returns an error instead of doing its job */
+static long emu_launch_count = 0, emu_launch_fail_at = 0;
+void orc_emu_fail_launch_at(long k) { emu_launch_count = 0; emu_launch_fail_at = k; }
+long orc_emu_launches(void) { return emu_launch_count; }
+static int emu_launch_fails(void) { return ++emu_launch_count == emu_launch_fail_at; }
+#define EMU_LAUNCH() do { if (emu_launch_fails()) return EMU_ERR; } while (0)
+void *nla_dev_malloc(size_t bytes) { return emu_alloc(bytes); }
+void nla_dev_free(void *p) { emu_release(p); }
+void *nla_host_malloc(size_t bytes) { return emu_alloc(bytes); }
+void nla_host_free(void *p) { emu_release(p); }
 int nla_memcpy_h2d(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
 int nla_memcpy_d2h(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
 int nla_memset(void *dst, int value, size_t bytes, void *st) { (void) st; if (bytes) memset(dst, value, bytes); return 0; }
-void *nla_stream_create(void) { return malloc(1); }
-void nla_stream_destroy(void *st) { free(st); }
+void *nla_stream_create(void) { return emu_alloc(1); }
+void nla_stream_destroy(void *st) { emu_release(st); }
 int nla_stream_sync(void *st) { (void) st; return 0; }
-void *nla_event_create(void) { return malloc(1); }
-void nla_event_destroy(void *ev) { free(ev); }
+void *nla_event_create(void) { return emu_alloc(1); }
+void nla_event_destroy(void *ev) { emu_release(ev); }
 int nla_event_record(void *ev, void *st) { (void) ev; (void) st; return 0; }
 int nla_event_sync(void *ev) { (void) ev; return 0; }
 float nla_event_elapsed_ms(void *a, void *b) { (void) a; (void) b; return 0.f; }
@@ -53,12 +74,14 @@ static double urand_from(double a, double b, uint32_t w0, uint32_t w1)       /* 
 /* ---- MT19937 word stream (hip/mt_kernels.hip) ----------------------------------------------------------------------------- */
 int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src, uint32_t *dst, int count, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int i = 0; i < count; ++i) nla_mt_apply_jump_host(poly, src + (size_t) i * NLA_MT_N, dst + (size_t) i * NLA_MT_N);
     return 0;
 }
 int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_first, uint64_t count, uint32_t *out, void *st)
 {
+    EMU_LAUNCH();
     const uint64_t g_end = g_first + count;
     (void) st;
     for (int s = 0; s < nseg; ++s) {
@@ -80,6 +103,7 @@ int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg, 
 int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t row_first,
                         int64_t nrows, double *X, double *F, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t r = 0; r < nrows; ++r) {
         double *x = X + (size_t) (row_first + r) * (size_t) ld;
@@ -91,6 +115,7 @@ int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, const double *
 }
 int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t c = 0; c < count; ++c) F[c] = nla_obj_eval_seq(obj, (unsigned) n, P + (size_t) c * (size_t) ld, NULL);
     return 0;
@@ -99,6 +124,7 @@ int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F
 /* ---- MLSL (hip/mlsl_kernels.hip) --------------------------------------------------------------------------------------------- */
 int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const double *ub, const uint32_t *V, uint32_t index_first, int count, double *P, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int r = 0; r < count; ++r) {
         const uint32_t k = index_first + (uint32_t) r;
@@ -112,6 +138,7 @@ int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const double *ub, con
 }
 int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int i = 0; i < na; ++i)
         for (int j = 0; j < nb; ++j) {
@@ -123,6 +150,7 @@ int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, in
 }
 int nla_k_mlsl_rowmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const double *init, double *out, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int i = 0; i < na; ++i) {
         double m = HUGE_VAL;
@@ -133,6 +161,7 @@ int nla_k_mlsl_rowmin(const double *D, int ldd, int na, int nb, const double *FA
 }
 int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA, const double *FB, const int32_t *skip, double *inout, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     if (na <= 0) return 0;
     for (int j = 0; j < nb; ++j) {
@@ -146,6 +175,7 @@ int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA
 }
 int nla_k_mlsl_gather_rows(int n, int ld, const double *src, const int64_t *idx, int count, double *dst, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int c = 0; c < count; ++c) memmove(dst + (size_t) c * ld, src + (size_t) idx[c] * (size_t) ld, sizeof(double) * (size_t) n);
     return 0;
@@ -153,6 +183,7 @@ int nla_k_mlsl_gather_rows(int n, int ld, const double *src, const int64_t *idx,
 int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, int count, const double *lb, const double *ub, double thr,
                           int32_t *flags, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int c = 0; c < count; ++c) {
         const double *x = P + (size_t) idx[c] * (size_t) ld;
@@ -182,6 +213,7 @@ static void local_stop(orc_stop *s, int n, double minf_max, double ftol_rel, dou
 int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X, double *work, int *iwork,
                       double *hist, const nla_lbfgs_params *P, nla_lbfgs_result *out, void *st)
 {
+    EMU_LAUNCH();
     (void) work; (void) iwork; (void) hist; (void) st;
     for (int i = 0; i < count; ++i) {
         emu_obj o = { obj, 0 };
@@ -196,6 +228,7 @@ int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *l
 int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const double *ub, const double *sigma_init, double *X, double *work,
                     const nla_mma_params *P, nla_lbfgs_result *out, void *st)
 {
+    EMU_LAUNCH();
     (void) work; (void) st;
     for (int i = 0; i < count; ++i) {
         emu_obj o = { obj, 0 };
@@ -216,6 +249,7 @@ int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const d
 int nla_k_isres_init(int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t k_first, int64_t count,
                      const double *x0, double *X, double *S, void *st)
 {
+    EMU_LAUNCH();
     const double sq = sqrt((double) n);
     (void) st;
     for (int64_t kl = 0; kl < count; ++kl) {
@@ -231,6 +265,7 @@ int nla_k_isres_init(int n, int ld, const double *lb, const double *ub, const ui
 int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t pop, int m, int p, const nla_dev_constraint *con, double *F,
                      double *PEN, double *GPEN, int32_t *FEAS, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t k = 0; k < pop; ++k) {                                       /* isres.c:138-166 */
         const double *x = X + (size_t) k * (size_t) ld;
@@ -257,6 +292,7 @@ int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t pop, int m
 #define EL_Z(e) ((int) ((e) >> 63))
 int nla_k_isres_rank_count(int64_t pop, const double *F, const double *PEN, uint64_t *elems, int32_t *sorted, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t k = 0; k < pop; ++k) {
         uint32_t rf = 0, rp = 0, ps = 0;
@@ -272,6 +308,7 @@ int nla_k_isres_rank_count(int64_t pop, const double *F, const double *PEN, uint
 }
 int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_t pop, uint64_t *bits, void *st)
 {
+    EMU_LAUNCH();
     const int64_t popm1 = pop - 1, rowwords = (popm1 + 63) / 64;
     (void) st;
     if (popm1 <= 0) return 0;
@@ -287,6 +324,7 @@ int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                           uint8_t *swapped, int32_t *irank, void *st)
 {
+    EMU_LAUNCH();
     const int64_t rowwords = (pop - 1 + 63) / 64;
     /* the kernel leaves streams[0..pop) — the elements in initial order — untouched (the driver re-runs the ranking with fewer
      * sweeps after an early exit, isres.c:227): sweep on a copy */
@@ -311,6 +349,7 @@ int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *
 int nla_k_isres_nrand(const uint32_t *words, int64_t nattempts, int64_t attempt_base, int32_t *counts, int64_t *ztotal, int64_t zbase,
                       double *z, int64_t *zatt, void *st)
 {
+    EMU_LAUNCH();
     int64_t cnt = 0;
     (void) counts; (void) st;
     for (int64_t a = 0; a < nattempts; ++a) {                                 /* nlopt_nrand(0,1), mt19937ar.c:216-232 */
@@ -327,6 +366,7 @@ int nla_k_isres_nrand(const uint32_t *words, int64_t nattempts, int64_t attempt_
 }
 int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *inv, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t k = 0; k < pop; ++k) inv[irank[k]] = (int32_t) k;
     return 0;
@@ -336,6 +376,7 @@ int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *inv, void *s
 int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau, const double *lb,
                        const double *ub, const double *z, const int32_t *irank, double *X, double *S, double *scratch, int64_t *state, void *st)
 {
+    EMU_LAUNCH();
     const double ALPHA = 0.2, GAMMA = 0.85, sqn = sqrt((double) n);
     int64_t k = state[0], pos = state[1], kend = phase == 0 ? pop : survivors;
     double *xo = (double *) malloc(sizeof(double) * 2 * (size_t) n), *so = xo + n;
@@ -400,6 +441,7 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
                               const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
                               double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
 {
+    EMU_LAUNCH();
     const int64_t kend = phase == 0 ? pop : survivors;
     (void) inv; (void) rho; (void) ws;
     for (int r = 0; r < rounds; ++r) {
@@ -427,6 +469,7 @@ int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, c
 
 int nla_k_crs_vitter(int n, int64_t N, const uint32_t *words, int nblocks, int32_t *jn, int32_t *pos, int32_t *last, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     orc_k_vitter(n, N, words, nblocks, jn, pos, last);
     return 0;
@@ -435,6 +478,7 @@ int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t 
                       uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W, int nW, const int32_t *t_in, int32_t *t_out,
                       int slot_mask, const double *lb, const double *ub, double *TX, int variant, void *st)
 {
+    EMU_LAUNCH();
     (void) variant; (void) st;
     for (int a = 0; a < K; ++a) {
         const uint64_t block = first_block + (uint64_t) a;
@@ -449,12 +493,14 @@ int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int
                            const int32_t *last_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *h_W, int nW,
                            const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *TX, int variant, void *st)
 {
+    EMU_LAUNCH();
     return nla_k_crs_advance(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, h_W, nW, h_t_in, t_out, slot_mask, lb, ub, TX, variant, st);
 }
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
                      uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
                      const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int a = 0; a < K; ++a) {
         const uint64_t block = first_block + (uint64_t) a;
@@ -478,11 +524,13 @@ int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, c
                           uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
                           const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
 {
+    EMU_LAUNCH();
     return nla_k_crs_finish(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, h_t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, st);
 }
 int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *slot, const int32_t *kind,
                      const int64_t *row, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int c = 0; c < ncommit; ++c)                                                                  /* crs.c:153 */
         memmove(X + (size_t) row[c] * (size_t) ld, (kind[c] == 1 ? TX : TM) + (size_t) slot[c] * (size_t) ld, sizeof(double) * (size_t) n);
@@ -491,10 +539,12 @@ int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *T
 int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *h_slot, const int32_t *h_kind,
                           const int64_t *h_row, void *st)
 {
+    EMU_LAUNCH();
     return nla_k_crs_commit(n, ld, X, TX, TM, ncommit, h_slot, h_kind, h_row, st);
 }
 int nla_k_crs_mutate(int n, const double *best, double *p, const uint32_t *words, const double *lb, const double *ub, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     orc_k_mutate(n, best, p, words, lb, ub, p);
     return 0;
@@ -514,6 +564,7 @@ static int esch_attempt(uint32_t w0, uint32_t w1, double *v01)            /* one
 int nla_k_esch_cauchy(const uint32_t *words, int64_t nattempts, int64_t attempt_base, int32_t *counts, int64_t *vtotal, int64_t vbase,
                       int64_t vcap, double *v, int64_t *vatt, void *st)
 {
+    EMU_LAUNCH();
     int64_t cnt = 0;
     (void) counts; (void) st;
     for (int64_t a = 0; a < nattempts; ++a) {
@@ -527,6 +578,7 @@ int nla_k_esch_cauchy(const uint32_t *words, int64_t nattempts, int64_t attempt_
 }
 int nla_k_esch_fill_rows(int n, int ld, const double *lb, const double *ub, const double *v, int64_t e0, int64_t count, double *R, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t e = e0; e < e0 + count; ++e) {
         const int64_t id = e / n;
@@ -537,6 +589,7 @@ int nla_k_esch_fill_rows(int n, int ld, const double *lb, const double *ub, cons
 }
 int nla_k_esch_crossover(int n, int ld, int64_t np, int64_t no, const uint32_t *words, const int32_t *slot, double *R, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t id = 0; id < no; ++id) {                                  /* esch.c:192-203 */
         const uint32_t *w = words + 3 * id;
@@ -552,6 +605,7 @@ size_t nla_esch_mut_scratch_bytes(int64_t M) { (void) M; return 16; }
 int nla_k_esch_mutate(const uint32_t *W, int64_t M, int64_t total, int n, int ld, int64_t np, int64_t no, const double *lb, const double *ub,
                       const int32_t *slot, double *R, int32_t *last, void *scratch, int64_t *out, void *st)
 {
+    EMU_LAUNCH();
     int64_t p = 0, c = 0;
     (void) last; (void) scratch; (void) st;
     out[0] = 0; out[1] = 0;
@@ -575,6 +629,7 @@ int nla_k_esch_mutate(const uint32_t *W, int64_t M, int64_t total, int n, int ld
 }
 int nla_k_esch_gather_rows(int n, int ld, const int32_t *slot, int64_t i0, int64_t count, const double *R, double *G, void *st)
 {
+    EMU_LAUNCH();
     (void) st;
     for (int64_t i = 0; i < count; ++i) memmove(G + (size_t) i * ld, R + (size_t) slot[i0 + i] * ld, sizeof(double) * (size_t) n);
     return 0;
@@ -583,6 +638,7 @@ size_t nla_esch_sort_scratch_bytes(int64_t count) { (void) count; return 16; }
 int nla_k_esch_select(int64_t count, const int32_t *slot_in, const double *fit_in, int32_t *slot_out, double *fit_out, void *scratch,
                       size_t scratch_bytes, void *st)
 {
+    EMU_LAUNCH();
     /* stable ascending order by fitness (esch.c:243: nlopt_qsort_r = glibc's merge sort): insertion into the sorted prefix after
      * every element that is not greater */
     (void) scratch; (void) scratch_bytes; (void) st;
