@@ -5,7 +5,8 @@
  * device kernel (hip/mma_kernels.hip): count = 1 from nlopt_optimize(LD_MMA), one workgroup per start from MLSL.
  *
  * Not provided, and refused with a message: nonlinear constraints (the dual problem then has variables and the
- * reference solves it with a nested optimiser), host-callback objectives, xtol_abs / x_weights. */
+ * reference solves it with a nested optimiser), host-callback objectives, xtol_abs / x_weights, and a run whose only stopping
+ * criterion is maxtime (the search is one kernel launch; the clock is watched between launches only). */
 #include "nla_internal.h"
 #include <math.h>
 #include <stdio.h>
@@ -40,6 +41,12 @@ nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, 
     (void) f_data;
     if ((rc = nla_mma_read_params(opt, &mma))) return (nlopt_result) rc;
     if (opt->m > 0) { nla_stop_msg(stop, "nlopt_amd: LD_MMA is provided without nonlinear constraints only (the MLSL local-search case)"); return NLOPT_INVALID_ARGS; }
+    /* the whole search is one kernel launch: it cannot watch the wall clock, so something it can test must be able to end it
+     * (MLSL gives its local optimiser tolerances when the caller did not, optimize.c:781-786) */
+    if (stop->ftol_rel <= 0 && stop->ftol_abs <= 0 && stop->xtol_rel <= 0 && stop->maxeval <= 0 && !(stop->minf_max > -HUGE_VAL)) {
+        nla_stop_msg(stop, "nlopt_amd: LD_MMA on the device needs a stopping criterion it can test (ftol, xtol_rel, maxeval or stopval); maxtime alone is not watched inside a search");
+        return NLOPT_INVALID_ARGS;
+    }
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
     if (obj < 0) { nla_stop_msg(stop, "nlopt_amd: LD_MMA is provided for device objectives (nlopt_amd_objective) only"); return NLOPT_INVALID_ARGS; }
     if (stop->xtol_abs || stop->x_weights) { nla_stop_msg(stop, "nlopt_amd: LD_MMA on the device does not take xtol_abs / x_weights"); return NLOPT_INVALID_ARGS; }

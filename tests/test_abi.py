@@ -115,3 +115,14 @@ def test_argument_errors_of_the_local_optimisers_come_before_any_device_work():
     o = mk(nlopt_amd.GN_MLSL)
     x, minf, ret = o.optimize_raw(np.zeros(3))
     assert ret == nlopt_amd.INVALID_ARGS and "COBYLA" in o.get_errmsg()
+
+
+def test_mma_without_a_testable_stopping_criterion_is_refused():
+    """a device-resident search cannot watch the wall clock: with maxtime as the only criterion LD_MMA would never return"""
+    o = nlopt_amd.Opt(nlopt_amd.LD_MMA, 3)
+    o.set_lower_bounds(-1.0)
+    o.set_upper_bounds(1.0)
+    o.set_min_objective(nlopt_amd.objective("sphere"))
+    o.set_maxtime(0.5)
+    x, minf, ret = o.optimize_raw(np.full(3, 0.5))
+    assert ret == nlopt_amd.INVALID_ARGS and "stopping criterion" in o.get_errmsg()
