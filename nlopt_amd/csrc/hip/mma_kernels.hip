@@ -83,9 +83,12 @@ __global__ __launch_bounds__(LB_T) void mma_batch_kernel(int n, int ld, int coun
             __syncthreads();
             fcur = lb_objgrad<OBJ>(n, xcur, dfdx_cur, S, oscratch);           /* mma.c:308 */
             ++nevals; ++inner_nevals; ++fcalls;
-            const int inner_done = (gval >= fcur) || (P.inner_maxeval > 0 && inner_nevals == P.inner_maxeval);
+            int inner_done = (gval >= fcur) || (P.inner_maxeval > 0 && inner_nevals == P.inner_maxeval);
             if (P.always_improve ? fcur < minf : inner_done) {               /* mma.c:329-331 with feasible = feasible_cur = 1 */
-                if (!P.inner_gradients) ++fcalls;                             /* the uncounted call with a gradient, mma.c:336-339 */
+                if (!P.inner_gradients) {
+                    ++fcalls;                                                 /* the uncounted call with a gradient, mma.c:336-339 */
+                    inner_done = gval >= fcur;                                /* mma.c:343: recomputed WITHOUT the inner_maxeval clause */
+                }
                 minf = fcur;
                 for (int j = tid; j < n; j += LB_T) { x[j] = xcur[j]; dfdx[j] = dfdx_cur[j]; }
             }

@@ -102,7 +102,8 @@ int orc_mma_minimize(int n, orc_func f, void *f_data, const double *lb, const do
                 if (!prm->inner_gradients) {
                     fcur = f((unsigned) n, xcur, dfdx_cur, f_data);         /* not counted, mma.c:336-339 */
                     if (stop->force_stop) { ret = ORC_FORCED_STOP; goto done; }
-                    /* mma.c:343: inner_done is recomputed from the same two numbers */
+                    inner_done = a.gval >= fcur;                           /* mma.c:343 — WITHOUT the inner_maxeval clause of :324: a
+                                                                              step that only ended because the inner limit was hit goes on */
                 }
                 *minf = fcur;
                 memcpy(x, xcur, sizeof(double) * (size_t) n);

@@ -116,6 +116,7 @@ MMA_CASES = [     # NLOPT_LD_MMA without nonlinear constraints (the GD_MLSL defa
     ("mma_rastrigin_n16_nograd", "rastrigin", 16, dict(ftol_rel=1e-9, params=dict(inner_gradients=0))),
     ("mma_levy_n7_original_rule", "levy", 7, dict(ftol_abs=1e-12, params=dict(always_improve=0, rho_init=0.1))),
     ("mma_rastrigin_n12_step", "rastrigin", 12, dict(ftol_rel=1e-9, step=0.3)),
+    ("mma_ackley_n6_nograd_innermax", "ackley", 6, dict(maxeval=300, params=dict(inner_gradients=0, inner_maxeval=1, always_improve=0))),
 ]
 MLSL_MMA_CASES = [   # (name, obj, n, ns, seed, alg, local, kw): local None = the dispatcher's default local optimiser
     ("gd_mlsl_default_rastrigin_n6", "rastrigin", 6, 20, 11, 21, None, dict(maxeval=3000, ftol_rel=1e-7)),

@@ -1,0 +1,250 @@
+"""Differential test of the API shell: drawn sequences of public NLopt calls (algorithm, bounds incl. fixed and invalid ones, any
+subset of the stopping criteria, x weights, population, minimise / maximise, scalar and vector constraints for ISRES, start points
+inside and outside the box) are issued, call by call, to the REAL reference and to the product over the emulated device; every
+return code, the result, the minimum, the argmin, the evaluation count and the error message must agree.  Objectives and
+constraints are Python callbacks, i.e. the host-callback path of CRS2_LM / ISRES / ESCH."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+EMU = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libnlopt_amd_emu.so")
+pytestmark = pytest.mark.skipif(not (O.have_ref() and os.path.exists(EMU)), reason="oracle/_ref or the emulated library not built")
+FUNC = C.CFUNCTYPE(C.c_double, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+MFUNC = C.CFUNCTYPE(None, C.c_uint, C.POINTER(C.c_double), C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+vp, dbl, dpp = C.c_void_p, C.c_double, C.POINTER(C.c_double)
+
+
+def bind(L):
+    L.nlopt_create.restype = vp
+    L.nlopt_create.argtypes = [C.c_int, C.c_uint]
+    L.nlopt_destroy.argtypes = [vp]
+    L.nlopt_copy.restype = vp
+    L.nlopt_copy.argtypes = [vp]
+    for nm in ("nlopt_set_lower_bounds", "nlopt_set_upper_bounds", "nlopt_set_xtol_abs", "nlopt_set_x_weights"):
+        getattr(L, nm).argtypes = [vp, dpp]
+    for nm in ("nlopt_set_stopval", "nlopt_set_ftol_rel", "nlopt_set_ftol_abs", "nlopt_set_xtol_rel", "nlopt_set_xtol_abs1", "nlopt_set_lower_bounds1"):
+        getattr(L, nm).argtypes = [vp, dbl]
+    L.nlopt_set_min_objective.argtypes = [vp, vp, vp]
+    L.nlopt_set_max_objective.argtypes = [vp, vp, vp]
+    L.nlopt_add_inequality_constraint.argtypes = [vp, vp, vp, dbl]
+    L.nlopt_add_equality_constraint.argtypes = [vp, vp, vp, dbl]
+    L.nlopt_add_inequality_mconstraint.argtypes = [vp, C.c_uint, vp, vp, dpp]
+    L.nlopt_set_population.argtypes = [vp, C.c_uint]
+    L.nlopt_set_maxeval.argtypes = [vp, C.c_int]
+    L.nlopt_optimize.argtypes = [vp, dpp, dpp]
+    L.nlopt_get_numevals.argtypes = [vp]
+    L.nlopt_get_errmsg.argtypes = [vp]
+    L.nlopt_get_errmsg.restype = C.c_char_p
+    L.nlopt_srand.argtypes = [C.c_ulong]
+    return L
+
+
+def play(L, draw):
+    rng = np.random.default_rng(9000 + draw)
+    dp = lambda a: a.ctypes.data_as(dpp)
+    alg = int(rng.choice([19, 35, 42]))
+    n = int(rng.integers(1, 7))
+    log = []
+    opt = L.nlopt_create(alg, n)
+    lb, ub = np.full(n, -3.0) - rng.random(n), np.full(n, 4.0) + rng.random(n)
+    r = rng.random()
+    if r < 0.15 and n > 1:
+        lb[int(rng.integers(n))] = ub[0]                 # a fixed coordinate (or an empty box if the index is 0 ... then lb == ub there)
+    elif r < 0.22:
+        lb[0], ub[0] = ub[0], lb[0]                      # lb > ub: invalid
+    log.append(L.nlopt_set_lower_bounds(opt, dp(lb)))
+    log.append(L.nlopt_set_upper_bounds(opt, dp(ub)))
+    centre = rng.uniform(-1, 2, n)
+
+    def f(nn, x, g, d):
+        return float(sum((x[i] - centre[i]) ** 2 * (1 + 0.3 * i) for i in range(nn))) + float(np.cos(3 * x[0]))
+    fcb = FUNC(f)
+    keep = [fcb]
+    maximise = rng.random() < 0.25
+    log.append((L.nlopt_set_max_objective if maximise else L.nlopt_set_min_objective)(opt, C.cast(fcb, vp), None))
+    if alg == 35:
+        for q in range(int(rng.integers(0, 3))):
+            cq = float(rng.uniform(-1, 1))
+            cb = FUNC(lambda nn, x, g, d, cq=cq, q=q: float(x[q % nn] - cq))
+            keep.append(cb)
+            add = L.nlopt_add_equality_constraint if rng.random() < 0.3 else L.nlopt_add_inequality_constraint
+            log.append(add(opt, C.cast(cb, vp), None, float(rng.choice([0.0, 1e-8, 1e-3, -1.0]))))      # -1: invalid tolerance
+        if rng.random() < 0.3:
+            m = int(rng.integers(1, 4))
+
+            def mf(mm, res, nn, x, g, d):
+                for i in range(mm):
+                    res[i] = x[i % nn] - 2.5 + 0.1 * i
+            mcb = MFUNC(mf)
+            keep.append(mcb)
+            tol = np.full(m, 1e-6)
+            log.append(L.nlopt_add_inequality_mconstraint(opt, m, C.cast(mcb, vp), None, dp(tol)))
+    if alg != 35 and rng.random() < 0.15:
+        cb = FUNC(lambda nn, x, g, d: float(x[0]))
+        keep.append(cb)
+        log.append(L.nlopt_add_inequality_constraint(opt, C.cast(cb, vp), None, 1e-8))                     # not supported by CRS / ESCH
+    if rng.random() < 0.7:
+        log.append(L.nlopt_set_population(opt, int(rng.choice([0, 1, n, n + 1, 3 * n + 5, 40]))))
+    log.append(L.nlopt_set_maxeval(opt, int(rng.integers(30, 900))))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_stopval(opt, float(rng.uniform(-5, 40)) * (-1 if maximise else 1)))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_ftol_rel(opt, float(10.0 ** rng.uniform(-9, -1))))
+    if rng.random() < 0.2:
+        log.append(L.nlopt_set_ftol_abs(opt, float(10.0 ** rng.uniform(-9, 0))))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_xtol_rel(opt, float(10.0 ** rng.uniform(-7, -1))))
+    if rng.random() < 0.2:
+        log.append(L.nlopt_set_xtol_abs1(opt, float(10.0 ** rng.uniform(-7, -1))))
+    if rng.random() < 0.2:
+        w = rng.uniform(0.1, 3.0, n)
+        if rng.random() < 0.2:
+            w[0] = -1.0                                   # invalid weight
+        log.append(L.nlopt_set_x_weights(opt, dp(w)))
+    if rng.random() < 0.2:                               # run a copy, destroy the original first
+        c2 = L.nlopt_copy(opt)
+        L.nlopt_destroy(opt)
+        opt = c2
+    x = rng.uniform(-2.5, 3.5, n)
+    if rng.random() < 0.1:
+        x[0] = 99.0                                      # start outside the box
+    minf = C.c_double(123.0)
+    L.nlopt_srand(int(rng.integers(1, 2 ** 31)))
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(minf))
+    msg = L.nlopt_get_errmsg(opt)
+    out = dict(log=log, ret=ret, minf=minf.value, x=x, nev=L.nlopt_get_numevals(opt), msg=msg.decode() if msg else None)
+    L.nlopt_destroy(opt)
+    del keep
+    return out
+
+
+@pytest.mark.parametrize("draw", range(150))
+def test_drawn_api_sequences_agree_with_the_reference(draw):
+    r = play(bind(O.ref()), draw)
+    a = play(bind(C.CDLL(EMU)), draw)
+    assert a["log"] == r["log"], (a["log"], r["log"])
+    assert a["ret"] == r["ret"], (a["ret"], r["ret"], a["msg"], r["msg"])
+    assert a["nev"] == r["nev"]
+    assert (a["minf"] == r["minf"]) or (np.isnan(a["minf"]) and np.isnan(r["minf"])), (a["minf"], r["minf"])
+    assert np.array_equal(a["x"], r["x"])
+    assert a["msg"] == r["msg"], (a["msg"], r["msg"])
+
+
+# ---- the device-objective algorithms: MLSL (all six enums), LD_LBFGS, LD_MMA with registered objectives ------------------------
+def play_local(L, draw, getter):
+    rng = np.random.default_rng(50000 + draw)
+    dp = lambda a: a.ctypes.data_as(dpp)
+    L.nlopt_set_local_optimizer.argtypes = [vp, vp]
+    L.nlopt_set_vector_storage.argtypes = [vp, C.c_uint]
+    L.nlopt_set_param.argtypes = [vp, C.c_char_p, dbl]
+    L.nlopt_set_initial_step1.argtypes = [vp, dbl]
+    g = getattr(L, getter)
+    g.restype = vp
+    g.argtypes = [C.c_int]
+    obj = ["rastrigin", "ackley", "griewank", "rosenbrock", "levy", "sphere"][int(rng.integers(6))]
+    n = int(rng.integers(2, 12))
+    xs, lo, hi = O.golden_x0(obj, n)
+    alg = int(rng.choice([11, 24, 20, 21, 22, 23, 38, 39]))
+    opt = L.nlopt_create(alg, n)
+    lb, ub = np.full(n, lo), np.full(n, hi)
+    log = [L.nlopt_set_lower_bounds(opt, dp(lb)), L.nlopt_set_upper_bounds(opt, dp(ub)), L.nlopt_set_min_objective(opt, g(O.OBJ[obj]), None)]
+    cfg = [obj, n, alg]                                   # what was drawn, for the failure message
+
+    def tolerances(o):
+        r = rng.random()
+        if r < 0.45:
+            v = float(10.0 ** -int(rng.integers(3, 11)))
+            cfg.append(("ftol_rel", v))
+            log.append(L.nlopt_set_ftol_rel(o, v))
+        elif r < 0.7:
+            v = float(10.0 ** -int(rng.integers(3, 9)))
+            cfg.append(("xtol_rel", v))
+            log.append(L.nlopt_set_xtol_rel(o, v))
+        elif r < 0.85:
+            v = float(10.0 ** -int(rng.integers(3, 12)))
+            cfg.append(("ftol_abs", v))
+            log.append(L.nlopt_set_ftol_abs(o, v))
+        else:
+            cfg.append(("no tolerance",))
+
+    def mma_params(o):
+        if rng.random() < 0.3:
+            cfg.append("inner_gradients=0")
+            log.append(L.nlopt_set_param(o, b"inner_gradients", 0.0))
+        if rng.random() < 0.3:
+            cfg.append("always_improve=0")
+            log.append(L.nlopt_set_param(o, b"always_improve", 0.0))
+        if rng.random() < 0.3:
+            v = float(10.0 ** rng.uniform(-3, 1))
+            cfg.append(("rho_init", v))
+            log.append(L.nlopt_set_param(o, b"rho_init", v))
+        if rng.random() < 0.2:
+            v = float(rng.integers(1, 6))
+            cfg.append(("inner_maxeval", v))
+            log.append(L.nlopt_set_param(o, b"inner_maxeval", v))
+        if rng.random() < 0.2:
+            v = float(rng.uniform(0.05, 2.0))
+            cfg.append(("initial_step", v))
+            log.append(L.nlopt_set_initial_step1(o, v))
+    if alg in (11, 24):
+        tolerances(opt)
+        log.append(L.nlopt_set_maxeval(opt, int(rng.integers(5, 400))))
+        if alg == 11 and rng.random() < 0.5:
+            log.append(L.nlopt_set_vector_storage(opt, int(rng.integers(1, 9))))
+        if alg == 24:
+            mma_params(opt)
+        if rng.random() < 0.2:
+            log.append(L.nlopt_set_stopval(opt, float(rng.uniform(0, 30))))
+    else:
+        explicit = alg in (38, 39, 20, 22) or rng.random() < 0.5           # G_MLSL needs one; GN_MLSL's default (COBYLA) is not provided
+        if explicit:
+            la = int(rng.choice([11, 24]))
+            cfg.append(("local", la))
+            loc = L.nlopt_create(la, n)
+            tolerances(loc)
+            if rng.random() < 0.3:
+                v = int(rng.integers(3, 60))
+                cfg.append(("local maxeval", v))
+                log.append(L.nlopt_set_maxeval(loc, v))
+            if la == 11 and rng.random() < 0.4:
+                log.append(L.nlopt_set_vector_storage(loc, int(rng.integers(1, 9))))
+            if la == 24:
+                mma_params(loc)
+            log.append(L.nlopt_set_local_optimizer(opt, loc))
+            L.nlopt_destroy(loc)
+        else:
+            tolerances(opt)                              # copied to the default local optimiser (LD_MMA for the GD variants)
+        if rng.random() < 0.7:
+            v = int(rng.integers(1, 40))
+            cfg.append(("population", v))
+            log.append(L.nlopt_set_population(opt, v))
+        v = int(rng.integers(100, 3000))
+        cfg.append(("maxeval", v))
+        log.append(L.nlopt_set_maxeval(opt, v))
+        if rng.random() < 0.2:
+            v = float(rng.uniform(0, 30))
+            cfg.append(("stopval", v))
+            log.append(L.nlopt_set_stopval(opt, v))
+    x = np.array(xs)
+    minf = C.c_double(123.0)
+    L.nlopt_srand(int(rng.integers(1, 2 ** 31)))
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(minf))
+    out = dict(log=log, ret=ret, minf=minf.value, x=x, nev=L.nlopt_get_numevals(opt), alg=alg, cfg=cfg)
+    L.nlopt_destroy(opt)
+    return out
+
+
+@pytest.mark.parametrize("draw", range(120))
+def test_drawn_local_and_mlsl_setups_agree_with_the_reference(draw):
+    """registered objectives: the reference calls the oracle's callback, the product its own evaluator on the (emulated) device"""
+    P = O.port()
+    ref = O.ref()
+    ref.orc_objective = P.orc_objective                  # the reference library is handed the oracle's callbacks
+    r = play_local(bind(ref), draw, "orc_objective")
+    a = play_local(bind(C.CDLL(EMU)), draw, "nlopt_amd_objective")
+    assert a["log"] == r["log"] and a["ret"] == r["ret"], (a["cfg"], a["ret"], r["ret"])
+    assert a["nev"] == r["nev"] and a["minf"] == r["minf"] and np.array_equal(a["x"], r["x"]), (a["cfg"], a["nev"], r["nev"], a["minf"], r["minf"])

@@ -53,6 +53,7 @@ def run_amd(obj, n, x0=None, lb=None, ub=None, maxeval=0, ftol_rel=0.0, ftol_abs
     ("sphere", 6, dict(stopval=1e-3), 0),
     ("rastrigin", 16, dict(ftol_rel=1e-9, params=dict(inner_gradients=0)), 2),
     ("ackley", 10, dict(ftol_rel=1e-9, params=dict(inner_maxeval=2, rho_init=0.01)), 2),
+    ("ackley", 10, dict(ftol_rel=1e-9, params=dict(inner_gradients=0, inner_maxeval=1)), 2),      # mma.c:343: the inner limit does not end the step here
     ("griewank", 10, dict(xtol_rel=1e-8, params=dict(sigma_min=0.5)), 8),
     ("rastrigin", 12, dict(ftol_rel=1e-9, step=0.3), 2),
     ("ackley", 4096, dict(ftol_rel=1e-8), 3),           # the config-4 shape

@@ -202,6 +202,13 @@ def test_port_mlsl_matches_reference_live(obj, n, ns, seed, kw):
     ("ackley", 10, dict(ftol_rel=1e-9, params=dict(inner_maxeval=2, rho_init=0.01))),
     ("griewank", 10, dict(xtol_rel=1e-8, params=dict(sigma_min=0.5))),
     ("rastrigin", 12, dict(ftol_rel=1e-9, step=0.3)),                                # initial step = sigma_init
+    # inner_gradients = 0 together with inner_maxeval: after the re-evaluation with a gradient mma.c:343 recomputes inner_done
+    # WITHOUT the inner_maxeval clause — a step that only ended because the inner limit was hit carries on (found by
+    # tests/test_api_differential.py; the first version of the port and of the kernel ended the step there)
+    ("rastrigin", 8, dict(ftol_rel=1e-9, params=dict(inner_gradients=0, inner_maxeval=2))),
+    ("ackley", 6, dict(maxeval=300, params=dict(inner_gradients=0, inner_maxeval=1, always_improve=0))),
+    ("griewank", 5, dict(xtol_rel=1e-7, params=dict(inner_gradients=0, inner_maxeval=4, rho_init=0.1))),
+    ("levy", 5, dict(maxeval=400, params=dict(inner_gradients=0, inner_maxeval=5, always_improve=0))),
 ])
 def test_port_mma_matches_reference_live(obj, n, kw):
     a = O.run_port_mma(obj, n, **kw)
@@ -407,6 +414,8 @@ def test_random_configurations_match_the_reference(draw, scale):
         mp["always_improve"] = 0
     if rng.random() < 0.3:
         mp["rho_init"] = float(10.0 ** rng.uniform(-3, 1))
+    if rng.random() < 0.3:
+        mp["inner_maxeval"] = int(rng.integers(1, 6))
     _same(O.run_port_mma(obj, n, params=mp, **lkw), O.run_ref_mma(obj, n, params=mp, **lkw))
     # MLSL: pseudo-random or Sobol sampling, LD_LBFGS or LD_MMA
     ns = int(rng.integers(0, 30))
