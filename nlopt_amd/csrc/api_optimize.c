@@ -106,6 +106,7 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
             nlopt_set_xtol_rel(local_opt, opt->xtol_rel); nlopt_set_xtol_abs(local_opt, opt->xtol_abs);
             nlopt_set_maxeval(local_opt, nla_local_search_maxeval);
         }
+        if (opt->dx) nlopt_set_initial_step(local_opt, opt->dx);                        /* optimize.c:778-779 */
         for (i = 0; i < n && stop.xtol_abs && stop.xtol_abs[i] > 0; ++i) { }
         if (local_opt->ftol_rel <= 0 && local_opt->ftol_abs <= 0 && local_opt->xtol_rel <= 0 && i < n) {
             nlopt_set_ftol_rel(local_opt, 1e-15);                                        /* optimize.c:781-786 */

@@ -218,6 +218,10 @@ def play_local(L, draw, getter):
             L.nlopt_destroy(loc)
         else:
             tolerances(opt)                              # copied to the default local optimiser (LD_MMA for the GD variants)
+        if rng.random() < 0.15:
+            v = float(rng.uniform(0.05, 2.0))
+            cfg.append(("global initial_step", v))           # handed on to the local optimiser (optimize.c:778-779)
+            log.append(L.nlopt_set_initial_step1(opt, v))
         if rng.random() < 0.7:
             v = int(rng.integers(1, 40))
             cfg.append(("population", v))
@@ -248,3 +252,114 @@ def test_drawn_local_and_mlsl_setups_agree_with_the_reference(draw):
     a = play_local(bind(C.CDLL(EMU)), draw, "nlopt_amd_objective")
     assert a["log"] == r["log"] and a["ret"] == r["ret"], (a["cfg"], a["ret"], r["ret"])
     assert a["nev"] == r["nev"] and a["minf"] == r["minf"] and np.array_equal(a["x"], r["x"]), (a["cfg"], a["nev"], r["nev"], a["minf"], r["minf"])
+
+
+# ---- option round trips: everything a setter stores, read back ------------------------------------------------------------------
+def play_options(L, draw):
+    rng = np.random.default_rng(777000 + draw)
+    dp = lambda a: a.ctypes.data_as(dpp)
+    for nm in ("nlopt_get_stopval", "nlopt_get_ftol_rel", "nlopt_get_ftol_abs", "nlopt_get_xtol_rel", "nlopt_get_maxtime"):
+        getattr(L, nm).restype = dbl
+        getattr(L, nm).argtypes = [vp]
+    for nm in ("nlopt_get_lower_bounds", "nlopt_get_upper_bounds", "nlopt_get_xtol_abs", "nlopt_get_x_weights"):
+        getattr(L, nm).argtypes = [vp, dpp]
+    L.nlopt_get_initial_step.argtypes = [vp, dpp, dpp]
+    L.nlopt_set_initial_step.argtypes = [vp, dpp]
+    L.nlopt_set_initial_step1.argtypes = [vp, dbl]
+    L.nlopt_set_maxtime.argtypes = [vp, dbl]
+    L.nlopt_set_upper_bounds1.argtypes = [vp, dbl]
+    L.nlopt_set_lower_bound.argtypes = [vp, C.c_int, dbl]
+    L.nlopt_set_upper_bound.argtypes = [vp, C.c_int, dbl]
+    L.nlopt_set_x_weights1.argtypes = [vp, dbl]
+    L.nlopt_set_vector_storage.argtypes = [vp, C.c_uint]
+    L.nlopt_get_vector_storage.argtypes = [vp]
+    L.nlopt_get_population.argtypes = [vp]
+    L.nlopt_get_maxeval.argtypes = [vp]
+    L.nlopt_get_algorithm.argtypes = [vp]
+    L.nlopt_get_dimension.argtypes = [vp]
+    L.nlopt_set_param.argtypes = [vp, C.c_char_p, dbl]
+    L.nlopt_get_param.argtypes = [vp, C.c_char_p, dbl]
+    L.nlopt_get_param.restype = dbl
+    L.nlopt_has_param.argtypes = [vp, C.c_char_p]
+    L.nlopt_num_params.argtypes = [vp]
+    L.nlopt_nth_param.argtypes = [vp, C.c_uint]
+    L.nlopt_nth_param.restype = C.c_char_p
+    L.nlopt_remove_inequality_constraints.argtypes = [vp]
+    L.nlopt_remove_equality_constraints.argtypes = [vp]
+    L.nlopt_set_force_stop.argtypes = [vp, C.c_int]
+    L.nlopt_get_force_stop.argtypes = [vp]
+    L.nlopt_algorithm_name.argtypes = [C.c_int]
+    L.nlopt_algorithm_name.restype = C.c_char_p
+    alg = int(rng.choice([19, 35, 42, 11, 24, 20, 21, 22, 23, 38, 39, 0, 25, 40, 43]))
+    n = int(rng.integers(0, 6))
+    opt = L.nlopt_create(alg, n)
+    log = [bool(opt), L.nlopt_algorithm_name(alg)]
+    if not opt:
+        return log
+    nn = max(n, 1)
+    for _ in range(int(rng.integers(3, 14))):
+        k = int(rng.integers(18))
+        v = float(rng.choice([-2.0, -1e-3, 0.0, 1e-6, 0.5, 3.0, np.inf, -np.inf, np.nan]))
+        arr = rng.choice([-1.0, 0.0, 0.25, 2.0, np.inf], nn).astype(np.float64)
+        if k == 0: log.append(("lb", L.nlopt_set_lower_bounds(opt, dp(arr))))
+        elif k == 1: log.append(("ub", L.nlopt_set_upper_bounds(opt, dp(arr))))
+        elif k == 2: log.append(("lb1", L.nlopt_set_lower_bounds1(opt, v)))
+        elif k == 3: log.append(("ub1", L.nlopt_set_upper_bounds1(opt, v)))
+        elif k == 4: log.append(("lbi", L.nlopt_set_lower_bound(opt, int(rng.integers(-1, n + 1)), v)))
+        elif k == 5: log.append(("stopval", L.nlopt_set_stopval(opt, v)))
+        elif k == 6: log.append(("ftol_rel", L.nlopt_set_ftol_rel(opt, v)))
+        elif k == 7: log.append(("ftol_abs", L.nlopt_set_ftol_abs(opt, v)))
+        elif k == 8: log.append(("xtol_rel", L.nlopt_set_xtol_rel(opt, v)))
+        elif k == 9: log.append(("xtol_abs", L.nlopt_set_xtol_abs(opt, dp(arr))))
+        elif k == 10: log.append(("xtol_abs1", L.nlopt_set_xtol_abs1(opt, v)))
+        elif k == 11: log.append(("weights", L.nlopt_set_x_weights(opt, dp(arr))))
+        elif k == 12: log.append(("weights1", L.nlopt_set_x_weights1(opt, v)))
+        elif k == 13: log.append(("maxeval", L.nlopt_set_maxeval(opt, int(rng.integers(-3, 1000)))))
+        elif k == 14: log.append(("maxtime", L.nlopt_set_maxtime(opt, v)))
+        elif k == 15: log.append(("pop", L.nlopt_set_population(opt, int(rng.integers(0, 500)))))
+        elif k == 16: log.append(("step1", L.nlopt_set_initial_step1(opt, v)))
+        elif k == 17:
+            name = [b"rho_init", b"tolg", b"amd_window_factor", b"x"][int(rng.integers(4))]
+            log.append(("param", L.nlopt_set_param(opt, name, v)))
+    if rng.random() < 0.3:
+        c2 = L.nlopt_copy(opt)
+        L.nlopt_destroy(opt)
+        opt = c2
+    out = np.zeros(nn)
+    for nm in ("nlopt_get_lower_bounds", "nlopt_get_upper_bounds", "nlopt_get_xtol_abs", "nlopt_get_x_weights"):
+        out[:] = 7.0
+        log.append((nm, getattr(L, nm)(opt, dp(out)), out[:n].tolist()))
+    for nm in ("nlopt_get_stopval", "nlopt_get_ftol_rel", "nlopt_get_ftol_abs", "nlopt_get_xtol_rel", "nlopt_get_maxtime"):
+        log.append((nm, getattr(L, nm)(opt)))
+    for nm in ("nlopt_get_maxeval", "nlopt_get_population", "nlopt_get_algorithm", "nlopt_get_dimension", "nlopt_get_vector_storage", "nlopt_get_force_stop",
+               "nlopt_num_params"):
+        log.append((nm, getattr(L, nm)(opt)))
+    log.append(("has", [L.nlopt_has_param(opt, p) for p in (b"rho_init", b"tolg", b"x", b"nope")], L.nlopt_get_param(opt, b"tolg", -9.0)))
+    log.append(("nth", [L.nlopt_nth_param(opt, i) for i in range(L.nlopt_num_params(opt) + 1)]))
+    x = np.full(nn, 0.5)
+    out[:] = 7.0
+    log.append(("get_step", L.nlopt_get_initial_step(opt, dp(x), dp(out)), out[:n].tolist()))
+    log.append(("rm", L.nlopt_remove_inequality_constraints(opt), L.nlopt_remove_equality_constraints(opt)))
+    msg = L.nlopt_get_errmsg(opt)
+    log.append(("msg", msg.decode() if msg else None))
+    L.nlopt_destroy(opt)
+    return log
+
+
+def _same_log(a, r):
+    def eq(u, v):
+        if isinstance(u, float) and isinstance(v, float):
+            return u == v or (np.isnan(u) and np.isnan(v))
+        if isinstance(u, (list, tuple)) and isinstance(v, (list, tuple)):
+            return len(u) == len(v) and all(eq(p, q) for p, q in zip(u, v))
+        return u == v
+    return eq(a, r)
+
+
+@pytest.mark.parametrize("draw", range(200))
+def test_drawn_option_round_trips_agree_with_the_reference(draw):
+    """setters with valid and invalid values (negative tolerances, NaN, infinities, out-of-range indices, unknown parameters), then
+    every getter: return codes, stored values, parameter lists and error messages as the reference's"""
+    r = play_options(bind(O.ref()), draw)
+    a = play_options(bind(C.CDLL(EMU)), draw)
+    assert _same_log(a, r), [(p, q) for p, q in zip(a, r) if not _same_log(p, q)][:3]
