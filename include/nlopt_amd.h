@@ -47,6 +47,19 @@ int nlopt_amd_constraint_id(nlopt_func f);             /* 0: block sum, -1: not 
 
 int nlopt_amd_device_count(void);                      /* visible HIP devices (0 => optimize fails loudly) */
 
+/* ---- user-supplied device objectives (required extension (ii): an additive setter) -----------------
+ * code_object: path of a gfx950 code object built from a source that describes the objective with
+ * include/nlopt_amd_device.h (NLOPT_AMD_DEVICE_OBJECTIVE(name, ...)); `name` selects the kernel <name>_evalgrad.
+ * host_twin (may be NULL): the same function as an ordinary nlopt_func; it is what nlopt_get_... style introspection and
+ * code outside the device paths see (e.g. the fixed-coordinate wrapper, optimize.c:219-445); when NULL the library
+ * evaluates single points through the device kernel instead.  The objective then runs on the device inside every algorithm of this
+ * library: population / sample evaluation in one launch, local searches as device coroutines with one launch of the
+ * user's kernel per step of a whole batch.  nlopt_set_min/max_objective afterwards unbinds it.  Returns NLOPT_SUCCESS,
+ * NLOPT_INVALID_ARGS (errmsg: the file / symbol that could not be loaded, or an ABI mismatch) or NLOPT_FAILURE (no device). */
+nlopt_result nlopt_amd_set_min_device_objective(nlopt_opt opt, const char *code_object, const char *name, nlopt_func host_twin, void *f_data);
+nlopt_result nlopt_amd_set_max_device_objective(nlopt_opt opt, const char *code_object, const char *name, nlopt_func host_twin, void *f_data);
+int nlopt_amd_has_device_objective(const nlopt_opt opt);   /* 1: a user objective is bound, 0: not */
+
 /* per-evaluation trace (same record as the oracle's): kind 0 = initial row, 1 = reflection trial,
  * 2 = local mutation; row = row written (init / accepted) or -1. */
 typedef struct { double f; int64_t row; int32_t kind; int32_t accepted; } nlopt_amd_trace_rec;
@@ -273,34 +286,68 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
                               double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
                               void *stream);
 
+/* ---- the batched local optimisers: common pieces ---------------------------------------------------- */
+/* External evaluation: the objective of a local search is not one of the compiled-in device objectives but a host callback
+ * (the reference's nlopt_func contract, src/api/nlopt.h:60-62: called on the caller's thread, one x at a time) or a
+ * user-supplied device module.  With obj == NLA_OBJ_EXTERNAL the batch kernels run as coroutines: at every objective
+ * evaluation of a search (plis.c:260,390; mma.c:219,297,337) the kernel writes the point into row `inst` of EX, sets
+ * req[inst] = {1, gradient wanted?} and returns; the caller evaluates, stores f in EF[inst] and the gradient in row inst of
+ * EG, and launches the same kernel again with resume = 1; req[inst].state == 2: the search has finished (out[inst] valid).
+ * All pointers are device pointers. */
+#define NLA_OBJ_EXTERNAL (-1)
+typedef struct { int32_t state, want_grad; } nla_local_req;
+typedef struct {
+    nla_local_req *req;            /* count entries */
+    double *EX, *EG, *EF;          /* count x ld points; count x ld gradients; count values */
+    void *save;                    /* count x nla_lbfgs_save_bytes() / nla_mma_save_bytes() */
+    int32_t resume;                /* 0: start the searches; 1: continue those whose evaluation was delivered */
+    int32_t forced, timeout;       /* the caller's nlopt_force_stop flag / maxtime verdict at this launch (stop.c:141-159) */
+    int32_t pad;
+} nla_local_ext;
+
 /* ---- LD_LBFGS (src/algs/luksan/plis.c), batched ----------------------------------------------------- */
-typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, tolg; int32_t maxeval, pad; } nla_lbfgs_params;
+/* exact != 0: every dot product / norm / objective sum accumulated in the reference's sequential order (mssubs.c:601-641,
+ * stop.c:37-57) instead of the workgroup tree — the iterates are then the reference's bit for bit; sign = -1: minimise -f
+ * (the reference's maximisation wrapper, optimize.c:970-980), 0 = +1; xtol_abs / x_weights: device arrays of n or NULL
+ * (nlopt_stop_dx, stop.c:110-120); abort: NULL, or a device-visible flag the kernel polls once per iteration:
+ * 100 = maxtime reached (plis.c:263,273,371), -999 = forced stop (pssubs.c:914). */
+typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, tolg; int32_t maxeval, exact; double sign;
+                 const double *xtol_abs, *x_weights; const int32_t *abort;
+                 double *ftrace; int64_t ftrace_cap;     /* NULL, or count x ftrace_cap doubles: f of every evaluation of search i, in order */
+               } nla_lbfgs_params;
 typedef struct { double f; int32_t ret, nevals, iterm, cols; } nla_lbfgs_result;   /* cols = history columns streamed: sum over iterations of k */
 size_t nla_lbfgs_work_doubles(int ld, int mf, int count);     /* doubles of `work` */
 size_t nla_lbfgs_hist_doubles(int ld, int mf, int count);     /* doubles of `hist` */
+size_t nla_lbfgs_save_bytes(void);                            /* per search, of nla_local_ext.save */
 
 /* replaces: luksan_plis (plis.c:420-510) for `count` independent starts at once, one workgroup per
  * start, the whole optimisation loop on the device.  X: count x ld, start points in, minimisers
  * out; lb/ub: the box (n); mf: history pairs kept (plis.c:441-445 computed by the caller); work /
  * iwork (count*ld ints) / hist: scratch sized by the helpers above; out[i] = (f, nlopt_result,
- * evaluations, PLIS termination code) of start i. */
+ * evaluations, PLIS termination code) of start i.  obj: a compiled-in device objective, or NLA_OBJ_EXTERNAL with `ext`
+ * (NULL otherwise). */
 int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
                       double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
-                      void *stream);
+                      const nla_local_ext *ext, void *stream);
 
 /* ---- LD_MMA without nonlinear constraints (src/algs/mma/mma.c), batched --------------------------- */
 /* stopping values as nlopt_stopping holds them (nlopt-util.h:79-91) + the algorithm's parameters as the dispatcher reads
- * them (optimize.c:798-803: rho_init 1, sigma_min 0, inner_maxeval 0, inner_gradients 1, always_improve 1) */
+ * them (optimize.c:798-803: rho_init 1, sigma_min 0, inner_maxeval 0, inner_gradients 1, always_improve 1); exact, sign,
+ * xtol_abs, x_weights (nlopt_stop_x, stop.c:98-108), abort (mma.c:258-260,394-396) as for LD_LBFGS */
 typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, rho_init, sigma_min;
-                 int32_t maxeval, inner_maxeval, inner_gradients, always_improve; } nla_mma_params;
+                 int32_t maxeval, inner_maxeval, inner_gradients, always_improve; int32_t exact, pad; double sign;
+                 const double *xtol_abs, *x_weights; const int32_t *abort;
+                 double *ftrace; int64_t ftrace_cap;     /* as for LD_LBFGS; indexed by objective calls (the uncounted call included) */
+               } nla_mma_params;
 size_t nla_mma_work_doubles(int ld, int count);               /* doubles of `work` */
+size_t nla_mma_save_bytes(void);
 
 /* replaces: mma_minimize (mma.c:146-449) with m = 0 for `count` independent starts at once, one workgroup per start, outer
  * and inner iterations on the device (the 0-dimensional dual "solve" is dual_func's closed form, mma.c:58-137).  X: count x
  * ld, starts in, minimisers out; sigma_init: the initial step (n, device) or NULL (mma.c:203-211); out[i] = (f,
  * nlopt_result, evaluations counted by the algorithm, iterm = objective calls made, cols = outer iterations). */
 int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const double *ub, const double *sigma_init, double *X,
-                    double *work, const nla_mma_params *params, nla_lbfgs_result *out, void *stream);
+                    double *work, const nla_mma_params *params, nla_lbfgs_result *out, const nla_local_ext *ext, void *stream);
 
 /* ---- MLSL (src/algs/mlsl/mlsl.c) ------------------------------------------------------------------- */
 /* replaces: nlopt_sobol_next (sobolseq.c:236-242) for `count` consecutive points: row r of P (count x ld) := point number
@@ -359,6 +406,7 @@ int nla_memset(void *dst, int value, size_t bytes, void *stream);
 void *nla_stream_create(void);
 void nla_stream_destroy(void *stream);
 int nla_stream_sync(void *stream);
+int nla_stream_query(void *stream);             /* 0: all work done, -1: still running, otherwise the hipError_t */
 void *nla_event_create(void);
 void nla_event_destroy(void *ev);
 int nla_event_record(void *ev, void *stream);
@@ -366,6 +414,12 @@ int nla_event_sync(void *ev);
 float nla_event_elapsed_ms(void *ev0, void *ev1);
 int nla_stream_wait_event(void *stream, void *ev);
 const char *nla_dev_error_string(int err);
+/* code objects loaded at run time (user device objectives) */
+void *nla_module_load_file(const char *path);
+void *nla_module_load_data(const void *image);
+void nla_module_unload(void *module);
+void *nla_module_function(void *module, const char *name);
+int nla_module_launch(void *function, unsigned grid_x, unsigned block_x, void *args, size_t arg_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,7 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
         if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
         return nla_crs_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, POP(opt, 0));
     case NLOPT_LD_LBFGS:                                                                 /* optimize.c:716-718 */
-        return nla_lbfgs_minimize((int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, (int) opt->vector_storage,
+        return nla_lbfgs_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop, (int) opt->vector_storage,
                                   nlopt_get_param(opt, "tolg", 0.));
     case NLOPT_LD_MMA:                                                                   /* optimize.c:795-834 */
         return nla_mma_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop);

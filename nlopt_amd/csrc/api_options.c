@@ -53,6 +53,7 @@ void nlopt_destroy(nlopt_opt opt)
     free(opt->params);
     free(opt->lb); free(opt->ub); free(opt->xtol_abs); free(opt->x_weights); free(opt->dx);
     nlopt_destroy(opt->local_opt);
+    nla_userobj_release(opt->userobj);
     free(opt->errmsg);
     free(opt);
 }
@@ -108,6 +109,7 @@ nlopt_opt nlopt_copy(const nlopt_opt opt)
     c->params = NULL; c->nparams = 0;
     c->local_opt = NULL; c->errmsg = NULL; c->force_stop_child = NULL;
     c->trace = NULL; c->trace_cap = c->trace_len = 0;
+    nla_userobj_retain(c->userobj);              /* shared, reference counted */
     if (c->munge_on_copy && c->f_data && !(c->f_data = c->munge_on_copy(c->f_data))) goto oom;
     if (opt->n > 0) {
         if (!(c->lb = dup_doubles(opt->lb, opt->n)) || !(c->ub = dup_doubles(opt->ub, opt->n))) goto oom;
@@ -180,6 +182,8 @@ static nlopt_result set_objective(nlopt_opt opt, nlopt_func f, nlopt_precond pre
     if (!opt) return NLOPT_INVALID_ARGS;
     nla_unset_errmsg(opt);
     if (opt->munge_on_destroy) opt->munge_on_destroy(opt->f_data);
+    nla_userobj_release(opt->userobj);           /* a user device objective (userobj.c) goes with the objective it was bound as */
+    opt->userobj = NULL;
     opt->f = f; opt->f_data = f_data; opt->pre = pre; opt->maximize = maximize;
     /* an untouched stopval follows the direction of optimisation (options.c:332-333,352-353) */
     if (nla_isinf(opt->stopval) && (maximize ? opt->stopval < 0 : opt->stopval > 0))

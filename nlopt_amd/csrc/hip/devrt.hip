@@ -60,6 +60,14 @@ extern "C" void *nla_stream_create(void)
 extern "C" void nla_stream_destroy(void *stream) { if (stream) (void) hipStreamDestroy((hipStream_t) stream); }
 extern "C" int nla_stream_sync(void *stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
 
+extern "C" int nla_stream_query(void *stream)
+{
+    const hipError_t e = hipStreamQuery((hipStream_t) stream);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) { (void) hipGetLastError(); return -1; }
+    return (int) e;
+}
+
 extern "C" void *nla_event_create(void)
 {
     hipEvent_t e = nullptr;
@@ -77,3 +85,30 @@ extern "C" float nla_event_elapsed_ms(void *ev0, void *ev1)
 }
 extern "C" int nla_stream_wait_event(void *stream, void *ev) { return (int) hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) ev, 0); }
 extern "C" const char *nla_dev_error_string(int err) { return hipGetErrorString((hipError_t) err); }
+
+/* ---- code objects supplied at run time (user device objectives, userobj.c) ------------------------------------- */
+extern "C" void *nla_module_load_file(const char *path)
+{
+    hipModule_t m = nullptr;
+    if (hipModuleLoad(&m, path) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return (void *) m;
+}
+extern "C" void *nla_module_load_data(const void *image)
+{
+    hipModule_t m = nullptr;
+    if (hipModuleLoadData(&m, image) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return (void *) m;
+}
+extern "C" void nla_module_unload(void *module) { if (module) (void) hipModuleUnload((hipModule_t) module); }
+extern "C" void *nla_module_function(void *module, const char *name)
+{
+    hipFunction_t f = nullptr;
+    if (hipModuleGetFunction(&f, (hipModule_t) module, name) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return (void *) f;
+}
+/* args: the kernel's parameters packed as the ABI lays them out (natural alignment), arg_bytes long */
+extern "C" int nla_module_launch(void *function, unsigned grid_x, unsigned block_x, void *args, size_t arg_bytes, void *stream)
+{
+    void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END };
+    return (int) hipModuleLaunchKernel((hipFunction_t) function, grid_x, 1, 1, block_x, 1, 1, 0, (hipStream_t) stream, nullptr, config);
+}

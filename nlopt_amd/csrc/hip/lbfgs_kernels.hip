@@ -18,12 +18,27 @@
  * Numerics: per-element formulas and the order of the scalar logic are the reference's; dot
  * products are workgroup reductions (fixed tree: thread-strided partials, xor-butterfly per
  * wavefront, wavefronts in order), so sums differ from the reference's sequential ones by
- * rounding only.
+ * rounding only.  With params.exact != 0 ("amd_exact_dot") every sum is accumulated in the
+ * reference's order instead (local_common.h) and the iterates are the reference's bit for bit
+ * (up to the device libm inside a device objective).
+ *
+ * External evaluation (OBJ == NLA_OBJ_EXTERNAL): the objective is not on the device — a host
+ * callback (the reference's nlopt_func contract: called on the caller's thread, one x at a time)
+ * or a user-supplied device module.  The kernel is then a coroutine: at each of its two evaluation
+ * points (plis.c:260 and :390) it writes the point into EX, saves its scalar state and returns;
+ * the host delivers f / gradient into EF / EG and launches it again with ext.resume = 1.
  */
 #include "local_common.h"
 #include <limits.h>
 #include "../lbfgs_scalar.h"
 #include "../../../include/nlopt_amd.h"
+
+/* scalar state of one search across an external evaluation (everything else lives in the instance's vectors) */
+struct lb_saved {
+    lb_ls_state lss; lb_ls_io q; lb_counters c;
+    double gmax, umax, fval, fo, p, po, gnorm, snorm, rmax, rmin;
+    int kd, nred, maxst, xstop, nevals, cols, head, point;
+};
 
 #define LB_EPT 16                  /* coordinates per thread held in registers by the direction loops (n <= 4096) */
 
@@ -52,12 +67,15 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
                                                             const double *__restrict__ ub, double *__restrict__ X,
                                                             double *__restrict__ work, int *__restrict__ iwork,
                                                             double *__restrict__ hist, nla_lbfgs_params P,
-                                                            nla_lbfgs_result *__restrict__ out)
+                                                            nla_lbfgs_result *__restrict__ out, nla_local_ext E)
 {
+    constexpr bool EXT = OBJ == NLA_OBJ_EXTERNAL;
     __shared__ lb_shared S;
     __shared__ double oscratch[2 * LB_W];
+    __shared__ lb_exact_buf XB;
     const int inst = blockIdx.x, tid = threadIdx.x;
     if (inst >= count) return;
+    if (EXT && E.resume && E.req[inst].state != 1) return;          /* finished earlier (or never asked) */
     double *x = X + (size_t) inst * ld;
     double *gf = work + (size_t) inst * 4 * ld, *s = gf + ld, *xl = s + ld, *xu = xl + ld;
     int *ix = iwork + (size_t) inst * ld;
@@ -76,9 +94,45 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
     double gmax = 0, umax = 0, fval, fo, p = 0, po = 0, a, b, gnorm, snorm = 0, rmax, rmin = 0;
     const double eta9 = 1e120, eps8 = 1., eps9 = 1e-8, alf1 = 1e-10, alf2 = 1e10, told = 1e-4, xmax = 1e16, maxf = 1e20,
                  minf_est = -HUGE_VAL;
-    int kd = 1, ld_ = -1, nred = 0, maxst = 0, xstop = 0, nevals = 0, k, cols = 0;
+    int kd = 1, ld_ = -1, nred = 0, maxst = 0, xstop = 0, nevals = 0, k, cols = 0, forced = 0, tmo = 0;
     double xtol_rel = P.xtol_rel, tolg = P.tolg;
+    lb_saved *sv = EXT ? (lb_saved *) E.save + inst : nullptr;
     (void) ld_;
+#define MDOT(u, v) (P.exact ? lb_mdot_exact(n, u, v, ix, XB) : lb_mdot(n, u, v, ix, S))
+    /* an evaluation point: device objective -> evaluate here; external -> publish the point, save the state, leave */
+#define LB_EVAL(POINT, LABEL, FOUT)                                                                                     \
+    if (EXT) {                                                                                                          \
+        for (int i = tid; i < n; i += LB_T) E.EX[(size_t) inst * ld + i] = x[i];                                        \
+        if (tid == 0) {                                                                                                 \
+            sv->lss = lss; sv->q = q; sv->c = c; sv->gmax = gmax; sv->umax = umax; sv->fval = fval; sv->fo = fo;        \
+            sv->p = p; sv->po = po; sv->gnorm = gnorm; sv->snorm = snorm; sv->rmax = rmax; sv->rmin = rmin; sv->kd = kd; \
+            sv->nred = nred; sv->maxst = maxst; sv->xstop = xstop; sv->nevals = nevals; sv->cols = cols;                \
+            sv->head = head; sv->point = POINT;                                                                         \
+            E.req[inst].state = 1; E.req[inst].want_grad = 1;                                                           \
+        }                                                                                                               \
+        return;                                                                                                         \
+    LABEL:                                                                                                              \
+        for (int i = tid; i < n; i += LB_T) gf[i] = E.EG[(size_t) inst * ld + i];                                       \
+        __syncthreads();                                                                                                \
+        FOUT = E.EF[inst];                                                                                              \
+    } else FOUT = lb_objgrad<EXT ? 0 : OBJ>(n, x, gf, S, oscratch, P.exact, XB, P.sign)
+
+    if (xtol_rel <= 0.) xtol_rel = 1e-16;                                    /* plis.c:202-214 */
+    ls.minf_max = P.minf_max; ls.ftol_rel = P.ftol_rel <= 0. ? 1e-14 : P.ftol_rel; ls.ftol_abs = P.ftol_abs; ls.maxeval = P.maxeval;
+    if (tolg <= 0.) tolg = 1e-8;
+    memset(&c, 0, sizeof c);
+    memset(&lss, 0, sizeof lss);
+    memset(&q, 0, sizeof q);
+    fval = 0; fo = minf_est; gnorm = 0; rmax = eta9;
+    if (EXT) { forced = E.forced; tmo = E.timeout; }
+    if (EXT && E.resume) {                                                   /* continue where the search left */
+        lss = sv->lss; q = sv->q; c = sv->c; gmax = sv->gmax; umax = sv->umax; fval = sv->fval; fo = sv->fo; p = sv->p;
+        po = sv->po; gnorm = sv->gnorm; snorm = sv->snorm; rmax = sv->rmax; rmin = sv->rmin; kd = sv->kd; nred = sv->nred;
+        maxst = sv->maxst; xstop = sv->xstop; nevals = sv->nevals; cols = sv->cols; head = sv->head;
+        __syncthreads();
+        if (tid == 0) E.req[inst].state = 0;
+        if (sv->point == 0) goto resume_first; else goto resume_linesearch;
+    }
 
     for (int i = tid; i < n; i += LB_T) {                                    /* plis.c:463-469 */
         const int lbu = lb[i] <= -0.99 * HUGE_VAL, ubu = ub[i] >= 0.99 * HUGE_VAL;
@@ -89,26 +143,21 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
         ix[i] = t; xl[i] = l; xu[i] = u;
         hx[i] = 0.; hg[i] = 0.;               /* the reference zero-fills xo (plis.c:475); column 1 is read before it is written */
     }
-    if (xtol_rel <= 0.) xtol_rel = 1e-16;                                    /* plis.c:202-214 */
-    ls.minf_max = P.minf_max; ls.ftol_rel = P.ftol_rel <= 0. ? 1e-14 : P.ftol_rel; ls.ftol_abs = P.ftol_abs; ls.maxeval = P.maxeval;
-    if (tolg <= 0.) tolg = 1e-8;
-    memset(&c, 0, sizeof c);
-    memset(&lss, 0, sizeof lss);
-    memset(&q, 0, sizeof q);
     c.ites = 1; c.mtesx = 2; c.mtesf = 2; c.iters = 2; c.ires1 = 999; c.ires2 = 0; c.kd = 1;
     c.mit = INT_MAX; c.mfg = P.maxeval > 0 ? P.maxeval : INT_MAX;
     c.kit = -(c.ires1 * n + c.ires2);
-    rmax = eta9;
-    fo = minf_est;
     __syncthreads();
     lb_project(n, x, ix, xl, xu, eps9);
     __syncthreads();
     lb_add_active(n, x, ix, xl, xu);
     __syncthreads();
-    fval = lb_objgrad<OBJ>(n, x, gf, S, oscratch);
+    LB_EVAL(0, resume_first, fval);
+    if (P.ftrace && tid == 0 && nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + nevals] = fval;
     ++nevals; ++c.nfg;
+    if (!EXT && P.abort) tmo = *(const volatile int32_t *) P.abort == 100;
+    if (tmo) c.iterm = 100;                                                  /* plis.c:263 */
 
-    for (;;) {
+    while (c.iterm != 100) {
         /* pytrcg: largest free gradient component, largest wrong-signed multiplier on an active bound */
         {
             double gm = 0, um = 0;
@@ -124,8 +173,10 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
             umax = lb_block_max(um, S);
         }
         c.kd = kd;
-        lb_pyfut1(n, fval, &fo, umax, gmax, xstop, &ls, 0, nevals, tolg, &c);
+        if (!EXT && P.abort) { const int ab = *(const volatile int32_t *) P.abort; forced = ab == -999; tmo = ab == 100; }
+        lb_pyfut1(n, fval, &fo, umax, gmax, xstop, &ls, forced, nevals, tolg, &c);
         if (c.iterm != 0) break;
+        if (tmo) { c.iterm = 100; break; }                                   /* plis.c:273 */
         if (rmax > 0. && umax > eps8 * gmax) {                               /* pyrmc0: release wrong-signed active bounds */
             int rel = 0;
             for (int i = tid; i < n; i += LB_T) {
@@ -140,17 +191,17 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
         }
         __syncthreads();
     direction:
-        gnorm = sqrt(lb_mdot(n, gf, gf, ix, S));
+        gnorm = sqrt(MDOT(gf, gf));
         if (c.irest == 0) {
             k = LB_MIN(c.nit - c.kit, mf);
             if (k <= 0) c.irest = LB_MAX(c.irest, 1);
             else {
-                b = lb_mdot(n, COLX(1), COLG(1), ix, S);
+                b = MDOT(COLX(1), COLG(1));
                 if (b <= 0.) c.irest = LB_MAX(c.irest, 1);
                 else {
                     if (tid == 0) COLU(1) = 1. / b;
                     cols += k;
-                    if (n <= LB_T * LB_EPT) {
+                    if (n <= LB_T * LB_EPT && !P.exact) {
                         /* the two Strang loops with s held in registers (thread t owns coordinates t, t+256, ...: the same
                          * partial-sum order as lb_mdot) and the next history column prefetched while the current dot
                          * product is being reduced — one barrier pair per column, no s traffic */
@@ -219,21 +270,21 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
                         __syncthreads();
                         for (int j = 1; j <= k; ++j) {                           /* mxdrcb */
                             const double *cx = COLX(j), *cg = COLG(j);
-                            const double v = COLU(j) * lb_mdot(n, s, cx, ix, S);
+                            const double v = COLU(j) * MDOT(s, cx);
                             if (tid == 0) vcol[j - 1] = v;
                             for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + (-v) * cg[i];
                             __syncthreads();
                         }
-                        a = lb_mdot(n, COLG(1), COLG(1), ix, S);
+                        a = MDOT(COLG(1), COLG(1));
                         if (a > 0.) { const double sc = b / a; for (int i = tid; i < n; i += LB_T) s[i] = s[i] * sc; __syncthreads(); }
                         for (int j = k; j >= 1; --j) {                           /* mxdrcf */
                             const double *cx = COLX(j), *cg = COLG(j);
-                            const double t = COLU(j) * lb_mdot(n, s, cg, ix, S);
+                            const double t = COLU(j) * MDOT(s, cg);
                             const double w = vcol[j - 1] - t;
                             for (int i = tid; i < n; i += LB_T) if (ix[i] >= 0) s[i] = s[i] + w * cx[i];
                             __syncthreads();
                         }
-                        snorm = sqrt(lb_mdot(n, s, s, ix, S));
+                        snorm = sqrt(MDOT(s, s));
                     }
                     head = (head + mf - 1) % mf;                             /* mxdrsu: every column one older */
                 }
@@ -246,7 +297,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
             if (c.kit < c.nit) c.kit = c.nit;
             else { c.iterm = -10; if (c.iters < 0) c.iterm = c.iters - 5; }
         }
-        if (kd > 0) p = lb_mdot(n, gf, s, ix, S);
+        if (kd > 0) p = MDOT(gf, s);
         if (snorm <= 0.) c.irest = LB_MAX(c.irest, 1);
         else if (p + told * gnorm * snorm <= 0.) c.irest = 0;
         else c.irest = LB_MAX(c.irest, 1);
@@ -256,6 +307,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
             rmax = LB_MIN(alf2 * gnorm / snorm, xmax / snorm);
         }
         if (c.iterm != 0) break;
+        if (tmo) { c.iterm = 100; break; }                                   /* plis.c:371 */
         if (c.irest != 0) goto direction;
         /* pytrcs: save x, g in column 1; zero s on active bounds; largest step inside the box */
         q.fp = fo; fo = fval; po = p;
@@ -286,9 +338,10 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
                 __syncthreads();
                 lb_project(n, x, ix, xl, xu, eps9);
                 __syncthreads();
-                q.f = lb_objgrad<OBJ>(n, x, gf, S, oscratch);
+                LB_EVAL(1, resume_linesearch, q.f);
+                if (P.ftrace && tid == 0 && nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + nevals] = q.f;
                 ++nevals; ++c.nfg;
-                q.p = lb_mdot(n, gf, s, ix, S);
+                q.p = MDOT(gf, s);
             }
             fval = q.f; p = q.p; kd = q.kd; nred = q.nred; maxst = q.maxst; c.iters = q.iters;
             if (c.iters <= 0) {                                              /* zero step: restore and restart */
@@ -307,12 +360,26 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
                     double ddx = x[i] - dx[i], ddg = gf[i] - dg[i];
                     if (ix[i] < 0) { ddx = 0.; ddg = 0.; }
                     dx[i] = ddx; dg[i] = ddg;
-                    nx += fabs(x[i]); ndx += fabs(ddx);
+                    if (P.x_weights) { nx += P.x_weights[i] * fabs(x[i]); ndx += P.x_weights[i] * fabs(ddx); }
+                    else { nx += fabs(x[i]); ndx += fabs(ddx); }
                 }
                 po = q.r * po; p = q.r * p;
-                nx = lb_block_sum(nx, S);
-                ndx = lb_block_sum(ndx, S);
-                xstop = ndx < xtol_rel * nx;                                  /* stop.c:110-120, no xtol_abs / weights on this path */
+                if (P.exact) {                                                /* stop.c:37-57 vector_norm, sequential */
+                    __syncthreads();
+                    const double *w = P.x_weights;
+                    nx = lb_seq_sum(n, 0., [&](int i) { return w ? w[i] * fabs(x[i]) : fabs(x[i]); }, XB.a);
+                    ndx = lb_seq_sum(n, 0., [&](int i) { return w ? w[i] * fabs(dx[i]) : fabs(dx[i]); }, XB.a);
+                } else {
+                    nx = lb_block_sum(nx, S);
+                    ndx = lb_block_sum(ndx, S);
+                }
+                xstop = ndx < xtol_rel * nx;                                  /* nlopt_stop_dx, stop.c:110-120 */
+                if (!xstop && P.xtol_abs) {
+                    int viol = 0;
+                    __syncthreads();
+                    for (int i = tid; i < n; i += LB_T) viol += fabs(dx[i]) >= P.xtol_abs[i];
+                    xstop = lb_block_isum(viol, S) == 0;
+                }
             }
         }
         for (int i = tid; i < n; i += LB_T) if (ix[i] < 0) ix[i] = -ix[i];   /* mxvine */
@@ -320,7 +387,12 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
         lb_add_active(n, x, ix, xl, xu);
         __syncthreads();
     }
-    if (tid == 0) { out[inst].f = fval; out[inst].ret = lb_result_of_iterm(c.iterm); out[inst].nevals = nevals; out[inst].iterm = c.iterm; out[inst].cols = cols; }
+    if (tid == 0) {
+        out[inst].f = fval; out[inst].ret = lb_result_of_iterm(c.iterm); out[inst].nevals = nevals; out[inst].iterm = c.iterm; out[inst].cols = cols;
+        if (EXT) E.req[inst].state = 2;
+    }
+#undef MDOT
+#undef LB_EVAL
 #undef COLX
 #undef COLG
 #undef COLU
@@ -329,15 +401,24 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
 extern "C" size_t nla_lbfgs_work_doubles(int ld, int mf, int count) { return (size_t) count * (4 * (size_t) ld + 2 * (size_t) mf); }
 extern "C" size_t nla_lbfgs_hist_doubles(int ld, int mf, int count) { return (size_t) count * 2 * (size_t) mf * (size_t) ld; }
 
+extern "C" size_t nla_lbfgs_save_bytes(void) { return sizeof(lb_saved); }
+
 extern "C" int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
                                  double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
-                                 void *stream)
+                                 const nla_local_ext *ext, void *stream)
 {
     if (count <= 0) return 0;
     hipStream_t st = (hipStream_t) stream;
-    const nla_lbfgs_params P = *params;
-#define CALL(O) hipLaunchKernelGGL((lbfgs_batch_kernel<O>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, iwork, hist, P, out)
-    NLA_OBJ_DISPATCH(obj, CALL)
+    nla_lbfgs_params P = *params;
+    nla_local_ext E = {};
+    if (P.sign == 0.) P.sign = 1.;
+    if (obj == NLA_OBJ_EXTERNAL) {
+        if (!ext || !ext->req || !ext->EX || !ext->EG || !ext->EF || !ext->save) return (int) hipErrorInvalidValue;
+        E = *ext;
+    }
+#define CALL(O) hipLaunchKernelGGL((lbfgs_batch_kernel<O>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, iwork, hist, P, out, E)
+    if (obj == NLA_OBJ_EXTERNAL) { CALL(NLA_OBJ_EXTERNAL); }
+    else NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     NLA_LAUNCH_CHECK();
     return 0;

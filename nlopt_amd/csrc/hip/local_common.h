@@ -56,6 +56,43 @@ __device__ __forceinline__ int lb_block_isum(int v, lb_shared &S)
     return t;
 }
 
+/* ---- exact-order mode ("amd_exact_dot", nla_lbfgs_params.exact / nla_mma_params.exact) --------------------------------
+ * The reference accumulates every dot product, norm and objective sum in ONE accumulator over i = 0 .. n-1
+ * (mssubs.c:601-641 mxudot, stop.c:37-57 vector_norm, mma.c:88-124 dual_func, the zoo's loops).  In exact mode the terms
+ * are formed in parallel into LDS and then added in that order by every thread redundantly (LDS broadcast reads), so all
+ * threads hold the bit-identical sum the sequential host loop produces.  A verification mode: n serial additions per
+ * reduction instead of log2(256) + n/256. */
+#define LB_XCH 1024
+struct lb_exact_buf { double a[LB_XCH]; double b[LB_XCH]; };
+
+template <class Term>
+__device__ __forceinline__ double lb_seq_sum(int n, double init, Term term, double *buf)
+{
+    double acc = init;
+    for (int base = 0; base < n; base += LB_XCH) {
+        const int m = n - base < LB_XCH ? n - base : LB_XCH;
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += LB_T) buf[i] = term(base + i);
+        __syncthreads();
+        for (int i = 0; i < m; ++i) acc += buf[i];
+    }
+    return acc;
+}
+/* two sums over the same index range at once (terms written by `fill(i, &a, &b)`), second one optionally a product */
+template <bool PROD, class Fill>
+__device__ __forceinline__ void lb_seq_sum2(int first, int n, double *acc_a, double *acc_b, Fill fill, lb_exact_buf &B)
+{
+    double a = *acc_a, b = *acc_b;
+    for (int base = first; base < n; base += LB_XCH) {
+        const int m = n - base < LB_XCH ? n - base : LB_XCH;
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += LB_T) fill(base + i, &B.a[i], &B.b[i]);
+        __syncthreads();
+        for (int i = 0; i < m; ++i) { a += B.a[i]; if (PROD) b *= B.b[i]; else b += B.b[i]; }
+    }
+    *acc_a = a; *acc_b = b;
+}
+
 /* masked dot product (mxudot, job > 0): coordinates on an active bound (ix < 0) are skipped */
 __device__ __forceinline__ double lb_mdot(int n, const double *x, const double *y, const int *ix, lb_shared &S)
 {
@@ -63,21 +100,63 @@ __device__ __forceinline__ double lb_mdot(int n, const double *x, const double *
     for (int i = threadIdx.x; i < n; i += LB_T) if (ix[i] >= 0) t += x[i] * y[i];
     return lb_block_sum(t, S);
 }
+/* the same in the reference's summation order (mssubs.c:601-641); a skipped coordinate contributes +0.0 */
+__device__ __forceinline__ double lb_mdot_exact(int n, const double *x, const double *y, const int *ix, lb_exact_buf &B)
+{
+    return lb_seq_sum(n, 0., [&](int i) { return ix[i] >= 0 ? x[i] * y[i] : 0.; }, B.a);
+}
+
+/* f in the host callback's summation order (../objfuncs.h nla_obj_eval_seq): one accumulator over i ascending, the
+ * accumulator's start value as there.  *t receives the sums the gradient formulas need. */
+template <int OBJ>
+__device__ __forceinline__ double lb_obj_exact(int n, const double *x, nla_obj_part *t, lb_exact_buf &B)
+{
+    double a = 0, b = 0;
+    if (OBJ == NLA_OBJ_RASTRIGIN) {
+        a = lb_seq_sum(n, 10.0 * n, [&](int i) { return nla_rastrigin_term(x[i]); }, B.a);
+        t->a = a; t->b = 0;
+        return a;
+    } else if (OBJ == NLA_OBJ_ACKLEY) {
+        lb_seq_sum2<false>(0, n, &a, &b, [&](int i, double *pa, double *pb) { *pa = nla_sqr(x[i]); *pb = nla_ackley_cos_term(x[i]); }, B);
+        t->a = a; t->b = b;
+        return nla_ackley_finish(a, b, (unsigned) n);
+    } else if (OBJ == NLA_OBJ_GRIEWANK) {
+        a = 1; b = 1;
+        lb_seq_sum2<true>(0, n, &a, &b, [&](int i, double *pa, double *pb) { *pa = nla_griewank_sum_term(x[i]); *pb = nla_griewank_prod_term(x[i], (unsigned) i); }, B);
+        t->a = a; t->b = b;
+        return a - b;
+    } else if (OBJ == NLA_OBJ_ROSENBROCK) {
+        a = lb_seq_sum(n - 1, 0., [&](int i) { return nla_rosenbrock_term(x[i], x[i + 1]); }, B.a);
+    } else if (OBJ == NLA_OBJ_LEVY) {
+        a = lb_seq_sum(n - 1, nla_levy_head(x[0], x[n - 1]), [&](int i) { return nla_levy_term(x[i], x[i + 1]); }, B.a);
+    } else {
+        a = lb_seq_sum(n, 0., [&](int i) { return nla_sqr(x[i]); }, B.a);
+    }
+    t->a = a; t->b = 0;
+    return a;
+}
 
 /* objective and gradient of one point by the workgroup (same per-element formulas as the host
- * callbacks in ../objfuncs.h nla_obj_eval_seq) */
+ * callbacks in ../objfuncs.h nla_obj_eval_seq); exact != 0: f summed in the host's order; sign = -1: the maximisation
+ * wrapper of the reference (f_max, optimize.c:970-980: -f and -gradient) */
 template <int OBJ>
-__device__ __forceinline__ double lb_objgrad(int n, const double *x, double *g, lb_shared &S, double *scratch)
+__device__ __forceinline__ double lb_objgrad(int n, const double *x, double *g, lb_shared &S, double *scratch, int exact,
+                                             lb_exact_buf &XB, double sign)
 {
     const int tid = threadIdx.x;
-    nla_obj_part t = nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, tid, LB_T, [&](int i) { return x[i]; }));
-    __syncthreads();
-    if ((tid & 63) == 0) { scratch[2 * (tid >> 6)] = t.a; scratch[2 * (tid >> 6) + 1] = t.b; }
-    __syncthreads();
-    t.a = scratch[0]; t.b = scratch[1];
+    nla_obj_part t;
+    double f;
+    if (exact) f = lb_obj_exact<OBJ>(n, x, &t, XB);
+    else {
+        t = nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, tid, LB_T, [&](int i) { return x[i]; }));
+        __syncthreads();
+        if ((tid & 63) == 0) { scratch[2 * (tid >> 6)] = t.a; scratch[2 * (tid >> 6) + 1] = t.b; }
+        __syncthreads();
+        t.a = scratch[0]; t.b = scratch[1];
 #pragma unroll
-    for (int w = 1; w < LB_W; ++w) { nla_obj_part o; o.a = scratch[2 * w]; o.b = scratch[2 * w + 1]; t = nla_obj_combine<OBJ>(t, o); }
-    const double f = nla_obj_finish<OBJ>(n, t, [&](int i) { return x[i]; });
+        for (int w = 1; w < LB_W; ++w) { nla_obj_part o; o.a = scratch[2 * w]; o.b = scratch[2 * w + 1]; t = nla_obj_combine<OBJ>(t, o); }
+        f = nla_obj_finish<OBJ>(n, t, [&](int i) { return x[i]; });
+    }
     if (OBJ == NLA_OBJ_RASTRIGIN) {
         for (int i = tid; i < n; i += LB_T) g[i] = 2 * x[i] + 10.0 * NLA_PI2 * sin(NLA_PI2 * x[i]);
     } else if (OBJ == NLA_OBJ_ACKLEY) {
@@ -115,6 +194,11 @@ __device__ __forceinline__ double lb_objgrad(int n, const double *x, double *g, 
         for (int i = tid; i < n; i += LB_T) g[i] = 2 * x[i];
     }
     __syncthreads();
+    if (sign < 0) {
+        for (int i = tid; i < n; i += LB_T) g[i] = -g[i];
+        __syncthreads();
+        f = -f;
+    }
     return f;
 }
 

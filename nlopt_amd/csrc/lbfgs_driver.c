@@ -1,13 +1,22 @@
 /* lbfgs_driver.c — NLOPT_LD_LBFGS behind the reference's entry point luksan_plis (plis.c:420-510):
- * argument handling on the host, the optimisation itself in one launch of the batched device
- * kernel (hip/lbfgs_kernels.hip) — used directly by nlopt_optimize(LD_LBFGS) with count = 1 and by
+ * argument handling on the host, the optimisation itself in the batched device kernel
+ * (hip/lbfgs_kernels.hip) — used directly by nlopt_optimize(LD_LBFGS) with count = 1 and by
  * MLSL (mlsl_driver.c) with one workgroup per start point.  The batch context (nla_local_ctx) also
  * carries the second local optimiser, LD_MMA (mma_driver.c, hip/mma_kernels.hip).
  *
- * Provided for device objectives (nlopt_amd_objective): the objective and its gradient are
- * evaluated inside the kernel.  A host callback would need a PCIe round trip per evaluation; that
- * path is not provided and says so. */
+ * Three kinds of objective (nla_evaluator):
+ *   device    a compiled-in device objective (nlopt_amd_objective): evaluated inside the kernel, a whole search is
+ *             one launch; the host only watches the clock / the force_stop flag while it waits and raises the
+ *             kernel's abort flag (plis.c:263,273,371, pssubs.c:914);
+ *   host      any other nlopt_func: the reference's callback contract (nlopt.h:60-62) — f is called on the caller's
+ *             thread, one x at a time, in the reference's order.  The kernel runs as a coroutine (include/nlopt_amd.h
+ *             "External evaluation"): every vector operation of the search stays on the device, only x travels to the
+ *             host and f / gradient back, once per evaluation;
+ *   user      a device objective supplied by the user as a code object (nlopt_amd_set_device_objective, userobj.c):
+ *             the same coroutine, the evaluations of all waiting searches of a batch made by one launch of the user's
+ *             kernel. */
 #include "nla_internal.h"
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,7 +34,8 @@ int nla_lbfgs_default_mf(int n, int mf, int maxeval)        /* plis.c:441-445 */
 
 /* a reusable batch: device buffers for up to `cap` simultaneous local searches by LD_LBFGS (alg 0) or LD_MMA (alg 1) */
 struct nla_local_ctx {
-    int alg, obj, n, ld, cap, mf;
+    int alg, n, ld, cap, mf;
+    nla_evaluator ev;
     nla_mma_params mma;            /* alg 1: the algorithm's own parameters (the stopping values come with each run) */
     const double *d_sigma_init;    /* alg 1: initial step on the device, or NULL */
     void *st;
@@ -35,64 +45,207 @@ struct nla_local_ctx {
     nla_lbfgs_result *d_res;
     void *ev0, *ev1;
     nlopt_amd_stats *stats;        /* optional: device time / algorithmic bytes of the launches are added here */
+    /* options of a run (nla_local_ctx_set_options) */
+    int exact;
+    double *d_xtol_abs, *d_x_weights;
+    int32_t *h_abort;              /* pinned, device-visible: 0, 100 (maxtime) or -999 (forced stop) */
+    /* external evaluation */
+    nla_local_ext ext;             /* device buffers */
+    nla_local_req *h_req;          /* pinned */
+    double *h_x, *h_g, *h_f;       /* pinned: one point, one gradient, cap values */
+    int32_t *h_list, *d_list;      /* user objective: indices of the waiting searches */
+    double *d_ftrace; int64_t ftrace_cap;   /* optional per-evaluation f trace (nla_local_ctx_set_ftrace) */
 };
 
 void nla_local_ctx_destroy(nla_local_ctx *c)
 {
     if (!c) return;
     nla_dev_free(c->d_X); nla_dev_free(c->d_work); nla_dev_free(c->d_iwork); nla_dev_free(c->d_hist); nla_dev_free(c->d_res);
+    nla_dev_free(c->d_xtol_abs); nla_dev_free(c->d_x_weights);
+    nla_dev_free(c->ext.req); nla_dev_free(c->ext.EX); nla_dev_free(c->ext.EG); nla_dev_free(c->ext.EF); nla_dev_free(c->ext.save);
+    nla_dev_free(c->d_list); nla_dev_free(c->d_ftrace);
+    nla_host_free(c->h_abort); nla_host_free(c->h_req); nla_host_free(c->h_x); nla_host_free(c->h_g); nla_host_free(c->h_f);
+    nla_host_free(c->h_list);
     nla_event_destroy(c->ev0); nla_event_destroy(c->ev1);
     free(c);
 }
 
-nla_local_ctx *nla_local_ctx_create(int obj, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream)
+static int ctx_common(nla_local_ctx *c, const nla_evaluator *ev, int n, int cap, const double *d_lb, const double *d_ub, void *stream)
+{
+    const size_t save = c->alg == 1 ? nla_mma_save_bytes() : nla_lbfgs_save_bytes();
+    c->ev = *ev; c->n = n; c->ld = (n + 1) & ~1; c->cap = cap; c->st = stream; c->d_lb = d_lb; c->d_ub = d_ub;
+    c->d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld * (size_t) cap);
+    c->d_res = (nla_lbfgs_result *) nla_dev_malloc(sizeof(nla_lbfgs_result) * (size_t) cap);
+    c->h_abort = (int32_t *) nla_host_malloc(sizeof(int32_t));
+    c->ev0 = nla_event_create(); c->ev1 = nla_event_create();
+    if (!c->d_X || !c->d_res || !c->h_abort || !c->ev0 || !c->ev1) return -1;
+    *c->h_abort = 0;
+    if (ev->kind != NLA_EVAL_DEVICE) {
+        c->ext.req = (nla_local_req *) nla_dev_malloc(sizeof(nla_local_req) * (size_t) cap);
+        c->ext.EX = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld * (size_t) cap);
+        c->ext.EG = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld * (size_t) cap);
+        c->ext.EF = (double *) nla_dev_malloc(sizeof(double) * (size_t) cap);
+        c->ext.save = nla_dev_malloc(save * (size_t) cap);
+        c->h_req = (nla_local_req *) nla_host_malloc(sizeof(nla_local_req) * (size_t) cap);
+        c->h_x = (double *) nla_host_malloc(sizeof(double) * (size_t) c->ld);
+        c->h_g = (double *) nla_host_malloc(sizeof(double) * (size_t) c->ld);
+        c->h_f = (double *) nla_host_malloc(sizeof(double) * (size_t) cap);
+        c->h_list = (int32_t *) nla_host_malloc(sizeof(int32_t) * (size_t) cap);
+        c->d_list = (int32_t *) nla_dev_malloc(sizeof(int32_t) * (size_t) cap);
+        if (!c->ext.req || !c->ext.EX || !c->ext.EG || !c->ext.EF || !c->ext.save || !c->h_req || !c->h_x || !c->h_g || !c->h_f ||
+            !c->h_list || !c->d_list) return -1;
+    }
+    return 0;
+}
+
+nla_local_ctx *nla_local_ctx_create(const nla_evaluator *ev, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream)
 {
     nla_local_ctx *c = (nla_local_ctx *) calloc(1, sizeof *c);
     if (!c) return NULL;
-    c->obj = obj; c->n = n; c->ld = (n + 1) & ~1; c->cap = cap; c->mf = mf; c->st = stream; c->d_lb = d_lb; c->d_ub = d_ub;
-    c->d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld * (size_t) cap);
+    c->mf = mf;
+    if (ctx_common(c, ev, n, cap, d_lb, d_ub, stream)) { nla_local_ctx_destroy(c); return NULL; }
     c->d_work = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_work_doubles(c->ld, mf, cap));
     c->d_iwork = (int *) nla_dev_malloc(sizeof(int) * (size_t) c->ld * (size_t) cap);
     c->d_hist = (double *) nla_dev_malloc(sizeof(double) * nla_lbfgs_hist_doubles(c->ld, mf, cap));
-    c->d_res = (nla_lbfgs_result *) nla_dev_malloc(sizeof(nla_lbfgs_result) * (size_t) cap);
-    c->ev0 = nla_event_create(); c->ev1 = nla_event_create();
-    if (!c->d_X || !c->d_work || !c->d_iwork || !c->d_hist || !c->d_res || !c->ev0 || !c->ev1) { nla_local_ctx_destroy(c); return NULL; }
+    if (!c->d_work || !c->d_iwork || !c->d_hist) { nla_local_ctx_destroy(c); return NULL; }
     return c;
 }
 /* the same for LD_MMA (mma_driver.c reads the parameters; sigma_init: device copy of the initial step or NULL) */
-nla_local_ctx *nla_local_ctx_create_mma(int obj, int n, int cap, const nla_mma_params *alg_params, const double *d_sigma_init,
+nla_local_ctx *nla_local_ctx_create_mma(const nla_evaluator *ev, int n, int cap, const nla_mma_params *alg_params, const double *d_sigma_init,
                                         const double *d_lb, const double *d_ub, void *stream)
 {
     nla_local_ctx *c = (nla_local_ctx *) calloc(1, sizeof *c);
     if (!c) return NULL;
-    c->alg = 1; c->obj = obj; c->n = n; c->ld = (n + 1) & ~1; c->cap = cap; c->st = stream; c->d_lb = d_lb; c->d_ub = d_ub;
+    c->alg = 1;
     c->mma = *alg_params; c->d_sigma_init = d_sigma_init;
-    c->d_X = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld * (size_t) cap);
+    if (ctx_common(c, ev, n, cap, d_lb, d_ub, stream)) { nla_local_ctx_destroy(c); return NULL; }
     c->d_work = (double *) nla_dev_malloc(sizeof(double) * nla_mma_work_doubles(c->ld, cap));
-    c->d_res = (nla_lbfgs_result *) nla_dev_malloc(sizeof(nla_lbfgs_result) * (size_t) cap);
-    c->ev0 = nla_event_create(); c->ev1 = nla_event_create();
-    if (!c->d_X || !c->d_work || !c->d_res || !c->ev0 || !c->ev1) { nla_local_ctx_destroy(c); return NULL; }
+    if (!c->d_work) { nla_local_ctx_destroy(c); return NULL; }
     return c;
 }
 void nla_local_ctx_set_stats(nla_local_ctx *c, nlopt_amd_stats *stats) { if (c) c->stats = stats; }
 int nla_local_ctx_alg(const nla_local_ctx *c) { return c->alg; }
-
 double *nla_local_ctx_X(nla_local_ctx *c) { return c->d_X; }
 
-/* run `count` searches from the rows already in ctx X; minimisers stay there, results come to the host */
-int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res)
+/* exact-order sums ("amd_exact_dot"), per-coordinate x tolerances and weights (host arrays of n or NULL; stop.c:98-120) */
+int nla_local_ctx_set_options(nla_local_ctx *c, int exact, const double *xtol_abs, const double *x_weights)
 {
-    int rc, i;
-    if (count > c->cap) return -1;
-    nla_event_record(c->ev0, c->st);
+    c->exact = exact;
+    nla_dev_free(c->d_xtol_abs); nla_dev_free(c->d_x_weights);
+    c->d_xtol_abs = c->d_x_weights = NULL;
+    if (xtol_abs) {
+        c->d_xtol_abs = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld);
+        if (!c->d_xtol_abs || nla_memcpy_h2d(c->d_xtol_abs, xtol_abs, sizeof(double) * (size_t) c->n, c->st)) return -1;
+    }
+    if (x_weights) {
+        c->d_x_weights = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld);
+        if (!c->d_x_weights || nla_memcpy_h2d(c->d_x_weights, x_weights, sizeof(double) * (size_t) c->n, c->st)) return -1;
+    }
+    return nla_stream_sync(c->st);
+}
+
+/* record f of every evaluation of each search (cap per search); read back with nla_local_ctx_read_ftrace */
+int nla_local_ctx_set_ftrace(nla_local_ctx *c, int64_t cap)
+{
+    nla_dev_free(c->d_ftrace);
+    c->d_ftrace = NULL; c->ftrace_cap = 0;
+    if (cap <= 0) return 0;
+    c->d_ftrace = (double *) nla_dev_malloc(sizeof(double) * (size_t) cap * (size_t) c->cap);
+    if (!c->d_ftrace) return -1;
+    c->ftrace_cap = cap;
+    return 0;
+}
+int nla_local_ctx_read_ftrace(nla_local_ctx *c, int inst, int64_t count, double *h_out)
+{
+    if (!c->d_ftrace || count > c->ftrace_cap) return -1;
+    if (nla_memcpy_d2h(h_out, c->d_ftrace + (size_t) inst * (size_t) c->ftrace_cap, sizeof(double) * (size_t) count, c->st)) return -1;
+    return nla_stream_sync(c->st);
+}
+
+static int launch(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, const nla_local_ext *ext)
+{
+    const int obj = c->ev.kind == NLA_EVAL_DEVICE ? c->ev.obj : NLA_OBJ_EXTERNAL;
     if (c->alg == 1) {
         nla_mma_params P = c->mma;
         P.minf_max = prm->minf_max; P.ftol_rel = prm->ftol_rel; P.ftol_abs = prm->ftol_abs; P.xtol_rel = prm->xtol_rel; P.maxeval = prm->maxeval;
-        if ((rc = nla_k_mma_batch(c->obj, c->n, c->ld, count, c->d_lb, c->d_ub, c->d_sigma_init, c->d_X, c->d_work, &P, c->d_res, c->st))) return rc;
-    } else if ((rc = nla_k_lbfgs_batch(c->obj, c->n, c->ld, c->mf, count, c->d_lb, c->d_ub, c->d_X, c->d_work, c->d_iwork, c->d_hist, prm, c->d_res, c->st))) return rc;
-    nla_event_record(c->ev1, c->st);
-    if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
-    if ((rc = nla_stream_sync(c->st))) return rc;
+        P.exact = c->exact; P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.x_weights = c->d_x_weights; P.abort = c->h_abort;
+        P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap;
+        return nla_k_mma_batch(obj, c->n, c->ld, count, c->d_lb, c->d_ub, c->d_sigma_init, c->d_X, c->d_work, &P, c->d_res, ext, c->st);
+    } else {
+        nla_lbfgs_params P = *prm;
+        P.exact = c->exact; P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.x_weights = c->d_x_weights; P.abort = c->h_abort;
+        P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap;
+        return nla_k_lbfgs_batch(obj, c->n, c->ld, c->mf, count, c->d_lb, c->d_ub, c->d_X, c->d_work, c->d_iwork, c->d_hist, &P, c->d_res, ext, c->st);
+    }
+}
+
+/* wait for the stream; meanwhile forward the caller's force_stop flag and maxtime to the kernel's abort flag */
+static int wait_watching(nla_local_ctx *c, const nla_stopping *stop)
+{
+    int rc;
+    if (!stop || (!stop->force_stop && stop->maxtime <= 0)) return nla_stream_sync(c->st);
+    while ((rc = nla_stream_query(c->st)) == -1) {
+        if (nla_stop_forced(stop)) *(volatile int32_t *) c->h_abort = -999;
+        else if (nla_stop_time(stop)) *(volatile int32_t *) c->h_abort = 100;
+        sched_yield();
+    }
+    return rc;
+}
+
+/* run `count` searches from the rows already in ctx X; minimisers stay there, results come to the host.  stop (may be
+ * NULL): the caller's force_stop flag and time limit, observed during the searches; live_nevals (may be NULL; host
+ * objective only): incremented at every counted evaluation as the reference does (plis.c:261,391; mma.c:219,298). */
+int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res, const nla_stopping *stop,
+                      int *live_nevals)
+{
+    int rc, i;
+    if (count > c->cap) return -1;
+    *c->h_abort = 0;
+    nla_event_record(c->ev0, c->st);
+    if (c->ev.kind == NLA_EVAL_DEVICE) {
+        if ((rc = launch(c, count, prm, NULL))) return rc;
+        nla_event_record(c->ev1, c->st);
+        if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
+        if ((rc = wait_watching(c, stop))) return rc;
+    } else {
+        nla_local_ext E = c->ext;
+        const size_t rowb = sizeof(double) * (size_t) c->n;
+        if ((rc = nla_memset(E.req, 0, sizeof(nla_local_req) * (size_t) count, c->st))) return rc;
+        E.resume = 0;
+        for (;;) {
+            int waiting = 0;
+            E.forced = stop ? nla_stop_forced(stop) : 0;
+            E.timeout = stop ? nla_stop_time(stop) : 0;
+            if ((rc = launch(c, count, prm, &E))) return rc;
+            if ((rc = nla_memcpy_d2h(c->h_req, E.req, sizeof(nla_local_req) * (size_t) count, c->st))) return rc;
+            if ((rc = nla_stream_sync(c->st))) return rc;
+            for (i = 0; i < count; ++i) waiting += c->h_req[i].state == 1;
+            if (!waiting) break;
+            if (c->ev.kind == NLA_EVAL_USER) {
+                /* every waiting search is evaluated by one launch of the user's kernel; list entry i: search i wants its
+                 * gradient, -(i+1): the value only */
+                int m = 0;
+                for (i = 0; i < count; ++i) if (c->h_req[i].state == 1) c->h_list[m++] = (c->h_req[i].want_grad & 1) ? i : -(i + 1);
+                if ((rc = nla_memcpy_h2d(c->d_list, c->h_list, sizeof(int32_t) * (size_t) m, c->st))) return rc;
+                if ((rc = nla_userobj_evalgrad_list(c->ev.user, c->n, c->ld, m, c->d_list, E.EX, E.EF, E.EG, c->ev.sign, c->st))) return rc;
+            } else {
+                for (i = 0; i < count; ++i) {
+                    const int want = c->h_req[i].want_grad;          /* bit 0: gradient wanted; bit 1: LD_MMA's uncounted call (mma.c:337-339) */
+                    if (c->h_req[i].state != 1) continue;
+                    if ((rc = nla_memcpy_d2h(c->h_x, E.EX + (size_t) i * c->ld, rowb, c->st)) || (rc = nla_stream_sync(c->st))) return rc;
+                    c->h_f[i] = c->ev.f((unsigned) c->n, c->h_x, (want & 1) ? c->h_g : NULL, c->ev.f_data);
+                    if (live_nevals && !(want & 2)) ++*live_nevals;
+                    if ((rc = nla_memcpy_h2d(E.EF + i, c->h_f + i, sizeof(double), c->st))) return rc;
+                    if ((want & 1) && (rc = nla_memcpy_h2d(E.EG + (size_t) i * c->ld, c->h_g, rowb, c->st))) return rc;
+                    if ((rc = nla_stream_sync(c->st))) return rc;         /* h_g is reused by the next evaluation */
+                }
+            }
+            E.resume = 1;
+        }
+        nla_event_record(c->ev1, c->st);
+        if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
+        if ((rc = nla_stream_sync(c->st))) return rc;
+    }
     if (c->stats) {
         ++c->stats->lbfgs_launches;
         c->stats->t_lbfgs_ms += (double) nla_event_elapsed_ms(c->ev0, c->ev1);
@@ -103,17 +256,11 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
     return 0;
 }
 
-/* `count` local searches from the rows of h_X (count x n, host), results back in h_X / res */
-int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
-                        const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen)
-{
-    return nla_local_run_batch(0, obj, n, count, lb, ub, h_X, mf, NULL, NULL, prm, res, err, errlen);
-}
-
-/* alg 0: LD_LBFGS with mf history pairs; alg 1: LD_MMA with its parameters and optional initial step (host, n) */
-int nla_local_run_batch(int alg, int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
+/* `count` local searches from the rows of h_X (count x n, host), results back in h_X / res.
+ * alg 0: LD_LBFGS with mf history pairs; alg 1: LD_MMA with its parameters and optional initial step (host, n) */
+int nla_local_run_batch(int alg, const nla_evaluator *ev, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
                         const nla_mma_params *mma, const double *sigma_init, const nla_lbfgs_params *prm, nla_lbfgs_result *res,
-                        char *err, size_t errlen)
+                        const nla_stopping *stop, int exact, int *live_nevals, nlopt_opt trace_to, char *err, size_t errlen)
 {
     const int ld = (n + 1) & ~1;
     void *st = nla_stream_create();
@@ -127,12 +274,24 @@ int nla_local_run_batch(int alg, int obj, int n, int count, const double *lb, co
         d_si = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld);
         if (!d_si || nla_memcpy_h2d(d_si, sigma_init, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "upload failed"); goto done; }
     }
-    if (d_lb && d_ub) c = alg == 1 ? nla_local_ctx_create_mma(obj, n, count, mma, d_si, d_lb, d_ub, st) : nla_local_ctx_create(obj, n, count, mf, d_lb, d_ub, st);
+    if (d_lb && d_ub) c = alg == 1 ? nla_local_ctx_create_mma(ev, n, count, mma, d_si, d_lb, d_ub, st) : nla_local_ctx_create(ev, n, count, mf, d_lb, d_ub, st);
     if (!c) { snprintf(err, errlen, "out of device memory"); goto done; }
     if (nla_memcpy_h2d(d_lb, lb, sizeof(double) * (size_t) n, st) || nla_memcpy_h2d(d_ub, ub, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "upload failed"); goto done; }
+    if (nla_local_ctx_set_options(c, exact, stop ? stop->xtol_abs : NULL, stop ? stop->x_weights : NULL)) { snprintf(err, errlen, "upload failed"); goto done; }
     for (i = 0; i < count; ++i)
         if (nla_memcpy_h2d(c->d_X + (size_t) i * ld, h_X + (size_t) i * n, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "upload failed"); goto done; }
-    if ((i = nla_local_ctx_run(c, count, prm, res))) { snprintf(err, errlen, "local-search batch failed: %s", nla_dev_error_string(i)); goto done; }
+    if (trace_to && trace_to->trace && count == 1 && nla_local_ctx_set_ftrace(c, (int64_t) trace_to->trace_cap)) { snprintf(err, errlen, "out of device memory"); goto done; }
+    if ((i = nla_local_ctx_run(c, count, prm, res, stop, live_nevals))) { snprintf(err, errlen, "local-search batch failed: %s", nla_dev_error_string(i)); goto done; }
+    if (trace_to && trace_to->trace && count == 1) {
+        /* per-evaluation trace (nlopt_amd_set_trace): kind 5 = an objective call of a local search */
+        const int64_t calls = alg == 1 ? res[0].iterm : res[0].nevals;
+        const int64_t k = calls < (int64_t) trace_to->trace_cap ? calls : (int64_t) trace_to->trace_cap;
+        double *tmp = (double *) malloc(sizeof(double) * (size_t) (k > 0 ? k : 1));
+        if (!tmp || (k > 0 && nla_local_ctx_read_ftrace(c, 0, k, tmp))) { free(tmp); snprintf(err, errlen, "trace read-back failed"); goto done; }
+        for (i = 0; i < (int) k; ++i) { nlopt_amd_trace_rec *tr = trace_to->trace + i; tr->f = tmp[i]; tr->row = i; tr->kind = 5; tr->accepted = 0; }
+        trace_to->trace_len = (size_t) calls;
+        free(tmp);
+    }
     for (i = 0; i < count; ++i)
         if (nla_memcpy_d2h(h_X + (size_t) i * n, c->d_X + (size_t) i * ld, sizeof(double) * (size_t) n, st)) { snprintf(err, errlen, "read-back failed"); goto done; }
     if ((i = nla_stream_sync(st))) { snprintf(err, errlen, "read-back failed: %s", nla_dev_error_string(i)); goto done; }
@@ -145,26 +304,22 @@ done:
 }
 
 /* reference-shaped entry: luksan_plis(n, f, f_data, lb, ub, x, minf, stop, mf, tolg) (plis.c:420-426) */
-nlopt_result nla_lbfgs_minimize(int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+nlopt_result nla_lbfgs_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                                 nla_stopping *stop, int mf, double tolg)
 {
-    const int obj = nlopt_amd_objective_id(f);
+    nla_evaluator ev;
     nla_lbfgs_params prm;
     nla_lbfgs_result res;
     char err[200];
-    (void) f_data;
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
-    if (obj < 0) {
-        nla_stop_msg(stop, "nlopt_amd: LD_LBFGS is provided for device objectives (nlopt_amd_objective) only");
-        return NLOPT_INVALID_ARGS;
-    }
-    if (stop->xtol_abs) { nla_stop_msg(stop, "nlopt_amd: LD_LBFGS on the device does not take xtol_abs"); return NLOPT_INVALID_ARGS; }
+    nla_evaluator_resolve(&ev, opt, f, f_data);
     memset(&prm, 0, sizeof prm);
     prm.minf_max = stop->minf_max; prm.ftol_rel = stop->ftol_rel; prm.ftol_abs = stop->ftol_abs; prm.xtol_rel = stop->xtol_rel;
     prm.tolg = tolg; prm.maxeval = stop->maxeval;
     mf = nla_lbfgs_default_mf(n, mf, stop->maxeval);
-    if (nla_lbfgs_run_batch(obj, n, 1, lb, ub, x, mf, &prm, &res, err, sizeof err)) { nla_stop_msg(stop, "device engine: %s", err); return NLOPT_FAILURE; }
+    if (nla_local_run_batch(0, &ev, n, 1, lb, ub, x, mf, NULL, NULL, &prm, &res, stop, nla_exact_mode(opt),
+                            ev.kind == NLA_EVAL_HOST ? stop->nevals_p : NULL, opt, err, sizeof err)) { nla_stop_msg(stop, "device engine: %s", err); return NLOPT_FAILURE; }
     *minf = res.f;
-    *stop->nevals_p += res.nevals;
+    if (ev.kind != NLA_EVAL_HOST) *stop->nevals_p += res.nevals;       /* host objective: counted call by call */
     return (nlopt_result) res.ret;
 }

@@ -21,7 +21,12 @@
  *       are ALL-GATHERED (SURVEY.md §8e "all-gather of local minima"), after which every rank commits
  *       the whole batch in walk order.  world x BATCH_MAX searches are in flight per batch.
  *
- * Provided: local optimisers NLOPT_LD_LBFGS and NLOPT_LD_MMA (the GD_MLSL default) with a device objective; pseudo-random sampling (the non-LDS
+ * Objectives: compiled-in and user-supplied device objectives run batched as described; an ordinary host callback
+ * (nlopt_func) is served with the reference's contract — f is called on the caller's thread, one point at a time, in the
+ * reference's order (samples in order with the stop tests between them, mlsl.c:360-366; then one local search after the
+ * other, mlsl.c:404) — while sampling, distances and every vector operation of the local searches stay on the device.
+ *
+ * Provided: local optimisers NLOPT_LD_LBFGS and NLOPT_LD_MMA (the GD_MLSL default); pseudo-random sampling (the non-LDS
  * variants, and the LDS variants for n > 1111 where the reference's Sobol generator is NULL — sobolseq.c:143
  * — and mlsl.c:355-359 falls back to nlopt_urand) and Sobol sampling (LDS variants, n <= 1111; points by
  * index, sobol.c; no MT words are drawn in that mode).
@@ -41,6 +46,8 @@ static double gam(int n) { double z = n / 2; return sqrt(pow(K2PI * z, 1.0 / n) 
 
 typedef struct {
     int n, ld, obj, N;
+    nla_evaluator ev;
+    double *h_rows;                 /* host objective: the iteration's samples, pinned (N x ld) */
     void *st;
     nla_mtstream *mts;
     uint64_t words_used;
@@ -82,6 +89,7 @@ static void mfree(mlsl_dev *d)
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd);
     nla_dev_free(d->d_LM); nla_dev_free(d->d_LF); nla_dev_free(d->d_D); nla_dev_free(d->d_tmp); nla_dev_free(d->d_min);
     nla_dev_free(d->d_words); nla_dev_free(d->d_LX); nla_dev_free(d->d_V); nla_dev_free(d->d_dx);
+    nla_host_free(d->h_rows);
     nla_host_free(d->h_D); nla_host_free(d->h_idx); nla_host_free(d->h_lf); nla_host_free(d->h_flags);
     nla_dev_free(d->d_idx); nla_dev_free(d->d_flags);
     if (d->st) nla_stream_destroy(d->st);
@@ -172,10 +180,10 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     double R_prefactor, *Fnew = NULL, best_f = HUGE_VAL;
     const double dlm = 1.0, dbound = 1e-6;
     const double *lbh = lb, *ubh = ub;
-    int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0;
+    int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0, host, batch;
     nla_mma_params mma;
+    nla_stopping lstop;
     size_t best_row = 0;
-    (void) f_data;
 
     memset(&D, 0, sizeof D);
     D.N = Nsamples ? Nsamples : 4;                                             /* mlsl.c:283-286 */
@@ -186,18 +194,23 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         return NLOPT_INVALID_ARGS;
     }
     use_mma = local_opt->algorithm == NLOPT_LD_MMA;
-    if (local_opt->xtol_abs || (use_mma && local_opt->x_weights)) { nla_stop_msg(stop, "nlopt_amd: the local optimizer on the device does not take xtol_abs / x_weights"); return NLOPT_INVALID_ARGS; }
     if (use_mma && (i = nla_mma_read_params(local_opt, &mma))) {
         nla_stop_msg(stop, "%s", local_opt->errmsg ? local_opt->errmsg : "invalid LD_MMA parameter");
         return (nlopt_result) i;
     }
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
-    D.obj = nlopt_amd_objective_id(f);
-    if (D.obj < 0) { nla_stop_msg(stop, "nlopt_amd: MLSL is provided for device objectives (nlopt_amd_objective) only"); return NLOPT_INVALID_ARGS; }
+    nla_evaluator_resolve(&D.ev, opt, f, f_data);
+    D.obj = D.ev.kind == NLA_EVAL_DEVICE ? D.ev.obj : -1;
+    host = D.ev.kind == NLA_EVAL_HOST;
     D.n = n; D.ld = (n + 1) & ~1;
     D.comm = opt ? opt->comm : NULL;
     D.world = nlopt_amd_comm_world(D.comm); D.rank = nlopt_amd_comm_rank(D.comm);
-    bmax = BATCH_MAX * D.world;
+    batch = host ? 1 : BATCH_MAX;             /* a host callback is called for one search at a time, in the reference's order */
+    bmax = (host ? 1 : BATCH_MAX) * D.world;
+    /* what a local search observes of the caller's stopping state: the force_stop flag and the run's clock
+     * (nlopt_optimize_limited hands the remaining time down, optimize.c:1101-1104) */
+    lstop = *stop;
+    lstop.xtol_abs = local_opt->xtol_abs; lstop.x_weights = local_opt->x_weights;
     R_prefactor = sqrt(2. / K2PI) * pow(gam(n) * MLSL_SIGMA, 1.0 / n);            /* mlsl.c:313-317 */
     for (i = 0; i < n; ++i) R_prefactor *= pow(ub[i] - lb[i], 1.0 / n);
 
@@ -221,10 +234,11 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.h_flags = (int32_t *) nla_host_malloc(sizeof(int32_t) * (size_t) bmax);
     D.d_flags = (int32_t *) nla_dev_malloc(sizeof(int32_t) * (size_t) bmax);
     Fnew = (double *) malloc(sizeof(double) * (size_t) D.N);
+    if (host) D.h_rows = (double *) nla_host_malloc(sizeof(double) * (size_t) D.N * (size_t) D.ld);
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
     cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
-    if (!D.h_idx || !D.d_idx || !D.h_lf || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
@@ -251,8 +265,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             return NLOPT_OUT_OF_MEMORY;
         }
     }
-    D.lb = use_mma ? nla_local_ctx_create_mma(D.obj, n, BATCH_MAX, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
-                   : nla_local_ctx_create(D.obj, n, BATCH_MAX, mf, D.d_lb, D.d_ub, D.st);
+    D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
+                   : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);
+    if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode(opt) || nla_exact_mode(local_opt), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
     if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_local_ctx_set_stats(D.lb, st);
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
@@ -262,8 +277,15 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 #define GET_MINF() do { if (D.npts) { best_f = D.F[D.ord[0]]; best_row = D.ord[0]; best_is_lm = 0; } \
         if (D.nlms && D.LF[D.lord[0]] < best_f) { best_f = D.LF[D.lord[0]]; best_row = D.lord[0]; best_is_lm = 1; } } while (0)
 
+    /* f of `cnt` rows on the device: compiled-in objective, or the user's kernel (host objectives are called in the loops below) */
+#define EVAL_ROWS(rows, cnt, dF) (D.ev.kind == NLA_EVAL_USER ? nla_userobj_eval_rows(D.ev.user, n, D.ld, (cnt), (rows), (dF), NULL, D.ev.sign, D.st) \
+                                                              : nla_k_eval(D.obj, n, D.ld, (rows), (cnt), (dF), D.st))
     /* the starting guess is the first point (mlsl.c:326-340) */
-    if (nla_memcpy_h2d(D.d_P, x, sizeof(double) * (size_t) n, D.st) || nla_k_eval(D.obj, n, D.ld, D.d_P, 1, D.d_F, D.st) ||
+    if (host) {
+        D.F[0] = f((unsigned) n, x, NULL, f_data);
+        if (nla_memcpy_h2d(D.d_P, x, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_F, D.F, sizeof(double), D.st) ||
+            nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "first evaluation failed"); DEVFAIL(); }
+    } else if (nla_memcpy_h2d(D.d_P, x, sizeof(double) * (size_t) n, D.st) || EVAL_ROWS(D.d_P, 1, D.d_F) ||
         nla_memcpy_d2h(D.F, D.d_F, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "first evaluation failed"); DEVFAIL(); }
     ++*stop->nevals_p;
     NEWPT(0);
@@ -281,14 +303,16 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         if (D.d_V) {                                                           /* nlopt_sobol_next, mlsl.c:355 */
             if ((uint64_t) D.sobol_next + (uint64_t) D.N >= 4294967295ULL) { snprintf(D.err, sizeof D.err, "Sobol sequence exhausted (2^32-1 points)"); DEVFAIL(); }
             if (nla_k_mlsl_sobol_rows(n, D.ld, D.d_lb, D.d_ub, D.d_V, D.sobol_next, D.N, D.d_P + old * (size_t) D.ld, D.st) ||
-                nla_k_eval(D.obj, n, D.ld, D.d_P + old * (size_t) D.ld, D.N, D.d_F + old, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+                (!host && EVAL_ROWS(D.d_P + old * (size_t) D.ld, D.N, D.d_F + old))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         } else {
             if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
-            if (nla_k_crs_init_rows(D.obj, n, D.ld, D.d_lb, D.d_ub, D.d_words, (int64_t) old, D.N, D.d_P, D.d_F, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+            if (nla_k_crs_init_rows(D.obj, n, D.ld, D.d_lb, D.d_ub, D.d_words, (int64_t) old, D.N, D.d_P, D.d_F, D.st) ||
+                (D.ev.kind == NLA_EVAL_USER && EVAL_ROWS(D.d_P + old * (size_t) D.ld, D.N, D.d_F + old))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         }
-        if (
-            nla_memcpy_d2h(Fnew, D.d_F + old, sizeof(double) * (size_t) D.N, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+        if ((host ? nla_memcpy_d2h(D.h_rows, D.d_P + old * (size_t) D.ld, sizeof(double) * (size_t) D.N * (size_t) D.ld, D.st)
+                  : nla_memcpy_d2h(Fnew, D.d_F + old, sizeof(double) * (size_t) D.N, D.st)) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         for (i = 0; i < D.N && ret == NLOPT_SUCCESS; ++i) {
+            if (host) Fnew[i] = f((unsigned) n, D.h_rows + (size_t) i * (size_t) D.ld, NULL, f_data);   /* mlsl.c:360 */
             D.F[old + (size_t) i] = Fnew[i];
             ++*stop->nevals_p;
             if (st) ++st->evals_trial;
@@ -302,6 +326,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         }
         if (D.d_V) D.sobol_next += (uint32_t) used;
         else D.words_used += 2ULL * (uint64_t) n * (uint64_t) used;
+        if (host && (nla_memcpy_h2d(D.d_F + old, Fnew, sizeof(double) * used, D.st) || nla_stream_sync(D.st))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         if (ret != NLOPT_SUCCESS) break;
         {
             const int na = D.N, nb = (int) D.npts;
@@ -354,11 +379,21 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 nla_k_mlsl_near_bound(n, D.ld, D.d_P, D.d_idx, nb, D.d_lb, D.d_ub, dbound * R, D.d_flags, D.st) ||
                 nla_memcpy_d2h(D.h_flags, D.d_flags, sizeof(int32_t) * (size_t) nb, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
             /* local searches of this rank's share, all-gather of the minimisers, then their distances to every point */
+            if (host && D.world == 1) {
+                /* a host objective sees its calls: the tests the reference makes in front of a search (mlsl.c:390-399) are made
+                 * here, before the search's first callback, not at commit time */
+                if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+                if (D.h_flags[0]) mine = 0;                                         /* too close to a bound: not started */
+                else if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP;
+                else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
+                else if (stop->maxtime > 0 && nla_seconds() - stop->start >= stop->maxtime) ret = NLOPT_MAXTIME_REACHED;
+                if (ret != NLOPT_SUCCESS) break;
+            }
             limited = (long) stop->maxeval - (long) *stop->nevals_p;             /* nlopt_optimize_limited, optimize.c:1097-1100 */
             eff = loc_maxeval;
             if (loc_maxeval <= 0 || (limited > 0 && limited < loc_maxeval)) eff = (int) limited;
             prm.maxeval = eff;
-            if (mine > 0 && nla_local_ctx_run(D.lb, mine, &prm, res_mine)) { snprintf(D.err, sizeof D.err, "local-search batch failed"); DEVFAIL(); }
+            if (mine > 0 && nla_local_ctx_run(D.lb, mine, &prm, res_mine, &lstop, NULL)) { snprintf(D.err, sizeof D.err, "local-search batch failed"); DEVFAIL(); }
             if (nla_comm_allgather_dev(D.comm, nla_local_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st) ||
                 nla_comm_allgather_host(D.comm, res_mine, res, sizeof *res * (size_t) per, D.st)) {
                 snprintf(D.err, sizeof D.err, "all-gather of the local minima failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL();
@@ -390,9 +425,11 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 idx = cand[c] + 1;
                 if (pot && D.h_flags[c]) pot = 0;                               /* too close to a bound (mlsl.c:211-218) */
                 if (!pot) continue;
-                if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; break; }
-                if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; break; }
-                if (stop->maxtime > 0 && nla_seconds() - stop->start >= stop->maxtime) { ret = NLOPT_MAXTIME_REACHED; break; }
+                if (!(host && D.world == 1)) {
+                    if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; break; }
+                    if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; break; }
+                    if (stop->maxtime > 0 && nla_seconds() - stop->start >= stop->maxtime) { ret = NLOPT_MAXTIME_REACHED; break; }
+                }
                 /* did this search run under the evaluation limit it would have had in the serial order? */
                 limited = (long) stop->maxeval - (long) *stop->nevals_p;
                 eff = loc_maxeval;
@@ -404,7 +441,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                     nla_lbfgs_result r1;
                     p1.maxeval = eff;
                     if (nla_memcpy_d2d(nla_local_ctx_X(D.lb), D.d_P + r * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
-                        nla_local_ctx_run(D.lb, 1, &p1, &r1) ||
+                        nla_local_ctx_run(D.lb, 1, &p1, &r1, &lstop, NULL) ||
                         nla_memcpy_d2d(D.d_LX + g * (size_t) D.ld, nla_local_ctx_X(D.lb), sizeof(double) * (size_t) n, D.st) ||
                         nla_k_mlsl_dist2(n, D.ld, D.d_LX + g * (size_t) D.ld, 1, D.d_P, (int) D.npts, D.d_D, D.st) ||
                         nla_memcpy_d2h(D.h_D + g * D.npts, D.d_D, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "local-search rerun failed"); DEVFAIL(); }

@@ -4,9 +4,10 @@
  * NLOPT_GD_MLSL(_LDS) (optimize.c:763-768, deprecated.c:28).  The optimisation runs in one launch of the batched
  * device kernel (hip/mma_kernels.hip): count = 1 from nlopt_optimize(LD_MMA), one workgroup per start from MLSL.
  *
- * Not provided, and refused with a message: nonlinear constraints (the dual problem then has variables and the
- * reference solves it with a nested optimiser), host-callback objectives, xtol_abs / x_weights, and a run whose only stopping
- * criterion is maxtime (the search is one kernel launch; the clock is watched between launches only). */
+ * Objectives: compiled-in device objectives (the whole search is one launch), user device objectives and ordinary host
+ * callbacks (the kernel runs as a coroutine, lbfgs_driver.c).  maxtime and nlopt_force_stop are observed inside a search
+ * (mma.c:258-260,394-396).  Not provided, and refused with a message: nonlinear constraints (the dual problem then has
+ * variables and the reference solves it with a nested optimiser). */
 #include "nla_internal.h"
 #include <math.h>
 #include <stdio.h>
@@ -32,29 +33,22 @@ int nla_mma_read_params(nlopt_opt opt, nla_mma_params *out)
 nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
                               double *minf, nla_stopping *stop)
 {
-    const int obj = nlopt_amd_objective_id(f);
+    nla_evaluator ev;
     nla_mma_params mma;
     nla_lbfgs_params prm;
     nla_lbfgs_result res;
     char err[200];
     int rc;
-    (void) f_data;
     if ((rc = nla_mma_read_params(opt, &mma))) return (nlopt_result) rc;
     if (opt->m > 0) { nla_stop_msg(stop, "nlopt_amd: LD_MMA is provided without nonlinear constraints only (the MLSL local-search case)"); return NLOPT_INVALID_ARGS; }
-    /* the whole search is one kernel launch: it cannot watch the wall clock, so something it can test must be able to end it
-     * (MLSL gives its local optimiser tolerances when the caller did not, optimize.c:781-786) */
-    if (stop->ftol_rel <= 0 && stop->ftol_abs <= 0 && stop->xtol_rel <= 0 && stop->maxeval <= 0 && !(stop->minf_max > -HUGE_VAL)) {
-        nla_stop_msg(stop, "nlopt_amd: LD_MMA on the device needs a stopping criterion it can test (ftol, xtol_rel, maxeval or stopval); maxtime alone is not watched inside a search");
-        return NLOPT_INVALID_ARGS;
-    }
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
-    if (obj < 0) { nla_stop_msg(stop, "nlopt_amd: LD_MMA is provided for device objectives (nlopt_amd_objective) only"); return NLOPT_INVALID_ARGS; }
-    if (stop->xtol_abs || stop->x_weights) { nla_stop_msg(stop, "nlopt_amd: LD_MMA on the device does not take xtol_abs / x_weights"); return NLOPT_INVALID_ARGS; }
+    nla_evaluator_resolve(&ev, opt, f, f_data);
     memset(&prm, 0, sizeof prm);
     prm.minf_max = stop->minf_max; prm.ftol_rel = stop->ftol_rel; prm.ftol_abs = stop->ftol_abs; prm.xtol_rel = stop->xtol_rel;
     prm.maxeval = stop->maxeval;
-    if (nla_local_run_batch(1, obj, n, 1, lb, ub, x, 0, &mma, opt->dx, &prm, &res, err, sizeof err)) { nla_stop_msg(stop, "device engine: %s", err); return NLOPT_FAILURE; }
+    if (nla_local_run_batch(1, &ev, n, 1, lb, ub, x, 0, &mma, opt->dx, &prm, &res, stop, nla_exact_mode(opt),
+                            ev.kind == NLA_EVAL_HOST ? stop->nevals_p : NULL, opt, err, sizeof err)) { nla_stop_msg(stop, "device engine: %s", err); return NLOPT_FAILURE; }
     *minf = res.f;
-    *stop->nevals_p += res.nevals;
+    if (ev.kind != NLA_EVAL_HOST) *stop->nevals_p += res.nevals;
     return (nlopt_result) res.ret;
 }

@@ -83,7 +83,31 @@ struct nlopt_opt_s {
     nlopt_amd_stats stats;
     nlopt_amd_progress_fn progress; void *progress_data;
     nlopt_amd_comm *comm;           /* multi-GPU run: borrowed communicator (comm.c), NULL = single process */
+    struct nla_userobj *userobj;    /* user-supplied device objective (userobj.c), shared by copies (reference counted) */
+    int dev_sign;                   /* -1 while a maximisation runs on a device objective without the host flip wrapper */
 };
+
+/* ---- how an objective is evaluated ----------------------------------------------------------------------- */
+enum { NLA_EVAL_DEVICE = 0, NLA_EVAL_HOST = 1, NLA_EVAL_USER = 2 };
+typedef struct nla_userobj nla_userobj;
+typedef struct {
+    int kind, obj;                  /* NLA_EVAL_DEVICE: obj = compiled-in objective id */
+    nlopt_func f; void *f_data;     /* NLA_EVAL_HOST: the caller's callback */
+    nla_userobj *user;              /* NLA_EVAL_USER */
+    double sign;                    /* +1, or -1: minimise -f (device / user objectives under nlopt_set_max_objective) */
+} nla_evaluator;
+void nla_evaluator_resolve(nla_evaluator *ev, nlopt_opt opt, nlopt_func f, void *f_data);
+int nla_exact_mode(nlopt_opt opt);                    /* nlopt_set_param(opt, "amd_exact_dot", 1) */
+
+/* user device objectives (userobj.c) */
+nla_userobj *nla_userobj_retain(nla_userobj *u);
+void nla_userobj_release(nla_userobj *u);
+int nla_userobj_is_adapter(nlopt_func f);
+/* F[c] = sign * f(row c of X), G row c = sign * gradient (G may be NULL), c < count; rows ld apart */
+int nla_userobj_eval_rows(nla_userobj *u, int n, int ld, int64_t count, const double *X, double *F, double *G, double sign, void *stream);
+/* the same for the rows named by list[0..m): entry i >= 0: row i with its gradient; entry -(i+1): row i, value only */
+int nla_userobj_evalgrad_list(nla_userobj *u, int n, int ld, int m, const int32_t *d_list, const double *X, double *F, double *G,
+                              double sign, void *stream);
 
 const char *nla_set_errmsg(nlopt_opt opt, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void nla_unset_errmsg(nlopt_opt opt);
@@ -182,24 +206,26 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
 /* LD_LBFGS (lbfgs_driver.c) */
 int nla_lbfgs_default_mf(int n, int mf, int maxeval);
 typedef struct nla_local_ctx nla_local_ctx;
-nla_local_ctx *nla_local_ctx_create(int obj, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream);
-nla_local_ctx *nla_local_ctx_create_mma(int obj, int n, int cap, const nla_mma_params *alg_params, const double *d_sigma_init,
+nla_local_ctx *nla_local_ctx_create(const nla_evaluator *ev, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream);
+nla_local_ctx *nla_local_ctx_create_mma(const nla_evaluator *ev, int n, int cap, const nla_mma_params *alg_params, const double *d_sigma_init,
                                         const double *d_lb, const double *d_ub, void *stream);
 int nla_local_ctx_alg(const nla_local_ctx *c);
 void nla_local_ctx_destroy(nla_local_ctx *c);
 double *nla_local_ctx_X(nla_local_ctx *c);
 void nla_local_ctx_set_stats(nla_local_ctx *c, nlopt_amd_stats *stats);
-int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res);
-int nla_lbfgs_run_batch(int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
-                        const nla_lbfgs_params *prm, nla_lbfgs_result *res, char *err, size_t errlen);
-int nla_local_run_batch(int alg, int obj, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
+int nla_local_ctx_set_options(nla_local_ctx *c, int exact, const double *xtol_abs, const double *x_weights);
+int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res, const nla_stopping *stop,
+                      int *live_nevals);
+int nla_local_run_batch(int alg, const nla_evaluator *ev, int n, int count, const double *lb, const double *ub, double *h_X, int mf,
                         const nla_mma_params *mma, const double *sigma_init, const nla_lbfgs_params *prm, nla_lbfgs_result *res,
-                        char *err, size_t errlen);
+                        const nla_stopping *stop, int exact, int *live_nevals, nlopt_opt trace_to, char *err, size_t errlen);
+int nla_local_ctx_set_ftrace(nla_local_ctx *c, int64_t cap);
+int nla_local_ctx_read_ftrace(nla_local_ctx *c, int inst, int64_t count, double *h_out);
 /* LD_MMA without nonlinear constraints (mma_driver.c) */
 int nla_mma_read_params(nlopt_opt opt, nla_mma_params *out);     /* optimize.c:798-815; 0 or an nlopt_result < 0 with errmsg set */
 nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
                               double *minf, nla_stopping *stop);
-nlopt_result nla_lbfgs_minimize(int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
+nlopt_result nla_lbfgs_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
                                 nla_stopping *stop, int mf, double tolg);
 
 /* Sobol LDS (sobol.c; src/util/sobolseq.c) */

@@ -57,6 +57,7 @@ int nla_memset(void *dst, int value, size_t bytes, void *st) { (void) st; if (by
 void *nla_stream_create(void) { return emu_alloc(1); }
 void nla_stream_destroy(void *st) { emu_release(st); }
 int nla_stream_sync(void *st) { (void) st; return 0; }
+int nla_stream_query(void *st) { (void) st; return 0; }
 void *nla_event_create(void) { return emu_alloc(1); }
 void nla_event_destroy(void *ev) { emu_release(ev); }
 int nla_event_record(void *ev, void *st) { (void) ev; (void) st; return 0; }
@@ -194,48 +195,148 @@ int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, in
     return 0;
 }
 
-/* ---- local optimisers: the oracle ports stand in for the batched kernels ------------------------------------------------------ */
-typedef struct { int obj; long calls; } emu_obj;
+/* ---- local optimisers: the oracle ports stand in for the batched kernels ------------------------------------------------------
+ * Device objectives: a whole search per call, as the kernels do.  External evaluation (NLA_OBJ_EXTERNAL, include/nlopt_amd.h):
+ * the port runs as a coroutine (ucontext) whose objective yields to the launcher's caller with the point in EX and is resumed by
+ * the next launch with f / gradient in EF / EG — the kernels' protocol, call for call. */
+typedef struct { int obj; long calls; double sign; double *ft; long ftcap; } emu_obj;
 static double emu_objective(unsigned n, const double *x, double *grad, void *p)
 {
     emu_obj *o = (emu_obj *) p;
+    double f;
     ++o->calls;
-    return nla_obj_eval_seq(o->obj, n, x, grad);
+    f = nla_obj_eval_seq(o->obj, n, x, grad);
+    if (o->sign < 0) { f = -f; if (grad) for (unsigned i = 0; i < n; ++i) grad[i] = -grad[i]; }
+    if (o->ft && o->calls <= o->ftcap) o->ft[o->calls - 1] = f;
+    return f;
 }
 size_t nla_lbfgs_work_doubles(int ld, int mf, int count) { (void) ld; (void) mf; (void) count; return 8; }
 size_t nla_lbfgs_hist_doubles(int ld, int mf, int count) { (void) ld; (void) mf; (void) count; return 8; }
 size_t nla_mma_work_doubles(int ld, int count) { (void) ld; (void) count; return 8; }
-static void local_stop(orc_stop *s, int n, double minf_max, double ftol_rel, double ftol_abs, double xtol_rel, int maxeval)
+static void local_stop(orc_stop *s, int n, double minf_max, double ftol_rel, double ftol_abs, double xtol_rel, int maxeval,
+                       const double *xtol_abs, const double *x_weights)
 {
     orc_stop_default(s, (unsigned) n);
     s->minf_max = minf_max; s->ftol_rel = ftol_rel; s->ftol_abs = ftol_abs; s->xtol_rel = xtol_rel; s->maxeval = maxeval; s->nevals = 0;
+    s->xtol_abs = xtol_abs; s->x_weights = x_weights;
 }
+
+#include <ucontext.h>
+#define EMU_CO_STACK (1 << 20)
+typedef struct emu_co {
+    ucontext_t co, caller;
+    char *stack;
+    int alg, n, ld, mf, inst, inner_gradients;
+    const double *lb, *ub, *sigma_init;
+    double *x;
+    double tolg;
+    orc_stop s;
+    orc_mma_params m;
+    nla_lbfgs_result *out;
+    nla_local_ext E;
+    long calls;
+    double *ft; long ftcap;
+} emu_co;
+size_t nla_lbfgs_save_bytes(void) { return sizeof(emu_co *); }
+size_t nla_mma_save_bytes(void) { return sizeof(emu_co *); }
+
+static double emu_co_objective(unsigned n, const double *x, double *grad, void *p)
+{
+    emu_co *c = (emu_co *) p;
+    /* LD_MMA's repeated call with a gradient (mma.c:337-339) is the one that asks for a gradient although inner_gradients = 0 */
+    const int uncounted = c->alg == 1 && !c->inner_gradients && grad && c->calls > 0;
+    memcpy(c->E.EX + (size_t) c->inst * c->ld, x, sizeof(double) * n);
+    c->E.req[c->inst].state = 1;
+    c->E.req[c->inst].want_grad = (grad ? 1 : 0) | (uncounted ? 2 : 0);
+    ++c->calls;
+    swapcontext(&c->co, &c->caller);
+    if (grad) memcpy(grad, c->E.EG + (size_t) c->inst * c->ld, sizeof(double) * n);
+    if (c->ft && c->calls <= c->ftcap) c->ft[c->calls - 1] = c->E.EF[c->inst];
+    return c->E.EF[c->inst];
+}
+static void emu_co_main(unsigned lo, unsigned hi)
+{
+    emu_co *c = (emu_co *) (((uintptr_t) hi << 32) | (uintptr_t) lo);
+    double minf = HUGE_VAL;
+    nla_lbfgs_result *o = c->out + c->inst;
+    if (c->alg == 1) o->ret = orc_mma_minimize(c->n, emu_co_objective, c, c->lb, c->ub, c->x, &minf, &c->s, &c->m);
+    else o->ret = orc_lbfgs_minimize(c->n, emu_co_objective, c, c->lb, c->ub, c->x, &minf, &c->s, c->mf, c->tolg);
+    o->f = minf; o->nevals = (int32_t) c->s.nevals; o->iterm = c->alg == 1 ? (int32_t) c->calls : 0; o->cols = 0;
+    c->E.req[c->inst].state = 2;
+    swapcontext(&c->co, &c->caller);
+}
+/* one launch of an external-evaluation batch: start (resume = 0) or continue (resume = 1) every search that is not finished */
+static int emu_co_launch(int alg, int n, int ld, int mf, int count, const double *lb, const double *ub, const double *sigma_init, double *X,
+                         const nla_lbfgs_params *PL, const nla_mma_params *PM, nla_lbfgs_result *out, const nla_local_ext *ext)
+{
+    emu_co **slot;
+    if (!ext || !ext->req || !ext->EX || !ext->EG || !ext->EF || !ext->save) return EMU_ERR;
+    slot = (emu_co **) ext->save;
+    for (int i = 0; i < count; ++i) {
+        emu_co *c;
+        if (!ext->resume) {
+            c = (emu_co *) calloc(1, sizeof *c);
+            if (!c || !(c->stack = (char *) malloc(EMU_CO_STACK))) { free(c); return EMU_ERR; }
+            slot[i] = c;
+            c->alg = alg; c->n = n; c->ld = ld; c->mf = mf; c->inst = i; c->lb = lb; c->ub = ub; c->sigma_init = sigma_init;
+            c->x = X + (size_t) i * ld; c->out = out; c->E = *ext;
+            if (alg == 1) {
+                local_stop(&c->s, n, PM->minf_max, PM->ftol_rel, PM->ftol_abs, PM->xtol_rel, PM->maxeval, PM->xtol_abs, PM->x_weights);
+                c->m.rho_init = PM->rho_init; c->m.sigma_min = PM->sigma_min; c->m.inner_maxeval = PM->inner_maxeval;
+                c->m.inner_gradients = PM->inner_gradients; c->m.always_improve = PM->always_improve; c->m.sigma_init = sigma_init;
+                c->inner_gradients = PM->inner_gradients;
+                if (PM->ftrace) { c->ft = PM->ftrace + (size_t) i * (size_t) PM->ftrace_cap; c->ftcap = (long) PM->ftrace_cap; }
+            } else {
+                local_stop(&c->s, n, PL->minf_max, PL->ftol_rel, PL->ftol_abs, PL->xtol_rel, PL->maxeval, PL->xtol_abs, PL->x_weights);
+                c->tolg = PL->tolg;
+                if (PL->ftrace) { c->ft = PL->ftrace + (size_t) i * (size_t) PL->ftrace_cap; c->ftcap = (long) PL->ftrace_cap; }
+            }
+            getcontext(&c->co);
+            c->co.uc_stack.ss_sp = c->stack; c->co.uc_stack.ss_size = EMU_CO_STACK; c->co.uc_link = NULL;
+            makecontext(&c->co, (void (*)(void)) emu_co_main, 2, (unsigned) ((uintptr_t) c & 0xffffffffu), (unsigned) ((uintptr_t) c >> 32));
+        } else {
+            c = slot[i];
+            if (!c || ext->req[i].state != 1) continue;
+            ext->req[i].state = 0;
+        }
+        c->s.force_stop = ext->forced;
+        if (ext->timeout) { c->s.maxtime = 1e-300; c->s.start = -1e300; }
+        swapcontext(&c->caller, &c->co);
+        if (ext->req[i].state == 2) { free(c->stack); free(c); slot[i] = NULL; }
+    }
+    return 0;
+}
+
 int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X, double *work, int *iwork,
-                      double *hist, const nla_lbfgs_params *P, nla_lbfgs_result *out, void *st)
+                      double *hist, const nla_lbfgs_params *P, nla_lbfgs_result *out, const nla_local_ext *ext, void *st)
 {
     EMU_LAUNCH();
     (void) work; (void) iwork; (void) hist; (void) st;
+    if (obj == NLA_OBJ_EXTERNAL) return emu_co_launch(0, n, ld, mf, count, lb, ub, NULL, X, P, NULL, out, ext);
     for (int i = 0; i < count; ++i) {
-        emu_obj o = { obj, 0 };
+        emu_obj o = { obj, 0, P->sign, P->ftrace ? P->ftrace + (size_t) i * (size_t) P->ftrace_cap : NULL, (long) P->ftrace_cap };
         orc_stop s;
         double minf = HUGE_VAL;
-        local_stop(&s, n, P->minf_max, P->ftol_rel, P->ftol_abs, P->xtol_rel, P->maxeval);
+        local_stop(&s, n, P->minf_max, P->ftol_rel, P->ftol_abs, P->xtol_rel, P->maxeval, P->xtol_abs, P->x_weights);
+        if (P->abort && *P->abort == -999) s.force_stop = 1;
         out[i].ret = orc_lbfgs_minimize(n, emu_objective, &o, lb, ub, X + (size_t) i * ld, &minf, &s, mf, P->tolg);
         out[i].f = minf; out[i].nevals = (int32_t) s.nevals; out[i].iterm = 0; out[i].cols = 0;
     }
     return 0;
 }
 int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const double *ub, const double *sigma_init, double *X, double *work,
-                    const nla_mma_params *P, nla_lbfgs_result *out, void *st)
+                    const nla_mma_params *P, nla_lbfgs_result *out, const nla_local_ext *ext, void *st)
 {
     EMU_LAUNCH();
     (void) work; (void) st;
+    if (obj == NLA_OBJ_EXTERNAL) return emu_co_launch(1, n, ld, 0, count, lb, ub, sigma_init, X, NULL, P, out, ext);
     for (int i = 0; i < count; ++i) {
-        emu_obj o = { obj, 0 };
+        emu_obj o = { obj, 0, P->sign, P->ftrace ? P->ftrace + (size_t) i * (size_t) P->ftrace_cap : NULL, (long) P->ftrace_cap };
         orc_stop s;
         orc_mma_params m;
         double minf = HUGE_VAL;
-        local_stop(&s, n, P->minf_max, P->ftol_rel, P->ftol_abs, P->xtol_rel, P->maxeval);
+        local_stop(&s, n, P->minf_max, P->ftol_rel, P->ftol_abs, P->xtol_rel, P->maxeval, P->xtol_abs, P->x_weights);
+        if (P->abort && *P->abort == -999) s.force_stop = 1;
         memset(&m, 0, sizeof m);
         m.rho_init = P->rho_init; m.sigma_min = P->sigma_min; m.inner_maxeval = P->inner_maxeval; m.inner_gradients = P->inner_gradients;
         m.always_improve = P->always_improve; m.sigma_init = sigma_init;
@@ -244,6 +345,14 @@ int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const d
     }
     return 0;
 }
+
+/* ---- code objects (hip/devrt.hip): none on the emulated device ------------------------------------------------------------- */
+void *nla_module_load_file(const char *path) { (void) path; return NULL; }
+void *nla_module_load_data(const void *image) { (void) image; return NULL; }
+void nla_module_unload(void *module) { (void) module; }
+void *nla_module_function(void *module, const char *name) { (void) module; (void) name; return NULL; }
+int nla_module_launch(void *function, unsigned gx, unsigned bx, void *args, size_t bytes, void *st)
+{ (void) function; (void) gx; (void) bx; (void) args; (void) bytes; (void) st; return EMU_ERR; }
 
 /* ---- ISRES (hip/isres_kernels.hip) ---------------------------------------------------------------------------------------------- */
 int nla_k_isres_init(int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t k_first, int64_t count,
