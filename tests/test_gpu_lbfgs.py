@@ -78,10 +78,20 @@ def test_lbfgs_active_bounds():
         assert np.array_equal(a["x"][::3], p["x"][::3])          # coordinates on their bounds: exactly the bound
 
 
-def test_lbfgs_host_callback_is_refused_loudly():
+def test_lbfgs_host_callback_is_served():
+    """an ordinary nlopt_func (here a Python callback) is served: the search runs on the device as a coroutine, f and the
+    gradient are computed on the caller's thread (tests/test_gpu_host_callbacks.py compares with the reference call by call)"""
+    calls = []
+
+    def f(x, g):
+        calls.append(x.copy())
+        if g.size:
+            g[:] = 2 * (x - 0.25)
+        return float(np.sum((x - 0.25) ** 2))
     o = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, 3)
     o.set_lower_bounds(-1.0)
     o.set_upper_bounds(1.0)
-    o.set_min_objective(lambda x, g: float(np.sum(x * x)))
+    o.set_min_objective(f)
+    o.set_ftol_rel(1e-12)
     x, minf, ret = o.optimize_raw(np.full(3, 0.5))
-    assert ret == nlopt_amd.INVALID_ARGS and "device objectives" in o.get_errmsg()
+    assert ret > 0 and minf < 1e-20 and np.allclose(x, 0.25) and o.get_numevals() == len(calls) >= 2

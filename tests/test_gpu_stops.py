@@ -82,3 +82,44 @@ def test_maxtime_stops_the_run(alg):
     nlopt_amd.srand(1)
     x, minf, ret = o.optimize_raw(xs)
     assert ret == nlopt_amd.MAXTIME_REACHED and o.get_numevals() > 2000 and np.isfinite(minf)
+
+
+@pytest.mark.parametrize("alg", [nlopt_amd.LD_MMA, nlopt_amd.LD_LBFGS])
+def test_maxtime_is_observed_inside_a_device_resident_local_search(alg):
+    """a local search with a device objective is ONE kernel launch; the kernel polls an abort flag the waiting host raises when
+    the clock runs out (plis.c:263,273,371; mma.c:258-260,394-396).  Rosenbrock n = 4096 with tolerances that cannot be met:
+    without the flag LD_MMA would run for minutes (round 1 refused a maxtime-only LD_MMA run for that reason)."""
+    import time
+    n = 4096
+    o = nlopt_amd.Opt(alg, n)
+    o.set_lower_bounds(-30.0)
+    o.set_upper_bounds(30.0)
+    o.set_min_objective(nlopt_amd.objective("rosenbrock"))
+    o.set_maxtime(0.4)
+    if alg == nlopt_amd.LD_LBFGS:
+        o.set_ftol_abs(1e-300)
+        o.set_param("tolg", 1e-300)
+    t0 = time.time()
+    x, minf, ret = o.optimize_raw(np.full(n, -1.2))
+    dt = time.time() - t0
+    assert ret in (nlopt_amd.MAXTIME_REACHED, nlopt_amd.SUCCESS, nlopt_amd.FTOL_REACHED, nlopt_amd.XTOL_REACHED), (ret, o.get_errmsg())
+    assert dt < 5.0, dt
+    if alg == nlopt_amd.LD_MMA:
+        assert ret == nlopt_amd.MAXTIME_REACHED and 0.35 <= dt
+
+
+def test_force_stop_from_another_thread_ends_a_device_resident_search():
+    import threading
+    import time
+    n = 4096
+    o = nlopt_amd.Opt(nlopt_amd.LD_MMA, n)
+    o.set_lower_bounds(-30.0)
+    o.set_upper_bounds(30.0)
+    o.set_min_objective(nlopt_amd.objective("rosenbrock"))
+    o.set_maxeval(2000000000)
+    th = threading.Timer(0.3, o.force_stop)
+    th.start()
+    t0 = time.time()
+    x, minf, ret = o.optimize_raw(np.full(n, -1.2))
+    th.join()
+    assert ret == nlopt_amd.FORCED_STOP and time.time() - t0 < 5.0
