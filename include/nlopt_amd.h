@@ -186,6 +186,27 @@ int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t 
                       const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
                       double *TX, int variant, void *stream);
 
+/* nla_k_crs_advance with VALUE FORWARDING (K <= 256): a slot does not stop at a pick of row W[k], k < a; it reads that row's
+ * new content — under the speculation that window block k is accepted and overwrites W[k], which the caller verifies later —
+ * from TX of window slot k as soon as that slot's coordinate chunk is final.  Every slot with t_in == 0 finishes (t_out = n);
+ * slots with t_in == n are left alone.  flags: KCAP x nla_crs_advance_chunks(n, ld, variant) u32, zero before first use;
+ * gen[a] = the tag slot a's flags carry when final (a fresh tag for slots computed now, the old one for finished slots);
+ * fwmask[8a .. 8a+8): bit k set = slot a took row W[k] from slot k (written for computed slots; may be pinned host memory);
+ * ticket: one u32 counter, zero before first use, ticket_base = workgroups launched by all earlier calls (mod 2^32). */
+int nla_crs_advance_chunks(int n, int ld, int variant);
+int nla_k_crs_advance_fwd(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                          const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                          uint64_t first_block, int K, const int64_t *W, int nW,
+                          const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                          double *TX, int variant, uint32_t *flags, const uint32_t *gen, uint32_t *fwmask,
+                          uint32_t *ticket, uint32_t ticket_base, void *stream);
+int nla_k_crs_advance_fwd_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                               uint64_t first_block, int K, const int64_t *h_W, int nW,
+                               const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                               double *TX, int variant, uint32_t *flags, const uint32_t *h_gen, uint32_t *fwmask,
+                               uint32_t *ticket, uint32_t ticket_base, void *stream);
+
 /* replaces: the evaluation of the trial (crs.c:133) and the local mutation + its evaluation
  * (crs.c:139-146, K5) for the slots completed by the preceding nla_k_crs_advance (same window):
  * fT_ring[q] = f(TX[q]); TM[q] = clamp(best*(1+w) - w*TX[q]), w from the words of block b+1

@@ -29,8 +29,9 @@ typedef struct {
     int waited;                    /* main stream already ordered after ev_ready */
 } crs_batch;
 
-/* one H2D per pass, packed: [W: nW i64][crow: nc i64][t_in: K i32][cslot: nc i32][ckind: nc i32] */
-#define UPLOAD_BYTES (KCAP * (8 + 8 + 4 + 4 + 4))
+/* one H2D per pass, packed: [W: nW i64][crow: nc i64][t_in: K i32][cslot: nc i32][ckind: nc i32][gen: K u32] */
+#define UPLOAD_BYTES (KCAP * (8 + 8 + 4 + 4 + 4 + 4))
+#define FWD_KMAX 256                       /* window slots a forwarding mask can name (NLA_FWD_WORDS x 32) */
 
 struct nla_crs_hip_engine {
     int n, ld, obj;
@@ -54,6 +55,10 @@ struct nla_crs_hip_engine {
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
+    /* value forwarding (crs_kernels.hip): per-(slot, chunk) completion flags, their generation tags, the ticket counter */
+    int chunks;
+    uint32_t *d_flags, *d_ticket, *h_fwmask;
+    uint32_t h_gen[KCAP], pass_id, ticket_base;
     int force_upload;              /* NLA_CRS_UPLOAD: the pass's lists through the H2D copy even when they fit the kernel arguments (A/B switch) */
     FILE *pass_log;                /* NLA_CRS_PASS_LOG=<file>: one line per pass (development aid, see tools/pass_log_summary.py) */
     nlopt_amd_stats *stats;
@@ -108,6 +113,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_initwords);
     nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
     nla_dev_free(e->d_up); nla_dev_free(e->d_tout); nla_dev_free(e->d_status);
+    nla_dev_free(e->d_flags); nla_dev_free(e->d_ticket); nla_host_free(e->h_fwmask);
     nla_host_free(e->h_up); nla_host_free(e->h_status);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
     nla_stream_destroy(e->main); nla_stream_destroy(e->rng);
@@ -163,11 +169,18 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * KCAP);
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
+    e->chunks = n / 64 + 2;                  /* upper bound over the kernel's tilings (nla_crs_advance_chunks) */
+    e->d_flags = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * (size_t) KCAP * (size_t) e->chunks);
+    e->d_ticket = (uint32_t *) nla_dev_malloc(sizeof(uint32_t));
+    e->h_fwmask = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * 8 * FWD_KMAX);
     e->direct_status = !getenv("NLA_CRS_COPY_STATUS");
     e->force_upload = getenv("NLA_CRS_UPLOAD") != NULL;
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
-        !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1) goto fail;
-    if (nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
+        !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1 ||
+        !e->d_flags || !e->d_ticket || !e->h_fwmask) goto fail;
+    if (nla_memset(e->d_flags, 0, sizeof(uint32_t) * (size_t) KCAP * (size_t) e->chunks, e->main) ||
+        nla_memset(e->d_ticket, 0, sizeof(uint32_t), e->main) ||
+        nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
         nla_memcpy_h2d(e->d_ub, ub, sizeof(double) * (size_t) n, e->main) || nla_stream_sync(e->main)) goto fail;
     return e;
 fail:
@@ -255,11 +268,12 @@ static int op_max_slots(void *ve, uint64_t first_block)
 /* upload W / t_in of the coming pass (K may be 0: commits only) together with the staged commits
  * in ONE copy, and write the commits to X before anything else runs on the main stream */
 static int upload_and_commit(nla_crs_hip_engine *e, const int64_t *W, int nW, const int32_t *t_in, int K,
-                             const int64_t **d_W, const int32_t **d_tin)
+                             const int64_t **d_W, const int32_t **d_tin, const uint32_t *gen, const uint32_t **d_gen)
 {
     const int nc = e->npending;
     size_t oW = 0, oR = oW + 8 * (size_t) nW, oT = oR + 8 * (size_t) nc, oS = oT + 4 * (size_t) K, oK = oS + 4 * (size_t) nc;
-    const size_t total = oK + 4 * (size_t) nc;
+    const size_t oG = oK + 4 * (size_t) nc;
+    const size_t total = oG + (gen ? 4 * (size_t) K : 0);
     if (total == 0) return 0;
     if (nW) memcpy(e->h_up + oW, W, 8 * (size_t) nW);
     if (nc) {
@@ -268,6 +282,7 @@ static int upload_and_commit(nla_crs_hip_engine *e, const int64_t *W, int nW, co
         memcpy(e->h_up + oK, e->pend_kind, 4 * (size_t) nc);
     }
     if (K) memcpy(e->h_up + oT, t_in, 4 * (size_t) K);
+    if (gen && K) memcpy(e->h_up + oG, gen, 4 * (size_t) K);
     CK(e, nla_memcpy_h2d(e->d_up, e->h_up, total, e->main));
     if (nc) {
         CK(e, nla_k_crs_commit(e->n, e->ld, e->d_X, e->d_TX, e->d_TM, nc, (const int32_t *) (e->d_up + oS),
@@ -276,6 +291,7 @@ static int upload_and_commit(nla_crs_hip_engine *e, const int64_t *W, int nW, co
     }
     if (d_W) *d_W = (const int64_t *) (e->d_up + oW);
     if (d_tin) *d_tin = (const int32_t *) (e->d_up + oT);
+    if (d_gen) *d_gen = (const uint32_t *) (e->d_up + oG);
     return 0;
 }
 
@@ -284,27 +300,37 @@ static int upload_and_commit(nla_crs_hip_engine *e, const int64_t *W, int nW, co
 static int flush_commits(nla_crs_hip_engine *e)
 {
     if (!e->npending) return 0;
-    if (upload_and_commit(e, NULL, 0, NULL, 0, NULL, NULL)) return -1;
+    if (upload_and_commit(e, NULL, 0, NULL, 0, NULL, NULL, NULL, NULL)) return -1;
     CK(e, nla_stream_sync(e->main));
     return 0;
 }
 
 static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
-                      nla_crs_slot_status *status)
+                      nla_crs_slot_status *status, uint32_t *fwd)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const int n = e->n;
     const uint32_t ring = 2u * (uint32_t) e->B;
     int32_t t_in[KCAP];
+    uint32_t gen[KCAP];
     const int64_t *d_W = NULL;
     const int32_t *d_tin = NULL;
+    const uint32_t *d_gen = NULL;
+    const int chunks = nla_crs_advance_chunks(n, e->ld, e->variant);
+    if (fwd && (K > FWD_KMAX || chunks > e->chunks)) FAIL(e, "forwarding window too wide (K=%d)", K);
     if (K < 1 || K > KCAP || nW > KCAP || nW < 0) FAIL(e, "bad window K=%d nW=%d", K, nW);
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
     if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
     for (int a = 0; a < K; ++a) {
         const uint64_t b = first_block + (uint64_t) a;
         t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
+        if (fwd) {
+            /* a slot that is not finished is computed from scratch by a forwarding pass; its flags get this pass's tag */
+            if (t_in[a] != n) { t_in[a] = 0; e->h_gen[b & (KCAP - 1)] = e->pass_id + 1; }
+            gen[a] = e->h_gen[b & (KCAP - 1)];
+        }
     }
+    if (fwd) ++e->pass_id;
     if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload) {
         /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
          * front of the pass */
@@ -313,6 +339,12 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
             e->npending = 0;
         }
         CK(e, nla_event_record(e->ev0, e->main));
+        if (fwd) {
+            CK(e, nla_k_crs_advance_fwd_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
+                                             t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->d_flags, gen,
+                                             e->h_fwmask, e->d_ticket, e->ticket_base, e->main));
+            e->ticket_base += (uint32_t) chunks * (uint32_t) K;
+        } else
         CK(e, nla_k_crs_advance_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
                                      t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         CK(e, nla_event_record(e->ev1, e->main));
@@ -327,8 +359,14 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         }
         goto launched;
     }
-    if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin)) return -1;
+    if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, fwd ? gen : NULL, &d_gen)) return -1;
     CK(e, nla_event_record(e->ev0, e->main));
+    if (fwd) {
+        CK(e, nla_k_crs_advance_fwd(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
+                                    d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->d_flags, d_gen,
+                                    e->h_fwmask, e->d_ticket, e->ticket_base, e->main));
+        e->ticket_base += (uint32_t) chunks * (uint32_t) K;
+    } else
     CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
                             d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
     CK(e, nla_event_record(e->ev1, e->main));
@@ -339,6 +377,11 @@ launched:
     CK(e, nla_stream_sync(e->main));
 have_status:
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
+    if (fwd)                       /* the masks of the slots computed in this pass (the kernel wrote them into pinned memory) */
+        for (int a = 0; a < K; ++a) {
+            if (t_in[a] == 0) memcpy(fwd + 8 * (size_t) a, e->h_fwmask + 8 * (size_t) a, 8 * sizeof(uint32_t));
+            else memset(fwd + 8 * (size_t) a, 0, 8 * sizeof(uint32_t));
+        }
     for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = status[a].t;
     if (e->stats) {
         float ms = nla_event_elapsed_ms(e->ev0, e->ev1);
@@ -406,8 +449,14 @@ static int op_mutate_slot(void *ve, uint64_t block, int64_t i0)
 
 static const char *op_last_error(void *ve) { return ((nla_crs_hip_engine *) ve)->err; }
 
+static int op_reset_slot(void *ve, uint64_t block)
+{
+    ((nla_crs_hip_engine *) ve)->h_t[block & (KCAP - 1)] = 0;
+    return 0;
+}
+
 const nla_crs_engine_ops nla_crs_hip_ops = {
-    op_init_population, op_max_slots, op_advance, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
+    op_init_population, op_max_slots, op_advance, op_reset_slot, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
 };
 
 static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,
@@ -420,6 +469,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         return NLOPT_INVALID_ARGS;
     }
     memset(pb, 0, sizeof *pb);
+    pb->forward = 1;
     pb->n = n; pb->N = N; pb->lb = lb; pb->ub = ub; pb->f = f; pb->f_data = f_data; pb->stop = stop;
     pb->obj = nlopt_amd_objective_id(f);
     if (opt) {
@@ -427,6 +477,8 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         pb->stats = &opt->stats;
         pb->max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
         pb->window_factor = nlopt_get_param(opt, "amd_window_factor", 0);
+        pb->forward = nlopt_get_param(opt, "amd_forward", 1) != 0;
+        if (getenv("NLA_CRS_NO_FORWARD")) pb->forward = 0;                 /* A/B switch for the bench */
         if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
     }
     if (nla_dev_count() <= 0) {

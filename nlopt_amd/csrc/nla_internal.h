@@ -167,7 +167,13 @@ typedef struct {
      * that may be overwritten next, worst first.  status[a] = (f of the finished trial, f of the
      * mutation that would follow its rejection (w from block+1), picks summed so far). */
     int (*advance)(void *e, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
-                   nla_crs_slot_status *status);
+                   nla_crs_slot_status *status, uint32_t *fwd);
+    /* fwd != NULL (K <= 256): VALUE FORWARDING — instead of stopping at a pick of row W[k], k < a, slot a takes that row's
+     * content from the finished trial point of window slot k (speculating that block first_block+k is accepted and
+     * overwrites W[k], the common case) and finishes in the same pass; fwd[8a .. 8a+8) = bit mask of the k it used, written
+     * for the slots computed in this pass.  The driver verifies every use at the slot's turn. */
+    /* forget the state of one in-flight block: it is recomputed from pick 0 by the next pass that holds it */
+    int (*reset_slot)(void *e, uint64_t block);
     /* X[row[c]] := point of slot block[c] (kind[c]: 1 trial, 2 its mutation); rows distinct */
     int (*commit)(void *e, int ncommit, const uint64_t *block, const int32_t *kind, const int64_t *row);
     int (*read_slot)(void *e, uint64_t block, int kind, double *x);
@@ -186,6 +192,7 @@ typedef struct {
     nlopt_amd_trace_rec *trace; size_t trace_cap, *trace_len;
     nlopt_amd_stats *stats;
     int max_spec;                   /* cap on slots per round (0 = default) */
+    int forward;                    /* value forwarding between the slots of a pass: 1 on (default where the engine offers it), 0 off */
     double window_factor;           /* window = factor x (blocks consumed per pass, smoothed) + 4 (0 = default 1.5) */
 } nla_crs_problem;
 

@@ -20,6 +20,10 @@ void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *wo
 int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
                        const int64_t *W, int nun, int t0, const double *lb, const double *ub, double *acc);
 
+void orc_k_advance_slot_fwd(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
+                            const int64_t *W, int nun, const double *TXring, uint64_t first_block, int ecap,
+                            const double *lb, const double *ub, double *acc, uint32_t *mask);
+
 #define ECAP 1024                           /* slot ring, block b at slot b % ECAP */
 
 typedef struct {
@@ -43,6 +47,8 @@ static void need_blocks(emu *e, uint64_t upto)     /* the oracle generator is se
  * produced in rank blocks and all-gathered over the communicator's host transport, the way
  * crs_engine.c's op_init_population does it on the device. */
 static nlopt_amd_comm *emu_comm = NULL;
+static int emu_forward = 1;                 /* value forwarding in the driver under test (orc_emu_set_forward) */
+void orc_emu_set_forward(int on) { emu_forward = on; }
 void orc_emu_set_comm(void *comm) { emu_comm = (nlopt_amd_comm *) comm; }
 
 static int emu_init(void *ve, const double *x0, double *F)
@@ -77,7 +83,7 @@ static int emu_init(void *ve, const double *x0, double *F)
 }
 static int emu_max_slots(void *ve, uint64_t first_block) { (void) first_block; return ((emu *) ve)->max_slots; }
 static int emu_advance(void *ve, uint64_t first, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
-                       nla_crs_slot_status *status)
+                       nla_crs_slot_status *status, uint32_t *fwd)
 {
     emu *e = (emu *) ve;
     const int n = e->n;
@@ -93,6 +99,15 @@ static int emu_advance(void *ve, uint64_t first, int K, uint64_t fresh_from, int
             e->t[q] = 0;
         }
         t0 = e->t[q];
+        if (fwd) {                      /* value forwarding: an unfinished slot is computed from pick 0 and always completes */
+            memset(fwd + 8 * (size_t) a, 0, 8 * sizeof(uint32_t));
+            if (t0 != n) {
+                t0 = 0;
+                orc_k_advance_slot_fwd(n, e->ld, e->X, i0, e->jn[q], e->pos + (size_t) q * n, e->last[q], W, a < nW ? a : nW, e->TX,
+                                       first, ECAP, e->lb, e->ub, acc, fwd + 8 * (size_t) a);
+            }
+            t1 = n;
+        } else
         t1 = orc_k_advance_slot(n, e->ld, e->X, i0, e->jn[q], e->pos + (size_t) q * n, e->last[q], W, a < nW ? a : nW, t0,
                                 e->lb, e->ub, acc);
         e->t[q] = t1;
@@ -137,8 +152,9 @@ static int emu_mutate_slot(void *ve, uint64_t block, int64_t i0)
     return 0;
 }
 static const char *emu_err(void *ve) { (void) ve; return "emu"; }
+static int emu_reset_slot(void *ve, uint64_t block) { ((emu *) ve)->t[block % ECAP] = 0; return 0; }
 
-static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_advance, emu_commit, emu_read_slot,
+static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_advance, emu_reset_slot, emu_commit, emu_read_slot,
                                             emu_read_row, emu_mutate_slot, emu_err };
 
 /* Run the PRODUCT's CRS driver over the emulated engine.  RNG = the oracle generator (orc_srand
@@ -176,7 +192,7 @@ int orc_emu_crs(int obj, int n, long N, const double *lb, const double *ub, doub
     memset(&pb, 0, sizeof pb);
     pb.n = n; pb.N = N; pb.lb = lb; pb.ub = ub; pb.obj = e.obj;
     pb.f = (nlopt_func) orc_objective(obj); pb.f_data = NULL; pb.stop = &stop;
-    pb.trace = trace; pb.trace_cap = trace_cap; pb.trace_len = trace_len; pb.stats = stats; pb.max_spec = max_spec; pb.window_factor = window_factor;
+    pb.trace = trace; pb.trace_cap = trace_cap; pb.trace_len = trace_len; pb.stats = stats; pb.max_spec = max_spec; pb.window_factor = window_factor; pb.forward = emu_forward;
     if (trace_len) *trace_len = 0;
     ret = (int) nla_crs_run(&emu_ops, &e, &pb, x, minf, &words);
     *nevals_out = nevals; *words_out = words;

@@ -127,3 +127,32 @@ int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, c
         }
     return e;
 }
+
+
+/* nla_k_crs_advance_fwd (value forwarding), one slot computed from pick 0: a pick of row W[j], j < nun, is read from the finished
+ * trial point of window slot j (TXring + ((first_block + j) % ecap) * ld) instead of from X, and bit j of mask[8] is set.  The
+ * sum always completes: acc becomes the trial point (scaled, clamped).  Slots must be processed front to back. */
+void orc_k_advance_slot_fwd(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
+                            const int64_t *W, int nun, const double *TXring, uint64_t first_block, int ecap,
+                            const double *lb, const double *ub, double *acc, uint32_t *mask)
+{
+    memset(mask, 0, 8 * sizeof(uint32_t));
+    memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) n);
+    for (int t = 0; t < n; ++t) {
+        const int64_t r = pick_row(n, pos, last, i0, t);
+        const double *xi = X + (size_t) r * (size_t) ld;
+        for (int j = 0; j < nun; ++j)
+            if (W[j] == r && r != i0) {
+                xi = TXring + (size_t) ((first_block + (uint64_t) j) % (uint64_t) ecap) * (size_t) ld;
+                mask[j >> 5] |= 1u << (j & 31);
+                break;
+            }
+        if (t == jn) for (int k = 0; k < n; ++k) acc[k] -= xi[k] * (0.5 * n);
+        else         for (int k = 0; k < n; ++k) acc[k] += xi[k];
+    }
+    for (int k = 0; k < n; ++k) {
+        acc[k] *= 2.0 / n;
+        if (acc[k] > ub[k]) acc[k] = ub[k];
+        else if (acc[k] < lb[k]) acc[k] = lb[k];
+    }
+}

@@ -135,6 +135,75 @@ class SlotStatus(C.Structure):
     _fields_ = [("fT", C.c_double), ("fM", C.c_double), ("t", C.c_int32), ("pad", C.c_int32)]
 
 
+@pytest.mark.parametrize("obj,n,N,K,i0,variant", [("rastrigin", 10, 100, 7, 0, 0), ("rastrigin", 10, 11, 9, 10, 0),
+                                                  ("griewank", 64, 70, 60, 33, 0), ("ackley", 257, 600, 40, 599, 0),
+                                                  ("levy", 128, 140, 130, 17, 0), ("rosenbrock", 512, 700, 256, 3, 0),
+                                                  ("griewank", 4096, 4200, 24, 4199, 0), ("sphere", 1, 9, 8, 4, 0),
+                                                  ("griewank", 2048, 2100, 20, 77, 832), ("ackley", 300, 320, 30, 5, 132),
+                                                  ("ackley", 9000, 9100, 6, 5, 416), ("griewank", 2048, 2100, 12, 77, 10816)])
+def test_advance_with_value_forwarding(L, obj, n, N, K, i0, variant):
+    """nla_k_crs_advance_fwd: every slot finishes in ONE launch; a pick of hazard row W[k], k < a, is read from the finished
+    trial point of window slot k (chunk-wise, through the completion flags) — bit-exact trial points and the exact masks of
+    what was forwarded, against the sequential statement orc_k_advance_slot_fwd.  Small populations (N barely above n) make
+    every slot depend on MANY earlier slots of the same launch: the in-kernel waiting is what is tested.  A second launch
+    with some slots marked finished must leave those alone and recompute the others from the same inputs."""
+    P = O.port()
+    ring = K + 1
+    first = 3 * ring + 2
+    mask = 255
+    ld, lb, ub, X, w0, jn0, pos0, last0 = _spec_inputs(n, N, ring, 77 + n, obj)
+    ent = [(first + a) % ring for a in range(ring)]
+    jn, pos, last = np.zeros(ring, np.int32), np.zeros(ring * n, np.int32), np.zeros(ring, np.int32)
+    for a in range(ring):
+        jn[ent[a]], last[ent[a]] = jn0[a], last0[a]
+        pos[ent[a] * n:(ent[a] + 1) * n] = pos0[a * n:(a + 1) * n]
+    rng = np.random.default_rng(11 + n)
+    # hazard list: K distinct rows, many of them sampled by later slots (N close to n: almost every row is sampled)
+    W = rng.permutation(N)[:K].astype(np.int64)
+    nW = K
+    P.orc_k_advance_slot_fwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    P.orc_k_advance_slot_fwd.restype = None
+    nslot = mask + 1
+    TXr = np.zeros((nslot, ld))
+    maskr = np.zeros((K, 8), np.uint32)
+    q = [(first + a) & mask for a in range(K)]
+    for a in range(K):
+        P.orc_k_advance_slot_fwd(n, ld, X.ctypes.data, i0, int(jn0[a]), pos0[a * n:].ctypes.data, int(last0[a]), W.ctypes.data,
+                                 min(a, nW), TXr.ctypes.data, first, nslot, lb.ctypes.data, ub.ctypes.data, TXr[q[a]].ctypes.data,
+                                 maskr[a].ctypes.data)
+    dX, dlb, dub = DevBuf.from_array(X), DevBuf.from_array(lb), DevBuf.from_array(ub)
+    dj, dp, dl, dW = DevBuf.from_array(jn), DevBuf.from_array(pos), DevBuf.from_array(last), DevBuf.from_array(W)
+    chunks = L.nla_crs_advance_chunks(n, ld, variant)
+    dTX = DevBuf.from_array(np.zeros(nslot * ld))
+    dflags = DevBuf.from_array(np.zeros(nslot * chunks, np.uint32))
+    dticket = DevBuf.from_array(np.zeros(1, np.uint32))
+    dmask = DevBuf.from_array(np.full(K * 8, 0xFFFFFFFF, np.uint32))
+    dt0, dt1 = DevBuf.from_array(np.zeros(K, np.int32)), DevBuf(4 * K)
+    dgen = DevBuf.from_array(np.full(K, 1, np.uint32))
+    assert L.nla_k_crs_advance_fwd(n, ld, dX.ptr, i0, dj.ptr, dp.ptr, dl.ptr, ring, first, K, dW.ptr, nW, dt0.ptr, dt1.ptr, mask,
+                                   dlb.ptr, dub.ptr, dTX.ptr, variant, dflags.ptr, dgen.ptr, dmask.ptr, dticket.ptr, 0, None) == 0
+    assert L.nla_stream_sync(None) == 0
+    assert np.all(dt1.to_array(np.int32, K) == n)
+    TX = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)
+    m = dmask.to_array(np.uint32, K * 8).reshape(K, 8)
+    assert np.array_equal(m, maskr)
+    for a in range(K):
+        assert np.array_equal(TX[q[a], :n], TXr[q[a], :n]), a
+    assert K < 3 or maskr.any()                   # the case does exercise forwarding
+    # second launch: the even slots count as finished (tag 1 stays), the odd ones are recomputed under tag 2
+    t_in2 = np.where(np.arange(K) % 2 == 0, n, 0).astype(np.int32)
+    gen2 = np.where(np.arange(K) % 2 == 0, 1, 2).astype(np.uint32)
+    dt2, dgen2 = DevBuf.from_array(t_in2), DevBuf.from_array(gen2)
+    assert L.nla_k_crs_advance_fwd(n, ld, dX.ptr, i0, dj.ptr, dp.ptr, dl.ptr, ring, first, K, dW.ptr, nW, dt2.ptr, dt1.ptr, mask,
+                                   dlb.ptr, dub.ptr, dTX.ptr, variant, dflags.ptr, dgen2.ptr, dmask.ptr, dticket.ptr, chunks * K, None) == 0
+    assert L.nla_stream_sync(None) == 0
+    TX2 = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)
+    assert np.array_equal(TX2, TX)
+    m2 = dmask.to_array(np.uint32, K * 8).reshape(K, 8)
+    assert np.array_equal(m2[1::2], maskr[1::2])
+
+
 @pytest.mark.parametrize("obj,n,N,K,i0,variant", [("rastrigin", 10, 100, 7, 0, 0), ("rastrigin", 10, 11, 5, 10, 0),
                                                   ("griewank", 64, 500, 33, 250, 0), ("ackley", 257, 600, 9, 599, 0),
                                                   ("levy", 128, 300, 4, 17, 0), ("rosenbrock", 512, 2000, 6, 3, 0),
