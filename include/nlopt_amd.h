@@ -70,7 +70,7 @@ typedef struct {
     uint64_t rounds;            /* advance/commit passes */
     uint64_t slots_launched;    /* stream blocks started on the device as reflection trials */
     uint64_t slots_used;        /* ... consumed by the in-order commit walk */
-    uint64_t slots_invalid;     /* always 0: a slot never reads a row that can still change (kept for layout) */
+    uint64_t slots_invalid;     /* value forwarding: slots recomputed because a row taken from a producer slot was not what the chain wrote */
     uint64_t slots_newbest;     /* ... discarded in flight: the best point changed */
     uint64_t slots_role;        /* ... discarded in flight: their block was consumed as a mutation block */
     uint64_t evals_init, evals_trial, evals_mutation;
@@ -87,6 +87,12 @@ typedef struct {
      * bytes they streamed: 32 n per history column used (two matrices, a dot and an axpy pass each) + 16 n per f/grad evaluation */
     uint64_t lbfgs_launches, lbfgs_bytes;
     double t_lbfgs_ms;
+    /* ISRES stochastic ranking (isres_stochrank_kernel): device time (HIP events), launches, and the serial ticks of the
+     * systolic pipeline those launches had to make: pop + 2 sweeps + 63 ceil(sweeps / 64) each */
+    double t_stochrank_ms;
+    uint64_t stochrank_launches, stochrank_ticks;
+    /* slots_invalid (above) is live again with value forwarding: slots recomputed because a forwarded row turned out not to be
+     * what the chain wrote */
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 

