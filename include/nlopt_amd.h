@@ -192,26 +192,25 @@ int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t 
                       const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
                       double *TX, int variant, void *stream);
 
-/* nla_k_crs_advance with VALUE FORWARDING (K <= 256): a slot does not stop at a pick of row W[k], k < a; it reads that row's
- * new content — under the speculation that window block k is accepted and overwrites W[k], which the caller verifies later —
- * from TX of window slot k as soon as that slot's coordinate chunk is final.  Every slot with t_in == 0 finishes (t_out = n);
- * slots with t_in == n are left alone.  flags: KCAP x nla_crs_advance_chunks(n, ld, variant) u32, zero before first use;
- * gen[a] = the tag slot a's flags carry when final (a fresh tag for slots computed now, the old one for finished slots);
- * fwmask[8a .. 8a+8): bit k set = slot a took row W[k] from slot k (written for computed slots; may be pinned host memory);
- * ticket: one u32 counter, zero before first use, ticket_base = workgroups launched by all earlier calls (mod 2^32). */
-int nla_crs_advance_chunks(int n, int ld, int variant);
-int nla_k_crs_advance_fwd(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
-                          const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
-                          uint64_t first_block, int K, const int64_t *W, int nW,
-                          const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                          double *TX, int variant, uint32_t *flags, const uint32_t *gen, uint32_t *fwmask,
-                          uint32_t *ticket, uint32_t ticket_base, void *stream);
-int nla_k_crs_advance_fwd_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
-                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
-                               uint64_t first_block, int K, const int64_t *h_W, int nW,
-                               const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                               double *TX, int variant, uint32_t *flags, const uint32_t *h_gen, uint32_t *fwmask,
-                               uint32_t *ticket, uint32_t ticket_base, void *stream);
+/* replaces: crs_trial's whole loop body (crs.c:125-156) for a window of K <= 256 consecutive stream blocks in ONE launch
+ * (hip/crs_chain.hip): the gather-sum of every block speculated as a reflection trial, its evaluation, the mutation that would
+ * follow its rejection (words of the next block) with its evaluation — and the accept/reject chain itself, resolved on the
+ * device in block order against the nW worst rows W (worst first) and their f values Wf, so that a slot whose pick is one of
+ * those rows reads what the chain says the row holds at the slot's turn: the point (TX or TM) of the block that overwrote it,
+ * or the row as it is.  Every slot finishes.  Outputs: TX / TM / status[a] = (fT, fM, n) as nla_k_crs_advance + nla_k_crs_finish
+ * would leave them; fwcnt[a] and fwrec[a * fwcap ..] = one record per pick of a row W[j], j < a:  j | producer slot << 8 |
+ * kind << 16  (kind 0: the row itself was read; 1 / 2: TX / TM of window slot `producer`) — the caller verifies them against
+ * the chain it replays (a stop, or a value landing among the worst rows twice, are not modelled on the device).
+ * ctrl: nla_crs_chain_ctrl_bytes(K, nW) bytes of device memory, zero before the first launch (the launcher re-zeroes all of it
+ * but its ticket counter); ticket_base = workgroups launched by earlier calls on this ctrl = sum of K * nla_crs_chain_chunks.
+ * w_on_host != 0 (nW <= 96): W / Wf are host arrays and travel as kernel arguments.  f_best = f of row i0. */
+size_t nla_crs_chain_ctrl_bytes(int K, int nW);
+int nla_crs_chain_chunks(int n, int ld);
+int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                    const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                    uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                    const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                    nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream);
 
 /* replaces: the evaluation of the trial (crs.c:133) and the local mutation + its evaluation
  * (crs.c:139-146, K5) for the slots completed by the preceding nla_k_crs_advance (same window):

@@ -178,9 +178,11 @@ def lib():
     L.nla_k_crs_vitter.argtypes = [C.c_int, C.c_int64, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_advance.argtypes = [C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, C.c_int,
                                     vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]
-    L.nla_k_crs_advance_fwd.argtypes = [C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, C.c_int,
-                                        vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp]
-    L.nla_crs_advance_chunks.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.nla_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_double, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp,
+                                  C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_int, vp]
+    L.nla_crs_chain_ctrl_bytes.argtypes = [C.c_int, C.c_int]
+    L.nla_crs_chain_ctrl_bytes.restype = C.c_size_t
+    L.nla_crs_chain_chunks.argtypes = [C.c_int, C.c_int]
     L.nla_k_crs_finish.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int,
                                    vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.nla_k_isres_rank_count.argtypes = [C.c_int64, vp, vp, vp, vp, vp]

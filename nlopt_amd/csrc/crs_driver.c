@@ -23,15 +23,15 @@
  * pass recomputes W from the updated order.  What is still discarded (and counted in the stats):
  *   (a) a slot whose block turned out to be a mutation block (its predecessor was rejected),
  *   (b) everything in flight when the best point changes (the sum starts from the best row).
- * VALUE FORWARDING (the engine's advance op with a mask array, default on): stopping at a hazard pick lets the chain
- * consume only the first ~sqrt(2N/n) blocks of a pass.  Instead a slot takes the content a hazard row W[k] will have at its
- * turn from where that content is produced — the trial point of window slot k — speculating that block k is accepted and
- * overwrites W[k] (each accepted block overwrites the then-worst row, and a new value is rarely among the worst itself).  All
- * slots of a window then finish in one pass.  This file keeps, per in-flight block, the list (row, producer block, producer
- * generation) of what it took from others, and per population row its last writer (block, reflection or mutation, generation
- * of that block's computation); a slot is consumed only if, for every entry, the row's last writer at that moment IS that
- * computation of that producer's reflection trial — otherwise it is recomputed as the front slot of the next pass (counted in
- * stats.slots_invalid).  What the chain consumes is therefore always a trial point built from the rows the reference reads.
+ * DEVICE-RESOLVED WINDOWS (the engine's chain op, hip/crs_chain.hip; default where the engine has it): the conservative
+ * passes above let the chain consume only the first ~sqrt(2N/n) blocks of a window.  The chain kernel instead computes every
+ * slot of the window to the end in one launch and resolves the dependences itself — it evaluates each finished trial, replays
+ * crs_trial's accept / reject decisions in block order on the window's worst rows, and a slot whose pick is one of those
+ * rows reads what the row holds AT ITS TURN: the point of the block that overwrote it, or the row as it is.  This file stays
+ * the authority: per slot it gets one record per such pick (row, what was read: the row itself / block b's trial point /
+ * block b's mutation) and consumes the slot only if, at that moment of the replayed chain, the row's last writer is exactly
+ * that (lastw[]); otherwise the window ends there and the slot is recomputed at the front of the next one (stats.slots_invalid).
+ * What the chain consumes is therefore always a trial point built from the rows the reference reads.
  * The result is the reference's exact sequence of (candidate, accept/reject, replaced row),
  * including its quirks: maxeval is only tested after a rejection (:136-137), ftol compares
  * successive bests (:256), ties in f break by row index (:51-56, here in key_less), and a reached
@@ -179,8 +179,7 @@ static int after_accept(run_state *rs, uint64_t block, int kind)
 
 /* ---- resumable run: begin (= crs_init), advance (= rounds of the trial loop), end -------------- */
 #define TRING 2048                 /* host mirror of per-slot progress, indexed by block % TRING */
-#define FWCAP 48                   /* forwarded rows remembered per slot; a slot with more is recomputed at the front */
-#define FWORDS 8                   /* mask words per slot (256 window slots) */
+#define FWCAP 48                   /* records per slot the chain kernel keeps; a slot with more is recomputed at the front */
 
 struct nla_crs_session {
     run_state rs;
@@ -197,17 +196,11 @@ struct nla_crs_session {
     uint64_t *cblock;
     int32_t *ckind;
     int64_t *W, *crow;
-    /* value forwarding */
+    /* device-resolved windows */
     int forward;
-    uint32_t pass;                 /* passes made; a slot's generation = the pass that computed it */
-    uint32_t *fwd;                 /* Kmax x FWORDS masks of the last pass */
-    uint32_t *slot_gen;            /* TRING */
-    int16_t *fw_n;                 /* TRING: entries of the slot's list, -1 = too many (never valid) */
-    int64_t *fw_row;               /* TRING x FWCAP */
-    uint64_t *fw_pb;               /* TRING x FWCAP: producer block */
-    uint32_t *fw_pgen;             /* TRING x FWCAP: producer's generation when it was read */
+    double *Wf;                    /* f of the rows W */
+    uint32_t *fwcnt, *fwrec;       /* Kmax, Kmax x FWCAP: the last window's records */
     uint64_t *lastw;               /* N: (block + 1) << 1 | (reflection trial ? 1 : 0) of the row's last writer, 0 = initial row */
-    uint32_t *lastw_gen;           /* N */
 };
 
 static void session_free(nla_crs_session *S)
@@ -215,7 +208,7 @@ static void session_free(nla_crs_session *S)
     if (!S) return;
     free(S->rs.F); free(S->rs.os.heap); free(S->rs.os.cand); free(S->rs.xtmp);
     free(S->status); free(S->tprev); free(S->W); free(S->cblock); free(S->ckind); free(S->crow);
-    free(S->fwd); free(S->slot_gen); free(S->fw_n); free(S->fw_row); free(S->fw_pb); free(S->fw_pgen); free(S->lastw); free(S->lastw_gen);
+    free(S->Wf); free(S->fwcnt); free(S->fwrec); free(S->lastw);
     free(S);
 }
 
@@ -251,8 +244,8 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     S->kmult = pb->window_factor > 0 ? pb->window_factor : 1.5;
     if (S->Kmax > 1024) S->Kmax = 1024;
     if (S->host_eval) S->Kmax = 1;
-    S->forward = pb->forward && ops->reset_slot && S->Kmax > 1;
-    if (S->forward && S->Kmax > 32 * FWORDS) S->Kmax = 32 * FWORDS;
+    S->forward = pb->forward && ops->chain && !S->host_eval && S->Kmax > 1;
+    if (S->forward && S->Kmax > 256) S->Kmax = 256;
     S->runlen = 4.0;
     rs->ops = ops; rs->e = e; rs->pb = &S->pb; rs->x = x; rs->minf = minf;
     rs->need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);
@@ -268,18 +261,13 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     S->ckind = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
     S->crow = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
     if (S->forward) {
-        S->fwd = (uint32_t *) calloc((size_t) S->Kmax * FWORDS, sizeof(uint32_t));
-        S->slot_gen = (uint32_t *) calloc(TRING, sizeof(uint32_t));
-        S->fw_n = (int16_t *) calloc(TRING, sizeof(int16_t));
-        S->fw_row = (int64_t *) malloc(sizeof(int64_t) * TRING * FWCAP);
-        S->fw_pb = (uint64_t *) malloc(sizeof(uint64_t) * TRING * FWCAP);
-        S->fw_pgen = (uint32_t *) malloc(sizeof(uint32_t) * TRING * FWCAP);
+        S->Wf = (double *) malloc(sizeof(double) * (size_t) S->Kmax);
+        S->fwcnt = (uint32_t *) calloc((size_t) S->Kmax, sizeof(uint32_t));
+        S->fwrec = (uint32_t *) calloc((size_t) S->Kmax * FWCAP, sizeof(uint32_t));
         S->lastw = (uint64_t *) calloc((size_t) N, sizeof(uint64_t));
-        S->lastw_gen = (uint32_t *) calloc((size_t) N, sizeof(uint32_t));
     }
     if (!rs->F || !rs->os.heap || !rs->os.cand || !rs->xtmp || !S->status || !S->tprev || !S->W || !S->cblock ||
-        !S->ckind || !S->crow ||
-        (S->forward && (!S->fwd || !S->slot_gen || !S->fw_n || !S->fw_row || !S->fw_pb || !S->fw_pgen || !S->lastw || !S->lastw_gen))) {
+        !S->ckind || !S->crow || (S->forward && (!S->Wf || !S->fwcnt || !S->fwrec || !S->lastw))) {
         session_free(S);
         *ret_out = NLOPT_OUT_OF_MEMORY;
         return NULL;
@@ -348,63 +336,20 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
         if (K > cap) K = cap;
         if (K < 1) K = 1;
         /* never shrink the window below what is already in flight (their state would be lost) */
-        if (S->fresh_from > S->block && (uint64_t) K < S->fresh_from - S->block && S->fresh_from - S->block <= (uint64_t) cap &&
+        if (!S->forward && S->fresh_from > S->block && (uint64_t) K < S->fresh_from - S->block && S->fresh_from - S->block <= (uint64_t) cap &&
             S->fresh_from - S->block <= (uint64_t) S->Kmax)
             K = (int) (S->fresh_from - S->block);
         nW = K < N ? K : (int) N;
         nW = os_topk(&rs->os, nW, W);
         if (S->forward) {
-            /* revalidate what is in flight against what is known NOW, front to back, so that everything that cannot (or is
-             * unlikely to) be consumed is recomputed by this one pass instead of costing a pass each when the walk reaches it:
-             * a list entry (row, producer, generation) still stands if the producer is behind the front and did write the row
-             * last, or is still in flight, unchanged, at the window position whose speculated target row is that row */
-            for (a = 0; a < K; ++a) {
-                const uint64_t b = S->block + (uint64_t) a;
-                const size_t ix = (size_t) (b % TRING);
-                int ok, c;
-                if (b >= S->fresh_from || S->slot_gen[ix] == 0) continue;
-                ok = S->fw_n[ix] >= 0;
-                for (c = 0; ok && c < S->fw_n[ix]; ++c) {
-                    const int64_t r = S->fw_row[ix * FWCAP + (size_t) c];
-                    const uint64_t pbk = S->fw_pb[ix * FWCAP + (size_t) c];
-                    const uint32_t pg = S->fw_pgen[ix * FWCAP + (size_t) c];
-                    if (pbk < S->block) ok = S->lastw[r] == (((pbk + 1) << 1) | 1u) && S->lastw_gen[r] == pg;
-                    else ok = S->slot_gen[pbk % TRING] == pg && (int64_t) (pbk - S->block) < nW && W[pbk - S->block] == r;
-                }
-                if (!ok) {
-                    if (st) ++st->slots_invalid;
-                    S->slot_gen[ix] = 0;
-                    S->tprev[ix] = 0;
-                    if (ops->reset_slot(e, b)) { engine_failed(S); return S->ret; }
-                }
-            }
-        }
-        if (ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status, S->forward ? S->fwd : NULL)) { engine_failed(S); return S->ret; }
+            /* every slot of the window is computed in this launch; what an earlier window left unconsumed is dropped */
+            if (st && S->fresh_from > S->block) st->slots_invalid += S->fresh_from - S->block;
+            S->fresh_from = S->block;
+            for (a = 0; a < nW; ++a) S->Wf[a] = rs->F[W[a]];
+            if (ops->chain(e, S->block, K, rs->os.best, rs->F[rs->os.best], W, S->Wf, nW, status, S->fwcnt, S->fwrec, FWCAP)) { engine_failed(S); return S->ret; }
+        } else
+        if (ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status)) { engine_failed(S); return S->ret; }
         wend = S->block + (uint64_t) K;
-        if (S->forward) {
-            /* the slots computed by this pass (the fresh ones and those that were reset) carry this pass as generation;
-             * then their lists: bit k of slot a's mask = it took row W[k] from the block at window position k */
-            ++S->pass;
-            for (a = 0; a < K; ++a) {
-                const uint64_t b = S->block + (uint64_t) a;
-                if (b >= S->fresh_from || S->slot_gen[b % TRING] == 0) S->slot_gen[b % TRING] = S->pass;
-            }
-            for (a = 0; a < K; ++a) {
-                const uint64_t b = S->block + (uint64_t) a;
-                const size_t ix = (size_t) (b % TRING);
-                int cnt = 0, k;
-                if (S->slot_gen[ix] != S->pass) continue;
-                for (k = 0; k < a && k < nW && cnt >= 0; ++k)
-                    if (S->fwd[(size_t) a * FWORDS + (size_t) (k >> 5)] >> (k & 31) & 1u) {
-                        if (cnt == FWCAP) { cnt = -1; break; }
-                        S->fw_row[ix * FWCAP + (size_t) cnt] = W[k];
-                        S->fw_pb[ix * FWCAP + (size_t) cnt] = S->block + (uint64_t) k;
-                        S->fw_pgen[ix * FWCAP + (size_t) cnt] = S->slot_gen[(S->block + (uint64_t) k) % TRING];
-                        ++cnt;
-                    }
-                S->fw_n[ix] = (int16_t) cnt;
-            }
-        }
         if (st) {
             ++st->rounds;
             for (a = 0; a < K; ++a) {          /* algorithmic bytes this pass moved: 8n per row summed */
@@ -426,21 +371,23 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             if (best_changed) break;
             if (status[j].t < n) break;             /* not finished yet: next pass */
             if (S->forward) {
-                /* every row this slot took from a producer must have been last written by THAT computation of that
-                 * producer's reflection trial; otherwise the trial point is not the reference's: recompute it at the front */
-                const size_t ix = (size_t) (blk % TRING);
-                int ok = S->fw_n[ix] >= 0, c;
-                for (c = 0; ok && c < S->fw_n[ix]; ++c) {
-                    const int64_t r = S->fw_row[ix * FWCAP + (size_t) c];
-                    ok = S->lastw[r] == (((S->fw_pb[ix * FWCAP + (size_t) c] + 1) << 1) | 1u) &&
-                         S->lastw_gen[r] == S->fw_pgen[ix * FWCAP + (size_t) c];
+                /* what this slot read for its picks among the window's worst rows must be what the chain, replayed up to
+                 * here, says those rows hold: the row untouched since the window started, or last written by exactly the
+                 * block and point (trial / mutation) the slot took it from */
+                const uint32_t cnt = S->fwcnt[j];
+                int ok = cnt <= FWCAP;
+                uint32_t c;
+                for (c = 0; ok && c < cnt; ++c) {
+                    const uint32_t rec = S->fwrec[(size_t) j * FWCAP + c];
+                    const int64_t r = W[rec & 0xffu];
+                    const uint64_t pbk = S->block + (uint64_t) ((rec >> 8) & 0xffu);
+                    const unsigned kind = (rec >> 16) & 3u;
+                    if (kind == 0) ok = (S->lastw[r] >> 1) <= S->block;          /* last written by a block before this window, or never */
+                    else ok = S->lastw[r] == (((pbk + 1) << 1) | (kind == 1 ? 1u : 0u));
                 }
                 if (!ok) {
                     if (st) ++st->slots_invalid;
-                    S->slot_gen[ix] = 0;
-                    S->tprev[ix] = 0;
-                    if (ops->reset_slot(e, blk)) { engine_failed(S); return S->ret; }
-                    break;
+                    break;                              /* recomputed as the front slot of the next window */
                 }
             }
             if (st) ++st->slots_used;
@@ -490,7 +437,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 trace_add(pb, fcand, worst, kind, 1);
                 if (st) ++st->accepted;
                 cblock[ncommit] = blk; ckind[ncommit] = host_eval ? 1 : kind; crow[ncommit] = worst; ++ncommit;
-                if (S->forward) { S->lastw[worst] = ((blk + 1) << 1) | (kind == 1 ? 1u : 0u); S->lastw_gen[worst] = S->slot_gen[blk % TRING]; }
+                if (S->forward) S->lastw[worst] = ((blk + 1) << 1) | (kind == 1 ? 1u : 0u);
                 if (key_less(rs->F, worst, rs->os.best)) { rs->os.best = worst; best_changed = 1; }
                 if (after_accept(rs, blk, host_eval ? 1 : kind)) { engine_failed(S); return S->ret; }
                 ret = rs->ret;

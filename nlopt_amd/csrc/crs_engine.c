@@ -31,7 +31,8 @@ typedef struct {
 
 /* one H2D per pass, packed: [W: nW i64][crow: nc i64][t_in: K i32][cslot: nc i32][ckind: nc i32][gen: K u32] */
 #define UPLOAD_BYTES (KCAP * (8 + 8 + 4 + 4 + 4 + 4))
-#define FWD_KMAX 256                       /* window slots a forwarding mask can name (NLA_FWD_WORDS x 32) */
+#define CHAIN_KMAX 256                     /* window slots / worst rows one device-resolved launch handles */
+#define CHAIN_FWCAP 48                     /* records per slot (crs_driver.c FWCAP) */
 
 struct nla_crs_hip_engine {
     int n, ld, obj;
@@ -55,10 +56,12 @@ struct nla_crs_hip_engine {
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
-    /* value forwarding (crs_kernels.hip): per-(slot, chunk) completion flags, their generation tags, the ticket counter */
-    int chunks;
-    uint32_t *d_flags, *d_ticket, *h_fwmask;
-    uint32_t h_gen[KCAP], pass_id, ticket_base;
+    /* device-resolved windows (hip/crs_chain.hip): control block, the walk's lists when they do not fit the kernel arguments,
+     * what every slot took from where (pinned, written by the kernel) */
+    void *d_ctrl;
+    uint32_t ticket_base;
+    uint32_t *h_fwcnt, *h_fwrec;
+    double *d_Wf;
     int force_upload;              /* NLA_CRS_UPLOAD: the pass's lists through the H2D copy even when they fit the kernel arguments (A/B switch) */
     FILE *pass_log;                /* NLA_CRS_PASS_LOG=<file>: one line per pass (development aid, see tools/pass_log_summary.py) */
     nlopt_amd_stats *stats;
@@ -113,7 +116,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_initwords);
     nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
     nla_dev_free(e->d_up); nla_dev_free(e->d_tout); nla_dev_free(e->d_status);
-    nla_dev_free(e->d_flags); nla_dev_free(e->d_ticket); nla_host_free(e->h_fwmask);
+    nla_dev_free(e->d_ctrl); nla_dev_free(e->d_Wf); nla_host_free(e->h_fwcnt); nla_host_free(e->h_fwrec);
     nla_host_free(e->h_up); nla_host_free(e->h_status);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
     nla_stream_destroy(e->main); nla_stream_destroy(e->rng);
@@ -169,17 +172,18 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * KCAP);
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
-    e->chunks = n / 64 + 2;                  /* upper bound over the kernel's tilings (nla_crs_advance_chunks) */
-    e->d_flags = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * (size_t) KCAP * (size_t) e->chunks);
-    e->d_ticket = (uint32_t *) nla_dev_malloc(sizeof(uint32_t));
-    e->h_fwmask = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * 8 * FWD_KMAX);
+    if (obj >= 0) {
+        e->d_ctrl = nla_dev_malloc(nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX));
+        e->d_Wf = (double *) nla_dev_malloc(sizeof(double) * CHAIN_KMAX);
+        e->h_fwcnt = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX);
+        e->h_fwrec = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX * CHAIN_FWCAP);
+    }
     e->direct_status = !getenv("NLA_CRS_COPY_STATUS");
     e->force_upload = getenv("NLA_CRS_UPLOAD") != NULL;
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1 ||
-        !e->d_flags || !e->d_ticket || !e->h_fwmask) goto fail;
-    if (nla_memset(e->d_flags, 0, sizeof(uint32_t) * (size_t) KCAP * (size_t) e->chunks, e->main) ||
-        nla_memset(e->d_ticket, 0, sizeof(uint32_t), e->main) ||
+        (obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
+    if ((e->d_ctrl && nla_memset(e->d_ctrl, 0, nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX), e->main)) ||
         nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
         nla_memcpy_h2d(e->d_ub, ub, sizeof(double) * (size_t) n, e->main) || nla_stream_sync(e->main)) goto fail;
     return e;
@@ -306,31 +310,21 @@ static int flush_commits(nla_crs_hip_engine *e)
 }
 
 static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
-                      nla_crs_slot_status *status, uint32_t *fwd)
+                      nla_crs_slot_status *status)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const int n = e->n;
     const uint32_t ring = 2u * (uint32_t) e->B;
     int32_t t_in[KCAP];
-    uint32_t gen[KCAP];
     const int64_t *d_W = NULL;
     const int32_t *d_tin = NULL;
-    const uint32_t *d_gen = NULL;
-    const int chunks = nla_crs_advance_chunks(n, e->ld, e->variant);
-    if (fwd && (K > FWD_KMAX || chunks > e->chunks)) FAIL(e, "forwarding window too wide (K=%d)", K);
     if (K < 1 || K > KCAP || nW > KCAP || nW < 0) FAIL(e, "bad window K=%d nW=%d", K, nW);
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
     if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
     for (int a = 0; a < K; ++a) {
         const uint64_t b = first_block + (uint64_t) a;
         t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
-        if (fwd) {
-            /* a slot that is not finished is computed from scratch by a forwarding pass; its flags get this pass's tag */
-            if (t_in[a] != n) { t_in[a] = 0; e->h_gen[b & (KCAP - 1)] = e->pass_id + 1; }
-            gen[a] = e->h_gen[b & (KCAP - 1)];
-        }
     }
-    if (fwd) ++e->pass_id;
     if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload) {
         /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
          * front of the pass */
@@ -339,12 +333,6 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
             e->npending = 0;
         }
         CK(e, nla_event_record(e->ev0, e->main));
-        if (fwd) {
-            CK(e, nla_k_crs_advance_fwd_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
-                                             t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->d_flags, gen,
-                                             e->h_fwmask, e->d_ticket, e->ticket_base, e->main));
-            e->ticket_base += (uint32_t) chunks * (uint32_t) K;
-        } else
         CK(e, nla_k_crs_advance_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
                                      t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         CK(e, nla_event_record(e->ev1, e->main));
@@ -359,14 +347,8 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         }
         goto launched;
     }
-    if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, fwd ? gen : NULL, &d_gen)) return -1;
+    if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, NULL, NULL)) return -1;
     CK(e, nla_event_record(e->ev0, e->main));
-    if (fwd) {
-        CK(e, nla_k_crs_advance_fwd(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
-                                    d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->d_flags, d_gen,
-                                    e->h_fwmask, e->d_ticket, e->ticket_base, e->main));
-        e->ticket_base += (uint32_t) chunks * (uint32_t) K;
-    } else
     CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
                             d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
     CK(e, nla_event_record(e->ev1, e->main));
@@ -377,11 +359,7 @@ launched:
     CK(e, nla_stream_sync(e->main));
 have_status:
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
-    if (fwd)                       /* the masks of the slots computed in this pass (the kernel wrote them into pinned memory) */
-        for (int a = 0; a < K; ++a) {
-            if (t_in[a] == 0) memcpy(fwd + 8 * (size_t) a, e->h_fwmask + 8 * (size_t) a, 8 * sizeof(uint32_t));
-            else memset(fwd + 8 * (size_t) a, 0, 8 * sizeof(uint32_t));
-        }
+
     for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = status[a].t;
     if (e->stats) {
         float ms = nla_event_elapsed_ms(e->ev0, e->ev1);
@@ -447,6 +425,53 @@ static int op_mutate_slot(void *ve, uint64_t block, int64_t i0)
     return 0;
 }
 
+/* a whole window in one launch with the chain resolved on the device (hip/crs_chain.hip) */
+static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_best, const int64_t *W, const double *Wf, int nW,
+                    nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap)
+{
+    nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
+    const int n = e->n;
+    const uint32_t ring = 2u * (uint32_t) e->B;
+    const int on_host = nW <= NLA_KARG_MAX && !e->force_upload;
+    const int64_t *d_W = W;
+    const double *d_Wf = Wf;
+    if (e->obj < 0 || !e->d_ctrl) FAIL(e, "no device-resolved windows for a host objective");
+    if (K < 1 || K > CHAIN_KMAX || nW < 0 || nW > CHAIN_KMAX || fwcap != CHAIN_FWCAP) FAIL(e, "bad window K=%d nW=%d", K, nW);
+    if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
+    if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
+    /* the commits of the previous pass, then (long lists only) W and its f values */
+    if (e->npending && e->npending <= NLA_KARG_MAX && !e->force_upload) {
+        CK(e, nla_k_crs_commit_args(n, e->ld, e->d_X, e->d_TX, e->d_TM, e->npending, e->pend_slot, e->pend_kind, e->pend_row, e->main));
+        e->npending = 0;
+    }
+    if (e->npending || !on_host) {
+        if (upload_and_commit(e, W, on_host ? 0 : nW, NULL, 0, &d_W, NULL, NULL, NULL)) return -1;
+        if (!on_host) { CK(e, nla_memcpy_h2d(e->d_Wf, Wf, sizeof(double) * (size_t) nW, e->main)); d_Wf = e->d_Wf; }
+        else { d_W = W; }
+    }
+    CK(e, nla_event_record(e->ev0, e->main));
+    {
+        const int rc = nla_k_crs_chain(e->obj, n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf, nW,
+                                       on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status, e->h_fwcnt,
+                                       e->h_fwrec, fwcap, e->main);
+        if (rc) FAIL(e, "nla_k_crs_chain failed: %s", nla_dev_error_string(rc));
+    }
+    e->ticket_base += (uint32_t) nla_crs_chain_chunks(n, e->ld) * (uint32_t) K;
+    CK(e, nla_event_record(e->ev1, e->main));
+    CK(e, nla_stream_sync(e->main));              /* status and records were written into pinned host memory by the kernel */
+    memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
+    memcpy(fwcnt, e->h_fwcnt, sizeof(uint32_t) * (size_t) K);
+    memcpy(fwrec, e->h_fwrec, sizeof(uint32_t) * (size_t) K * (size_t) fwcap);
+    for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = n;
+    if (e->stats) {
+        float ms = nla_event_elapsed_ms(e->ev0, e->ev1);
+        if (ms >= 0) e->stats->t_gather_ms += ms;
+        e->stats->gather_launches += 1;
+    }
+    if (e->pass_log) fprintf(e->pass_log, "%d,%d,%d,%d,%d,%d,%ld,%.4f\n", n, K, nW, 0, K, 0, (long) K * n, (double) nla_event_elapsed_ms(e->ev0, e->ev1));
+    return 0;
+}
+
 static const char *op_last_error(void *ve) { return ((nla_crs_hip_engine *) ve)->err; }
 
 static int op_reset_slot(void *ve, uint64_t block)
@@ -456,7 +481,7 @@ static int op_reset_slot(void *ve, uint64_t block)
 }
 
 const nla_crs_engine_ops nla_crs_hip_ops = {
-    op_init_population, op_max_slots, op_advance, op_reset_slot, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
+    op_init_population, op_max_slots, op_advance, op_chain, op_reset_slot, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
 };
 
 static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,
@@ -469,7 +494,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         return NLOPT_INVALID_ARGS;
     }
     memset(pb, 0, sizeof *pb);
-    pb->forward = 0;
+    pb->forward = 1;
     pb->n = n; pb->N = N; pb->lb = lb; pb->ub = ub; pb->f = f; pb->f_data = f_data; pb->stop = stop;
     pb->obj = nlopt_amd_objective_id(f);
     if (opt) {
@@ -477,10 +502,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         pb->stats = &opt->stats;
         pb->max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
         pb->window_factor = nlopt_get_param(opt, "amd_window_factor", 0);
-        /* measured on MI355X (n = 4096, N = 1e5): speculating "every block is accepted" consumes 28 blocks per pass instead of
-         * 6, but 3.6 % of the blocks are rejected and each rejection shifts which block writes which row for everything behind
-         * it: half of the gathered bytes are recomputed, 22.6 k evals/s against 31.1 k without — off unless asked for */
-        pb->forward = nlopt_get_param(opt, "amd_forward", 0) != 0;
+        pb->forward = nlopt_get_param(opt, "amd_forward", 1) != 0;
         if (getenv("NLA_CRS_FORWARD")) pb->forward = atoi(getenv("NLA_CRS_FORWARD"));                 /* A/B switch for the bench */
         if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
     }

@@ -1,0 +1,342 @@
+/* crs_chain.hip — CRS2_LM: a whole window of trials with the accept/reject chain RESOLVED INSIDE THE LAUNCH.
+ *
+ * The reference is one serial chain (src/algs/crs/crs.c:125-156): trial point = best + sum of n random rows, accept it over
+ * the current worst row or not, maybe one mutation, next.  Trial b+1 may sample a row that trial b has just overwritten, so
+ * the chain is a dependence chain through the population.  crs_kernels.hip breaks it by NEVER reading a row that may still
+ * change (a slot stops at its first pick among the d worst rows, d = its distance from the window front): exact, nothing
+ * wasted — but only the first ~sqrt(2N/n) slots of a window get through, 6 per pass at n = 4096, N = 1e5, and every pass
+ * pays its fixed costs and the latency floor of a lone trial.  Speculating "every block is accepted and overwrites the k-th
+ * worst row" lets a slot take a hazard row from the producer's trial point, but each rejection (3.6 % of the blocks) shifts
+ * which block writes which row for everything behind it: measured 22.6 k evals/s against 31.1 k (half the bytes recomputed).
+ *
+ * Here the dependences are resolved exactly, by the kernel itself:
+ *   gather     grid = K slots x coordinate chunks, as in crs_advance_kernel (same tiling, same accumulation order: x is the
+ *              reference's bit for bit).  Workgroups draw (slot, chunk) from a ticket counter, front slot first.
+ *   evaluate   the workgroup that completes the LAST chunk of a slot evaluates f of the trial point, forms the mutation the
+ *              reference would try after a rejection (crs.c:139-146, words of the next stream block) and evaluates it too.
+ *   resolve    whoever finished an evaluation advances the chain as far as the evaluated slots reach, in block order, under
+ *              a lock: f(T) < f(current worst)? else f(M) < f(worst)? — crs_trial's decisions on the window's list of worst
+ *              rows (their f values come with the launch; a new value that lands among them is tracked) — and publishes, per
+ *              worst row, who overwrote it (slot, trial or mutation) and how far the chain has got.
+ *   consume    a slot whose next pick is one of the worst rows ahead of it waits until that row's fate is known: overwritten
+ *              by an earlier block -> read the writer's point (TX / TM of that slot, final before it was published);
+ *              chain already past this slot's predecessors without touching the row -> read the row itself.
+ * Every slot finishes in the one launch and nothing is guessed, so (nearly) every slot is consumed: the window can be as wide
+ * as the per-pass costs want (up to 256) and the gather runs at its saturated bandwidth.  What remains unused: the slot of a
+ * block that turned out to be a mutation block (its predecessor was rejected), and whatever is in flight when the best point
+ * changes (the sums start from the best row; the resolver halts there).
+ *
+ * The host stays the authority: its in-order walk (crs_driver.c) recomputes every decision from the f values and accepts a
+ * slot only if each row it took from a producer was in fact last written by that producer's point — the device's resolution
+ * is a prediction that is right unless something the device does not model intervenes (a stop, a value re-entering the
+ * worst rows twice); then the slot is recomputed.  Deadlock cannot occur: a slot waits only for blocks before it, their
+ * workgroups hold earlier tickets and are therefore running or done, and the front slot never waits.
+ *
+ * Roofline: HBM, 8 n (n+1) algorithmic bytes per trial; the evaluation adds 24 n.
+ */
+#include "crs_common.h"
+#include "../../../include/nlopt_amd.h"
+
+#define CH_EXTRA 32                      /* accepted values that landed among the window's worst rows */
+
+/* control block of one launch (device memory, zeroed before the launch except `ticket`, which only grows) */
+struct chain_ctrl {
+    uint32_t ticket, lock, next, halt, naccept, wp, nextra, pad;
+    double xf[CH_EXTRA]; int64_t xrow[CH_EXTRA];
+};
+/* behind the control block: fv[2K] doubles (fT, fM of every slot, for the resolver — the status records themselves may live in
+ * pinned host memory), then the u32 arrays done[K], evald[K], rowstate[nW] */
+
+#define NLA_KA_MAX 96                    /* list length that still travels as kernel arguments */
+struct chain_lists { int inl; int64_t W[NLA_KA_MAX]; double Wf[NLA_KA_MAX]; };
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* crs_trial's decisions for the evaluated slots at the front of the unresolved part (one thread, under the lock) */
+__device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate, const double *fv, int K, int nW,
+                              const int64_t *W, const double *Wf, double f_best, int64_t i0)
+{
+    for (;;) {
+        if (atomicCAS(&c->lock, 0u, 1u) != 0u) return;          /* the holder re-checks after it lets go */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        uint32_t j = c->next;
+        while (j < (uint32_t) K && !c->halt && ld_agent(&evald[j])) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            /* the current worst: the next untouched row of the list, or a value that landed among them */
+            double fw = -HUGE_VAL; int64_t rw = -1; int xi = -1;
+            if (c->wp < (uint32_t) nW) { fw = Wf[c->wp]; rw = W[c->wp]; }
+            for (uint32_t e = 0; e < c->nextra; ++e)
+                if (rw < 0 || c->xf[e] > fw || (c->xf[e] == fw && c->xrow[e] > rw)) { fw = c->xf[e]; rw = c->xrow[e]; xi = (int) e; }
+            if (rw < 0) { c->halt = 1; break; }                 /* beyond the rows this launch knows */
+            const double fT = fv[2 * j], fM = fv[2 * j + 1];
+            int kind = 0;
+            double fnew = 0;
+            if (fT < fw) { kind = 1; fnew = fT; }               /* crs.c:135 */
+            else if (fM < fw) { kind = 2; fnew = fM; }           /* the mutation of crs.c:139-146, accepted at :135 */
+            if (kind) {
+                if (xi >= 0) { c->xf[xi] = c->xf[c->nextra - 1]; c->xrow[xi] = c->xrow[c->nextra - 1]; --c->nextra; }   /* (its row's first writer stays on record) */
+                else { st_agent(&rowstate[c->wp], 1u | ((uint32_t) kind << 1) | (j << 3)); ++c->wp; }
+                ++c->naccept;
+                /* the new value may itself be among the worst that are left */
+                if (nW > 0 && (fnew > Wf[nW - 1] || (fnew == Wf[nW - 1] && rw > W[nW - 1]))) {
+                    if (c->nextra == CH_EXTRA) c->halt = 1;
+                    else { c->xf[c->nextra] = fnew; c->xrow[c->nextra] = rw; ++c->nextra; }
+                }
+                if (fnew < f_best || (fnew == f_best && rw < i0)) c->halt = 1;   /* a new best: everything behind started from the old one */
+            }
+            j += (kind == 1) ? 1u : 2u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            st_agent(&c->next, j);
+        }
+        if (c->halt) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); st_agent(&c->next, (uint32_t) K + 2u); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&c->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");       /* unlock before the re-check (the arriving side: publish, fence, try the lock) */
+        const uint32_t nx = ld_agent(&c->next);
+        if (!(nx < (uint32_t) K && ld_agent(&evald[nx]))) return;
+    }
+}
+
+template <int VEC, int U, int WAVES, int OBJ>
+__global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
+    int n, int ld, const double *__restrict__ X, int64_t i0, double f_best, const int32_t *__restrict__ jn_ring,
+    const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, const uint32_t *__restrict__ words_ring,
+    uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *__restrict__ Wd, const double *__restrict__ Wfd, int nW,
+    int slot_mask, int chunks, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX,
+    double *__restrict__ TM, chain_ctrl *__restrict__ ctrl, uint32_t ticket_base, nla_crs_slot_status *__restrict__ status,
+    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, const chain_lists L)
+{
+    typedef typename VecT<VEC>::T V;
+    static_assert(U <= 64, "one lane per row of a batch");
+    __shared__ V sacc[64];
+    __shared__ int32_t srow[NLA_ADV_RCAP];
+    __shared__ int s_turn, s_ticket, s_last;
+    __shared__ uint32_t s_nrec;
+    __shared__ double scratch[2 * WAVES];
+    volatile __attribute__((address_space(3))) int *turn = (volatile __attribute__((address_space(3))) int *) &s_turn;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    double *fv = reinterpret_cast<double *>(ctrl + 1);
+    uint32_t *done = reinterpret_cast<uint32_t *>(fv + 2 * (size_t) K), *evald = done + K, *rowstate = evald + K;
+    const int64_t *W = L.inl ? L.W : Wd;
+    const double *Wf = L.inl ? L.Wf : Wfd;
+    if (threadIdx.x == 0) { s_ticket = (int) (atomicAdd(&ctrl->ticket, 1u) - ticket_base); s_nrec = 0; }
+    __syncthreads();
+    const int wg = s_ticket;
+    const int a = wg / chunks, chunk = wg % chunks;             /* front slot first: producers before consumers */
+    const uint64_t block = first_block + (uint64_t) a;
+    const uint32_t rb = (uint32_t) (block % ring_blocks);
+    const int q = (int) (block & (uint64_t) slot_mask);
+    const int32_t *p = pos_ring + (size_t) rb * (size_t) n;
+    const int jn = jn_ring[rb];
+    const int64_t rbase = p[n - 1];                             /* last pick: i += iurand(Nleft); i += i == i0  (crs.c:109) */
+    int64_t al = rbase + (rbase >= i0 ? 1 : 0) + (int64_t) last_ring[rb];
+    al += (al == i0) ? 1 : 0;
+    auto pick_row = [&](int t) -> int32_t {
+        int64_t r;
+        if (t < n - 1) { r = p[t]; r += (r >= i0 ? 1 : 0); } else r = al;
+        return (int32_t) r;
+    };
+    const int nun = a < nW ? a : nW;
+    /* the picks of the staged segment that are rows W[j], j < nun, become -(j+1): "ask what happened to worst row j" */
+    auto mark_hazards = [&](int cnt) {
+        int hit[(256 + 63) / 64];
+#pragma unroll
+        for (int it = 0; it < (256 + 63) / 64; ++it) {
+            const int j = it * 64 + lane;
+            hit[it] = -1;
+            if (j < nun) {
+                const int64_t r = W[j];
+                int lo = 0, hi = cnt - 1;
+                while (r != i0 && lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int32_t pv = srow[mid];
+                    if (pv == (int32_t) r) { hit[it] = mid; break; }
+                    if (pv < (int32_t) r) lo = mid + 1; else hi = mid - 1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < (256 + 63) / 64; ++it)
+            if (hit[it] >= 0) srow[hit[it]] = -(it * 64 + lane + 1);
+    };
+    const int col = (chunk * 64 + lane) * VEC;
+    const bool active = col < n;
+    const size_t colc = active ? (size_t) col : 0;
+    const double *Xc = X + colc;
+    double *accrow = TX + (size_t) q * (size_t) ld + colc;
+    if (wave == 0) sacc[lane] = ldv<VEC>(Xc + (size_t) i0 * (size_t) ld);       /* x := best (crs.c:69) */
+    const double hneg = -(0.5 * n);         /* x -= xi*(0.5*n)  ==  x += xi*(-(0.5*n)), exactly */
+    const uint32_t lane_off = (uint32_t) (colc * sizeof(double));
+    V v[U];
+    for (int seg0 = 0; seg0 < n; seg0 += NLA_ADV_RCAP) {
+        const int cnt = (n - seg0 < NLA_ADV_RCAP) ? n - seg0 : NLA_ADV_RCAP;
+        nla_lds_barrier();
+        for (int i = threadIdx.x; i < cnt; i += WAVES * 64) srow[i] = pick_row(seg0 + i);
+        nla_lds_barrier();
+        if (wave == 0 && nun > 0) mark_hazards(cnt);
+        if (threadIdx.x == 0) *turn = 0;
+        nla_lds_barrier();
+        const int nb = (cnt + U - 1) / U;
+        auto issue = [&](int b) {
+            const int base = b * U;
+            const int mine = base + lane < cnt ? base + lane : cnt - 1;
+            const int32_t myrow = srow[mine];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {        /* unconditional: lanes past the end hold the last row */
+                const int64_t r = (int64_t) __builtin_amdgcn_readlane(myrow, u);
+                const char *rowp = reinterpret_cast<const char *>(X + (size_t) r * (size_t) ld);   /* wave-uniform */
+                if (r < 0) {
+                    /* worst row j of the launch's list: overwritten by a block before this one?  Wait until the chain says so
+                     * (rowstate[j]) or has passed every block before this slot without touching it */
+                    const int j = (int) (-r - 1);
+                    uint32_t rs;
+                    for (;;) {
+                        rs = ld_agent(&rowstate[j]);
+                        if (rs) break;
+                        if (ld_agent(&ctrl->next) >= (uint32_t) a) { rs = ld_agent(&rowstate[j]); break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    /* a writer at or behind this slot's own block does not count: the row is read as it is before that */
+                    int pj = 0, kind = 0;                    /* kind 0: the row as it is (no block before this one wrote it) */
+                    if (rs && (int) (rs >> 3) < a) {
+                        pj = (int) (rs >> 3); kind = (int) ((rs >> 1) & 3u);
+                        const int qk = (int) ((first_block + (uint64_t) pj) & (uint64_t) slot_mask);
+                        rowp = reinterpret_cast<const char *>((kind == 1 ? TX : TM) + (size_t) qk * (size_t) ld);
+                    } else rowp = reinterpret_cast<const char *>(X + (size_t) W[j] * (size_t) ld);
+                    if (chunk == 0 && lane == 0 && base + u < cnt) {     /* what was decided, for the host to verify */
+                        const uint32_t k = atomicAdd(&s_nrec, 1u);
+                        if ((int) k < fwcap) fwrec[(size_t) a * (size_t) fwcap + k] = (uint32_t) j | ((uint32_t) pj << 8) | ((uint32_t) kind << 16);
+                    }
+                }
+                v[u] = *reinterpret_cast<const V *>(rowp + lane_off);
+            }
+        };
+        if (wave < nb) issue(wave);
+        for (int ph = wave; ph < nb; ph += WAVES) {
+            while (*turn != ph) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            V acc = sacc[lane];
+            const int base = ph * U, tb = seg0 + base;
+            if (base + U <= cnt && !(jn >= tb && jn < tb + U)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) add_row(acc, v[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (base + u < cnt) acc_row(acc, v[u], (tb + u == jn) ? hneg : 1.0);
+            }
+            sacc[lane] = acc;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *turn = ph + 1;
+            if (ph + WAVES < nb) issue(ph + WAVES);
+        }
+        if (wave == 0) {
+            while (*turn != nb) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
+    }
+    if (wave == 0 && active) {              /* x[k] *= 2.0 / n, then clamp (crs.c:116-120) */
+        V acc = sacc[lane];
+        const double s = 2.0 / n;
+        if constexpr (VEC == 1) {
+            double a0 = *reinterpret_cast<double *>(&acc);
+            *accrow = nla_clamp_box(a0 * s, lb[col], ub[col]);
+        } else {
+            double2 a2 = *reinterpret_cast<double2 *>(&acc), r2;
+            r2.x = nla_clamp_box(a2.x * s, lb[col], ub[col]);
+            r2.y = nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]);
+            *reinterpret_cast<double2 *>(accrow) = r2;
+        }
+    }
+    /* this chunk of the trial point is final; the workgroup that completes the slot evaluates it */
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (chunk == 0) fwcnt[a] = s_nrec;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = (atomicAdd(&done[a], 1u) == (uint32_t) (chunks - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+        const int tid = threadIdx.x;
+        const double *x = TX + (size_t) q * (size_t) ld;
+        const double *xb = X + (size_t) i0 * (size_t) ld;
+        const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n;
+        double *m = TM + (size_t) q * (size_t) ld;
+        auto getx = [&](int i) { return __builtin_nontemporal_load(x + i); };
+        const double fT = nla_block_objective<OBJ, WAVES>(n, getx, scratch);
+        auto mut = [&](int i) {        /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
+            const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
+            const double wv = nla_urand_from(0., 1., ww.x, ww.y);
+            return nla_clamp_box(xb[i] * (1 + wv) - wv * getx(i), lb[i], ub[i]);
+        };
+        for (int i = tid; i < n; i += WAVES * 64) m[i] = mut(i);
+        const double fM = nla_block_objective<OBJ, WAVES>(n, mut, scratch);
+        __syncthreads();
+        if (tid == 0) {
+            status[a].fT = fT; status[a].fM = fM; status[a].t = n; status[a].pad = 0;
+            fv[2 * a] = fT; fv[2 * a + 1] = fM;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            st_agent(&evald[a], 1u);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            chain_resolve(ctrl, evald, rowstate, fv, K, nW, W, Wf, f_best, i0);
+        }
+    }
+}
+
+extern "C" size_t nla_crs_chain_ctrl_bytes(int K, int nW)
+{
+    return sizeof(chain_ctrl) + sizeof(double) * 2 * (size_t) K + sizeof(uint32_t) * (2 * (size_t) K + (size_t) nW + 8);
+}
+
+extern "C" int nla_crs_chain_chunks(int n, int ld)
+{
+    const bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    const int cpw = vec2 ? 128 : 64;
+    return (n + cpw - 1) / cpw;
+}
+
+extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                               const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                               uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                               const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                               nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream)
+{
+    if (K <= 0) return 0;
+    if (K > 256 || nW > 256 || nW < 0 || obj < 0) return (int) hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t) stream;
+    chain_lists L;
+    L.inl = 0;
+    if (w_on_host) {                                          /* the lists travel as kernel arguments: no copy in front of the launch */
+        if (nW > NLA_KA_MAX) return (int) hipErrorInvalidValue;
+        L.inl = 1;
+        for (int j = 0; j < nW; ++j) { L.W[j] = W[j]; L.Wf[j] = Wf[j]; }
+        W = nullptr; Wf = nullptr;
+    }
+    const bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    const int chunks = nla_crs_chain_chunks(n, ld);
+    const dim3 grid((unsigned) ((long) chunks * K));
+    chain_ctrl *c = (chain_ctrl *) ctrl;
+    /* everything but the ticket counter starts from zero */
+    hipError_t e = hipMemsetAsync((char *) ctrl + sizeof(uint32_t), 0, nla_crs_chain_ctrl_bytes(K, nW) - sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int) e;
+#define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, n, ld, X, i0, f_best, jn_ring, \
+        pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
+        fwcnt, fwrec, fwcap, L)
+#define CHAIN_SHAPE(O)                                                                   \
+    if (vec2) {                                                                          \
+        if (n >= 2048) CHAIN(2, 32, 8, O); else if (n >= 512) CHAIN(2, 16, 4, O); else CHAIN(2, 16, 2, O); \
+    } else {                                                                             \
+        if (n >= 2048) CHAIN(1, 32, 8, O); else if (n >= 512) CHAIN(1, 16, 4, O); else if (n >= 128) CHAIN(1, 16, 2, O); else CHAIN(1, 16, 1, O); \
+    }
+    NLA_OBJ_DISPATCH(obj, CHAIN_SHAPE)
+#undef CHAIN_SHAPE
+#undef CHAIN
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

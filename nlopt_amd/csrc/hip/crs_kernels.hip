@@ -104,20 +104,7 @@ __global__ __launch_bounds__(64) void crs_vitter_kernel(int n, int64_t N, const 
     last[b] = (int32_t) (w[2 * n - 1] % (uint32_t) Nleft);       /* nlopt_iurand(Nleft), crs.c:109 */
 }
 
-/* vector width helpers for the gather-sum */
-template <int VEC> struct VecT;
-template <> struct VecT<1> { typedef double T; };
-template <> struct VecT<2> { typedef double2 T; };
-
-template <int VEC>
-__device__ __forceinline__ typename VecT<VEC>::T ldv(const double *p);
-template <> __device__ __forceinline__ double ldv<1>(const double *p) { return *p; }
-template <> __device__ __forceinline__ double2 ldv<2>(const double *p) { return *reinterpret_cast<const double2 *>(p); }
-
-__device__ __forceinline__ void add_row(double &a, double v) { a = a + v; }
-__device__ __forceinline__ void add_row(double2 &a, double2 v) { a.x = a.x + v.x; a.y = a.y + v.y; }
-__device__ __forceinline__ void acc_row(double &a, double v, double m) { a = a + v * m; }
-__device__ __forceinline__ void acc_row(double2 &a, double2 v, double m) { a.x = a.x + v.x * m; a.y = a.y + v.y * m; }
+#include "crs_common.h"
 
 /* ------------------------------------------------------------------------------------------------
  * K4': resumable gather-sum ("advance").  The reference accumulates the n sampled rows of a trial
@@ -138,32 +125,11 @@ __device__ __forceinline__ void acc_row(double2 &a, double2 v, double m) { a.x =
  * accumulator travels through LDS from wavefront to wavefront in batch order as a token (an LDS
  * turn counter; only the 2U fp64 adds of a batch and the hand-off are on the serial path) —
  * WAVES*U rows of one chunk are in flight instead of U.
- *
- * Value forwarding (F.enable): stopping at a hazard pick makes the chain consume only ~N/n... blocks per pass (6 at
- * n = 4096, N = 1e5: slot a is clear of all its a predecessors with probability exp(-a^2 n / 2N)).  But the content a hazard
- * row W[k] WILL have at slot a's turn is known in the common case: the k-th block of the window is accepted (96 %) and
- * overwrites the then-worst row, which is W[k] — with that block's own trial point, TX of window slot k, finished earlier in
- * this same launch.  So instead of stopping, slot a reads row W[k] from TX[slot k] as soon as that slot's chunk is final
- * (per-(slot, chunk) flags with agent-scope release / acquire; the trial point is summed per coordinate, so chunk c of slot a
- * needs only chunk c of slot k), and reports which producers it used (fwmask: bit k).  Every slot of the window finishes in
- * one launch; the host's in-order walk accepts a slot only if every row it took from a producer was in fact last written by
- * that producer's reflection trial (crs_driver.c) and recomputes it otherwise — the sequence stays the reference's exactly.
- * Workgroups take their (slot, chunk) from a ticket counter, front slot first, so a consumer's producers have always been
- * started before it: waiting cannot deadlock whatever the dispatch order.
  * ---------------------------------------------------------------------------------------------- */
-/* LDS-only barrier: orders this wavefront's LDS traffic, leaves its global loads in flight
- * (__syncthreads() carries a workgroup release fence that drains vmcnt). */
-__device__ __forceinline__ void nla_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-#define NLA_ADV_RCAP 8192               /* picks staged in LDS per segment (32 KB) */
-
 /* The small per-pass lists can travel as KERNEL ARGUMENTS instead of through a host-to-device copy in front of the pass
  * (one dependent stream operation and its gap less per pass): inl != 0 -> use these, else the device pointers. */
 #define NLA_KA_MAX 96
-struct crs_lists { int inl; int32_t t_in[NLA_KA_MAX]; int64_t W[NLA_KA_MAX]; uint32_t gen[NLA_KA_MAX]; };
-/* value forwarding between the slots of one pass (see the kernel's header): all device pointers; enable == 0: off */
-struct crs_fwd { int enable; uint32_t ticket_base; uint32_t *flags; const uint32_t *gen; uint32_t *fwmask; uint32_t *ticket; };
-#define NLA_FWD_WORDS 8                 /* 256 window slots as a bit mask */
+struct crs_lists { int inl; int32_t t_in[NLA_KA_MAX]; int64_t W[NLA_KA_MAX]; };
 struct crs_commits { int inl; int32_t slot[NLA_KA_MAX], kind[NLA_KA_MAX]; int64_t row[NLA_KA_MAX]; };
 
 template <int VEC, int U, int WAVES>
@@ -172,7 +138,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, uint32_t ring_blocks,
     uint64_t first_block, int K, const int64_t *__restrict__ W, int nW,
     const int32_t *__restrict__ t_in, int32_t *__restrict__ t_out, int slot_mask, int chunks,
-    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX, const crs_lists L, const crs_fwd F)
+    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX, const crs_lists L)
 {
     typedef typename VecT<VEC>::T V;
     static_assert(U <= 64, "one lane per row of a batch");
@@ -180,32 +146,19 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     __shared__ int32_t srow[NLA_ADV_RCAP];
     __shared__ int s_e;
     __shared__ int s_turn;
-    __shared__ int s_ticket;
     /* polled through an explicit LDS-address-space pointer: volatile accesses through a generic
      * pointer become flat loads, whose waits would also drain the global loads in flight */
     volatile __attribute__((address_space(3))) int *turn = (volatile __attribute__((address_space(3))) int *) &s_turn;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    /* without forwarding: back of the window first (fresh slots have the longest pieces, the front ones the shortest);
-     * with forwarding: front first in ticket order (producers before consumers) */
-    int wg = (int) blockIdx.x;
-    if (F.enable) {
-        /* the counter is never reset: the launcher passes how many tickets earlier launches drew (mod 2^32) */
-        if (threadIdx.x == 0) s_ticket = (int) (atomicAdd(F.ticket, 1u) - F.ticket_base);
-        __syncthreads();
-        wg = s_ticket;
-    }
-    const int a = F.enable ? wg / chunks : K - 1 - wg / chunks, chunk = wg % chunks;
+    /* back of the window first: fresh slots have the longest pieces, the front ones the shortest */
+    const int a = K - 1 - (int) (blockIdx.x / chunks), chunk = blockIdx.x % chunks;
     const uint64_t block = first_block + (uint64_t) a;
     const uint32_t rb = (uint32_t) (block % ring_blocks);
     const int q = (int) (block & (uint64_t) slot_mask);
     const int32_t *p = pos_ring + (size_t) rb * (size_t) n;
     const int jn = jn_ring[rb];
     const int t0 = L.inl ? L.t_in[a] : t_in[a];
-    if (F.enable && t0 >= n) {              /* finished in an earlier pass: nothing to do, its flags stay as they are */
-        if (chunk == 0 && threadIdx.x == 0) t_out[a] = n;
-        return;
-    }
     /* last pick: i += iurand(Nleft); i += i == i0  (crs.c:109) */
     const int64_t rbase = p[n - 1];
     int64_t al = rbase + (rbase >= i0 ? 1 : 0) + (int64_t) last_ring[rb];
@@ -221,41 +174,9 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     const int cnt0 = (n - t0 < NLA_ADV_RCAP) ? n - t0 : NLA_ADV_RCAP;
     for (int i = threadIdx.x; i < cnt0; i += WAVES * 64) srow[i] = pick_row(t0 + i);
     __syncthreads();
-    const int nun = a < nW ? a : nW;
-    /* forwarding: the picks of the staged segment that are hazard rows W[j], j < nun, become -(j+1) = "take it from window
-     * slot j"; srow stays searchable because the marks are made after all searches (two phases) */
-    auto mark_hazards = [&](int cnt, uint32_t *mask) {
-        int hit[(256 + 63) / 64];
-#pragma unroll
-        for (int it = 0; it < (256 + 63) / 64; ++it) {
-            const int j = it * 64 + lane;
-            hit[it] = -1;
-            if (j < nun) {
-                const int64_t r = L.inl ? L.W[j] : W[j];
-                int lo = 0, hi = cnt - 1;
-                while (r != i0 && lo <= hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const int32_t pv = srow[mid];
-                    if (pv == (int32_t) r) { hit[it] = mid; break; }
-                    if (pv < (int32_t) r) lo = mid + 1; else hi = mid - 1;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < (256 + 63) / 64; ++it) {
-            const int j = it * 64 + lane;
-            if (hit[it] >= 0) srow[hit[it]] = -(j + 1);
-            const unsigned long long b = __ballot(hit[it] >= 0);
-            if (lane == 0) { mask[2 * it] |= (uint32_t) b; mask[2 * it + 1] |= (uint32_t) (b >> 32); }
-        }
-    };
-    uint32_t fmask[NLA_FWD_WORDS] = { 0, 0, 0, 0, 0, 0, 0, 0 };     /* wave 0, lane 0 */
-    if (wave == 0 && F.enable) {
-        mark_hazards(cnt0, fmask);
-        if (lane == 0) s_e = n;
-    } else if (wave == 0) {                 /* plan: where must this slot stop in this pass? */
+    if (wave == 0) {                        /* plan: where must this slot stop in this pass? */
         int e = n;
+        const int nun = a < nW ? a : nW;
         for (int j = lane; j < nun; j += 64) {
             const int64_t r = L.inl ? L.W[j] : W[j];
             if (r == i0) continue;          /* the best row is never sampled */
@@ -303,13 +224,8 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
     for (int seg0 = t0; seg0 < e; seg0 += NLA_ADV_RCAP) {
         const int cnt = (e - seg0 < NLA_ADV_RCAP) ? e - seg0 : NLA_ADV_RCAP;
         nla_lds_barrier();                  /* the previous segment's row list is no longer needed */
-        if (seg0 != t0) {                   /* (the first segment was staged for the plan) */
+        if (seg0 != t0)                     /* (the first segment was staged for the plan) */
             for (int i = threadIdx.x; i < cnt; i += WAVES * 64) srow[i] = pick_row(seg0 + i);
-            if (F.enable) {
-                nla_lds_barrier();
-                if (wave == 0) mark_hazards(cnt, fmask);
-            }
-        }
         if (threadIdx.x == 0) *turn = 0;
         nla_lds_barrier();
         const int nb = (cnt + U - 1) / U;
@@ -321,15 +237,6 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
             for (int u = 0; u < U; ++u) {        /* unconditional: lanes past the end hold the last row */
                 const int64_t r = (int64_t) __builtin_amdgcn_readlane(myrow, u);
                 const char *rowp = reinterpret_cast<const char *>(X + (size_t) r * (size_t) ld);   /* wave-uniform */
-                if (r < 0) {                     /* hazard row: its new content is window slot k's trial point */
-                    const int k = (int) (-r - 1);
-                    const int qk = (int) ((first_block + (uint64_t) k) & (uint64_t) slot_mask);
-                    const uint32_t want = L.inl ? L.gen[k] : F.gen[k];
-                    uint32_t *fl = F.flags + (size_t) qk * (size_t) chunks + (size_t) chunk;
-                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(2);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    rowp = reinterpret_cast<const char *>(TX + (size_t) qk * (size_t) ld);
-                }
                 v[u] = *reinterpret_cast<const V *>(rowp + lane_off);
             }
         };
@@ -375,15 +282,6 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
             }
         } else {
             *reinterpret_cast<V *>(accrow) = acc;
-        }
-    }
-    if (F.enable && wave == 0) {            /* this chunk of the trial point is final: let the consumers go */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) {
-            __hip_atomic_store(F.flags + (size_t) q * (size_t) chunks + (size_t) chunk, L.inl ? L.gen[a] : F.gen[a], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (chunk == 0)
-                for (int w = 0; w < NLA_FWD_WORDS; ++w) F.fwmask[(size_t) a * NLA_FWD_WORDS + w] = fmask[w];
         }
     }
     if (chunk == 0 && threadIdx.x == 0) t_out[a] = e;
@@ -547,8 +445,7 @@ static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const 
                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                               uint64_t first_block, int K, const int64_t *W, int nW,
                               const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                              double *TX, int variant, const crs_lists &L, const crs_fwd &F, void *stream);
-static crs_fwd fwd_off() { crs_fwd F = {}; return F; }
+                              double *TX, int variant, const crs_lists &L, void *stream);
 extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                                  const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                                  uint64_t first_block, int K, const int64_t *W, int nW,
@@ -558,7 +455,7 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
     crs_lists L;
     L.inl = 0;
     return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, lb, ub,
-                              TX, variant, L, fwd_off(), stream);
+                              TX, variant, L, stream);
 }
 /* the same with W (nW <= 96) and t_in (K <= 96) given as HOST arrays: they travel as kernel arguments */
 extern "C" int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
@@ -573,48 +470,13 @@ extern "C" int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0
     for (int a = 0; a < K; ++a) L.t_in[a] = h_t_in[a];
     for (int j = 0; j < nW; ++j) L.W[j] = h_W[j];
     return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, nullptr, nW, nullptr, t_out, slot_mask,
-                              lb, ub, TX, variant, L, fwd_off(), stream);
-}
-
-/* the forwarding forms (see the kernel's header and include/nlopt_amd.h) */
-extern "C" int nla_crs_advance_chunks(int n, int ld, int variant);
-extern "C" int nla_k_crs_advance_fwd(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
-                                     const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
-                                     uint64_t first_block, int K, const int64_t *W, int nW,
-                                     const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                                     double *TX, int variant, uint32_t *flags, const uint32_t *gen, uint32_t *fwmask,
-                                     uint32_t *ticket, uint32_t ticket_base, void *stream)
-{
-    if (K > 256) return (int) hipErrorInvalidValue;
-    crs_lists L;
-    L.inl = 0;
-    crs_fwd F;
-    F.enable = 1; F.ticket_base = ticket_base; F.flags = flags; F.gen = gen; F.fwmask = fwmask; F.ticket = ticket;
-    return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, lb, ub,
-                              TX, variant, L, F, stream);
-}
-extern "C" int nla_k_crs_advance_fwd_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
-                                          const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
-                                          uint64_t first_block, int K, const int64_t *h_W, int nW,
-                                          const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                                          double *TX, int variant, uint32_t *flags, const uint32_t *h_gen, uint32_t *fwmask,
-                                          uint32_t *ticket, uint32_t ticket_base, void *stream)
-{
-    if (K > NLA_KA_MAX || nW > NLA_KA_MAX) return (int) hipErrorInvalidValue;
-    crs_lists L;
-    L.inl = 1;
-    for (int a = 0; a < K; ++a) { L.t_in[a] = h_t_in[a]; L.gen[a] = h_gen[a]; }
-    for (int j = 0; j < nW; ++j) L.W[j] = h_W[j];
-    crs_fwd F;
-    F.enable = 1; F.ticket_base = ticket_base; F.flags = flags; F.gen = nullptr; F.fwmask = fwmask; F.ticket = ticket;
-    return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, nullptr, nW, nullptr, t_out, slot_mask,
-                              lb, ub, TX, variant, L, F, stream);
+                              lb, ub, TX, variant, L, stream);
 }
 static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                               uint64_t first_block, int K, const int64_t *W, int nW,
                               const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                              double *TX, int variant, const crs_lists &L, const crs_fwd &F, void *stream)
+                              double *TX, int variant, const crs_lists &L, void *stream)
 {
     if (K <= 0) return 0;
     hipStream_t st = (hipStream_t) stream;
@@ -627,7 +489,7 @@ static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const 
     const int chunks = (n + cpw - 1) / cpw;
     const dim3 grid((unsigned) ((long) chunks * K));
 #define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, n, ld, X, i0, jn_ring, \
-        pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX, L, F)
+        pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX, L)
     if (vec2) {
         switch (variant) {
         case 116: ADV(2, 16, 1); break;
@@ -656,15 +518,6 @@ static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const 
 #undef ADV
     NLA_LAUNCH_CHECK();
     return 0;
-}
-
-/* coordinate chunks (= workgroups per slot, = flags per slot) the advance kernel uses for this shape */
-extern "C" int nla_crs_advance_chunks(int n, int ld, int variant)
-{
-    bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
-    if (variant >= 10000) vec2 = false;
-    const int cpw = vec2 ? 128 : 64;
-    return (n + cpw - 1) / cpw;
 }
 
 static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,

@@ -167,11 +167,14 @@ typedef struct {
      * that may be overwritten next, worst first.  status[a] = (f of the finished trial, f of the
      * mutation that would follow its rejection (w from block+1), picks summed so far). */
     int (*advance)(void *e, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
-                   nla_crs_slot_status *status, uint32_t *fwd);
-    /* fwd != NULL (K <= 256): VALUE FORWARDING — instead of stopping at a pick of row W[k], k < a, slot a takes that row's
-     * content from the finished trial point of window slot k (speculating that block first_block+k is accepted and
-     * overwrites W[k], the common case) and finishes in the same pass; fwd[8a .. 8a+8) = bit mask of the k it used, written
-     * for the slots computed in this pass.  The driver verifies every use at the slot's turn. */
+                   nla_crs_slot_status *status);
+    /* the same window in ONE launch with the accept/reject chain resolved on the device (hip/crs_chain.hip; K, nW <= 256):
+     * every slot is computed from pick 0 and finishes; a pick of row W[j], j < a, is read as the device's resolution of the
+     * chain says the row stands at the slot's turn.  Wf = f of the rows W, f_best = f of row i0.  fwcnt[a] / fwrec[a * fwcap ..]:
+     * one record per such pick, j | producer window slot << 8 | kind << 16 (kind 0: the row itself; 1 / 2: the producer's trial
+     * point / mutation), fwcnt[a] > fwcap: more than recorded.  NULL where the engine has no such kernel. */
+    int (*chain)(void *e, uint64_t first_block, int K, int64_t i0, double f_best, const int64_t *W, const double *Wf, int nW,
+                 nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap);
     /* forget the state of one in-flight block: it is recomputed from pick 0 by the next pass that holds it */
     int (*reset_slot)(void *e, uint64_t block);
     /* X[row[c]] := point of slot block[c] (kind[c]: 1 trial, 2 its mutation); rows distinct */
@@ -192,7 +195,7 @@ typedef struct {
     nlopt_amd_trace_rec *trace; size_t trace_cap, *trace_len;
     nlopt_amd_stats *stats;
     int max_spec;                   /* cap on slots per round (0 = default) */
-    int forward;                    /* value forwarding between the slots of a pass: 1 on (default where the engine offers it), 0 off */
+    int forward;                    /* 1: windows through the engine's chain op (device-resolved dependences), 0: the conservative passes */
     double window_factor;           /* window = factor x (blocks consumed per pass, smoothed) + 4 (0 = default 1.5) */
 } nla_crs_problem;
 

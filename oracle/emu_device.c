@@ -605,41 +605,24 @@ int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int
     EMU_LAUNCH();
     return nla_k_crs_advance(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, h_W, nW, h_t_in, t_out, slot_mask, lb, ub, TX, variant, st);
 }
-void orc_k_advance_slot_fwd(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
-                            const int64_t *W, int nun, const double *TXring, uint64_t first_block, int ecap,
-                            const double *lb, const double *ub, double *acc, uint32_t *mask);
-int nla_crs_advance_chunks(int n, int ld, int variant) { (void) ld; (void) variant; return (n + 63) / 64; }
-int nla_k_crs_advance_fwd(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring, const int32_t *pos_ring, const int32_t *last_ring,
-                          uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W, int nW, const int32_t *t_in, int32_t *t_out,
-                          int slot_mask, const double *lb, const double *ub, double *TX, int variant, uint32_t *flags, const uint32_t *gen,
-                          uint32_t *fwmask, uint32_t *ticket, uint32_t ticket_base, void *st)
+typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
+void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
+                     const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                     const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
+                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap);
+size_t nla_crs_chain_ctrl_bytes(int K, int nW) { (void) K; (void) nW; return 64; }
+int nla_crs_chain_chunks(int n, int ld) { (void) ld; return (n + 63) / 64; }
+int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
+                    const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W,
+                    const double *Wf, int nW, int w_on_host, int slot_mask, const double *lb, const double *ub, double *TX, double *TM, void *ctrl,
+                    uint32_t ticket_base, nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *st)
 {
     EMU_LAUNCH();
-    (void) variant; (void) st; (void) ticket; (void) ticket_base;
-    if (K > 256) return EMU_ERR;
-    for (int a = 0; a < K; ++a) {                 /* front to back: a slot's producers are final before it runs */
-        const uint64_t block = first_block + (uint64_t) a;
-        const uint32_t rb = (uint32_t) (block % ring_blocks);
-        const int q = (int) (block & (uint64_t) slot_mask);
-        t_out[a] = n;
-        if (t_in[a] >= n) continue;
-        /* the trial points of the producers this slot may use must carry the tags the caller expects (the kernel would wait) */
-        for (int k = 0; k < a && k < nW; ++k)
-            if (flags[(size_t) ((first_block + (uint64_t) k) & (uint64_t) slot_mask)] != gen[k]) return EMU_ERR;
-        orc_k_advance_slot_fwd(n, ld, X, i0, jn_ring[rb], pos_ring + (size_t) rb * (size_t) n, last_ring[rb], W, a < nW ? a : nW, TX, first_block,
-                               slot_mask + 1, lb, ub, TX + (size_t) q * (size_t) ld, fwmask + 8 * (size_t) a);
-        flags[(size_t) q] = gen[a];
-    }
+    (void) w_on_host; (void) ctrl; (void) ticket_base; (void) st;
+    if (K > 256 || nW > 256 || obj < 0) return EMU_ERR;
+    orc_k_crs_chain(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, lb, ub,
+                    TX, TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap);
     return 0;
-}
-int nla_k_crs_advance_fwd_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring, const int32_t *pos_ring,
-                               const int32_t *last_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *h_W, int nW,
-                               const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *TX, int variant,
-                               uint32_t *flags, const uint32_t *h_gen, uint32_t *fwmask, uint32_t *ticket, uint32_t ticket_base, void *st)
-{
-    EMU_LAUNCH();
-    return nla_k_crs_advance_fwd(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, h_W, nW, h_t_in, t_out, slot_mask, lb, ub, TX,
-                                 variant, flags, h_gen, fwmask, ticket, ticket_base, st);
 }
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
                      uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,

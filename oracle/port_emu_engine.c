@@ -20,9 +20,11 @@ void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *wo
 int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
                        const int64_t *W, int nun, int t0, const double *lb, const double *ub, double *acc);
 
-void orc_k_advance_slot_fwd(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
-                            const int64_t *W, int nun, const double *TXring, uint64_t first_block, int ecap,
-                            const double *lb, const double *ub, double *acc, uint32_t *mask);
+typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
+void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
+                     const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                     const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
+                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap);
 
 #define ECAP 1024                           /* slot ring, block b at slot b % ECAP */
 
@@ -47,7 +49,7 @@ static void need_blocks(emu *e, uint64_t upto)     /* the oracle generator is se
  * produced in rank blocks and all-gathered over the communicator's host transport, the way
  * crs_engine.c's op_init_population does it on the device. */
 static nlopt_amd_comm *emu_comm = NULL;
-static int emu_forward = 1;                 /* value forwarding in the driver under test (orc_emu_set_forward) */
+static int emu_forward = 1;                 /* device-resolved windows in the driver under test (orc_emu_set_forward) */
 void orc_emu_set_forward(int on) { emu_forward = on; }
 void orc_emu_set_comm(void *comm) { emu_comm = (nlopt_amd_comm *) comm; }
 
@@ -83,7 +85,7 @@ static int emu_init(void *ve, const double *x0, double *F)
 }
 static int emu_max_slots(void *ve, uint64_t first_block) { (void) first_block; return ((emu *) ve)->max_slots; }
 static int emu_advance(void *ve, uint64_t first, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
-                       nla_crs_slot_status *status, uint32_t *fwd)
+                       nla_crs_slot_status *status)
 {
     emu *e = (emu *) ve;
     const int n = e->n;
@@ -99,15 +101,6 @@ static int emu_advance(void *ve, uint64_t first, int K, uint64_t fresh_from, int
             e->t[q] = 0;
         }
         t0 = e->t[q];
-        if (fwd) {                      /* value forwarding: an unfinished slot is computed from pick 0 and always completes */
-            memset(fwd + 8 * (size_t) a, 0, 8 * sizeof(uint32_t));
-            if (t0 != n) {
-                t0 = 0;
-                orc_k_advance_slot_fwd(n, e->ld, e->X, i0, e->jn[q], e->pos + (size_t) q * n, e->last[q], W, a < nW ? a : nW, e->TX,
-                                       first, ECAP, e->lb, e->ub, acc, fwd + 8 * (size_t) a);
-            }
-            t1 = n;
-        } else
         t1 = orc_k_advance_slot(n, e->ld, e->X, i0, e->jn[q], e->pos + (size_t) q * n, e->last[q], W, a < nW ? a : nW, t0,
                                 e->lb, e->ub, acc);
         e->t[q] = t1;
@@ -123,6 +116,34 @@ static int emu_advance(void *ve, uint64_t first, int K, uint64_t fresh_from, int
     }
     return 0;
 }
+/* a whole window with the chain resolved by the "device" (port_kernels.c orc_k_crs_chain over this engine's rings, which are indexed
+ * like the slot ring: block b at entry b % ECAP) */
+static int emu_chain(void *ve, uint64_t first, int K, int64_t i0, double f_best, const int64_t *W, const double *Wf, int nW,
+                     nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap)
+{
+    emu *e = (emu *) ve;
+    const int n = e->n;
+    uint32_t *wring;
+    if (K > e->cap || e->obj < 0) return -1;
+    need_blocks(e, first + (uint64_t) K + 1);
+    wring = (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) n * ECAP);
+    for (int a = 0; a <= K; ++a) {                 /* digest the window's blocks (+ the one behind it: mutation words) into the rings */
+        const uint64_t b = first + (uint64_t) a;
+        const int q = (int) (b % ECAP);
+        memcpy(wring + (size_t) q * 2 * (size_t) n, e->tw + b * 2 * (uint64_t) n, sizeof(uint32_t) * 2 * (size_t) n);
+        if (a < K) orc_k_vitter(n, e->N, e->tw + b * 2 * (uint64_t) n, 1, e->jn + q, e->pos + (size_t) q * n, e->last + q);
+    }
+    orc_k_crs_chain(e->obj, n, e->ld, e->X, i0, f_best, e->jn, e->pos, e->last, wring, ECAP, first, K, W, Wf, nW, ECAP - 1, e->lb, e->ub,
+                    e->TX, e->TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap);
+    for (int a = 0; a < K; ++a) {
+        const int q = (int) ((first + (uint64_t) a) % ECAP);
+        e->t[q] = n; e->fT[q] = status[a].fT; e->fM[q] = status[a].fM;
+    }
+    free(wring);
+    return 0;
+}
+static int emu_reset_slot(void *ve, uint64_t block) { ((emu *) ve)->t[block % ECAP] = 0; return 0; }
+
 static int emu_commit(void *ve, int nc, const uint64_t *block, const int32_t *kind, const int64_t *row)
 {
     emu *e = (emu *) ve;
@@ -152,9 +173,8 @@ static int emu_mutate_slot(void *ve, uint64_t block, int64_t i0)
     return 0;
 }
 static const char *emu_err(void *ve) { (void) ve; return "emu"; }
-static int emu_reset_slot(void *ve, uint64_t block) { ((emu *) ve)->t[block % ECAP] = 0; return 0; }
 
-static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_advance, emu_reset_slot, emu_commit, emu_read_slot,
+static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_advance, emu_chain, emu_reset_slot, emu_commit, emu_read_slot,
                                             emu_read_row, emu_mutate_slot, emu_err };
 
 /* Run the PRODUCT's CRS driver over the emulated engine.  RNG = the oracle generator (orc_srand

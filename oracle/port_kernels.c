@@ -5,6 +5,8 @@
 #include "port_oracle.h"
 #include "objfuncs.h"
 #include <limits.h>
+#include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* tempered stream words of a generator state, in order (mt19937ar.c:97-131) */
@@ -129,30 +131,82 @@ int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, c
 }
 
 
-/* nla_k_crs_advance_fwd (value forwarding), one slot computed from pick 0: a pick of row W[j], j < nun, is read from the finished
- * trial point of window slot j (TXring + ((first_block + j) % ecap) * ld) instead of from X, and bit j of mask[8] is set.  The
- * sum always completes: acc becomes the trial point (scaled, clamped).  Slots must be processed front to back. */
-void orc_k_advance_slot_fwd(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
-                            const int64_t *W, int nun, const double *TXring, uint64_t first_block, int ecap,
-                            const double *lb, const double *ub, double *acc, uint32_t *mask)
+/* nla_k_crs_chain (hip/crs_chain.hip) stated sequentially: the window's slots front to back; each slot's gather-sum reads a pick
+ * of row W[j], j < a, as the chain resolved so far says the row stands (written by an earlier block of the window -> that block's
+ * trial point / mutation, else the row itself), then the slot is evaluated (trial, mutation with the next block's words) and the
+ * chain advanced over every block that can now be decided — crs_trial's decisions (crs.c:125-156) on the list of worst rows W
+ * with their values Wf, a new value that lands among them being tracked.  The device does the same with the slots in flight
+ * concurrently; a slot there waits until the fate of the row it needs is known, so its reads are these.  Records as the kernel
+ * writes them: j | producer slot << 8 | kind << 16. */
+typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
+void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
+                     const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                     const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
+                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap)
 {
-    memset(mask, 0, 8 * sizeof(uint32_t));
-    memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) n);
-    for (int t = 0; t < n; ++t) {
-        const int64_t r = pick_row(n, pos, last, i0, t);
-        const double *xi = X + (size_t) r * (size_t) ld;
-        for (int j = 0; j < nun; ++j)
-            if (W[j] == r && r != i0) {
-                xi = TXring + (size_t) ((first_block + (uint64_t) j) % (uint64_t) ecap) * (size_t) ld;
-                mask[j >> 5] |= 1u << (j & 31);
-                break;
+    enum { XCAP = 32 };
+    uint32_t next = 0, wp = 0, nextra = 0, *rowstate = (uint32_t *) calloc((size_t) (nW > 0 ? nW : 1), sizeof(uint32_t));
+    int halt = 0;
+    double xf[XCAP]; int64_t xrow[XCAP];
+    for (int a = 0; a < K; ++a) {
+        const uint64_t block = first_block + (uint64_t) a;
+        const uint32_t rb = (uint32_t) (block % ring_blocks);
+        const int q = (int) (block & (uint64_t) slot_mask), nun = a < nW ? a : nW;
+        const int32_t *pos = pos_ring + (size_t) rb * (size_t) n;
+        double *acc = TX + (size_t) q * (size_t) ld, *m = TM + (size_t) q * (size_t) ld;
+        uint32_t nrec = 0;
+        memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) n);
+        for (int t = 0; t < n; ++t) {
+            const int64_t r = pick_row(n, pos, last_ring[rb], i0, t);
+            const double *xi = X + (size_t) r * (size_t) ld;
+            for (int j = 0; j < nun; ++j)
+                if (W[j] == r && r != i0) {
+                    const uint32_t rs = rowstate[j];
+                    uint32_t pj = 0, kind = 0;
+                    if (rs && (int) (rs >> 3) < a) {
+                        pj = rs >> 3; kind = (rs >> 1) & 3u;
+                        xi = (kind == 1 ? TX : TM) + (size_t) ((first_block + pj) & (uint64_t) slot_mask) * (size_t) ld;
+                    }
+                    if ((int) nrec < fwcap) fwrec[(size_t) a * (size_t) fwcap + nrec] = (uint32_t) j | (pj << 8) | (kind << 16);
+                    ++nrec;
+                    break;
+                }
+            if (t == jn_ring[rb]) for (int k = 0; k < n; ++k) acc[k] -= xi[k] * (0.5 * n);
+            else                  for (int k = 0; k < n; ++k) acc[k] += xi[k];
+        }
+        for (int k = 0; k < n; ++k) {
+            acc[k] *= 2.0 / n;
+            if (acc[k] > ub[k]) acc[k] = ub[k];
+            else if (acc[k] < lb[k]) acc[k] = lb[k];
+        }
+        fwcnt[a] = nrec;
+        orc_k_eval(obj, n, ld, acc, 1, &status[a].fT);
+        orc_k_mutate(n, X + (size_t) i0 * (size_t) ld, acc, words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n, lb, ub, m);
+        orc_k_eval(obj, n, ld, m, 1, &status[a].fM);
+        status[a].t = n; status[a].pad = 0;
+        /* the chain: every block up to this one can be decided now */
+        while (!halt && next < (uint32_t) K && next <= (uint32_t) a) {
+            const uint32_t j = next;
+            double fw = -HUGE_VAL, fnew = 0;
+            int64_t rw = -1;
+            int xi = -1, kind = 0;
+            if (wp < (uint32_t) nW) { fw = Wf[wp]; rw = W[wp]; }
+            for (uint32_t e = 0; e < nextra; ++e)
+                if (rw < 0 || xf[e] > fw || (xf[e] == fw && xrow[e] > rw)) { fw = xf[e]; rw = xrow[e]; xi = (int) e; }
+            if (rw < 0) { halt = 1; break; }
+            if (status[j].fT < fw) { kind = 1; fnew = status[j].fT; }
+            else if (status[j].fM < fw) { kind = 2; fnew = status[j].fM; }
+            if (kind) {
+                if (xi >= 0) { xf[xi] = xf[nextra - 1]; xrow[xi] = xrow[nextra - 1]; --nextra; }
+                else { rowstate[wp] = 1u | ((uint32_t) kind << 1) | (j << 3); ++wp; }
+                if (nW > 0 && (fnew > Wf[nW - 1] || (fnew == Wf[nW - 1] && rw > W[nW - 1]))) {
+                    if (nextra == XCAP) halt = 1;
+                    else { xf[nextra] = fnew; xrow[nextra] = rw; ++nextra; }
+                }
+                if (fnew < f_best || (fnew == f_best && rw < i0)) halt = 1;
             }
-        if (t == jn) for (int k = 0; k < n; ++k) acc[k] -= xi[k] * (0.5 * n);
-        else         for (int k = 0; k < n; ++k) acc[k] += xi[k];
+            next = j + (kind == 1 ? 1u : 2u);
+        }
     }
-    for (int k = 0; k < n; ++k) {
-        acc[k] *= 2.0 / n;
-        if (acc[k] > ub[k]) acc[k] = ub[k];
-        else if (acc[k] < lb[k]) acc[k] = lb[k];
-    }
+    free(rowstate);
 }

@@ -135,73 +135,88 @@ class SlotStatus(C.Structure):
     _fields_ = [("fT", C.c_double), ("fM", C.c_double), ("t", C.c_int32), ("pad", C.c_int32)]
 
 
-@pytest.mark.parametrize("obj,n,N,K,i0,variant", [("rastrigin", 10, 100, 7, 0, 0), ("rastrigin", 10, 11, 9, 10, 0),
-                                                  ("griewank", 64, 70, 60, 33, 0), ("ackley", 257, 600, 40, 599, 0),
-                                                  ("levy", 128, 140, 130, 17, 0), ("rosenbrock", 512, 700, 256, 3, 0),
-                                                  ("griewank", 4096, 4200, 24, 4199, 0), ("sphere", 1, 9, 8, 4, 0),
-                                                  ("griewank", 2048, 2100, 20, 77, 832), ("ackley", 300, 320, 30, 5, 132),
-                                                  ("ackley", 9000, 9100, 6, 5, 416), ("griewank", 2048, 2100, 12, 77, 10816)])
-def test_advance_with_value_forwarding(L, obj, n, N, K, i0, variant):
-    """nla_k_crs_advance_fwd: every slot finishes in ONE launch; a pick of hazard row W[k], k < a, is read from the finished
-    trial point of window slot k (chunk-wise, through the completion flags) — bit-exact trial points and the exact masks of
-    what was forwarded, against the sequential statement orc_k_advance_slot_fwd.  Small populations (N barely above n) make
-    every slot depend on MANY earlier slots of the same launch: the in-kernel waiting is what is tested.  A second launch
-    with some slots marked finished must leave those alone and recompute the others from the same inputs."""
+@pytest.mark.parametrize("obj,n,N,K,i0", [("rastrigin", 10, 100, 7, 0), ("rastrigin", 10, 11, 9, 10), ("griewank", 64, 70, 60, 33),
+                                          ("ackley", 257, 600, 40, 599), ("levy", 128, 140, 130, 17), ("rosenbrock", 512, 700, 256, 3),
+                                          ("griewank", 4096, 4200, 24, 4199), ("sphere", 2, 9, 8, 4), ("griewank", 2048, 2100, 20, 77),
+                                          ("ackley", 300, 320, 30, 5), ("ackley", 9000, 9100, 6, 5), ("rastrigin", 1000, 1100, 200, 1)])
+def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, n, N, K, i0):
+    """nla_k_crs_chain (hip/crs_chain.hip): one launch computes every slot of the window, evaluates it, replays the accept / reject
+    chain on the window's worst rows and lets later slots read what the chain says a worst row holds at their turn.  Against the
+    sequential statement orc_k_crs_chain: bit-exact trial points and mutations, f within 1e-10, the same records of what every
+    slot read from where.  Small populations (N barely above n) make every slot depend on MANY earlier slots of the same launch:
+    the in-kernel waiting, evaluation and resolution are what is tested.  The objective values of the rows are random, so the
+    chain has rejections, accepted mutations and values landing among the worst rows again."""
     P = O.port()
-    ring = K + 1
+    ring = 2 * K + 3
     first = 3 * ring + 2
-    mask = 255
-    ld, lb, ub, X, w0, jn0, pos0, last0 = _spec_inputs(n, N, ring, 77 + n, obj)
+    mask = 511
+    ld, lb, ub, X, w0, jn0, pos0, last0 = _spec_inputs(n, N, ring, 177 + n, obj)
+    oid = O.OBJ[obj]
     ent = [(first + a) % ring for a in range(ring)]
+    w = np.zeros(2 * n * ring, np.uint32)
     jn, pos, last = np.zeros(ring, np.int32), np.zeros(ring * n, np.int32), np.zeros(ring, np.int32)
     for a in range(ring):
+        w[ent[a] * 2 * n:(ent[a] + 1) * 2 * n] = w0[a * 2 * n:(a + 1) * 2 * n]
         jn[ent[a]], last[ent[a]] = jn0[a], last0[a]
         pos[ent[a] * n:(ent[a] + 1) * n] = pos0[a * n:(a + 1) * n]
-    rng = np.random.default_rng(11 + n)
-    # hazard list: K distinct rows, many of them sampled by later slots (N close to n: almost every row is sampled)
-    W = rng.permutation(N)[:K].astype(np.int64)
-    nW = K
-    P.orc_k_advance_slot_fwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int,
-                                         C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    P.orc_k_advance_slot_fwd.restype = None
+    # f of every row (the real objective), the K worst rows worst first with the reference's tie rule, the best row = i0 by decree
+    F = np.zeros(N)
+    P.orc_k_eval.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    P.orc_k_eval(oid, n, ld, X.ctypes.data, N, F.ctypes.data)
+    F[i0] = F.min() - 1.0
+    order = np.lexsort((np.arange(N), F))[::-1]
+    nW = min(K, N - 1)
+    W = order[:nW].astype(np.int64)
+    # make the chain interesting: pull the worst values close together so that trial values fall on both sides of them
+    Wf = F[W].copy()
+    fbest = float(F[i0])
+
+    class St(C.Structure):
+        _fields_ = [("fT", C.c_double), ("fM", C.c_double), ("t", C.c_int32), ("pad", C.c_int32)]
+    fwcap = 48
     nslot = mask + 1
-    TXr = np.zeros((nslot, ld))
-    maskr = np.zeros((K, 8), np.uint32)
-    q = [(first + a) & mask for a in range(K)]
-    for a in range(K):
-        P.orc_k_advance_slot_fwd(n, ld, X.ctypes.data, i0, int(jn0[a]), pos0[a * n:].ctypes.data, int(last0[a]), W.ctypes.data,
-                                 min(a, nW), TXr.ctypes.data, first, nslot, lb.ctypes.data, ub.ctypes.data, TXr[q[a]].ctypes.data,
-                                 maskr[a].ctypes.data)
-    dX, dlb, dub = DevBuf.from_array(X), DevBuf.from_array(lb), DevBuf.from_array(ub)
-    dj, dp, dl, dW = DevBuf.from_array(jn), DevBuf.from_array(pos), DevBuf.from_array(last), DevBuf.from_array(W)
-    chunks = L.nla_crs_advance_chunks(n, ld, variant)
-    dTX = DevBuf.from_array(np.zeros(nslot * ld))
-    dflags = DevBuf.from_array(np.zeros(nslot * chunks, np.uint32))
-    dticket = DevBuf.from_array(np.zeros(1, np.uint32))
-    dmask = DevBuf.from_array(np.full(K * 8, 0xFFFFFFFF, np.uint32))
-    dt0, dt1 = DevBuf.from_array(np.zeros(K, np.int32)), DevBuf(4 * K)
-    dgen = DevBuf.from_array(np.full(K, 1, np.uint32))
-    assert L.nla_k_crs_advance_fwd(n, ld, dX.ptr, i0, dj.ptr, dp.ptr, dl.ptr, ring, first, K, dW.ptr, nW, dt0.ptr, dt1.ptr, mask,
-                                   dlb.ptr, dub.ptr, dTX.ptr, variant, dflags.ptr, dgen.ptr, dmask.ptr, dticket.ptr, 0, None) == 0
-    assert L.nla_stream_sync(None) == 0
-    assert np.all(dt1.to_array(np.int32, K) == n)
-    TX = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)
-    m = dmask.to_array(np.uint32, K * 8).reshape(K, 8)
-    assert np.array_equal(m, maskr)
-    for a in range(K):
-        assert np.array_equal(TX[q[a], :n], TXr[q[a], :n]), a
-    assert K < 3 or maskr.any()                   # the case does exercise forwarding
-    # second launch: the even slots count as finished (tag 1 stays), the odd ones are recomputed under tag 2
-    t_in2 = np.where(np.arange(K) % 2 == 0, n, 0).astype(np.int32)
-    gen2 = np.where(np.arange(K) % 2 == 0, 1, 2).astype(np.uint32)
-    dt2, dgen2 = DevBuf.from_array(t_in2), DevBuf.from_array(gen2)
-    assert L.nla_k_crs_advance_fwd(n, ld, dX.ptr, i0, dj.ptr, dp.ptr, dl.ptr, ring, first, K, dW.ptr, nW, dt2.ptr, dt1.ptr, mask,
-                                   dlb.ptr, dub.ptr, dTX.ptr, variant, dflags.ptr, dgen2.ptr, dmask.ptr, dticket.ptr, chunks * K, None) == 0
-    assert L.nla_stream_sync(None) == 0
-    TX2 = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)
-    assert np.array_equal(TX2, TX)
-    m2 = dmask.to_array(np.uint32, K * 8).reshape(K, 8)
-    assert np.array_equal(m2[1::2], maskr[1::2])
+    TXr, TMr = np.zeros((nslot, ld)), np.zeros((nslot, ld))
+    str_ = (St * K)()
+    cntr, recr = np.zeros(K, np.uint32), np.zeros(K * fwcap, np.uint32)
+    P.orc_k_crs_chain.restype = None
+    P.orc_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    P.orc_k_crs_chain(oid, n, ld, X.ctypes.data, i0, fbest, jn.ctypes.data, pos.ctypes.data, last.ctypes.data, w.ctypes.data, ring, first, K,
+                      W.ctypes.data, Wf.ctypes.data, nW, mask, lb.ctypes.data, ub.ctypes.data, TXr.ctypes.data, TMr.ctypes.data,
+                      C.addressof(str_), cntr.ctypes.data, recr.ctypes.data, fwcap)
+    dX, dlb, dub, dw = DevBuf.from_array(X), DevBuf.from_array(lb), DevBuf.from_array(ub), DevBuf.from_array(w)
+    dj, dp, dl = DevBuf.from_array(jn), DevBuf.from_array(pos), DevBuf.from_array(last)
+    dW, dWf = DevBuf.from_array(W), DevBuf.from_array(Wf)
+    dTX, dTM = DevBuf.from_array(np.zeros(nslot * ld)), DevBuf.from_array(np.zeros(nslot * ld))
+    cb = L.nla_crs_chain_ctrl_bytes(256, 256)
+    dctrl = DevBuf.from_array(np.zeros(cb, np.uint8))
+    dst = DevBuf(C.sizeof(St) * K)
+    dcnt, drec = DevBuf.from_array(np.zeros(K, np.uint32)), DevBuf.from_array(np.zeros(K * fwcap, np.uint32))
+    for rep in range(2):                        # twice on the same control block: the ticket base carries over
+        assert L.nla_k_crs_chain(oid, n, ld, dX.ptr, i0, fbest, dj.ptr, dp.ptr, dl.ptr, dw.ptr, ring, first, K, dW.ptr, dWf.ptr, nW, 0, mask,
+                                 dlb.ptr, dub.ptr, dTX.ptr, dTM.ptr, dctrl.ptr, rep * K * L.nla_crs_chain_chunks(n, ld), dst.ptr, dcnt.ptr,
+                                 drec.ptr, fwcap, None) == 0
+        assert L.nla_stream_sync(None) == 0
+        raw = dst.to_array(np.uint8, C.sizeof(St) * K)
+        st = np.frombuffer(raw.tobytes(), dtype=[("fT", "f8"), ("fM", "f8"), ("t", "i4"), ("pad", "i4")])
+        fTr = np.array([str_[a].fT for a in range(K)])
+        fMr = np.array([str_[a].fM for a in range(K)])
+        assert np.all(st["t"] == n)
+        scale = np.abs(np.concatenate([fTr, fMr])).mean()
+        cnt, rec = dcnt.to_array(np.uint32, K), drec.to_array(np.uint32, K * fwcap).reshape(K, fwcap)
+        TX = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)
+        TM = dTM.to_array(np.float64, nslot * ld).reshape(nslot, ld)
+        for a in range(K):
+            qa = (first + a) & mask
+            assert cnt[a] == cntr[a], (a, cnt[a], cntr[a])
+            k = min(int(cnt[a]), fwcap)
+            assert sorted(rec[a, :k].tolist()) == sorted(recr.reshape(K, fwcap)[a, :k].tolist()), a
+            assert np.array_equal(TX[qa, :n], TXr[qa, :n]), a
+            assert np.array_equal(TM[qa, :n], TMr[qa, :n]), a
+        assert close(st["fT"], fTr, scale) and close(st["fM"], fMr, scale)
+    kinds = (recr >> 16) & 3
+    assert K < 8 or (cntr.sum() > 0 and (kinds[recr > 0] > 0).any())      # the case does exercise reading from producers
 
 
 @pytest.mark.parametrize("obj,n,N,K,i0,variant", [("rastrigin", 10, 100, 7, 0, 0), ("rastrigin", 10, 11, 5, 10, 0),
