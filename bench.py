@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--max-spec", type=int, default=0)
     ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="crs: skip the other sizes / workloads / end-to-end call (tuning runs)")
     ap.add_argument("--cpu-sample-pop", type=int, default=0)
     ap.add_argument("--cpu-sample-trials", type=int, default=400)
     a = ap.parse_args()
@@ -358,7 +359,7 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         "init": {"evals": pop, "seconds": t_init, "init_evals_per_s": pop / t_init},
         "final_result": int(fret), "minf": m["minf"],
     }
-    if world == 1 and (n, pop, a.obj) == (4096, 100000, "griewank"):
+    if world == 1 and (n, pop, a.obj) == (4096, 100000, "griewank") and not a.headline_only:
         # north_star asks for n in {64, 512, 4096}: the two smaller sizes (512 = BASELINE config 2), shorter runs, same contract
         out["other_sizes"] = {}
         for n2 in (512, 64):
@@ -383,7 +384,7 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         out["gens_to_ftol"] = gens_to_ftol()
     except Exception as e:        # the headline line must still be printed
         out["gens_to_ftol"] = {"error": repr(e)}
-    if world == 1 and (n, pop, a.obj) == (4096, 100000, "griewank"):
+    if world == 1 and (n, pop, a.obj) == (4096, 100000, "griewank") and not a.headline_only:
         # SURVEY.md §8d defines the metric on nlopt_optimize(): one whole call (population initialisation included) on record
         try:
             out["nlopt_optimize_end_to_end"] = crs_end_to_end(nlopt_amd, a.obj, n, pop, a.seed, 20000)

@@ -494,7 +494,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         return NLOPT_INVALID_ARGS;
     }
     memset(pb, 0, sizeof *pb);
-    pb->forward = 1;
+    pb->forward = n >= 2048;
     pb->n = n; pb->N = N; pb->lb = lb; pb->ub = ub; pb->f = f; pb->f_data = f_data; pb->stop = stop;
     pb->obj = nlopt_amd_objective_id(f);
     if (opt) {
@@ -502,7 +502,9 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         pb->stats = &opt->stats;
         pb->max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
         pb->window_factor = nlopt_get_param(opt, "amd_window_factor", 0);
-        pb->forward = nlopt_get_param(opt, "amd_forward", 1) != 0;
+        /* the device-resolved windows pay a few microseconds per block for the in-kernel chain: worth it where a trial's gather
+         * takes longer than that (n >= 2048: 33 MB per trial) */
+        pb->forward = nlopt_get_param(opt, "amd_forward", n >= 2048 ? 1 : 0) != 0;
         if (getenv("NLA_CRS_FORWARD")) pb->forward = atoi(getenv("NLA_CRS_FORWARD"));                 /* A/B switch for the bench */
         if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
     }

@@ -142,8 +142,10 @@ typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
 void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                      const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                      const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
-                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap)
+                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with)
 {
+    /* decide_with != NULL: the chain's decisions are taken on THESE f values (a device run's, which differ from this file's in the
+     * last bits: enough to flip a comparison between two nearly equal values) — everything else is computed here as always */
     enum { XCAP = 32 };
     uint32_t next = 0, wp = 0, nextra = 0, *rowstate = (uint32_t *) calloc((size_t) (nW > 0 ? nW : 1), sizeof(uint32_t));
     int halt = 0;
@@ -194,8 +196,9 @@ void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double
             for (uint32_t e = 0; e < nextra; ++e)
                 if (rw < 0 || xf[e] > fw || (xf[e] == fw && xrow[e] > rw)) { fw = xf[e]; rw = xrow[e]; xi = (int) e; }
             if (rw < 0) { halt = 1; break; }
-            if (status[j].fT < fw) { kind = 1; fnew = status[j].fT; }
-            else if (status[j].fM < fw) { kind = 2; fnew = status[j].fM; }
+            const orc_slot_status *dj = decide_with ? decide_with + j : status + j;
+            if (dj->fT < fw) { kind = 1; fnew = dj->fT; }
+            else if (dj->fM < fw) { kind = 2; fnew = dj->fM; }
             if (kind) {
                 if (xi >= 0) { xf[xi] = xf[nextra - 1]; xrow[xi] = xrow[nextra - 1]; --nextra; }
                 else { rowstate[wp] = 1u | ((uint32_t) kind << 1) | (j << 3); ++wp; }

@@ -175,16 +175,10 @@ def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, 
         _fields_ = [("fT", C.c_double), ("fM", C.c_double), ("t", C.c_int32), ("pad", C.c_int32)]
     fwcap = 48
     nslot = mask + 1
-    TXr, TMr = np.zeros((nslot, ld)), np.zeros((nslot, ld))
-    str_ = (St * K)()
-    cntr, recr = np.zeros(K, np.uint32), np.zeros(K * fwcap, np.uint32)
     P.orc_k_crs_chain.restype = None
     P.orc_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    P.orc_k_crs_chain(oid, n, ld, X.ctypes.data, i0, fbest, jn.ctypes.data, pos.ctypes.data, last.ctypes.data, w.ctypes.data, ring, first, K,
-                      W.ctypes.data, Wf.ctypes.data, nW, mask, lb.ctypes.data, ub.ctypes.data, TXr.ctypes.data, TMr.ctypes.data,
-                      C.addressof(str_), cntr.ctypes.data, recr.ctypes.data, fwcap)
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     dX, dlb, dub, dw = DevBuf.from_array(X), DevBuf.from_array(lb), DevBuf.from_array(ub), DevBuf.from_array(w)
     dj, dp, dl = DevBuf.from_array(jn), DevBuf.from_array(pos), DevBuf.from_array(last)
     dW, dWf = DevBuf.from_array(W), DevBuf.from_array(Wf)
@@ -200,9 +194,19 @@ def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, 
         assert L.nla_stream_sync(None) == 0
         raw = dst.to_array(np.uint8, C.sizeof(St) * K)
         st = np.frombuffer(raw.tobytes(), dtype=[("fT", "f8"), ("fM", "f8"), ("t", "i4"), ("pad", "i4")])
+        assert np.all(st["t"] == n)
+        # the sequential statement, its accept / reject decisions taken on the DEVICE's f values (they differ from the host's in the
+        # last bits; with N barely above n the trial points are nearly equal and so are their f: a comparison could go either way)
+        dev_status = (St * K)()
+        C.memmove(dev_status, raw.tobytes(), C.sizeof(St) * K)
+        TXr, TMr = np.zeros((nslot, ld)), np.zeros((nslot, ld))
+        str_ = (St * K)()
+        cntr, recr = np.zeros(K, np.uint32), np.zeros(K * fwcap, np.uint32)
+        P.orc_k_crs_chain(oid, n, ld, X.ctypes.data, i0, fbest, jn.ctypes.data, pos.ctypes.data, last.ctypes.data, w.ctypes.data, ring, first, K,
+                          W.ctypes.data, Wf.ctypes.data, nW, mask, lb.ctypes.data, ub.ctypes.data, TXr.ctypes.data, TMr.ctypes.data,
+                          C.addressof(str_), cntr.ctypes.data, recr.ctypes.data, fwcap, C.addressof(dev_status))
         fTr = np.array([str_[a].fT for a in range(K)])
         fMr = np.array([str_[a].fM for a in range(K)])
-        assert np.all(st["t"] == n)
         scale = np.abs(np.concatenate([fTr, fMr])).mean()
         cnt, rec = dcnt.to_array(np.uint32, K), drec.to_array(np.uint32, K * fwcap).reshape(K, fwcap)
         TX = dTX.to_array(np.float64, nslot * ld).reshape(nslot, ld)
