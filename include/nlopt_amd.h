@@ -216,7 +216,8 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
  * (crs.c:139-146, K5) for the slots completed by the preceding nla_k_crs_advance (same window):
  * fT_ring[q] = f(TX[q]); TM[q] = clamp(best*(1+w) - w*TX[q]), w from the words of block b+1
  * (words_ring entry (b+1) % ring_blocks); fM_ring[q] = f(TM[q]); status[a] = (fT, fM, t) of
- * window slot a for all a < K.  obj < 0: no evaluation / no mutation (host-callback mode). */
+ * window slot a for all a < K.  obj == -1: no evaluation / no mutation (host-callback mode); obj == -2: the mutation only (the
+ * objective is a user-supplied kernel the caller runs on TX / TM afterwards). */
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
                      const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                      const int32_t *t_in, const int32_t *t_out, int slot_mask,
@@ -262,7 +263,8 @@ int nla_k_isres_init(int n, int ld, const double *lb, const double *ub, const ui
 
 /* replaces: f and the constraint penalties of every candidate, isres.c:138-166.  con[0..m) are the
  * inequality, con[m..m+p) the equality constraints.  PEN = sum max(g,0)^2 + sum h^2 in constraint
- * order, GPEN = the inequality part, FEAS = every g <= tol and |h| <= tol. */
+ * order, GPEN = the inequality part, FEAS = every g <= tol and |h| <= tol.  obj < 0: the constraint part only (F untouched: the
+ * objective is a user-supplied kernel, nlopt_amd_set_min_device_objective). */
 int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t pop, int m, int p, const nla_dev_constraint *con,
                      double *F, double *PEN, double *GPEN, int32_t *FEAS, void *stream);
 

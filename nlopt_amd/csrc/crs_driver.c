@@ -236,7 +236,7 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     if (!S) { *ret_out = NLOPT_OUT_OF_MEMORY; return NULL; }
     rs = &S->rs;
     S->pb = *pb;
-    S->host_eval = pb->obj < 0;
+    S->host_eval = pb->obj == -1;               /* (-2: a user-supplied device kernel, evaluated by the engine) */
     S->Kmax = pb->max_spec > 0 ? pb->max_spec : 256;
     /* measured (MI355X, pop 1e5): the chain consumes the same number of blocks per pass whether the window is 1.5x or 12x
      * that number wide — the slots behind only add workgroups, status records and hazard rows: 1.5 is as fast as 3 at
@@ -244,11 +244,11 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     S->kmult = pb->window_factor > 0 ? pb->window_factor : 1.5;
     if (S->Kmax > 1024) S->Kmax = 1024;
     if (S->host_eval) S->Kmax = 1;
-    S->forward = pb->forward && ops->chain && !S->host_eval && S->Kmax > 1;
+    S->forward = pb->forward && ops->chain && pb->obj >= 0 && S->Kmax > 1;
     if (S->forward && S->Kmax > 256) S->Kmax = 256;
-    /* measured (MI355X, n = 4096, N = 1e5): 24.5 us per slot at 130-200 slots per launch, 35 us at 256 (every slot then has ~10
-     * picks among the worst rows ahead of it) */
-    if (S->forward && pb->max_spec <= 0 && S->Kmax > 160) S->Kmax = 160;
+    /* measured (MI355X, n = 4096, N = 1e5): 28 us per slot at 48 slots per launch, 32 at 128, 40 at 256 (a slot deep in the window
+     * has many picks among the worst rows ahead of it, each one a wait); 48 = 6 full rounds of workgroups on 256 CUs */
+    if (S->forward && pb->max_spec <= 0 && S->Kmax > 48) S->Kmax = 48;
     S->runlen = 4.0;
     rs->ops = ops; rs->e = e; rs->pb = &S->pb; rs->x = x; rs->minf = minf;
     rs->need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);

@@ -35,7 +35,10 @@ typedef struct {
 #define CHAIN_FWCAP 48                     /* records per slot (crs_driver.c FWCAP) */
 
 struct nla_crs_hip_engine {
-    int n, ld, obj;
+    int n, ld, obj;                /* obj: compiled-in objective id; -1: host callback; -2: user-supplied kernel (user, sign) */
+    nla_userobj *user; double sign;
+    int32_t *d_list, *h_list;      /* user kernel: the window's slot rows */
+    double *h_fTM;                 /* user kernel: fT / fM rings read back (2 x KCAP) */
     int64_t N;
     int B;                         /* blocks per batch; the block ring holds 2B */
     int variant;                   /* advance-kernel tiling override (0 = automatic) */
@@ -116,6 +119,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_initwords);
     nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
     nla_dev_free(e->d_up); nla_dev_free(e->d_tout); nla_dev_free(e->d_status);
+    nla_dev_free(e->d_list); nla_host_free(e->h_list); nla_host_free(e->h_fTM);
     nla_dev_free(e->d_ctrl); nla_dev_free(e->d_Wf); nla_host_free(e->h_fwcnt); nla_host_free(e->h_fwrec);
     nla_host_free(e->h_up); nla_host_free(e->h_status);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
@@ -172,6 +176,12 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * KCAP);
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
+    if (obj == -2) {
+        e->d_list = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
+        e->h_list = (int32_t *) nla_host_malloc(sizeof(int32_t) * KCAP);
+        e->h_fTM = (double *) nla_host_malloc(sizeof(double) * 2 * KCAP);
+        if (!e->d_list || !e->h_list || !e->h_fTM) goto fail;
+    }
     if (obj >= 0) {
         e->d_ctrl = nla_dev_malloc(nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX));
         e->d_Wf = (double *) nla_dev_malloc(sizeof(double) * CHAIN_KMAX);
@@ -224,6 +234,7 @@ static int op_init_population(void *ve, const double *x0, double *F)
     /* row 0 = the caller's starting guess (crs.c:204) */
     if (nla_memcpy_h2d(e->d_X, x0, sizeof(double) * (size_t) n, e->main)) { nla_event_destroy(ev); FAIL(e, "H2D x0 failed"); }
     if (e->obj >= 0 && nla_k_eval(e->obj, n, e->ld, e->d_X, 1, e->d_F, e->main)) { nla_event_destroy(ev); FAIL(e, "eval launch failed"); }
+    if (e->obj == -2 && nla_userobj_eval_rows(e->user, n, e->ld, 1, e->d_X, e->d_F, NULL, e->sign, e->main)) { nla_event_destroy(ev); FAIL(e, "user objective launch failed"); }
     for (r0 = first; r0 < last; r0 += rows_per_chunk) {
         int64_t nr = last - r0 < rows_per_chunk ? last - r0 : rows_per_chunk;
         /* the words buffer is reused: the generator must not overwrite it before the previous
@@ -235,18 +246,19 @@ static int op_init_population(void *ve, const double *x0, double *F)
             nla_event_destroy(ev); FAIL(e, "MT stream fill failed (init)");
         }
         if (nla_event_record(ev, e->rng) || nla_stream_wait_event(e->main, ev)) { nla_event_destroy(ev); FAIL(e, "event failed"); }
-        if (nla_k_crs_init_rows(e->obj, n, e->ld, e->d_lb, e->d_ub, e->d_initwords, r0, nr, e->d_X, e->d_F, e->main)) {
+        if (nla_k_crs_init_rows(e->obj >= 0 ? e->obj : -1, n, e->ld, e->d_lb, e->d_ub, e->d_initwords, r0, nr, e->d_X, e->d_F, e->main) ||
+            (e->obj == -2 && nla_userobj_eval_rows(e->user, n, e->ld, nr, e->d_X + (size_t) r0 * (size_t) e->ld, e->d_F + r0, NULL, e->sign, e->main))) {
             nla_event_destroy(ev); FAIL(e, "init kernel launch failed");
         }
     }
     if (world > 1) {
         if (nla_comm_allgather_dev(e->comm, e->d_X + (size_t) first * (size_t) e->ld, e->d_X + (size_t) e->ld,
                                    sizeof(double) * (size_t) per * (size_t) e->ld, e->main) ||
-            (e->obj >= 0 && nla_comm_allgather_dev(e->comm, e->d_F + first, e->d_F + 1, sizeof(double) * (size_t) per, e->main))) {
+            (e->obj != -1 && nla_comm_allgather_dev(e->comm, e->d_F + first, e->d_F + 1, sizeof(double) * (size_t) per, e->main))) {
             nla_event_destroy(ev); FAIL(e, "all-gather of the initial population failed: %s", nlopt_amd_comm_error(e->comm));
         }
     }
-    if (e->obj >= 0) {
+    if (e->obj != -1) {
         if (nla_memcpy_d2h(F, e->d_F, sizeof(double) * (size_t) e->N, e->main)) { nla_event_destroy(ev); FAIL(e, "D2H F failed"); }
     }
     {
@@ -325,7 +337,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         const uint64_t b = first_block + (uint64_t) a;
         t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
     }
-    if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload) {
+    if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload && e->obj != -2) {
         /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
          * front of the pass */
         if (e->npending) {
@@ -355,8 +367,22 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     CK(e, nla_k_crs_finish(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                            d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
 launched:
+    if (e->obj == -2) {
+        /* the objective is the user's kernel: f of every window slot's trial point and mutation in two launches over the slot
+         * rows (rows of unfinished slots hold partial sums: their values are never looked at), then the rings come back */
+        for (int a = 0; a < K; ++a) e->h_list[a] = -(int32_t) (((first_block + (uint64_t) a) & (KCAP - 1)) + 1);
+        CK(e, nla_memcpy_h2d(e->d_list, e->h_list, sizeof(int32_t) * (size_t) K, e->main));
+        CK(e, nla_userobj_evalgrad_list(e->user, n, e->ld, K, e->d_list, e->d_TX, e->d_fT, NULL, e->sign, e->main));
+        CK(e, nla_userobj_evalgrad_list(e->user, n, e->ld, K, e->d_list, e->d_TM, e->d_fM, NULL, e->sign, e->main));
+        CK(e, nla_memcpy_d2h(e->h_fTM, e->d_fT, sizeof(double) * 2 * KCAP, e->main));
+    }
     CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * (size_t) K, e->main));
     CK(e, nla_stream_sync(e->main));
+    if (e->obj == -2)
+        for (int a = 0; a < K; ++a) {
+            const size_t q = (size_t) ((first_block + (uint64_t) a) & (KCAP - 1));
+            e->h_status[a].fT = e->h_fTM[q]; e->h_status[a].fM = e->h_fTM[KCAP + q];
+        }
 have_status:
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
 
@@ -488,6 +514,8 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
                                     nla_stopping *stop, int population, nla_crs_problem *pb, nla_crs_hip_engine **eout)
 {
     int64_t N = population ? (int64_t) population : 10 * ((int64_t) n + 1);     /* crs.c:172-179 */
+    nla_userobj *user = NULL;
+    double sign = 1.;
     *eout = NULL;
     if (N < n + 1) {                                                            /* crs.c:180-184 */
         nla_stop_msg(stop, "population %d should be >= dimension + 1 = %d", (int) N, n + 1);
@@ -496,7 +524,12 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
     memset(pb, 0, sizeof *pb);
     pb->forward = n >= 2048;
     pb->n = n; pb->N = N; pb->lb = lb; pb->ub = ub; pb->f = f; pb->f_data = f_data; pb->stop = stop;
-    pb->obj = nlopt_amd_objective_id(f);
+    {
+        nla_evaluator ev;
+        nla_evaluator_resolve(&ev, opt, f, f_data);
+        pb->obj = ev.kind == NLA_EVAL_DEVICE ? ev.obj : (ev.kind == NLA_EVAL_USER ? -2 : -1);
+        user = ev.user; sign = ev.sign;
+    }
     if (opt) {
         pb->trace = opt->trace; pb->trace_cap = opt->trace_cap; pb->trace_len = &opt->trace_len;
         pb->stats = &opt->stats;
@@ -517,6 +550,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
         return NLOPT_OUT_OF_MEMORY;
     }
+    (*eout)->user = user; (*eout)->sign = sign;
     if (opt) { (*eout)->variant = (int) nlopt_get_param(opt, "amd_gather_variant", 0); (*eout)->comm = opt->comm; }
     return NLOPT_SUCCESS;
 }

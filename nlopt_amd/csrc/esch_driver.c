@@ -18,7 +18,8 @@
 #include <string.h>
 
 typedef struct {
-    int n, ld, obj;
+    int n, ld, obj;                /* obj: compiled-in objective id, -2: user-supplied kernel (ev), -1: host callback */
+    nla_evaluator ev;
     int64_t np, no, P;
     void *st;
     nla_mtstream *mts;
@@ -88,8 +89,9 @@ static int init_rows(esch_dev *d, const double *x0)
 static int evaluate(esch_dev *d, int cur, int64_t i0, int64_t count)
 {
     ECK(d, nla_k_esch_gather_rows(d->n, d->ld, d->d_slot[cur], i0, count, d->d_R, d->d_G, d->st));
-    if (d->obj >= 0) {
-        ECK(d, nla_k_eval(d->obj, d->n, d->ld, d->d_G, count, d->d_F, d->st));
+    if (d->obj != -1) {
+        if (d->obj >= 0) ECK(d, nla_k_eval(d->obj, d->n, d->ld, d->d_G, count, d->d_F, d->st));
+        else ECK(d, nla_userobj_eval_rows(d->ev.user, d->n, d->ld, count, d->d_G, d->d_F, NULL, d->ev.sign, d->st));
         ECK(d, nla_memcpy_d2h(d->h_fit + i0, d->d_F, sizeof(double) * (size_t) count, d->st));
     } else
         ECK(d, nla_memcpy_d2h(d->h_G, d->d_G, sizeof(double) * (size_t) count * (size_t) d->ld, d->st));
@@ -110,7 +112,8 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     if (D.np < 1 || D.no < 1) { nla_stop_msg(stop, "populations %d, %d are too small", (int) D.np, (int) D.no); return NLOPT_INVALID_ARGS; }
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
     D.P = D.np + D.no; D.n = n; D.ld = (n + 1) & ~1;
-    D.obj = nlopt_amd_objective_id(f);
+    nla_evaluator_resolve(&D.ev, opt, f, f_data);
+    D.obj = D.ev.kind == NLA_EVAL_DEVICE ? D.ev.obj : (D.ev.kind == NLA_EVAL_USER ? -2 : -1);
     if (opt && nlopt_get_param(opt, "amd_host_eval", 0) != 0) D.obj = -1;
     if ((uint64_t) D.no * (uint64_t) n >= (1ULL << 31)) { nla_stop_msg(stop, "nlopt_amd: ESCH with offspring x dimension >= 2^31 is not supported"); return NLOPT_INVALID_ARGS; }
     total = (int) (((unsigned) D.no * (unsigned) n) / 10);                          /* esch.c:207 */
@@ -134,7 +137,7 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.d_out = (int64_t *) nla_dev_malloc(2 * sizeof(int64_t));
     D.d_sscratch = nla_dev_malloc(D.sscratch_bytes);
     D.h_fit = (double *) nla_host_malloc(sizeof(double) * (size_t) D.P);
-    D.h_G = (double *) nla_host_malloc(sizeof(double) * (D.obj >= 0 ? (size_t) D.ld : (size_t) (D.np > D.no ? D.np : D.no) * (size_t) D.ld));
+    D.h_G = (double *) nla_host_malloc(sizeof(double) * (D.obj != -1 ? (size_t) D.ld : (size_t) (D.np > D.no ? D.np : D.no) * (size_t) D.ld));
     if (!D.d_lb || !D.d_ub || !D.d_R || !D.d_G || !D.d_F || !D.d_fit[0] || !D.d_fit[1] || !D.d_slot[0] || !D.d_slot[1] || !D.d_v || !D.d_vatt ||
         !D.d_last || !D.d_out || !D.d_sscratch || !D.h_fit || !D.h_G) {
         nla_stop_msg(stop, "nlopt_amd: could not create the ESCH device state (out of device memory?)");
@@ -156,7 +159,7 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 
     /* best point / stop tests of one evaluated candidate, esch.c:173-182 = :227-237 */
 #define AFTER_EVAL(idx, knd, off) do { \
-        if (D.obj < 0) D.h_fit[idx] = f((unsigned) n, D.h_G + (size_t) ((idx) - (off)) * (size_t) D.ld, NULL, f_data); \
+        if (D.obj == -1) D.h_fit[idx] = f((unsigned) n, D.h_G + (size_t) ((idx) - (off)) * (size_t) D.ld, NULL, f_data); \
         const double fv_ = D.h_fit[idx]; \
         ++*stop->nevals_p; \
         if (st) { if ((knd) == 0) ++st->evals_init; else ++st->evals_trial; } \

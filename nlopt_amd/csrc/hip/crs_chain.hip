@@ -33,6 +33,14 @@
  * workgroups hold earlier tickets and are therefore running or done, and the front slot never waits.
  *
  * Roofline: HBM, 8 n (n+1) algorithmic bytes per trial; the evaluation adds 24 n.
+ *
+ * Measured on MI355X (n = 4096, N = 1e5, Griewank; gpurun_out/r02g, r02h): 28 us per slot at 48 slots per launch (4.8 TB/s),
+ * 32 us at 128, 40 us at 256 — a slot deeper in the window has more picks among the worst rows ahead of it (0.04 per row) and
+ * each of them is a wait; 34.6 k evals/s at 48 slots against 31.0 k for the conservative passes of crs_kernels.hip.
+ * Tried and dropped: agent-coherent (sc1) accesses or uncached TX / TM instead of the release / acquire fences, write-through
+ * stores of the finished chunk, a back-off in the polling loops — each within 2 %.  What does matter: the U rows in flight must
+ * stay in registers; any data-dependent branch beyond the one below inside the unrolled load loop (a `continue`, a conditional
+ * fence) sends them to scratch (1.5 KB per lane) and costs 45 %.
  */
 #include "crs_common.h"
 #include "../../../include/nlopt_amd.h"
@@ -50,30 +58,8 @@ struct chain_ctrl {
 #define NLA_KA_MAX 96                    /* list length that still travels as kernel arguments */
 struct chain_lists { int inl; int64_t W[NLA_KA_MAX]; double Wf[NLA_KA_MAX]; };
 
-/* Everything the workgroups of one launch tell each other goes through agent-coherent accesses (relaxed atomics at agent scope:
- * they are served by the memory side all XCDs share, not by an XCD's own L2 lines), issued in program order and completed
- * (s_waitcnt) before the access that publishes them.  That keeps the heavy fences (L2 write-back / invalidate) off the
- * paths that run thousands of times per launch. */
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ldd_agent(const double *p)
-{
-    return __longlong_as_double((long long) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void std_agent(double *p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <int VEC> __device__ __forceinline__ typename VecT<VEC>::T ldv_agent(const char *p);
-template <> __device__ __forceinline__ double ldv_agent<1>(const char *p) { return ldd_agent(reinterpret_cast<const double *>(p)); }
-template <> __device__ __forceinline__ double2 ldv_agent<2>(const char *p)
-{
-    double2 r;
-    r.x = ldd_agent(reinterpret_cast<const double *>(p));
-    r.y = ldd_agent(reinterpret_cast<const double *>(p) + 1);
-    return r;
-}
 
 /* crs_trial's decisions for the evaluated slots at the front of the unresolved part (one thread, under the lock) */
 __device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate, const double *fv, int K, int nW,
@@ -81,16 +67,17 @@ __device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate
 {
     for (;;) {
         if (atomicCAS(&c->lock, 0u, 1u) != 0u) return;          /* the holder re-checks after it lets go */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       /* the previous holder's state (once per lock acquisition) */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         uint32_t j = c->next;
         while (j < (uint32_t) K && !c->halt && ld_agent(&evald[j])) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             /* the current worst: the next untouched row of the list, or a value that landed among them */
             double fw = -HUGE_VAL; int64_t rw = -1; int xi = -1;
             if (c->wp < (uint32_t) nW) { fw = Wf[c->wp]; rw = W[c->wp]; }
             for (uint32_t e = 0; e < c->nextra; ++e)
                 if (rw < 0 || c->xf[e] > fw || (c->xf[e] == fw && c->xrow[e] > rw)) { fw = c->xf[e]; rw = c->xrow[e]; xi = (int) e; }
             if (rw < 0) { c->halt = 1; break; }                 /* beyond the rows this launch knows */
-            const double fT = ldd_agent(&fv[2 * j]), fM = ldd_agent(&fv[2 * j + 1]);
+            const double fT = fv[2 * j], fM = fv[2 * j + 1];
             int kind = 0;
             double fnew = 0;
             if (fT < fw) { kind = 1; fnew = fT; }               /* crs.c:135 */
@@ -107,7 +94,7 @@ __device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate
                 if (fnew < f_best || (fnew == f_best && rw < i0)) c->halt = 1;   /* a new best: everything behind started from the old one */
             }
             j += (kind == 1) ? 1u : 2u;
-            stores_done();                                       /* the row's state before the chain position that implies it */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             st_agent(&c->next, j);
         }
         if (c->halt) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); st_agent(&c->next, (uint32_t) K + 2u); }
@@ -214,12 +201,13 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
                      * (rowstate[j]) or has passed every block before this slot without touching it */
                     const int j = (int) (-r - 1);
                     uint32_t rs;
-                    for (int spin = 0;; ++spin) {
+                    for (;;) {
                         rs = ld_agent(&rowstate[j]);
                         if (rs) break;
                         if (ld_agent(&ctrl->next) >= (uint32_t) a) { rs = ld_agent(&rowstate[j]); break; }
-                        if (spin < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);   /* back off: many wait on one line */
+                        __builtin_amdgcn_s_sleep(4);
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     /* a writer at or behind this slot's own block does not count: the row is read as it is before that */
                     int pj = 0, kind = 0;                    /* kind 0: the row as it is (no block before this one wrote it) */
                     if (rs && (int) (rs >> 3) < a) {
@@ -231,7 +219,6 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
                         const uint32_t k = atomicAdd(&s_nrec, 1u);
                         if ((int) k < fwcap) fwrec[(size_t) a * (size_t) fwcap + k] = (uint32_t) j | ((uint32_t) pj << 8) | ((uint32_t) kind << 16);
                     }
-                    if (kind) { v[u] = ldv_agent<VEC>(rowp + lane_off); continue; }   /* another workgroup's point: coherent read */
                 }
                 v[u] = *reinterpret_cast<const V *>(rowp + lane_off);
             }
@@ -265,43 +252,44 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         const double s = 2.0 / n;
         if constexpr (VEC == 1) {
             double a0 = *reinterpret_cast<double *>(&acc);
-            std_agent(accrow, nla_clamp_box(a0 * s, lb[col], ub[col]));
+            *accrow = nla_clamp_box(a0 * s, lb[col], ub[col]);
         } else {
-            double2 a2 = *reinterpret_cast<double2 *>(&acc);
-            std_agent(accrow, nla_clamp_box(a2.x * s, lb[col], ub[col]));
-            std_agent(accrow + 1, nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]));
+            double2 a2 = *reinterpret_cast<double2 *>(&acc), r2;
+            r2.x = nla_clamp_box(a2.x * s, lb[col], ub[col]);
+            r2.y = nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]);
+            *reinterpret_cast<double2 *>(accrow) = r2;
         }
-        stores_done();
     }
     /* this chunk of the trial point is final; the workgroup that completes the slot evaluates it */
     __syncthreads();
     if (threadIdx.x == 0) {
         if (chunk == 0) fwcnt[a] = s_nrec;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         s_last = (atomicAdd(&done[a], 1u) == (uint32_t) (chunks - 1));
     }
     __syncthreads();
     if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
         const int tid = threadIdx.x;
         const double *x = TX + (size_t) q * (size_t) ld;
         const double *xb = X + (size_t) i0 * (size_t) ld;
         const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n;
         double *m = TM + (size_t) q * (size_t) ld;
-        auto getx = [&](int i) { return ldd_agent(x + i); };             /* chunks written by other workgroups */
+        auto getx = [&](int i) { return __builtin_nontemporal_load(x + i); };
         const double fT = nla_block_objective<OBJ, WAVES>(n, getx, scratch);
         auto mut = [&](int i) {        /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
             const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
             const double wv = nla_urand_from(0., 1., ww.x, ww.y);
             return nla_clamp_box(xb[i] * (1 + wv) - wv * getx(i), lb[i], ub[i]);
         };
-        for (int i = tid; i < n; i += WAVES * 64) std_agent(m + i, mut(i));
+        for (int i = tid; i < n; i += WAVES * 64) m[i] = mut(i);
         const double fM = nla_block_objective<OBJ, WAVES>(n, mut, scratch);
-        stores_done();
         __syncthreads();
         if (tid == 0) {
             status[a].fT = fT; status[a].fM = fM; status[a].t = n; status[a].pad = 0;
-            std_agent(&fv[2 * a], fT); std_agent(&fv[2 * a + 1], fM);
-            stores_done();
+            fv[2 * a] = fT; fv[2 * a + 1] = fM;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             st_agent(&evald[a], 1u);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             chain_resolve(ctrl, evald, rowstate, fv, K, nW, W, Wf, f_best, i0);

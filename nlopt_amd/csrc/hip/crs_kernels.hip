@@ -319,7 +319,7 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
         if (tid == 0) { status[a].fT = f; status[a].t = t1; }
     } else {
         double f = 0;
-        if (OBJ >= 0) {
+        if (OBJ >= 0 || OBJ == -2) {            /* -2: mutate only — the objective is a user-supplied kernel run by the caller */
             if (newly) {
                 const double *xb = X + (size_t) i0 * (size_t) ld;
                 const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n;
@@ -330,9 +330,11 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
                     return nla_clamp_box(xb[i] * (1 + wv) - wv * x[i], lb[i], ub[i]);
                 };
                 for (int i = tid; i < n; i += NLA_FIN_WAVES * 64) m[i] = mut(i);
-                f = nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, mut, scratch);
-                if (tid == 0) fM_ring[q] = f;
-            } else if (t1 == n) f = fM_ring[q];
+                if (OBJ >= 0) {
+                    f = nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, mut, scratch);
+                    if (tid == 0) fM_ring[q] = f;
+                }
+            } else if (t1 == n && OBJ >= 0) f = fM_ring[q];
         }
         if (tid == 0) status[a].fM = f;
     }
@@ -559,7 +561,10 @@ static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0
     if (K <= 0) return 0;
     const dim3 grid((unsigned) (2 * K)), block(NLA_FIN_WAVES * 64);
     hipStream_t st = (hipStream_t) stream;
-    if (obj < 0) {
+    if (obj == -2) {
+        hipLaunchKernelGGL((crs_finish_kernel<-2>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
+                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L);
+    } else if (obj < 0) {
         hipLaunchKernelGGL((crs_finish_kernel<-1>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
                            first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L);
     } else {

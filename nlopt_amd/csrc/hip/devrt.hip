@@ -21,7 +21,6 @@ extern "C" void *nla_dev_malloc(size_t bytes)
     return p;
 }
 extern "C" void nla_dev_free(void *p) { if (p) (void) hipFree(p); }
-
 extern "C" void *nla_host_malloc(size_t bytes)
 {
     void *p = nullptr;

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void isres_eval_kernel(int n, int ld, const do
     const int64_t k = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= pop) return;
     const double *x = X + (size_t) k * (size_t) ld;
-    const double f = nla_wave_objective<OBJ>(n, [&](int i) { return x[i]; });
+    double f = 0;
+    if constexpr (OBJ >= 0) f = nla_wave_objective<OBJ>(n, [&](int i) { return x[i]; });   /* OBJ < 0: f comes from a user kernel */
     double pen = 0, gpen = 0;
     int feas = 1;
     const int mp = m + p;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void isres_eval_kernel(int n, int ld, const do
         }
     }
     if (p == 0) gpen = pen;
-    if (lane == 0) { F[k] = f; PEN[k] = pen; GPEN[k] = gpen; FEAS[k] = feas; }
+    if (lane == 0) { if (OBJ >= 0) F[k] = f; PEN[k] = pen; GPEN[k] = gpen; FEAS[k] = feas; }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -715,7 +716,8 @@ extern "C" int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t
     const dim3 grid((unsigned) ((pop + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t) stream;
 #define CALL(O) hipLaunchKernelGGL((isres_eval_kernel<O>), grid, block, 0, st, n, ld, X, pop, m, p, con, F, PEN, GPEN, FEAS)
-    NLA_OBJ_DISPATCH(obj, CALL)
+    if (obj < 0) { CALL(-1); }                 /* constraints only: f by a user-supplied kernel (userobj.c) */
+    else NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     NLA_LAUNCH_CHECK();
     return 0;

@@ -36,6 +36,7 @@
 
 typedef struct {
     int n, ld, m, p, obj, dev_eval;
+    nla_evaluator ev;              /* how the objective is evaluated (compiled-in kernel / user kernel / host callback) */
     int64_t pop, survivors, units, rowwords;
     nlopt_amd_comm *comm;
     uint64_t wchunk;                /* words per generator pass: what the largest phase needs, up to WORD_CHUNK_MAX */
@@ -316,8 +317,9 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
 
     /* can everything be evaluated on the device? */
     memset(&D, 0, sizeof D);
-    D.obj = nlopt_amd_objective_id(f);
-    dev_eval = D.obj >= 0 && !(opt && nlopt_get_param(opt, "amd_host_eval", 0) != 0);
+    nla_evaluator_resolve(&D.ev, opt, f, f_data);
+    D.obj = D.ev.kind == NLA_EVAL_DEVICE ? D.ev.obj : -1;
+    dev_eval = D.ev.kind != NLA_EVAL_HOST && !(opt && nlopt_get_param(opt, "amd_host_eval", 0) != 0);
     con = (nla_dev_constraint *) calloc((size_t) (m + p + 1), sizeof *con);
     if (!con) { nla_stop_msg(stop, "nlopt_amd: out of memory"); return NLOPT_OUT_OF_MEMORY; }
     for (c = 0; c < m + p; ++c) {
@@ -355,6 +357,8 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
             const int64_t mine = first >= D.pop ? 0 : (D.pop - first < D.per ? D.pop - first : D.per);
             if (nla_k_isres_eval(D.obj, n, D.ld, D.d_X + (size_t) first * (size_t) D.ld, mine, m, p, D.d_con, D.d_F + first, D.d_PEN + first,
                                  D.d_GPEN + first, D.d_FEAS + first, D.st) ||
+                (D.ev.kind == NLA_EVAL_USER && nla_userobj_eval_rows(D.ev.user, n, D.ld, mine, D.d_X + (size_t) first * (size_t) D.ld, D.d_F + first,
+                                                                      NULL, D.ev.sign, D.st)) ||
                 nla_comm_allgather_dev(D.comm, D.d_F + first, D.d_F, sizeof(double) * (size_t) D.per, D.st) ||
                 nla_comm_allgather_dev(D.comm, D.d_PEN + first, D.d_PEN, sizeof(double) * (size_t) D.per, D.st) ||
                 nla_comm_allgather_dev(D.comm, D.d_GPEN + first, D.d_GPEN, sizeof(double) * (size_t) D.per, D.st) ||

@@ -609,7 +609,7 @@ typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
 void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                      const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                      const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
-                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with);
+                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with, uint32_t *dbg);
 size_t nla_crs_chain_ctrl_bytes(int K, int nW) { (void) K; (void) nW; return 64; }
 int nla_crs_chain_chunks(int n, int ld) { (void) ld; return (n + 63) / 64; }
 int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
@@ -621,7 +621,7 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
     (void) w_on_host; (void) ctrl; (void) ticket_base; (void) st;
     if (K > 256 || nW > 256 || obj < 0) return EMU_ERR;
     orc_k_crs_chain(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, lb, ub,
-                    TX, TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL);
+                    TX, TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL, NULL);
     return 0;
 }
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,

@@ -24,7 +24,7 @@ typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
 void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                      const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                      const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
-                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with);
+                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with, uint32_t *dbg);
 
 #define ECAP 1024                           /* slot ring, block b at slot b % ECAP */
 
@@ -134,7 +134,7 @@ static int emu_chain(void *ve, uint64_t first, int K, int64_t i0, double f_best,
         if (a < K) orc_k_vitter(n, e->N, e->tw + b * 2 * (uint64_t) n, 1, e->jn + q, e->pos + (size_t) q * n, e->last + q);
     }
     orc_k_crs_chain(e->obj, n, e->ld, e->X, i0, f_best, e->jn, e->pos, e->last, wring, ECAP, first, K, W, Wf, nW, ECAP - 1, e->lb, e->ub,
-                    e->TX, e->TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL);
+                    e->TX, e->TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL, NULL);
     for (int a = 0; a < K; ++a) {
         const int q = (int) ((first + (uint64_t) a) % ECAP);
         e->t[q] = n; e->fT[q] = status[a].fT; e->fM[q] = status[a].fM;

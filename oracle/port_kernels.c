@@ -142,7 +142,7 @@ typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
 void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                      const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                      const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
-                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with)
+                     orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with, uint32_t *dbg)
 {
     /* decide_with != NULL: the chain's decisions are taken on THESE f values (a device run's, which differ from this file's in the
      * last bits: enough to flip a comparison between two nearly equal values) — everything else is computed here as always */
@@ -210,6 +210,10 @@ void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double
             }
             next = j + (kind == 1 ? 1u : 2u);
         }
+    }
+    if (dbg) {                                  /* final chain state for comparisons: next, halt, wp, nextra, then rowstate[nW] */
+        dbg[0] = next; dbg[1] = (uint32_t) halt; dbg[2] = wp; dbg[3] = nextra;
+        for (int j = 0; j < nW; ++j) dbg[8 + j] = rowstate[j];
     }
     free(rowstate);
 }
