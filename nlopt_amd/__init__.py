@@ -428,6 +428,12 @@ class Opt:
     def set_max_objective(self, f, f_data=None):
         self._ck(self._L.nlopt_set_max_objective(self._h, self._fptr(f), f_data))
 
+    def set_min_device_objective(self, code_object, name, host_twin=None, maximize=False):
+        """bind a user-supplied device objective (include/nlopt_amd_device.h): kernel <name>_evalgrad of the code object"""
+        fn = self._L.nlopt_amd_set_max_device_objective if maximize else self._L.nlopt_amd_set_min_device_objective
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
+        return fn(self._h, code_object.encode(), name.encode(), self._fptr(host_twin) if host_twin is not None else None, None)
+
     def set_lower_bounds(self, lb):
         if np.isscalar(lb):
             self._ck(self._L.nlopt_set_lower_bounds1(self._h, float(lb)))
