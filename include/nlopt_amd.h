@@ -34,7 +34,10 @@ extern "C" {
 #define NLOPT_AMD_OBJ_COUNT      6
 
 /* Host callback (sequential, same formulae) for device objective `id`; passing exactly this
- * pointer to nlopt_set_min/max_objective selects the HIP evaluator (pointer identity). */
+ * pointer to nlopt_set_min/max_objective selects the HIP evaluator (pointer identity).  Under nlopt_set_max_objective the local
+ * optimisers and MLSL keep the device evaluator (f and gradient are negated on the device, as the reference's f_max wrapper
+ * does on the host, optimize.c:970-980); CRS2_LM / ISRES / ESCH run the maximisation through that wrapper, i.e. on the exact
+ * host-callback path. */
 nlopt_func nlopt_amd_objective(int id);
 int nlopt_amd_objective_id(nlopt_func f);              /* -1: not a device objective */
 const char *nlopt_amd_objective_name(int id);
@@ -398,6 +401,9 @@ int nla_k_mlsl_gather_rows(int n, int ld, const double *src, const int64_t *idx,
 int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, int count, const double *lb, const double *ub,
                           double thr, int32_t *flags, void *stream);
 
+/* replaces: the sign flip of the maximisation wrapper f_max (optimize.c:970-980) for `count` device-evaluated values */
+int nla_k_mlsl_negate(double *F, int count, void *stream);
+
 /* ---- ESCH (src/algs/esch/esch.c) -------------------------------------------------------------------- */
 /* replaces: randcauchy (esch.c:28-50) called back to back: appends the accepted values (folded to [0,1], i.e. `valor` before the
  * scaling into [lb,ub]) of attempts [attempt_base, attempt_base + nattempts) (2 words each) to v[vbase ...) (capacity vcap),
@@ -447,7 +453,7 @@ void *nla_module_load_file(const char *path);
 void *nla_module_load_data(const void *image);
 void nla_module_unload(void *module);
 void *nla_module_function(void *module, const char *name);
-int nla_module_launch(void *function, unsigned grid_x, unsigned block_x, void *args, size_t arg_bytes, void *stream);
+int nla_module_launch(void *function, unsigned grid_x, unsigned block_x, void **params, void *stream);   /* params[i] = &argument i */
 
 #ifdef __cplusplus
 }

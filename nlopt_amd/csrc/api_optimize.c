@@ -249,15 +249,24 @@ nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
     nlopt_set_force_stop(opt, 0);
     opt->force_stop_child = NULL;
     if ((maximize = opt->maximize)) {          /* minimise -f (optimize.c:1014-1024) */
-        fd.f = f; fd.f_data = f_data; fd.pre = pre;
-        opt->f = flipped_objective; opt->f_data = &fd;
-        if (opt->pre) opt->pre = flipped_precond;
+        const nlopt_algorithm a = opt->algorithm;
+        const int local_or_mlsl = a == NLOPT_LD_LBFGS || a == NLOPT_LD_MMA || a == NLOPT_G_MLSL || a == NLOPT_G_MLSL_LDS ||
+                                  (a >= NLOPT_GN_MLSL && a <= NLOPT_GD_MLSL_LDS);
+        if (local_or_mlsl && (nlopt_amd_objective_id(f) >= 0 || nla_userobj_is_adapter(f))) {
+            /* a device objective stays on the device: those drivers negate f and its gradient there (nla_evaluator.sign) */
+            opt->dev_sign = -1;
+        } else {
+            fd.f = f; fd.f_data = f_data; fd.pre = pre;
+            opt->f = flipped_objective; opt->f_data = &fd;
+            if (opt->pre) opt->pre = flipped_precond;
+        }
         opt->stopval = -opt->stopval;
         opt->maximize = 0;
     }
     ret = fix_applies(opt) ? minimize_fixed_eliminated(opt, x, opt_f) : minimize_dispatch(opt, x, opt_f);
     if (maximize) {
         opt->maximize = maximize;
+        opt->dev_sign = 0;
         opt->stopval = -opt->stopval;
         opt->f = f; opt->f_data = f_data; opt->pre = pre;
         *opt_f = -*opt_f;

@@ -198,3 +198,29 @@ void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, in
     if (first) *first = f;
     if (mine) *mine = m;
 }
+
+
+/* Multi-rank runs: the wall clock and the force_stop flag belong to a process, but the ranks must leave a run at the same
+ * point — one rank returning MAXTIME_REACHED while another enters the next all-gather would hang it (or they would return
+ * different results).  So the two per-process stop conditions are decided COLLECTIVELY at the points where the ranks exchange
+ * data anyway: every rank contributes what it sees now, the OR over all ranks is what every rank then acts on until the next
+ * agreement.  Returns `stop` itself for a single process; otherwise `view` = *stop with the flag / clock replaced by the
+ * agreed verdicts (NULL if the exchange failed). */
+const nla_stopping *nla_comm_agree_stop(nlopt_amd_comm *c, const nla_stopping *stop, nla_stopping *view, int *force_store)
+{
+    int mine[2], *all, r, forced = 0, timed = 0;
+    const int world = nlopt_amd_comm_world(c);
+    if (world <= 1) return stop;
+    mine[0] = nla_stop_forced(stop);
+    mine[1] = nla_stop_time(stop);
+    all = (int *) malloc(sizeof(int) * 2 * (size_t) world);
+    if (!all || nla_comm_allgather_host(c, mine, all, sizeof mine, NULL)) { free(all); return NULL; }
+    for (r = 0; r < world; ++r) { forced |= all[2 * r]; timed |= all[2 * r + 1]; }
+    free(all);
+    *view = *stop;
+    *force_store = forced;
+    view->force_stop = force_store;
+    if (timed) { view->maxtime = 1e-300; view->start = -1e300; }      /* nla_stop_time(view) is true from now on */
+    else view->maxtime = 0;                                           /* ... or false until the next agreement */
+    return view;
+}

@@ -105,9 +105,8 @@ extern "C" void *nla_module_function(void *module, const char *name)
     if (hipModuleGetFunction(&f, (hipModule_t) module, name) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     return (void *) f;
 }
-/* args: the kernel's parameters packed as the ABI lays them out (natural alignment), arg_bytes long */
-extern "C" int nla_module_launch(void *function, unsigned grid_x, unsigned block_x, void *args, size_t arg_bytes, void *stream)
+/* params[i] = address of the kernel's i-th argument (hipModuleLaunchKernel's kernelParams form) */
+extern "C" int nla_module_launch(void *function, unsigned grid_x, unsigned block_x, void **params, void *stream)
 {
-    void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END };
-    return (int) hipModuleLaunchKernel((hipFunction_t) function, grid_x, 1, 1, block_x, 1, 1, 0, (hipStream_t) stream, nullptr, config);
+    return (int) hipModuleLaunchKernel((hipFunction_t) function, grid_x, 1, 1, block_x, 1, 1, 0, (hipStream_t) stream, params, nullptr);
 }

@@ -160,3 +160,18 @@ extern "C" int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64
     NLA_LAUNCH_CHECK();
     return 0;
 }
+
+
+/* F[i] := -F[i]: the reference's maximisation wrapper (f_max, optimize.c:970-980) applied to a batch of device-evaluated samples */
+__global__ __launch_bounds__(256) void mlsl_negate_kernel(double *__restrict__ F, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) F[i] = -F[i];
+}
+extern "C" int nla_k_mlsl_negate(double *F, int count, void *stream)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_negate_kernel, dim3((unsigned) ((count + 255) / 256)), dim3(256), 0, (hipStream_t) stream, F, count);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

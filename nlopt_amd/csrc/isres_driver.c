@@ -298,7 +298,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     nlopt_amd_stats *st = opt ? &opt->stats : NULL;
     double minf_penalty = HUGE_VAL, minf_gpenalty = HUGE_VAL, taup, tau, *results = NULL;
     unsigned maxdim = 1;
-    int j, c, dev_eval;
+    int j, c, dev_eval, agreed_force = 0;
     const int need_x = stop->xtol_rel > 0 || stop->xtol_abs != NULL;
     int64_t k;
 
@@ -349,6 +349,8 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         int all_feasible = 1;
         int64_t kbest = -1, sweeps = 0;
         double t0, t_rng = 0;
+        nla_stopping agreed_view;
+        const nla_stopping *sp;                      /* what the clock / force_stop tests of this generation look at (all ranks the same) */
         if (opt && opt->progress) opt->progress(opt->progress_data, st ? (long) st->generations : 0, (long) *stop->nevals_p);
         t0 = nla_seconds();
         if (dev_eval) {
@@ -377,6 +379,9 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         if (st) st->t_eval_s += nla_seconds() - t0;
 
         /* the reference's per-candidate bookkeeping, in candidate order (isres.c:134-199) */
+        /* several ranks: the clock and the force_stop flag are decided once per generation, by all ranks together (comm.c) */
+        sp = nla_comm_agree_stop(D.comm, stop, &agreed_view, &agreed_force);
+        if (!sp) { snprintf(D.err, sizeof D.err, "stop agreement failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL(); }
         for (k = 0; k < D.pop; ++k) {
             int feasible = 1;
             double gpenalty, fk, pk;
@@ -441,9 +446,9 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
                 minf_gpenalty = feasible ? 0 : gpenalty;
                 if (ret != NLOPT_SUCCESS) break;
             }
-            if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP;
+            if (nla_stop_forced(sp)) ret = NLOPT_FORCED_STOP;
             else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
-            else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
+            else if (nla_stop_time(sp)) ret = NLOPT_MAXTIME_REACHED;
             if (ret != NLOPT_SUCCESS) break;
         }
         if (kbest >= 0) {                          /* the last accepted best of this generation -> x */

@@ -182,7 +182,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     const double *lbh = lb, *ubh = ub;
     int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0, host, batch;
     nla_mma_params mma;
-    nla_stopping lstop;
+    nla_stopping lstop, agreed_view;
+    const nla_stopping *sp = stop;
+    int agreed_force = 0;
     size_t best_row = 0;
 
     memset(&D, 0, sizeof D);
@@ -272,14 +274,19 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     nla_local_ctx_set_stats(D.lb, st);
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
-#define STOPS(fv) do { if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP; else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED; \
-        else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED; else if ((fv) < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED; } while (0)
+    /* several ranks: the clock and the force_stop flag are decided by all ranks together at the start of every phase (comm.c);
+     * sp is what those two tests look at until the next agreement */
+#define AGREE() do { sp = nla_comm_agree_stop(D.comm, stop, &agreed_view, &agreed_force); \
+        if (!sp) { snprintf(D.err, sizeof D.err, "stop agreement failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL(); } } while (0)
+#define STOPS(fv) do { if (nla_stop_forced(sp)) ret = NLOPT_FORCED_STOP; else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED; \
+        else if (nla_stop_time(sp)) ret = NLOPT_MAXTIME_REACHED; else if ((fv) < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED; } while (0)
 #define GET_MINF() do { if (D.npts) { best_f = D.F[D.ord[0]]; best_row = D.ord[0]; best_is_lm = 0; } \
         if (D.nlms && D.LF[D.lord[0]] < best_f) { best_f = D.LF[D.lord[0]]; best_row = D.lord[0]; best_is_lm = 1; } } while (0)
 
     /* f of `cnt` rows on the device: compiled-in objective, or the user's kernel (host objectives are called in the loops below) */
 #define EVAL_ROWS(rows, cnt, dF) (D.ev.kind == NLA_EVAL_USER ? nla_userobj_eval_rows(D.ev.user, n, D.ld, (cnt), (rows), (dF), NULL, D.ev.sign, D.st) \
-                                                              : nla_k_eval(D.obj, n, D.ld, (rows), (cnt), (dF), D.st))
+                                                              : (nla_k_eval(D.obj, n, D.ld, (rows), (cnt), (dF), D.st) || \
+                                                                 (D.ev.sign < 0 && nla_k_mlsl_negate((dF), (int) (cnt), D.st))))
     /* the starting guess is the first point (mlsl.c:326-340) */
     if (host) {
         D.F[0] = f((unsigned) n, x, NULL, f_data);
@@ -289,6 +296,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         nla_memcpy_d2h(D.F, D.d_F, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "first evaluation failed"); DEVFAIL(); }
     ++*stop->nevals_p;
     NEWPT(0);
+    AGREE();
     STOPS(D.F[0]);
 
     while (ret == NLOPT_SUCCESS) {
@@ -296,6 +304,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         size_t old = D.npts, used = 0, idx;
         int remaining;
         GET_MINF();                                                            /* mlsl.c:347 */
+        AGREE();
         if (opt && opt->progress) { opt->progress(opt->progress_data, st ? (long) st->generations : 0, (long) *stop->nevals_p); t0 = nla_seconds(); }
 
         /* ---- sampling phase (mlsl.c:349-374) ---- */
@@ -307,6 +316,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         } else {
             if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
             if (nla_k_crs_init_rows(D.obj, n, D.ld, D.d_lb, D.d_ub, D.d_words, (int64_t) old, D.N, D.d_P, D.d_F, D.st) ||
+                (D.ev.kind == NLA_EVAL_DEVICE && D.ev.sign < 0 && nla_k_mlsl_negate(D.d_F + old, D.N, D.st)) ||
                 (D.ev.kind == NLA_EVAL_USER && EVAL_ROWS(D.d_P + old * (size_t) D.ld, D.N, D.d_F + old))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         }
         if ((host ? nla_memcpy_d2h(D.h_rows, D.d_P + old * (size_t) D.ld, sizeof(double) * (size_t) D.N * (size_t) D.ld, D.st)
@@ -367,6 +377,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 cand[nb++] = scan - 1;
             }
             if (nb == 0) { idx = scan; remaining = rem; break; }
+            AGREE();
             /* candidate c is minimised by rank c mod world in its slot c / world; gathered row of c: GI(c) */
             per = (nb + D.world - 1) / D.world;
 #define GI(c) ((size_t) ((c) % D.world) * (size_t) per + (size_t) ((c) / D.world))
@@ -426,9 +437,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 if (pot && D.h_flags[c]) pot = 0;                               /* too close to a bound (mlsl.c:211-218) */
                 if (!pot) continue;
                 if (!(host && D.world == 1)) {
-                    if (nla_stop_forced(stop)) { ret = NLOPT_FORCED_STOP; break; }
+                    if (nla_stop_forced(sp)) { ret = NLOPT_FORCED_STOP; break; }
                     if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; break; }
-                    if (stop->maxtime > 0 && nla_seconds() - stop->start >= stop->maxtime) { ret = NLOPT_MAXTIME_REACHED; break; }
+                    if (nla_stop_time(sp)) { ret = NLOPT_MAXTIME_REACHED; break; }
                 }
                 /* did this search run under the evaluation limit it would have had in the serial order? */
                 limited = (long) stop->maxeval - (long) *stop->nevals_p;
@@ -465,10 +476,10 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 D.LF[D.nlms] = lf;
                 ord_insert(D.lord, D.nlms, D.LF, D.nlms);
                 ++D.nlms;
-                if (nla_stop_forced(stop)) ret = NLOPT_FORCED_STOP;
+                if (nla_stop_forced(sp)) ret = NLOPT_FORCED_STOP;
                 else if (lf < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
                 else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
-                else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
+                else if (nla_stop_time(sp)) ret = NLOPT_MAXTIME_REACHED;
                 else {
                     const double *dr = D.h_D + g * D.npts;              /* pts_update_newlm, mlsl.c:180-194 */
                     for (k = 0; k < D.npts; ++k)

@@ -123,6 +123,7 @@ nlopt_result nla_optimize_limited(nlopt_opt opt, double *x, double *minf, int ma
 int nla_comm_allgather_dev(nlopt_amd_comm *c, const void *d_send, void *d_recv, size_t bytes, void *stream);
 int nla_comm_allgather_host(nlopt_amd_comm *c, const void *h_send, void *h_recv, size_t bytes, void *stream);
 void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, int64_t *first, int64_t *mine);
+const nla_stopping *nla_comm_agree_stop(nlopt_amd_comm *c, const nla_stopping *stop, nla_stopping *view, int *force_store);
 
 /* ---- MT19937 host side (mt_host.c) ------------------------------------------------------------ */
 void nla_mt_seed_array(uint32_t mt[NLA_MT_N], unsigned long seed);

@@ -22,8 +22,6 @@ struct nla_userobj {
     int cap;
 };
 
-typedef struct { int32_t n, ld; int64_t count; const int32_t *list; const double *X; double *F; double *G; double sign; } evalgrad_args;
-
 nla_userobj *nla_userobj_retain(nla_userobj *u) { if (u) __atomic_add_fetch(&u->refs, 1, __ATOMIC_RELAXED); return u; }
 void nla_userobj_release(nla_userobj *u)
 {
@@ -37,11 +35,14 @@ void nla_userobj_release(nla_userobj *u)
 
 static int launch(nla_userobj *u, int n, int ld, int64_t count, const int32_t *list, const double *X, double *F, double *G, double sign, void *stream)
 {
-    evalgrad_args a;
+    /* <name>_evalgrad(int n, int ld, long count, const int *list, const double *X, double *F, double *G, double sign) */
+    int32_t an = n, ald = ld;
+    int64_t acount = count;
+    double asign = sign == 0. ? 1. : sign;
+    void *params[8];
     if (count <= 0) return 0;
-    memset(&a, 0, sizeof a);
-    a.n = n; a.ld = ld; a.count = count; a.list = list; a.X = X; a.F = F; a.G = G; a.sign = sign == 0. ? 1. : sign;
-    return nla_module_launch(u->fn, (unsigned) ((count + 3) / 4), 256, &a, sizeof a, stream);
+    params[0] = &an; params[1] = &ald; params[2] = &acount; params[3] = &list; params[4] = &X; params[5] = &F; params[6] = &G; params[7] = &asign;
+    return nla_module_launch(u->fn, (unsigned) ((count + 3) / 4), 256, params, stream);
 }
 
 int nla_userobj_eval_rows(nla_userobj *u, int n, int ld, int64_t count, const double *X, double *F, double *G, double sign, void *stream)
@@ -105,11 +106,11 @@ static nlopt_result bind(nlopt_opt opt, const char *code_object, const char *nam
     {   /* ABI check: <name>_abi writes the header's version */
         void *abi;
         int32_t *d_v = (int32_t *) nla_dev_malloc(sizeof(int32_t)), v = -1;
-        struct { int32_t *out; } a;
+        void *params[1];
         snprintf(sym, sizeof sym, "%s_abi", name);
         abi = nla_module_function(u->module, sym);
-        a.out = d_v;
-        if (!abi || !d_v || nla_module_launch(abi, 1, 1, &a, sizeof a, u->st) || nla_memcpy_d2h(&v, d_v, sizeof v, u->st) || nla_stream_sync(u->st) || v != 1) {
+        params[0] = &d_v;
+        if (!abi || !d_v || nla_module_launch(abi, 1, 1, params, u->st) || nla_memcpy_d2h(&v, d_v, sizeof v, u->st) || nla_stream_sync(u->st) || v != 1) {
             nla_dev_free(d_v);
             nla_set_errmsg(opt, "nlopt_amd: %s in %s was not built with this library's nlopt_amd_device.h (ABI %d, expected 1)", name, code_object, (int) v);
             nla_userobj_release(u); return NLOPT_INVALID_ARGS;

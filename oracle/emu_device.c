@@ -195,6 +195,8 @@ int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, in
     return 0;
 }
 
+int nla_k_mlsl_negate(double *F, int count, void *st) { EMU_LAUNCH(); (void) st; for (int i = 0; i < count; ++i) F[i] = -F[i]; return 0; }
+
 /* ---- local optimisers: the oracle ports stand in for the batched kernels ------------------------------------------------------
  * Device objectives: a whole search per call, as the kernels do.  External evaluation (NLA_OBJ_EXTERNAL, include/nlopt_amd.h):
  * the port runs as a coroutine (ucontext) whose objective yields to the launcher's caller with the point in EX and is resumed by
@@ -351,8 +353,8 @@ void *nla_module_load_file(const char *path) { (void) path; return NULL; }
 void *nla_module_load_data(const void *image) { (void) image; return NULL; }
 void nla_module_unload(void *module) { (void) module; }
 void *nla_module_function(void *module, const char *name) { (void) module; (void) name; return NULL; }
-int nla_module_launch(void *function, unsigned gx, unsigned bx, void *args, size_t bytes, void *st)
-{ (void) function; (void) gx; (void) bx; (void) args; (void) bytes; (void) st; return EMU_ERR; }
+int nla_module_launch(void *function, unsigned gx, unsigned bx, void **params, void *st)
+{ (void) function; (void) gx; (void) bx; (void) params; (void) st; return EMU_ERR; }
 
 /* ---- ISRES (hip/isres_kernels.hip) ---------------------------------------------------------------------------------------------- */
 int nla_k_isres_init(int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t k_first, int64_t count,

@@ -259,3 +259,69 @@ def test_mlsl_exact_mode_is_the_oracles_run(obj, n, ns, seed, kw, local, host):
         assert abs(len(fl) - len(p["floc"])) <= max(2, len(p["floc"]) // 10)
     assert abs(minf - p["minf"]) <= 1e-8 * max(abs(p["minf"]), 1.0)
     assert np.allclose(x, p["x"], rtol=1e-6, atol=1e-7 * max(np.abs(p["x"]).max(), 1.0))
+
+
+@pytest.mark.parametrize("alg,obj,n", [(nlopt_amd.LD_LBFGS, "sphere", 3), (nlopt_amd.LD_MMA, "sphere", 3), (nlopt_amd.LD_LBFGS, "rastrigin", 12),
+                                       (nlopt_amd.LD_MMA, "ackley", 9)])
+def test_maximisation_keeps_the_device_objective(alg, obj, n):
+    """nlopt_set_max_objective with a registered device objective (the flip wrapper hid it and LD_LBFGS / LD_MMA / MLSL
+    refused): f and its gradient are negated on the device, as the reference's f_max wrapper does on the host
+    (optimize.c:970-980,1014-1024).  Against the REAL reference maximising the same function."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    R, P = O.ref(), O.port()
+    xs, lo, hi = O.golden_x0(obj, n)
+    o = nlopt_amd.Opt(alg, n)
+    o.set_lower_bounds(lo)
+    o.set_upper_bounds(hi)
+    o.set_max_objective(nlopt_amd.objective(obj))
+    o.set_ftol_rel(1e-9)
+    o.set_maxeval(300)
+    o.set_param("amd_exact_dot", 1)
+    x, maxf, ret = o.optimize_raw(xs)
+    opt = R.nlopt_create(alg, n)
+    lb, ub = np.full(n, lo), np.full(n, hi)
+    R.nlopt_set_lower_bounds(opt, O.dptr(lb))
+    R.nlopt_set_upper_bounds(opt, O.dptr(ub))
+    R.nlopt_set_max_objective(opt, P.orc_objective(O.OBJ[obj]), None)
+    R.nlopt_set_ftol_rel(opt, 1e-9)
+    R.nlopt_set_maxeval(opt, 300)
+    xr = np.array(xs)
+    mf = C.c_double()
+    rret = R.nlopt_optimize(opt, O.dptr(xr), C.byref(mf))
+    nev = R.nlopt_get_numevals(opt)
+    R.nlopt_destroy(opt)
+    assert ret == rret, (ret, rret, o.get_errmsg())
+    assert o.get_numevals() == nev
+    assert abs(maxf - mf.value) <= 1e-10 * max(abs(mf.value), 1.0)
+    assert np.allclose(x, xr, rtol=1e-9, atol=1e-10)
+
+
+def test_mlsl_maximisation_on_the_device():
+    """G_MLSL maximising a device objective: samples and local searches stay on the device (sign applied there)"""
+    n = 5
+    xs, lo, hi = O.golden_x0("rastrigin", n)
+    L = nlopt_amd.lib()
+    res = []
+    for device in (True, False):
+        o = nlopt_amd.Opt(nlopt_amd.G_MLSL, n)
+        o.set_lower_bounds(lo)
+        o.set_upper_bounds(hi)
+        if device:
+            o.set_max_objective(nlopt_amd.objective("rastrigin"))
+        else:
+            rec, fbuf, hbuf, cb = recorder("rastrigin", 20000)
+            o.set_max_objective(cb, C.cast(C.pointer(rec), C.c_void_p))       # the same function as a host callback
+        loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, n)
+        loc.set_ftol_rel(1e-8)
+        assert L.nlopt_set_local_optimizer(o._h, loc._h) > 0
+        o.set_population(12)
+        o.set_maxeval(1500)
+        o.set_param("amd_exact_dot", 1)
+        nlopt_amd.srand(5)
+        x, maxf, ret = o.optimize_raw(xs)
+        res.append((ret, maxf, x, o.get_numevals(), o.stats()))
+    (r1, f1, x1, n1, s1), (r2, f2, x2, n2, s2) = res
+    assert r1 == r2 and n1 == n2
+    assert abs(f1 - f2) <= 1e-9 * max(abs(f2), 1.0) and np.allclose(x1, x2, rtol=1e-8, atol=1e-9)
+    assert s1["lbfgs_launches"] >= 1 and f1 > 0
