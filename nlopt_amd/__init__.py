@@ -178,6 +178,7 @@ def lib():
     L.nla_k_crs_vitter.argtypes = [C.c_int, C.c_int64, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_advance.argtypes = [C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, C.c_int,
                                     vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]
+    L.nlopt_amd_has_device_objective.argtypes = [vp]
     L.nla_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_double, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp,
                                   C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_int, vp]
     L.nla_crs_chain_ctrl_bytes.argtypes = [C.c_int, C.c_int]
