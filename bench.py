@@ -335,7 +335,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
     slots = st1["slots_launched"] - st0["slots_launched"]
     used = st1["slots_used"] - st0["slots_used"]
-    traffic, traffic_src = pmc_traffic("crs_advance_kernel") if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
+    # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) from n = 2048 on, the conservative passes below
+    chain = n >= 2048 and os.environ.get("NLA_CRS_FORWARD", "1") != "0"
+    gkernel = "crs_chain_kernel" if chain else "crs_advance_kernel"
+    traffic, traffic_src = pmc_traffic(gkernel) if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
     out = {
         "metric": "candidate-evals/sec, CRS2_LM n=%d pop=%d (trial phase)" % (n, pop),
         "value": evals_all / dt_max, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -345,13 +348,13 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                                % (a.obj, n, pop, a.seed, a.evals_per_step,
                                   "" if world == 1 else "; %d independent replicas (seed+rank)" % world),
                    "evals_timed": int(evals_all), "evals_per_step_requested": a.evals_per_step},
-        "roofline": {"bound": "hbm", "kernel": "crs_advance_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": gkernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                      "launches": int(g_launch), "avg_launch_ms": (g_ms / g_launch) if g_launch else None,
                      "algorithmic_bytes_per_trial": 8 * n * (n + 1),
                      "avg_algorithmic_bytes_per_launch": (g_bytes / g_launch) if g_launch else None,
                      "avg_trials_consumed_per_launch": (used / g_launch) if g_launch else None},
-        "window": {"slots_started": int(slots), "slots_used": int(used),
+        "window": {"slots_started": int(slots), "slots_used": int(used), "slots_recomputed_or_dropped": int(st1["slots_invalid"] - st0["slots_invalid"]),
                    "useful_frac": (used / slots) if slots else None,
                    "newbest": int(st1["slots_newbest"] - st0["slots_newbest"]),
                    "role": int(st1["slots_role"] - st0["slots_role"]),

@@ -206,7 +206,9 @@ int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t 
  * the chain it replays (a stop, or a value landing among the worst rows twice, are not modelled on the device).
  * ctrl: nla_crs_chain_ctrl_bytes(K, nW) bytes of device memory, zero before the first launch (the launcher re-zeroes all of it
  * but its ticket counter); ticket_base = workgroups launched by earlier calls on this ctrl = sum of K * nla_crs_chain_chunks.
- * w_on_host != 0 (nW <= 96): W / Wf are host arrays and travel as kernel arguments.  f_best = f of row i0. */
+ * w_on_host != 0 (nW <= 96): W / Wf are host arrays and travel as kernel arguments.  f_best = f of row i0.
+ * TX, TM and ctrl MUST be nla_dev_malloc_uncached memory: the workgroups hand trial points to each other through them; and
+ * ld % 16 == 0 with TX / TM 128-byte aligned (no cache line shared by two slots) — the launcher refuses anything else. */
 size_t nla_crs_chain_ctrl_bytes(int K, int nW);
 int nla_crs_chain_chunks(int n, int ld);
 int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
@@ -431,6 +433,7 @@ int nla_dev_count(void);
 int nla_dev_set(int dev);
 void *nla_dev_malloc(size_t bytes);
 void nla_dev_free(void *p);
+void *nla_dev_malloc_uncached(size_t bytes);    /* MTYPE UC device memory: coherent between workgroups / XCDs without cache maintenance */
 void *nla_host_malloc(size_t bytes);            /* pinned */
 void nla_host_free(void *p);
 int nla_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream);

@@ -179,6 +179,8 @@ def lib():
     L.nla_k_crs_advance.argtypes = [C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, C.c_int,
                                     vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]
     L.nlopt_amd_has_device_objective.argtypes = [vp]
+    L.nla_dev_malloc_uncached.argtypes = [C.c_size_t]
+    L.nla_dev_malloc_uncached.restype = vp
     L.nla_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_double, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp,
                                   C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_int, vp]
     L.nla_crs_chain_ctrl_bytes.argtypes = [C.c_int, C.c_int]
@@ -253,16 +255,16 @@ def objective_box(name_or_id):
 class DevBuf:
     """a device allocation owned by libnlopt_amd's runtime layer, with numpy staging"""
 
-    def __init__(self, nbytes):
+    def __init__(self, nbytes, uncached=False):
         self.nbytes = int(nbytes)
-        self.ptr = lib().nla_dev_malloc(self.nbytes)
+        self.ptr = (lib().nla_dev_malloc_uncached if uncached else lib().nla_dev_malloc)(self.nbytes)
         if not self.ptr:
             raise MemoryError("nla_dev_malloc(%d) failed" % self.nbytes)
 
     @classmethod
-    def from_array(cls, a):
+    def from_array(cls, a, uncached=False):
         a = np.ascontiguousarray(a)
-        b = cls(max(a.nbytes, 1))
+        b = cls(max(a.nbytes, 1), uncached)
         L = lib()
         rc = L.nla_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes, None) or L.nla_stream_sync(None)
         if rc:

@@ -137,13 +137,19 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e = (nla_crs_hip_engine *) calloc(1, sizeof *e);
     if (!e) return NULL;
     e->n = n; e->N = N; e->obj = obj; e->stats = stats;
-    e->ld = (n + 1) & ~1;
+    e->ld = (n + 15) & ~15;          /* rows start on a 128-byte line (the chain kernel's contract; coalesced row reads everywhere) */
     e->bat[0].index = e->bat[1].index = -1;
-    B = (size_t) ((1ULL << 25) / (2ULL * (uint64_t) n));
-    /* the Vitter kernel walks all N rows per block, one lane per block (a serial fp64 chain): its time per launch grows
-     * with N, not with the blocks in it — large populations digest proportionally more blocks per launch so that the
-     * digestion keeps ahead of the trial loop (N = 1e6, n = 4096: 205 ms per launch whatever the batch) */
-    B *= (size_t) (1 + N / 250000);
+    /* blocks digested per batch (the block ring holds two batches).  The Vitter kernel walks all N rows per block, one lane per
+     * block (a serial fp64 chain): a launch takes the same 40-70 ms (N = 1e5) whether it digests 4096 blocks or 32768 — it is
+     * the number of lanes, not the time, that grows.  Measured with 4096-block batches at n = 4096 (profiles/r02_v1_kernel_stats.csv):
+     * the kernel was running under the gather 40-60 % of the time, on a quarter of the CUs, and the gather's workgroups on those
+     * CUs were the last to finish every pass.  With 2^28 words per batch (32768 blocks at n = 4096: 2.1 GB of words + 1 GB of
+     * positions in the ring, of 288 GB) it runs a few per cent of the time. */
+    {
+        const char *lg = getenv("NLA_CRS_BATCH_LOG2");                /* development switch */
+        const int lg2 = lg ? atoi(lg) : 28;
+        B = (size_t) ((1ULL << (lg2 >= 20 && lg2 <= 31 ? lg2 : 28)) / (2ULL * (uint64_t) n));
+    }
     if (B > 65536) B = 65536;
     if (B < 2 * KCAP) B = 2 * KCAP;
     e->B = (int) B;
@@ -165,8 +171,9 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         e->bat[i].ev_ready = nla_event_create();
         if (!e->bat[i].ev_ready) goto fail;
     }
-    e->d_TX = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * KCAP);
-    e->d_TM = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ld * KCAP);
+    /* trial points and the chain kernel's control block: uncached memory (the workgroups of one launch read each other's) */
+    e->d_TX = (double *) nla_dev_malloc_uncached(sizeof(double) * (size_t) e->ld * KCAP);
+    e->d_TM = (double *) nla_dev_malloc_uncached(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_fT = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP);
     e->d_fM = e->d_fT ? e->d_fT + KCAP : NULL;
     e->d_up = (char *) nla_dev_malloc(UPLOAD_BYTES);
@@ -183,7 +190,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         if (!e->d_list || !e->h_list || !e->h_fTM) goto fail;
     }
     if (obj >= 0) {
-        e->d_ctrl = nla_dev_malloc(nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX));
+        e->d_ctrl = nla_dev_malloc_uncached(nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX));
         e->d_Wf = (double *) nla_dev_malloc(sizeof(double) * CHAIN_KMAX);
         e->h_fwcnt = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX);
         e->h_fwrec = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX * CHAIN_FWCAP);

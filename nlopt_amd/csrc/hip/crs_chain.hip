@@ -37,12 +37,15 @@
  * Measured on MI355X (n = 4096, N = 1e5, Griewank; gpurun_out/r02g, r02h): 28 us per slot at 48 slots per launch (4.8 TB/s),
  * 32 us at 128, 40 us at 256 — a slot deeper in the window has more picks among the worst rows ahead of it (0.04 per row) and
  * each of them is a wait; 34.6 k evals/s at 48 slots against 31.0 k for the conservative passes of crs_kernels.hip.
- * Tried and dropped: agent-coherent (sc1) accesses or uncached TX / TM instead of the release / acquire fences, write-through
- * stores of the finished chunk, a back-off in the polling loops — each within 2 %.  What does matter: the U rows in flight must
- * stay in registers; any data-dependent branch beyond the one below inside the unrolled load loop (a `continue`, a conditional
- * fence) sends them to scratch (1.5 KB per lane) and costs 45 %.
+ * TX, TM and the control block are UNCACHED device memory (nla_dev_malloc_uncached): what one workgroup stores another loads
+ * without the L2 write-back / invalidate an agent-scope release / acquire pair costs per chunk and per pick (+5 %: 36.4 k).
+ * Tried and dropped: agent-coherent (sc1) loads of the forwarded rows, a back-off in the polling loops, 8x larger Vitter batches
+ * (the digest kernel runs under the gather on a quarter of the CUs: +2 %, kept), polling intervals 4 / 32 / 127 (no change).
+ * What does matter: the U rows in flight must stay in registers; a data-dependent `continue`, a conditional fence or NO fence at
+ * all after the polling loop sends them to scratch (1.5 KB per lane) and costs 45 %.
  */
 #include "crs_common.h"
+#include <stdlib.h>
 #include "../../../include/nlopt_amd.h"
 
 #define CH_EXTRA 32                      /* accepted values that landed among the window's worst rows */
@@ -207,7 +210,10 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
                         if (ld_agent(&ctrl->next) >= (uint32_t) a) { rs = ld_agent(&rowstate[j]); break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    /* TX / TM are uncached memory (nla_dev_malloc_uncached): nothing stale to drop, so no agent-scope acquire
+                     * (= an L2 invalidate per pick) here.  The wavefront-scope fence orders the loads below after the poll —
+                     * and keeps the U rows in flight in registers: without any fence at this point the compiler spills them */
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     /* a writer at or behind this slot's own block does not count: the row is read as it is before that */
                     int pj = 0, kind = 0;                    /* kind 0: the row as it is (no block before this one wrote it) */
                     if (rs && (int) (rs >> 3) < a) {
@@ -259,12 +265,15 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
             r2.y = nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]);
             *reinterpret_cast<double2 *>(accrow) = r2;
         }
+        /* the stores must have LANDED before this wave's lane 0 counts the chunk as done below (the barrier alone does not wait
+         * for them: a workgroup-scope release drops vmcnt).  TX is uncached memory, so landed = visible to every CU: no L2
+         * write-back, no agent-scope release */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     /* this chunk of the trial point is final; the workgroup that completes the slot evaluates it */
     __syncthreads();
     if (threadIdx.x == 0) {
         if (chunk == 0) fwcnt[a] = s_nrec;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         s_last = (atomicAdd(&done[a], 1u) == (uint32_t) (chunks - 1));
     }
     __syncthreads();
@@ -285,6 +294,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         };
         for (int i = tid; i < n; i += WAVES * 64) m[i] = mut(i);
         const double fM = nla_block_objective<OBJ, WAVES>(n, mut, scratch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* every wave's part of m[] has landed before lane 0 publishes the slot */
         __syncthreads();
         if (tid == 0) {
             status[a].fT = fT; status[a].fM = fM; status[a].t = n; status[a].pad = 0;
@@ -317,6 +327,9 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
 {
     if (K <= 0) return 0;
     if (K > 256 || nW > 256 || nW < 0 || obj < 0) return (int) hipErrorInvalidValue;
+    /* rows of TX / TM start on a 128-byte line: a line that holds the end of one slot's row and the start of the next one's could
+     * sit in a CU's vector L1 from the read of the first and serve a stale start of the second (consumers take no L1 invalidate) */
+    if (ld % 16 != 0 || ((uintptr_t) TX | (uintptr_t) TM) % 128 != 0) return (int) hipErrorInvalidValue;
     hipStream_t st = (hipStream_t) stream;
     chain_lists L;
     L.inl = 0;

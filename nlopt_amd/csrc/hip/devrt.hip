@@ -21,6 +21,14 @@ extern "C" void *nla_dev_malloc(size_t bytes)
     return p;
 }
 extern "C" void nla_dev_free(void *p) { if (p) (void) hipFree(p); }
+/* device memory no cache holds on to (MTYPE UC): what one workgroup stores any other workgroup loads, on whichever XCD it runs,
+ * without cache maintenance — for the small buffers the workgroups of hip/crs_chain.hip hand results to each other through */
+extern "C" void *nla_dev_malloc_uncached(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return p;
+}
 extern "C" void *nla_host_malloc(size_t bytes)
 {
     void *p = nullptr;

@@ -116,9 +116,9 @@ def test_vitter_kernel_bit_exact(L, n, N, nblocks):
     assert np.array_equal(dl.to_array(np.int32, nblocks), lr)
 
 
-def _spec_inputs(n, N, K, seed, obj):
+def _spec_inputs(n, N, K, seed, obj, align=2):
     P = O.port()
-    ld = (n + 1) & ~1
+    ld = (n + align - 1) & ~(align - 1)
     rng = np.random.default_rng(seed)
     lo, hi = nlopt_amd.objective_box(obj)
     lb, ub = np.full(n, lo), np.full(n, hi)
@@ -150,7 +150,7 @@ def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, 
     ring = 2 * K + 3
     first = 3 * ring + 2
     mask = 511
-    ld, lb, ub, X, w0, jn0, pos0, last0 = _spec_inputs(n, N, ring, 177 + n, obj)
+    ld, lb, ub, X, w0, jn0, pos0, last0 = _spec_inputs(n, N, ring, 177 + n, obj, align=16)      # the chain kernel's contract: rows on 128-byte lines
     oid = O.OBJ[obj]
     ent = [(first + a) % ring for a in range(ring)]
     w = np.zeros(2 * n * ring, np.uint32)
@@ -182,9 +182,9 @@ def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, 
     dX, dlb, dub, dw = DevBuf.from_array(X), DevBuf.from_array(lb), DevBuf.from_array(ub), DevBuf.from_array(w)
     dj, dp, dl = DevBuf.from_array(jn), DevBuf.from_array(pos), DevBuf.from_array(last)
     dW, dWf = DevBuf.from_array(W), DevBuf.from_array(Wf)
-    dTX, dTM = DevBuf.from_array(np.zeros(nslot * ld)), DevBuf.from_array(np.zeros(nslot * ld))
+    dTX, dTM = DevBuf.from_array(np.zeros(nslot * ld), uncached=True), DevBuf.from_array(np.zeros(nslot * ld), uncached=True)
     cb = L.nla_crs_chain_ctrl_bytes(256, 256)
-    dctrl = DevBuf.from_array(np.zeros(cb, np.uint8))
+    dctrl = DevBuf.from_array(np.zeros(cb, np.uint8), uncached=True)      # the kernel's contract: TX, TM, ctrl are uncached memory
     dst = DevBuf(C.sizeof(St) * K)
     dcnt, drec = DevBuf.from_array(np.zeros(K, np.uint32)), DevBuf.from_array(np.zeros(K * fwcap, np.uint32))
     for rep in range(2):                        # twice on the same control block: the ticket base carries over
