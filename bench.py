@@ -54,6 +54,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config5-pop", type=int, default=1000000, help="population of the one-job CRS block reported at --gpus > 1")
+    ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("crs", "isres", "mlsl"), default="crs")
@@ -298,6 +300,58 @@ def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, 
     return dict(dt=dt, evals=ev1 - ev0, st0=st0, st1=st1, t_init=t_init, fret=int(fret), minf=minf.value)
 
 
+def crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce):
+    """BASELINE.json config 5 (CRS2_LM Griewank n=4096, pop=1e6) as ONE job over all ranks: the initial population is sharded —
+    every rank draws and evaluates 1/world of the rows from the same MT19937 stream — and ALL-GATHERED over RCCL (32.8 GB of rows
+    per rank at the full size); then every rank walks the identical serial trial chain on its own copy (crs.c:125-156 does not
+    shard).  Reported: the initialisation (wall, max over ranks), the all-gather inside it (HIP events), the chain's rate."""
+    import _oracle as O
+    n, pop, obj = 4096, a.config5_pop, "griewank"
+    xs, lo, hi = O.golden_x0(obj, n)
+    o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
+    o.set_lower_bounds(lo)
+    o.set_upper_bounds(hi)
+    o.set_min_objective(nlopt_amd.objective(obj))
+    o.set_population(pop)
+    comm = nlopt_amd.Comm.from_torch_distributed()
+    o.set_comm(comm)
+    nlopt_amd.srand(a.seed)                                   # every rank: the same stream (one job)
+    x = np.array(xs)
+    minf, ret = C.c_double(), C.c_int()
+    sync_all()
+    t0 = time.perf_counter()
+    s = L.nlopt_amd_crs_open(o._h, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(minf), C.byref(ret))
+    sync_all()
+    t_init = time.perf_counter() - t0
+    if not s or ret.value != 1:
+        raise SystemExit("bench.py: config 5 crs_open failed: ret=%d %s" % (ret.value, o.get_errmsg()))
+    st_i = o.stats()
+    steps, per = 2, 2000
+    if L.nlopt_amd_crs_step(s, per) != 1:
+        raise SystemExit("bench.py: config 5 stopped during warm-up")
+    sync_all()
+    ev0 = o.get_numevals()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if L.nlopt_amd_crs_step(s, per) != 1:
+            raise SystemExit("bench.py: config 5 stopped inside the timed region")
+    sync_all()
+    dt = time.perf_counter() - t0
+    ev1 = o.get_numevals()
+    minf_all = o.stats()
+    L.nlopt_amd_crs_close(s)
+    t_init_max, _ = reduce(t_init, 0, False)
+    dt_max, evals_max = reduce(dt, ev1 - ev0, False)
+    ag_ms, ag_bytes = st_i["t_allgather_ms"], st_i["allgather_bytes"]
+    return {"workload": "NLOPT_GN_CRS2_LM griewank n=%d pop=%d seed=%d, ONE job over %d ranks (library communicator over RCCL)" % (n, pop, a.seed, world),
+            "scaling": "strong (initialisation only: rows sharded, all-gathered); the trial chain is replicated, not sharded",
+            "init_wall_s": t_init_max, "init_evals_per_s": pop / t_init_max,
+            "allgather_ms": ag_ms, "allgather_GB_received_per_rank": ag_bytes / 1e9,
+            "allgather_busbw_GBps": (ag_bytes / 1e9) * (world - 1) / world / (ag_ms / 1e3) if ag_ms > 0 else None,
+            "chain_evals_per_s": evals_max / dt_max, "chain_steps": steps, "chain_evals_timed": int(evals_max),
+            "population_GB_per_rank": 8.0 * n * pop / 1e9}
+
+
 def crs_end_to_end(nlopt_amd, obj, n, pop, seed, trial_evals):
     """ONE nlopt_optimize() call of the metric configuration from nlopt_create to the result: crs_init (pop evaluations) + about
     `trial_evals` trial-loop evaluations, wall clock around the call"""
@@ -327,6 +381,13 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     m = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed + rank, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec, a.gather_variant)
     dt, st0, st1, t_init, fret = m["dt"], m["st0"], m["st1"], m["t_init"], m["fret"]
     dt_max, evals_all = reduce(dt, m["evals"], True)
+    one_job = None
+    if world > 1 and not a.no_config5:
+        # BASELINE.json config 5 is the only CRS configuration with multi-GPU work in it: ONE job over all ranks
+        try:
+            one_job = crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce)
+        except (Exception, SystemExit) as e:
+            one_job = {"error": repr(e)}
     if rank != 0:
         return None
     g_ms = st1["t_gather_ms"] - st0["t_gather_ms"]
@@ -383,6 +444,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                 out["other_sizes"]["n=%d" % n2] = e2
             except Exception as e:
                 out["other_sizes"]["n=%d" % n2] = {"error": repr(e)}
+    if world > 1:
+        out["replicas_note"] = ("value = sum over %d independent replicas of the metric configuration (the trial loop is one serial chain: it "
+                                "does not shard); the one multi-GPU CRS job is config5_one_job below — not part of value" % world)
+        out["config5_one_job"] = one_job
     try:
         out["gens_to_ftol"] = gens_to_ftol()
     except Exception as e:        # the headline line must still be printed

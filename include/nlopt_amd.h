@@ -96,6 +96,10 @@ typedef struct {
     uint64_t stochrank_launches, stochrank_ticks;
     /* slots_invalid (above) is live again with value forwarding: slots recomputed because a forwarded row turned out not to be
      * what the chain wrote */
+    /* multi-rank CRS2_LM initialisation: device time (HIP events) of the all-gather of the rows and their f, and the bytes
+     * every rank received (0 on a single rank) */
+    double t_allgather_ms;
+    uint64_t allgather_bytes;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 

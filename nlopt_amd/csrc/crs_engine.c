@@ -224,7 +224,7 @@ static int op_init_population(void *ve, const double *x0, double *F)
     const int64_t first = 1 + per * rank;
     const int64_t last = first + per < e->N ? first + per : e->N;     /* this rank's rows: [first, last) */
     int64_t rows_per_chunk = (int64_t) (INIT_CHUNK_WORDS / wpr), r0;
-    void *ev = nla_event_create();
+    void *ev = nla_event_create(), *ev_ag0 = NULL, *ev_ag1 = NULL;
     if (!ev) FAIL(e, "event create failed");
     if (world > ROWPAD) { nla_event_destroy(ev); FAIL(e, "more than %d ranks are not supported", ROWPAD); }
     if (rows_per_chunk < 1) rows_per_chunk = 1;
@@ -259,11 +259,15 @@ static int op_init_population(void *ve, const double *x0, double *F)
         }
     }
     if (world > 1) {
+        ev_ag0 = nla_event_create(); ev_ag1 = nla_event_create();
+        if (ev_ag0) nla_event_record(ev_ag0, e->main);
         if (nla_comm_allgather_dev(e->comm, e->d_X + (size_t) first * (size_t) e->ld, e->d_X + (size_t) e->ld,
                                    sizeof(double) * (size_t) per * (size_t) e->ld, e->main) ||
             (e->obj != -1 && nla_comm_allgather_dev(e->comm, e->d_F + first, e->d_F + 1, sizeof(double) * (size_t) per, e->main))) {
-            nla_event_destroy(ev); FAIL(e, "all-gather of the initial population failed: %s", nlopt_amd_comm_error(e->comm));
+            nla_event_destroy(ev); nla_event_destroy(ev_ag0); nla_event_destroy(ev_ag1);
+            FAIL(e, "all-gather of the initial population failed: %s", nlopt_amd_comm_error(e->comm));
         }
+        if (ev_ag1) nla_event_record(ev_ag1, e->main);
     }
     if (e->obj != -1) {
         if (nla_memcpy_d2h(F, e->d_F, sizeof(double) * (size_t) e->N, e->main)) { nla_event_destroy(ev); FAIL(e, "D2H F failed"); }
@@ -271,6 +275,11 @@ static int op_init_population(void *ve, const double *x0, double *F)
     {
         int rc = nla_stream_sync(e->main);
         nla_event_destroy(ev);
+        if (!rc && ev_ag0 && ev_ag1 && e->stats) {
+            e->stats->t_allgather_ms += (double) nla_event_elapsed_ms(ev_ag0, ev_ag1);
+            e->stats->allgather_bytes += (uint64_t) world * (uint64_t) per * (sizeof(double) * (uint64_t) e->ld + (e->obj != -1 ? sizeof(double) : 0));
+        }
+        nla_event_destroy(ev_ag0); nla_event_destroy(ev_ag1);
         if (rc) FAIL(e, "init sync failed: %s", nla_dev_error_string(rc));
     }
     nla_dev_free(e->d_initwords); e->d_initwords = NULL; e->initwords_cap = 0;

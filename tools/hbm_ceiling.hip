@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
+#include <cstdint>
 
 __global__ __launch_bounds__(256) void stream_kernel(const double2 *__restrict__ p, size_t count, double *out)
 {
@@ -47,6 +49,15 @@ int main(int argc, char **argv)
     hipMalloc(&X, sizeof(double) * (size_t) N * ld);
     hipMalloc(&out, 64);
     hipMemset(X, 0, sizeof(double) * (size_t) N * ld);
+    const bool realistic = argc > 3 && atoi(argv[3]);           /* 3rd argument 1: random bits in memory, every slot's rows ascending (as Vitter's picks are) */
+    if (realistic) {
+        std::vector<uint64_t> blk((size_t) 1000 * ld);
+        unsigned long long s = 1234567ULL;
+        for (auto &v : blk) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (s >> 12) | 0x3ff0000000000000ULL; }
+        for (long r0 = 0; r0 < N; r0 += 1000)
+            hipMemcpy(X + (size_t) r0 * ld, blk.data(), sizeof(double) * (size_t) ld * (size_t) (N - r0 < 1000 ? N - r0 : 1000), hipMemcpyHostToDevice);
+        printf("realistic: random doubles in memory, rows of a slot ascending\n");
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("matrix %ld x %d fp64 = %.2f GB\n", N, n, 8.0 * N * ld / 1e9);
@@ -65,6 +76,7 @@ int main(int argc, char **argv)
         std::vector<int32_t> h((size_t) slots * n);
         unsigned long long s = 88172645463325252ULL;
         for (auto &v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (int32_t) (s % (unsigned long long) N); }
+        if (realistic) for (int sl = 0; sl < slots; ++sl) std::sort(h.begin() + (size_t) sl * n, h.begin() + (size_t) (sl + 1) * n);
         int32_t *rows;
         hipMalloc(&rows, h.size() * 4);
         hipMemcpy(rows, h.data(), h.size() * 4, hipMemcpyHostToDevice);
