@@ -55,6 +55,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--config5-pop", type=int, default=1000000, help="population of the one-job CRS block reported at --gpus > 1")
+    ap.add_argument("--config5-n", type=int, default=4096)
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -226,8 +227,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:                                   # tests/test_bench_emulated.py: the contract at world 2 without a GPU (emulated device layer)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     import nlopt_amd
     L = nlopt_amd.lib()
     if nlopt_amd.device_count() <= 0:
@@ -246,9 +250,10 @@ def main():
     def reduce(dt, evals, sum_evals):
         if dist is None:
             return dt, float(evals)
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        te = torch.tensor([float(evals)], dtype=torch.float64, device="cuda")
+        te = torch.tensor([float(evals)], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.SUM if sum_evals else dist.ReduceOp.MAX)
         return float(tt.item()), float(te.item())
 
@@ -306,7 +311,7 @@ def crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce):
     per rank at the full size); then every rank walks the identical serial trial chain on its own copy (crs.c:125-156 does not
     shard).  Reported: the initialisation (wall, max over ranks), the all-gather inside it (HIP events), the chain's rate."""
     import _oracle as O
-    n, pop, obj = 4096, a.config5_pop, "griewank"
+    n, pop, obj = a.config5_n, a.config5_pop, "griewank"
     xs, lo, hi = O.golden_x0(obj, n)
     o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
     o.set_lower_bounds(lo)
@@ -545,9 +550,9 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                           "serial_ticks_per_launch": ticks / d["stochrank_launches"],
                           "achieved": t_sr * 1e9 / ticks if ticks else None, "unit": "ns per serial tick",
                           "model": "ticks = pop + 2*sweeps + 63*ceil(sweeps/64); one tick = one DPP lane shift + compare-exchange of the "
-                                   "packed element on a wavefront that is alone on its SIMD (about 80 dependent instructions)",
-                          "peak": 80 / 2.4, "peak_note": "80 dependent VALU/DPP instructions at 2.4 GHz issue rate = 33 ns: the floor of this formulation",
-                          "frac": (80 / 2.4) / (t_sr * 1e9 / ticks) if ticks and t_sr > 0 else None,
+                                   "packed element on a wavefront that is alone on its SIMD (26 VALU/DPP instructions, isres_kernels.hip)",
+                          "peak": 26 * 4 / 2.4, "peak_note": "26 instructions x 4 cycles each (wave64 on a 16-lane SIMD) at 2.4 GHz = 43 ns: the floor of this formulation",
+                          "frac": (26 * 4 / 2.4) / (t_sr * 1e9 / ticks) if ticks and t_sr > 0 else None,
                           "ranking_steps_per_s": steps / t_sr if t_sr > 0 else None,
                           "share_of_generation": t_sr / (dt_max) if dt_max > 0 else None, "traffic": None}
         metric = "candidate-evals/sec, ISRES n=%d pop=%d, %d inequality constraints" % (n, pop, ncon)

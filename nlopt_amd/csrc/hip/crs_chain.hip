@@ -312,9 +312,16 @@ extern "C" size_t nla_crs_chain_ctrl_bytes(int K, int nW)
     return sizeof(chain_ctrl) + sizeof(double) * 2 * (size_t) K + sizeof(uint32_t) * (2 * (size_t) K + (size_t) nW + 8);
 }
 
+static bool chain_vec2(int n, int ld)
+{
+    static int force1 = -1;              /* experiment switch: NLA_CHAIN_VEC1=1 -> 64-coordinate chunks everywhere */
+    if (force1 < 0) { const char *s = getenv("NLA_CHAIN_VEC1"); force1 = (s && atoi(s) > 0) ? 1 : 0; }
+    return !force1 && (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+}
+
 extern "C" int nla_crs_chain_chunks(int n, int ld)
 {
-    const bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    const bool vec2 = chain_vec2(n, ld);
     const int cpw = vec2 ? 128 : 64;
     return (n + cpw - 1) / cpw;
 }
@@ -339,7 +346,7 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
         for (int j = 0; j < nW; ++j) { L.W[j] = W[j]; L.Wf[j] = Wf[j]; }
         W = nullptr; Wf = nullptr;
     }
-    const bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    const bool vec2 = chain_vec2(n, ld);
     const int chunks = nla_crs_chain_chunks(n, ld);
     const dim3 grid((unsigned) ((long) chunks * K));
     chain_ctrl *c = (chain_ctrl *) ctrl;

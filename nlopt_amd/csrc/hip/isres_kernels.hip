@@ -169,14 +169,34 @@ __global__ __launch_bounds__(64) void isres_bits_kernel(const uint32_t *__restri
  * the stream sweep i emits, so the pop sweeps are pop chained stages: stage i handles its j-th
  * compare two ticks after stage i-1 handled its (j+1)-th.  Lane = stage (64 consecutive sweeps per
  * wavefront, elements move lane-to-lane by DPP wave shift); wavefront u hands its output stream to
- * wavefront u+1 through a global buffer, 64 elements per publication (agent-scope release /
- * acquire on a progress counter).  Units are claimed by ticket so that a unit only ever waits for
- * units that are already running.  3*pop ticks instead of pop^2 steps.
+ * wavefront u+1 through a global buffer, 64 elements per publication (device-coherent stores, then a
+ * progress counter).  Units are claimed by ticket so that a unit only ever waits for units that are
+ * already running.  3*pop ticks instead of pop^2 steps.
+ *
+ * Every tick is on the serial path of the whole pipeline (pop + 2 sweeps + 63 units ticks end to end), so
+ * the tick is ~25 straight-line instructions with no per-lane phase logic:
+ *  - sentinels instead of phases: a stage starts with the carry "-inf" (all zero: never greater than
+ *    anything, so it is emitted untouched and the first real element becomes the carry — the reference's
+ *    first read), and the unit's input is followed by "+inf" elements (nothing is greater: every stage
+ *    emits its carry when the first one arrives — the flush — and then passes +inf on).  Compares that
+ *    involve a sentinel never swap, whatever their bit;
+ *  - the unit's 64 inputs of a block sit one per lane and move down one lane per tick (wave_shl), lane 0
+ *    always holds the current one and the DPP shift that brings the left neighbour's output leaves it
+ *    there (`old` operand); lane 63's outputs are collected the same way, one lane per tick;
+ *  - the u < PF bits of a lane's next 64 ticks are one 64-bit window cut from two row words once per
+ *    block (the cut position 63 - 2 lane (mod 64) never changes); a tick tests bit k of it, k static.
  * ---------------------------------------------------------------------------------------------- */
-__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v)
+#define SR_DPP_SHL1 0x130               /* wave_shl:1 — lane i reads lane i+1 */
+#define SR_DPP_SHR1 0x138               /* wave_shr:1 — lane i reads lane i-1 */
+#define SR_PINF_LO 0xFFFFF000u
+#define SR_PINF_HI 0x0FFFFF00u
+__device__ __forceinline__ uint32_t sr_dpp(uint32_t old, uint32_t src, const int ctrl_is_shl)
 {
-    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return ctrl_is_shl ? (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) src, SR_DPP_SHL1, 0xf, 0xf, false)
+                       : (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) src, SR_DPP_SHR1, 0xf, 0xf, false);
 }
+__device__ __forceinline__ uint64_t sr_ld(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sr_st(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(64) void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__restrict__ streams,
                                                               int *__restrict__ progress, const uint64_t *__restrict__ bits,
@@ -193,75 +213,65 @@ __global__ __launch_bounds__(64) void isres_stochrank_kernel(int64_t pop, int64_
     uint64_t *out = streams + (size_t) (unit + 1) * (size_t) pop;
     int *prog_in = progress + unit, *prog_out = progress + unit + 1;
     const uint64_t *brow = bits + (size_t) (active ? stage : 0) * (size_t) rowwords;
-    uint32_t c_lo = 0, c_hi = 0, o_lo = 0, o_hi = 0;         /* carry and output element of this stage, as two words */
-    uint64_t inb = 0, outb = 0;
-    uint64_t cur0 = 0, cur1 = 0, nxt0 = 0, nxt1 = 0;
-    int curw = 0;                           /* 64-bit word index (within the row) of cur0 */
-    uint32_t swapped = 0;
-    const int ipop = (int) pop;
-    const int t_first = 2 * lane;           /* tick of this stage's first input */
-    const int nticks = ipop + 128;
-    const bool lane0 = lane == 0;
-    auto wordidx = [&](int t) {             /* row word holding the step this lane handles at tick t */
-        int j = t - t_first - 1;
-        if (j < 0) j = 0;
-        int w = j >> 6;
-        if (w > (int) rowwords - 1) w = (int) rowwords - 1;
-        return w;
-    };
-    if (active) { const int w = wordidx(0); nxt0 = brow[w]; nxt1 = brow[w + 1 < rowwords ? w + 1 : w]; }
-    for (int t = 0; t < nticks; ++t) {
-        if ((t & 63) == 0) {
-            /* bit window for ticks [t, t+64): loaded one period ago; prefetch the next one */
-            cur0 = nxt0; cur1 = nxt1; curw = wordidx(t);
-            if (active) { const int w = wordidx(t + 64); nxt0 = brow[w]; nxt1 = brow[w + 1 < rowwords ? w + 1 : w]; }
-            if (t < ipop) {                 /* next 64 inputs of this unit */
-                const int need = t + 64 < ipop ? t + 64 : ipop;
-                if (lane == 0) while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                inb = (t + lane < ipop) ? in[t + lane] : 0;
-            }
+    const int ipop = (int) pop, rw1 = (int) rowwords - 1;
+    const int half = lane >> 5;                 /* row word of the window of block b starts at word b - 1 - half */
+    const int cut = (63 - 2 * lane) & 63;       /* ... at this bit (1..63, never 0) */
+    uint32_t c_lo = 0, c_hi = 0, o_lo = 0, o_hi = 0;         /* carry and output element of this stage ("-inf"), as two words */
+    uint32_t vin_lo = 0, vin_hi = 0, ob_lo = 0, ob_hi = 0;   /* the unit's inputs / outputs of the current block, one per lane */
+    uint32_t swv = 0;                                        /* bit 31: this stage swapped at least once */
+    const uint32_t amask = active ? 0x80000000u : 0u;
+    auto clampw = [&](int w) { return w < 0 ? 0 : (w > rw1 ? rw1 : w); };
+    uint64_t wa = brow[clampw(-1 - half)], wb = brow[clampw(0 - half)], wp = brow[clampw(1 - half)];
+    const int nblk = (ipop + 63) / 64 + 2;      /* the last output leaves lane 63 at tick pop + 126 */
+    for (int b = 0; b < nblk; ++b) {
+        const int tb = b * 64;
+        /* u < PF bits of ticks tb .. tb+63 of this stage: row bits tb - 2 lane - 1 + k */
+        const uint64_t win = (wa >> cut) | (wb << (64 - cut));
+        wa = wb; wb = wp;
+        wp = brow[clampw(b + 2 - half)];        /* (used two blocks from now: the load has a whole block to land) */
+        /* the unit's next 64 inputs; past the end of the stream: +inf */
+        uint64_t inb = ((uint64_t) SR_PINF_HI << 32) | SR_PINF_LO;
+        if (tb < ipop) {
+            const int need = tb + 64 < ipop ? tb + 64 : ipop;
+            if (lane == 0) while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (tb + lane < ipop) inb = sr_ld(in + tb + lane);
         }
-        /* One tick, branch-free (the lanes of a wavefront are in different phases of their sweeps; every tick is on the
-         * serial path of the whole pipeline, so it is kept to straight-line 32-bit code).
-         * input: lane 0 from the unit's input stream, the others from their left neighbour's output */
-        const int sel = t & 63;
-        const uint32_t in0lo = __builtin_amdgcn_readlane((uint32_t) inb, sel), in0hi = __builtin_amdgcn_readlane((uint32_t) (inb >> 32), sel);
-        uint32_t x_lo = dpp_wave_shr1(o_lo), x_hi = dpp_wave_shr1(o_hi);
-        x_lo = lane0 ? in0lo : x_lo;
-        x_hi = lane0 ? in0hi : x_hi;
-        const int rel = t - t_first;        /* 0: first input, 1..pop-1: compare steps, pop: flush */
-        const bool is_first = rel == 0;
-        const bool is_cmp = (unsigned) (rel - 1) < (unsigned) (ipop - 1);
-        /* u < PF of this step (isres.c:210): bit j of the sweep's row */
-        const int j = rel - 1;
-        const uint64_t bw = ((j >> 6) != curw) ? cur1 : cur0;
-        const bool ulow = (bw >> (j & 63)) & 1;
-        const bool bothzero = (int32_t) (c_hi & x_hi) < 0;
-        const bool gtf = (c_lo >> 12) > (x_lo >> 12);                            /* fval[carry] > fval[x]   (isres.c:213) */
-        const bool gtp = (c_hi & 0x0FFFFF00u) > (x_hi & 0x0FFFFF00u);            /* penalty[carry] > penalty[x]  (:220) */
-        const bool swap = is_cmp && active && ((ulow || bothzero) ? gtf : gtp);  /* :211-212 */
-        swapped |= (uint32_t) swap;
-        const bool take = is_first || (is_cmp && !swap);                         /* the input becomes the carry */
-        o_lo = swap ? x_lo : c_lo;          /* emitted: the smaller of the pair, or (flush / idle) the carry */
-        o_hi = swap ? x_hi : c_hi;
-        c_lo = take ? x_lo : c_lo;
-        c_hi = take ? x_hi : c_hi;
-        /* lane 63 emits output o = t - 127 of the unit's output stream */
-        const int o = t - 127;
-        if (o >= 0 && o < ipop) {
-            const uint32_t olo = __builtin_amdgcn_readlane(o_lo, 63), ohi = __builtin_amdgcn_readlane(o_hi, 63);
-            if (lane == (o & 63)) outb = ((uint64_t) ohi << 32) | olo;
-            if ((o & 63) == 63 || o == ipop - 1) {
-                const int base = o - (o & 63);
-                if (base + lane <= o) out[base + lane] = outb;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(prog_out, o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vin_lo = (uint32_t) inb; vin_hi = (uint32_t) (inb >> 32);
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t wcur = h ? (uint32_t) (win >> 32) : (uint32_t) win;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                /* input: lane 0 from the unit's input block, the others from their left neighbour's output of the previous tick */
+                const uint32_t x_lo = sr_dpp(vin_lo, o_lo, 0), x_hi = sr_dpp(vin_hi, o_hi, 0);
+                vin_lo = sr_dpp(vin_lo, vin_lo, 1); vin_hi = sr_dpp(vin_hi, vin_hi, 1);
+                /* by fval if u < PF (bit k of the window: isres.c:210) or both penalties are zero (bit 31 of both high words),
+                 * else by penalty (:211-212, :220) — sign bits instead of booleans: the tick stays straight-line integer code */
+                const uint32_t usef = (wcur << (31 - k)) | (c_hi & x_hi);
+                const int32_t df = (int32_t) (x_lo >> 12) - (int32_t) (c_lo >> 12);                    /* < 0: fval[carry] > fval[x]   (:213) */
+                const int32_t dp = (int32_t) (x_hi & 0x0FFFFF00u) - (int32_t) (c_hi & 0x0FFFFF00u);    /* < 0: penalty[carry] > penalty[x] */
+                const int32_t d = ((int32_t) usef < 0) ? df : dp;
+                const bool swap = active && d < 0;
+                swv |= (uint32_t) d & amask;
+                o_lo = swap ? x_lo : c_lo;          /* emitted: the smaller of the pair */
+                o_hi = swap ? x_hi : c_hi;
+                c_lo = swap ? c_lo : x_lo;          /* kept: the larger */
+                c_hi = swap ? c_hi : x_hi;
+                /* lane 63's outputs move down one lane per tick: after tick tb + 62 lane l holds output tb - 128 + l of the unit */
+                ob_lo = sr_dpp(o_lo, ob_lo, 1); ob_hi = sr_dpp(o_hi, ob_hi, 1);
+                if (k == 30) {
+                    if (h == 1 && tb >= 128) {
+                        const int base = tb - 128;
+                        if (base + lane < ipop) sr_st(out + base + lane, ((uint64_t) ob_hi << 32) | ob_lo);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         /* the elements have landed before the count says so */
+                        if (lane == 0) __hip_atomic_store(prog_out, base + 64 < ipop ? base + 64 : ipop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
         }
     }
-    if (active) swapped_out[stage] = (uint8_t) swapped;
+    if (active) swapped_out[stage] = (uint8_t) (swv >> 31);
 }
 
 /* final order: irank[pos] = individual of the element at pos */

@@ -54,3 +54,35 @@ def test_bench_line_has_the_contracts_keys(argv):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, (k, cb)
     assert cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists(EMU), reason="emulated library not built")
+def test_bench_line_at_two_ranks_reports_replicas_and_the_one_job_config5_block_apart():
+    """--gpus 2 --workload crs: value = the sum over independent replicas (scaling weak); BASELINE config 5 — the one CRS job with
+    multi-rank work in it (sharded initial population, all-gathered) — stands in its own block.  Two gloo ranks
+    over the emulated device layer, toy sizes."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = ["--gpus", "2", "--n", "16", "--pop", "200", "--steps", "2", "--warmup", "1", "--evals-per-step", "100", "--config5-pop", "300", "--config5-n", "12",
+            "--headline-only", "--no-cpu-baseline"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", SNIPPET % (ROOT, EMU, argv)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so_, se) in zip(procs, outs):
+        assert p.returncode == 0, so_[-2000:] + se[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # rank 0 prints, once
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "2 independent replicas" in d["config"]["workload"]
+    c5 = d["config5_one_job"]
+    assert "error" not in c5, c5
+    assert "ONE job over 2 ranks" in c5["workload"] and "pop=300" in c5["workload"]
+    assert c5["init_wall_s"] > 0 and c5["chain_evals_per_s"] > 0 and c5["allgather_GB_received_per_rank"] > 0
+    assert "not part of value" in d["replicas_note"]
