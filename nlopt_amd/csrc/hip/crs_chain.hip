@@ -41,8 +41,12 @@
  * without the L2 write-back / invalidate an agent-scope release / acquire pair costs per chunk and per pick (+5 %: 36.4 k).
  * Tried and dropped: agent-coherent (sc1) loads of the forwarded rows, a back-off in the polling loops, 8x larger Vitter batches
  * (the digest kernel runs under the gather on a quarter of the CUs: +2 %, kept), polling intervals 4 / 32 / 127 (no change).
- * What does matter: the U rows in flight must stay in registers; a data-dependent `continue`, a conditional fence or NO fence at
- * all after the polling loop sends them to scratch (1.5 KB per lane) and costs 45 %.
+ * What does matter: no scratch memory.  The worst-row lists travel as a 1.5 KB by-value kernel argument; indexing that argument
+ * by name with a run-time j makes the compiler copy it to private memory — depending on innocuous details of the surrounding
+ * control flow — and 1.5 KB of scratch per lane costs 45 % (fewer workgroups resident).  The kernel therefore reads the lists
+ * through the kernarg segment pointer (first argument, offset 0) and never by name.
+ * A waiting slot also stops waiting when the chain can no longer reach its row (see the polling loop): the full serialisation
+ * behind a pick that nobody overwrites was the larger part of the wait time at a 9 % rejection rate.
  */
 #include "crs_common.h"
 #include <stdlib.h>
@@ -52,7 +56,7 @@
 
 /* control block of one launch (device memory, zeroed before the launch except `ticket`, which only grows) */
 struct chain_ctrl {
-    uint32_t ticket, lock, next, halt, naccept, wp, nextra, pad;
+    uint32_t ticket, lock, next, halt, naccept, wp, nextra, pk;     /* pk = next | (next - wp) << 16: what a waiting slot polls */
     double xf[CH_EXTRA]; int64_t xrow[CH_EXTRA];
 };
 /* behind the control block: fv[2K] doubles (fT, fM of every slot, for the resolver — the status records themselves may live in
@@ -99,8 +103,9 @@ __device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate
             j += (kind == 1) ? 1u : 2u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             st_agent(&c->next, j);
+            st_agent(&c->pk, j | ((j - c->wp) << 16));
         }
-        if (c->halt) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); st_agent(&c->next, (uint32_t) K + 2u); }
+        if (c->halt) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); st_agent(&c->next, (uint32_t) K + 2u); st_agent(&c->pk, 0xffffffffu); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(&c->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");       /* unlock before the re-check (the arriving side: publish, fence, try the lock) */
@@ -111,13 +116,18 @@ __device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate
 
 template <int VEC, int U, int WAVES, int OBJ>
 __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
+    const chain_lists L_first_kernel_argument,  /* read through the kernarg segment below, never by name: indexing the by-value copy
+                                                 * with a run-time j makes the compiler move all 1.5 KB of it to scratch memory */
     int n, int ld, const double *__restrict__ X, int64_t i0, double f_best, const int32_t *__restrict__ jn_ring,
     const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, const uint32_t *__restrict__ words_ring,
     uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *__restrict__ Wd, const double *__restrict__ Wfd, int nW,
     int slot_mask, int chunks, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX,
     double *__restrict__ TM, chain_ctrl *__restrict__ ctrl, uint32_t ticket_base, nla_crs_slot_status *__restrict__ status,
-    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, const chain_lists L)
+    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap)
 {
+    typedef const __attribute__((address_space(4))) chain_lists *kernarg_lists;
+    const kernarg_lists Lk = (kernarg_lists) __builtin_amdgcn_kernarg_segment_ptr();       /* explicit arguments start at offset 0 */
+    (void) L_first_kernel_argument;
     typedef typename VecT<VEC>::T V;
     static_assert(U <= 64, "one lane per row of a batch");
     __shared__ V sacc[64];
@@ -130,8 +140,8 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     double *fv = reinterpret_cast<double *>(ctrl + 1);
     uint32_t *done = reinterpret_cast<uint32_t *>(fv + 2 * (size_t) K), *evald = done + K, *rowstate = evald + K;
-    const int64_t *W = L.inl ? L.W : Wd;
-    const double *Wf = L.inl ? L.Wf : Wfd;
+    const int64_t *W = Lk->inl ? (const int64_t *) Lk->W : Wd;
+    const double *Wf = Lk->inl ? (const double *) Lk->Wf : Wfd;
     if (threadIdx.x == 0) { s_ticket = (int) (atomicAdd(&ctrl->ticket, 1u) - ticket_base); s_nrec = 0; }
     __syncthreads();
     const int wg = s_ticket;
@@ -207,12 +217,16 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
                     for (;;) {
                         rs = ld_agent(&rowstate[j]);
                         if (rs) break;
-                        if (ld_agent(&ctrl->next) >= (uint32_t) a) { rs = ld_agent(&rowstate[j]); break; }
+                        /* ... or cannot touch it any more: rows are overwritten in list order, one per accepted block at most, so
+                         * with wp rows gone and a - next blocks still to be decided before this slot, row j >= wp + (a - next)
+                         * stays as it is */
+                        const uint32_t pk = ld_agent(&ctrl->pk);         /* next | (next - wp) << 16, one word */
+                        /* next >= a  or  next - wp >= a - j, as one branch: both differences negative <=> keep waiting */
+                        if ((int32_t) (((pk & 0xffffu) - (uint32_t) a) & ((pk >> 16) - (uint32_t) (a - j))) >= 0) { rs = ld_agent(&rowstate[j]); break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
                     /* TX / TM are uncached memory (nla_dev_malloc_uncached): nothing stale to drop, so no agent-scope acquire
-                     * (= an L2 invalidate per pick) here.  The wavefront-scope fence orders the loads below after the poll —
-                     * and keeps the U rows in flight in registers: without any fence at this point the compiler spills them */
+                     * (= an L2 invalidate per pick) here.  The wavefront-scope fence orders the loads below after the poll */
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     /* a writer at or behind this slot's own block does not count: the row is read as it is before that */
                     int pj = 0, kind = 0;                    /* kind 0: the row as it is (no block before this one wrote it) */
@@ -353,9 +367,9 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
     /* everything but the ticket counter starts from zero */
     hipError_t e = hipMemsetAsync((char *) ctrl + sizeof(uint32_t), 0, nla_crs_chain_ctrl_bytes(K, nW) - sizeof(uint32_t), st);
     if (e != hipSuccess) return (int) e;
-#define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, n, ld, X, i0, f_best, jn_ring, \
+#define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
         pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
-        fwcnt, fwrec, fwcap, L)
+        fwcnt, fwrec, fwcap)
 #define CHAIN_SHAPE(O)                                                                   \
     if (vec2) {                                                                          \
         if (n >= 2048) CHAIN(2, 32, 8, O); else if (n >= 512) CHAIN(2, 16, 4, O); else CHAIN(2, 16, 2, O); \
