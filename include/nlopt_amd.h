@@ -210,7 +210,7 @@ int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t 
  * the chain it replays (a stop, or a value landing among the worst rows twice, are not modelled on the device).
  * ctrl: nla_crs_chain_ctrl_bytes(K, nW) bytes of device memory, zero before the first launch (the launcher re-zeroes all of it
  * but its ticket counter); ticket_base = workgroups launched by earlier calls on this ctrl = sum of K * nla_crs_chain_chunks.
- * w_on_host != 0 (nW <= 96): W / Wf are host arrays and travel as kernel arguments.  f_best = f of row i0.
+ * w_on_host != 0 (nW <= 128): W / Wf are host arrays and travel as kernel arguments.  f_best = f of row i0.
  * TX, TM and ctrl MUST be nla_dev_malloc_uncached memory: the workgroups hand trial points to each other through them; and
  * ld % 16 == 0 with TX / TM 128-byte aligned (no cache line shared by two slots) — the launcher refuses anything else. */
 size_t nla_crs_chain_ctrl_bytes(int K, int nW);
@@ -233,7 +233,7 @@ int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const 
                      const double *lb, const double *ub, double *fT_ring, double *fM_ring,
                      nla_crs_slot_status *status, void *stream);
 
-/* nla_k_crs_advance / nla_k_crs_finish / nla_k_crs_commit with their small per-pass lists (W, t_in, the commit list; at most 96
+/* nla_k_crs_advance / nla_k_crs_finish / nla_k_crs_commit with their small per-pass lists (W, t_in, the commit list; at most 128
  * entries each) given as HOST arrays: the lists travel as kernel arguments, so a pass needs no host-to-device copy in front of it
  * (one dependent stream operation less).  Everything else as in the pointer forms. */
 int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,

@@ -246,9 +246,10 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     if (S->host_eval) S->Kmax = 1;
     S->forward = pb->forward && ops->chain && pb->obj >= 0 && S->Kmax > 1;
     if (S->forward && S->Kmax > 256) S->Kmax = 256;
-    /* measured (MI355X, n = 4096, N = 1e5): 28 us per slot at 48 slots per launch, 32 at 128, 40 at 256 (a slot deep in the window
-     * has many picks among the worst rows ahead of it, each one a wait); 48 = 6 full rounds of workgroups on 256 CUs */
-    if (S->forward && pb->max_spec <= 0 && S->Kmax > 48) S->Kmax = 48;
+    /* measured (MI355X, n = 4096, N = 1e5, bench.py --max-spec): 39.9 k evals/s at 40 slots per launch, 40.7 k at 48, 41.6 k at 64,
+     * 42.5 k at 96, 43.0 k at 128, 43.1 k at 160 / 192, 42.3 k at 256 — a longer window amortises the launch ramp and the 53 us of
+     * host turnaround between windows; past 128 the slots recomputed because a value landed among the worst rows twice eat the gain */
+    if (S->forward && pb->max_spec <= 0 && S->Kmax > 128) S->Kmax = 128;
     S->runlen = 4.0;
     rs->ops = ops; rs->e = e; rs->pb = &S->pb; rs->x = x; rs->minf = minf;
     rs->need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);

@@ -20,7 +20,7 @@
 
 #define INIT_CHUNK_WORDS (1ULL << 28)      /* 1 GiB of stream words per init pass */
 #define KCAP 1024                          /* slot ring (power of two) */
-#define NLA_KARG_MAX 96                    /* list length that still travels as kernel arguments (hip/crs_kernels.hip NLA_KA_MAX) */
+#define NLA_KARG_MAX 128                   /* list length that still travels as kernel arguments (hip/crs_kernels.hip NLA_KA_MAX) */
 #define ROWPAD 64                          /* spare rows behind X / F: the init all-gather wants equal blocks per rank (world <= 64) */
 
 typedef struct {

@@ -62,7 +62,7 @@ struct chain_ctrl {
 /* behind the control block: fv[2K] doubles (fT, fM of every slot, for the resolver — the status records themselves may live in
  * pinned host memory), then the u32 arrays done[K], evald[K], rowstate[nW] */
 
-#define NLA_KA_MAX 96                    /* list length that still travels as kernel arguments */
+#define NLA_KA_MAX 128                   /* list length that still travels as kernel arguments (2 KB of the 4 KB there are) */
 struct chain_lists { int inl; int64_t W[NLA_KA_MAX]; double Wf[NLA_KA_MAX]; };
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void crs_vitter_kernel(int n, int64_t N, const 
  * ---------------------------------------------------------------------------------------------- */
 /* The small per-pass lists can travel as KERNEL ARGUMENTS instead of through a host-to-device copy in front of the pass
  * (one dependent stream operation and its gap less per pass): inl != 0 -> use these, else the device pointers. */
-#define NLA_KA_MAX 96
+#define NLA_KA_MAX 128
 struct crs_lists { int inl; int32_t t_in[NLA_KA_MAX]; int64_t W[NLA_KA_MAX]; };
 struct crs_commits { int inl; int32_t slot[NLA_KA_MAX], kind[NLA_KA_MAX]; int64_t row[NLA_KA_MAX]; };
 
@@ -418,7 +418,7 @@ extern "C" int nla_k_crs_commit(int n, int ld, double *X, const double *TX, cons
     return 0;
 }
 
-/* the same with the commit list given as HOST arrays (ncommit <= 96): it travels as kernel arguments, no copy to the device */
+/* the same with the commit list given as HOST arrays (ncommit <= 128): it travels as kernel arguments, no copy to the device */
 extern "C" int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
                                      const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *stream)
 {
@@ -459,7 +459,7 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
     return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, lb, ub,
                               TX, variant, L, stream);
 }
-/* the same with W (nW <= 96) and t_in (K <= 96) given as HOST arrays: they travel as kernel arguments */
+/* the same with W (nW <= 128) and t_in (K <= 128) given as HOST arrays: they travel as kernel arguments */
 extern "C" int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                                       const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                                       uint64_t first_block, int K, const int64_t *h_W, int nW,
@@ -538,7 +538,7 @@ extern "C" int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t
     return crs_finish_launch(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring,
                              status, L, stream);
 }
-/* the same with t_in (K <= 96) given as a HOST array */
+/* the same with t_in (K <= 128) given as a HOST array */
 extern "C" int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
                                      const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                                      const int32_t *h_t_in, const int32_t *t_out, int slot_mask,

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
     LB_EVAL(0, resume_first, fval);
     if (P.ftrace && tid == 0 && nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + nevals] = fval;
     ++nevals; ++c.nfg;
-    if (!EXT && P.abort) tmo = *(const volatile int32_t *) P.abort == 100;
+    if (!EXT && P.abort) tmo = lb_poll_abort(P.abort) == 100;
     if (tmo) c.iterm = 100;                                                  /* plis.c:263 */
 
     while (c.iterm != 100) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
             umax = lb_block_max(um, S);
         }
         c.kd = kd;
-        if (!EXT && P.abort) { const int ab = *(const volatile int32_t *) P.abort; forced = ab == -999; tmo = ab == 100; }
+        if (!EXT && P.abort) { const int ab = lb_poll_abort(P.abort); forced = ab == -999; tmo = ab == 100; }
         lb_pyfut1(n, fval, &fo, umax, gmax, xstop, &ls, forced, nevals, tolg, &c);
         if (c.iterm != 0) break;
         if (tmo) { c.iterm = 100; break; }                                   /* plis.c:273 */

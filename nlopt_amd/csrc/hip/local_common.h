@@ -202,4 +202,17 @@ __device__ __forceinline__ double lb_objgrad(int n, const double *x, double *g, 
     return f;
 }
 
+
+/* the host's abort flag (pinned memory: 0, 100 = time limit, -999 = forced stop), read ONCE per poll for the whole workgroup: the
+ * flag changes while the kernel runs, and threads that read it separately could see different values, leave a loop at
+ * different iterations and hang at the next barrier */
+__device__ __forceinline__ int lb_poll_abort(const int32_t *flag)
+{
+    __shared__ int s_abort_seen;
+    __syncthreads();
+    if (threadIdx.x == 0) s_abort_seen = *(const volatile int32_t *) flag;
+    __syncthreads();
+    return s_abort_seen;
+}
+
 #endif

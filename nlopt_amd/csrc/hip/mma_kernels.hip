@@ -68,7 +68,7 @@ __global__ __launch_bounds__(LB_T) void mma_batch_kernel(int n, int ld, int coun
         __syncthreads();                                                                                                 \
         fcur = E.EF[inst];                                                                                               \
     } else fcur = lb_objgrad<EXT ? 0 : OBJ>(n, XPT, GPT, S, oscratch, P.exact, XB, P.sign)
-#define MMA_POLL() do { if (!EXT && P.abort) { const int ab_ = *(const volatile int32_t *) P.abort; forced = ab_ == -999; tmo = ab_ == 100; } } while (0)
+#define MMA_POLL() do { if (!EXT && P.abort) { const int ab_ = lb_poll_abort(P.abort); forced = ab_ == -999; tmo = ab_ == 100; } } while (0)
 
     if (EXT) { forced = E.forced; tmo = E.timeout; }
     if (EXT && E.resume) {

@@ -205,8 +205,11 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
     if (c->ev.kind == NLA_EVAL_DEVICE) {
         if ((rc = launch(c, count, prm, NULL))) return rc;
         nla_event_record(c->ev1, c->st);
-        if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
+        /* watch first, copy afterwards: a device-to-host copy into pageable memory (the caller's result record may live on its
+         * stack) does not return before the kernel has finished, and nobody would raise the abort flag meanwhile */
         if ((rc = wait_watching(c, stop))) return rc;
+        if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
+        if ((rc = nla_stream_sync(c->st))) return rc;
     } else {
         nla_local_ext E = c->ext;
         const size_t rowb = sizeof(double) * (size_t) c->n;
