@@ -8,6 +8,7 @@
  * (its population default, stream consumption and results are those of the reduced dimension) through a wrapper
  * objective — a host function, so such runs take the host-callback path even for a registered device objective. */
 #include "nla_internal.h"
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -86,6 +87,17 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
                                   nlopt_get_param(opt, "tolg", 0.));
     case NLOPT_LD_MMA:                                                                   /* optimize.c:795-834 */
         return nla_mma_minimize(opt, (int) n, opt->f, opt->f_data, opt->lb, opt->ub, x, minf, &stop);
+    case NLOPT_LN_COBYLA: {                                                              /* optimize.c:836-851: a host algorithm (cobyla_host.c) */
+        nlopt_result ret;
+        int freedx = 0;
+        if (!opt->dx) {
+            freedx = 1;
+            if (nlopt_set_default_initial_step(opt, x) != NLOPT_SUCCESS) { nla_set_errmsg(opt, "failed to allocate initial step"); return NLOPT_OUT_OF_MEMORY; }
+        }
+        ret = nla_cobyla_minimize(n, opt->f, opt->f_data, opt->m, opt->fc, opt->p, opt->h, opt->lb, opt->ub, x, minf, &stop, opt->dx);
+        if (freedx) { free(opt->dx); opt->dx = NULL; }
+        return ret;
+    }
     case NLOPT_G_MLSL: case NLOPT_G_MLSL_LDS: case NLOPT_GN_MLSL: case NLOPT_GD_MLSL:
     case NLOPT_GN_MLSL_LDS: case NLOPT_GD_MLSL_LDS: {                                    /* optimize.c:748-793 */
         nlopt_opt local_opt = opt->local_opt;
@@ -181,7 +193,8 @@ static void fix_expand(unsigned n, double *v, const double *lb, const double *ub
 static int fix_applies(const nlopt_opt opt)                                           /* elimdim_wrapcheck, restricted to what is provided */
 {
     if (fix_free_count(opt->n, opt->lb, opt->ub) == opt->n) return 0;
-    return opt->algorithm == NLOPT_GN_CRS2_LM || opt->algorithm == NLOPT_GN_ISRES || opt->algorithm == NLOPT_GN_ESCH;
+    return opt->algorithm == NLOPT_GN_CRS2_LM || opt->algorithm == NLOPT_GN_ISRES || opt->algorithm == NLOPT_GN_ESCH ||
+           opt->algorithm == NLOPT_LN_COBYLA;
 }
 
 /* minimise on the reduced problem; x is shrunk on entry and expanded on return */
@@ -237,11 +250,27 @@ static nlopt_result minimize_fixed_eliminated(nlopt_opt opt, double *x, double *
     return ret;
 }
 
+/* memoize_func (optimize.c:450-483): the objective, remembering the best value seen inside the box */
+typedef struct { nlopt_func f; void *f_data; const double *lb, *ub; double minf; double *bestx; } best_seen;
+static double best_seen_objective(unsigned n, const double *x, double *grad, void *p)
+{
+    best_seen *d = (best_seen *) p;
+    const double val = d->f(n, x, grad, d->f_data);
+    unsigned i, feasible = 1;
+    for (i = 0; i < n; ++i) {
+        if (d->lb && x[i] < d->lb[i]) feasible = 0;
+        if (d->ub && x[i] > d->ub[i]) feasible = 0;
+    }
+    if (feasible && val < d->minf) { d->minf = val; memcpy(d->bestx, x, sizeof(double) * n); }
+    return val;
+}
+
 nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
 {
     nlopt_func f; void *f_data; nlopt_precond pre;
     flip_data fd;
-    int maximize;
+    best_seen mm;
+    int maximize, memo = 0;
     nlopt_result ret;
     nla_unset_errmsg(opt);
     if (!opt || !opt_f || !opt->f) { if (opt) nla_set_errmsg(opt, "NULL args to nlopt_optimize"); return NLOPT_INVALID_ARGS; }
@@ -263,7 +292,23 @@ nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
         opt->stopval = -opt->stopval;
         opt->maximize = 0;
     }
+    if ((memo = opt->algorithm == NLOPT_LN_COBYLA && opt->m == 0 && opt->p == 0)) {
+        /* the reference returns the best FEASIBLE point any objective call of an unconstrained COBYLA run saw, not the
+         * algorithm's own answer (memoize_func, optimize.c:450-508,1026-1036,1064-1071) */
+        mm.f = opt->f; mm.f_data = opt->f_data; mm.lb = opt->lb; mm.ub = opt->ub; mm.minf = DBL_MAX;
+        mm.bestx = (double *) malloc(sizeof(double) * (opt->n ? opt->n : 1));
+        if (!mm.bestx) { nla_set_errmsg(opt, "out of memory"); memo = 0; ret = NLOPT_OUT_OF_MEMORY; goto restore; }
+        if (x) memcpy(mm.bestx, x, sizeof(double) * opt->n);       /* (the reference leaves it uninitialised) */
+        opt->f = best_seen_objective; opt->f_data = &mm;
+    }
     ret = fix_applies(opt) ? minimize_fixed_eliminated(opt, x, opt_f) : minimize_dispatch(opt, x, opt_f);
+    if (memo) {
+        memcpy(x, mm.bestx, sizeof(double) * opt->n);
+        free(mm.bestx);
+        *opt_f = mm.minf;
+        opt->f = mm.f; opt->f_data = mm.f_data;
+    }
+restore:
     if (maximize) {
         opt->maximize = maximize;
         opt->dev_sign = 0;

@@ -98,6 +98,13 @@ static int lp_significant(double sum, double sumabs, double c1, double c2)
     const double acca = sumabs + fabs(sum) * c1, accb = sumabs + fabs(sum) * c2;
     return sumabs < acca && acca < accb;
 }
+/* the same test as the reference writes it where a sum is to be ZEROED (e.g. cobyla.c:1424): not the negation of the above when
+ * a NaN is involved — a NaN sum is noise for neither form, and runs that have gone NaN must still match the reference's */
+static int lp_noise(double sum, double sumabs, double c1, double c2)
+{
+    const double acca = sumabs + fabs(sum) * c1, accb = sumabs + fabs(sum) * c2;
+    return sumabs >= acca || acca >= accb;
+}
 
 /* rotate columns k, k+1 of Z so that active constraint k+1 takes position k (cobyla.c:1524-1551 and :1628-1655: the same
  * operation written twice in the reference): moves the constraint at position `from` to the end of the active set */
@@ -183,7 +190,7 @@ static nlopt_result cob_trust_lp(lp_state *S, int *ifull)
                 double sp = 0., spabs = 0.;
                 double *zk = ZC(S, k);
                 for (i = 0; i < n; ++i) { temp = zk[i] * S->dxnew[i]; sp += temp; spabs += fabs(temp); }
-                if (!lp_significant(sp, spabs, .1, .2)) sp = 0.;
+                if (lp_noise(sp, spabs, .1, .2)) sp = 0.;
                 if (tot == 0.) tot = sp;
                 else {
                     double *zkp = ZC(S, k + 1), alpha, beta;
@@ -319,7 +326,7 @@ static nlopt_result cob_trust_lp(lp_state *S, int *ifull)
             double zdotw = 0., zdwabs = 0.;
             const double *zk = ZC(S, k);
             for (i = 0; i < n; ++i) { temp = zk[i] * S->dxnew[i]; zdotw += temp; zdwabs += fabs(temp); }
-            if (!lp_significant(zdotw, zdwabs, .1, .2)) zdotw = 0.;
+            if (lp_noise(zdotw, zdwabs, .1, .2)) zdotw = 0.;
             S->vmultd[k] = zdotw / S->zdota[k];
             if (k >= 1) { const double *ak = AC(S, S->iact[k]); for (i = 0; i < n; ++i) S->dxnew[i] -= S->vmultd[k] * ak[i]; }
         }
@@ -331,7 +338,7 @@ static nlopt_result cob_trust_lp(lp_state *S, int *ifull)
             const double *ak = AC(S, id);
             double sum = resmax - S->b[id], sumabs = resmax + fabs(S->b[id]);
             for (i = 0; i < n; ++i) { temp = ak[i] * S->dxnew[i]; sum += temp; sumabs += fabs(temp); }
-            if (!lp_significant(sum, sumabs, c1f, c2f)) sum = 0.;
+            if (lp_noise(sum, sumabs, c1f, c2f)) sum = 0.;
             S->vmultd[k] = sum;
         }
         /* how much of the step can be taken (cobyla.c:1815-1844) */
@@ -699,8 +706,7 @@ nlopt_result nla_cobyla_minimize(unsigned n, nlopt_func f, void *f_data, unsigne
     nlopt_result ret;
 
     memset(&P, 0, sizeof P);
-    *stop->nevals_p = 0;                                          /* cobyla.c:390 */
-    if (n == 0) return NLOPT_SUCCESS;
+    if (n == 0) { *stop->nevals_p = 0; return NLOPT_SUCCESS; }
     scale = (double *) malloc(sizeof(double) * n);                /* nlopt_compute_rescaling (rescale.c:30-48) */
     slb = (double *) malloc(sizeof(double) * n);
     sub = (double *) malloc(sizeof(double) * n);
@@ -712,7 +718,7 @@ nlopt_result nla_cobyla_minimize(unsigned n, nlopt_func f, void *f_data, unsigne
         if (i < n) for (i = 1; i < n; ++i) scale[i] = dx[i] / dx[0];
     }
     for (j = 0; j < n; ++j)
-        if (scale[j] == 0 || isnan(scale[j]) || nla_isinf(scale[j])) {
+        if (scale[j] == 0 || !isfinite(scale[j])) {
             nla_stop_msg(stop, "invalid scaling %g of dimension %d: possible over/underflow?", scale[j], (int) j);
             ret = NLOPT_INVALID_ARGS; goto done;
         }
@@ -733,6 +739,7 @@ nlopt_result nla_cobyla_minimize(unsigned n, nlopt_func f, void *f_data, unsigne
     P.f = f; P.f_data = f_data; P.m_nl = m; P.fc = fc; P.p = p; P.h = h; P.lb = slb; P.ub = sub; P.scale = scale; P.xtmp = xtmp;
     P.con_tol = con_tol; P.stop = stop;
     for (j = 0; j < n; ++j) x[j] = x[j] / scale[j];
+    *stop->nevals_p = 0;                                          /* cobyla.c:390 */
     ret = cob_iterate(&P, (int) n, (int) mtot, x, minf, rhobeg, rhoend, stop, slb, sub);
     for (j = 0; j < n; ++j) x[j] = x[j] * scale[j];
     for (j = 0; j < n; ++j) { if (x[j] < lb[j]) x[j] = lb[j]; if (x[j] > ub[j]) x[j] = ub[j]; }       /* cobyla.c:259-263 */

@@ -167,6 +167,22 @@ static void ord_insert(size_t *ord, size_t cnt, const double *F, size_t r)
     ord[lo] = r;
 }
 
+/* the objective as MLSL's local optimiser sees it (fcount, mlsl.c:246-251): every call counted where the caller can see it */
+typedef struct { nlopt_func f; void *f_data; double sign; int *nevals_p; } mlsl_count_wrap;
+static double mlsl_counted_f(unsigned n, const double *x, double *grad, void *p)
+{
+    mlsl_count_wrap *w = (mlsl_count_wrap *) p;
+    ++*w->nevals_p;
+    return w->f(n, x, grad, w->f_data);
+}
+/* -f for a maximisation whose objective the dispatcher left unflipped (dev_sign) but which runs through host calls here */
+static double mlsl_signed_f(unsigned n, const double *x, double *grad, void *p)
+{
+    mlsl_count_wrap *w = (mlsl_count_wrap *) p;
+    (void) grad;
+    return w->sign * w->f(n, x, NULL, w->f_data);
+}
+
 nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,
                                double *minf, nla_stopping *stop, nlopt_opt local_opt, int Nsamples, int lds)
 {
@@ -180,22 +196,29 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     double R_prefactor, *Fnew = NULL, best_f = HUGE_VAL;
     const double dlm = 1.0, dbound = 1e-6;
     const double *lbh = lb, *ubh = ub;
-    int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0, host, batch;
+    int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0, use_cobyla = 0, host, batch;
+    mlsl_count_wrap cw, sw;
+    nlopt_func lo_f = NULL; void *lo_fdata = NULL;
     nla_mma_params mma;
     nla_stopping lstop, agreed_view;
     const nla_stopping *sp = stop;
     int agreed_force = 0;
     size_t best_row = 0;
+    double *cob_x = NULL;
 
     memset(&D, 0, sizeof D);
     D.N = Nsamples ? Nsamples : 4;                                             /* mlsl.c:283-286 */
     if (D.N < 1) { nla_stop_msg(stop, "population %d is too small", D.N); return NLOPT_INVALID_ARGS; }
-    if (!local_opt || (local_opt->algorithm != NLOPT_LD_LBFGS && local_opt->algorithm != NLOPT_LD_MMA)) {
-        nla_stop_msg(stop, "nlopt_amd: MLSL is provided with NLOPT_LD_LBFGS or NLOPT_LD_MMA as the local optimizer only (not %s)",
+    if (!local_opt || (local_opt->algorithm != NLOPT_LD_LBFGS && local_opt->algorithm != NLOPT_LD_MMA && local_opt->algorithm != NLOPT_LN_COBYLA)) {
+        nla_stop_msg(stop, "nlopt_amd: MLSL is provided with NLOPT_LD_LBFGS, NLOPT_LD_MMA or NLOPT_LN_COBYLA as the local optimizer only (not %s)",
                      local_opt ? nlopt_algorithm_name(local_opt->algorithm) : "none");
         return NLOPT_INVALID_ARGS;
     }
     use_mma = local_opt->algorithm == NLOPT_LD_MMA;
+    /* LN_COBYLA (GN_MLSL's default, optimize.c:763-768) is a HOST algorithm (cobyla_host.c): the searches run one at a time on the
+     * caller's thread through the library's own nlopt_optimize, exactly as mlsl.c:404-407 runs them; samples, distances and the
+     * bookkeeping stay on the device.  The whole run then takes the host-callback path, also for a device objective (its host twin). */
+    use_cobyla = local_opt->algorithm == NLOPT_LN_COBYLA;
     if (use_mma && (i = nla_mma_read_params(local_opt, &mma))) {
         nla_stop_msg(stop, "%s", local_opt->errmsg ? local_opt->errmsg : "invalid LD_MMA parameter");
         return (nlopt_result) i;
@@ -203,9 +226,11 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
     nla_evaluator_resolve(&D.ev, opt, f, f_data);
     D.obj = D.ev.kind == NLA_EVAL_DEVICE ? D.ev.obj : -1;
-    host = D.ev.kind == NLA_EVAL_HOST;
+    host = D.ev.kind == NLA_EVAL_HOST || use_cobyla;
+    sw.f = f; sw.f_data = f_data; sw.sign = -1.; sw.nevals_p = NULL;
+    if (use_cobyla && D.ev.kind != NLA_EVAL_HOST && D.ev.sign < 0) { f = mlsl_signed_f; f_data = &sw; }   /* a maximisation the dispatcher left unflipped (dev_sign): flip here */
     D.n = n; D.ld = (n + 1) & ~1;
-    D.comm = opt ? opt->comm : NULL;
+    D.comm = (opt && !use_cobyla) ? opt->comm : NULL;              /* host searches: every rank runs the identical job, nothing to exchange */
     D.world = nlopt_amd_comm_world(D.comm); D.rank = nlopt_amd_comm_rank(D.comm);
     batch = host ? 1 : BATCH_MAX;             /* a host callback is called for one search at a time, in the reference's order */
     bmax = (host ? 1 : BATCH_MAX) * D.world;
@@ -267,11 +292,23 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             return NLOPT_OUT_OF_MEMORY;
         }
     }
+    if (use_cobyla) {
+        /* the local optimiser as mlsl.c:303-306 configures it: counted objective, the box, the stop value */
+        lo_f = local_opt->f; lo_fdata = local_opt->f_data;
+        cw.f = f; cw.f_data = f_data; cw.sign = 1.; cw.nevals_p = stop->nevals_p;      /* (f is already the flipped one where that applies) */
+        nlopt_set_min_objective(local_opt, mlsl_counted_f, &cw);
+        nlopt_set_lower_bounds(local_opt, lb);
+        nlopt_set_upper_bounds(local_opt, ub);
+        nlopt_set_stopval(local_opt, stop->minf_max);
+        cob_x = (double *) nla_host_malloc(sizeof(double) * (size_t) n);
+        if (!cob_x) { nla_stop_msg(stop, "nlopt_amd: out of pinned memory"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
+    } else {
     D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
                    : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);
     if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode(opt) || nla_exact_mode(local_opt), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
     if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_local_ctx_set_stats(D.lb, st);
+    }
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
     /* several ranks: the clock and the force_stop flag are decided by all ranks together at the start of every phase (comm.c);
@@ -386,7 +423,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             for (c = 0; c < nb; ++c) D.h_idx[c] = (int64_t) D.ord[cand[c]];
             for (c = D.rank; c < nb; c += D.world, ++mine) D.h_idx[bmax + mine] = (int64_t) D.ord[cand[c]];
             if (nla_memcpy_h2d(D.d_idx, D.h_idx, sizeof(int64_t) * (size_t) (bmax + mine), D.st) ||
-                nla_k_mlsl_gather_rows(n, D.ld, D.d_P, D.d_idx + bmax, mine, nla_local_ctx_X(D.lb), D.st) ||
+                nla_k_mlsl_gather_rows(n, D.ld, D.d_P, D.d_idx + bmax, mine, use_cobyla ? D.d_LX : nla_local_ctx_X(D.lb), D.st) ||
                 nla_k_mlsl_near_bound(n, D.ld, D.d_P, D.d_idx, nb, D.d_lb, D.d_ub, dbound * R, D.d_flags, D.st) ||
                 nla_memcpy_d2h(D.h_flags, D.d_flags, sizeof(int32_t) * (size_t) nb, D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
             /* local searches of this rank's share, all-gather of the minimisers, then their distances to every point */
@@ -404,10 +441,24 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             eff = loc_maxeval;
             if (loc_maxeval <= 0 || (limited > 0 && limited < loc_maxeval)) eff = (int) limited;
             prm.maxeval = eff;
+            if (use_cobyla) {
+                memset(&res[0], 0, sizeof res[0]);
+                if (mine > 0) {                                                     /* mlsl.c:400-407 */
+                    const double t = nla_seconds();
+                    double lf = HUGE_VAL;
+                    nlopt_result lret;
+                    if (nla_memcpy_d2h(cob_x, D.d_LX, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "gather failed"); DEVFAIL(); }
+                    lret = nla_optimize_limited(local_opt, cob_x, &lf, stop->maxeval - *stop->nevals_p, stop->maxtime - (t - stop->start));
+                    if (nla_memcpy_h2d(D.d_LX, cob_x, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "minimum store failed"); DEVFAIL(); }
+                    res[0].ret = (int) lret; res[0].f = lf;
+                    res[0].nevals = 0; res[0].iterm = 0;                            /* the calls were counted one by one (mlsl_counted_f) */
+                }
+            } else {
             if (mine > 0 && nla_local_ctx_run(D.lb, mine, &prm, res_mine, &lstop, NULL)) { snprintf(D.err, sizeof D.err, "local-search batch failed"); DEVFAIL(); }
             if (nla_comm_allgather_dev(D.comm, nla_local_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st) ||
                 nla_comm_allgather_host(D.comm, res_mine, res, sizeof *res * (size_t) per, D.st)) {
                 snprintf(D.err, sizeof D.err, "all-gather of the local minima failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL();
+            }
             }
             {
                 const size_t na = (size_t) per * (size_t) D.world;
@@ -510,6 +561,7 @@ done_noget:
     }
 done:
     if (st) st->mt_words = D.words_used;
+    if (use_cobyla) { local_opt->f = lo_f; local_opt->f_data = lo_fdata; nla_host_free(cob_x); }   /* (the wrapper's data live on this stack) */
     mfree(&D);
     free(Fnew); free(res); free(res_mine); free(cand);
     return ret;

@@ -1,0 +1,171 @@
+"""NLOPT_LN_COBYLA (cobyla_host.c) and NLOPT_GN_MLSL / GN_MLSL_LDS with their default local optimiser (LN_COBYLA,
+optimize.c:763-768) against the REAL reference, evaluation by evaluation: drawn problems (dimension, box, start point inside /
+on / outside the box, unequal initial steps, nonlinear inequality / equality / vector constraints, every stopping criterion) are
+given to both libraries through Python callbacks; the point of EVERY objective call, the results, the counts and the messages
+must be identical.  The product runs over the emulated device layer here (tests/test_gpu_cobyla.py is the twin on the GPU)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from test_api_differential import EMU, FUNC, MFUNC, bind, vp, dpp
+
+pytestmark = pytest.mark.skipif(not (O.have_ref() and os.path.exists(EMU)), reason="oracle/_ref or the emulated library not built")
+LN_COBYLA, GN_MLSL, GN_MLSL_LDS = 25, 20, 22
+
+
+def dp(a):
+    return a.ctypes.data_as(dpp)
+
+
+def more_bind(L):
+    bind(L)
+    L.nlopt_set_initial_step.argtypes = [vp, dpp]
+    L.nlopt_set_initial_step1.argtypes = [vp, C.c_double]
+    L.nlopt_set_maxtime.argtypes = [vp, C.c_double]
+    L.nlopt_add_equality_mconstraint.argtypes = [vp, C.c_uint, vp, vp, dpp]
+    return L
+
+
+def play_cobyla(L, draw):
+    rng = np.random.default_rng(31000 + draw)
+    n = int(rng.integers(1, 8))
+    calls = []
+    opt = L.nlopt_create(LN_COBYLA, n)
+    lb, ub = np.full(n, -3.0) - rng.random(n), np.full(n, 4.0) + rng.random(n)
+    r = rng.random()
+    if r < 0.15:
+        lb[:] = -np.inf                                   # half-open / open boxes: fewer bound rows
+    elif r < 0.3:
+        ub[int(rng.integers(n))] = np.inf
+    elif r < 0.4 and n > 1:
+        lb[int(rng.integers(n))] = ub[0] if rng.random() < 0.5 else lb[0]
+    log = [L.nlopt_set_lower_bounds(opt, dp(lb)), L.nlopt_set_upper_bounds(opt, dp(ub))]
+    centre = rng.uniform(-2, 3, n)
+    kind = int(rng.integers(3))
+
+    def f(nn, x, g, d):
+        xs = np.array([x[i] for i in range(nn)])
+        calls.append(xs.copy())
+        if kind == 0:
+            return float(np.sum((xs - centre) ** 2 * (1 + 0.3 * np.arange(nn))) + np.cos(3 * xs[0]))
+        if kind == 1:
+            return float(np.sum(100 * (xs[1:] - xs[:-1] ** 2) ** 2 + (1 - xs[:-1]) ** 2)) if nn > 1 else float((xs[0] - 1) ** 2)
+        return float(np.sum(np.abs(xs - centre)) + 0.1 * np.sum(xs ** 2))
+    fcb = FUNC(f)
+    keep = [fcb]
+    maximise = rng.random() < 0.15
+    log.append((L.nlopt_set_max_objective if maximise else L.nlopt_set_min_objective)(opt, C.cast(fcb, vp), None))
+    for q in range(int(rng.integers(0, 3))):
+        cq = float(rng.uniform(-1, 1))
+        cb = FUNC(lambda nn, x, g, d, cq=cq, q=q: float(x[q % nn] ** 2 + x[(q + 1) % nn] - 2 - cq))
+        keep.append(cb)
+        add = L.nlopt_add_equality_constraint if rng.random() < 0.3 else L.nlopt_add_inequality_constraint
+        log.append(add(opt, C.cast(cb, vp), None, float(rng.choice([0.0, 1e-8, 1e-3]))))
+    if rng.random() < 0.3:
+        m = int(rng.integers(1, 4))
+
+        def mf(mm, res, nn, x, g, d):
+            for i in range(mm):
+                res[i] = float(x[i % nn] + 0.5 * x[(i + 1) % nn] - 3.0 - 0.2 * i)
+        mcb = MFUNC(mf)
+        keep.append(mcb)
+        tol = np.full(m, 1e-6)
+        add = L.nlopt_add_equality_mconstraint if rng.random() < 0.25 else L.nlopt_add_inequality_mconstraint
+        log.append(add(opt, m, C.cast(mcb, vp), None, dp(tol)))
+    r = rng.random()
+    if r < 0.3:
+        step = rng.uniform(0.05, 1.5, n) * rng.choice([1.0, -1.0], n)
+        log.append(L.nlopt_set_initial_step(opt, dp(step)))       # unequal steps: the rescaling path
+    elif r < 0.5:
+        log.append(L.nlopt_set_initial_step1(opt, float(rng.uniform(0.01, 2.0))))
+    if rng.random() < 0.7:
+        log.append(L.nlopt_set_xtol_rel(opt, float(rng.choice([1e-2, 1e-4, 1e-8]))))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_ftol_rel(opt, float(rng.choice([1e-3, 1e-6]))))
+    if rng.random() < 0.2:
+        log.append(L.nlopt_set_ftol_abs(opt, 1e-5))
+    if rng.random() < 0.2:
+        xa = np.full(n, 1e-3)
+        log.append(L.nlopt_set_xtol_abs(opt, dp(xa)))
+    if rng.random() < 0.2:
+        log.append(L.nlopt_set_stopval(opt, float(rng.uniform(-5, 5))))
+    log.append(L.nlopt_set_maxeval(opt, int(rng.choice([1, 3, 17, 60, 400, 2500]))))
+    x = rng.uniform(-5, 6, n)
+    if rng.random() < 0.6:
+        x = np.clip(x, np.where(np.isinf(lb), -5, lb), np.where(np.isinf(ub), 6, ub))
+    if rng.random() < 0.2:
+        x[0] = ub[0] if np.isfinite(ub[0]) else x[0]
+    minf = C.c_double(0)
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(minf))
+    msg = L.nlopt_get_errmsg(opt)
+    out = dict(log=log, ret=ret, minf=minf.value, x=x.copy(), nev=L.nlopt_get_numevals(opt), msg=msg, calls=np.array(calls))
+    L.nlopt_destroy(opt)
+    return out
+
+
+def same(a, b, draw):
+    assert a["log"] == b["log"], (draw, a["log"], b["log"])
+    assert a["ret"] == b["ret"], (draw, a["ret"], b["ret"], a["msg"], b["msg"])
+    assert a["nev"] == b["nev"], (draw, a["nev"], b["nev"])
+    assert a["calls"].shape == b["calls"].shape, (draw, a["calls"].shape, b["calls"].shape)
+    if a["calls"].size:
+        bad = np.flatnonzero(np.any((a["calls"] != b["calls"]) & ~(np.isnan(a["calls"]) & np.isnan(b["calls"])), axis=1))   # (NaN points must match as NaN)
+        assert bad.size == 0, (draw, "first differing call", int(bad[0]), a["calls"][bad[0]], b["calls"][bad[0]])
+    assert a["msg"] == b["msg"], (draw, a["msg"], b["msg"])
+    if a["minf"] == np.finfo(float).max and b["minf"] == a["minf"]:
+        return          # no call inside the box had a usable value: the reference returns uninitialised memory as x (optimize.c:1031,1066)
+    if a["ret"] > 0 or a["ret"] in (-4, -5):
+        assert (a["minf"] == b["minf"] or (np.isnan(a["minf"]) and np.isnan(b["minf"]))) and np.array_equal(a["x"], b["x"], equal_nan=True), (draw, a["minf"], b["minf"])
+
+
+@pytest.mark.parametrize("first", range(0, 240, 40))
+def test_cobyla_is_the_references_run_call_by_call(first):
+    R, A = more_bind(O.ref()), more_bind(C.CDLL(EMU))
+    for draw in range(first, first + 40):
+        same(play_cobyla(R, draw), play_cobyla(A, draw), draw)
+
+
+def play_mlsl(L, draw):
+    rng = np.random.default_rng(47000 + draw)
+    n = int(rng.integers(1, 5))
+    alg = GN_MLSL_LDS if rng.random() < 0.5 else GN_MLSL
+    calls = []
+    opt = L.nlopt_create(alg, n)
+    lb, ub = np.full(n, -2.0) - rng.random(n), np.full(n, 2.0) + rng.random(n)
+    log = [L.nlopt_set_lower_bounds(opt, dp(lb)), L.nlopt_set_upper_bounds(opt, dp(ub))]
+    w = rng.uniform(1, 4, n)
+
+    def f(nn, x, g, d):
+        xs = np.array([x[i] for i in range(nn)])
+        calls.append(xs.copy())
+        return float(np.sum(xs ** 2 - np.cos(w * xs)))               # a few local minima per coordinate
+    fcb = FUNC(f)
+    maximise = rng.random() < 0.15
+    log.append((L.nlopt_set_max_objective if maximise else L.nlopt_set_min_objective)(opt, C.cast(fcb, vp), None))
+    log.append(L.nlopt_set_population(opt, int(rng.choice([0, 3, 7]))))
+    if rng.random() < 0.5:
+        log.append(L.nlopt_set_xtol_rel(opt, float(rng.choice([1e-3, 1e-6]))))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_ftol_rel(opt, 1e-5))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_initial_step1(opt, float(rng.uniform(0.05, 0.6))))
+    if rng.random() < 0.2:
+        log.append(L.nlopt_set_stopval(opt, float(rng.uniform(-n, 0))))
+    log.append(L.nlopt_set_maxeval(opt, int(rng.choice([5, 60, 300, 900]))))
+    L.nlopt_srand(1234 + draw)
+    x = rng.uniform(lb, ub)
+    minf = C.c_double(0)
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(minf))
+    out = dict(log=log, ret=ret, minf=minf.value, x=x.copy(), nev=L.nlopt_get_numevals(opt), msg=L.nlopt_get_errmsg(opt), calls=np.array(calls))
+    L.nlopt_destroy(opt)
+    return out
+
+
+@pytest.mark.parametrize("first", range(0, 60, 20))
+def test_gn_mlsl_with_its_default_local_optimiser_is_the_references_run_call_by_call(first):
+    R, A = more_bind(O.ref()), more_bind(C.CDLL(EMU))
+    for draw in range(first, first + 20):
+        same(play_mlsl(R, draw), play_mlsl(A, draw), draw)

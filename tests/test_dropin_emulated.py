@@ -17,7 +17,8 @@ need = pytest.mark.skipif(not (O.have_ref() and os.path.exists(EMU)), reason="or
 
 @need
 @pytest.mark.parametrize("alg,n,pop,maxeval,seed", [(19, 12, 150, 3000, 42), (19, 40, 0, 2500, 7), (19, 3, 0, 800, 1),
-                                                    (35, 10, 60, 1200, 5), (35, 6, 0, 1500, 11), (42, 8, 30, 1500, 3), (42, 5, 0, 900, 9)])
+                                                    (35, 10, 60, 1200, 5), (35, 6, 0, 1500, 11), (42, 8, 30, 1500, 3), (42, 5, 0, 900, 9),
+                                                    (20, 4, 0, 1500, 5), (22, 3, 10, 1200, 8), (25, 6, 0, 400, 1)])      # GN_MLSL(_LDS) with LN_COBYLA, LN_COBYLA
 def test_same_client_same_output(alg, n, pop, maxeval, seed):
     ref = run(REF, alg, n, pop, maxeval, seed)
     emu = run(EMU, alg, n, pop, maxeval, seed)

@@ -70,9 +70,11 @@ def test_device_objective_reaches_the_reference_result():
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("alg,local,n,pop,maxeval,seed", [(39, 11, 6, 20, 4000, 42), (38, 11, 24, 0, 6000, 3), (38, 24, 10, 15, 5000, 9), (23, 0, 5, 0, 3000, 4),
-                                                      (11, 0, 30, 0, 500, 1), (24, 0, 12, 0, 400, 1)])
+                                                      (11, 0, 30, 0, 500, 1), (24, 0, 12, 0, 400, 1),
+                                                      (20, 0, 4, 0, 1500, 5), (22, 0, 3, 10, 1200, 8), (25, 0, 6, 0, 400, 1)])
 def test_mlsl_and_local_optimisers_with_the_clients_own_callback(alg, local, n, pop, maxeval, seed):
-    """G_MLSL(_LDS) + LD_LBFGS / LD_MMA, GD_MLSL_LDS with its default local optimiser, and the local optimisers themselves, with
+    """G_MLSL(_LDS) + LD_LBFGS / LD_MMA, GD_MLSL_LDS and GN_MLSL(_LDS) with their default local optimisers (LD_MMA, LN_COBYLA),
+    and the local optimisers themselves, with
     the client's own C callback (mlsl.c:335,360,404, optimize.c:716-718,749-793): f is called on the caller's
     thread in the reference's order.  In exact-order mode the same client prints the same line against both libraries — every
     point handed to the callback, every gradient request, the result bit for bit."""
