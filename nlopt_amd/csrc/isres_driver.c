@@ -110,7 +110,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     A(d_F, double, d->popcap); A(d_PEN, double, d->popcap); A(d_GPEN, double, d->popcap); A(d_FEAS, int32_t, d->popcap);
     A(d_irank, int32_t, pop); A(d_scratch, double, 3 * ld);
     A(d_streams, uint64_t, (size_t) (d->units + 1) * pop); A(d_progress, int, d->units + 1); A(d_ticket, int, 1);
-    A(d_swapped, uint8_t, pop); A(d_bits, uint64_t, pop * (size_t) d->rowwords);
+    A(d_swapped, uint8_t, pop); A(d_bits, uint64_t, (size_t) d->popcap * (size_t) d->rowwords);      /* (equal blocks of `per` rows for the all-gather) */
     A(d_words, uint32_t, d->wchunk); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
     A(d_counts, int32_t, d->wchunk / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
     A(d_con, nla_dev_constraint, d->m + d->p + 1);
@@ -166,11 +166,23 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
     t0 = nla_seconds();
     rows_per = (int64_t) (d->wchunk / (2ULL * (uint64_t) popm1));
     if (rows_per < 1) DFAIL(d, "population too large for the word buffer");
-    for (r0 = 0; r0 < pop; r0 += rows_per) {
-        const int64_t nr = pop - r0 < rows_per ? pop - r0 : rows_per;
-        if (nla_mtstream_fill(d->mts, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) r0, 2ULL * (uint64_t) popm1 * (uint64_t) nr, d->d_words))
-            DFAIL(d, "MT stream fill failed");
-        DCK(d, nla_k_isres_bits(d->d_words, r0, (int) nr, pop, d->d_bits, d->st));
+    {
+        /* several ranks: the sweeps' rows of bits are dealt in blocks over the ranks — each generates the stream words of ITS sweeps
+         * (5e9 words per generation at pop = 5e4 in all: the costliest replicated phase) and reduces them to bits; the rows are then
+         * all-gathered in place (pop^2 / 8 bytes: 313 MB at pop = 5e4).  The segment states behind the words (mt_jump_kernel) are
+         * still built by every rank up to its last segment */
+        const int world = nlopt_amd_comm_world(d->comm), rank = nlopt_amd_comm_rank(d->comm);
+        const int64_t first = world > 1 ? (d->per * rank < pop ? d->per * rank : pop) : 0;
+        const int64_t last = world > 1 ? (first + d->per < pop ? first + d->per : pop) : pop;
+        for (r0 = first; r0 < last; r0 += rows_per) {
+            const int64_t nr = last - r0 < rows_per ? last - r0 : rows_per;
+            if (nla_mtstream_fill(d->mts, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) r0, 2ULL * (uint64_t) popm1 * (uint64_t) nr, d->d_words))
+                DFAIL(d, "MT stream fill failed");
+            DCK(d, nla_k_isres_bits(d->d_words, r0, (int) nr, pop, d->d_bits, d->st));
+        }
+        if (world > 1 && nla_comm_allgather_dev(d->comm, d->d_bits + (size_t) (d->per * rank) * (size_t) d->rowwords, d->d_bits,
+                                                sizeof(uint64_t) * (size_t) d->per * (size_t) d->rowwords, d->st))
+            DFAIL(d, "all-gather of the ranking bits failed: %s", nlopt_amd_comm_error(d->comm));
     }
     DCK(d, nla_stream_sync(d->st));
     *t_rng += nla_seconds() - t0;

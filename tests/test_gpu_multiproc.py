@@ -61,7 +61,7 @@ def test_isres_sharded_eval(world, ncon):
     s = single("gpu_isres", a)
     for d in run_world("gpu_isres", a, world=world):
         same(d, s)
-        assert d["collectives"][0] == 5 * 4            # (f, penalty, inequality penalty, feasible) + the stop agreement, per generation
+        assert 5 * 4 <= d["collectives"][0] <= 6 * 4   # (f, penalty, inequality penalty, feasible) + the stop agreement per generation, + the ranking bits where a generation ranks stochastically
 
 
 @pytest.mark.parametrize("world", [2, 3])

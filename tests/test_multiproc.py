@@ -56,7 +56,7 @@ def _check_against_oracle(d, p, nsamp_kind=None):
 @pytest.mark.parametrize("world", [1, 2, 3])
 @pytest.mark.parametrize("obj,n,pop,seed,ncon,gens", [("rastrigin", 12, 60, 5, 2, 6), ("griewank", 7, 0, 11, 0, 3), ("ackley", 20, 45, 2, 3, 5)])
 def test_isres_driver_over_emulated_device_matches_oracle(world, obj, n, pop, seed, ncon, gens):
-    """ISRES, evaluation sharded over the ranks + 4 all-gathers per generation (and one small one in which the ranks agree on
+    """ISRES, evaluation and ranking-bit generation sharded over the ranks + 4 (+1: the bits) all-gathers per generation (and one small one in which the ranks agree on
     the clock / force_stop verdict of the generation, comm.c nla_comm_agree_stop): every rank reproduces the oracle's evaluation
     sequence (f and penalty of every candidate, bit for bit), result and stream position"""
     effpop = pop or 20 * (n + 1)
@@ -66,7 +66,8 @@ def test_isres_driver_over_emulated_device_matches_oracle(world, obj, n, pop, se
         _check_against_oracle(d, p)
         assert np.array_equal(d["f"], p["ftrace"][:len(d["f"])]) and len(d["f"]) == len(p["ftrace"])
         if world > 1:
-            assert d["collectives"][0] == 5 * gens
+            # + one all-gather of the ranking bits in every generation that ranks stochastically (some infeasible individual)
+            assert 5 * gens <= d["collectives"][0] <= 6 * gens and (ncon > 0 or d["collectives"][0] == 5 * gens)
 
 
 @pytest.mark.parametrize("world", [1, 2])
