@@ -160,6 +160,12 @@ int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src_states, uint32_t *ds
  * segment seg_first+s; the nseg segments must cover [g_first, g_first+count). */
 int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg,
                       uint64_t g_first, uint64_t count, uint32_t *out, void *stream);
+/* replaces: the ranking's nlopt_urand calls (isres.c:210, mt19937ar.c:194-198) — words [g_first, g_first + count) of the stream
+ * (global word indices; g_rank0 = the ranking's first word, (g_first - g_rank0) even) reduced on the fly to the bits u < 0.45:
+ * step s = (g - g_rank0) / 2 sets bit (s % popm1) of row (s / popm1) of `bits` (rows of `rowwords` u64, ZEROED by the caller).
+ * seg_states: block arrays of segments seg_first .. seg_first + nseg - 1 as for nla_k_mt_generate. */
+int nla_k_mt_rankbits(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_rank0, uint64_t g_first,
+                      uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *bits, void *stream);
 
 /* replaces: crs_init's row loop, src/algs/crs/crs.c:211-226 (K1+K2 of SURVEY.md §2.3).
  * rows row_first .. row_first+nrows-1 of X (leading dimension ld) := lb + (ub-lb)*res53(words),

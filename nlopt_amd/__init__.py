@@ -172,6 +172,7 @@ def lib():
     L.nla_mtstream_destroy.restype = None
     L.nla_mtstream_fill.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
     L.nla_mtstream_finish.argtypes = [vp, C.c_uint64]
+    L.nla_mtstream_rankbits.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, vp]
     L.nla_k_mt_jump.argtypes = [vp, vp, vp, C.c_int, vp]
     L.nla_k_mt_generate.argtypes = [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, vp, vp]
     L.nla_k_crs_init_rows.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp]

@@ -110,6 +110,98 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint64_t *__restrict
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * The ranking's uniforms never need to exist as words in memory: ISRES asks of u = nlopt_urand(0,1) (isres.c:210, one per
+ * ranking step, two stream words each) only the bit u < PF.  One wavefront per segment regenerates its blocks as
+ * mt_generate_kernel does and turns every block's 312 steps into bits on the spot: step s of the ranking (s = sweep * (pop-1) +
+ * position, counted from the ranking's first word g_rank0) sets bit (position) of row (sweep) of `bits` (rows of `rowwords`
+ * 64-bit words, zeroed by the launcher's caller).  64 consecutive steps are one ballot; lane 0 ORs its pieces into the one to
+ * three words they fall into (row ends do not fall on word boundaries).  No 4 B/word written, no 4 B/word read back — and,
+ * with no word buffer to size passes by, ALL segments of a generation's ranking run in one launch (7800 wavefronts at
+ * pop = 5e4 instead of five passes of 1678), which is what this latency-bound generator needs.
+ * ---------------------------------------------------------------------------------------------- */
+/* lane 0: OR the bits of `left` consecutive ranking steps starting at step s (bit i of bm = step s + i) into the rows of `bits`.
+ * (row, j) of a step follow from those of the previous call by addition — the steps of a wavefront are consecutive — so the
+ * one 64-bit division is paid once per wavefront */
+struct mt_rowpos { int64_t s, row, j; int ready; };
+__device__ __forceinline__ void mt_scatter_bits(mt_rowpos &P, int64_t s, unsigned long long bm, int left, int64_t popm1, int64_t rowwords,
+                                                unsigned long long *__restrict__ bits)
+{
+    int64_t row, j;
+    if (!P.ready) { row = s / popm1; j = s - row * popm1; P.ready = 1; }
+    else { row = P.row; j = P.j + (s - P.s); while (j >= popm1) { j -= popm1; ++row; } }
+    P.s = s; P.row = row; P.j = j;
+    while (left > 0) {
+        const int take = (int) (popm1 - j < (int64_t) left ? popm1 - j : (int64_t) left);      /* steps left in this row */
+        const unsigned long long piece = take >= 64 ? bm : (bm & ((1ULL << take) - 1ULL));
+        unsigned long long *w = bits + (size_t) row * (size_t) rowwords + (size_t) (j >> 6);
+        const int sh = (int) (j & 63);
+        if (piece << sh) atomicOr(w, piece << sh);
+        if (sh && (piece >> (64 - sh))) atomicOr(w + 1, piece >> (64 - sh));
+        bm = take >= 64 ? 0ULL : bm >> take;
+        left -= take;
+        j += take;
+        if (j >= popm1) { j = 0; ++row; }
+    }
+}
+
+__global__ __launch_bounds__(64) void mt_rankbits_kernel(const uint32_t *__restrict__ seg_states, uint64_t seg_first, uint64_t g_rank0,
+                                                          uint64_t g_first, uint64_t count, int64_t popm1, int64_t rowwords,
+                                                          unsigned long long *__restrict__ bits)
+{
+    __shared__ uint32_t mt[MT_N];
+    const int lane = threadIdx.x;
+    const uint64_t seg = seg_first + blockIdx.x;
+    const uint64_t g_end = g_first + count;
+    const uint64_t g0 = seg * NLA_MT_SEG_WORDS;
+    const int par = (int) (g_rank0 & 1);          /* blocks start at even word indices: a step is (2k + par, 2k + par + 1) of its block */
+    mt_rowpos P = { 0, 0, 0, 0 };
+
+    for (int i = lane; i < MT_N; i += 64) mt[i] = seg_states[(size_t) blockIdx.x * MT_N + i];
+    __syncthreads();
+
+    for (int r = 0; r < NLA_MT_SEG_REGENS; ++r) {
+        const uint64_t gb = g0 + (uint64_t) r * MT_N;
+        uint32_t w_last = 0;
+        if (gb >= g_end) break;
+        const bool touches = gb + MT_N > g_first;
+        if (touches) {
+            const int npairs = par ? MT_N / 2 - 1 : MT_N / 2;      /* pairs wholly inside the block */
+            for (int it = 0; it < (MT_N / 2 + 63) / 64; ++it) {
+                const int k = it * 64 + lane;
+                const uint64_t g = gb + 2 * (uint64_t) k + (uint64_t) par;
+                const bool valid = k < npairs && g >= g_first && g + 1 < g_end;
+                bool b = false;
+                if (valid) b = nla_urand_from(0., 1., mt_temper(mt[2 * k + par]), mt_temper(mt[2 * k + par + 1])) < 0.45;      /* PF, isres.c:72 */
+                const unsigned long long vm = __ballot(valid), bm = __ballot(b);
+                if (lane == 0 && vm) {                              /* the valid lanes are one run of consecutive steps */
+                    const int lo = __builtin_ctzll(vm);
+                    const int64_t s = (int64_t) ((gb + 2 * (uint64_t) (it * 64 + lo) + (uint64_t) par - g_rank0) >> 1);
+                    mt_scatter_bits(P, s, bm >> lo, __builtin_popcountll(vm), popm1, rowwords, bits);
+                }
+            }
+            if (par) w_last = mt_temper(mt[MT_N - 1]);             /* first word of the step that straddles into the next block */
+        }
+        __syncthreads();
+        /* regenerate in place (as mt_generate_kernel) */
+        for (int k = lane; k < MT_N - MT_M; k += 64) { uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k + MT_M]); mt[k] = v; }
+        __syncthreads();
+        for (int k = MT_N - MT_M + lane; k < 2 * (MT_N - MT_M); k += 64) { uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]); mt[k] = v; }
+        __syncthreads();
+        for (int k = 2 * (MT_N - MT_M) + lane; k < MT_N - 1; k += 64) { uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]); mt[k] = v; }
+        __syncthreads();
+        if (lane == 0) mt[MT_N - 1] = mt_twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+        __syncthreads();
+        if (par && touches && lane == 0) {
+            const uint64_t g = gb + MT_N - 1;                       /* (word 623 of block r, word 0 of block r + 1) */
+            if (g >= g_first && g + 1 < g_end) {
+                const bool b = nla_urand_from(0., 1., w_last, mt_temper(mt[0])) < 0.45;
+                mt_scatter_bits(P, (int64_t) ((g - g_rank0) >> 1), b ? 1ULL : 0ULL, 1, popm1, rowwords, bits);
+            }
+        }
+    }
+}
+
 extern "C" int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src_states, uint32_t *dst_states, int count, void *stream)
 {
     if (count <= 0) return 0;
@@ -124,6 +216,16 @@ extern "C" int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first,
     if (nseg <= 0 || count == 0) return 0;
     hipLaunchKernelGGL(mt_generate_kernel, dim3(nseg), dim3(64), 0, (hipStream_t) stream,
                        seg_states, seg_first, g_first, count, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nla_k_mt_rankbits(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_rank0, uint64_t g_first,
+                                 uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *bits, void *stream)
+{
+    if (nseg <= 0 || count == 0 || popm1 <= 0) return 0;
+    hipLaunchKernelGGL(mt_rankbits_kernel, dim3(nseg), dim3(64), 0, (hipStream_t) stream, seg_states, seg_first, g_rank0, g_first, count,
+                       popm1, rowwords, (unsigned long long *) bits);
     NLA_LAUNCH_CHECK();
     return 0;
 }

@@ -41,6 +41,7 @@ typedef struct {
     nlopt_amd_comm *comm;
     uint64_t wchunk;                /* words per generator pass: what the largest phase needs, up to WORD_CHUNK_MAX */
     int64_t per, popcap;            /* candidates per rank, per * world >= pop (all-gather wants equal blocks) */
+    int bits_two_pass;              /* A/B switch: ranking words through a buffer + isres_bits_kernel instead of the fused kernel */
     void *st, *ev0, *ev1;
     nla_mtstream *mts;
     uint64_t words_used;
@@ -101,6 +102,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
         while (d->wchunk < need && d->wchunk < WORD_CHUNK_MAX) d->wchunk <<= 1;
     }
     d->st = nla_stream_create();
+    { const char *e = getenv("NLA_ISRES_BITS_TWO_PASS"); d->bits_two_pass = e && atoi(e) > 0; }
     d->ev0 = nla_event_create(); d->ev1 = nla_event_create();      /* device time of the ranking kernel for the stats */
     if (!d->st || !d->ev0 || !d->ev1) return -1;
     d->mts = nla_mtstream_create(d->st);
@@ -174,7 +176,17 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         const int world = nlopt_amd_comm_world(d->comm), rank = nlopt_amd_comm_rank(d->comm);
         const int64_t first = world > 1 ? (d->per * rank < pop ? d->per * rank : pop) : 0;
         const int64_t last = world > 1 ? (first + d->per < pop ? first + d->per : pop) : pop;
-        for (r0 = first; r0 < last; r0 += rows_per) {
+        if (!d->bits_two_pass) {
+            /* words -> bits in one kernel, all of this rank's sweeps in one launch (hip/mt_kernels.hip, mt_rankbits_kernel):
+             * the words are never written to memory */
+            if (last > first) {
+                DCK(d, nla_memset(d->d_bits + (size_t) first * (size_t) d->rowwords, 0, sizeof(uint64_t) * (size_t) (last - first) * (size_t) d->rowwords, d->st));
+                if (nla_mtstream_rankbits(d->mts, d->words_used, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) first,
+                                          2ULL * (uint64_t) popm1 * (uint64_t) (last - first), popm1, d->rowwords, d->d_bits))
+                    DFAIL(d, "MT stream ranking bits failed");
+            }
+        } else
+        for (r0 = first; r0 < last; r0 += rows_per) {               /* A/B (NLA_ISRES_BITS_TWO_PASS=1): words into a buffer in passes, then isres_bits_kernel */
             const int64_t nr = last - r0 < rows_per ? last - r0 : rows_per;
             if (nla_mtstream_fill(d->mts, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) r0, 2ULL * (uint64_t) popm1 * (uint64_t) nr, d->d_words))
                 DFAIL(d, "MT stream fill failed");

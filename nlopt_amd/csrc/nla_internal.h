@@ -149,6 +149,7 @@ void nla_mtstream_destroy(nla_mtstream *s);
 uint64_t nla_mtstream_origin(const nla_mtstream *s); /* global index of the first unconsumed word */
 /* out[i] = stream word (origin + rel_first + i), i < count; device pointer, async on `stream` */
 int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint32_t *d_out);
+int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *d_bits);
 /* leave the calling thread's generator as if it had drawn `consumed` words since create */
 int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed);
 

@@ -101,6 +101,24 @@ int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg, 
     return 0;
 }
 
+int nla_k_mt_rankbits(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_rank0, uint64_t g_first, uint64_t count,
+                      int64_t popm1, int64_t rowwords, uint64_t *bits, void *st)
+{
+    /* the fused kernel's contract, stated the slow way: the words, then one bit per pair */
+    uint32_t *w;
+    int rc;
+    if (nseg <= 0 || count == 0 || popm1 <= 0) return 0;
+    w = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) count);
+    if (!w) return EMU_ERR;
+    rc = nla_k_mt_generate(seg_states, seg_first, nseg, g_first, count, w, st);
+    for (uint64_t k = 0; !rc && k + 1 < count; k += 2) {
+        const uint64_t s = (g_first + k - g_rank0) >> 1, row = s / (uint64_t) popm1, j = s - row * (uint64_t) popm1;
+        if (urand_from(0., 1., w[k], w[k + 1]) < 0.45) bits[(size_t) row * (size_t) rowwords + (j >> 6)] |= 1ULL << (j & 63);
+    }
+    free(w);
+    return rc;
+}
+
 /* ---- rows from the stream, evaluation (hip/crs_kernels.hip: crs_init_rows_kernel, eval_kernel) ------------------------------ */
 int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t row_first,
                         int64_t nrows, double *X, double *F, void *st)

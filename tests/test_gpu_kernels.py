@@ -69,6 +69,40 @@ def test_mt_stream_matches_serial_generator(L, seed, predraw):
         L.nla_mtstream_destroy(s)
 
 
+@pytest.mark.parametrize("seed,predraw,pop,rel0", [(42, 0, 1000, 0), (7, 1, 777, 6), (5489, 623, 65, 2 * 64 * 7), (9, 3, 2, 10), (11, 0, 5000, 4)])
+def test_ranking_bits_fused_with_the_generator_equal_words_then_bits(L, seed, predraw, pop, rel0):
+    """mt_rankbits_kernel (words -> u < PF bits without the words ever reaching memory, all segments in one launch) against the
+    two-pass statement it replaces: the serial generator's words, nlopt_urand(0,1) < 0.45 per pair (isres.c:210), bit j of row i for
+    step i (pop-1) + j.  Both parities of the ranking's first word (predraw odd: a step then straddles two regenerations, and two
+    segments), rows that end inside a 64-bit word, a sub-range of the sweeps (the multi-rank partition), pop = 2."""
+    popm1 = pop - 1
+    roww = (popm1 + 63) // 64
+    L.nlopt_srand(seed)
+    for _ in range(predraw):
+        L.nla_genrand_int32()
+    nsweeps = pop
+    total = rel0 + 2 * popm1 * nsweeps
+    ref = words_from_seed(seed, total + 8, skip=predraw)
+    w = ref[rel0:rel0 + 2 * popm1 * nsweeps].astype(np.uint64)
+    u = ((w[0::2] >> np.uint64(5)) * 67108864.0 + (w[1::2] >> np.uint64(6)).astype(np.float64)) * (1.0 / 9007199254740992.0)
+    want = np.zeros((nsweeps, roww * 64), bool)
+    want[:, :popm1] = (u < 0.45).reshape(nsweeps, popm1)
+    want_words = np.packbits(want.reshape(nsweeps, roww, 64), axis=2, bitorder="little").view(np.uint64).reshape(nsweeps, roww)
+    s = L.nla_mtstream_create(None)
+    assert s
+    try:
+        for first, last in ((0, nsweeps), (nsweeps // 3, nsweeps - nsweeps // 4)):
+            d = DevBuf.from_array(np.zeros(nsweeps * roww, np.uint64))
+            assert L.nla_mtstream_rankbits(s, rel0, rel0 + 2 * popm1 * first, 2 * popm1 * (last - first), popm1, roww, d.ptr) == 0
+            assert L.nla_stream_sync(None) == 0
+            got = d.to_array(np.uint64, nsweeps * roww).reshape(nsweeps, roww)
+            assert np.array_equal(got[first:last], want_words[first:last]), (first, last)
+            assert not got[:first].any() and not got[last:].any()
+            d.free()
+    finally:
+        L.nla_mtstream_destroy(s)
+
+
 @pytest.mark.parametrize("obj,n,nrows", [("rastrigin", 10, 99), ("griewank", 257, 300), ("ackley", 512, 1000),
                                          ("rosenbrock", 64, 513), ("levy", 33, 77), ("sphere", 4096, 64)])
 def test_init_rows_kernel(L, obj, n, nrows):

@@ -2,14 +2,13 @@
 # scratch runner for one gpurun call (edited per experiment)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02q; mkdir -p $O
-for n in 512 64; do for fw in 0 1; do
-NLA_CRS_FORWARD=$fw timeout -k 5 120 python bench.py --n $n --pop 100000 --obj rastrigin --evals-per-step 20000 --steps 3 --warmup 1 --no-cpu-baseline --headline-only > $O/bench_n${n}_fw$fw.json 2> $O/bench_n${n}_fw$fw.err
+timeout -k 5 200 python -m pytest tests/test_gpu_kernels.py -k "ranking_bits" -m gpu -q --timeout 120 2>&1 | tail -n 12
+timeout -k 5 300 python -m pytest tests/test_gpu_isres.py tests/test_gpu_fullsize.py -k "isres" -m gpu -q --timeout 200 2>&1 | tail -n 4
+for tp in 0 1; do
+NLA_ISRES_BITS_TWO_PASS=$tp timeout -k 5 200 python bench.py --workload isres --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_isres_tp$tp.json 2> $O/bench_isres_tp$tp.err
 python - <<PY
 import json
-try:
-    d=json.loads(open("$O/bench_n${n}_fw$fw.json").read().strip().splitlines()[-1])
-    print("n=$n forward=$fw", round(d["value"]), "launch ms", d["roofline"]["avg_launch_ms"], "frac", d["roofline"]["frac"], d["window"])
-except Exception as e:
-    print("n=$n forward=$fw failed", e, open("$O/bench_n${n}_fw$fw.err").read()[-300:])
+d=json.loads(open("$O/bench_isres_tp$tp.json").read().strip().splitlines()[-1])
+print("two_pass=$tp", round(d["value"]), round(d["ms_per_step"],2), d["phases"])
 PY
-done; done
+done
