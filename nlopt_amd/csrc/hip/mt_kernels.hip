@@ -75,39 +75,52 @@ __global__ __launch_bounds__(64) void mt_generate_kernel(const uint32_t *__restr
     }
 }
 
-/* dst = block array J words after src, g = t^J mod phi.  One 640-thread workgroup per state:
- * (a) extend src to the 33*624 consecutive untempered words x[0 .. 20591] in LDS (88 dependent
- * steps of 227 words), (b) thread j < 624 forms y_j = XOR_{i : g_i} x[i+j]; g is wave-uniform so
- * the bit test is a scalar branch and the LDS reads of a wavefront are 64 consecutive words. */
-#define JUMP_BLOCKS 33
-#define JUMP_WORDS (JUMP_BLOCKS * MT_N)
+/* dst = block array J words after src, g = t^J mod phi:  y_j = XOR_{i : g_i} x[i + j], j < 624, over the untempered word
+ * sequence x[0 .. 19937 + 623] that continues src.  One 640-thread workgroup per state.  The sequence is walked in WINDOWS of
+ * JUMP_CHUNK polynomial bits: the window holds x[c .. c + JUMP_CHUNK + 624) — thread j's terms of the chunk — and is extended
+ * from its own last 624 words for the next chunk (x[m+624] = x[m+397] ^ A(x[m], x[m+1]): 227 independent words per step).
+ * 19 KB of LDS instead of the 82 KB of the whole sequence: three workgroups per CU instead of one on this LDS-bandwidth-bound
+ * kernel (10^4 set bits x 624 reads per state).  g is wave-uniform, so the bit test is a scalar branch and the LDS reads of a
+ * wavefront are 64 consecutive words. */
+#define JUMP_CHUNK 4096                          /* polynomial bits per window: a multiple of 64 */
+#define JUMP_WIN (JUMP_CHUNK + MT_N)
 __global__ __launch_bounds__(640) void mt_jump_kernel(const uint64_t *__restrict__ poly, const uint32_t *__restrict__ src,
                                                        uint32_t *__restrict__ dst)
 {
-    __shared__ uint32_t x[JUMP_WORDS];
+    __shared__ uint32_t x[JUMP_WIN];
     const int tid = threadIdx.x;
     const uint32_t *s = src + (size_t) blockIdx.x * MT_N;
+    uint32_t acc = 0;
     if (tid < MT_N) x[tid] = s[tid];
     __syncthreads();
-    /* x[m+624] = x[m+397] ^ A(x[m] upper | x[m+1] lower); chunk c produces words 624+227c .. */
-    for (int base = MT_N; base < JUMP_WORDS; base += (MT_N - MT_M)) {
-        int j = base + tid;
-        if (tid < (MT_N - MT_M) && j < JUMP_WORDS) x[j] = mt_twist(x[j - MT_N], x[j - MT_N + 1], x[j - (MT_N - MT_M)]);
-        __syncthreads();
-    }
-    if (tid < MT_N) {
-        uint32_t acc = 0;
-        for (int w = 0; w < NLA_MT_POLYWORDS; ++w) {
-            uint64_t gw = poly[w];                       /* uniform -> scalar load */
-            const uint32_t *xw = x + w * 64 + tid;
-            while (gw) {
-                int b = __builtin_ctzll(gw);
-                gw &= gw - 1;
-                acc ^= xw[b];
+    for (int c = 0; c < NLA_MT_POLYWORDS * 64; c += JUMP_CHUNK) {
+        /* extend the window: words 624 .. JUMP_WIN-1 from the 624 before them, 227 at a time */
+        for (int base = MT_N; base < JUMP_WIN; base += (MT_N - MT_M)) {
+            const int j = base + tid;
+            if (tid < (MT_N - MT_M) && j < JUMP_WIN) x[j] = mt_twist(x[j - MT_N], x[j - MT_N + 1], x[j - (MT_N - MT_M)]);
+            __syncthreads();
+        }
+        if (tid < MT_N) {
+            const int w1 = (c + JUMP_CHUNK) / 64 < NLA_MT_POLYWORDS ? (c + JUMP_CHUNK) / 64 : NLA_MT_POLYWORDS;
+            for (int w = c / 64; w < w1; ++w) {
+                uint64_t gw = poly[w];                       /* uniform -> scalar load */
+                const uint32_t *xw = x + (w * 64 - c) + tid;
+                while (gw) {
+                    const int b = __builtin_ctzll(gw);
+                    gw &= gw - 1;
+                    acc ^= xw[b];
+                }
             }
         }
-        dst[(size_t) blockIdx.x * MT_N + tid] = acc;
+        __syncthreads();
+        /* the next window starts JUMP_CHUNK words further on: its first 624 words are this window's last 624 */
+        uint32_t keep = 0;
+        if (tid < MT_N) keep = x[JUMP_CHUNK + tid];
+        __syncthreads();
+        if (tid < MT_N) x[tid] = keep;
+        __syncthreads();
     }
+    if (tid < MT_N) dst[(size_t) blockIdx.x * MT_N + tid] = acc;
 }
 
 /* ------------------------------------------------------------------------------------------------
