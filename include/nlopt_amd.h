@@ -73,7 +73,7 @@ typedef struct {
     uint64_t rounds;            /* advance/commit passes */
     uint64_t slots_launched;    /* stream blocks started on the device as reflection trials */
     uint64_t slots_used;        /* ... consumed by the in-order commit walk */
-    uint64_t slots_invalid;     /* value forwarding: slots recomputed because a row taken from a producer slot was not what the chain wrote */
+    uint64_t slots_invalid;     /* device-resolved windows: slots recomputed because a row taken from a producer slot was not what the chain wrote */
     uint64_t slots_newbest;     /* ... discarded in flight: the best point changed */
     uint64_t slots_role;        /* ... discarded in flight: their block was consumed as a mutation block */
     uint64_t evals_init, evals_trial, evals_mutation;
@@ -94,8 +94,6 @@ typedef struct {
      * systolic pipeline those launches had to make: pop + 2 sweeps + 63 ceil(sweeps / 64) each */
     double t_stochrank_ms;
     uint64_t stochrank_launches, stochrank_ticks;
-    /* slots_invalid (above) is live again with value forwarding: slots recomputed because a forwarded row turned out not to be
-     * what the chain wrote */
     /* multi-rank CRS2_LM initialisation: device time (HIP events) of the all-gather of the rows and their f, and the bytes
      * every rank received (0 on a single rank) */
     double t_allgather_ms;
@@ -451,6 +449,7 @@ int nla_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream);
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int nla_memset(void *dst, int value, size_t bytes, void *stream);
 void *nla_stream_create(void);
+void *nla_stream_create_sparse(int every);       /* kernels of this stream run on every `every`-th CU only (<= 1: an ordinary stream) */
 void nla_stream_destroy(void *stream);
 int nla_stream_sync(void *stream);
 int nla_stream_query(void *stream);             /* 0: all work done, -1: still running, otherwise the hipError_t */

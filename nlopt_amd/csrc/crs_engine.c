@@ -155,7 +155,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->B = (int) B;
     if (getenv("NLA_CRS_PASS_LOG")) e->pass_log = fopen(getenv("NLA_CRS_PASS_LOG"), "a");
     e->main = nla_stream_create();
-    e->rng = nla_stream_create();
+    { const char *m = getenv("NLA_CRS_RNG_CU_EVERY"); e->rng = nla_stream_create_sparse(m ? atoi(m) : 0); }     /* experiment: digest kernels on a subset of the CUs */
     if (!e->main || !e->rng) goto fail;
     e->mts = nla_mtstream_create(e->rng);
     if (!e->mts) goto fail;

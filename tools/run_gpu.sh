@@ -2,11 +2,14 @@
 # scratch runner for one gpurun call (edited per experiment)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02q; mkdir -p $O
-timeout -k 5 200 python -m pytest tests/test_gpu_kernels.py -k "mt_stream or ranking_bits or init" -m gpu -q --timeout 120 2>&1 | tail -n 4
-timeout -k 5 200 python bench.py --workload isres --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_isres_j.json 2> $O/bench_isres_j.err
+for ev in 0 4 8 16; do
+NLA_CRS_RNG_CU_EVERY=$ev timeout -k 5 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --headline-only > $O/bench_cu$ev.json 2> $O/bench_cu$ev.err
 python - <<PY
 import json
-d=json.loads(open("$O/bench_isres_j.json").read().strip().splitlines()[-1])
-print("isres", round(d["value"]), round(d["ms_per_step"],2), d["phases"])
+try:
+    d=json.loads(open("$O/bench_cu$ev.json").read().strip().splitlines()[-1])
+    print("rng on every $ev-th CU:", round(d["value"]), "frac", round(d["roofline"]["frac"],3), "launch ms", round(d["roofline"]["avg_launch_ms"],3))
+except Exception as e:
+    print("every=$ev failed", e, open("$O/bench_cu$ev.err").read()[-400:])
 PY
-cd /tmp; rm -rf /tmp/kt; timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/kt -o i -- python $GRAFT_REPO_ROOT/bench.py --workload isres --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; f=$(find /tmp/kt -name '*.db' | head -1); python profiles/summarize_rocpd.py $f | head -9
+done
