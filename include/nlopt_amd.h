@@ -336,6 +336,10 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
  * EG, and launches the same kernel again with resume = 1; req[inst].state == 2: the search has finished (out[inst] valid).
  * All pointers are device pointers. */
 #define NLA_OBJ_EXTERNAL (-1)
+/* OR-ed into a compiled-in objective id given to a kernel launcher (nla_k_eval, nla_k_crs_init_rows, nla_k_crs_finish*,
+ * nla_k_crs_chain, nla_k_isres_eval): the kernel delivers -f — how nlopt_set_max_objective keeps a device objective on the
+ * device (the run minimises -f, optimize.c:1014-1024; the dispatcher turns the result's sign back) */
+#define NLA_OBJ_NEGATE 0x100
 typedef struct { int32_t state, want_grad; } nla_local_req;
 typedef struct {
     nla_local_req *req;            /* count entries */
@@ -449,7 +453,6 @@ int nla_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream);
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int nla_memset(void *dst, int value, size_t bytes, void *stream);
 void *nla_stream_create(void);
-void *nla_stream_create_sparse(int every);       /* kernels of this stream run on every `every`-th CU only (<= 1: an ordinary stream) */
 void nla_stream_destroy(void *stream);
 int nla_stream_sync(void *stream);
 int nla_stream_query(void *stream);             /* 0: all work done, -1: still running, otherwise the hipError_t */

@@ -281,7 +281,9 @@ nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
         const nlopt_algorithm a = opt->algorithm;
         const int local_or_mlsl = a == NLOPT_LD_LBFGS || a == NLOPT_LD_MMA || a == NLOPT_G_MLSL || a == NLOPT_G_MLSL_LDS ||
                                   (a >= NLOPT_GN_MLSL && a <= NLOPT_GD_MLSL_LDS);
-        if (local_or_mlsl && (nlopt_amd_objective_id(f) >= 0 || nla_userobj_is_adapter(f))) {
+        /* the population algorithms likewise, unless fixed coordinates put the elimination wrapper in front of the objective */
+        const int population_alg = (a == NLOPT_GN_CRS2_LM || a == NLOPT_GN_ISRES || a == NLOPT_GN_ESCH) && !fix_applies(opt);
+        if ((local_or_mlsl || population_alg) && (nlopt_amd_objective_id(f) >= 0 || nla_userobj_is_adapter(f))) {
             /* a device objective stays on the device: those drivers negate f and its gradient there (nla_evaluator.sign) */
             opt->dev_sign = -1;
         } else {

@@ -20,6 +20,8 @@
 
 #define INIT_CHUNK_WORDS (1ULL << 28)      /* 1 GiB of stream words per init pass */
 #define KCAP 1024                          /* slot ring (power of two) */
+/* the objective id as the kernel launchers take it: a compiled-in objective under nlopt_set_max_objective delivers -f (e->sign) */
+#define OBJK(e) (((e)->obj >= 0 && (e)->sign < 0) ? ((e)->obj | NLA_OBJ_NEGATE) : (e)->obj)
 #define NLA_KARG_MAX 128                   /* list length that still travels as kernel arguments (hip/crs_kernels.hip NLA_KA_MAX) */
 #define ROWPAD 64                          /* spare rows behind X / F: the init all-gather wants equal blocks per rank (world <= 64) */
 
@@ -155,7 +157,8 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->B = (int) B;
     if (getenv("NLA_CRS_PASS_LOG")) e->pass_log = fopen(getenv("NLA_CRS_PASS_LOG"), "a");
     e->main = nla_stream_create();
-    { const char *m = getenv("NLA_CRS_RNG_CU_EVERY"); e->rng = nla_stream_create_sparse(m ? atoi(m) : 0); }     /* experiment: digest kernels on a subset of the CUs */
+    e->rng = nla_stream_create();      /* (restricting this stream to a subset of the CUs — hipExtStreamCreateWithCUMask, every 4th / 16th CU — was measured:
+                                        *  43.0 -> 43.1 k evals/s; what the digest kernels cost the gather is memory traffic, not CUs) */
     if (!e->main || !e->rng) goto fail;
     e->mts = nla_mtstream_create(e->rng);
     if (!e->mts) goto fail;
@@ -240,7 +243,7 @@ static int op_init_population(void *ve, const double *x0, double *F)
     }
     /* row 0 = the caller's starting guess (crs.c:204) */
     if (nla_memcpy_h2d(e->d_X, x0, sizeof(double) * (size_t) n, e->main)) { nla_event_destroy(ev); FAIL(e, "H2D x0 failed"); }
-    if (e->obj >= 0 && nla_k_eval(e->obj, n, e->ld, e->d_X, 1, e->d_F, e->main)) { nla_event_destroy(ev); FAIL(e, "eval launch failed"); }
+    if (e->obj >= 0 && nla_k_eval(OBJK(e), n, e->ld, e->d_X, 1, e->d_F, e->main)) { nla_event_destroy(ev); FAIL(e, "eval launch failed"); }
     if (e->obj == -2 && nla_userobj_eval_rows(e->user, n, e->ld, 1, e->d_X, e->d_F, NULL, e->sign, e->main)) { nla_event_destroy(ev); FAIL(e, "user objective launch failed"); }
     for (r0 = first; r0 < last; r0 += rows_per_chunk) {
         int64_t nr = last - r0 < rows_per_chunk ? last - r0 : rows_per_chunk;
@@ -253,7 +256,7 @@ static int op_init_population(void *ve, const double *x0, double *F)
             nla_event_destroy(ev); FAIL(e, "MT stream fill failed (init)");
         }
         if (nla_event_record(ev, e->rng) || nla_stream_wait_event(e->main, ev)) { nla_event_destroy(ev); FAIL(e, "event failed"); }
-        if (nla_k_crs_init_rows(e->obj >= 0 ? e->obj : -1, n, e->ld, e->d_lb, e->d_ub, e->d_initwords, r0, nr, e->d_X, e->d_F, e->main) ||
+        if (nla_k_crs_init_rows(e->obj >= 0 ? OBJK(e) : -1, n, e->ld, e->d_lb, e->d_ub, e->d_initwords, r0, nr, e->d_X, e->d_F, e->main) ||
             (e->obj == -2 && nla_userobj_eval_rows(e->user, n, e->ld, nr, e->d_X + (size_t) r0 * (size_t) e->ld, e->d_F + r0, NULL, e->sign, e->main))) {
             nla_event_destroy(ev); FAIL(e, "init kernel launch failed");
         }
@@ -364,7 +367,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         CK(e, nla_k_crs_advance_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
                                      t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         CK(e, nla_event_record(e->ev1, e->main));
-        CK(e, nla_k_crs_finish_args(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
+        CK(e, nla_k_crs_finish_args(OBJK(e), n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                                     t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM,
                                     e->direct_status ? e->h_status : e->d_status, e->main));
         if (e->direct_status) {
@@ -380,7 +383,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
                             d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
     CK(e, nla_event_record(e->ev1, e->main));
-    CK(e, nla_k_crs_finish(e->obj, n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
+    CK(e, nla_k_crs_finish(OBJK(e), n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                            d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
 launched:
     if (e->obj == -2) {
@@ -493,7 +496,7 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     }
     CK(e, nla_event_record(e->ev0, e->main));
     {
-        const int rc = nla_k_crs_chain(e->obj, n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf, nW,
+        const int rc = nla_k_crs_chain(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf, nW,
                                        on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status, e->h_fwcnt,
                                        e->h_fwrec, fwcap, e->main);
         if (rc) FAIL(e, "nla_k_crs_chain failed: %s", nla_dev_error_string(rc));

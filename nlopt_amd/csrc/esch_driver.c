@@ -90,7 +90,7 @@ static int evaluate(esch_dev *d, int cur, int64_t i0, int64_t count)
 {
     ECK(d, nla_k_esch_gather_rows(d->n, d->ld, d->d_slot[cur], i0, count, d->d_R, d->d_G, d->st));
     if (d->obj != -1) {
-        if (d->obj >= 0) ECK(d, nla_k_eval(d->obj, d->n, d->ld, d->d_G, count, d->d_F, d->st));
+        if (d->obj >= 0) ECK(d, nla_k_eval(d->ev.sign < 0 ? (d->obj | NLA_OBJ_NEGATE) : d->obj, d->n, d->ld, d->d_G, count, d->d_F, d->st));
         else ECK(d, nla_userobj_eval_rows(d->ev.user, d->n, d->ld, count, d->d_G, d->d_F, NULL, d->ev.sign, d->st));
         ECK(d, nla_memcpy_d2h(d->h_fit + i0, d->d_F, sizeof(double) * (size_t) count, d->st));
     } else

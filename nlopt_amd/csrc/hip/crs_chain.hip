@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *__restrict__ Wd, const double *__restrict__ Wfd, int nW,
     int slot_mask, int chunks, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX,
     double *__restrict__ TM, chain_ctrl *__restrict__ ctrl, uint32_t ticket_base, nla_crs_slot_status *__restrict__ status,
-    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap)
+    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, double sign)
 {
     typedef const __attribute__((address_space(4))) chain_lists *kernarg_lists;
     const kernarg_lists Lk = (kernarg_lists) __builtin_amdgcn_kernarg_segment_ptr();       /* explicit arguments start at offset 0 */
@@ -300,14 +300,14 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n;
         double *m = TM + (size_t) q * (size_t) ld;
         auto getx = [&](int i) { return __builtin_nontemporal_load(x + i); };
-        const double fT = nla_block_objective<OBJ, WAVES>(n, getx, scratch);
+        const double fT = sign * nla_block_objective<OBJ, WAVES>(n, getx, scratch);
         auto mut = [&](int i) {        /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
             const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
             const double wv = nla_urand_from(0., 1., ww.x, ww.y);
             return nla_clamp_box(xb[i] * (1 + wv) - wv * getx(i), lb[i], ub[i]);
         };
         for (int i = tid; i < n; i += WAVES * 64) m[i] = mut(i);
-        const double fM = nla_block_objective<OBJ, WAVES>(n, mut, scratch);
+        const double fM = sign * nla_block_objective<OBJ, WAVES>(n, mut, scratch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* every wave's part of m[] has landed before lane 0 publishes the slot */
         __syncthreads();
         if (tid == 0) {
@@ -348,6 +348,7 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
 {
     if (K <= 0) return 0;
     if (K > 256 || nW > 256 || nW < 0 || obj < 0) return (int) hipErrorInvalidValue;
+    const double sign = nla_obj_sign(&obj);
     /* rows of TX / TM start on a 128-byte line: a line that holds the end of one slot's row and the start of the next one's could
      * sit in a CU's vector L1 from the read of the first and serve a stale start of the second (consumers take no L1 invalidate) */
     if (ld % 16 != 0 || ((uintptr_t) TX | (uintptr_t) TM) % 128 != 0) return (int) hipErrorInvalidValue;
@@ -369,7 +370,7 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
     if (e != hipSuccess) return (int) e;
 #define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
         pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
-        fwcnt, fwrec, fwcap)
+        fwcnt, fwrec, fwcap, sign)
 #define CHAIN_SHAPE(O)                                                                   \
     if (vec2) {                                                                          \
         if (n >= 2048) CHAIN(2, 32, 8, O); else if (n >= 512) CHAIN(2, 16, 4, O); else CHAIN(2, 16, 2, O); \

@@ -28,7 +28,7 @@ template <int OBJ>
 __global__ __launch_bounds__(256) void crs_init_rows_kernel(int n, int ld, const double *__restrict__ lb,
                                                              const double *__restrict__ ub,
                                                              const uint32_t *__restrict__ words, int64_t row_first,
-                                                             int64_t nrows, double *__restrict__ X, double *__restrict__ F)
+                                                             int64_t nrows, double *__restrict__ X, double *__restrict__ F, double sign)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -42,21 +42,21 @@ __global__ __launch_bounds__(256) void crs_init_rows_kernel(int n, int ld, const
     for (int i = lane; i < n; i += 64) xr[i] = gen(i);
     if (OBJ >= 0) {
         double f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, gen);
-        if (lane == 0) F[row_first + r] = f;
+        if (lane == 0) F[row_first + r] = sign * f;
     }
 }
 
 /* generic batched evaluation: one wavefront per candidate */
 template <int OBJ>
 __global__ __launch_bounds__(256) void eval_kernel(int n, int ld, const double *__restrict__ P, int64_t count,
-                                                    double *__restrict__ F)
+                                                    double *__restrict__ F, double sign)
 {
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= count) return;
     const double *x = P + (size_t) c * (size_t) ld;
     double f = nla_wave_objective<OBJ>(n, [&](int i) { return x[i]; });
-    if (lane == 0) F[c] = f;
+    if (lane == 0) F[c] = sign * f;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
     const uint32_t *__restrict__ words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
     const int32_t *__restrict__ t_in, const int32_t *__restrict__ t_out, int slot_mask,
     const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ fT_ring,
-    double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status, const crs_lists L)
+    double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status, const crs_lists L, double sign)
 {
     __shared__ double scratch[2 * NLA_FIN_WAVES];
     const int tid = threadIdx.x;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
         double f = 0;
         if (OBJ >= 0) {
             if (newly) {
-                f = nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, [&](int i) { return x[i]; }, scratch);
+                f = sign * nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, [&](int i) { return x[i]; }, scratch);
                 if (tid == 0) fT_ring[q] = f;
             } else if (t1 == n) f = fT_ring[q];
         }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
                 };
                 for (int i = tid; i < n; i += NLA_FIN_WAVES * 64) m[i] = mut(i);
                 if (OBJ >= 0) {
-                    f = nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, mut, scratch);
+                    f = sign * nla_block_objective<(OBJ >= 0 ? OBJ : 0), NLA_FIN_WAVES>(n, mut, scratch);
                     if (tid == 0) fM_ring[q] = f;
                 }
             } else if (t1 == n && OBJ >= 0) f = fM_ring[q];
@@ -373,10 +373,11 @@ extern "C" int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, con
     if (nrows <= 0) return 0;
     const dim3 grid((unsigned) ((nrows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t) stream;
+    const double sign = nla_obj_sign(&obj);
     if (obj < 0) {
-        hipLaunchKernelGGL((crs_init_rows_kernel<-1>), grid, block, 0, st, n, ld, lb, ub, words, row_first, nrows, X, F);
+        hipLaunchKernelGGL((crs_init_rows_kernel<-1>), grid, block, 0, st, n, ld, lb, ub, words, row_first, nrows, X, F, sign);
     } else {
-#define CALL(O) hipLaunchKernelGGL((crs_init_rows_kernel<O>), grid, block, 0, st, n, ld, lb, ub, words, row_first, nrows, X, F)
+#define CALL(O) hipLaunchKernelGGL((crs_init_rows_kernel<O>), grid, block, 0, st, n, ld, lb, ub, words, row_first, nrows, X, F, sign)
         NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     }
@@ -389,7 +390,8 @@ extern "C" int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count
     if (count <= 0) return 0;
     const dim3 grid((unsigned) ((count + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t) stream;
-#define CALL(O) hipLaunchKernelGGL((eval_kernel<O>), grid, block, 0, st, n, ld, P, count, F)
+    const double sign = nla_obj_sign(&obj);
+#define CALL(O) hipLaunchKernelGGL((eval_kernel<O>), grid, block, 0, st, n, ld, P, count, F, sign)
     NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     NLA_LAUNCH_CHECK();
@@ -561,15 +563,16 @@ static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0
     if (K <= 0) return 0;
     const dim3 grid((unsigned) (2 * K)), block(NLA_FIN_WAVES * 64);
     hipStream_t st = (hipStream_t) stream;
+    const double sign = nla_obj_sign(&obj);
     if (obj == -2) {
         hipLaunchKernelGGL((crs_finish_kernel<-2>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
-                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L);
+                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign);
     } else if (obj < 0) {
         hipLaunchKernelGGL((crs_finish_kernel<-1>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
-                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L);
+                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign);
     } else {
 #define CALL(O) hipLaunchKernelGGL((crs_finish_kernel<O>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks, \
-                                   first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L)
+                                   first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign)
         NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     }

@@ -167,6 +167,16 @@ __device__ __forceinline__ double nla_block_objective(int n, Get get, double *sc
     default: return (int) hipErrorInvalidValue;                       \
     }
 
+#ifndef NLA_OBJ_NEGATE
+#define NLA_OBJ_NEGATE 0x100            /* (include/nlopt_amd.h) */
+#endif
+/* launcher side of NLA_OBJ_NEGATE: strips the flag from obj, yields the factor the kernel multiplies f by */
+static inline double nla_obj_sign(int *obj)
+{
+    if (*obj >= 0 && (*obj & NLA_OBJ_NEGATE)) { *obj &= ~NLA_OBJ_NEGATE; return -1.; }
+    return 1.;
+}
+
 #define NLA_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int) e_; } while (0)
 
 #endif

@@ -64,25 +64,6 @@ extern "C" void *nla_stream_create(void)
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     return (void *) s;
 }
-/* a stream whose kernels run on every `every`-th CU only (hipExtStreamCreateWithCUMask): for a background kernel that should
- * leave most of the chip to the kernel on the critical path.  every <= 1, or no such API on this stack: an ordinary stream. */
-extern "C" void *nla_stream_create_sparse(int every)
-{
-    hipStream_t s = nullptr;
-    hipDeviceProp_t prop;
-    if (every <= 1 || hipGetDeviceProperties(&prop, 0) != hipSuccess) return nla_stream_create();
-    {
-        int dev = 0;
-        (void) hipGetDevice(&dev);
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nla_stream_create();
-    }
-    const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    uint32_t mask[32] = { 0 };
-    const int words = (ncu + 31) / 32 < 32 ? (ncu + 31) / 32 : 32;
-    for (int i = 0; i < ncu && i < 1024; i += every) mask[i >> 5] |= 1u << (i & 31);
-    if (hipExtStreamCreateWithCUMask(&s, (uint32_t) words, mask) != hipSuccess) { (void) hipGetLastError(); return nla_stream_create(); }
-    return (void *) s;
-}
 extern "C" void nla_stream_destroy(void *stream) { if (stream) (void) hipStreamDestroy((hipStream_t) stream); }
 extern "C" int nla_stream_sync(void *stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
 

@@ -68,7 +68,7 @@ __device__ __forceinline__ double isres_constraint_value(const nla_dev_constrain
 template <int OBJ>
 __global__ __launch_bounds__(256) void isres_eval_kernel(int n, int ld, const double *__restrict__ X, int64_t pop, int m, int p,
                                                           const nla_dev_constraint *__restrict__ con, double *__restrict__ F,
-                                                          double *__restrict__ PEN, double *__restrict__ GPEN, int32_t *__restrict__ FEAS)
+                                                          double *__restrict__ PEN, double *__restrict__ GPEN, int32_t *__restrict__ FEAS, double sign)
 {
     const int lane = threadIdx.x & 63;
     const int64_t k = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void isres_eval_kernel(int n, int ld, const do
         }
     }
     if (p == 0) gpen = pen;
-    if (lane == 0) { if (OBJ >= 0) F[k] = f; PEN[k] = pen; GPEN[k] = gpen; FEAS[k] = feas; }
+    if (lane == 0) { if (OBJ >= 0) F[k] = sign * f; PEN[k] = pen; GPEN[k] = gpen; FEAS[k] = feas; }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -725,7 +725,8 @@ extern "C" int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t
     if (pop <= 0) return 0;
     const dim3 grid((unsigned) ((pop + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t) stream;
-#define CALL(O) hipLaunchKernelGGL((isres_eval_kernel<O>), grid, block, 0, st, n, ld, X, pop, m, p, con, F, PEN, GPEN, FEAS)
+    const double sign = nla_obj_sign(&obj);
+#define CALL(O) hipLaunchKernelGGL((isres_eval_kernel<O>), grid, block, 0, st, n, ld, X, pop, m, p, con, F, PEN, GPEN, FEAS, sign)
     if (obj < 0) { CALL(-1); }                 /* constraints only: f by a user-supplied kernel (userobj.c) */
     else NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL

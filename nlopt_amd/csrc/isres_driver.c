@@ -381,7 +381,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
             /* this rank's block of candidates, then the all-gather (in place: block r sits at r * per) */
             const int64_t first = D.per * nlopt_amd_comm_rank(D.comm);
             const int64_t mine = first >= D.pop ? 0 : (D.pop - first < D.per ? D.pop - first : D.per);
-            if (nla_k_isres_eval(D.obj, n, D.ld, D.d_X + (size_t) first * (size_t) D.ld, mine, m, p, D.d_con, D.d_F + first, D.d_PEN + first,
+            if (nla_k_isres_eval((D.obj >= 0 && D.ev.sign < 0) ? (D.obj | NLA_OBJ_NEGATE) : D.obj, n, D.ld, D.d_X + (size_t) first * (size_t) D.ld, mine, m, p, D.d_con, D.d_F + first, D.d_PEN + first,
                                  D.d_GPEN + first, D.d_FEAS + first, D.st) ||
                 (D.ev.kind == NLA_EVAL_USER && nla_userobj_eval_rows(D.ev.user, n, D.ld, mine, D.d_X + (size_t) first * (size_t) D.ld, D.d_F + first,
                                                                       NULL, D.ev.sign, D.st)) ||

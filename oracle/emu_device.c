@@ -56,7 +56,6 @@ int nla_memcpy_d2h(void *dst, const void *src, size_t bytes, void *st) { (void) 
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
 int nla_memset(void *dst, int value, size_t bytes, void *st) { (void) st; if (bytes) memset(dst, value, bytes); return 0; }
 void *nla_stream_create(void) { return emu_alloc(1); }
-void *nla_stream_create_sparse(int every) { (void) every; return nla_stream_create(); }
 void nla_stream_destroy(void *st) { emu_release(st); }
 int nla_stream_sync(void *st) { (void) st; return 0; }
 int nla_stream_query(void *st) { (void) st; return 0; }
@@ -121,24 +120,32 @@ int nla_k_mt_rankbits(const uint32_t *seg_states, uint64_t seg_first, int nseg, 
 }
 
 /* ---- rows from the stream, evaluation (hip/crs_kernels.hip: crs_init_rows_kernel, eval_kernel) ------------------------------ */
+/* NLA_OBJ_NEGATE: the flag stripped from obj, the factor f is multiplied by */
+static double emu_obj_sign(int *obj)
+{
+    if (*obj >= 0 && (*obj & NLA_OBJ_NEGATE)) { *obj &= ~NLA_OBJ_NEGATE; return -1.; }
+    return 1.;
+}
 int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t row_first,
                         int64_t nrows, double *X, double *F, void *st)
 {
     EMU_LAUNCH();
+    const double sign = emu_obj_sign(&obj);
     (void) st;
     for (int64_t r = 0; r < nrows; ++r) {
         double *x = X + (size_t) (row_first + r) * (size_t) ld;
         const uint32_t *w = words + (size_t) r * 2 * (size_t) n;
         for (int i = 0; i < n; ++i) x[i] = urand_from(lb[i], ub[i], w[2 * i], w[2 * i + 1]);
-        if (obj >= 0) F[row_first + r] = nla_obj_eval_seq(obj, (unsigned) n, x, NULL);
+        if (obj >= 0) F[row_first + r] = sign * nla_obj_eval_seq(obj, (unsigned) n, x, NULL);
     }
     return 0;
 }
 int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F, void *st)
 {
     EMU_LAUNCH();
+    const double sign = emu_obj_sign(&obj);
     (void) st;
-    for (int64_t c = 0; c < count; ++c) F[c] = nla_obj_eval_seq(obj, (unsigned) n, P + (size_t) c * (size_t) ld, NULL);
+    for (int64_t c = 0; c < count; ++c) F[c] = sign * nla_obj_eval_seq(obj, (unsigned) n, P + (size_t) c * (size_t) ld, NULL);
     return 0;
 }
 
@@ -397,12 +404,13 @@ int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t pop, int m
                      double *PEN, double *GPEN, int32_t *FEAS, void *st)
 {
     EMU_LAUNCH();
+    const double sign = emu_obj_sign(&obj);
     (void) st;
     for (int64_t k = 0; k < pop; ++k) {                                       /* isres.c:138-166 */
         const double *x = X + (size_t) k * (size_t) ld;
         double pen = 0, gpen = 0;
         int feas = 1;
-        F[k] = nla_obj_eval_seq(obj, (unsigned) n, x, NULL);
+        F[k] = sign * nla_obj_eval_seq(obj, (unsigned) n, x, NULL);
         for (int c = 0; c < m + p; ++c) {
             double g = nla_con_blocksum_seq((unsigned) n, x, NULL, con[c].q, con[c].Q);
             if (c == m) gpen = pen;
@@ -651,6 +659,7 @@ int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const 
                      const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
 {
     EMU_LAUNCH();
+    const double sign = emu_obj_sign(&obj);
     (void) st;
     for (int a = 0; a < K; ++a) {
         const uint64_t block = first_block + (uint64_t) a;
@@ -661,9 +670,9 @@ int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const 
         if (obj >= 0) {
             if (newly) {
                 double *m = TM + (size_t) q * (size_t) ld;
-                fT = fT_ring[q] = nla_obj_eval_seq(obj, (unsigned) n, x, NULL);                       /* crs.c:133 */
+                fT = fT_ring[q] = sign * nla_obj_eval_seq(obj, (unsigned) n, x, NULL);                /* crs.c:133 */
                 orc_k_mutate(n, X + (size_t) i0 * (size_t) ld, x, words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n, lb, ub, m);
-                fM = fM_ring[q] = nla_obj_eval_seq(obj, (unsigned) n, m, NULL);                       /* crs.c:139-146 */
+                fM = fM_ring[q] = sign * nla_obj_eval_seq(obj, (unsigned) n, m, NULL);                /* crs.c:139-146 */
             } else if (t1 == n) { fT = fT_ring[q]; fM = fM_ring[q]; }
         }
         status[a].fT = fT; status[a].fM = fM; status[a].t = t1; status[a].pad = 0;

@@ -33,7 +33,9 @@ void orc_k_init_rows(int n, int ld, const double *lb, const double *ub, const ui
 
 void orc_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F)
 {
-    for (int64_t c = 0; c < count; ++c) F[c] = nla_obj_eval_seq(obj, (unsigned) n, P + (size_t) c * (size_t) ld, NULL);
+    const double sign = (obj >= 0 && (obj & 0x100)) ? -1. : 1.;          /* NLA_OBJ_NEGATE (include/nlopt_amd.h): the launcher's caller minimises -f */
+    if (obj >= 0) obj &= 0xff;
+    for (int64_t c = 0; c < count; ++c) F[c] = sign * nla_obj_eval_seq(obj, (unsigned) n, P + (size_t) c * (size_t) ld, NULL);
 }
 
 /* crs.c:72,89-109 on one 2n-word block, positions in reduced space (best row removed) */

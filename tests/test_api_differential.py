@@ -254,6 +254,54 @@ def test_drawn_local_and_mlsl_setups_agree_with_the_reference(draw):
     assert a["nev"] == r["nev"] and a["minf"] == r["minf"] and np.array_equal(a["x"], r["x"]), (a["cfg"], a["nev"], r["nev"], a["minf"], r["minf"])
 
 
+def play_population_max(L, draw, getter):
+    """CRS2_LM / ISRES / ESCH MAXIMISING (or minimising) a registered objective, with or without a fixed coordinate"""
+    rng = np.random.default_rng(88000 + draw)
+    dp = lambda a: a.ctypes.data_as(dpp)
+    g = getattr(L, getter)
+    g.restype = vp
+    g.argtypes = [C.c_int]
+    obj = ["rastrigin", "ackley", "griewank", "rosenbrock", "levy", "sphere"][int(rng.integers(6))]
+    n = int(rng.integers(2, 9))
+    xs, lo, hi = O.golden_x0(obj, n)
+    alg = int(rng.choice([19, 35, 42]))
+    opt = L.nlopt_create(alg, n)
+    lb, ub = np.full(n, lo), np.full(n, hi)
+    fixed = rng.random() < 0.25
+    if fixed:
+        lb[n - 1] = ub[n - 1] = 0.5 * (lo + hi) + 0.1           # a fixed coordinate: the elimination wrapper sits in front of f
+    maximise = rng.random() < 0.75
+    log = [L.nlopt_set_lower_bounds(opt, dp(lb)), L.nlopt_set_upper_bounds(opt, dp(ub)),
+           (L.nlopt_set_max_objective if maximise else L.nlopt_set_min_objective)(opt, g(O.OBJ[obj]), None)]
+    log.append(L.nlopt_set_population(opt, int(rng.choice([0, 25, 60]))))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_stopval(opt, float(rng.uniform(0, 50))))
+    if rng.random() < 0.3:
+        log.append(L.nlopt_set_ftol_rel(opt, 1e-4))
+    log.append(L.nlopt_set_maxeval(opt, int(rng.choice([40, 300, 1200]))))
+    L.nlopt_srand(4321 + draw)
+    x = np.clip(np.array(xs, dtype=float), lb, ub)
+    minf = C.c_double(0)
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(minf))
+    out = dict(log=log, ret=ret, minf=minf.value, x=x, nev=L.nlopt_get_numevals(opt), cfg=(obj, n, alg, maximise, fixed))
+    L.nlopt_destroy(opt)
+    return out
+
+
+@pytest.mark.parametrize("first", range(0, 90, 30))
+def test_population_algorithms_maximising_a_registered_objective_agree_with_the_reference(first):
+    """nlopt_set_max_objective with a device objective stays on the device for CRS2_LM / ISRES / ESCH too (the kernels deliver -f,
+    NLA_OBJ_NEGATE): same run as the reference's, which minimises the flipped host callback (optimize.c:1014-1024)"""
+    P = O.port()
+    ref = O.ref()
+    ref.orc_objective = P.orc_objective
+    for draw in range(first, first + 30):
+        r = play_population_max(bind(ref), draw, "orc_objective")
+        a = play_population_max(bind(C.CDLL(EMU)), draw, "nlopt_amd_objective")
+        assert a["log"] == r["log"] and a["ret"] == r["ret"], (a["cfg"], a["ret"], r["ret"])
+        assert a["nev"] == r["nev"] and a["minf"] == r["minf"] and np.array_equal(a["x"], r["x"]), (a["cfg"], a["nev"], r["nev"], a["minf"], r["minf"])
+
+
 # ---- option round trips: everything a setter stores, read back ------------------------------------------------------------------
 def play_options(L, draw):
     rng = np.random.default_rng(777000 + draw)
