@@ -4,6 +4,7 @@
  * layer").  There is no CPU fallback anywhere: with no visible device nla_dev_count() returns 0
  * and the optimisers fail with NLOPT_FAILURE and an errmsg. */
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "../../../include/nlopt_amd.h"
 
 extern "C" int nla_dev_count(void)
@@ -14,10 +15,19 @@ extern "C" int nla_dev_count(void)
 }
 extern "C" int nla_dev_set(int dev) { return (int) hipSetDevice(dev); }
 
+/* test aid: NLA_DEV_MALLOC_FILL=<0..255> fills every new device allocation with that byte (fresh allocations are whatever the
+ * previous owner left — a kernel that reads memory it never wrote shows up as a result that depends on the fill) */
+static int alloc_fill(void)
+{
+    static int fill = -2;
+    if (fill == -2) { const char *e = getenv("NLA_DEV_MALLOC_FILL"); fill = e ? (atoi(e) & 255) : -1; }
+    return fill;
+}
 extern "C" void *nla_dev_malloc(size_t bytes)
 {
     void *p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    if (alloc_fill() >= 0 && (hipMemset(p, alloc_fill(), bytes ? bytes : 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void) hipGetLastError();
     return p;
 }
 extern "C" void nla_dev_free(void *p) { if (p) (void) hipFree(p); }
@@ -27,6 +37,7 @@ extern "C" void *nla_dev_malloc_uncached(size_t bytes)
 {
     void *p = nullptr;
     if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    if (alloc_fill() >= 0 && (hipMemset(p, alloc_fill(), bytes ? bytes : 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void) hipGetLastError();
     return p;
 }
 extern "C" void *nla_host_malloc(size_t bytes)
