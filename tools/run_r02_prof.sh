@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 evidence: the driver's default bench line, rocprofv3 kernel traces and separate PMC passes for the three workloads
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02prof2; mkdir -p $O
+O=gpurun_out/r02prof3; mkdir -p $O
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 summ() { f=$(find $1 -name '*.db' | head -1); [ -n "$f" ] && python profiles/summarize_rocpd.py $f $3 > $2; find $1 -name '*.db' -size +20M -delete; }
 HB="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --headline-only"
