@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+STUCK = []                     # set when the one-job config-5 block of a multi-GPU run had to be abandoned (see bench_crs)
 
 
 def parse():
@@ -57,6 +58,7 @@ def parse():
     ap.add_argument("--config5-pop", type=int, default=1000000, help="population of the one-job CRS block reported at --gpus > 1")
     ap.add_argument("--config5-n", type=int, default=4096)
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--config5-timeout", type=int, default=300)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("crs", "isres", "mlsl"), default="crs")
@@ -262,7 +264,9 @@ def main():
     else:
         out = bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if STUCK:                              # a hung collective thread is still alive: no barrier, no orderly teardown
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -388,11 +392,33 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     dt_max, evals_all = reduce(dt, m["evals"], True)
     one_job = None
     if world > 1 and not a.no_config5:
-        # BASELINE.json config 5 is the only CRS configuration with multi-GPU work in it: ONE job over all ranks
-        try:
-            one_job = crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce)
-        except (Exception, SystemExit) as e:
-            one_job = {"error": repr(e)}
+        # BASELINE.json config 5 is the only CRS configuration with multi-GPU work in it: ONE job over all ranks.
+        # It runs under a watchdog: the replica value above is already measured, and a communicator that never comes up (RCCL's
+        # bootstrap did not return on one box in round 1) must not take the whole line with it
+        import threading
+        box = {}
+
+        def job():
+            try:
+                lr = int(os.environ.get("LOCAL_RANK", "0"))      # the current HIP device is a per-thread setting
+                L.nla_dev_set(lr)
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        torch.cuda.set_device(lr)
+                except ImportError:
+                    pass
+                box["r"] = crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce)
+            except (Exception, SystemExit) as e:
+                box["r"] = {"error": repr(e)}
+        th = threading.Thread(target=job, daemon=True)
+        th.start()
+        th.join(a.config5_timeout)
+        if th.is_alive():
+            one_job = {"error": "did not finish within %d s (communicator bootstrap or a collective hung); the replica value is unaffected" % a.config5_timeout}
+            STUCK.append(True)            # main() prints the line and leaves without the closing barrier
+        else:
+            one_job = box.get("r")
     if rank != 0:
         return None
     g_ms = st1["t_gather_ms"] - st0["t_gather_ms"]

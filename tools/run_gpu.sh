@@ -1,4 +1,11 @@
 #!/bin/bash
 # scratch runner for one gpurun call (edited per experiment)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 5 200 python -m pytest tests/test_gpu_maximise.py tests/test_gpu_isres.py -m gpu -q --timeout 120 2>&1 | tail -n 8
+O=gpurun_out/r02q; mkdir -p $O
+timeout -k 5 120 python -m pytest tests/test_gpu_isres.py tests/test_gpu_fullsize.py -k "isres" -m gpu -q --timeout 100 2>&1 | tail -n 3
+timeout -k 5 120 python bench.py --workload isres --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_isres_c.json 2> $O/bench_isres_c.err
+python - <<PY
+import json
+d=json.loads(open("$O/bench_isres_c.json").read().strip().splitlines()[-1])
+print("isres", round(d["value"]), round(d["ms_per_step"],2), d["phases"])
+PY
