@@ -580,7 +580,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                           "peak": 26 * 4 / 2.4, "peak_note": "26 instructions x 4 cycles each (wave64 on a 16-lane SIMD) at 2.4 GHz = 43 ns: the floor of this formulation",
                           "frac": (26 * 4 / 2.4) / (t_sr * 1e9 / ticks) if ticks and t_sr > 0 else None,
                           "ranking_steps_per_s": steps / t_sr if t_sr > 0 else None,
-                          "share_of_generation": t_sr / (dt_max) if dt_max > 0 else None, "traffic": None}
+                          "share_of_generation": t_sr / (dt_max) if dt_max > 0 else None,
+                          "traffic": pmc_traffic("isres_stochrank_kernel")[0] if (n, pop, a.obj) == (256, 50000, "rastrigin") else None}
         metric = "candidate-evals/sec, ISRES n=%d pop=%d, %d inequality constraints" % (n, pop, ncon)
         wl = "NLOPT_GN_ISRES %s n=%d pop=%d + %d block-sum inequality constraints, seed=%d; step = 1 generation" % (a.obj, n, pop, ncon, a.seed)
         phases = {"eval_s_per_gen": d["t_eval_s"] / K, "rank_s_per_gen": d["t_rank_s"] / K, "evolve_s_per_gen": d["t_evolve_s"] / K,
@@ -595,6 +596,9 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
         phases = {"sampling_s_per_iter": d["t_eval_s"] / K, "local_phase_s_per_iter": d["t_evolve_s"] / K,
                   "local_searches": int(d["accepted"]), "sample_evals": int(d["evals_trial"]), "local_evals": int(d["evals_mutation"])}
     achieved = (bytes_dom / 1e9) / t_dom if t_dom > 0 else None
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes of the same command (BASELINE's shapes only)
+    std = (a.workload == "isres" and (n, pop, a.obj) == (256, 50000, "rastrigin")) or (a.workload == "mlsl" and (n, pop, a.obj) == (4096, 1000, "ackley"))
+    traffic_dom, traffic_src = pmc_traffic(kern.split(" ")[0].split("<")[0]) if (std and a.workload == "mlsl") else (None, None)
     out = {
         "metric": metric, "value": evals_all / dt_max, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
@@ -602,7 +606,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
         "config": {"workload": wl + ("" if world == 1 else "; ONE job over %d ranks (library communicator over RCCL)" % world),
                    "evals_timed": int(evals_all)},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None, "launches": launches,
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_dom, "traffic_source": traffic_src,
+                     "launches": launches,
                      "avg_launch_ms": 1e3 * t_dom / launches if launches else None,
                      "avg_algorithmic_bytes_per_launch": bytes_dom / launches if launches else None},
         "phases": phases, "total_seconds_incl_setup": t_total, "final_result": int(ret), "minf": minf,
