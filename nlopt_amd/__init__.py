@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnlopt_amd.so")
 # nlopt_algorithm values (include/nlopt.h; ABI)
 GN_CRS2_LM, GN_MLSL, GD_MLSL, GN_MLSL_LDS, GD_MLSL_LDS = 19, 20, 21, 22, 23
 LD_LBFGS, LD_MMA, GN_ISRES, G_MLSL, G_MLSL_LDS, GN_ESCH = 11, 24, 35, 38, 39, 42
+LN_COBYLA = 25
 # nlopt_result values
 FAILURE, INVALID_ARGS, OUT_OF_MEMORY, ROUNDOFF_LIMITED, FORCED_STOP = -1, -2, -3, -4, -5
 SUCCESS, STOPVAL_REACHED, FTOL_REACHED, XTOL_REACHED, MAXEVAL_REACHED, MAXTIME_REACHED = 1, 2, 3, 4, 5, 6

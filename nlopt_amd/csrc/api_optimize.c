@@ -90,6 +90,9 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
     case NLOPT_LN_COBYLA: {                                                              /* optimize.c:836-851: a host algorithm (cobyla_host.c) */
         nlopt_result ret;
         int freedx = 0;
+        /* a host algorithm, here for GN_MLSL's sake — but this library is not a CPU NLopt: like every other entry it serves a machine
+         * with a HIP device only */
+        if (nla_dev_count() <= 0) { nla_set_errmsg(opt, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
         if (!opt->dx) {
             freedx = 1;
             if (nlopt_set_default_initial_step(opt, x) != NLOPT_SUCCESS) { nla_set_errmsg(opt, "failed to allocate initial step"); return NLOPT_OUT_OF_MEMORY; }

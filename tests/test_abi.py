@@ -112,6 +112,10 @@ def test_argument_errors_of_the_local_optimisers_come_before_any_device_work():
     assert L.nlopt_add_inequality_constraint(o._h, con, None, 1e-8) > 0
     x, minf, ret = o.optimize_raw(np.full(3, 0.5))
     assert ret == nlopt_amd.INVALID_ARGS and "without nonlinear constraints" in o.get_errmsg()
+    o = mk(nlopt_amd.LN_COBYLA) if hasattr(nlopt_amd, "LN_COBYLA") else None
+    if o is not None:                                  # a host algorithm, but not a CPU NLopt either: no device, no run
+        x, minf, ret = o.optimize_raw(np.zeros(3))
+        assert ret == nlopt_amd.FAILURE and "no HIP device" in o.get_errmsg()
     o = mk(nlopt_amd.GN_MLSL)                          # its default local optimiser LN_COBYLA is served (cobyla_host.c): a valid run,
     x, minf, ret = o.optimize_raw(np.zeros(3))         # which on a machine without a GPU fails loudly like every other one
     assert ret == nlopt_amd.FAILURE and "no HIP device" in o.get_errmsg()
