@@ -79,48 +79,66 @@ __global__ __launch_bounds__(64) void mt_generate_kernel(const uint32_t *__restr
  * sequence x[0 .. 19937 + 623] that continues src.  One 640-thread workgroup per state.  The sequence is walked in WINDOWS of
  * JUMP_CHUNK polynomial bits: the window holds x[c .. c + JUMP_CHUNK + 624) — thread j's terms of the chunk — and is extended
  * from its own last 624 words for the next chunk (x[m+624] = x[m+397] ^ A(x[m], x[m+1]): 227 independent words per step).
- * 19 KB of LDS instead of the 82 KB of the whole sequence: three workgroups per CU instead of one on this LDS-bandwidth-bound
- * kernel (10^4 set bits x 624 reads per state).  g is wave-uniform, so the bit test is a scalar branch and the LDS reads of a
+ * A window of FOUR states is 43 KB of LDS (the whole sequence of one state was 82 KB): three workgroups = twelve states per CU, and
+ * the scalar walk over the polynomial's 10^4 set bits is paid once for the four states' reads.  g is wave-uniform, so the bit test is a scalar branch and the LDS reads of a
  * wavefront are 64 consecutive words. */
-#define JUMP_CHUNK 4096                          /* polynomial bits per window: a multiple of 64 */
+#define JUMP_CHUNK 2048                          /* polynomial bits per window: a multiple of 64 */
 #define JUMP_WIN (JUMP_CHUNK + MT_N)
+#define JUMP_STATES 4                            /* states per workgroup: the scalar walk over the polynomial's set bits is shared by their reads */
 __global__ __launch_bounds__(640) void mt_jump_kernel(const uint64_t *__restrict__ poly, const uint32_t *__restrict__ src,
-                                                       uint32_t *__restrict__ dst)
+                                                       uint32_t *__restrict__ dst, int count)
 {
-    __shared__ uint32_t x[JUMP_WIN];
+    __shared__ uint32_t x[JUMP_STATES][JUMP_WIN];
     const int tid = threadIdx.x;
-    const uint32_t *s = src + (size_t) blockIdx.x * MT_N;
-    uint32_t acc = 0;
-    if (tid < MT_N) x[tid] = s[tid];
+    const int s0 = blockIdx.x * JUMP_STATES;
+    uint32_t acc[JUMP_STATES];
+#pragma unroll
+    for (int q = 0; q < JUMP_STATES; ++q) {
+        acc[q] = 0;
+        /* (a workgroup past the end of the list repeats the last state: same work, nothing stored) */
+        const int sq = s0 + q < count ? s0 + q : count - 1;
+        if (tid < MT_N) x[q][tid] = src[(size_t) sq * MT_N + tid];
+    }
     __syncthreads();
     for (int c = 0; c < NLA_MT_POLYWORDS * 64; c += JUMP_CHUNK) {
-        /* extend the window: words 624 .. JUMP_WIN-1 from the 624 before them, 227 at a time */
+        /* extend the windows: words 624 .. JUMP_WIN-1 from the 624 before them, 227 at a time */
         for (int base = MT_N; base < JUMP_WIN; base += (MT_N - MT_M)) {
             const int j = base + tid;
-            if (tid < (MT_N - MT_M) && j < JUMP_WIN) x[j] = mt_twist(x[j - MT_N], x[j - MT_N + 1], x[j - (MT_N - MT_M)]);
+            if (tid < (MT_N - MT_M) && j < JUMP_WIN) {
+#pragma unroll
+                for (int q = 0; q < JUMP_STATES; ++q) x[q][j] = mt_twist(x[q][j - MT_N], x[q][j - MT_N + 1], x[q][j - (MT_N - MT_M)]);
+            }
             __syncthreads();
         }
         if (tid < MT_N) {
             const int w1 = (c + JUMP_CHUNK) / 64 < NLA_MT_POLYWORDS ? (c + JUMP_CHUNK) / 64 : NLA_MT_POLYWORDS;
             for (int w = c / 64; w < w1; ++w) {
                 uint64_t gw = poly[w];                       /* uniform -> scalar load */
-                const uint32_t *xw = x + (w * 64 - c) + tid;
+                const int off = (w * 64 - c) + tid;
                 while (gw) {
-                    const int b = __builtin_ctzll(gw);
+                    const int bb = __builtin_ctzll(gw);
                     gw &= gw - 1;
-                    acc ^= xw[b];
+#pragma unroll
+                    for (int q = 0; q < JUMP_STATES; ++q) acc[q] ^= x[q][off + bb];
                 }
             }
         }
         __syncthreads();
         /* the next window starts JUMP_CHUNK words further on: its first 624 words are this window's last 624 */
-        uint32_t keep = 0;
-        if (tid < MT_N) keep = x[JUMP_CHUNK + tid];
+        uint32_t keep[JUMP_STATES];
+#pragma unroll
+        for (int q = 0; q < JUMP_STATES; ++q) keep[q] = tid < MT_N ? x[q][JUMP_CHUNK + tid] : 0;
         __syncthreads();
-        if (tid < MT_N) x[tid] = keep;
+        if (tid < MT_N) {
+#pragma unroll
+            for (int q = 0; q < JUMP_STATES; ++q) x[q][tid] = keep[q];
+        }
         __syncthreads();
     }
-    if (tid < MT_N) dst[(size_t) blockIdx.x * MT_N + tid] = acc;
+    if (tid < MT_N) {
+#pragma unroll
+        for (int q = 0; q < JUMP_STATES; ++q) if (s0 + q < count) dst[(size_t) (s0 + q) * MT_N + tid] = acc[q];
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(64) void mt_rankbits_kernel(const uint32_t *__restr
 extern "C" int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src_states, uint32_t *dst_states, int count, void *stream)
 {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(mt_jump_kernel, dim3(count), dim3(640), 0, (hipStream_t) stream, poly, src_states, dst_states);
+    hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned) ((count + JUMP_STATES - 1) / JUMP_STATES)), dim3(640), 0, (hipStream_t) stream, poly, src_states, dst_states, count);
     NLA_LAUNCH_CHECK();
     return 0;
 }
