@@ -169,3 +169,32 @@ def test_gn_mlsl_with_its_default_local_optimiser_is_the_references_run_call_by_
     R, A = more_bind(O.ref()), more_bind(C.CDLL(EMU))
     for draw in range(first, first + 20):
         same(play_mlsl(R, draw), play_mlsl(A, draw), draw)
+
+
+@pytest.mark.parametrize("alg,obj,n,maximise", [(GN_MLSL, "rastrigin", 3, True), (GN_MLSL_LDS, "ackley", 2, True), (GN_MLSL_LDS, "sphere", 4, False)])
+def test_gn_mlsl_with_a_registered_objective_min_and_max(alg, obj, n, maximise):
+    """a registered (device) objective under GN_MLSL: the run takes the host path with the objective's host twin — also when the
+    dispatcher left a maximisation unflipped for the device (dev_sign): the driver flips it itself"""
+    P = O.port()
+    ref = O.ref()
+    ref.orc_objective = P.orc_objective
+    out = []
+    for lib, getter in ((more_bind(ref), "orc_objective"), (more_bind(C.CDLL(EMU)), "nlopt_amd_objective")):
+        g = getattr(lib, getter)
+        g.restype = vp
+        g.argtypes = [C.c_int]
+        xs, lo, hi = O.golden_x0(obj, n)
+        opt = lib.nlopt_create(alg, n)
+        lb, ub = np.full(n, lo), np.full(n, hi)
+        lib.nlopt_set_lower_bounds(opt, dp(lb))
+        lib.nlopt_set_upper_bounds(opt, dp(ub))
+        (lib.nlopt_set_max_objective if maximise else lib.nlopt_set_min_objective)(opt, g(O.OBJ[obj]), None)
+        lib.nlopt_set_xtol_rel(opt, 1e-4)
+        lib.nlopt_set_maxeval(opt, 500)
+        lib.nlopt_srand(99)
+        x = np.array(xs, dtype=float)
+        minf = C.c_double(0)
+        ret = lib.nlopt_optimize(opt, dp(x), C.byref(minf))
+        out.append((ret, minf.value, x.copy(), lib.nlopt_get_numevals(opt)))
+        lib.nlopt_destroy(opt)
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3], out
