@@ -86,3 +86,39 @@ def test_bench_line_at_two_ranks_reports_replicas_and_the_one_job_config5_block_
     assert "ONE job over 2 ranks" in c5["workload"] and "pop=300" in c5["workload"]
     assert c5["init_wall_s"] > 0 and c5["chain_evals_per_s"] > 0 and c5["allgather_GB_received_per_rank"] > 0
     assert "not part of value" in d["replicas_note"]
+
+
+HANG_SNIPPET = """
+import sys, time
+sys.path.insert(0, %r)
+import nlopt_amd
+nlopt_amd.LIB_PATH = %r
+import bench
+bench.crs_config5_one_job = lambda *a, **k: time.sleep(600)          # a communicator bootstrap that never returns
+sys.argv = ["bench.py"] + %r
+bench.main()
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(EMU), reason="emulated library not built")
+def test_bench_line_survives_a_one_job_block_that_never_returns():
+    """the replica value of --gpus N is measured before the one-job config-5 block; if that block hangs (RCCL's bootstrap did on one
+    box in round 1) the line is still printed, says so, and every rank exits"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = ["--gpus", "2", "--n", "16", "--pop", "200", "--steps", "2", "--warmup", "1", "--evals-per-step", "100", "--config5-timeout", "3",
+            "--headline-only", "--no-cpu-baseline"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", HANG_SNIPPET % (ROOT, EMU, argv)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so_, se) in zip(procs, outs):
+        assert p.returncode == 0, so_[-2000:] + se[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["config5_one_job"]["error"]
