@@ -35,6 +35,18 @@ def test_testopt_identical_printout(alg, obj, seed, maxeval):
 
 
 @need
+@pytest.mark.parametrize("alg", [20, 22, 25])
+@pytest.mark.parametrize("obj,seed,maxeval", [(0, 0, 1000), (1, 3, 1000), (5, 7, 1500), (17, 2, 2000)])
+def test_testopt_gn_mlsl_and_cobyla_identical_printout(alg, obj, seed, maxeval):
+    """GN_MLSL / GN_MLSL_LDS with their default local optimiser, and LN_COBYLA itself, on the reference's zoo — among them
+    SURVEY.md section 8(c)'s pin `testopt -r 0 -a 22 -o 1` (f = -1.91322 after 1000 evaluations)"""
+    rc_e, out_e, err_e = run("testopt_amd", "-r", seed, "-a", alg, "-o", obj, "-e", maxeval, preload=EMU)
+    rc_r, out_r, _ = run("testopt_ref", "-r", seed, "-a", alg, "-o", obj, "-e", maxeval)
+    assert rc_e == rc_r == 0, err_e
+    assert out_e == out_r
+
+
+@need
 @pytest.mark.parametrize("alg", [19, 35, 42])
 def test_testopt_fixed_dimension_identical_printout(alg):
     rc_e, out_e, err_e = run("testopt_amd", "-r", 5, "-a", alg, "-o", 5, "-e", 800, "-b", 1, preload=EMU)

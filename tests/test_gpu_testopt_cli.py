@@ -31,6 +31,20 @@ def test_testopt_crs_identical_printout(obj, seed, maxeval):
 
 
 @need
+@pytest.mark.parametrize("alg", [20, 22, 25])
+@pytest.mark.parametrize("obj,seed,maxeval", [(0, 0, 1000), (1, 3, 1000), (17, 2, 2000)])
+def test_testopt_gn_mlsl_and_cobyla_identical_printout(alg, obj, seed, maxeval):
+    """NLOPT_GN_MLSL / GN_MLSL_LDS with their default local optimiser LN_COBYLA, and LN_COBYLA itself: the exact host path (samples
+    from the device's stream / Sobol kernels, distances on the device, COBYLA on the host) — identical text, among it SURVEY.md
+    §8c's pin `testopt -r 0 -a 22 -o 1`"""
+    a = run(AMD, "-r", seed, "-a", alg, "-o", obj, "-e", maxeval)
+    r = run(REF, "-r", seed, "-a", alg, "-o", obj, "-e", maxeval)
+    assert a == r
+    if (alg, obj, seed, maxeval) == (22, 1, 0, 1000):
+        assert any("f = -1.91322" in l for l in a)
+
+
+@need
 @pytest.mark.parametrize("alg", [19, 35, 42])
 def test_testopt_fixed_dimension(alg):
     """-b 1: the driver equates the bounds of dimension 1 — the library eliminates it (optimize.c:1038-1060) and runs in one dimension less"""
