@@ -153,6 +153,25 @@ NLOPT_EXTERN(void) nlopt_set_munge(nlopt_opt opt, nlopt_munge munge_on_destroy, 
 typedef void *(*nlopt_munge2)(void *p, void *data);
 NLOPT_EXTERN(void) nlopt_munge_data(nlopt_opt opt, nlopt_munge2 munge, void *data);
 
+/* the pre-2.0 one-call interface (reference: src/api/nlopt.h:317-337; behaviour src/api/deprecated.c:65-189) */
+typedef double (*nlopt_func_old)(int n, const double *x, double *gradient, void *func_data);
+NLOPT_EXTERN(nlopt_result) nlopt_minimize(nlopt_algorithm algorithm, int n, nlopt_func_old f, void *f_data,
+                                          const double *lb, const double *ub, double *x, double *minf,
+                                          double minf_max, double ftol_rel, double ftol_abs, double xtol_rel, const double *xtol_abs,
+                                          int maxeval, double maxtime);
+NLOPT_EXTERN(nlopt_result) nlopt_minimize_constrained(nlopt_algorithm algorithm, int n, nlopt_func_old f, void *f_data,
+                                                      int m, nlopt_func_old fc, void *fc_data, ptrdiff_t fc_datum_size,
+                                                      const double *lb, const double *ub, double *x, double *minf,
+                                                      double minf_max, double ftol_rel, double ftol_abs, double xtol_rel,
+                                                      const double *xtol_abs, int maxeval, double maxtime);
+NLOPT_EXTERN(nlopt_result) nlopt_minimize_econstrained(nlopt_algorithm algorithm, int n, nlopt_func_old f, void *f_data,
+                                                       int m, nlopt_func_old fc, void *fc_data, ptrdiff_t fc_datum_size,
+                                                       int p, nlopt_func_old h, void *h_data, ptrdiff_t h_datum_size,
+                                                       const double *lb, const double *ub, double *x, double *minf,
+                                                       double minf_max, double ftol_rel, double ftol_abs, double xtol_rel,
+                                                       const double *xtol_abs, double htol_rel, double htol_abs,
+                                                       int maxeval, double maxtime);
+
 /* deprecated-API globals whose semantics the dispatcher still honours
  * (reference: src/api/deprecated.c:28-61, read by POP() at src/api/optimize.c:511) */
 NLOPT_EXTERN(int) nlopt_get_stochastic_population(void);

@@ -123,3 +123,62 @@ void nlopt_set_local_search_algorithm(nlopt_algorithm deriv, nlopt_algorithm non
 {
     nla_local_search_alg_deriv = deriv; nla_local_search_alg_nonderiv = nonderiv; nla_local_search_maxeval = maxeval;
 }
+
+/* The pre-2.0 one-call interface (reference: src/api/nlopt.h:317-337, src/api/deprecated.c:65-189): everything the object API
+ * sets, as positional arguments.  Kept because callers of the global-search path written against it — nlopt_minimize(NLOPT_GN_CRS2_LM,
+ * ...) — otherwise cannot link.  The old callback type differs from nlopt_func only in the signedness of n; like the reference,
+ * the pointers are handed on as they are.  Constraint i gets the datum at byte offset i * datum_size.  htol_rel is ignored
+ * (deprecated.c:97), and nlopt_minimize_constrained passes its ftol pair in the htol slots (deprecated.c:177). */
+nlopt_result nlopt_minimize_econstrained(nlopt_algorithm algorithm, int n, nlopt_func_old f, void *f_data,
+                                         int m, nlopt_func_old fc, void *fc_data, ptrdiff_t fc_datum_size,
+                                         int p, nlopt_func_old h, void *h_data, ptrdiff_t h_datum_size,
+                                         const double *lb, const double *ub, double *x, double *minf,
+                                         double minf_max, double ftol_rel, double ftol_abs, double xtol_rel, const double *xtol_abs,
+                                         double htol_rel, double htol_abs, int maxeval, double maxtime)
+{
+    nlopt_result ret = NLOPT_INVALID_ARGS;
+    nlopt_opt opt;
+    int i;
+    (void) htol_rel;
+    if (n < 0 || m < 0 || p < 0) return ret;
+    opt = nlopt_create(algorithm, (unsigned) n);
+    if (!opt) return ret;
+#define LEGACY_STEP(call) do { ret = (call); if (ret != NLOPT_SUCCESS) goto out; } while (0)
+    LEGACY_STEP(nlopt_set_min_objective(opt, (nlopt_func) f, f_data));
+    for (i = 0; i < m; ++i)
+        LEGACY_STEP(nlopt_add_inequality_constraint(opt, (nlopt_func) fc, (char *) fc_data + i * fc_datum_size, 0.0));
+    for (i = 0; i < p; ++i)
+        LEGACY_STEP(nlopt_add_equality_constraint(opt, (nlopt_func) h, (char *) h_data + i * h_datum_size, htol_abs));
+    LEGACY_STEP(nlopt_set_lower_bounds(opt, lb));
+    LEGACY_STEP(nlopt_set_upper_bounds(opt, ub));
+    LEGACY_STEP(nlopt_set_stopval(opt, minf_max));
+    LEGACY_STEP(nlopt_set_ftol_rel(opt, ftol_rel));
+    LEGACY_STEP(nlopt_set_ftol_abs(opt, ftol_abs));
+    LEGACY_STEP(nlopt_set_xtol_rel(opt, xtol_rel));
+    if (xtol_abs) LEGACY_STEP(nlopt_set_xtol_abs(opt, xtol_abs));
+    LEGACY_STEP(nlopt_set_maxeval(opt, maxeval));
+    LEGACY_STEP(nlopt_set_maxtime(opt, maxtime));
+#undef LEGACY_STEP
+    ret = nlopt_optimize(opt, x, minf);
+out:
+    nlopt_destroy(opt);
+    return ret;
+}
+
+nlopt_result nlopt_minimize_constrained(nlopt_algorithm algorithm, int n, nlopt_func_old f, void *f_data,
+                                        int m, nlopt_func_old fc, void *fc_data, ptrdiff_t fc_datum_size,
+                                        const double *lb, const double *ub, double *x, double *minf,
+                                        double minf_max, double ftol_rel, double ftol_abs, double xtol_rel, const double *xtol_abs,
+                                        int maxeval, double maxtime)
+{
+    return nlopt_minimize_econstrained(algorithm, n, f, f_data, m, fc, fc_data, fc_datum_size, 0, NULL, NULL, 0, lb, ub, x, minf,
+                                       minf_max, ftol_rel, ftol_abs, xtol_rel, xtol_abs, ftol_rel, ftol_abs, maxeval, maxtime);
+}
+
+nlopt_result nlopt_minimize(nlopt_algorithm algorithm, int n, nlopt_func_old f, void *f_data, const double *lb, const double *ub,
+                            double *x, double *minf, double minf_max, double ftol_rel, double ftol_abs, double xtol_rel,
+                            const double *xtol_abs, int maxeval, double maxtime)
+{
+    return nlopt_minimize_constrained(algorithm, n, f, f_data, 0, NULL, NULL, 0, lb, ub, x, minf,
+                                      minf_max, ftol_rel, ftol_abs, xtol_rel, xtol_abs, maxeval, maxtime);
+}
