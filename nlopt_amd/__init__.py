@@ -2,9 +2,9 @@
 population-based global optimisers (CRS2_LM / ISRES / MLSL).
 
 The product is the C-ABI shared library (include/nlopt.h + include/nlopt_amd.h); this module only
-loads it with ctypes and mirrors the object-oriented surface of the reference's SWIG binding
-(`nlopt.opt`: set_min_objective, set_lower_bounds, optimize, last_optimize_result, ... —
-src/swig/nlopt-python.i) so the parity tests read like the reference's own (test/t_python.py).
+loads it with ctypes: `Opt` is the thin face the tests and bench.py use (traces, statistics, communicators, device
+buffers for the kernel-level tests); nlopt_amd/nlopt.py is the full mirror of the reference's Python module
+(`import nlopt`: src/swig/nlopt.i, nlopt-python.i) for programs written against that.
 There is no CPU implementation behind it: without a visible HIP device `optimize` raises.
 """
 import ctypes as C

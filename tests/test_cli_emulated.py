@@ -61,3 +61,25 @@ def test_the_references_cpp_client_test_passes(alg):
     """t_bounded.cxx: functor trampolines, munge hooks, maximisation through nlopt.hpp — exit code 0 as under ctest"""
     rc, out, err = run("t_bounded_amd", alg, preload=EMU)
     assert rc == 0, "\n".join(out) + err
+
+
+@pytest.mark.skipif(not all(os.path.exists(p) for p in (EMU, os.path.join(REFDIR, "t_tutorial_amd"), os.path.join(REFDIR, "t_tutorial_ref"))),
+                    reason="oracle/_ref/t_tutorial_* or the emulated library not built")
+def test_the_references_tutorial_program_with_cobyla():
+    """t_tutorial.cxx as ctest runs it for LN_COBYLA (test/CMakeLists.txt:19: `t_tutorial 25`): the constrained tutorial problem
+    (two cubic inequality constraints with per-constraint data, a half-open box replaced by [1e-6, 10]^2, stopval, initial
+    step 0.1) and the string-keyed parameters (set_param / get_param / num_params / nth_param) — exit code 0 and the same
+    line, evaluation count included, as the reference build prints"""
+    rc_e, out_e, err_e = run("t_tutorial_amd", 25, preload=EMU)
+    rc_r, out_r, _ = run("t_tutorial_ref", 25)
+    assert rc_e == rc_r == 0, "\n".join(out_e) + err_e
+    assert out_e == out_r and "found minimum at f(" in out_e[0]
+
+
+@pytest.mark.skipif(not all(os.path.exists(p) for p in (EMU, os.path.join(REFDIR, "t_tutorial_amd"))),
+                    reason="oracle/_ref/t_tutorial_amd or the emulated library not built")
+def test_the_tutorial_program_with_constrained_mma_is_refused_by_name():
+    """LD_MMA with nonlinear constraints is outside the path: the program must end with the library's
+    message, not with a wrong answer"""
+    rc, out, err = run("t_tutorial_amd", preload=EMU)
+    assert rc != 0 and "LD_MMA is provided without nonlinear constraints only" in err

@@ -18,3 +18,15 @@ def test_reference_cpp_client_passes_against_libnlopt_amd(alg):
     r = subprocess.run([EXE, str(alg)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "found minimum at f(" in r.stdout
+
+
+TUT, TUT_REF = os.path.join(REFDIR, "t_tutorial_amd"), os.path.join(REFDIR, "t_tutorial_ref")
+
+
+@pytest.mark.skipif(not (os.path.exists(TUT) and os.path.exists(TUT_REF)), reason="oracle/_ref/t_tutorial_* not built (no /root/reference at build time)")
+def test_reference_tutorial_program_with_cobyla_against_libnlopt_amd():
+    """test/t_tutorial.cxx as ctest runs it for LN_COBYLA (test/CMakeLists.txt:19): same line as the reference build prints"""
+    r = subprocess.run([TUT, "25"], capture_output=True, text=True, timeout=300)
+    q = subprocess.run([TUT_REF, "25"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and q.returncode == 0, r.stdout + r.stderr
+    assert r.stdout == q.stdout
