@@ -23,7 +23,7 @@ def pytest_configure(config):
         if not os.path.exists(os.path.join(ref, "libnlopt_ref.so")):
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
         if not os.path.exists(os.path.join(ref, "testopt_amd")) or not os.path.exists(os.path.join(ref, "t_bounded_amd")) \
-                or not os.path.exists(os.path.join(ref, "t_tutorial_amd")):
+                or not os.path.exists(os.path.join(ref, "t_tutorial_amd")) or not os.path.exists(os.path.join(ref, "cpp_functor_amd")):
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "cpptest"], check=True)
 
 

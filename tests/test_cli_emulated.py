@@ -83,3 +83,26 @@ def test_the_tutorial_program_with_constrained_mma_is_refused_by_name():
     message, not with a wrong answer"""
     rc, out, err = run("t_tutorial_amd", preload=EMU)
     assert rc != 0 and "LD_MMA is provided without nonlinear constraints only" in err
+
+
+@pytest.mark.skipif(not all(os.path.exists(p) for p in (EMU, os.path.join(REFDIR, "cpp_functor_amd"), os.path.join(REFDIR, "cpp_functor_ref"))),
+                    reason="oracle/_ref/cpp_functor_* or the emulated library not built")
+def test_the_references_functor_program():
+    """cpp_functor.cxx (ctest: `cpp_functor 0`): objectives given as std::function objects, nlopt::opt("LD_MMA", 3) by name,
+    no bounds at all, the same optimiser reused for a second objective — same printout as the reference build"""
+    rc_e, out_e, err_e = run("cpp_functor_amd", preload=EMU)
+    rc_r, out_r, _ = run("cpp_functor_ref")
+    assert rc_e == rc_r == 0, "\n".join(out_e) + err_e
+    assert out_e == out_r and any("Sine regression" in l for l in out_e)
+
+
+@need
+@pytest.mark.parametrize("obj", [0, 1])
+@pytest.mark.parametrize("alg", [11, 19, 20, 21, 22, 23, 24, 25])
+def test_testopt_as_ctest_runs_it(alg, obj):
+    """the reference's ctest matrix `testopt -r 0 -a <0..28> -o <0,1>` (test/CMakeLists.txt:39-66), for the algorithms of it
+    that this library serves: LD_LBFGS, CRS2_LM, the four MLSL enums with their default local optimisers, LD_MMA, LN_COBYLA"""
+    rc_e, out_e, err_e = run("testopt_amd", "-r", 0, "-a", alg, "-o", obj, preload=EMU)
+    rc_r, out_r, _ = run("testopt_ref", "-r", 0, "-a", alg, "-o", obj)
+    assert rc_e == rc_r == 0, err_e
+    assert out_e == out_r

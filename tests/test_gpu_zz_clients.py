@@ -1,0 +1,88 @@
+"""-m gpu twins of the client-program tests that were written after round 2's GPU budget had been spent (the file sorts last
+so that the established suite runs first): tests/pyapi/seeded_runs.py (written against `import nlopt` only) over the real
+reference library and over libnlopt_amd.so on the MI355X — every algorithm of the path with the client's own Python callbacks
+(the exact host-callback paths: candidates / iterates built on the device, f called on the caller's thread in the reference's
+order) must print the same text; a registered device objective selected through the module reaches the same result as
+through nlopt_amd.Opt; the reference's cpp_functor.cxx and its ctest matrix of testopt for the served algorithms print what
+the reference build prints."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "libnlopt_ref.so")
+SHIM = os.path.join(ROOT, "tests", "pyapi")
+
+
+def run(script, library=None):
+    env = dict(os.environ, PYTHONPATH=SHIM + os.pathsep + ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("NLOPT_AMD_PYAPI_LIBRARY", None)
+    if library:
+        env["NLOPT_AMD_PYAPI_LIBRARY"] = library
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900, env=env, cwd=SHIM)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
+def test_a_seeded_client_script_prints_the_same_over_the_reference_and_the_device_library():
+    rc_r, out_r, err_r = run(os.path.join(SHIM, "seeded_runs.py"), library=REF)
+    rc_a, out_a, err_a = run(os.path.join(SHIM, "seeded_runs.py"))
+    assert rc_r == 0 and rc_a == 0, err_r + err_a
+    assert out_a.splitlines() == out_r.splitlines()
+
+
+def test_a_registered_device_objective_through_the_module():
+    import nlopt_amd
+    import nlopt_amd.nlopt as nlopt
+    n, lo, hi = 64, -600.0, 600.0
+    x0 = np.linspace(-300, 300, n)
+    nlopt.srand(11)
+    a = nlopt.opt(nlopt.GN_CRS2_LM, n)
+    a.set_min_objective(nlopt.device_objective("griewank"))
+    a.set_lower_bounds(lo)
+    a.set_upper_bounds(hi)
+    a.set_maxeval(5000)
+    xa = a.optimize(x0)
+    nlopt_amd.srand(11)
+    b = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
+    b.set_min_objective(nlopt_amd.objective("griewank"))
+    b.set_lower_bounds(lo)
+    b.set_upper_bounds(hi)
+    b.set_maxeval(5000)
+    xb = b.optimize(x0)
+    assert a.last_optimize_result() == b.last_optimize_result() == nlopt.MAXEVAL_REACHED
+    assert np.array_equal(xa, xb) and a.last_optimum_value() == b.last_optimum_value()
+    assert a.get_numevals() == b.get_numevals()
+
+
+FUN, FUN_REF = os.path.join(ROOT, "oracle", "_ref", "cpp_functor_amd"), os.path.join(ROOT, "oracle", "_ref", "cpp_functor_ref")
+
+
+@pytest.mark.skipif(not (os.path.exists(FUN) and os.path.exists(FUN_REF)), reason="oracle/_ref/cpp_functor_* not built (no /root/reference at build time)")
+def test_reference_functor_program_against_libnlopt_amd():
+    """test/cpp_functor.cxx (std::function objectives, unbounded LD_MMA by name): same printout as the reference build"""
+    r = subprocess.run([FUN], capture_output=True, text=True, timeout=300)
+    q = subprocess.run([FUN_REF], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and q.returncode == 0, r.stdout + r.stderr
+    assert r.stdout == q.stdout
+
+
+TESTOPT, TESTOPT_REF = os.path.join(ROOT, "oracle", "_ref", "testopt_amd"), os.path.join(ROOT, "oracle", "_ref", "testopt_ref")
+
+
+@pytest.mark.skipif(not (os.path.exists(TESTOPT) and os.path.exists(TESTOPT_REF)), reason="oracle/_ref/testopt_* not built")
+@pytest.mark.parametrize("obj", [0, 1])
+@pytest.mark.parametrize("alg", [11, 19, 20, 21, 22, 23, 24, 25])
+def test_testopt_as_ctest_runs_it(alg, obj):
+    """the reference's ctest matrix `testopt -r 0 -a <alg> -o <obj>` (test/CMakeLists.txt:39-66) for the served algorithms"""
+    def go(exe):
+        r = subprocess.run([exe, "-r", "0", "-a", str(alg), "-o", str(obj)], capture_output=True, text=True, timeout=600)
+        return r.returncode, [l for l in r.stdout.splitlines() if not l.startswith("finished after")], r.stderr
+    rc_a, out_a, err_a = go(TESTOPT)
+    rc_r, out_r, _ = go(TESTOPT_REF)
+    assert rc_a == rc_r == 0, err_a
+    assert out_a == out_r
