@@ -328,7 +328,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     } else {
     D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
                    : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);
-    if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode(opt) || nla_exact_mode(local_opt), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
+    if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode_for(opt, local_opt, &D.ev), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
     if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_local_ctx_set_stats(D.lb, st);
     }

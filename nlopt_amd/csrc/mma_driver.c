@@ -46,7 +46,7 @@ nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, 
     memset(&prm, 0, sizeof prm);
     prm.minf_max = stop->minf_max; prm.ftol_rel = stop->ftol_rel; prm.ftol_abs = stop->ftol_abs; prm.xtol_rel = stop->xtol_rel;
     prm.maxeval = stop->maxeval;
-    if (nla_local_run_batch(1, &ev, n, 1, lb, ub, x, 0, &mma, opt->dx, &prm, &res, stop, nla_exact_mode(opt),
+    if (nla_local_run_batch(1, &ev, n, 1, lb, ub, x, 0, &mma, opt->dx, &prm, &res, stop, nla_exact_mode_for(opt, NULL, &ev),
                             ev.kind == NLA_EVAL_HOST ? stop->nevals_p : NULL, opt, err, sizeof err)) { nla_stop_msg(stop, "device engine: %s", err); return NLOPT_FAILURE; }
     *minf = res.f;
     if (ev.kind != NLA_EVAL_HOST) *stop->nevals_p += res.nevals;

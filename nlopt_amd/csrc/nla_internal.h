@@ -98,6 +98,7 @@ typedef struct {
 } nla_evaluator;
 void nla_evaluator_resolve(nla_evaluator *ev, nlopt_opt opt, nlopt_func f, void *f_data);
 int nla_exact_mode(nlopt_opt opt);                    /* nlopt_set_param(opt, "amd_exact_dot", 1) */
+int nla_exact_mode_for(nlopt_opt opt, nlopt_opt also, const nla_evaluator *ev);   /* unset: exact order iff the objective is a host callback */
 
 /* user device objectives (userobj.c) */
 nla_userobj *nla_userobj_retain(nla_userobj *u);

@@ -142,3 +142,14 @@ void nla_evaluator_resolve(nla_evaluator *ev, nlopt_opt opt, nlopt_func f, void 
 }
 
 int nla_exact_mode(nlopt_opt opt) { return opt && nlopt_get_param(opt, "amd_exact_dot", 0.) != 0.; }
+
+/* Which summation order a local search uses.  "amd_exact_dot" set on the object (or on MLSL's local optimiser, `also`) decides;
+ * unset, a client's own nlopt_func gets the reference's sequential order — its callback sees exactly the points the reference
+ * would hand it, which is what a drop-in owes it, and the callback's round trip dwarfs the cost of the ordered sums — while
+ * device objectives get the tree reductions (results to rounding). */
+int nla_exact_mode_for(nlopt_opt opt, nlopt_opt also, const nla_evaluator *ev)
+{
+    const int set_a = opt && nlopt_has_param(opt, "amd_exact_dot"), set_b = also && nlopt_has_param(also, "amd_exact_dot");
+    if (set_a || set_b) return (set_a && nla_exact_mode(opt)) || (set_b && nla_exact_mode(also));
+    return ev && ev->kind == NLA_EVAL_HOST;
+}

@@ -336,10 +336,15 @@ static int emu_co_launch(int alg, int n, int ld, int mf, int count, const double
     return 0;
 }
 
+/* test hook: the summation order (params.exact) the host drivers asked for in the last local-search launch — the emulation
+ * itself always sums in the reference's order */
+int nla_emu_last_exact = -1;
+
 int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X, double *work, int *iwork,
                       double *hist, const nla_lbfgs_params *P, nla_lbfgs_result *out, const nla_local_ext *ext, void *st)
 {
     EMU_LAUNCH();
+    nla_emu_last_exact = P->exact;
     (void) work; (void) iwork; (void) hist; (void) st;
     if (obj == NLA_OBJ_EXTERNAL) return emu_co_launch(0, n, ld, mf, count, lb, ub, NULL, X, P, NULL, out, ext);
     for (int i = 0; i < count; ++i) {
@@ -357,6 +362,7 @@ int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const d
                     const nla_mma_params *P, nla_lbfgs_result *out, const nla_local_ext *ext, void *st)
 {
     EMU_LAUNCH();
+    nla_emu_last_exact = P->exact;
     (void) work; (void) st;
     if (obj == NLA_OBJ_EXTERNAL) return emu_co_launch(1, n, ld, 0, count, lb, ub, sigma_init, X, NULL, P, out, ext);
     for (int i = 0; i < count; ++i) {

@@ -174,3 +174,52 @@ def test_mlsl_with_host_callbacks_equals_the_reference(libs, draw):
     R, E = libs
     algs = [G_MLSL, G_MLSL_LDS, GD_MLSL, GD_MLSL_LDS]
     same(play(R, 1000 + draw, algs), play(E, 1000 + draw, algs), 1000 + draw)
+
+
+def test_summation_order_default_follows_the_kind_of_objective():
+    """nla_exact_mode_for (userobj.c): a client's own nlopt_func gets the reference's sequential sums in the device local
+    optimisers unless "amd_exact_dot" says otherwise; registered device objectives get the tree reductions unless it says so —
+    read back from the launch parameters through the emulated device's hook"""
+    import ctypes as C
+    import numpy as np
+    from test_api_differential import EMU, FUNC, bind, vp, dpp
+    L = bind(C.CDLL(EMU))
+    L.nlopt_set_param.argtypes = [vp, C.c_char_p, C.c_double]
+    L.nlopt_amd_objective.restype = vp
+    L.nlopt_amd_objective.argtypes = [C.c_int]
+    L.nlopt_set_local_optimizer.argtypes = [vp, vp]
+    hook = C.c_int.in_dll(L, "nla_emu_last_exact")
+    own = FUNC(lambda n, x, g, d: (g and [g.__setitem__(i, 2 * x[i]) for i in range(n)]) and 0.0 or float(sum(x[i] * x[i] for i in range(n))))
+
+    def run(alg, f, param=None, local=None, local_param=None):
+        o = L.nlopt_create(alg, 3)
+        L.nlopt_set_min_objective(o, f, None)
+        lb, ub, x = np.full(3, -1.0), np.full(3, 2.0), np.full(3, 0.5)
+        L.nlopt_set_lower_bounds(o, lb.ctypes.data_as(dpp))
+        L.nlopt_set_upper_bounds(o, ub.ctypes.data_as(dpp))
+        L.nlopt_set_maxeval(o, 40)
+        if param is not None:
+            L.nlopt_set_param(o, b"amd_exact_dot", float(param))
+        lo = None
+        if local is not None:
+            lo = L.nlopt_create(local, 3)
+            if local_param is not None:
+                L.nlopt_set_param(lo, b"amd_exact_dot", float(local_param))
+            L.nlopt_set_local_optimizer(o, lo)
+        hook.value = -1
+        mf = C.c_double()
+        r = L.nlopt_optimize(o, x.ctypes.data_as(dpp), C.byref(mf))
+        L.nlopt_destroy(o)
+        if lo:
+            L.nlopt_destroy(lo)
+        assert r > 0
+        return hook.value
+    dev, host = L.nlopt_amd_objective(5), C.cast(own, vp)
+    LD_LBFGS, LD_MMA, G_MLSL_LDS, GD_MLSL = 11, 24, 39, 21
+    for alg in (LD_LBFGS, LD_MMA):
+        assert run(alg, host) == 1 and run(alg, dev) == 0
+        assert run(alg, host, param=0) == 0 and run(alg, dev, param=1) == 1
+    assert run(GD_MLSL, host) == 1 and run(GD_MLSL, dev) == 0
+    assert run(G_MLSL_LDS, host, local=LD_LBFGS) == 1 and run(G_MLSL_LDS, dev, local=LD_LBFGS) == 0
+    assert run(G_MLSL_LDS, dev, local=LD_LBFGS, local_param=1) == 1 and run(G_MLSL_LDS, host, local=LD_MMA, local_param=0) == 0
+    assert run(G_MLSL_LDS, dev, param=1, local=LD_LBFGS, local_param=0) == 1
