@@ -79,6 +79,14 @@ def test_a_seeded_client_script_prints_the_same_over_both_libraries():
     assert out_a.count("\nrun ") == 24 and "ForcedStop NLopt forced stop 60" in out_a and "raised Boom" in out_a
 
 
+@need
+def test_mlsl_with_explicit_local_optimisers_prints_the_same_over_both_libraries():
+    rc_r, out_r, err_r = run(os.path.join(SHIM, "mlsl_locals.py"), library=REF)
+    rc_a, out_a, err_a = run(os.path.join(SHIM, "mlsl_locals.py"), library=EMU)
+    assert rc_r == 0 and rc_a == 0, err_r + err_a
+    assert out_a == out_r and len(out_a.splitlines()) == 12 and "Error" not in out_a and "invalid" not in out_a
+
+
 def test_the_constants_are_the_headers():
     """names and values of nlopt_algorithm / nlopt_result as include/nlopt.h (= src/api/nlopt.h:71-177) declares them"""
     sys.path.insert(0, ROOT)
