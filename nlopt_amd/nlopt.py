@@ -439,7 +439,7 @@ class opt:
 
     # -- vectors: set_X(scalar | sequence), get_X() (NLOPT_GETSET_VEC, nlopt-in.hpp:531-553) --
     def _set_vec(self, name, v):
-        if isinstance(v, (int, float)) and not isinstance(v, bool) or isinstance(v, _np.floating):
+        if isinstance(v, (int, float, _np.floating, _np.integer)) and not isinstance(v, bool):
             self._throw(getattr(self._L, "nlopt_set_%s1" % name)(self._o, float(v)))
             return
         a = _vector(v, name)
