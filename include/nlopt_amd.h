@@ -375,7 +375,8 @@ int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *l
                       double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
                       const nla_local_ext *ext, void *stream);
 
-/* ---- LD_MMA without nonlinear constraints (src/algs/mma/mma.c), batched --------------------------- */
+/* ---- LD_MMA without nonlinear constraints (src/algs/mma/mma.c), batched; with constraints the outer algorithm runs on the
+ * host (csrc/mma_host.c) and this kernel solves its dual problems ------------------------------------------------------ */
 /* stopping values as nlopt_stopping holds them (nlopt-util.h:79-91) + the algorithm's parameters as the dispatcher reads
  * them (optimize.c:798-803: rho_init 1, sigma_min 0, inner_maxeval 0, inner_gradients 1, always_improve 1); exact, sign,
  * xtol_abs, x_weights (nlopt_stop_x, stop.c:98-108), abort (mma.c:258-260,394-396) as for LD_LBFGS */

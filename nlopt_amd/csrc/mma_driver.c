@@ -6,8 +6,8 @@
  *
  * Objectives: compiled-in device objectives (the whole search is one launch), user device objectives and ordinary host
  * callbacks (the kernel runs as a coroutine, lbfgs_driver.c).  maxtime and nlopt_force_stop are observed inside a search
- * (mma.c:258-260,394-396).  Not provided, and refused with a message: nonlinear constraints (the dual problem then has
- * variables and the reference solves it with a nested optimiser). */
+ * (mma.c:258-260,394-396).  With nonlinear constraints the dual problem has variables: the outer algorithm then runs on the host
+ * (mma_host.c) and solves each dual problem through this file, as the reference solves it through a nested LD_MMA. */
 #include "nla_internal.h"
 #include <math.h>
 #include <stdio.h>
@@ -40,8 +40,8 @@ nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, 
     char err[200];
     int rc;
     if ((rc = nla_mma_read_params(opt, &mma))) return (nlopt_result) rc;
-    if (opt->m > 0) { nla_stop_msg(stop, "nlopt_amd: LD_MMA is provided without nonlinear constraints only (the MLSL local-search case)"); return NLOPT_INVALID_ARGS; }
     if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
+    if (opt->m > 0) return nla_mma_constrained(opt, (unsigned) n, f, f_data, lb, ub, x, minf, stop, &mma);   /* mma_host.c */
     nla_evaluator_resolve(&ev, opt, f, f_data);
     memset(&prm, 0, sizeof prm);
     prm.minf_max = stop->minf_max; prm.ftol_rel = stop->ftol_rel; prm.ftol_abs = stop->ftol_abs; prm.xtol_rel = stop->xtol_rel;

@@ -237,6 +237,8 @@ int nla_local_ctx_read_ftrace(nla_local_ctx *c, int inst, int64_t count, double 
 /* LD_MMA without nonlinear constraints (mma_driver.c) */
 int nla_mma_read_params(nlopt_opt opt, nla_mma_params *out);     /* optimize.c:798-815; 0 or an nlopt_result < 0 with errmsg set */
 /* NLOPT_LN_COBYLA on the host (cobyla_host.c; reference entry cobyla_minimize, cobyla.c:181-271) */
+nlopt_result nla_mma_constrained(nlopt_opt opt, unsigned n, nlopt_func f, void *f_data, const double *lb, const double *ub,
+                                 double *x, double *minf, nla_stopping *stop, const nla_mma_params *prm);   /* mma_host.c */
 nlopt_result nla_cobyla_minimize(unsigned n, nlopt_func f, void *f_data, unsigned m, const nla_constraint *fc, unsigned p, const nla_constraint *h,
                                  const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, const double *dx);
 nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,

@@ -84,7 +84,7 @@ def test_unprovided_algorithms_refuse_with_a_message():
 
 def test_argument_errors_of_the_local_optimisers_come_before_any_device_work():
     """LD_MMA's parameters are validated as the reference's dispatcher does (optimize.c:807-815); what the device path does
-    not provide is refused by name — nonlinear constraints for LD_MMA, GN_MLSL's default local optimiser LN_COBYLA"""
+    not provide is refused by name; what it provides needs a device (constrained LD_MMA, LN_COBYLA, GN_MLSL with its default)"""
     L = nlopt_amd.lib()
 
     def mk(alg):
@@ -110,8 +110,8 @@ def test_argument_errors_of_the_local_optimisers_come_before_any_device_work():
     con = nlopt_amd.NLOPT_FUNC(lambda n, x, g, d: x[0] - 0.25)
     L.nlopt_add_inequality_constraint.argtypes = [C.c_void_p, nlopt_amd.NLOPT_FUNC, C.c_void_p, C.c_double]
     assert L.nlopt_add_inequality_constraint(o._h, con, None, 1e-8) > 0
-    x, minf, ret = o.optimize_raw(np.full(3, 0.5))
-    assert ret == nlopt_amd.INVALID_ARGS and "without nonlinear constraints" in o.get_errmsg()
+    x, minf, ret = o.optimize_raw(np.full(3, 0.5))          # constrained LD_MMA is served (mma_host.c) — on a machine with a device
+    assert ret == nlopt_amd.FAILURE and "no HIP device" in o.get_errmsg()
     o = mk(nlopt_amd.LN_COBYLA) if hasattr(nlopt_amd, "LN_COBYLA") else None
     if o is not None:                                  # a host algorithm, but not a CPU NLopt either: no device, no run
         x, minf, ret = o.optimize_raw(np.zeros(3))

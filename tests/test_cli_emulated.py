@@ -76,13 +76,17 @@ def test_the_references_tutorial_program_with_cobyla():
     assert out_e == out_r and "found minimum at f(" in out_e[0]
 
 
-@pytest.mark.skipif(not all(os.path.exists(p) for p in (EMU, os.path.join(REFDIR, "t_tutorial_amd"))),
-                    reason="oracle/_ref/t_tutorial_amd or the emulated library not built")
-def test_the_tutorial_program_with_constrained_mma_is_refused_by_name():
-    """LD_MMA with nonlinear constraints is outside the path: the program must end with the library's
-    message, not with a wrong answer"""
-    rc, out, err = run("t_tutorial_amd", preload=EMU)
-    assert rc != 0 and "LD_MMA is provided without nonlinear constraints only" in err
+@pytest.mark.skipif(not all(os.path.exists(p) for p in (EMU, os.path.join(REFDIR, "t_tutorial_amd"), os.path.join(REFDIR, "t_tutorial_ref"))),
+                    reason="oracle/_ref/t_tutorial_* or the emulated library not built")
+@pytest.mark.parametrize("args", [(), (24,)])
+def test_the_references_tutorial_program_with_constrained_mma(args):
+    """t_tutorial.cxx with its default algorithm, LD_MMA under two nonlinear inequality constraints (the tutorial of the
+    reference's documentation; ctest: `t_tutorial 24`): mma_host.c with the dual problems solved through the library's own
+    LD_MMA — same line as the reference build prints, evaluation count included"""
+    rc_e, out_e, err_e = run("t_tutorial_amd", *args, preload=EMU)
+    rc_r, out_r, _ = run("t_tutorial_ref", *args)
+    assert rc_e == rc_r == 0, "\n".join(out_e) + err_e
+    assert out_e == out_r and "Method of Moving Asymptotes" in out_e[0]
 
 
 @pytest.mark.skipif(not all(os.path.exists(p) for p in (EMU, os.path.join(REFDIR, "cpp_functor_amd"), os.path.join(REFDIR, "cpp_functor_ref"))),

@@ -110,3 +110,18 @@ def test_testopt_as_ctest_runs_it(alg, obj):
     rc_r, out_r, _ = go(TESTOPT_REF)
     assert rc_a == rc_r == 0, err_a
     assert out_a == out_r
+
+
+TUT, TUT_REF = os.path.join(ROOT, "oracle", "_ref", "t_tutorial_amd"), os.path.join(ROOT, "oracle", "_ref", "t_tutorial_ref")
+
+
+@pytest.mark.skipif(not (os.path.exists(TUT) and os.path.exists(TUT_REF)), reason="oracle/_ref/t_tutorial_* not built (no /root/reference at build time)")
+@pytest.mark.parametrize("args", [[], ["24"]])
+def test_reference_tutorial_program_with_constrained_mma(args):
+    """test/t_tutorial.cxx with LD_MMA under two nonlinear constraints (mma_host.c; every dual problem is an LD_MMA run of the
+    device kernel in coroutine mode with the reference's summation order): same line as the reference build prints.
+    Written after round 2's GPU budget was spent — first run on the device is the round-end suite."""
+    r = subprocess.run([TUT] + args, capture_output=True, text=True, timeout=300)
+    q = subprocess.run([TUT_REF] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and q.returncode == 0, r.stdout + r.stderr
+    assert r.stdout == q.stdout

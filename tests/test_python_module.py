@@ -3,7 +3,7 @@ nlopt-python.i, src/api/nlopt-in.hpp) over libnlopt_amd.  Client scripts written
 once with the module bound to the REAL reference library (oracle/_ref/libnlopt_ref.so) and once bound to the product (here: its
 build over the emulated device layer), and must print the same text:
 
-  * the reference's own test/t_python.py as ctest runs it for LN_COBYLA (test/CMakeLists.txt:76-79), unmodified;
+  * the reference's own test/t_python.py as ctest runs it for LN_COBYLA and LD_MMA (test/CMakeLists.txt:76-79), unmodified;
   * the reference's own test/t_memoize.py (all algorithms in one process, unmodified): it must pass, and the blocks of the
     algorithms of the path that draw no random numbers must be identical (the others start from a generator position that
     depends on algorithms outside the path having run before them);
@@ -37,9 +37,11 @@ def run(script, *args, library=None, timeout=900):
 
 @need
 @need_reftest
-def test_the_references_t_python_script_with_cobyla():
-    rc_r, out_r, err_r = run(os.path.join(REFTEST, "t_python.py"), 25, library=REF)
-    rc_a, out_a, err_a = run(os.path.join(REFTEST, "t_python.py"), 25, library=EMU)
+@pytest.mark.parametrize("args", [(25,), (24,), ()])
+def test_the_references_t_python_script(args):
+    """LN_COBYLA and (constrained) LD_MMA — the script's default — as ctest runs it (test/CMakeLists.txt:76-79)"""
+    rc_r, out_r, err_r = run(os.path.join(REFTEST, "t_python.py"), *args, library=REF)
+    rc_a, out_a, err_a = run(os.path.join(REFTEST, "t_python.py"), *args, library=EMU)
     assert rc_r == 0 and rc_a == 0, err_r + err_a
     assert out_a == out_r and "result code: 4" in out_a
 
