@@ -134,6 +134,29 @@ static nlopt_result minimize_dispatch(nlopt_opt opt, double *x, double *minf)
         if (own) nlopt_destroy(local_opt);
         return ret;
     }
+    case NLOPT_AUGLAG: case NLOPT_AUGLAG_EQ: case NLOPT_LN_AUGLAG: case NLOPT_LN_AUGLAG_EQ:
+    case NLOPT_LD_AUGLAG: case NLOPT_LD_AUGLAG_EQ: {                                     /* optimize.c:907-939: a caller of the path (auglag_host.c) */
+        nlopt_opt local_opt = opt->local_opt;
+        const nlopt_algorithm alg = opt->algorithm;
+        nlopt_result ret;
+        int own = 0;
+        if ((alg == NLOPT_AUGLAG || alg == NLOPT_AUGLAG_EQ) && !local_opt) { nla_set_errmsg(opt, "local optimizer must be specified for AUGLAG"); return NLOPT_INVALID_ARGS; }
+        if (!local_opt) {
+            local_opt = nlopt_create(alg == NLOPT_LN_AUGLAG || alg == NLOPT_LN_AUGLAG_EQ ? nla_local_search_alg_nonderiv : nla_local_search_alg_deriv, n);
+            if (!local_opt) { nla_set_errmsg(opt, "failed to create local_opt"); return NLOPT_FAILURE; }
+            own = 1;
+            nlopt_set_ftol_rel(local_opt, opt->ftol_rel); nlopt_set_ftol_abs(local_opt, opt->ftol_abs);
+            nlopt_set_xtol_rel(local_opt, opt->xtol_rel); nlopt_set_xtol_abs(local_opt, opt->xtol_abs);
+            nlopt_set_maxeval(local_opt, nla_local_search_maxeval);
+        }
+        if (opt->dx) nlopt_set_initial_step(local_opt, opt->dx);
+        opt->force_stop_child = local_opt;
+        ret = nla_auglag_minimize(n, opt->f, opt->f_data, opt->m, opt->fc, opt->p, opt->h, opt->lb, opt->ub, x, minf, &stop, local_opt,
+                                  alg == NLOPT_AUGLAG_EQ || alg == NLOPT_LN_AUGLAG_EQ || alg == NLOPT_LD_AUGLAG_EQ);
+        opt->force_stop_child = NULL;
+        if (own) nlopt_destroy(local_opt);
+        return ret;
+    }
     case NLOPT_GN_ISRES:                                                                 /* optimize.c:941-944 */
         if (!finite_domain(n, opt->lb, opt->ub)) { nla_set_errmsg(opt, "finite domain required for global algorithm"); return NLOPT_INVALID_ARGS; }
         return nla_isres_minimize(opt, (int) n, opt->f, opt->f_data, (int) opt->m, opt->fc, (int) opt->p, opt->h, opt->lb, opt->ub,
@@ -336,7 +359,7 @@ nlopt_result nla_optimize_limited(nlopt_opt opt, double *x, double *minf, int ma
     if (save_maxeval <= 0 || (maxeval > 0 && maxeval < save_maxeval)) nlopt_set_maxeval(opt, maxeval);
     if (save_maxtime <= 0 || (maxtime > 0 && maxtime < save_maxtime)) nlopt_set_maxtime(opt, maxtime);
     ret = nlopt_optimize(opt, x, minf);
-    nlopt_set_maxeval(opt, save_maxeval);
-    nlopt_set_maxtime(opt, save_maxtime);
+    opt->maxeval = save_maxeval;        /* restored directly: the setters would clear the run's message (as optimize.c:1109-1110 does), */
+    opt->maxtime = save_maxtime;        /* and the callers below want to pass a device failure's text on */
     return ret;
 }

@@ -179,10 +179,10 @@ nlopt_result nla_mma_constrained(nlopt_opt opt, unsigned n, nlopt_func f, void *
             M.rho = rho; M.count = 0;
             reti = nla_optimize_limited(dual_opt, y, &min_dual, 0, stop->maxtime - (nla_seconds() - stop->start));
             if (reti < 0 || reti == NLOPT_MAXTIME_REACHED) {
-                /* (the nested object's own message is gone by now: restoring its limits cleared it, optimize.c:1109-1110) */
-                if (reti < 0 && reti != NLOPT_FORCED_STOP)
-                    nla_stop_msg(stop, "nlopt_amd: the dual problem's optimiser %s (\"dual_algorithm\") ended with %s; LD_MMA, LD_LBFGS and LN_COBYLA are provided for it",
-                                 nlopt_algorithm_to_string(nlopt_get_algorithm(dual_opt)), nlopt_result_to_string(reti));
+                /* the reference reports a failure down there without text (restoring the limits clears it, optimize.c:1109-1110);
+                 * here a message of the nested run — a device failure, a "dual_algorithm" this library does not provide — is passed on */
+                const char *why = nlopt_get_errmsg(dual_opt);
+                if (reti < 0 && why) nla_stop_msg(stop, "dual problem (%s): %s", nlopt_algorithm_to_string(nlopt_get_algorithm(dual_opt)), why);
                 ret = reti;
                 goto done;
             }

@@ -239,6 +239,8 @@ int nla_mma_read_params(nlopt_opt opt, nla_mma_params *out);     /* optimize.c:7
 /* NLOPT_LN_COBYLA on the host (cobyla_host.c; reference entry cobyla_minimize, cobyla.c:181-271) */
 nlopt_result nla_mma_constrained(nlopt_opt opt, unsigned n, nlopt_func f, void *f_data, const double *lb, const double *ub,
                                  double *x, double *minf, nla_stopping *stop, const nla_mma_params *prm);   /* mma_host.c */
+nlopt_result nla_auglag_minimize(unsigned n, nlopt_func f, void *f_data, unsigned m, const nla_constraint *fc, unsigned p, const nla_constraint *h,
+                                 const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, nlopt_opt sub_opt, int sub_has_fc);   /* auglag_host.c */
 nlopt_result nla_cobyla_minimize(unsigned n, nlopt_func f, void *f_data, unsigned m, const nla_constraint *fc, unsigned p, const nla_constraint *h,
                                  const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, const double *dx);
 nlopt_result nla_mma_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x,

@@ -302,7 +302,7 @@ static int emu_co_launch(int alg, int n, int ld, int mf, int count, const double
     if (!ext || !ext->req || !ext->EX || !ext->EG || !ext->EF || !ext->save) return EMU_ERR;
     slot = (emu_co **) ext->save;
     for (int i = 0; i < count; ++i) {
-        emu_co *c;
+        emu_co *volatile c;             /* volatile: getcontext() may return twice */
         if (!ext->resume) {
             c = (emu_co *) calloc(1, sizeof *c);
             if (!c || !(c->stack = (char *) malloc(EMU_CO_STACK))) { free(c); return EMU_ERR; }

@@ -23,7 +23,7 @@ def make(alg):
     if grow:
         alg = "mlsl"
     a = {"crs": nlopt_amd.GN_CRS2_LM, "isres": nlopt_amd.GN_ISRES, "esch": nlopt_amd.GN_ESCH, "mlsl": nlopt_amd.G_MLSL_LDS, "mlsl_mma": nlopt_amd.GD_MLSL,
-         "lbfgs": nlopt_amd.LD_LBFGS, "mma": nlopt_amd.LD_MMA, "mma_con": nlopt_amd.LD_MMA}[alg]
+         "lbfgs": nlopt_amd.LD_LBFGS, "mma": nlopt_amd.LD_MMA, "mma_con": nlopt_amd.LD_MMA, "auglag": 31}[alg]    # 31 = NLOPT_LD_AUGLAG
     o = nlopt_amd.Opt(a, n)
     o.set_lower_bounds(lo); o.set_upper_bounds(hi); o.set_min_objective(nlopt_amd.objective(obj))
     o.set_maxeval(400)
@@ -42,6 +42,8 @@ def make(alg):
         o.set_ftol_rel(1e-6); o.set_population(10)
     if alg in ("lbfgs", "mma"):
         o.set_ftol_rel(1e-8)
+    if alg == "auglag":                  # the penalised problem goes to the default LD_MMA: one device context per outer iteration
+        o.add_blocksum_constraints(2, 1e-8); o.set_ftol_rel(1e-4); o.set_maxeval(40)
     if alg == "mma_con":                 # nonlinear constraints: host outer algorithm, one device context per dual problem
         o.add_blocksum_constraints(2, 1e-8); o.set_ftol_rel(1e-6); o.set_maxeval(12)
     return o, xs

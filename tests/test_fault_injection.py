@@ -13,7 +13,7 @@ EMU = os.path.join(os.path.dirname(HERE), "oracle", "libnlopt_amd_emu.so")
 
 
 @pytest.mark.skipif(not os.path.exists(EMU), reason="emulated library not built")
-@pytest.mark.parametrize("alg", ["crs", "isres", "esch", "mlsl", "mlsl_mma", "mlsl_grow", "lbfgs", "mma", "mma_con"])
+@pytest.mark.parametrize("alg", ["crs", "isres", "esch", "mlsl", "mlsl_mma", "mlsl_grow", "lbfgs", "mma", "mma_con", "auglag"])
 def test_every_failing_allocation_is_reported(alg):
     r = subprocess.run([sys.executable, os.path.join(HERE, "_emu_fault_worker.py"), alg], capture_output=True, text=True, timeout=900)
     last = (r.stdout.strip().splitlines() or ["<no output>"])[-1]

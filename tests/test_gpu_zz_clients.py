@@ -116,7 +116,7 @@ TUT, TUT_REF = os.path.join(ROOT, "oracle", "_ref", "t_tutorial_amd"), os.path.j
 
 
 @pytest.mark.skipif(not (os.path.exists(TUT) and os.path.exists(TUT_REF)), reason="oracle/_ref/t_tutorial_* not built (no /root/reference at build time)")
-@pytest.mark.parametrize("args", [[], ["24"]])
+@pytest.mark.parametrize("args", [[], ["24"], ["31"]])
 def test_reference_tutorial_program_with_constrained_mma(args):
     """test/t_tutorial.cxx with LD_MMA under two nonlinear constraints (mma_host.c; every dual problem is an LD_MMA run of the
     device kernel in coroutine mode with the reference's summation order): same line as the reference build prints.

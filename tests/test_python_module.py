@@ -37,13 +37,13 @@ def run(script, *args, library=None, timeout=900):
 
 @need
 @need_reftest
-@pytest.mark.parametrize("args", [(25,), (24,), ()])
+@pytest.mark.parametrize("args", [(25,), (24,), (31,), ()])
 def test_the_references_t_python_script(args):
-    """LN_COBYLA and (constrained) LD_MMA — the script's default — as ctest runs it (test/CMakeLists.txt:76-79)"""
+    """LN_COBYLA, (constrained) LD_MMA — the script's default — and LD_AUGLAG as ctest runs it (test/CMakeLists.txt:76-79)"""
     rc_r, out_r, err_r = run(os.path.join(REFTEST, "t_python.py"), *args, library=REF)
     rc_a, out_a, err_a = run(os.path.join(REFTEST, "t_python.py"), *args, library=EMU)
     assert rc_r == 0 and rc_a == 0, err_r + err_a
-    assert out_a == out_r and "result code: 4" in out_a
+    assert out_a == out_r and "result code:" in out_a
 
 
 def blocks(text):
@@ -67,8 +67,8 @@ def test_the_references_t_memoize_script():
     b_r, b_a = blocks(out_r), blocks(out_a)
     assert sorted(b_r) == sorted(b_a)
     served = [a for a in b_a if any(l.startswith("minimum value") for l in b_a[a])]
-    assert sorted(served) == [19, 20, 21, 22, 23, 24, 25, 35, 38, 39, 42]
-    for a in (22, 23, 24, 25, 39):                   # quasi-random MLSL, MMA, COBYLA: no draws from the shared generator
+    assert sorted(served) == [19, 20, 21, 22, 23, 24, 25, 30, 31, 32, 33, 35, 36, 37, 38, 39, 42]
+    for a in (22, 23, 24, 25, 30, 31, 32, 33, 36, 37, 39):   # quasi-random MLSL, MMA, COBYLA, the AUGLAG family: no draws from the shared generator
         assert b_a[a] == b_r[a], a
 
 
