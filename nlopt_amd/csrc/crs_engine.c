@@ -125,7 +125,8 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_ctrl); nla_dev_free(e->d_Wf); nla_host_free(e->h_fwcnt); nla_host_free(e->h_fwrec);
     nla_host_free(e->h_up); nla_host_free(e->h_status);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
-    nla_stream_destroy(e->main); nla_stream_destroy(e->rng);
+    if (e->rng != e->main) nla_stream_destroy(e->rng);
+    nla_stream_destroy(e->main);
     free(e);
 }
 
@@ -157,7 +158,8 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->B = (int) B;
     if (getenv("NLA_CRS_PASS_LOG")) e->pass_log = fopen(getenv("NLA_CRS_PASS_LOG"), "a");
     e->main = nla_stream_create();
-    e->rng = nla_stream_create();      /* (restricting this stream to a subset of the CUs — hipExtStreamCreateWithCUMask, every 4th / 16th CU — was measured:
+    /* NLA_ONE_STREAM (A/B switch for debugging stream-ordering problems): the generator work on the main stream too */
+    e->rng = getenv("NLA_ONE_STREAM") ? e->main : nla_stream_create();      /* (restricting this stream to a subset of the CUs — hipExtStreamCreateWithCUMask, every 4th / 16th CU — was measured:
                                         *  43.0 -> 43.1 k evals/s; what the digest kernels cost the gather is memory traffic, not CUs) */
     if (!e->main || !e->rng) goto fail;
     e->mts = nla_mtstream_create(e->rng);
@@ -210,6 +212,29 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
 fail:
     nla_crs_hip_engine_destroy(e, 0);
     return NULL;
+}
+
+/* development aid (NLA_CRS_DEBUG_DIR=<dir>): what the init kernels saw and made — the stream words, the rows and their f — of the
+ * LAST run, as <dir>/init_last.bin: header {n, ld, N, nwords, origin} (5 x i64), words (u32), X (N x ld f64), F (N f64).  A harness
+ * that finds a run diverging from the oracle keeps the file and can tell wrong words from wrong rows from wrong values. */
+static void dump_init(nla_crs_hip_engine *e, size_t nwords)
+{
+    char path[512];
+    FILE *fp;
+    const size_t nx = (size_t) e->N * (size_t) e->ld;
+    int64_t hdr[5] = { e->n, e->ld, e->N, (int64_t) nwords, (int64_t) nla_mtstream_origin(e->mts) };
+    uint32_t *w = (uint32_t *) malloc(sizeof(uint32_t) * (nwords ? nwords : 1));
+    double *x = (double *) malloc(sizeof(double) * (nx + (size_t) e->N));
+    if (w && x && !nla_memcpy_d2h(w, e->d_initwords, sizeof(uint32_t) * nwords, e->main) &&
+        !nla_memcpy_d2h(x, e->d_X, sizeof(double) * nx, e->main) && !nla_memcpy_d2h(x + nx, e->d_F, sizeof(double) * (size_t) e->N, e->main) &&
+        !nla_stream_sync(e->main)) {
+        snprintf(path, sizeof path, "%s/init_last.bin", getenv("NLA_CRS_DEBUG_DIR"));
+        if ((fp = fopen(path, "wb"))) {
+            fwrite(hdr, sizeof hdr, 1, fp); fwrite(w, sizeof(uint32_t), nwords, fp); fwrite(x, sizeof(double), nx + (size_t) e->N, fp);
+            fclose(fp);
+        }
+    }
+    free(w); free(x);
 }
 
 /* ---- ops ------------------------------------------------------------------------------------ */
@@ -285,6 +310,7 @@ static int op_init_population(void *ve, const double *x0, double *F)
         nla_event_destroy(ev_ag0); nla_event_destroy(ev_ag1);
         if (rc) FAIL(e, "init sync failed: %s", nla_dev_error_string(rc));
     }
+    if (getenv("NLA_CRS_DEBUG_DIR") && world == 1 && rows_per_chunk >= per) dump_init(e, (size_t) (wpr * (uint64_t) (e->N - 1)));
     nla_dev_free(e->d_initwords); e->d_initwords = NULL; e->initwords_cap = 0;
     /* start digesting the first batch of trial blocks while the host builds its ordered set */
     if (ensure_blocks(e, 0, 0)) return -1;

@@ -68,14 +68,36 @@ def main_isres():
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+CHK = 50     # evaluations per checkpoint of the decision sequence
+
+
+def decision_checkpoints(trace, fseq):
+    """The run as checkpoints a test can localise a divergence with on ANY machine: per block of CHK evaluations the CRC32 of
+    its (row, kind, accepted) records, and the f of the block's last evaluation (hex; compared to 1e-10 by the tests)."""
+    import zlib
+    rec = np.zeros(len(trace), dtype=[("row", "<i8"), ("kind", "<i4"), ("accepted", "<i4")])
+    rec["row"], rec["kind"], rec["accepted"] = trace["row"], trace["kind"], trace["accepted"]
+    crc, fl = [], []
+    for i in range(0, len(rec), CHK):
+        crc.append(zlib.crc32(rec[i:i + CHK].tobytes()) & 0xffffffff)
+        fl.append(float(fseq[min(i + CHK, len(rec)) - 1]).hex())
+    return dict(every=CHK, crc32=crc, f_last=fl)
+
+
 def main():
     out = {}
     for name, obj, n, pop, seed, kw in CASES:
         r = O.run_ref(19, obj, n, pop, seed, **kw)
+        # which row every evaluation went to is not visible through the reference's API: it comes from the 64-bit port, whose
+        # f sequence must be the reference's own, evaluation by evaluation and bit for bit, for it to count
+        p = O.run_port_crs(obj, n, pop, seed, trace_cap=len(r["fseq"]) + 8, **kw)
+        assert p["ret"] == r["ret"] and p["nevals"] == r["nevals"] and len(p["trace"]) == len(r["fseq"]), name
+        assert np.array_equal(p["trace"]["f"], r["fseq"]) and np.array_equal(p["x"], r["x"]), name
         out[name] = dict(obj=obj, n=n, pop=pop, seed=seed, kwargs=kw, ret=int(r["ret"]), nevals=int(r["nevals"]),
                          minf=float(r["minf"]).hex(), x=[float(v).hex() for v in r["x"]],
                          fseq_sha256=fhash(r["fseq"]), xhash_sha256=hashlib.sha256(r["xhash"].tobytes()).hexdigest(),
-                         fseq_head=[float(v).hex() for v in r["fseq"][:8]], fseq_tail=[float(v).hex() for v in r["fseq"][-8:]])
+                         fseq_head=[float(v).hex() for v in r["fseq"][:8]], fseq_tail=[float(v).hex() for v in r["fseq"][-8:]],
+                         checkpoints=decision_checkpoints(p["trace"], r["fseq"]))
         print(name, r["ret"], r["nevals"], r["minf"])
     with open(os.path.join(HERE, "crs_golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
