@@ -36,8 +36,10 @@ extern "C" {
 /* Host callback (sequential, same formulae) for device objective `id`; passing exactly this
  * pointer to nlopt_set_min/max_objective selects the HIP evaluator (pointer identity).  Under nlopt_set_max_objective the local
  * optimisers and MLSL keep the device evaluator (f and gradient are negated on the device, as the reference's f_max wrapper
- * does on the host, optimize.c:970-980); CRS2_LM / ISRES / ESCH run the maximisation through that wrapper, i.e. on the exact
- * host-callback path. */
+ * does on the host, optimize.c:970-980), and so do CRS2_LM / ISRES / ESCH (their evaluation kernels multiply f by -1: the flag
+ * NLA_OBJ_NEGATE).  Where part of the run has to call f on the HOST — fixed coordinates (the elimination wrapper), the parameter
+ * amd_host_eval, an ISRES constraint that is not a device constraint, LD_MMA with nonlinear constraints — the whole run goes through
+ * the reference's f_max wrapper instead, i.e. takes the exact host-callback path (api_optimize.c: objective_stays_on_device). */
 nlopt_func nlopt_amd_objective(int id);
 int nlopt_amd_objective_id(nlopt_func f);              /* -1: not a device objective */
 const char *nlopt_amd_objective_name(int id);

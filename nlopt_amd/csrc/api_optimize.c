@@ -291,12 +291,31 @@ static double best_seen_objective(unsigned n, const double *x, double *grad, voi
     return val;
 }
 
+/* Maximisation of a device objective (a registered one, or a user's kernel): may the run keep it on the device and let the
+ * drivers negate f there (opt->dev_sign), or will some part of the run call f on the host — which must then see the flipped
+ * callback like any other objective?  "On the device" only where the driver really evaluates every point there:
+ *   LD_LBFGS, MLSL*: always;  LD_MMA: without nonlinear constraints (with them the outer algorithm calls f on the host, mma_host.c);
+ *   CRS2_LM / ESCH: unless amd_host_eval or fixed coordinates (the elimination wrapper) put a host function in front;
+ *   ISRES: additionally only if every constraint is a device constraint (isres_driver.c falls back to host calls otherwise). */
+static int objective_stays_on_device(const nlopt_opt opt)
+{
+    const nlopt_algorithm a = opt->algorithm;
+    if (!(nlopt_amd_objective_id(opt->f) >= 0 || nla_userobj_is_adapter(opt->f))) return 0;
+    if (a == NLOPT_LD_LBFGS || a == NLOPT_G_MLSL || a == NLOPT_G_MLSL_LDS || (a >= NLOPT_GN_MLSL && a <= NLOPT_GD_MLSL_LDS)) return 1;
+    if (a == NLOPT_LD_MMA) return opt->m == 0;
+    if (a == NLOPT_GN_CRS2_LM || a == NLOPT_GN_ISRES || a == NLOPT_GN_ESCH) {
+        if (fix_applies(opt) || nlopt_get_param(opt, "amd_host_eval", 0) != 0) return 0;
+        return a != NLOPT_GN_ISRES || nla_isres_constraints_on_device(opt->m, opt->fc, opt->p, opt->h);
+    }
+    return 0;
+}
+
 nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
 {
     nlopt_func f; void *f_data; nlopt_precond pre;
     flip_data fd;
     best_seen mm;
-    int maximize, memo = 0;
+    int maximize, memo = 0, computed = 1;
     nlopt_result ret;
     nla_unset_errmsg(opt);
     if (!opt || !opt_f || !opt->f) { if (opt) nla_set_errmsg(opt, "NULL args to nlopt_optimize"); return NLOPT_INVALID_ARGS; }
@@ -304,12 +323,7 @@ nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
     nlopt_set_force_stop(opt, 0);
     opt->force_stop_child = NULL;
     if ((maximize = opt->maximize)) {          /* minimise -f (optimize.c:1014-1024) */
-        const nlopt_algorithm a = opt->algorithm;
-        const int local_or_mlsl = a == NLOPT_LD_LBFGS || a == NLOPT_LD_MMA || a == NLOPT_G_MLSL || a == NLOPT_G_MLSL_LDS ||
-                                  (a >= NLOPT_GN_MLSL && a <= NLOPT_GD_MLSL_LDS);
-        /* the population algorithms likewise, unless fixed coordinates put the elimination wrapper in front of the objective */
-        const int population_alg = (a == NLOPT_GN_CRS2_LM || a == NLOPT_GN_ISRES || a == NLOPT_GN_ESCH) && !fix_applies(opt);
-        if ((local_or_mlsl || population_alg) && (nlopt_amd_objective_id(f) >= 0 || nla_userobj_is_adapter(f))) {
+        if (objective_stays_on_device(opt)) {
             /* a device objective stays on the device: those drivers negate f and its gradient there (nla_evaluator.sign) */
             opt->dev_sign = -1;
         } else {
@@ -325,15 +339,15 @@ nlopt_result nlopt_optimize(nlopt_opt opt, double *x, double *opt_f)
          * algorithm's own answer (memoize_func, optimize.c:450-508,1026-1036,1064-1071) */
         mm.f = opt->f; mm.f_data = opt->f_data; mm.lb = opt->lb; mm.ub = opt->ub; mm.minf = DBL_MAX;
         mm.bestx = (double *) malloc(sizeof(double) * (opt->n ? opt->n : 1));
-        if (!mm.bestx) { nla_set_errmsg(opt, "out of memory"); memo = 0; ret = NLOPT_OUT_OF_MEMORY; goto restore; }
+        if (!mm.bestx) { nla_set_errmsg(opt, "out of memory"); memo = 0; ret = NLOPT_OUT_OF_MEMORY; computed = 0; goto restore; }
         if (x) memcpy(mm.bestx, x, sizeof(double) * opt->n);       /* (the reference leaves it uninitialised) */
         opt->f = best_seen_objective; opt->f_data = &mm;
     }
     ret = fix_applies(opt) ? minimize_fixed_eliminated(opt, x, opt_f) : minimize_dispatch(opt, x, opt_f);
     if (memo) {
-        memcpy(x, mm.bestx, sizeof(double) * opt->n);
+        /* (an early failure — no device, invalid arguments — made no objective call: leave x and *opt_f as the dispatcher left them) */
+        if (mm.minf < DBL_MAX) { memcpy(x, mm.bestx, sizeof(double) * opt->n); *opt_f = mm.minf; }
         free(mm.bestx);
-        *opt_f = mm.minf;
         opt->f = mm.f; opt->f_data = mm.f_data;
     }
 restore:
@@ -342,7 +356,7 @@ restore:
         opt->dev_sign = 0;
         opt->stopval = -opt->stopval;
         opt->f = f; opt->f_data = f_data; opt->pre = pre;
-        *opt_f = -*opt_f;
+        if (computed) *opt_f = -*opt_f;
     }
     return ret;
 }

@@ -312,6 +312,22 @@ static int con_eval_host(const nla_constraint *c, unsigned n, const double *x, d
     return 0;
 }
 
+/* a constraint the evaluation kernel can compute: the registered block-sum constraint with valid data */
+static int device_constraint(const nla_constraint *cc)
+{
+    const unsigned *qQ = (const unsigned *) cc->f_data;
+    return cc->f && cc->m == 1 && nlopt_amd_constraint_id(cc->f) == NLA_CON_BLOCKSUM && qQ && qQ[1] != 0 && qQ[0] < qQ[1];
+}
+/* will a run with these constraints evaluate everything on the device (given a device objective)?  The dispatcher asks before it
+ * decides who negates a maximised objective (api_optimize.c). */
+int nla_isres_constraints_on_device(unsigned m, const nla_constraint *fc, unsigned p, const nla_constraint *h)
+{
+    unsigned c;
+    for (c = 0; c < m; ++c) if (!device_constraint(fc + c)) return 0;
+    for (c = 0; c < p; ++c) if (!device_constraint(h + c)) return 0;
+    return 1;
+}
+
 nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, int m, nla_constraint *fc, int p, nla_constraint *h,
                                 const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, int population)
 {
@@ -349,10 +365,9 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     for (c = 0; c < m + p; ++c) {
         const nla_constraint *cc = c < m ? fc + c : h + (c - m);
         if (cc->m > maxdim) maxdim = cc->m;
-        if (cc->f && cc->m == 1 && nlopt_amd_constraint_id(cc->f) == NLA_CON_BLOCKSUM && cc->f_data) {
+        if (device_constraint(cc)) {
             const unsigned *qQ = (const unsigned *) cc->f_data;
             con[c].type = NLA_CON_BLOCKSUM; con[c].q = qQ[0]; con[c].Q = qQ[1]; con[c].tol = cc->tol[0];
-            if (qQ[1] == 0 || qQ[0] >= qQ[1]) dev_eval = 0;
         } else dev_eval = 0;
     }
     results = (double *) malloc(sizeof(double) * maxdim);

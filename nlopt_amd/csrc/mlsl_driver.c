@@ -319,12 +319,15 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         /* the local optimiser as mlsl.c:303-306 configures it: counted objective, the box, the stop value */
         lo_f = local_opt->f; lo_fdata = local_opt->f_data;
         cw.f = f; cw.f_data = f_data; cw.sign = 1.; cw.nevals_p = stop->nevals_p;      /* (f is already the flipped one where that applies) */
-        nlopt_set_min_objective(local_opt, mlsl_counted_f, &cw);
+        /* installed by assignment and taken out again at every exit below (opt->local_opt is the object's own copy whose objective
+         * nlopt_set_local_optimizer cleared, options.c:824-846: nothing of the user's to munge, but nothing of this stack frame
+         * may stay behind in it either) */
+        local_opt->f = mlsl_counted_f; local_opt->f_data = &cw; local_opt->pre = NULL; local_opt->maximize = 0;
         nlopt_set_lower_bounds(local_opt, lb);
         nlopt_set_upper_bounds(local_opt, ub);
         nlopt_set_stopval(local_opt, stop->minf_max);
         cob_x = (double *) nla_host_malloc(sizeof(double) * (size_t) n);
-        if (!cob_x) { nla_stop_msg(stop, "nlopt_amd: out of pinned memory"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
+        if (!cob_x) { nla_stop_msg(stop, "nlopt_amd: out of pinned memory"); ret = NLOPT_OUT_OF_MEMORY; goto done; }
     } else {
     D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
                    : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);

@@ -213,6 +213,7 @@ nlopt_result nla_crs_run(const nla_crs_engine_ops *ops, void *engine, const nla_
                          double *x, double *minf, uint64_t *words_used);
 
 /* reference-shaped entry (src/algs/isres/isres.h:34-41) */
+int nla_isres_constraints_on_device(unsigned m, const nla_constraint *fc, unsigned p, const nla_constraint *h);
 nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, int m, nla_constraint *fc, int p, nla_constraint *h,
                                 const double *lb, const double *ub, double *x, double *minf, nla_stopping *stop, int population);
 

@@ -8,6 +8,7 @@
  *   anything else           the adapter callback below: a single point through the same kernel (exact, slow) */
 #include "nla_internal.h"
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,7 +17,9 @@ struct nla_userobj {
     int refs;
     void *module, *fn;
     nlopt_func twin; void *twin_data;
-    /* single-point evaluation through the kernel (adapter) */
+    /* single-point evaluation through the kernel (adapter): one scratch set per object — and the object is shared by nlopt_copy
+     * (per-thread copies are the normal NLopt pattern), so the adapter serialises on `lock` */
+    pthread_mutex_t lock;
     void *st;
     double *d_x, *d_g, *d_f, *h_buf;       /* h_buf pinned: x | g | f */
     int cap;
@@ -30,6 +33,7 @@ void nla_userobj_release(nla_userobj *u)
     nla_dev_free(u->d_x); nla_dev_free(u->d_g); nla_dev_free(u->d_f); nla_host_free(u->h_buf);
     if (u->st) nla_stream_destroy(u->st);
     nla_module_unload(u->module);
+    pthread_mutex_destroy(&u->lock);
     free(u);
 }
 
@@ -60,22 +64,28 @@ static double adapter(unsigned n, const double *x, double *grad, void *data)
 {
     nla_userobj *u = (nla_userobj *) data;
     const int ld = (int) ((n + 1) & ~1u);
+    double fv = HUGE_VAL;
     if (u->twin) return u->twin(n, x, grad, u->twin_data);
+    pthread_mutex_lock(&u->lock);
     if ((int) n > u->cap) {
         nla_dev_free(u->d_x); nla_dev_free(u->d_g); nla_host_free(u->h_buf);
         u->d_x = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld);
         u->d_g = (double *) nla_dev_malloc(sizeof(double) * (size_t) ld);
         u->h_buf = (double *) nla_host_malloc(sizeof(double) * (2 * (size_t) ld + 1));
         u->cap = (u->d_x && u->d_g && u->h_buf) ? (int) n : 0;
-        if (!u->cap) return HUGE_VAL;
     }
-    memcpy(u->h_buf, x, sizeof(double) * n);
-    if (nla_memcpy_h2d(u->d_x, u->h_buf, sizeof(double) * n, u->st) ||
-        launch(u, (int) n, ld, 1, NULL, u->d_x, u->d_f, grad ? u->d_g : NULL, 1., u->st) ||
-        nla_memcpy_d2h(u->h_buf + 2 * (size_t) ld, u->d_f, sizeof(double), u->st) ||
-        (grad && nla_memcpy_d2h(u->h_buf + ld, u->d_g, sizeof(double) * n, u->st)) || nla_stream_sync(u->st)) return HUGE_VAL;
-    if (grad) memcpy(grad, u->h_buf + ld, sizeof(double) * n);
-    return u->h_buf[2 * (size_t) ld];
+    if (u->cap >= (int) n) {
+        memcpy(u->h_buf, x, sizeof(double) * n);
+        if (!(nla_memcpy_h2d(u->d_x, u->h_buf, sizeof(double) * n, u->st) ||
+              launch(u, (int) n, ld, 1, NULL, u->d_x, u->d_f, grad ? u->d_g : NULL, 1., u->st) ||
+              nla_memcpy_d2h(u->h_buf + 2 * (size_t) ld, u->d_f, sizeof(double), u->st) ||
+              (grad && nla_memcpy_d2h(u->h_buf + ld, u->d_g, sizeof(double) * n, u->st)) || nla_stream_sync(u->st))) {
+            if (grad) memcpy(grad, u->h_buf + ld, sizeof(double) * n);
+            fv = u->h_buf[2 * (size_t) ld];
+        }
+    }
+    pthread_mutex_unlock(&u->lock);
+    return fv;
 }
 int nla_userobj_is_adapter(nlopt_func f) { return f == adapter; }
 
@@ -91,6 +101,7 @@ static nlopt_result bind(nlopt_opt opt, const char *code_object, const char *nam
     u = (nla_userobj *) calloc(1, sizeof *u);
     if (!u) return NLOPT_OUT_OF_MEMORY;
     u->refs = 1; u->twin = twin; u->twin_data = f_data;
+    pthread_mutex_init(&u->lock, NULL);
     if (!(u->module = nla_module_load_file(code_object))) {
         nla_set_errmsg(opt, "nlopt_amd: could not load code object %s (build it for gfx950 with hipcc --genco)", code_object);
         nla_userobj_release(u); return NLOPT_INVALID_ARGS;

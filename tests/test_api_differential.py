@@ -302,6 +302,67 @@ def test_population_algorithms_maximising_a_registered_objective_agree_with_the_
         assert a["nev"] == r["nev"] and a["minf"] == r["minf"] and np.array_equal(a["x"], r["x"]), (a["cfg"], a["nev"], r["nev"], a["minf"], r["minf"])
 
 
+def play_max_with_host_parts(L, case, getter):
+    """MAXIMISING a registered (device) objective in the setups where part of the run calls f on the HOST after all: ISRES with an
+    ordinary host constraint, CRS2_LM / ESCH forced onto the host-callback path (amd_host_eval), LD_MMA with a nonlinear constraint.
+    The run must still maximise (round-2 advisor: it minimised and returned -min)."""
+    dp = lambda a: a.ctypes.data_as(dpp)
+    g = getattr(L, getter)
+    g.restype = vp
+    g.argtypes = [C.c_int]
+    alg, obj, n, host_eval = case
+    xs, lo, hi = O.golden_x0(obj, n)
+    opt = L.nlopt_create(alg, n)
+    lb, ub = np.full(n, lo), np.full(n, hi)
+    keep = []
+    log = [L.nlopt_set_lower_bounds(opt, dp(lb)), L.nlopt_set_upper_bounds(opt, dp(ub)), L.nlopt_set_max_objective(opt, g(O.OBJ[obj]), None)]
+    if alg in (35, 24):
+        if alg == 24:
+            def con(nn, x, gr, d):             # inactive: x0 <= hi + 1, with its gradient
+                if gr:
+                    for i in range(nn):
+                        gr[i] = 1.0 if i == 0 else 0.0
+                return float(x[0] - (hi + 1.0))
+        else:
+            def con(nn, x, gr, d):
+                return float(x[0] - (hi + 1.0))
+        cb = FUNC(con)
+        keep.append(cb)
+        log.append(L.nlopt_add_inequality_constraint(opt, C.cast(cb, vp), None, 1e-8))
+    if host_eval and hasattr(L, "nlopt_set_param") and getter == "nlopt_amd_objective":
+        L.nlopt_set_param.argtypes = [vp, C.c_char_p, dbl]
+        L.nlopt_set_param(opt, b"amd_host_eval", 1.0)          # (the reference ignores unknown parameters; not set there)
+    if alg != 24:
+        log.append(L.nlopt_set_population(opt, 30))
+    log.append(L.nlopt_set_maxeval(opt, 400))
+    if alg == 24:
+        log.append(L.nlopt_set_ftol_rel(opt, 1e-10))
+    L.nlopt_srand(97)
+    x = np.array(xs, dtype=float)
+    maxf = C.c_double(0)
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(maxf))
+    out = dict(log=log, ret=ret, maxf=maxf.value, x=x, nev=L.nlopt_get_numevals(opt))
+    L.nlopt_destroy(opt)
+    del keep
+    return out
+
+
+MAX_HOST_CASES = [(35, "rastrigin", 4, 0), (35, "sphere", 3, 0), (19, "rastrigin", 4, 1), (42, "griewank", 5, 1), (35, "ackley", 4, 1),
+                  (24, "sphere", 3, 0), (24, "rosenbrock", 4, 0)]
+
+
+@pytest.mark.parametrize("case", MAX_HOST_CASES, ids=lambda c: "alg%d_%s_n%d_hosteval%d" % c)
+def test_maximising_a_registered_objective_where_the_run_calls_f_on_the_host(case):
+    P = O.port()
+    ref = O.ref()
+    ref.orc_objective = P.orc_objective
+    r = play_max_with_host_parts(bind(ref), case, "orc_objective")
+    a = play_max_with_host_parts(bind(C.CDLL(EMU)), case, "nlopt_amd_objective")
+    assert a["log"] == r["log"] and a["ret"] == r["ret"], (case, a["ret"], r["ret"])
+    assert a["nev"] == r["nev"] and a["maxf"] == r["maxf"] and np.array_equal(a["x"], r["x"]), (case, a["nev"], r["nev"], a["maxf"], r["maxf"])
+    assert a["maxf"] > 0                   # a maximum of these objectives over their boxes, not minus a minimum
+
+
 # ---- option round trips: everything a setter stores, read back ------------------------------------------------------------------
 def play_options(L, draw):
     rng = np.random.default_rng(777000 + draw)

@@ -31,3 +31,20 @@ def test_population_algorithms_maximise_on_the_device(first):
         assert abs(a["minf"] - r["minf"]) <= 1e-7 * max(abs(r["minf"]), 1.0), (draw, a["cfg"], a["minf"], r["minf"])
         if alg == 19 and a["nev"] == r["nev"]:
             assert np.array_equal(a["x"], r["x"]), (draw, a["cfg"])          # CRS2_LM: nothing on the way to x involves libm
+
+
+@pytest.mark.parametrize("case", T.MAX_HOST_CASES, ids=lambda c: "alg%d_%s_n%d_hosteval%d" % c)
+def test_maximising_where_the_run_calls_f_on_the_host(case):
+    """round-2 advisor (high): with a host constraint, amd_host_eval or constrained LD_MMA the run called the unflipped callback
+    and MINIMISED.  These runs take the exact host-callback path: identical to the reference."""
+    P = O.port()
+    ref = O.ref()
+    ref.orc_objective = P.orc_objective
+    r = T.play_max_with_host_parts(T.bind(ref), case, "orc_objective")
+    a = T.play_max_with_host_parts(T.bind(C.CDLL(nlopt_amd.LIB_PATH)), case, "nlopt_amd_objective")
+    assert a["log"] == r["log"] and a["ret"] == r["ret"], (case, a["ret"], r["ret"])
+    assert a["maxf"] > 0 and a["nev"] == r["nev"]
+    if case[0] == 35:        # ISRES: candidates go through exp / log on the device (1 ulp from glibc here and there)
+        assert abs(a["maxf"] - r["maxf"]) <= 1e-9 * max(abs(r["maxf"]), 1.0)
+    else:
+        assert a["maxf"] == r["maxf"] and np.array_equal(a["x"], r["x"])
