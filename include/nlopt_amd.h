@@ -449,6 +449,7 @@ int nla_dev_set(int dev);
 void *nla_dev_malloc(size_t bytes);
 void nla_dev_free(void *p);
 void *nla_dev_malloc_uncached(size_t bytes);    /* MTYPE UC device memory: coherent between workgroups / XCDs without cache maintenance */
+void nla_dev_free_uncached(void *p);            /* back to the library's pool: uncached blocks are never returned to the driver while the process lives (devrt.hip) */
 void *nla_host_malloc(size_t bytes);            /* pinned */
 void nla_host_free(void *p);
 int nla_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream);

@@ -184,6 +184,8 @@ def lib():
     L.nlopt_amd_has_device_objective.argtypes = [vp]
     L.nla_dev_malloc_uncached.argtypes = [C.c_size_t]
     L.nla_dev_malloc_uncached.restype = vp
+    L.nla_dev_free_uncached.argtypes = [vp]
+    L.nla_dev_free_uncached.restype = None
     L.nla_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_double, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp,
                                   C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_int, vp]
     L.nla_crs_chain_ctrl_bytes.argtypes = [C.c_int, C.c_int]
@@ -260,6 +262,7 @@ class DevBuf:
 
     def __init__(self, nbytes, uncached=False):
         self.nbytes = int(nbytes)
+        self.uncached = bool(uncached)
         self.ptr = (lib().nla_dev_malloc_uncached if uncached else lib().nla_dev_malloc)(self.nbytes)
         if not self.ptr:
             raise MemoryError("nla_dev_malloc(%d) failed" % self.nbytes)
@@ -284,7 +287,7 @@ class DevBuf:
 
     def free(self):
         if self.ptr:
-            lib().nla_dev_free(self.ptr)
+            (lib().nla_dev_free_uncached if getattr(self, "uncached", False) else lib().nla_dev_free)(self.ptr)
             self.ptr = None
 
     def __del__(self):

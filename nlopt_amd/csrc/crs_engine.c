@@ -60,6 +60,7 @@ struct nla_crs_hip_engine {
     int32_t pend_slot[KCAP], pend_kind[KCAP];
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
+    int uncached;                  /* TX / TM / ctrl are uncached memory (the chain kernel may run) */
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
     /* device-resolved windows (hip/crs_chain.hip): control block, the walk's lists when they do not fit the kernel arguments,
      * what every slot took from where (pinned, written by the kernel) */
@@ -119,10 +120,12 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_words); nla_dev_free(e->d_jn); nla_dev_free(e->d_pos); nla_dev_free(e->d_last);
     nla_dev_free(e->d_lb); nla_dev_free(e->d_ub); nla_dev_free(e->d_X); nla_dev_free(e->d_F);
     nla_dev_free(e->d_initwords);
-    nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
+    if (e->uncached) { nla_dev_free_uncached(e->d_TX); nla_dev_free_uncached(e->d_TM); nla_dev_free_uncached(e->d_ctrl); }
+    else { nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_ctrl); }
+    nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
     nla_dev_free(e->d_up); nla_dev_free(e->d_tout); nla_dev_free(e->d_status);
     nla_dev_free(e->d_list); nla_host_free(e->h_list); nla_host_free(e->h_fTM);
-    nla_dev_free(e->d_ctrl); nla_dev_free(e->d_Wf); nla_host_free(e->h_fwcnt); nla_host_free(e->h_fwrec);
+    nla_dev_free(e->d_Wf); nla_host_free(e->h_fwcnt); nla_host_free(e->h_fwrec);
     nla_host_free(e->h_up); nla_host_free(e->h_status);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
     if (e->rng != e->main) nla_stream_destroy(e->rng);
@@ -130,7 +133,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     free(e);
 }
 
-nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj,
+nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj, int forward,
                                               nlopt_amd_stats *stats, char **errmsg)
 {
     nla_crs_hip_engine *e;
@@ -176,9 +179,11 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         e->bat[i].ev_ready = nla_event_create();
         if (!e->bat[i].ev_ready) goto fail;
     }
-    /* trial points and the chain kernel's control block: uncached memory (the workgroups of one launch read each other's) */
-    e->d_TX = (double *) nla_dev_malloc_uncached(sizeof(double) * (size_t) e->ld * KCAP);
-    e->d_TM = (double *) nla_dev_malloc_uncached(sizeof(double) * (size_t) e->ld * KCAP);
+    /* trial points and the chain kernel's control block: uncached memory where the workgroups of one launch read each other's
+     * (device-resolved windows); ordinary memory for the conservative passes, whose kernels meet only at launch boundaries */
+    e->uncached = (forward && obj >= 0) || getenv("NLA_UC_ALWAYS") != NULL;       /* (NLA_UC_ALWAYS: round 2's allocation pattern, A/B) */
+    e->d_TX = (double *) (e->uncached ? nla_dev_malloc_uncached : nla_dev_malloc)(sizeof(double) * (size_t) e->ld * KCAP);
+    e->d_TM = (double *) (e->uncached ? nla_dev_malloc_uncached : nla_dev_malloc)(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_fT = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP);
     e->d_fM = e->d_fT ? e->d_fT + KCAP : NULL;
     e->d_up = (char *) nla_dev_malloc(UPLOAD_BYTES);
@@ -194,7 +199,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         e->h_fTM = (double *) nla_host_malloc(sizeof(double) * 2 * KCAP);
         if (!e->d_list || !e->h_list || !e->h_fTM) goto fail;
     }
-    if (obj >= 0) {
+    if (e->uncached && obj >= 0) {
         e->d_ctrl = nla_dev_malloc_uncached(nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX));
         e->d_Wf = (double *) nla_dev_malloc(sizeof(double) * CHAIN_KMAX);
         e->h_fwcnt = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX);
@@ -204,7 +209,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->force_upload = getenv("NLA_CRS_UPLOAD") != NULL;
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1 ||
-        (obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
+        (e->uncached && obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
     if ((e->d_ctrl && nla_memset(e->d_ctrl, 0, nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX), e->main)) ||
         nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
         nla_memcpy_h2d(e->d_ub, ub, sizeof(double) * (size_t) n, e->main) || nla_stream_sync(e->main)) goto fail;
@@ -590,7 +595,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
         return NLOPT_FAILURE;
     }
-    *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->stats, NULL);
+    *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, pb->stats, NULL);
     if (!*eout) {
         nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
         return NLOPT_OUT_OF_MEMORY;

@@ -4,6 +4,7 @@
  * layer").  There is no CPU fallback anywhere: with no visible device nla_dev_count() returns 0
  * and the optimisers fail with NLOPT_FAILURE and an errmsg. */
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include "../../../include/nlopt_amd.h"
 
@@ -32,14 +33,75 @@ extern "C" void *nla_dev_malloc(size_t bytes)
 }
 extern "C" void nla_dev_free(void *p) { if (p) (void) hipFree(p); }
 /* device memory no cache holds on to (MTYPE UC): what one workgroup stores any other workgroup loads, on whichever XCD it runs,
- * without cache maintenance — for the small buffers the workgroups of hip/crs_chain.hip hand results to each other through */
+ * without cache maintenance — for the small buffers the workgroups of hip/crs_chain.hip hand results to each other through.
+ *
+ * These blocks are NEVER given back to the driver while the process lives: a released block goes to a free list and the next
+ * request of at most its size gets it again.  Round 2 allocated and freed them per run, and runs then saw — rarely, a few cache
+ * lines at a time — stale contents in ORDINARY allocations made afterwards ("the intermittent divergence"): memory that
+ * has been mapped uncached must not come back as cached memory (or the other way round) while caches may still hold its lines. */
+#include <mutex>
+struct uc_block { void *p; size_t bytes; bool busy; };
+static std::mutex uc_mu;
+static uc_block uc_pool[64];
+static int uc_n = 0;
+static bool uc_pool_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("NLA_UC_POOL"); on = (e && atoi(e) == 0) ? 0 : 1; }    /* NLA_UC_POOL=0: the round-2 behaviour (A/B) */
+    return on != 0;
+}
 extern "C" void *nla_dev_malloc_uncached(size_t bytes)
 {
     void *p = nullptr;
-    if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
-    if (alloc_fill() >= 0 && (hipMemset(p, alloc_fill(), bytes ? bytes : 1) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void) hipGetLastError();
+    if (!bytes) bytes = 1;
+    if (getenv("NLA_NO_UNCACHED")) return nla_dev_malloc(bytes);         /* A/B switch (debugging): ordinary memory instead */
+    if (uc_pool_on()) {
+        std::lock_guard<std::mutex> g(uc_mu);
+        int best = -1;
+        for (int i = 0; i < uc_n; ++i)
+            if (!uc_pool[i].busy && uc_pool[i].bytes >= bytes && (best < 0 || uc_pool[i].bytes < uc_pool[best].bytes)) best = i;
+        if (best >= 0) { uc_pool[best].busy = true; return uc_pool[best].p; }
+    }
+    if (uc_pool_on()) {
+        /* whole 2 MB pages of its own, with a guard page on either side: no ordinary allocation shares a page-table fragment with
+         * an uncached one */
+        const size_t two = (size_t) 2 << 20, want = (bytes + two - 1) / two * two;
+        void *raw = nullptr;
+        if (hipExtMallocWithFlags(&raw, want + 2 * two, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+        p = (void *) (((uintptr_t) raw + two + two - 1) / two * two);
+        bytes = want;
+    } else if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    if (alloc_fill() >= 0 && (hipMemset(p, alloc_fill(), bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void) hipGetLastError();
+    if (uc_pool_on()) {
+        std::lock_guard<std::mutex> g(uc_mu);
+        if (uc_n < 64) { uc_pool[uc_n].p = p; uc_pool[uc_n].bytes = bytes; uc_pool[uc_n].busy = true; ++uc_n; }
+        /* (a full table: the block is simply never pooled — and, by the rule above, never freed either: see nla_dev_free_uncached) */
+    }
     return p;
 }
+extern "C" void nla_dev_free_uncached(void *p)
+{
+    if (!p) return;
+    if (getenv("NLA_NO_UNCACHED")) { (void) hipFree(p); return; }
+    if (uc_pool_on()) {
+        std::lock_guard<std::mutex> g(uc_mu);
+        for (int i = 0; i < uc_n; ++i) if (uc_pool[i].p == p) { uc_pool[i].busy = false; return; }
+        return;                                   /* not in the table (it was full): kept until the process ends */
+    }
+    (void) hipFree(p);
+}
+/* development aid (tools/stress_crs.py --uc-churn): one raw uncached allocation, written once, given straight back to the driver —
+ * what every round-2 run did with its trial-point buffers */
+extern "C" int nla_debug_uncached_churn(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return -1; }
+    hipError_t e = hipMemset(p, 0x5a, bytes ? bytes : 1);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void) hipFree(p);
+    return (int) e;
+}
+
 extern "C" void *nla_host_malloc(size_t bytes)
 {
     void *p = nullptr;

@@ -264,7 +264,7 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 
 /* HIP engine (crs_engine.c) */
 typedef struct nla_crs_hip_engine nla_crs_hip_engine;
-nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj,
+nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj, int forward,
                                               nlopt_amd_stats *stats, char **errmsg);
 void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used);
 extern const nla_crs_engine_ops nla_crs_hip_ops;

@@ -164,7 +164,7 @@ def run_port_crs(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0
 
 
 def run_ref(alg, obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0.0, ftol_abs=0.0, xtol_rel=0.0,
-            record=True, setup=None):
+            record=True, setup=None, cap=None):
     """run the REAL reference through its public C API with the zoo objective as host callback"""
     R, L = ref(), port()
     xs, lo, hi = golden_x0(obj, n)
@@ -175,7 +175,7 @@ def run_ref(alg, obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0
     R.nlopt_set_lower_bounds(opt, dptr(lb))
     R.nlopt_set_upper_bounds(opt, dptr(ub))
     f = L.orc_objective(OBJ[obj])
-    cap = (maxeval or 100000) + 2 * n + 50000
+    cap = cap or (maxeval or 100000) + 2 * n + 50000
     fbuf = np.zeros(cap)
     hbuf = np.zeros(cap, dtype=np.uint64)
     rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)

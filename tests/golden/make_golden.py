@@ -33,6 +33,8 @@ CASES = [
     ("rosenbrock_n5_xtol", "rosenbrock", 5, 60, 9, dict(xtol_rel=1e-3, maxeval=20000)),
     ("rastrigin_n257_pop600_odd_n", "rastrigin", 257, 600, 5, dict(maxeval=1500)),
     ("griewank_n512_pop3000", "griewank", 512, 3000, 42, dict(maxeval=5000)),
+    # BASELINE.md's second gens-to-ftol pin: 191387 evaluations = 95.69 generations, minf 7.9706244871590783
+    ("rastrigin_n64_pop2000_ftol1e-6", "rastrigin", 64, 2000, 42, dict(ftol_rel=1e-6)),
 ]
 
 
@@ -87,7 +89,7 @@ def decision_checkpoints(trace, fseq):
 def main():
     out = {}
     for name, obj, n, pop, seed, kw in CASES:
-        r = O.run_ref(19, obj, n, pop, seed, **kw)
+        r = O.run_ref(19, obj, n, pop, seed, cap=400000, **kw)
         # which row every evaluation went to is not visible through the reference's API: it comes from the 64-bit port, whose
         # f sequence must be the reference's own, evaluation by evaluation and bit for bit, for it to count
         p = O.run_port_crs(obj, n, pop, seed, trace_cap=len(r["fseq"]) + 8, **kw)

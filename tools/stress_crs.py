@@ -9,6 +9,7 @@ ISRES runs the way the test suite does (other streams, other allocation sizes). 
 kernels saw (NLA_CRS_DEBUG_DIR) and, on a divergence, analyses it on the spot: stream words against the host generator, rows
 against the words.  Everything found goes to gpurun_out/crs_divergence.jsonl; the summary to gpurun_out/stress_<tag>.json."""
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -27,6 +28,8 @@ ap.add_argument("--churn", type=int, default=1)
 ap.add_argument("--dump", type=int, default=0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--golden-too", type=int, default=1)
+ap.add_argument("--golden-only", type=int, default=0, help="only the golden cases (robust: far from convergence), in sorted order")
+ap.add_argument("--uc-churn", type=int, default=0, help="between runs: allocate, write and free a raw uncached buffer (MB drawn up to this)")
 args = ap.parse_args()
 
 OUT = os.path.join(ROOT, "gpurun_out")
@@ -91,7 +94,16 @@ def analyse_dump(seed, obj):
     return rep
 
 
+_gi = [0]
+
+
 def draw():
+    if args.golden_only:
+        names = [k for k in sorted(GOLD) if GOLD[k]["nevals"] < 50000]
+        name = names[_gi[0] % len(names)]
+        _gi[0] += 1
+        g = GOLD[name]
+        return name, g["obj"], g["n"], g["pop"], g["seed"], dict(g["kwargs"]), g
     if args.golden_too and rng.rand() < 0.3:
         name = sorted(GOLD)[rng.randint(len(GOLD))]
         g = GOLD[name]
@@ -133,13 +145,19 @@ def churn(it):
         print("churn failed:", e)
 
 
+PORT_CACHE = {}
 t_end = time.time() + args.seconds
 runs = bad = 0
 kinds = {}
 while time.time() < t_end:
     name, obj, n, pop, seed, kw, g = draw()
     a = T.run_amd(obj, n, pop, seed, trace_cap=200000, **kw)
-    p = O.run_port_crs(obj, n, pop, seed, trace_cap=200000, **kw)
+    if g is not None and name in PORT_CACHE:
+        p = PORT_CACHE[name]
+    else:
+        p = O.run_port_crs(obj, n, pop, seed, trace_cap=200000, **kw)
+        if g is not None:
+            PORT_CACHE[name] = p
     runs += 1
     rep = D.explain(name, a, p, g, extra=dict(tag=args.tag, iteration=runs))
     if not rep["ok"]:
@@ -152,7 +170,13 @@ while time.time() < t_end:
                 f.write(json.dumps(dict(case=name, dump_analysis=more, tag=args.tag)) + "\n")
     if args.churn and runs % 3 == 0:
         churn(runs)
-summary = dict(tag=args.tag, seconds=args.seconds, runs=runs, bad=bad, phases=kinds, churn=args.churn, dump=args.dump,
+    if args.uc_churn:
+        L = nlopt_amd.lib()
+        L.nla_debug_uncached_churn.argtypes = [C.c_size_t]
+        for _ in range(2):
+            L.nla_debug_uncached_churn(int(rng.randint(1, args.uc_churn * (1 << 20))))
+summary = dict(tag=args.tag, seconds=args.seconds, runs=runs, bad=bad, phases=kinds, churn=args.churn, dump=args.dump, uc_churn=args.uc_churn,
+               golden_only=args.golden_only,
                env={k: v for k, v in os.environ.items() if k.startswith("NLA_")})
 print("SUMMARY", json.dumps(summary))
 with open(os.path.join(OUT, "stress_%s.json" % args.tag), "w") as f:
