@@ -255,6 +255,30 @@ int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, c
 int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
                           const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *stream);
 
+/* ---- CRS2_LM over several GPUs: the population sharded by COORDINATE (hip/crs_shard.hip) -----------------------------------------
+ * Rank r holds columns [r * colper, r * colper + nc) of every row (colper = ceil(n / world); local index i = global column c0 + i;
+ * rows ld >= nc apart, pad columns zero).  The reference's trial point (crs.c:63-121), mutation (:139-146) and row replacement
+ * (:153) are per coordinate, so each rank runs them on its slice unchanged; the candidates of a pass cross the ranks (all-gather
+ * of their slices) and every rank evaluates the assembled points with the single-GPU reduction: identical f everywhere. */
+/* nla_k_crs_advance on a column slice: n rows are summed, ncol <= ld coordinates of each are held (X, TX, lb, ub: the slice's) */
+int nla_k_crs_advance_cols(int n, int ncol, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                           const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                           uint64_t first_block, int K, const int64_t *W, int nW,
+                           const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                           double *TX, int variant, void *stream);
+/* replaces: crs.c:211-219 for the slice — X[row_first + r][i] = urand(lb[i], ub[i]) from the words of (row, column c0 + i), i < nc */
+int nla_k_crs_sh_init_rows(int n, int c0, int nc, int ld, const double *lb, const double *ub, const uint32_t *words,
+                           int64_t row_first, int64_t nrows, double *X, void *stream);
+/* the mutation half of nla_k_crs_finish on the slice, for the window slots completed by the preceding advance: TM[q] = slice of the
+ * mutation (crs.c:139-146), and both slices packed for the all-gather: SEND[(2a) * colper + i] = T_i, SEND[(2a+1) * colper + i] = M_i */
+int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colper, const double *X, int64_t i0, const double *TX, double *TM,
+                             const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in,
+                             const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND, void *stream);
+/* the evaluation half (crs.c:133, :146) on the gathered candidates: RECV rank-major, each rank's block = 2K slices of colper doubles;
+ * fT_ring / fM_ring / status as nla_k_crs_finish writes them */
+int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
+                      const double *RECV, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *stream);
+
 /* replaces: memcpy(worst->k, d->p, ...) at crs.c:153 for a batch of accepted candidates.
  * X[row[c]] := (kind[c] == 1 ? TX : TM)[slot[c]];  rows must be distinct within one call. */
 int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,

@@ -133,6 +133,7 @@ typedef struct {
     double *minf;
     double *xtmp;
     int need_x;
+    const nla_stopping *sp;   /* what the clock / force_stop tests look at: pb->stop, or the view all ranks agreed on for this pass */
     int64_t xrow;         /* row whose content is the x of the last STRICT improvement of minf (crs.c:253-259), -1: rs->x holds it */
     nlopt_result ret;
 } run_state;
@@ -171,7 +172,7 @@ static int after_accept(run_state *rs, uint64_t block, int kind)
     }
     if (ret != NLOPT_SUCCESS) {                 /* quirk kept: crs.c:263-268 */
         if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
-        else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
+        else if (nla_stop_time(rs->sp)) ret = NLOPT_MAXTIME_REACHED;
     }
     rs->ret = ret;
     return 0;
@@ -201,6 +202,7 @@ struct nla_crs_session {
     double *Wf;                    /* f of the rows W */
     uint32_t *fwcnt, *fwrec;       /* Kmax, Kmax x FWCAP: the last window's records */
     uint64_t *lastw;               /* N: (block + 1) << 1 | (reflection trial ? 1 : 0) of the row's last writer, 0 = initial row */
+    nla_stopping view; int agreed_force;      /* the stop view all ranks agreed on (collective passes only) */
 };
 
 static void session_free(nla_crs_session *S)
@@ -280,7 +282,12 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
 
     /* the device generates and (if it can) evaluates all N rows; the reference's stop tests run
      * after *every* evaluation, so replay them in row order and forget rows past the first stop */
+    rs->sp = stop;
     if (ops->init_population(e, x, rs->F)) { engine_failed(S); *ret_out = S->ret; return S; }
+    if (pb->comm) {            /* collective passes follow: every rank must leave the replay below at the same row */
+        rs->sp = nla_comm_agree_stop(pb->comm, stop, &S->view, &S->agreed_force);
+        if (!rs->sp) { nla_stop_msg(stop, "stop agreement failed: %s", nlopt_amd_comm_error(pb->comm)); S->ret = NLOPT_FAILURE; *ret_out = S->ret; return S; }
+    }
     for (i = 0; i < N && ret == NLOPT_SUCCESS; ++i) {
         if (S->host_eval) {
             if (i == 0) rs->F[0] = pb->f((unsigned) n, x, NULL, pb->f_data);
@@ -296,7 +303,7 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
         rows_done = i + 1;
         if (rs->F[i] < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
         else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
-        else if (nla_stop_time(stop)) ret = NLOPT_MAXTIME_REACHED;
+        else if (nla_stop_time(rs->sp)) ret = NLOPT_MAXTIME_REACHED;
     }
     S->init_words = 2ULL * (uint64_t) n * (uint64_t) (rows_done - 1);
     *minf = rs->F[rs->os.best];                               /* crs.c:246-248 */
@@ -333,6 +340,10 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
         int K, nW, j = 0, ncommit = 0, best_changed = 0, cap, a;
         uint64_t wend;
         if (eval_budget > 0 && (int64_t) (*stop->nevals_p - evals_at_entry) >= eval_budget) break;
+        if (pb->comm) {        /* the clock and the force_stop flag are decided once per pass, by all ranks together (comm.c) */
+            rs->sp = nla_comm_agree_stop(pb->comm, stop, &S->view, &S->agreed_force);
+            if (!rs->sp) { nla_stop_msg(stop, "stop agreement failed: %s", nlopt_amd_comm_error(pb->comm)); S->ret = NLOPT_FAILURE; return S->ret; }
+        }
         cap = ops->max_slots(e, S->block);
         if (cap <= 0) { engine_failed(S); return S->ret; }
         K = (int) ceil(S->kmult * S->runlen) + 4;
@@ -404,12 +415,12 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             fcand = status[j].fT;
             ++*stop->nevals_p;
             if (st) ++st->evals_trial;
-            if (nla_stop_forced(stop)) { trace_add(pb, fcand, -1, 1, 0); ret = NLOPT_FORCED_STOP; ++j; break; }
+            if (nla_stop_forced(rs->sp)) { trace_add(pb, fcand, -1, 1, 0); ret = NLOPT_FORCED_STOP; ++j; break; }
             if (fcand < rs->F[worst]) accepted = 1;
             else {
                 trace_add(pb, fcand, -1, 1, 0);
                 if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; ++j; break; }   /* only after a rejection */
-                if (nla_stop_time(stop)) { ret = NLOPT_MAXTIME_REACHED; ++j; break; }
+                if (nla_stop_time(rs->sp)) { ret = NLOPT_MAXTIME_REACHED; ++j; break; }
                 /* local mutation: consumes block blk+1 (crs.c:139-146) */
                 kind = 2;
                 if (host_eval) {
@@ -419,12 +430,12 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 fcand = status[j].fM;
                 ++*stop->nevals_p;
                 if (st) { ++st->evals_mutation; if (blk + 1 < S->fresh_from) ++st->slots_role; }
-                if (nla_stop_forced(stop)) { trace_add(pb, fcand, -1, 2, 0); ret = NLOPT_FORCED_STOP; j += 2; break; }
+                if (nla_stop_forced(rs->sp)) { trace_add(pb, fcand, -1, 2, 0); ret = NLOPT_FORCED_STOP; j += 2; break; }
                 if (fcand < rs->F[worst]) accepted = 1;
                 else {
                     trace_add(pb, fcand, -1, 2, 0);
                     if (nla_stop_evals(stop)) { ret = NLOPT_MAXEVAL_REACHED; j += 2; break; }
-                    if (nla_stop_time(stop)) { ret = NLOPT_MAXTIME_REACHED; j += 2; break; }
+                    if (nla_stop_time(rs->sp)) { ret = NLOPT_MAXTIME_REACHED; j += 2; break; }
                 }
             }
             if (accepted) {

@@ -71,12 +71,27 @@ struct nla_crs_hip_engine {
     int force_upload;              /* NLA_CRS_UPLOAD: the pass's lists through the H2D copy even when they fit the kernel arguments (A/B switch) */
     FILE *pass_log;                /* NLA_CRS_PASS_LOG=<file>: one line per pass (development aid, see tools/pass_log_summary.py) */
     nlopt_amd_stats *stats;
-    nlopt_amd_comm *comm;          /* multi-GPU: initial rows are generated in rank blocks and all-gathered; NULL = single process */
+    nlopt_amd_comm *comm;          /* multi-GPU: NULL = single process */
+    /* several GPUs, compiled-in objective: the population is sharded BY COORDINATE (hip/crs_shard.hip) — this rank holds columns
+     * [c0, c0 + nc) of every row, c0 = rank * colper, colper = ceil(n / world); ld = the slice's row stride.  Every rank replays the
+     * identical chain on identical f values: the candidates of a pass are all-gathered and evaluated by every rank */
+    int sharded, world, rank, c0, nc, colper;
+    int ncopy;                     /* coordinates a row copy moves: n, or nc */
+    double *d_csend, *d_crecv;     /* a pass's candidates: 2 KCAP slices of colper doubles, world x that */
+    double *d_gsend, *d_grecv, *h_g;   /* a whole point from its slices (read_row / read_slot): colper, world x colper */
+    const double *h_lb_full, *h_ub_full;   /* the caller's bounds (valid for the engine's life: the run's own arrays) */
     char err[256];
 };
 
 #define FAIL(e, ...) do { snprintf((e)->err, sizeof (e)->err, __VA_ARGS__); return -1; } while (0)
 #define CK(e, call) do { int rc_ = (call); if (rc_) FAIL(e, "%s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
+
+/* can n coordinates be dealt over `world` ranks in equal blocks of ceil(n / world) with nobody left empty? */
+int nla_crs_can_shard(int n, int world)
+{
+    if (world < 2) return 0;
+    return (int64_t) (world - 1) * ((n + world - 1) / world) < n;
+}
 
 static uint64_t trial_word0(const nla_crs_hip_engine *e) { return 2ULL * (uint64_t) e->n * (uint64_t) (e->N - 1); }
 
@@ -127,6 +142,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_list); nla_host_free(e->h_list); nla_host_free(e->h_fTM);
     nla_dev_free(e->d_Wf); nla_host_free(e->h_fwcnt); nla_host_free(e->h_fwrec);
     nla_host_free(e->h_up); nla_host_free(e->h_status);
+    nla_dev_free(e->d_csend); nla_dev_free(e->d_crecv); nla_dev_free(e->d_gsend); nla_dev_free(e->d_grecv); nla_host_free(e->h_g);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
     if (e->rng != e->main) nla_stream_destroy(e->rng);
     nla_stream_destroy(e->main);
@@ -134,7 +150,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
 }
 
 nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj, int forward,
-                                              nlopt_amd_stats *stats, char **errmsg)
+                                              nlopt_amd_comm *comm, int shard, nlopt_amd_stats *stats, char **errmsg)
 {
     nla_crs_hip_engine *e;
     size_t B;
@@ -142,8 +158,18 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     if (nla_dev_count() <= 0) return NULL;
     e = (nla_crs_hip_engine *) calloc(1, sizeof *e);
     if (!e) return NULL;
-    e->n = n; e->N = N; e->obj = obj; e->stats = stats;
-    e->ld = (n + 15) & ~15;          /* rows start on a 128-byte line (the chain kernel's contract; coalesced row reads everywhere) */
+    e->n = n; e->N = N; e->obj = obj; e->stats = stats; e->comm = comm; e->h_lb_full = lb; e->h_ub_full = ub;
+    e->world = nlopt_amd_comm_world(comm); e->rank = nlopt_amd_comm_rank(comm);
+    e->sharded = shard && nla_crs_can_shard(n, e->world) && obj >= 0;
+    e->c0 = 0; e->nc = e->ncopy = n; e->colper = n;
+    if (e->sharded) {
+        e->colper = (n + e->world - 1) / e->world;
+        e->c0 = e->rank * e->colper;
+        e->nc = n - e->c0 < e->colper ? n - e->c0 : e->colper;
+        e->ncopy = e->nc;
+        forward = 0;
+    }
+    e->ld = (e->nc + 15) & ~15;      /* rows start on a 128-byte line (the chain kernel's contract; coalesced row reads everywhere) */
     e->bat[0].index = e->bat[1].index = -1;
     /* blocks digested per batch (the block ring holds two batches).  The Vitter kernel walks all N rows per block, one lane per
      * block (a serial fp64 chain): a launch takes the same 40-70 ms (N = 1e5) whether it digests 4096 blocks or 32768 — it is
@@ -210,9 +236,21 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1 ||
         (e->uncached && obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
+    if (e->sharded) {
+        e->d_csend = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP * (size_t) e->colper);
+        e->d_crecv = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP * (size_t) e->colper * (size_t) e->world);
+        e->d_gsend = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->colper);
+        e->d_grecv = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
+        e->h_g = (double *) nla_host_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
+        if (!e->d_csend || !e->d_crecv || !e->d_gsend || !e->d_grecv || !e->h_g) goto fail;
+        if (nla_memset(e->d_gsend, 0, sizeof(double) * (size_t) e->colper, e->main) ||
+            nla_memset(e->d_csend, 0, sizeof(double) * 2 * KCAP * (size_t) e->colper, e->main)) goto fail;
+    }
+    /* the slice's bounds (the whole vectors in a single-process run); pad entries are zero */
     if ((e->d_ctrl && nla_memset(e->d_ctrl, 0, nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX), e->main)) ||
-        nla_memcpy_h2d(e->d_lb, lb, sizeof(double) * (size_t) n, e->main) ||
-        nla_memcpy_h2d(e->d_ub, ub, sizeof(double) * (size_t) n, e->main) || nla_stream_sync(e->main)) goto fail;
+        nla_memset(e->d_lb, 0, sizeof(double) * (size_t) e->ld, e->main) || nla_memset(e->d_ub, 0, sizeof(double) * (size_t) e->ld, e->main) ||
+        nla_memcpy_h2d(e->d_lb, lb + e->c0, sizeof(double) * (size_t) e->nc, e->main) ||
+        nla_memcpy_h2d(e->d_ub, ub + e->c0, sizeof(double) * (size_t) e->nc, e->main) || nla_stream_sync(e->main)) goto fail;
     return e;
 fail:
     nla_crs_hip_engine_destroy(e, 0);
@@ -247,6 +285,85 @@ static void dump_init(nla_crs_hip_engine *e, size_t nwords)
  * rows can be produced independently: with a communicator, rank r generates and evaluates rows
  * [1 + r*per, 1 + (r+1)*per) and the rows and their f are ALL-GATHERED in place ("CRS
  * init"); every rank then holds the whole population and runs the identical trial chain. */
+/* a whole point from its column slices: every rank contributes the nc coordinates it holds of the row at `src`, all-gathered */
+static int gather_point(nla_crs_hip_engine *e, const double *src, double *x)
+{
+    CK(e, nla_memcpy_d2d(e->d_gsend, src, sizeof(double) * (size_t) e->nc, e->main));
+    if (nla_comm_allgather_dev(e->comm, e->d_gsend, e->d_grecv, sizeof(double) * (size_t) e->colper, e->main))
+        FAIL(e, "all-gather of a point's slices failed: %s", nlopt_amd_comm_error(e->comm));
+    CK(e, nla_memcpy_d2h(e->h_g, e->d_grecv, sizeof(double) * (size_t) e->colper * (size_t) e->world, e->main));
+    CK(e, nla_stream_sync(e->main));
+    for (int r = 0; r < e->world; ++r) {
+        const int c0 = r * e->colper, cnt = e->n - c0 < e->colper ? e->n - c0 : e->colper;
+        memcpy(x + c0, e->h_g + (size_t) r * (size_t) e->colper, sizeof(double) * (size_t) cnt);
+    }
+    return 0;
+}
+
+/* crs_init's row loop on a column-sharded population.  Every rank draws ITS columns of every row from the same stream words (row
+ * i >= 1 owns words [2n(i-1), 2n i), coordinate j the pair at 2j).  The objective needs whole rows: the ROWS are dealt over the
+ * ranks in blocks for that — rank r evaluates rows [1 + r per, 1 + (r+1) per) straight from the words (crs_init_rows_kernel without
+ * the store: the same reduction as a single-GPU run, bit for bit) — and the f values are all-gathered in place (8 bytes per row).
+ * Nothing of the population itself travels. */
+static int op_init_population_sharded(nla_crs_hip_engine *e, const double *x0, double *F)
+{
+    const int n = e->n;
+    const uint64_t wpr = 2ULL * (uint64_t) n;
+    const int64_t per = (e->N - 1 + e->world - 1) / e->world;          /* rows per rank (evaluation) */
+    const int64_t first = 1 + per * e->rank, last = first + per < e->N ? first + per : e->N;
+    int64_t rows_per_chunk = (int64_t) (INIT_CHUNK_WORDS / wpr), r0;
+    void *ev = nla_event_create(), *ev_ag0 = nla_event_create(), *ev_ag1 = nla_event_create();
+    double *h_row = (double *) calloc((size_t) (e->ld > n ? e->ld : n), sizeof(double));
+    double *d_lbf = NULL, *d_ubf = NULL, *d_x0 = NULL;                 /* whole-row bounds and starting guess (evaluation only) */
+    const double *lbh = NULL, *ubh = NULL;
+    int rc = -1;
+    if (!ev || !ev_ag0 || !ev_ag1 || !h_row) { snprintf(e->err, sizeof e->err, "out of memory (init)"); goto out; }
+    if (e->world > ROWPAD) { snprintf(e->err, sizeof e->err, "more than %d ranks are not supported", ROWPAD); goto out; }
+    if (rows_per_chunk < 1) rows_per_chunk = 1;
+    if (rows_per_chunk > e->N - 1) rows_per_chunk = e->N - 1 > 0 ? e->N - 1 : 1;
+    e->d_initwords = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * (size_t) (rows_per_chunk * (int64_t) wpr));
+    d_lbf = (double *) nla_dev_malloc(sizeof(double) * (size_t) n);
+    d_ubf = (double *) nla_dev_malloc(sizeof(double) * (size_t) n);
+    d_x0 = (double *) nla_dev_malloc(sizeof(double) * (size_t) n);
+    if (!e->d_initwords || !d_lbf || !d_ubf || !d_x0) { snprintf(e->err, sizeof e->err, "out of device memory (init)"); goto out; }
+    lbh = e->h_lb_full; ubh = e->h_ub_full;
+    if (nla_memcpy_h2d(d_lbf, lbh, sizeof(double) * (size_t) n, e->main) || nla_memcpy_h2d(d_ubf, ubh, sizeof(double) * (size_t) n, e->main) ||
+        nla_memcpy_h2d(d_x0, x0, sizeof(double) * (size_t) n, e->main)) { snprintf(e->err, sizeof e->err, "H2D (init) failed"); goto out; }
+    /* row 0 = the caller's starting guess (crs.c:204): its slice (pad zero), and its value from the whole point */
+    memcpy(h_row, x0 + e->c0, sizeof(double) * (size_t) e->nc);
+    if (nla_memcpy_h2d(e->d_X, h_row, sizeof(double) * (size_t) e->ld, e->main) ||
+        nla_k_eval(OBJK(e), n, n, d_x0, 1, e->d_F, e->main) || nla_stream_sync(e->main)) { snprintf(e->err, sizeof e->err, "row 0 failed"); goto out; }
+    for (r0 = 1; r0 < e->N; r0 += rows_per_chunk) {
+        const int64_t nr = e->N - r0 < rows_per_chunk ? e->N - r0 : rows_per_chunk;
+        const int64_t lo = first > r0 ? first : r0, hi = last < r0 + nr ? last : r0 + nr;       /* this rank's rows inside the chunk */
+        if (r0 > 1 && (nla_event_record(ev, e->main) || nla_stream_wait_event(e->rng, ev))) { snprintf(e->err, sizeof e->err, "event failed"); goto out; }
+        if (nla_mtstream_fill(e->mts, wpr * (uint64_t) (r0 - 1), wpr * (uint64_t) nr, e->d_initwords)) { snprintf(e->err, sizeof e->err, "MT stream fill failed (init)"); goto out; }
+        if (nla_event_record(ev, e->rng) || nla_stream_wait_event(e->main, ev)) { snprintf(e->err, sizeof e->err, "event failed"); goto out; }
+        if (nla_k_crs_sh_init_rows(n, e->c0, e->nc, e->ld, e->d_lb, e->d_ub, e->d_initwords, r0, nr, e->d_X, e->main) ||
+            (hi > lo && nla_k_crs_init_rows(OBJK(e), n, n, d_lbf, d_ubf, e->d_initwords + (size_t) (lo - r0) * (size_t) wpr, lo, hi - lo, NULL, e->d_F, e->main))) {
+            snprintf(e->err, sizeof e->err, "init kernel launch failed"); goto out;
+        }
+    }
+    nla_event_record(ev_ag0, e->main);
+    if (nla_comm_allgather_dev(e->comm, e->d_F + first, e->d_F + 1, sizeof(double) * (size_t) per, e->main)) {
+        snprintf(e->err, sizeof e->err, "all-gather of the initial values failed: %s", nlopt_amd_comm_error(e->comm)); goto out;
+    }
+    nla_event_record(ev_ag1, e->main);
+    if (nla_memcpy_d2h(F, e->d_F, sizeof(double) * (size_t) e->N, e->main) || nla_stream_sync(e->main)) { snprintf(e->err, sizeof e->err, "D2H F failed"); goto out; }
+    if (e->stats) {
+        e->stats->t_allgather_ms += (double) nla_event_elapsed_ms(ev_ag0, ev_ag1);
+        e->stats->allgather_bytes += (uint64_t) e->world * (uint64_t) per * sizeof(double);
+    }
+    rc = 0;
+out:
+    nla_event_destroy(ev); nla_event_destroy(ev_ag0); nla_event_destroy(ev_ag1);
+    free(h_row);
+    nla_dev_free(d_lbf); nla_dev_free(d_ubf); nla_dev_free(d_x0);
+    nla_dev_free(e->d_initwords); e->d_initwords = NULL; e->initwords_cap = 0;
+    if (rc) return -1;
+    return ensure_blocks(e, 0, 0);
+}
+
 static int op_init_population(void *ve, const double *x0, double *F)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
@@ -257,7 +374,9 @@ static int op_init_population(void *ve, const double *x0, double *F)
     const int64_t first = 1 + per * rank;
     const int64_t last = first + per < e->N ? first + per : e->N;     /* this rank's rows: [first, last) */
     int64_t rows_per_chunk = (int64_t) (INIT_CHUNK_WORDS / wpr), r0;
-    void *ev = nla_event_create(), *ev_ag0 = NULL, *ev_ag1 = NULL;
+    void *ev, *ev_ag0 = NULL, *ev_ag1 = NULL;
+    if (e->sharded) return op_init_population_sharded(e, x0, F);
+    ev = nla_event_create();
     if (!ev) FAIL(e, "event create failed");
     if (world > ROWPAD) { nla_event_destroy(ev); FAIL(e, "more than %d ranks are not supported", ROWPAD); }
     if (rows_per_chunk < 1) rows_per_chunk = 1;
@@ -315,7 +434,7 @@ static int op_init_population(void *ve, const double *x0, double *F)
         nla_event_destroy(ev_ag0); nla_event_destroy(ev_ag1);
         if (rc) FAIL(e, "init sync failed: %s", nla_dev_error_string(rc));
     }
-    if (getenv("NLA_CRS_DEBUG_DIR") && world == 1 && rows_per_chunk >= per) dump_init(e, (size_t) (wpr * (uint64_t) (e->N - 1)));
+    if (getenv("NLA_CRS_DEBUG_DIR") && world == 1 && rows_per_chunk >= per && !e->sharded) dump_init(e, (size_t) (wpr * (uint64_t) (e->N - 1)));
     nla_dev_free(e->d_initwords); e->d_initwords = NULL; e->initwords_cap = 0;
     /* start digesting the first batch of trial blocks while the host builds its ordered set */
     if (ensure_blocks(e, 0, 0)) return -1;
@@ -351,7 +470,7 @@ static int upload_and_commit(nla_crs_hip_engine *e, const int64_t *W, int nW, co
     if (gen && K) memcpy(e->h_up + oG, gen, 4 * (size_t) K);
     CK(e, nla_memcpy_h2d(e->d_up, e->h_up, total, e->main));
     if (nc) {
-        CK(e, nla_k_crs_commit(e->n, e->ld, e->d_X, e->d_TX, e->d_TM, nc, (const int32_t *) (e->d_up + oS),
+        CK(e, nla_k_crs_commit(e->ncopy, e->ld, e->d_X, e->d_TX, e->d_TM, nc, (const int32_t *) (e->d_up + oS),
                                (const int32_t *) (e->d_up + oK), (const int64_t *) (e->d_up + oR), e->main));
         e->npending = 0;
     }
@@ -386,6 +505,23 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     for (int a = 0; a < K; ++a) {
         const uint64_t b = first_block + (uint64_t) a;
         t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
+    }
+    if (e->sharded) {
+        /* one rank of a column-sharded run: the same pass on the slice; the slices of the candidates that completed (trial point and
+         * mutation) are all-gathered and every rank evaluates the assembled points — identical status records on every rank */
+        const int ncol = (e->ld % 2 == 0 && e->nc % 2 != 0) ? e->nc + 1 : e->nc;      /* (an even count lets the gather take coordinate pairs; the pad column is zero) */
+        if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, NULL, NULL)) return -1;
+        CK(e, nla_event_record(e->ev0, e->main));
+        CK(e, nla_k_crs_advance_cols(n, ncol, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
+                                     d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
+        CK(e, nla_event_record(e->ev1, e->main));
+        CK(e, nla_k_crs_sh_mutate_pack(n, e->c0, e->nc, e->ld, e->colper, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
+                                       d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_csend, e->main));
+        if (nla_comm_allgather_dev(e->comm, e->d_csend, e->d_crecv, sizeof(double) * 2 * (size_t) K * (size_t) e->colper, e->main))
+            FAIL(e, "all-gather of the candidates failed: %s", nlopt_amd_comm_error(e->comm));
+        CK(e, nla_k_crs_sh_eval(OBJK(e), n, e->colper, first_block, K, d_tin, e->d_tout, KCAP - 1, e->d_crecv, e->d_fT, e->d_fM, e->d_status, e->main));
+        if (e->stats) e->stats->allgather_bytes += (uint64_t) e->world * 2 * (uint64_t) K * (uint64_t) e->colper * sizeof(double);
+        goto launched;
     }
     if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload && e->obj != -2) {
         /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
@@ -477,6 +613,7 @@ static int op_read_slot(void *ve, uint64_t block, int kind, double *x)
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const double *src = (kind == 1 ? e->d_TX : e->d_TM) + (size_t) (block & (KCAP - 1)) * (size_t) e->ld;
     if (flush_commits(e)) return -1;
+    if (e->sharded) return gather_point(e, src, x);
     CK(e, nla_memcpy_d2h(x, src, sizeof(double) * (size_t) e->n, e->main));
     CK(e, nla_stream_sync(e->main));
     return 0;
@@ -486,6 +623,7 @@ static int op_read_row(void *ve, int64_t row, double *x)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     if (flush_commits(e)) return -1;
+    if (e->sharded) return gather_point(e, e->d_X + (size_t) row * (size_t) e->ld, x);
     CK(e, nla_memcpy_d2h(x, e->d_X + (size_t) row * (size_t) e->ld, sizeof(double) * (size_t) e->n, e->main));
     CK(e, nla_stream_sync(e->main));
     return 0;
@@ -595,13 +733,21 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
         return NLOPT_FAILURE;
     }
-    *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, pb->stats, NULL);
+    {
+        /* several ranks and a compiled-in objective: the population is sharded by coordinate and the window runs as conservative
+         * passes on every rank's slice ("amd_shard" = 0: every rank keeps the whole population — replicas of the one chain) */
+        nlopt_amd_comm *comm = opt ? opt->comm : NULL;
+        const int shard = comm && nla_crs_can_shard(n, nlopt_amd_comm_world(comm)) && pb->obj >= 0 &&
+                          (!opt || nlopt_get_param(opt, "amd_shard", 1) != 0);
+        if (shard) { pb->forward = 0; pb->comm = comm; }
+        *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
+    }
     if (!*eout) {
         nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
         return NLOPT_OUT_OF_MEMORY;
     }
     (*eout)->user = user; (*eout)->sign = sign;
-    if (opt) { (*eout)->variant = (int) nlopt_get_param(opt, "amd_gather_variant", 0); (*eout)->comm = opt->comm; }
+    if (opt) (*eout)->variant = (int) nlopt_get_param(opt, "amd_gather_variant", 0);
     return NLOPT_SUCCESS;
 }
 

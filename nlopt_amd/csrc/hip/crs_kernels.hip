@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void crs_init_rows_kernel(int n, int ld, const
         const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
         return nla_urand_from(lb[i], ub[i], ww.x, ww.y);
     };
-    for (int i = lane; i < n; i += 64) xr[i] = gen(i);
+    if (X) for (int i = lane; i < n; i += 64) xr[i] = gen(i);      /* X == NULL: the values only (a column-sharded run keeps slices, crs_shard.hip) */
     if (OBJ >= 0) {
         double f = nla_wave_objective<(OBJ >= 0 ? OBJ : 0)>(n, gen);
         if (lane == 0) F[row_first + r] = sign * f;
@@ -134,7 +134,7 @@ struct crs_commits { int inl; int32_t slot[NLA_KA_MAX], kind[NLA_KA_MAX]; int64_
 
 template <int VEC, int U, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
-    int n, int ld, const double *__restrict__ X, int64_t i0, const int32_t *__restrict__ jn_ring,
+    int n, int ncol, int ld, const double *__restrict__ X, int64_t i0, const int32_t *__restrict__ jn_ring,
     const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, uint32_t ring_blocks,
     uint64_t first_block, int K, const int64_t *__restrict__ W, int nW,
     const int32_t *__restrict__ t_in, int32_t *__restrict__ t_out, int slot_mask, int chunks,
@@ -210,8 +210,9 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
         if (chunk == 0 && threadIdx.x == 0) t_out[a] = t0;
         return;
     }
+    /* n rows are summed; ncol coordinates of them are held here (ncol == n: the whole rows; a column slice on several GPUs, crs_shard.hip) */
     const int col = (chunk * 64 + lane) * VEC;
-    const bool active = col < n;
+    const bool active = col < ncol;
     const size_t colc = active ? (size_t) col : 0;
     const double *Xc = X + colc;
     double *accrow = TX + (size_t) q * (size_t) ld + colc;
@@ -445,7 +446,7 @@ extern "C" int nla_k_crs_mutate(int n, const double *best, double *p, const uint
 }
 
 /* variant: 0 = automatic; otherwise WAVES*100 + U (tuning / microbenchmarks) */
-static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+static int crs_advance_launch(int n, int ncol, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                               uint64_t first_block, int K, const int64_t *W, int nW,
                               const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
@@ -458,7 +459,21 @@ extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, con
 {
     crs_lists L;
     L.inl = 0;
-    return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, lb, ub,
+    return crs_advance_launch(n, n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, lb, ub,
+                              TX, variant, L, stream);
+}
+/* the same on a column slice: n rows are summed (the stream blocks' picks), ncol coordinates of every row are held (X, TX, lb, ub
+ * are the slice's: ld apart, local indices) — the gather-sum of one rank of a column-sharded run (crs_shard.hip) */
+extern "C" int nla_k_crs_advance_cols(int n, int ncol, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+                                      const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                                      uint64_t first_block, int K, const int64_t *W, int nW,
+                                      const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                                      double *TX, int variant, void *stream)
+{
+    crs_lists L;
+    L.inl = 0;
+    if (ncol < 1 || ncol > ld) return (int) hipErrorInvalidValue;
+    return crs_advance_launch(n, ncol, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, lb, ub,
                               TX, variant, L, stream);
 }
 /* the same with W (nW <= 128) and t_in (K <= 128) given as HOST arrays: they travel as kernel arguments */
@@ -473,10 +488,10 @@ extern "C" int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0
     L.inl = 1;
     for (int a = 0; a < K; ++a) L.t_in[a] = h_t_in[a];
     for (int j = 0; j < nW; ++j) L.W[j] = h_W[j];
-    return crs_advance_launch(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, nullptr, nW, nullptr, t_out, slot_mask,
+    return crs_advance_launch(n, n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, nullptr, nW, nullptr, t_out, slot_mask,
                               lb, ub, TX, variant, L, stream);
 }
-static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
+static int crs_advance_launch(int n, int ncol, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                               uint64_t first_block, int K, const int64_t *W, int nW,
                               const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
@@ -486,13 +501,13 @@ static int crs_advance_launch(int n, int ld, const double *X, int64_t i0, const 
     hipStream_t st = (hipStream_t) stream;
     /* variant = [1 if thin][WAVES][U as two digits]; thin = one coordinate per lane (64-coordinate chunks:
      * twice the workgroups per slot, for when few slots must spread over the whole chip) */
-    bool vec2 = (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
+    bool vec2 = (ncol % 2 == 0) && (ld % 2 == 0) && ncol >= 128;
     if (variant == 0) variant = n >= 2048 ? 832 : (n >= 512 ? 416 : (n >= 128 ? 216 : 116));
     if (variant >= 10000) { vec2 = false; variant -= 10000; }
     const int cpw = vec2 ? 128 : 64;
-    const int chunks = (n + cpw - 1) / cpw;
+    const int chunks = (ncol + cpw - 1) / cpw;
     const dim3 grid((unsigned) ((long) chunks * K));
-#define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, n, ld, X, i0, jn_ring, \
+#define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, n, ncol, ld, X, i0, jn_ring, \
         pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX, L)
     if (vec2) {
         switch (variant) {

@@ -200,6 +200,8 @@ typedef struct {
     int max_spec;                   /* cap on slots per round (0 = default) */
     int forward;                    /* 1: windows through the engine's chain op (device-resolved dependences), 0: the conservative passes */
     double window_factor;           /* window = factor x (blocks consumed per pass, smoothed) + 4 (0 = default 1.5) */
+    nlopt_amd_comm *comm;           /* non-NULL: the engine's passes are collective (column-sharded run) — the per-process stop conditions
+                                     * (clock, force_stop) are then agreed by all ranks once per pass (nla_comm_agree_stop) */
 } nla_crs_problem;
 
 /* the algorithm, resumable between speculation rounds (bench steps, sessions);
@@ -265,8 +267,9 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 /* HIP engine (crs_engine.c) */
 typedef struct nla_crs_hip_engine nla_crs_hip_engine;
 nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj, int forward,
-                                              nlopt_amd_stats *stats, char **errmsg);
+                                              nlopt_amd_comm *comm, int shard, nlopt_amd_stats *stats, char **errmsg);
 void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used);
+int nla_crs_can_shard(int n, int world);
 extern const nla_crs_engine_ops nla_crs_hip_ops;
 
 /* reference-shaped entry (src/algs/crs/crs.h:34-40) */

@@ -133,12 +133,14 @@ int nla_k_crs_init_rows(int obj, int n, int ld, const double *lb, const double *
     EMU_LAUNCH();
     const double sign = emu_obj_sign(&obj);
     (void) st;
+    double *tmp = X ? NULL : (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));      /* X == NULL: the values only */
     for (int64_t r = 0; r < nrows; ++r) {
-        double *x = X + (size_t) (row_first + r) * (size_t) ld;
+        double *x = X ? X + (size_t) (row_first + r) * (size_t) ld : tmp;
         const uint32_t *w = words + (size_t) r * 2 * (size_t) n;
         for (int i = 0; i < n; ++i) x[i] = urand_from(lb[i], ub[i], w[2 * i], w[2 * i + 1]);
         if (obj >= 0) F[row_first + r] = sign * nla_obj_eval_seq(obj, (unsigned) n, x, NULL);
     }
+    free(tmp);
     return 0;
 }
 int nla_k_eval(int obj, int n, int ld, const double *P, int64_t count, double *F, void *st)
@@ -642,6 +644,91 @@ int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0, const int
     EMU_LAUNCH();
     return nla_k_crs_advance(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, h_W, nW, h_t_in, t_out, slot_mask, lb, ub, TX, variant, st);
 }
+int orc_k_advance_slot_cols(int n, int ncol, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last, const int64_t *W,
+                            int nun, int t0, const double *lb, const double *ub, double *acc);
+int nla_k_crs_advance_cols(int n, int ncol, int ld, const double *X, int64_t i0, const int32_t *jn_ring, const int32_t *pos_ring,
+                           const int32_t *last_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W, int nW, const int32_t *t_in,
+                           int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *TX, int variant, void *st)
+{
+    EMU_LAUNCH();
+    (void) variant; (void) st;
+    for (int a = 0; a < K; ++a) {
+        const uint64_t block = first_block + (uint64_t) a;
+        const uint32_t rb = (uint32_t) (block % ring_blocks);
+        const int q = (int) (block & (uint64_t) slot_mask);
+        t_out[a] = orc_k_advance_slot_cols(n, ncol, ld, X, i0, jn_ring[rb], pos_ring + (size_t) rb * (size_t) n, last_ring[rb], W, a < nW ? a : nW,
+                                           t_in[a], lb, ub, TX + (size_t) q * (size_t) ld);
+    }
+    return 0;
+}
+
+/* ---- the column-sharded CRS2_LM (hip/crs_shard.hip): slices of rows, the pass's candidates packed, gathered and evaluated ------------ */
+int nla_k_crs_sh_init_rows(int n, int c0, int nc, int ld, const double *lb, const double *ub, const uint32_t *words, int64_t row_first,
+                           int64_t nrows, double *X, void *st)
+{
+    EMU_LAUNCH();
+    (void) st;
+    for (int64_t r = 0; r < nrows; ++r) {
+        const uint32_t *w = words + (size_t) r * 2 * (size_t) n + 2 * (size_t) c0;
+        double *xr = X + (size_t) (row_first + r) * (size_t) ld;
+        for (int i = 0; i < ld; ++i) xr[i] = i < nc ? urand_from(lb[i], ub[i], w[2 * i], w[2 * i + 1]) : 0.0;
+    }
+    return 0;
+}
+int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colper, const double *X, int64_t i0, const double *TX, double *TM,
+                             const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in,
+                             const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND, void *st)
+{
+    EMU_LAUNCH();
+    (void) st;
+    if (nc > colper || nc > ld) return EMU_ERR;
+    for (int a = 0; a < K; ++a) {
+        const uint64_t block = first_block + (uint64_t) a;
+        const int q = (int) (block & (uint64_t) slot_mask);
+        const double *x = TX + (size_t) q * (size_t) ld, *xb = X + (size_t) i0 * (size_t) ld;
+        const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n + 2 * (size_t) c0;
+        double *m = TM + (size_t) q * (size_t) ld, *sT = SEND + (size_t) (2 * a) * (size_t) colper, *sM = sT + colper;
+        if (!(t_out[a] == n && t_in[a] != n)) continue;
+        for (int i = 0; i < ld; ++i) {                                         /* crs.c:140-145 on the slice */
+            double v = 0;
+            if (i < nc) {
+                const double wv = urand_from(0., 1., w[2 * i], w[2 * i + 1]);
+                v = xb[i] * (1 + wv) - wv * x[i];
+                if (v > ub[i]) v = ub[i]; else if (v < lb[i]) v = lb[i];
+                sT[i] = x[i]; sM[i] = v;
+            }
+            m[i] = v;
+        }
+    }
+    return 0;
+}
+int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
+                      const double *RECV, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
+{
+    EMU_LAUNCH();
+    const double sign = emu_obj_sign(&obj);
+    double *p;
+    (void) st;
+    if (obj < 0 || obj >= NLA_OBJ_COUNT || colper < 1) return EMU_ERR;
+    p = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+    for (int a = 0; a < K; ++a) {
+        const int q = (int) ((first_block + (uint64_t) a) & (uint64_t) slot_mask);
+        const int t1 = t_out[a];
+        double f[2] = { 0, 0 };
+        if (t1 == n && t_in[a] != n) {
+            for (int task = 0; task < 2; ++task) {
+                for (int g = 0; g < n; ++g)
+                    p[g] = RECV[(size_t) (g / colper) * (size_t) 2 * (size_t) K * (size_t) colper + (size_t) (2 * a + task) * (size_t) colper + (size_t) (g % colper)];
+                f[task] = sign * nla_obj_eval_seq(obj, (unsigned) n, p, NULL);           /* crs.c:133 / :146 on the assembled point */
+            }
+            fT_ring[q] = f[0]; fM_ring[q] = f[1];
+        } else if (t1 == n) { f[0] = fT_ring[q]; f[1] = fM_ring[q]; }
+        status[a].fT = f[0]; status[a].fM = f[1]; status[a].t = t1; status[a].pad = 0;
+    }
+    free(p);
+    return 0;
+}
+
 typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
 void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                      const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,

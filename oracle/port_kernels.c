@@ -108,28 +108,34 @@ void orc_k_mutate(int n, const double *best, const double *p, const uint32_t *wo
  * added to acc (n doubles; initialised from the best row when t0 == 0), stopping before the first
  * pick >= t0 whose row is among W[0..nun); when the sum completes (returns n) acc is scaled by
  * 2/n and clamped, i.e. becomes the trial point x. */
-int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
-                       const int64_t *W, int nun, int t0, const double *lb, const double *ub, double *acc)
+int orc_k_advance_slot_cols(int n, int ncol, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
+                            const int64_t *W, int nun, int t0, const double *lb, const double *ub, double *acc)
 {
+    /* n picks are summed; ncol coordinates of every row are held here (ncol == n: whole rows; a column slice otherwise) */
     int e = n, t;
     for (t = t0; t < n && e == n; ++t) {
         const int64_t r = pick_row(n, pos, last, i0, t);
         for (int j = 0; j < nun; ++j) if (W[j] == r) { e = t; break; }
     }
     if (e == t0) return e;
-    if (t0 == 0) memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) n);
+    if (t0 == 0) memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) ncol);
     for (t = t0; t < e; ++t) {
         const double *xi = X + (size_t) pick_row(n, pos, last, i0, t) * (size_t) ld;
-        if (t == jn) for (int k = 0; k < n; ++k) acc[k] -= xi[k] * (0.5 * n);
-        else         for (int k = 0; k < n; ++k) acc[k] += xi[k];
+        if (t == jn) for (int k = 0; k < ncol; ++k) acc[k] -= xi[k] * (0.5 * n);
+        else         for (int k = 0; k < ncol; ++k) acc[k] += xi[k];
     }
     if (e == n)
-        for (int k = 0; k < n; ++k) {
+        for (int k = 0; k < ncol; ++k) {
             acc[k] *= 2.0 / n;
             if (acc[k] > ub[k]) acc[k] = ub[k];
             else if (acc[k] < lb[k]) acc[k] = lb[k];
         }
     return e;
+}
+int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, const int32_t *pos, int32_t last,
+                       const int64_t *W, int nun, int t0, const double *lb, const double *ub, double *acc)
+{
+    return orc_k_advance_slot_cols(n, n, ld, X, i0, jn, pos, last, W, nun, t0, lb, ub, acc);
 }
 
 

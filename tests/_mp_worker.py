@@ -76,13 +76,20 @@ def main():
             nlopt_amd.lib().nlopt_set_local_optimizer(o._h, loc._h)
         if args.get("sharded", True):
             o.set_comm(comm)
+        for k, v in (args.get("params") or {}).items():
+            o.set_param(k, v)
+        if args.get("ftol_rel"):
+            o.set_ftol_rel(args["ftol_rel"])
+        if args.get("xtol_rel"):
+            o.set_xtol_rel(args["xtol_rel"])
         o.enable_trace(args["maxeval"] + 4096)
         nlopt_amd.srand(seed)
         x, minf, ret = o.optimize_raw(xs)
         t = o.trace()
         res = dict(ret=np.array([ret]), minf=np.array([minf]), x=x, nevals=np.array([o.get_numevals()]), f=t["f"], row=t["row"],
                    kind=t["kind"], accepted=t["accepted"], collectives=np.array([comm.counters()["collectives"]]),
-                   gathered_bytes=np.array([comm.counters()["bytes"]]), after=np.array([nlopt_amd.lib().nla_genrand_int32()], dtype=np.uint64))
+                   gathered_bytes=np.array([comm.counters()["bytes"]]), after=np.array([nlopt_amd.lib().nla_genrand_int32()], dtype=np.uint64),
+                   stats_allgather_bytes=np.array([o.stats()["allgather_bytes"]], dtype=np.uint64), rounds=np.array([o.stats()["rounds"]]))
     elif case == "emu_sweep":
         # drawn configurations of the ISRES and MLSL host drivers over the emulated device, each checked against the oracle here
         # (every rank runs the same draws; the multi-rank runs shard them)

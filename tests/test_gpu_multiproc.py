@@ -48,11 +48,26 @@ def same(d, s):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_crs_sharded_init(world):
+    """"amd_shard" = 0: every rank keeps the whole population; only crs_init's rows are dealt over the ranks and all-gathered"""
     a = dict(obj="rastrigin", n=96, pop=1501, seed=11, maxeval=4000)
+    s = single("gpu_crs", a)
+    for d in run_world("gpu_crs", dict(a, params={"amd_shard": 0}), world=world):
+        same(d, s)
+        assert d["collectives"][0] == 2                # rows, f
+
+
+@pytest.mark.parametrize("world,a", [(2, dict(obj="rastrigin", n=96, pop=1501, seed=11, maxeval=4000)),
+                                     (3, dict(obj="levy", n=257, pop=600, seed=5, maxeval=1500)),
+                                     (3, dict(obj="rosenbrock", n=10, pop=100, seed=42, maxeval=2500)),
+                                     (2, dict(obj="griewank", n=4096, pop=3000, seed=42, maxeval=3400))])
+def test_crs_column_sharded(world, a):
+    """the population sharded BY COORDINATE (hip/crs_shard.hip): the gather-sum, mutation and row replacement run on every rank's
+    slice, the candidates of a pass are all-gathered and evaluated with the single-GPU reduction — so the run is the
+    single-process run of this device bit for bit (at n = 4096 that one resolves its windows in the chain kernel: same sequence)"""
     s = single("gpu_crs", a)
     for d in run_world("gpu_crs", a, world=world):
         same(d, s)
-        assert d["collectives"][0] == 2                # rows, f
+        assert d["collectives"][0] >= d["rounds"][0] and d["stats_allgather_bytes"][0] > 0
 
 
 @pytest.mark.parametrize("world,ncon", [(2, 4), (3, 0)])

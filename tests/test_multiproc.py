@@ -100,3 +100,59 @@ def test_drawn_configurations_of_the_host_drivers_over_the_emulated_device(world
     count = 15 if world == 1 else 10
     for d in run_world("emu_sweep", dict(first=first, count=count), world=world, extra_env=dict(EMU, **env), timeout=900):
         assert d["checked"][0] == count
+
+
+# ---- CRS2_LM with the population sharded BY COORDINATE over the ranks (hip/crs_shard.hip, crs_engine.c) ---------------------------
+SHARDED_CRS = [
+    # obj, n, pop, seed, maxeval, extra
+    ("rastrigin", 10, 100, 42, 1400, {}),                       # BASELINE config 1's shape
+    ("rosenbrock", 7, 40, 9, 900, dict(xtol_rel=1e-3)),          # coordinates coupled across slice boundaries; x needed on the host (xtol)
+    ("levy", 9, 0, 12345, 1200, {}),                             # head term wants x_0 and x_{n-1} (first and last rank)
+    ("griewank", 257, 600, 5, 1100, {}),                         # odd n: unequal slices (world 2: 129 + 128, world 3: 86 + 86 + 85)
+    ("ackley", 64, 300, 7, 1500, dict(params={"amd_window_factor": 3.0})),
+    ("sphere", 5, 30, 3, 600, dict(ftol_rel=1e-6)),
+]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("obj,n,pop,seed,maxeval,extra", SHARDED_CRS)
+def test_crs_column_sharded_over_the_ranks_is_the_oracles_run(world, obj, n, pop, seed, maxeval, extra):
+    """every rank keeps 1/world of the COLUMNS of the population, runs the gather-sum, mutation and row replacement on its slice, the
+    candidates of a pass are all-gathered and evaluated by every rank: the run — every f, every decision, the result, the stream
+    position — is the single-process oracle's, bit for bit, on every rank"""
+    kw = {k: v for k, v in extra.items() if k in ("ftol_rel", "xtol_rel")}
+    res = run_world("gpu_crs", dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=maxeval, **extra), world=world, extra_env=EMU)
+    p = O.run_port_crs(obj, n, pop, seed, maxeval=maxeval, trace_cap=maxeval + 4096, **kw)
+    for d in res:
+        assert d["ret"][0] == p["ret"] and d["nevals"][0] == p["nevals"] and d["minf"][0] == p["minf"]
+        assert np.array_equal(d["x"], p["x"])
+        for key in ("f", "row", "kind", "accepted"):
+            assert np.array_equal(d[key], p["trace"][key]), key
+        assert d["after"][0] == res[0]["after"][0]
+        # sharded for real: an all-gather of candidates per pass (+ the initial values, + the stop agreements)
+        assert d["collectives"][0] >= d["rounds"][0] and d["stats_allgather_bytes"][0] > 0
+
+
+def test_crs_column_sharding_can_be_switched_off_and_falls_back_to_replicas():
+    res = run_world("gpu_crs", dict(obj="rastrigin", n=10, pop=100, seed=42, maxeval=700, params={"amd_shard": 0}), world=2, extra_env=EMU)
+    p = O.run_port_crs("rastrigin", 10, 100, 42, maxeval=700, trace_cap=5000)
+    for d in res:
+        assert np.array_equal(d["f"], p["trace"]["f"]) and np.array_equal(d["x"], p["x"])
+        assert d["collectives"][0] == 2           # the row-sharded initialisation only: rows + values
+    # n < world columns cannot be dealt: replicas as well
+    res = run_world("gpu_crs", dict(obj="sphere", n=2, pop=20, seed=1, maxeval=300), world=3, extra_env=EMU)
+    p = O.run_port_crs("sphere", 2, 20, 1, maxeval=300, trace_cap=5000)
+    for d in res:
+        assert np.array_equal(d["f"], p["trace"]["f"]) and np.array_equal(d["x"], p["x"])
+
+
+def test_crs_column_sharded_large_n_prefix_world3():
+    """the metric's dimension: n = 4096 over 3 ranks (1366 + 1366 + 1364 columns), a prefix of the trial chain"""
+    n, pop, seed, me = 4096, 4200, 42, 4330
+    res = run_world("gpu_crs", dict(obj="griewank", n=n, pop=pop, seed=seed, maxeval=me), world=3, extra_env=EMU, timeout=1200)
+    p = O.run_port_crs("griewank", n, pop, seed, maxeval=me, trace_cap=me + 64)
+    for d in res:
+        assert d["ret"][0] == p["ret"] and d["nevals"][0] == p["nevals"]
+        for key in ("f", "row", "kind", "accepted"):
+            assert np.array_equal(d[key], p["trace"][key]), key
+        assert np.array_equal(d["x"], p["x"])
