@@ -286,8 +286,9 @@ def main():
         dist.destroy_process_group()
 
 
-def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, sync_all, max_spec=0, variant=0):
-    """open a CRS2_LM run (population initialisation untimed), W warm-up steps, K timed steps; returns the raw numbers"""
+def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, sync_all, max_spec=0, variant=0, comm=None):
+    """open a CRS2_LM run (population initialisation untimed), W warm-up steps, K timed steps; returns the raw numbers.
+    comm: ONE job over the communicator's ranks (population sharded by coordinate), every rank with the same seed"""
     import _oracle as O
     xs, lo, hi = O.golden_x0(obj, n)
     o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
@@ -299,9 +300,13 @@ def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, 
         o.set_param("amd_max_spec", max_spec)
     if variant:
         o.set_param("amd_gather_variant", variant)
+    if comm is not None:
+        o.set_comm(comm)
     nlopt_amd.srand(seed)
     x = np.array(xs)
     minf, ret = C.c_double(), C.c_int()
+    if comm is not None:
+        sync_all()
     t0 = time.perf_counter()
     s = L.nlopt_amd_crs_open(o._h, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(minf), C.byref(ret))
     t_init = time.perf_counter() - t0
@@ -324,10 +329,10 @@ def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, 
 
 
 def crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce):
-    """BASELINE.json config 5 (CRS2_LM Griewank n=4096, pop=1e6) as ONE job over all ranks: the initial population is sharded —
-    every rank draws and evaluates 1/world of the rows from the same MT19937 stream — and ALL-GATHERED over RCCL (32.8 GB of rows
-    per rank at the full size); then every rank walks the identical serial trial chain on its own copy (crs.c:125-156 does not
-    shard).  Reported: the initialisation (wall, max over ranks), the all-gather inside it (HIP events), the chain's rate."""
+    """BASELINE.json config 5 (CRS2_LM Griewank n=4096, pop=1e6) as ONE job over all ranks: the population is sharded BY COORDINATE
+    (every rank keeps n/world columns of every row: 32.8 GB / world), each rank runs the gather-sum, mutation and row replacement on
+    its slice, the candidates of a pass are all-gathered over RCCL and every rank replays the identical chain (hip/crs_shard.hip).
+    Reported: the initialisation (wall, max over ranks), the bytes all-gathered, the chain's rate."""
     import _oracle as O
     n, pop, obj = a.config5_n, a.config5_pop, "griewank"
     xs, lo, hi = O.golden_x0(obj, n)
@@ -367,12 +372,12 @@ def crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce):
     dt_max, evals_max = reduce(dt, ev1 - ev0, False)
     ag_ms, ag_bytes = st_i["t_allgather_ms"], st_i["allgather_bytes"]
     return {"workload": "NLOPT_GN_CRS2_LM griewank n=%d pop=%d seed=%d, ONE job over %d ranks (library communicator over RCCL)" % (n, pop, a.seed, world),
-            "scaling": "strong (initialisation only: rows sharded, all-gathered); the trial chain is replicated, not sharded",
+            "scaling": "strong: one job, the population sharded by coordinate over the ranks",
             "init_wall_s": t_init_max, "init_evals_per_s": pop / t_init_max,
             "allgather_ms": ag_ms, "allgather_GB_received_per_rank": ag_bytes / 1e9,
             "allgather_busbw_GBps": (ag_bytes / 1e9) * (world - 1) / world / (ag_ms / 1e3) if ag_ms > 0 else None,
             "chain_evals_per_s": evals_max / dt_max, "chain_steps": steps, "chain_evals_timed": int(evals_max),
-            "population_GB_per_rank": 8.0 * n * pop / 1e9}
+            "population_GB_per_rank": 8.0 * n * pop / 1e9 / world, "ranks": comm.world}
 
 
 def crs_end_to_end(nlopt_amd, obj, n, pop, seed, trial_evals):
@@ -404,8 +409,50 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     m = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed + rank, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec, a.gather_variant)
     dt, st0, st1, t_init, fret = m["dt"], m["st0"], m["st1"], m["t_init"], m["fret"]
     dt_max, evals_all = reduce(dt, m["evals"], True)
+    replicas = None
     one_job = None
-    if world > 1 and not a.no_config5:
+    headline_one_job = None
+    if world > 1:
+        # N GPUs: the metric configuration as ONE job over all ranks — the population sharded by coordinate, the candidates of a pass
+        # all-gathered over RCCL (hip/crs_shard.hip) — is the headline (strong scaling).  The replica figure measured above stays in
+        # the line as the fallback: the one-job run goes under a watchdog, because a communicator that never comes up (RCCL's
+        # bootstrap did not return on one box in round 1) or a hung collective must not take the whole line with it
+        import threading
+        replicas = {"value": evals_all / dt_max, "unit": "evals/s", "what": "sum over %d independent replicas (seed+rank), no collective" % world,
+                    "ms_per_step": 1e3 * dt_max / a.steps}
+        box1 = {}
+
+        def job1():
+            try:
+                lr = int(os.environ.get("LOCAL_RANK", "0"))      # the current HIP device is a per-thread setting
+                L.nla_dev_set(lr)
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        torch.cuda.set_device(lr)
+                except ImportError:
+                    pass
+                comm = nlopt_amd.Comm.from_torch_distributed()
+                mm = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec, a.gather_variant, comm=comm)
+                dtm, evm = reduce(mm["dt"], mm["evals"], False)
+                tim, _ = reduce(mm["t_init"], 0, False)
+                box1["r"] = dict(m=mm, dt=dtm, evals=evm, t_init=tim, ranks=comm.world, transport="rccl" if os.environ.get("NLA_BENCH_TRANSPORT", "") != "host" else "host")
+            except (Exception, SystemExit) as e:
+                box1["r"] = {"error": repr(e)}
+        th1 = threading.Thread(target=job1, daemon=True)
+        th1.start()
+        th1.join(a.config5_timeout)
+        if th1.is_alive():
+            headline_one_job = {"error": "did not finish within %d s (communicator bootstrap or a collective hung)" % a.config5_timeout}
+            STUCK.append(True)
+        else:
+            headline_one_job = box1.get("r")
+        if headline_one_job and "error" not in headline_one_job:
+            m = headline_one_job["m"]
+            dt, st0, st1, t_init, fret = m["dt"], m["st0"], m["st1"], headline_one_job["t_init"], m["fret"]
+            dt_max, evals_all = headline_one_job["dt"], headline_one_job["evals"]
+    sharded = bool(world > 1 and headline_one_job and "error" not in headline_one_job)
+    if world > 1 and not a.no_config5 and not STUCK:
         # BASELINE.json config 5 is the only CRS configuration with multi-GPU work in it: ONE job over all ranks.
         # It runs under a watchdog: the replica value above is already measured, and a communicator that never comes up (RCCL's
         # bootstrap did not return on one box in round 1) must not take the whole line with it
@@ -436,24 +483,27 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     if rank != 0:
         return None
     g_ms = st1["t_gather_ms"] - st0["t_gather_ms"]
-    g_bytes = st1["gather_bytes"] - st0["gather_bytes"]
+    g_bytes = (st1["gather_bytes"] - st0["gather_bytes"]) / (world if sharded else 1)      # a rank of a sharded job moves 1/world of every row
     g_launch = st1["gather_launches"] - st0["gather_launches"]
     achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
     slots = st1["slots_launched"] - st0["slots_launched"]
     used = st1["slots_used"] - st0["slots_used"]
-    useful_gbs = (used * 8.0 * n * (n + 1) / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
+    useful_gbs = (used * 8.0 * n * (n + 1) / (world if sharded else 1) / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
     # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) from n = 2048 on, the conservative passes below
-    chain = n >= 2048 and os.environ.get("NLA_CRS_FORWARD", "1") != "0"
+    # (and always the conservative passes, on column slices, in a sharded job)
+    chain = n >= 2048 and os.environ.get("NLA_CRS_FORWARD", "1") != "0" and not sharded
     gkernel = "crs_chain_kernel" if chain else "crs_advance_kernel"
     traffic, traffic_src = pmc_traffic(gkernel) if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
     out = {
         "metric": "candidate-evals/sec, CRS2_LM n=%d pop=%d (trial phase)" % (n, pop),
         "value": evals_all / dt_max, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt_max / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt_max / a.steps, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "NLOPT_GN_CRS2_LM %s n=%d pop=%d seed=%d, %d candidate evals per step, population resident in HBM%s"
                                % (a.obj, n, pop, a.seed, a.evals_per_step,
-                                  "" if world == 1 else "; %d independent replicas (seed+rank)" % world),
+                                  "" if world == 1 else ("; ONE job over %d ranks: population sharded by coordinate (%d columns per rank), candidates of a pass "
+                                                         "all-gathered over RCCL (communicator ranks: %d)" % (world, (n + world - 1) // world, headline_one_job["ranks"])
+                                                         if sharded else "; %d independent replicas (seed+rank)" % world)),
                    "evals_timed": int(evals_all), "evals_per_step_requested": a.evals_per_step},
         "roofline": {"bound": "hbm", "kernel": gkernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
@@ -497,8 +547,14 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
             except Exception as e:
                 out["other_sizes"]["n=%d" % n2] = {"error": repr(e)}
     if world > 1:
-        out["replicas_note"] = ("value = sum over %d independent replicas of the metric configuration (the trial loop is one serial chain: it "
-                                "does not shard); the one multi-GPU CRS job is config5_one_job below — not part of value" % world)
+        if sharded:
+            out["one_job"] = {"ranks": headline_one_job["ranks"], "init_wall_s": t_init, "allgather_bytes_timed": int(st1["allgather_bytes"] - st0["allgather_bytes"]),
+                              "passes_timed": int(st1["rounds"] - st0["rounds"]),
+                              "note": "value = the ONE job's rate (strong scaling); roofline = one rank's gather kernel on its column slice"}
+        else:
+            out["one_job"] = headline_one_job
+            out["replicas_note"] = ("the one-job run failed (see one_job): value = sum over %d independent replicas of the metric configuration, scaling weak" % world)
+        out["replicas"] = replicas
         out["config5_one_job"] = one_job
     try:
         out["gens_to_ftol"] = gens_to_ftol()
