@@ -62,8 +62,92 @@ __device__ __forceinline__ void lb_add_active(int n, double *x, int *ix, const d
     }
 }
 
+/* The two Strang loops (mxdrcb / mxdrcf, mssubs.c:353-441) with the direction held in REGISTERS (thread t owns coordinates t, t+256, ...:
+ * the same partial-sum order as lb_mdot) and the next history column prefetched while the current dot product is being reduced — one
+ * barrier pair per column, no traffic for s.  A function of its own, not inlined: its five register arrays (160 VGPRs) are then
+ * the callee's whole budget, and what the caller keeps alive (the line search's state, the counters) is saved ONCE around the call
+ * instead of being spilled and reloaded inside the per-column loop — the kernel fits two workgroups per CU that way
+ * (round 2: 443-490 VGPRs, one workgroup per CU, 320 searches taking turns on 256 CUs).  Returns |s|. */
+__device__ __attribute__((noinline)) double lb_strang_in_registers(int n, int k, int mf, int head, int ld, const int *__restrict__ ix,
+                                                                    const double *__restrict__ gf, double *__restrict__ s,
+                                                                    const double *__restrict__ hx, const double *__restrict__ hg,
+                                                                    const double *__restrict__ ucol, double *__restrict__ vcol, double b)
+{
+    __shared__ lb_shared S;
+    const int tid = threadIdx.x;
+    double snorm, a;
+#define COLX(i) (hx + (size_t) ((head + (i) - 1) % mf) * ld)
+#define COLG(i) (hg + (size_t) ((head + (i) - 1) % mf) * ld)
+#define COLU(i) (ucol[(head + (i) - 1) % mf])
+    double sr[LB_EPT], c1[LB_EPT], c2[LB_EPT], n1[LB_EPT], n2[LB_EPT];
+    unsigned live = 0;
+    const int ept = (n + LB_T - 1) / LB_T;
+#pragma unroll
+    for (int e = 0; e < LB_EPT; ++e) {
+        const int i = tid + e * LB_T;
+        sr[e] = 0.; c1[e] = 0.; c2[e] = 0.; n1[e] = 0.; n2[e] = 0.;
+        if (e < ept && i < n && ix[i] >= 0) { live |= 1u << e; sr[e] = -gf[i]; }     /* mxuneg */
+    }
+    auto load_col = [&](int j, double *px, double *pg) {
+        const double *cx = COLX(j), *cg = COLG(j);
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { px[e] = cx[tid + e * LB_T]; pg[e] = cg[tid + e * LB_T]; }
+    };
+    load_col(1, c1, c2);
+    for (int j = 1; j <= k; ++j) {                       /* mxdrcb */
+        if (j < k) load_col(j + 1, n1, n2);
+        double t = 0;
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c1[e];
+        const double v = COLU(j) * lb_block_sum(t, S);
+        if (tid == 0) vcol[j - 1] = v;
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + (-v) * c2[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
+    }
+    {
+        double t = 0;
+        const double *cg = COLG(1);
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { const double gv = cg[tid + e * LB_T]; t += gv * gv; }
+        a = lb_block_sum(t, S);
+        if (a > 0.) {
+            const double sc = b / a;
+#pragma unroll
+            for (int e = 0; e < LB_EPT; ++e) sr[e] = sr[e] * sc;
+        }
+    }
+    load_col(k, c1, c2);
+    for (int j = k; j >= 1; --j) {                       /* mxdrcf */
+        if (j > 1) load_col(j - 1, n1, n2);
+        double t = 0;
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c2[e];
+        const double tt = COLU(j) * lb_block_sum(t, S);
+        const double w = vcol[j - 1] - tt;
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + w * c1[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
+    }
+    {
+        double t = 0;
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) {
+            const int i = tid + e * LB_T;
+            if (e < ept && i < n) s[i] = sr[e];
+            if (live & (1u << e)) t += sr[e] * sr[e];
+        }
+        snorm = sqrt(lb_block_sum(t, S));
+    }
+    __syncthreads();
+#undef COLX
+#undef COLG
+#undef COLU
+    return snorm;
+}
+
+/* two workgroups per CU (<= 256 registers per lane): what does not fit is spilled in the scalar outer logic, once per iteration —
+ * the per-column loops live in lb_strang_in_registers and stay spill-free (checked in the ISA: only its prologue / epilogue touch scratch) */
 template <int OBJ>
-__global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf, int count, const double *__restrict__ lb,
+__global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbfgs_batch_kernel(int n, int ld, int mf, int count, const double *__restrict__ lb,
                                                             const double *__restrict__ ub, double *__restrict__ X,
                                                             double *__restrict__ work, int *__restrict__ iwork,
                                                             double *__restrict__ hist, nla_lbfgs_params P,
@@ -202,69 +286,8 @@ __global__ __launch_bounds__(LB_T) void lbfgs_batch_kernel(int n, int ld, int mf
                     if (tid == 0) COLU(1) = 1. / b;
                     cols += k;
                     if (n <= LB_T * LB_EPT && !P.exact) {
-                        /* the two Strang loops with s held in registers (thread t owns coordinates t, t+256, ...: the same
-                         * partial-sum order as lb_mdot) and the next history column prefetched while the current dot
-                         * product is being reduced — one barrier pair per column, no s traffic */
-                        double sr[LB_EPT], c1[LB_EPT], c2[LB_EPT], n1[LB_EPT], n2[LB_EPT];
-                        unsigned live = 0;
-                        const int ept = (n + LB_T - 1) / LB_T;
-#pragma unroll
-                        for (int e = 0; e < LB_EPT; ++e) {
-                            const int i = tid + e * LB_T;
-                            sr[e] = 0.; c1[e] = 0.; c2[e] = 0.; n1[e] = 0.; n2[e] = 0.;
-                            if (e < ept && i < n && ix[i] >= 0) { live |= 1u << e; sr[e] = -gf[i]; }     /* mxuneg */
-                        }
                         __syncthreads();                       /* COLU(1) visible */
-                        auto load_col = [&](int j, double *px, double *pg) {
-                            const double *cx = COLX(j), *cg = COLG(j);
-#pragma unroll
-                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { px[e] = cx[tid + e * LB_T]; pg[e] = cg[tid + e * LB_T]; }
-                        };
-                        load_col(1, c1, c2);
-                        for (int j = 1; j <= k; ++j) {                       /* mxdrcb */
-                            if (j < k) load_col(j + 1, n1, n2);
-                            double t = 0;
-#pragma unroll
-                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c1[e];
-                            const double v = COLU(j) * lb_block_sum(t, S);
-                            if (tid == 0) vcol[j - 1] = v;
-#pragma unroll
-                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + (-v) * c2[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
-                        }
-                        {
-                            double t = 0;
-                            const double *cg = COLG(1);
-#pragma unroll
-                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { const double gv = cg[tid + e * LB_T]; t += gv * gv; }
-                            a = lb_block_sum(t, S);
-                            if (a > 0.) {
-                                const double sc = b / a;
-#pragma unroll
-                                for (int e = 0; e < LB_EPT; ++e) sr[e] = sr[e] * sc;
-                            }
-                        }
-                        load_col(k, c1, c2);
-                        for (int j = k; j >= 1; --j) {                       /* mxdrcf */
-                            if (j > 1) load_col(j - 1, n1, n2);
-                            double t = 0;
-#pragma unroll
-                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c2[e];
-                            const double tt = COLU(j) * lb_block_sum(t, S);
-                            const double w = vcol[j - 1] - tt;
-#pragma unroll
-                            for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + w * c1[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
-                        }
-                        {
-                            double t = 0;
-#pragma unroll
-                            for (int e = 0; e < LB_EPT; ++e) {
-                                const int i = tid + e * LB_T;
-                                if (e < ept && i < n) s[i] = sr[e];
-                                if (live & (1u << e)) t += sr[e] * sr[e];
-                            }
-                            snorm = sqrt(lb_block_sum(t, S));
-                        }
-                        __syncthreads();
+                        snorm = lb_strang_in_registers(n, k, mf, head, ld, ix, gf, s, hx, hg, ucol, vcol, b);
                     } else {
                         for (int i = tid; i < n; i += LB_T) s[i] = ix[i] >= 0 ? -gf[i] : 0.;      /* mxuneg */
                         __syncthreads();
