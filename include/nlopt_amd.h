@@ -473,6 +473,7 @@ int nla_dev_set(int dev);
 void *nla_dev_malloc(size_t bytes);
 void nla_dev_free(void *p);
 void *nla_dev_malloc_uncached(size_t bytes);    /* MTYPE UC device memory: coherent between workgroups / XCDs without cache maintenance */
+void nla_debug_uncached_stats(long out[4]);     /* [0] uncached allocations made, [1] returned to the driver (never, with the pool), [2] pooled blocks, [3] in use */
 void nla_dev_free_uncached(void *p);            /* back to the library's pool: uncached blocks are never returned to the driver while the process lives (devrt.hip) */
 void *nla_host_malloc(size_t bytes);            /* pinned */
 void nla_host_free(void *p);

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE            /* qsort_r */
 /* esch_driver.c — NLOPT_GN_ESCH behind the reference's entry point
  *   chevolutionarystrategy(n, f, f_data, lb, ub, x, minf, stop, np, no)   (src/algs/esch/esch.h; dispatched at
  *   optimize.c:946-949 with np = population, no = (unsigned)(population * 1.5); 0 -> 40 / 60, esch.c:96-97),
@@ -97,6 +98,37 @@ static int evaluate(esch_dev *d, int cur, int64_t i0, int64_t count)
         ECK(d, nla_memcpy_d2h(d->h_G, d->d_G, sizeof(double) * (size_t) count * (size_t) d->ld, d->st));
     ECK(d, nla_stream_sync(d->st));
     return 0;
+}
+
+/* Selection of a generation with NaN fitness values, on the host and literally as the reference does it: the device's stable sort
+ * works on order-preserving keys (a total order) and a NaN has none; the reference's comparator (esch.c:59-64) calls a NaN equal to
+ * everything and its result is what glibc's qsort_r (nlopt_qsort_r on Linux, util/qsort_r.c:164-170) makes of those answers on the
+ * np + no records of 16 bytes (esch.c:243).  Same libc, same comparator, records of the same size in the same order: same result. */
+typedef struct { int64_t slot; double fitness; } esch_rec;
+static int esch_rec_compare(const void *a_, const void *b_, void *unused)               /* CompareIndividuals, esch.c:59-64 */
+{
+    const esch_rec *a = (const esch_rec *) a_, *b = (const esch_rec *) b_;
+    (void) unused;
+    return a->fitness < b->fitness ? -1 : (a->fitness > b->fitness ? +1 : 0);
+}
+static int select_with_nan(esch_dev *d, int cur)
+{
+    const int64_t P = d->P;
+    esch_rec *rec = (esch_rec *) malloc(sizeof(esch_rec) * (size_t) P);
+    int32_t *slot = (int32_t *) malloc(sizeof(int32_t) * (size_t) P);
+    int64_t i;
+    int rc = -1;
+    if (!rec || !slot) goto out;
+    if (nla_memcpy_d2h(slot, d->d_slot[cur], sizeof(int32_t) * (size_t) P, d->st) || nla_stream_sync(d->st)) goto out;
+    for (i = 0; i < P; ++i) { rec[i].slot = slot[i]; rec[i].fitness = d->h_fit[i]; }
+    qsort_r(rec, (size_t) P, sizeof(esch_rec), esch_rec_compare, NULL);
+    for (i = 0; i < P; ++i) { slot[i] = (int32_t) rec[i].slot; d->h_fit[i] = rec[i].fitness; }
+    if (nla_memcpy_h2d(d->d_slot[cur ^ 1], slot, sizeof(int32_t) * (size_t) P, d->st) ||
+        nla_memcpy_h2d(d->d_fit[cur ^ 1], d->h_fit, sizeof(double) * (size_t) P, d->st) || nla_stream_sync(d->st)) goto out;
+    rc = 0;
+out:
+    free(rec); free(slot);
+    return rc;
 }
 
 nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, double *x, double *minf,
@@ -227,9 +259,15 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         if (ret != NLOPT_SUCCESS) break;
         /* selection */
         t0 = nla_seconds();
+        {
+            int has_nan = 0;
+            for (i = 0; i < D.P && !has_nan; ++i) has_nan = D.h_fit[i] != D.h_fit[i];
+            if (has_nan) { if (select_with_nan(&D, cur)) { snprintf(D.err, sizeof D.err, "selection failed"); DEVFAIL(); } }
+            else
         if (nla_memcpy_h2d(D.d_fit[cur] + D.np, D.h_fit + D.np, sizeof(double) * (size_t) D.no, D.st) ||
             nla_k_esch_select(D.P, D.d_slot[cur], D.d_fit[cur], D.d_slot[cur ^ 1], D.d_fit[cur ^ 1], D.d_sscratch, D.sscratch_bytes, D.st) ||
             nla_memcpy_d2h(D.h_fit, D.d_fit[cur ^ 1], sizeof(double) * (size_t) D.P, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "selection failed"); DEVFAIL(); }
+        }
         cur ^= 1;
         if (st) { st->t_rank_s += nla_seconds() - t0; ++st->generations; st->mt_words = D.words_used; }
     }

@@ -44,6 +44,7 @@ struct uc_block { void *p; size_t bytes; bool busy; };
 static std::mutex uc_mu;
 static uc_block uc_pool[64];
 static int uc_n = 0;
+static long uc_raw_allocs = 0, uc_driver_frees = 0;       /* what tests/test_gpu_crs.py watches: see nla_debug_uncached_stats */
 static bool uc_pool_on()
 {
     static int on = -1;
@@ -71,6 +72,7 @@ extern "C" void *nla_dev_malloc_uncached(size_t bytes)
         p = (void *) (((uintptr_t) raw + two + two - 1) / two * two);
         bytes = want;
     } else if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    { std::lock_guard<std::mutex> g(uc_mu); ++uc_raw_allocs; }
     if (alloc_fill() >= 0 && (hipMemset(p, alloc_fill(), bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void) hipGetLastError();
     if (uc_pool_on()) {
         std::lock_guard<std::mutex> g(uc_mu);
@@ -88,7 +90,16 @@ extern "C" void nla_dev_free_uncached(void *p)
         for (int i = 0; i < uc_n; ++i) if (uc_pool[i].p == p) { uc_pool[i].busy = false; return; }
         return;                                   /* not in the table (it was full): kept until the process ends */
     }
+    { std::lock_guard<std::mutex> g(uc_mu); ++uc_driver_frees; }
     (void) hipFree(p);
+}
+/* [0] uncached allocations obtained from the driver so far, [1] of them returned to it, [2] blocks in the pool, [3] of them in use */
+extern "C" void nla_debug_uncached_stats(long out[4])
+{
+    std::lock_guard<std::mutex> g(uc_mu);
+    int busy = 0;
+    for (int i = 0; i < uc_n; ++i) busy += uc_pool[i].busy ? 1 : 0;
+    out[0] = uc_raw_allocs; out[1] = uc_driver_frees; out[2] = uc_n; out[3] = busy;
 }
 /* development aid (tools/stress_crs.py --uc-churn): one raw uncached allocation, written once, given straight back to the driver —
  * what every round-2 run did with its trial-point buffers */

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE            /* qsort_r */
 /* isres_driver.c — NLOPT_GN_ISRES behind the reference's entry point
  *   isres_minimize(n, f, f_data, m, fc, p, h, lb, ub, x, minf, stop, population)   (isres.h:34-41),
  * host side: the generation loop, the best-point/stop bookkeeping the reference runs after EVERY
@@ -218,6 +219,57 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
     }
     *sweeps_out = nsweeps;
     d->words_used += 2ULL * (uint64_t) popm1 * (uint64_t) nsweeps;
+    return 0;
+}
+
+/* ---- a generation with NaN objective / penalty values: the selection on the HOST, literally as the reference does it ---------------
+ * The device ranking works on dense integer ranks of the values (a total order); a NaN has none.  The reference's comparisons with
+ * a NaN are all false: its sort comparator (isres.c:48-54) then calls the NaN equal to everything — not an ordering, so the result
+ * is whatever glibc's qsort_r (which nlopt_qsort_r calls on Linux, util/qsort_r.c:164-170) makes of those answers — and its
+ * stochastic-ranking sweeps (isres.c:207-228) never move an element past a NaN.  Both are reproduced here by running exactly that
+ * code: the same qsort_r of the same libc with the same comparator, the same sweeps over uniforms drawn sequentially from the run's
+ * stream.  Slow (pop^2 steps on one core) and rare; everything else of the generation stays on the device. */
+static int nan_key_compare(const void *a_, const void *b_, void *keys_)                 /* isres.c:48-54 */
+{
+    const double *keys = (const double *) keys_;
+    const int32_t *a = (const int32_t *) a_, *b = (const int32_t *) b_;
+    return keys[*a] < keys[*b] ? -1 : (keys[*a] > keys[*b] ? +1 : 0);
+}
+static int host_rank_with_nan(isres_dev *d, int all_feasible, int64_t *sweeps_out)
+{
+    const int64_t pop = d->pop;
+    const double *fval = d->h_F, *penalty = d->h_PEN;
+    int32_t *irank = (int32_t *) malloc(sizeof(int32_t) * (size_t) pop);
+    int64_t i, j, sweeps = 0;
+    if (!irank) DFAIL(d, "out of memory (host ranking)");
+    for (i = 0; i < pop; ++i) irank[i] = (int32_t) i;
+    if (all_feasible) qsort_r(irank, (size_t) pop, sizeof(int32_t), nan_key_compare, (void *) fval);
+    else {
+        uint32_t mt[NLA_MT_N];
+        int pos;
+        nla_mtstream_host_state(d->mts, d->words_used, mt, &pos);
+        for (i = 0; i < pop; ++i) {                                                      /* isres.c:207-228 */
+            int swapped = 0;
+            for (j = 0; j < pop - 1; ++j) {
+                uint32_t w[2];
+                double u;
+                for (int q = 0; q < 2; ++q) {
+                    if (pos >= NLA_MT_N) { nla_mt_regen(mt); pos = 0; }
+                    w[q] = nla_mt_temper(mt[pos++]);
+                }
+                u = 0. + (1. - 0.) * (((w[0] >> 5) * 67108864.0 + (w[1] >> 6)) * (1.0 / 9007199254740992.0));
+                if (u < 0.45 || (penalty[irank[j]] == 0 && penalty[irank[j + 1]] == 0)) {
+                    if (fval[irank[j]] > fval[irank[j + 1]]) { const int32_t t = irank[j]; irank[j] = irank[j + 1]; irank[j + 1] = t; swapped = 1; }
+                } else if (penalty[irank[j]] > penalty[irank[j + 1]]) { const int32_t t = irank[j]; irank[j] = irank[j + 1]; irank[j + 1] = t; swapped = 1; }
+            }
+            ++sweeps;
+            if (!swapped) break;
+        }
+        d->words_used += 2ULL * (uint64_t) (pop - 1) * (uint64_t) sweeps;
+    }
+    if (nla_memcpy_h2d(d->d_irank, irank, sizeof(int32_t) * (size_t) pop, d->st) || nla_stream_sync(d->st)) { free(irank); DFAIL(d, "upload of the ranking failed"); }
+    free(irank);
+    *sweeps_out = sweeps;
     return 0;
 }
 
@@ -503,7 +555,12 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         }
 
         t0 = nla_seconds();
-        if (dev_rank(&D, all_feasible, &sweeps, &t_rng, st)) DEVFAIL();
+        {
+            int has_nan = 0;
+            if (!getenv("NLA_ISRES_NO_NAN_HOST"))           /* (A/B switch for the tests: without the host selection a NaN generation differs) */
+            for (k = 0; k < D.pop && !has_nan; ++k) has_nan = (D.h_F[k] != D.h_F[k]) || (D.h_PEN[k] != D.h_PEN[k]);
+            if (has_nan ? host_rank_with_nan(&D, all_feasible, &sweeps) : dev_rank(&D, all_feasible, &sweeps, &t_rng, st)) DEVFAIL();
+        }
         if (st) { st->t_rank_s += nla_seconds() - t0; st->rank_sweeps += (uint64_t) sweeps; }
         t0 = nla_seconds();
         if (dev_evolve(&D, taup, tau, &t_rng)) DEVFAIL();

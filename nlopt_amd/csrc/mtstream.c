@@ -128,6 +128,15 @@ int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_firs
                              g_first, count, popm1, rowwords, d_bits, s->stream);
 }
 
+/* the generator as the host would hold it `rel_word` words into the run: block array + index of the next word in it (for the rare
+ * host fall-backs that must draw sequentially from the run's stream, e.g. ISRES's ranking of a generation with NaN values) */
+void nla_mtstream_host_state(nla_mtstream *s, uint64_t rel_word, uint32_t mt[NLA_MT_N], int *pos)
+{
+    const uint64_t g = (uint64_t) s->base_consumed + rel_word;
+    nla_mt_advance_blocks_host(s->base, g / NLA_MT_N, mt);
+    *pos = (int) (g % NLA_MT_N);
+}
+
 int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed)
 {
     const uint64_t g = (uint64_t) s->base_consumed + consumed;

@@ -147,6 +147,7 @@ void nla_mt_advance_blocks_host(const uint32_t src[NLA_MT_N], uint64_t regens, u
 typedef struct nla_mtstream nla_mtstream;
 nla_mtstream *nla_mtstream_create(void *stream);     /* snapshots the calling thread's generator */
 void nla_mtstream_destroy(nla_mtstream *s);
+void nla_mtstream_host_state(nla_mtstream *s, uint64_t rel_word, uint32_t mt[NLA_MT_N], int *pos);
 uint64_t nla_mtstream_origin(const nla_mtstream *s); /* global index of the first unconsumed word */
 /* out[i] = stream word (origin + rel_first + i), i < count; device pointer, async on `stream` */
 int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint32_t *d_out);

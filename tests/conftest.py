@@ -33,7 +33,7 @@ def pytest_configure(config):
 # the log (round-2 verdict, item 2).  Files not listed (the CPU suite) keep their alphabetical order in front.
 GPU_ORDER = ["test_gpu_crs", "test_gpu_fullsize", "test_gpu_kernels", "test_gpu_isres", "test_gpu_mlsl", "test_gpu_lbfgs",
              "test_gpu_exact_local", "test_gpu_mma", "test_gpu_esch", "test_gpu_stops", "test_gpu_fixed_dims", "test_gpu_userobj",
-             "test_gpu_maximise", "test_gpu_host_callbacks", "test_gpu_multiproc", "test_gpu_cobyla", "test_gpu_dropin",
+             "test_gpu_maximise", "test_gpu_nan", "test_gpu_host_callbacks", "test_gpu_multiproc", "test_gpu_cobyla", "test_gpu_dropin",
              "test_gpu_cpp_client", "test_gpu_testopt_cli", "test_gpu_zz_clients"]
 
 

@@ -472,3 +472,90 @@ def test_drawn_option_round_trips_agree_with_the_reference(draw):
     r = play_options(bind(O.ref()), draw)
     a = play_options(bind(C.CDLL(EMU)), draw)
     assert _same_log(a, r), [(p, q) for p, q in zip(a, r) if not _same_log(p, q)][:3]
+
+
+# ---- NaN objective values: ISRES's selection (round-2 verdict, missing item 4) ------------------------------------------------------
+def play_isres_nan(L, case):
+    """ISRES on an objective that is NaN on part of the box, with and without constraints (sort by f / stochastic ranking): every
+    comparison with a NaN is false — the reference's comparator then calls it equal to everything and glibc's qsort_r makes of that
+    what it makes; the ranking sweeps never move an element past it.  The library must give the same run."""
+    dp = lambda a: a.ctypes.data_as(dpp)
+    n, pop, ncon, nan_frac, seed, maxeval = case
+    rng = np.random.default_rng(1234 + seed)
+    opt = L.nlopt_create(35, n)
+    lb, ub = np.full(n, -2.0), np.full(n, 3.0)
+    cut = -2.0 + 5.0 * (1 - nan_frac)
+    calls = []
+
+    def f(nn, x, g, d):
+        calls.append(tuple(x[i] for i in range(nn)))
+        if x[0] > cut:
+            return float("nan")
+        return float(sum((x[i] - 0.3 * i) ** 2 for i in range(nn)))
+    keep = [FUNC(f)]
+    log = [L.nlopt_set_lower_bounds(opt, dp(lb)), L.nlopt_set_upper_bounds(opt, dp(ub)), L.nlopt_set_min_objective(opt, C.cast(keep[0], vp), None)]
+    for q in range(ncon):
+        cb = FUNC(lambda nn, x, g, d, q=q: float(x[q % nn] - 1.0) if x[(q + 1) % nn] < 2.5 else float("nan"))
+        keep.append(cb)
+        log.append(L.nlopt_add_inequality_constraint(opt, C.cast(cb, vp), None, 1e-8))
+    log.append(L.nlopt_set_population(opt, pop))
+    log.append(L.nlopt_set_maxeval(opt, maxeval))
+    L.nlopt_srand(seed)
+    x = rng.uniform(-1.5, 1.0, n)
+    minf = C.c_double(0)
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(minf))
+    out = dict(log=log, ret=ret, minf=minf.value, x=x, nev=L.nlopt_get_numevals(opt), calls=calls)
+    L.nlopt_destroy(opt)
+    del keep
+    return out
+
+
+@pytest.mark.parametrize("case", [(3, 20, 0, 0.3, 1, 400), (5, 35, 0, 0.6, 2, 600), (4, 30, 2, 0.25, 3, 500), (2, 15, 1, 0.5, 4, 300),
+                                  (6, 50, 3, 0.1, 5, 700), (3, 25, 0, 1.0, 6, 200)],
+                         ids=lambda c: "n%d_pop%d_con%d_nan%g_seed%d" % c[:5])
+def test_isres_with_nan_objective_values_is_the_references_run(case):
+    r = play_isres_nan(bind(O.ref()), case)
+    a = play_isres_nan(bind(C.CDLL(EMU)), case)
+    assert a["log"] == r["log"] and a["ret"] == r["ret"] and a["nev"] == r["nev"], (a["ret"], r["ret"], a["nev"], r["nev"])
+    assert len(a["calls"]) == len(r["calls"])
+    first = next((i for i, (u, v) in enumerate(zip(a["calls"], r["calls"])) if u != v), None)
+    assert first is None, "candidate %d differs" % first
+    assert (a["minf"] == r["minf"] or (np.isnan(a["minf"]) and np.isnan(r["minf"]))) and np.array_equal(a["x"], r["x"], equal_nan=True)
+
+
+def play_esch_nan(L, case):
+    dp = lambda a: a.ctypes.data_as(dpp)
+    n, pop, nan_frac, seed, maxeval = case
+    opt = L.nlopt_create(42, n)
+    lb, ub = np.full(n, -2.0), np.full(n, 3.0)
+    cut = -2.0 + 5.0 * (1 - nan_frac)
+    calls = []
+
+    def f(nn, x, g, d):
+        calls.append(tuple(x[i] for i in range(nn)))
+        if x[nn - 1] > cut:
+            return float("nan")
+        return float(sum((x[i] - 0.2 * i) ** 2 for i in range(nn)) + np.cos(5 * x[0]))
+    keep = [FUNC(f)]
+    log = [L.nlopt_set_lower_bounds(opt, dp(lb)), L.nlopt_set_upper_bounds(opt, dp(ub)), L.nlopt_set_min_objective(opt, C.cast(keep[0], vp), None),
+           L.nlopt_set_population(opt, pop), L.nlopt_set_maxeval(opt, maxeval)]
+    L.nlopt_srand(seed)
+    x = np.full(n, 0.25)
+    minf = C.c_double(0)
+    ret = L.nlopt_optimize(opt, dp(x), C.byref(minf))
+    out = dict(log=log, ret=ret, minf=minf.value, x=x, nev=L.nlopt_get_numevals(opt), calls=calls)
+    L.nlopt_destroy(opt)
+    del keep
+    return out
+
+
+@pytest.mark.parametrize("case", [(3, 12, 0.3, 1, 500), (5, 30, 0.6, 2, 900), (2, 8, 0.15, 3, 400), (6, 0, 0.4, 4, 800)],
+                         ids=lambda c: "n%d_pop%d_nan%g_seed%d" % c[:4])
+def test_esch_with_nan_fitness_values_is_the_references_run(case):
+    """GN_ESCH's selection sorts parents + offspring by fitness with a comparator for which a NaN equals everything (esch.c:59-64,243)"""
+    r = play_esch_nan(bind(O.ref()), case)
+    a = play_esch_nan(bind(C.CDLL(EMU)), case)
+    assert a["log"] == r["log"] and a["ret"] == r["ret"] and a["nev"] == r["nev"], (a["ret"], r["ret"], a["nev"], r["nev"])
+    first = next((i for i, (u, v) in enumerate(zip(a["calls"], r["calls"])) if u != v), None)
+    assert first is None, "candidate %d differs" % first
+    assert (a["minf"] == r["minf"] or (np.isnan(a["minf"]) and np.isnan(r["minf"]))) and np.array_equal(a["x"], r["x"], equal_nan=True)

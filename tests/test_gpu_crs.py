@@ -88,6 +88,31 @@ def test_crs_matches_golden_and_oracle(name):
     assert_same_run(a, p)
 
 
+def _uc_stats():
+    out = (C.c_long * 4)()
+    nlopt_amd.lib().nla_debug_uncached_stats(out)
+    return list(out)
+
+
+def test_uncached_memory_is_pooled_and_the_conservative_passes_never_touch_it():
+    """Regression test for round 2's intermittent divergence (DESIGN.md "the intermittent divergence"): every CRS2_LM run used to
+    allocate its trial-point buffers as UNCACHED device memory and free them at the end; ordinary allocations made afterwards then
+    showed stale cache lines now and then (wrong initial rows, wrong trial points — 7 of 64 suite processes).  Now: runs below
+    n = 2048 (conservative passes) use no uncached memory at all, and the chain kernel's uncached blocks come from a pool that never
+    hands memory back to the driver while the process lives."""
+    a0 = _uc_stats()
+    run_amd("rastrigin", 64, 2000, 42, maxeval=2600)
+    run_amd("levy", 4, 50, 12345, maxeval=400)
+    a1 = _uc_stats()
+    assert a1[0] == a0[0] and a1[3] == a0[3], "a conservative-pass run allocated uncached memory: %r -> %r" % (a0, a1)
+    run_amd("griewank", 2048, 2100, 42, maxeval=2160)               # device-resolved windows: TX, TM and the control block are uncached
+    a2 = _uc_stats()
+    assert a2[0] - a1[0] <= 3 and a2[1] == 0 and a2[3] == a1[3]     # at most three blocks from the driver, all back in the pool, none freed
+    run_amd("griewank", 2048, 2100, 7, maxeval=2160)
+    a3 = _uc_stats()
+    assert a3[0] == a2[0] and a3[1] == 0 and a3[2] == a2[2], "the second run did not reuse the pooled blocks: %r -> %r" % (a2, a3)
+
+
 def test_speculation_depth_does_not_change_the_sequence():
     base = None
     for spec in (1, 2, 16, 0):

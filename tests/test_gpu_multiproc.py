@@ -59,7 +59,7 @@ def test_crs_sharded_init(world):
 @pytest.mark.parametrize("world,a", [(2, dict(obj="rastrigin", n=96, pop=1501, seed=11, maxeval=4000)),
                                      (3, dict(obj="levy", n=257, pop=600, seed=5, maxeval=1500)),
                                      (3, dict(obj="rosenbrock", n=10, pop=100, seed=42, maxeval=2500)),
-                                     (2, dict(obj="griewank", n=4096, pop=3000, seed=42, maxeval=3400))])
+                                     (2, dict(obj="griewank", n=4096, pop=4200, seed=42, maxeval=4500))])
 def test_crs_column_sharded(world, a):
     """the population sharded BY COORDINATE (hip/crs_shard.hip): the gather-sum, mutation and row replacement run on every rank's
     slice, the candidates of a pass are all-gathered and evaluated with the single-GPU reduction — so the run is the
