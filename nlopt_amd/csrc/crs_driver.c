@@ -337,7 +337,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
     double t0 = nla_seconds();
 
     while (ret == NLOPT_SUCCESS) {
-        int K, nW, j = 0, ncommit = 0, best_changed = 0, cap, a;
+        int K, nW, j = 0, ncommit = 0, best_changed = 0, cap, a, timed_pass = 1;
         uint64_t wend;
         if (eval_budget > 0 && (int64_t) (*stop->nevals_p - evals_at_entry) >= eval_budget) break;
         if (pb->comm) {        /* the clock and the force_stop flag are decided once per pass, by all ranks together (comm.c) */
@@ -363,7 +363,11 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             for (a = 0; a < nW; ++a) S->Wf[a] = rs->F[W[a]];
             if (ops->chain(e, S->block, K, rs->os.best, rs->F[rs->os.best], W, S->Wf, nW, status, S->fwcnt, S->fwrec, FWCAP)) { engine_failed(S); return S->ret; }
         } else
-        if (ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status)) { engine_failed(S); return S->ret; }
+        {
+            const uint64_t gl0 = st ? st->gather_launches : 0;
+            if (!S->forward && ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status)) { engine_failed(S); return S->ret; }
+            timed_pass = !st || st->gather_launches != gl0;        /* the engine times the gather of every pass, or of a sample of them: bytes follow */
+        }
         wend = S->block + (uint64_t) K;
         if (st) {
             ++st->rounds;
@@ -372,7 +376,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 const int32_t told = b >= S->fresh_from ? 0 : S->tprev[b % TRING];
                 const int32_t tnew = status[a].t;
                 if (b >= S->fresh_from) ++st->slots_launched;
-                if (tnew > told) st->gather_bytes += 8ULL * (uint64_t) n * (uint64_t) (tnew - told + (told == 0 ? 1 : 0));
+                if (tnew > told && timed_pass) st->gather_bytes += 8ULL * (uint64_t) n * (uint64_t) (tnew - told + (told == 0 ? 1 : 0));
                 S->tprev[b % TRING] = tnew;
             }
         }

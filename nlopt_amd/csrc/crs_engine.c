@@ -23,6 +23,7 @@
 /* the objective id as the kernel launchers take it: a compiled-in objective under nlopt_set_max_objective delivers -f (e->sign) */
 #define OBJK(e) (((e)->obj >= 0 && (e)->sign < 0) ? ((e)->obj | NLA_OBJ_NEGATE) : (e)->obj)
 #define NLA_KARG_MAX 128                   /* list length that still travels as kernel arguments (hip/crs_kernels.hip NLA_KA_MAX) */
+#define TIME_EVERY 8                       /* conservative passes below n = 2048: one in so many is timed */
 #define ROWPAD 64                          /* spare rows behind X / F: the init all-gather wants equal blocks per rank (world <= 64) */
 
 typedef struct {
@@ -60,6 +61,10 @@ struct nla_crs_hip_engine {
     int32_t pend_slot[KCAP], pend_kind[KCAP];
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
+    /* the gather kernel is timed with an event pair around it (the roofline figure of bench.py).  A pair costs two barrier packets
+     * in front of and behind the kernel: nothing next to a 0.2-3 ms gather, a good part of a 10-20 us pass at small n — there only
+     * every TIME_EVERY-th pass is timed; its bytes and its time go into the statistics together (gather_launches counts timed passes) */
+    unsigned pass_no; int timed;
     int uncached;                  /* TX / TM / ctrl are uncached memory (the chain kernel may run) */
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
     /* device-resolved windows (hip/crs_chain.hip): control block, the walk's lists when they do not fit the kernel arguments,
@@ -502,6 +507,8 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     if (K < 1 || K > KCAP || nW > KCAP || nW < 0) FAIL(e, "bad window K=%d nW=%d", K, nW);
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
     if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
+    e->timed = (e->n >= 2048 || e->pass_log || (e->pass_no++ % TIME_EVERY) == 0) && e->stats;
+#define EVREC(ev) do { if (e->timed) CK(e, nla_event_record((ev), e->main)); } while (0)
     for (int a = 0; a < K; ++a) {
         const uint64_t b = first_block + (uint64_t) a;
         t_in[a] = b >= fresh_from ? 0 : e->h_t[b & (KCAP - 1)];
@@ -511,10 +518,10 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
          * mutation) are all-gathered and every rank evaluates the assembled points — identical status records on every rank */
         const int ncol = (e->ld % 2 == 0 && e->nc % 2 != 0) ? e->nc + 1 : e->nc;      /* (an even count lets the gather take coordinate pairs; the pad column is zero) */
         if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, NULL, NULL)) return -1;
-        CK(e, nla_event_record(e->ev0, e->main));
+        EVREC(e->ev0);
         CK(e, nla_k_crs_advance_cols(n, ncol, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
                                      d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
-        CK(e, nla_event_record(e->ev1, e->main));
+        EVREC(e->ev1);
         CK(e, nla_k_crs_sh_mutate_pack(n, e->c0, e->nc, e->ld, e->colper, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                                        d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_csend, e->main));
         if (nla_comm_allgather_dev(e->comm, e->d_csend, e->d_crecv, sizeof(double) * 2 * (size_t) K * (size_t) e->colper, e->main))
@@ -530,10 +537,10 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
             CK(e, nla_k_crs_commit_args(n, e->ld, e->d_X, e->d_TX, e->d_TM, e->npending, e->pend_slot, e->pend_kind, e->pend_row, e->main));
             e->npending = 0;
         }
-        CK(e, nla_event_record(e->ev0, e->main));
+        EVREC(e->ev0);
         CK(e, nla_k_crs_advance_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
                                      t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
-        CK(e, nla_event_record(e->ev1, e->main));
+        EVREC(e->ev1);
         CK(e, nla_k_crs_finish_args(OBJK(e), n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                                     t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM,
                                     e->direct_status ? e->h_status : e->d_status, e->main));
@@ -546,10 +553,10 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         goto launched;
     }
     if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, NULL, NULL)) return -1;
-    CK(e, nla_event_record(e->ev0, e->main));
+    EVREC(e->ev0);
     CK(e, nla_k_crs_advance(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
                             d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
-    CK(e, nla_event_record(e->ev1, e->main));
+    EVREC(e->ev1);
     CK(e, nla_k_crs_finish(OBJK(e), n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                            d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->d_status, e->main));
 launched:
@@ -573,11 +580,12 @@ have_status:
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
 
     for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = status[a].t;
-    if (e->stats) {
+    if (e->timed) {
         float ms = nla_event_elapsed_ms(e->ev0, e->ev1);
         if (ms >= 0) e->stats->t_gather_ms += ms;
         e->stats->gather_launches += 1;
     }
+#undef EVREC
     if (e->pass_log) {             /* K, nW, slots already complete / fresh / stopped short, rows summed, kernel ms */
         long rows = 0;
         int done_in = 0, fresh = 0, stopped = 0;

@@ -90,6 +90,39 @@ def main():
                    kind=t["kind"], accepted=t["accepted"], collectives=np.array([comm.counters()["collectives"]]),
                    gathered_bytes=np.array([comm.counters()["bytes"]]), after=np.array([nlopt_amd.lib().nla_genrand_int32()], dtype=np.uint64),
                    stats_allgather_bytes=np.array([o.stats()["allgather_bytes"]], dtype=np.uint64), rounds=np.array([o.stats()["rounds"]]))
+    elif case == "gpu_crs_rate":
+        # tools/shard_probe.py: the trial-phase rate of one CRS2_LM job (population initialisation untimed), as bench.py measures it
+        import ctypes as C
+        import time
+        L = nlopt_amd.lib()
+        obj, n, pop, seed = args["obj"], args["n"], args["pop"], args["seed"]
+        xs, lo, hi = O.golden_x0(obj, n)
+        o = nlopt_amd.Opt(nlopt_amd.GN_CRS2_LM, n)
+        o.set_lower_bounds(lo); o.set_upper_bounds(hi); o.set_min_objective(nlopt_amd.objective(obj)); o.set_population(pop)
+        for k, v in (args.get("params") or {}).items():
+            o.set_param(k, v)
+        if world > 1:
+            o.set_comm(comm)
+        nlopt_amd.srand(seed)
+        x = np.array(xs)
+        minf, ret = C.c_double(), C.c_int()
+        dist.barrier()
+        t0 = time.perf_counter()
+        s = L.nlopt_amd_crs_open(o._h, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(minf), C.byref(ret))
+        t_init = time.perf_counter() - t0
+        assert s and ret.value == 1, (ret.value, o.get_errmsg())
+        L.nlopt_amd_crs_step(s, args["evals"] // 4)
+        dist.barrier()
+        st0, ev0, t0 = o.stats(), o.get_numevals(), time.perf_counter()
+        L.nlopt_amd_crs_step(s, args["evals"])
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        st1, ev1 = o.stats(), o.get_numevals()
+        L.nlopt_amd_crs_close(s)
+        res = dict(evals_per_s=np.array([(ev1 - ev0) / dt]), passes=np.array([st1["rounds"] - st0["rounds"]]), dt=np.array([dt]), t_init=np.array([t_init]),
+                   evals=np.array([ev1 - ev0]), gather_ms=np.array([st1["t_gather_ms"] - st0["t_gather_ms"]]),
+                   gather_launches=np.array([st1["gather_launches"] - st0["gather_launches"]]),
+                   allgather_bytes=np.array([st1["allgather_bytes"] - st0["allgather_bytes"]], dtype=np.uint64), minf=np.array([minf.value]))
     elif case == "emu_sweep":
         # drawn configurations of the ISRES and MLSL host drivers over the emulated device, each checked against the oracle here
         # (every rank runs the same draws; the multi-rank runs shard them)

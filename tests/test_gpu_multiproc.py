@@ -65,9 +65,10 @@ def test_crs_column_sharded(world, a):
     slice, the candidates of a pass are all-gathered and evaluated with the single-GPU reduction — so the run is the
     single-process run of this device bit for bit (at n = 4096 that one resolves its windows in the chain kernel: same sequence)"""
     s = single("gpu_crs", a)
+    assert s["ret"] == 5 and s["nevals"] >= a["maxeval"]             # a real run (MAXEVAL_REACHED), not an argument error
     for d in run_world("gpu_crs", a, world=world):
         same(d, s)
-        assert d["collectives"][0] >= d["rounds"][0] and d["stats_allgather_bytes"][0] > 0
+        assert d["collectives"][0] >= d["rounds"][0] > 0 and d["stats_allgather_bytes"][0] > 0
 
 
 @pytest.mark.parametrize("world,ncon", [(2, 4), (3, 0)])
