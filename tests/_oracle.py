@@ -144,7 +144,7 @@ def run_port_crs(obj, n, pop, seed, maxeval=0, x0=None, stopval=None, ftol_rel=0
     fdata = None
     rec = None
     if record:
-        cap = (maxeval or 100000) + 2 * n + 50000
+        cap = (maxeval or 350000) + 2 * n + 50000
         fbuf = np.zeros(cap)
         hbuf = np.zeros(cap, dtype=np.uint64)
         rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
