@@ -73,8 +73,21 @@ __device__ __attribute__((noinline)) double lb_strang_in_registers(int n, int k,
                                                                     const double *__restrict__ hx, const double *__restrict__ hg,
                                                                     const double *__restrict__ ucol, double *__restrict__ vcol, double b)
 {
-    __shared__ lb_shared S;
+    /* the per-column reductions alternate between two LDS slots: a wavefront may already write the NEXT column's partial while a
+     * slower one still reads this column's — ONE barrier per reduction instead of lb_block_sum's two (same tree, same sums) */
+    __shared__ double red[2][LB_W];
     const int tid = threadIdx.x;
+    int par = 0;
+    auto block_sum = [&](double v) {
+        v = lb_wave_sum(v);
+        if ((tid & 63) == 0) red[par][tid >> 6] = v;
+        __syncthreads();
+        double t = red[par][0];
+#pragma unroll
+        for (int w = 1; w < LB_W; ++w) t += red[par][w];
+        par ^= 1;
+        return t;
+    };
     double snorm, a;
 #define COLX(i) (hx + (size_t) ((head + (i) - 1) % mf) * ld)
 #define COLG(i) (hg + (size_t) ((head + (i) - 1) % mf) * ld)
@@ -99,7 +112,7 @@ __device__ __attribute__((noinline)) double lb_strang_in_registers(int n, int k,
         double t = 0;
 #pragma unroll
         for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c1[e];
-        const double v = COLU(j) * lb_block_sum(t, S);
+        const double v = COLU(j) * block_sum(t);
         if (tid == 0) vcol[j - 1] = v;
 #pragma unroll
         for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + (-v) * c2[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
@@ -109,7 +122,7 @@ __device__ __attribute__((noinline)) double lb_strang_in_registers(int n, int k,
         const double *cg = COLG(1);
 #pragma unroll
         for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { const double gv = cg[tid + e * LB_T]; t += gv * gv; }
-        a = lb_block_sum(t, S);
+        a = block_sum(t);
         if (a > 0.) {
             const double sc = b / a;
 #pragma unroll
@@ -122,7 +135,7 @@ __device__ __attribute__((noinline)) double lb_strang_in_registers(int n, int k,
         double t = 0;
 #pragma unroll
         for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) t += sr[e] * c2[e];
-        const double tt = COLU(j) * lb_block_sum(t, S);
+        const double tt = COLU(j) * block_sum(t);
         const double w = vcol[j - 1] - tt;
 #pragma unroll
         for (int e = 0; e < LB_EPT; ++e) if (live & (1u << e)) { sr[e] = sr[e] + w * c1[e]; c1[e] = n1[e]; c2[e] = n2[e]; }
@@ -135,7 +148,7 @@ __device__ __attribute__((noinline)) double lb_strang_in_registers(int n, int k,
             if (e < ept && i < n) s[i] = sr[e];
             if (live & (1u << e)) t += sr[e] * sr[e];
         }
-        snorm = sqrt(lb_block_sum(t, S));
+        snorm = sqrt(block_sum(t));
     }
     __syncthreads();
 #undef COLX

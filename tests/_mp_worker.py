@@ -62,10 +62,26 @@ def main():
         o = nlopt_amd.Opt(alg, n)
         o.set_lower_bounds(lo)
         o.set_upper_bounds(hi)
-        o.set_min_objective(nlopt_amd.objective(obj))
+        if args.get("fix_last"):                     # a fixed coordinate: the elimination wrapper puts a host function in front
+            lo_v, hi_v = np.full(n, lo), np.full(n, hi)
+            lo_v[n - 1] = hi_v[n - 1] = 0.5 * (lo + hi) + 0.1
+            o.set_lower_bounds(lo_v)
+            o.set_upper_bounds(hi_v)
+            xs = list(np.clip(np.array(xs, dtype=float), lo_v, hi_v))
+        if args.get("maximize"):
+            o.set_max_objective(nlopt_amd.objective(obj))
+        else:
+            o.set_min_objective(nlopt_amd.objective(obj))
         if args.get("pop"):
             o.set_population(args["pop"])
         o.set_maxeval(args["maxeval"])
+        if args.get("stopval") is not None:
+            o.set_stopval(args["stopval"])
+        if args.get("maxtime_rank") is not None and rank == args["maxtime_rank"]:
+            o.set_maxtime(args["maxtime"])            # ONE rank's clock runs out: all ranks must leave together
+        if args.get("force_stop_rank") is not None and rank == args["force_stop_rank"]:
+            import threading
+            threading.Timer(args["force_stop_after"], o.force_stop).start()   # ONE rank's user raises force_stop
         if case == "gpu_isres" and args.get("ncon"):
             o.add_blocksum_constraints(args["ncon"], 1e-8)
         if case == "gpu_mlsl" and args.get("local") == "default":
@@ -85,11 +101,17 @@ def main():
         o.enable_trace(args["maxeval"] + 4096)
         nlopt_amd.srand(seed)
         x, minf, ret = o.optimize_raw(xs)
+        if args.get("twice"):                        # the same object again, generator continuing: a second, different run
+            first_run = (x.copy(), minf, ret, o.get_numevals())
+            x, minf, ret = o.optimize_raw(xs)
+            res_first = dict(x1=first_run[0], minf1=np.array([first_run[1]]), ret1=np.array([first_run[2]]), nevals1=np.array([first_run[3]]))
         t = o.trace()
         res = dict(ret=np.array([ret]), minf=np.array([minf]), x=x, nevals=np.array([o.get_numevals()]), f=t["f"], row=t["row"],
                    kind=t["kind"], accepted=t["accepted"], collectives=np.array([comm.counters()["collectives"]]),
                    gathered_bytes=np.array([comm.counters()["bytes"]]), after=np.array([nlopt_amd.lib().nla_genrand_int32()], dtype=np.uint64),
                    stats_allgather_bytes=np.array([o.stats()["allgather_bytes"]], dtype=np.uint64), rounds=np.array([o.stats()["rounds"]]))
+        if args.get("twice"):
+            res.update(res_first)
     elif case == "gpu_crs_rate":
         # tools/shard_probe.py: the trial-phase rate of one CRS2_LM job (population initialisation untimed), as bench.py measures it
         import ctypes as C

@@ -156,3 +156,37 @@ def test_crs_column_sharded_large_n_prefix_world3():
         for key in ("f", "row", "kind", "accepted"):
             assert np.array_equal(d[key], p["trace"][key]), key
         assert np.array_equal(d["x"], p["x"])
+
+
+def _single_emu(a):
+    """the same job in ONE process over the emulated device (what every rank of a sharded run must reproduce)"""
+    return run_world("gpu_crs", dict(a, sharded=False), world=1, extra_env=EMU)[0]
+
+
+@pytest.mark.parametrize("a", [
+    dict(obj="rastrigin", n=8, pop=60, seed=5, maxeval=900, maximize=True),                 # nlopt_set_max_objective: the kernels deliver -f on every rank
+    dict(obj="sphere", n=6, pop=40, seed=3, maxeval=5000, stopval=0.05),                     # STOPVAL_REACHED mid-run
+    dict(obj="ackley", n=12, pop=80, seed=9, maxeval=700, fix_last=True),                    # a fixed coordinate: host wrapper -> replicas, still identical
+    dict(obj="griewank", n=9, pop=50, seed=2, maxeval=500, twice=True),                      # the object reused: the generator continues
+], ids=["maximize", "stopval", "fixed_dim", "twice"])
+def test_crs_column_sharded_variants_equal_the_single_process_run(a):
+    s = _single_emu(a)
+    for d in run_world("gpu_crs", a, world=2, extra_env=EMU):
+        assert d["ret"][0] == s["ret"][0] and d["nevals"][0] == s["nevals"][0] and d["minf"][0] == s["minf"][0]
+        assert np.array_equal(d["x"], s["x"]) and np.array_equal(d["f"], s["f"]) and np.array_equal(d["row"], s["row"])
+        assert d["after"][0] == s["after"][0]
+        if a.get("twice"):
+            assert np.array_equal(d["x1"], s["x1"]) and d["minf1"][0] == s["minf1"][0] and d["nevals1"][0] == s["nevals1"][0]
+            assert not np.array_equal(d["x1"], d["x"])
+
+
+@pytest.mark.parametrize("a", [dict(force_stop_rank=1, force_stop_after=0.3), dict(maxtime_rank=0, maxtime=4.0)], ids=["force_stop_on_one_rank", "maxtime_on_one_rank"])
+def test_crs_column_sharded_ranks_leave_together(a):
+    """a stop condition only ONE rank sees (its user's force_stop, its own clock) is agreed by all ranks once per pass: every rank
+    returns the same result after the same number of evaluations — nobody is left waiting in an all-gather"""
+    cfg = dict(obj="rastrigin", n=64, pop=400, seed=7, maxeval=2000000, **a)
+    res = run_world("gpu_crs", cfg, world=2, extra_env=EMU, timeout=300)
+    want = -5 if "force_stop_rank" in a else 6                  # NLOPT_FORCED_STOP / NLOPT_MAXTIME_REACHED
+    assert res[0]["ret"][0] == want and res[1]["ret"][0] == want
+    assert res[0]["nevals"][0] == res[1]["nevals"][0] and 400 < res[0]["nevals"][0] < 2000000
+    assert np.array_equal(res[0]["x"], res[1]["x"]) and res[0]["minf"][0] == res[1]["minf"][0]
