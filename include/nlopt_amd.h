@@ -270,14 +270,16 @@ int nla_k_crs_advance_cols(int n, int ncol, int ld, const double *X, int64_t i0,
 int nla_k_crs_sh_init_rows(int n, int c0, int nc, int ld, const double *lb, const double *ub, const uint32_t *words,
                            int64_t row_first, int64_t nrows, double *X, void *stream);
 /* the mutation half of nla_k_crs_finish on the slice, for the window slots completed by the preceding advance: TM[q] = slice of the
- * mutation (crs.c:139-146), and both slices packed for the all-gather: SEND[(2a) * colper + i] = T_i, SEND[(2a+1) * colper + i] = M_i */
+ * mutation (crs.c:139-146), and both slices packed for the all-gather: SEND[(2a) * colper + i] = T_i, SEND[(2a+1) * colper + i] = M_i;
+ * SEND[2 K colper], [+1] = this rank's stop flags (force_stop raised, clock run out): a rank's block is 2 K colper + 2 doubles */
 int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colper, const double *X, int64_t i0, const double *TX, double *TM,
                              const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in,
-                             const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND, void *stream);
-/* the evaluation half (crs.c:133, :146) on the gathered candidates: RECV rank-major, each rank's block = 2K slices of colper doubles;
- * fT_ring / fM_ring / status as nla_k_crs_finish writes them */
+                             const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND,
+                             int flag_forced, int flag_timed, void *stream);
+/* the evaluation half (crs.c:133, :146) on the gathered candidates: RECV rank-major, each rank's block = 2K slices of colper doubles + 2;
+ * fT_ring / fM_ring / status as nla_k_crs_finish writes them; status[K].fT / .fM = the stop flags OR-ed over the ranks */
 int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
-                      const double *RECV, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *stream);
+                      const double *RECV, int world, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *stream);
 
 /* replaces: memcpy(worst->k, d->p, ...) at crs.c:153 for a batch of accepted candidates.
  * X[row[c]] := (kind[c] == 1 ? TX : TM)[slot[c]];  rows must be distinct within one call. */

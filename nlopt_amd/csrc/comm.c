@@ -217,10 +217,16 @@ const nla_stopping *nla_comm_agree_stop(nlopt_amd_comm *c, const nla_stopping *s
     if (!all || nla_comm_allgather_host(c, mine, all, sizeof mine, NULL)) { free(all); return NULL; }
     for (r = 0; r < world; ++r) { forced |= all[2 * r]; timed |= all[2 * r + 1]; }
     free(all);
+    nla_stop_view(stop, forced, timed, view, force_store);
+    return view;
+}
+
+/* *stop with its two per-process conditions replaced by agreed verdicts */
+void nla_stop_view(const nla_stopping *stop, int forced, int timed, nla_stopping *view, int *force_store)
+{
     *view = *stop;
     *force_store = forced;
     view->force_stop = force_store;
     if (timed) { view->maxtime = 1e-300; view->start = -1e300; }      /* nla_stop_time(view) is true from now on */
     else view->maxtime = 0;                                           /* ... or false until the next agreement */
-    return view;
 }

@@ -340,9 +340,14 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
         int K, nW, j = 0, ncommit = 0, best_changed = 0, cap, a, timed_pass = 1;
         uint64_t wend;
         if (eval_budget > 0 && (int64_t) (*stop->nevals_p - evals_at_entry) >= eval_budget) break;
-        if (pb->comm) {        /* the clock and the force_stop flag are decided once per pass, by all ranks together (comm.c) */
-            rs->sp = nla_comm_agree_stop(pb->comm, stop, &S->view, &S->agreed_force);
-            if (!rs->sp) { nla_stop_msg(stop, "stop agreement failed: %s", nlopt_amd_comm_error(pb->comm)); S->ret = NLOPT_FAILURE; return S->ret; }
+        if (pb->comm) {
+            /* the clock and the force_stop flag are decided once per pass, by all ranks together: this rank's view travels with the
+             * pass's candidates and comes back OR-ed with the status (no collective of its own); an engine without that: comm.c */
+            if (ops->stop_flags_in && ops->stop_flags_out) ops->stop_flags_in(e, nla_stop_forced(stop), nla_stop_time(stop));
+            else {
+                rs->sp = nla_comm_agree_stop(pb->comm, stop, &S->view, &S->agreed_force);
+                if (!rs->sp) { nla_stop_msg(stop, "stop agreement failed: %s", nlopt_amd_comm_error(pb->comm)); S->ret = NLOPT_FAILURE; return S->ret; }
+            }
         }
         cap = ops->max_slots(e, S->block);
         if (cap <= 0) { engine_failed(S); return S->ret; }
@@ -367,6 +372,12 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             const uint64_t gl0 = st ? st->gather_launches : 0;
             if (!S->forward && ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status)) { engine_failed(S); return S->ret; }
             timed_pass = !st || st->gather_launches != gl0;        /* the engine times the gather of every pass, or of a sample of them: bytes follow */
+            if (pb->comm && ops->stop_flags_in && ops->stop_flags_out) {
+                int forced = 0, timed = 0;
+                ops->stop_flags_out(e, &forced, &timed);
+                nla_stop_view(stop, forced, timed, &S->view, &S->agreed_force);
+                rs->sp = &S->view;
+            }
         }
         wend = S->block + (uint64_t) K;
         if (st) {

@@ -82,7 +82,8 @@ struct nla_crs_hip_engine {
      * identical chain on identical f values: the candidates of a pass are all-gathered and evaluated by every rank */
     int sharded, world, rank, c0, nc, colper;
     int ncopy;                     /* coordinates a row copy moves: n, or nc */
-    double *d_csend, *d_crecv;     /* a pass's candidates: 2 KCAP slices of colper doubles, world x that */
+    double *d_csend, *d_crecv;     /* a pass's candidates: 2 KCAP slices of colper doubles (+ 2 stop flags), world x that */
+    int stop_in[2], stop_out[2];   /* the per-process stop conditions: this rank's view into a pass, all ranks' OR out of it */
     double *d_gsend, *d_grecv, *h_g;   /* a whole point from its slices (read_row / read_slot): colper, world x colper */
     const double *h_lb_full, *h_ub_full;   /* the caller's bounds (valid for the engine's life: the run's own arrays) */
     char err[256];
@@ -219,9 +220,9 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->d_fM = e->d_fT ? e->d_fT + KCAP : NULL;
     e->d_up = (char *) nla_dev_malloc(UPLOAD_BYTES);
     e->d_tout = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
-    e->d_status = (nla_crs_slot_status *) nla_dev_malloc(sizeof(nla_crs_slot_status) * KCAP);
+    e->d_status = (nla_crs_slot_status *) nla_dev_malloc(sizeof(nla_crs_slot_status) * (KCAP + 1));
     e->h_up = (char *) nla_host_malloc(UPLOAD_BYTES);
-    e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * KCAP);
+    e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * (KCAP + 1));
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
     if (obj == -2) {
@@ -242,14 +243,14 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1 ||
         (e->uncached && obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
     if (e->sharded) {
-        e->d_csend = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP * (size_t) e->colper);
-        e->d_crecv = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP * (size_t) e->colper * (size_t) e->world);
+        e->d_csend = (double *) nla_dev_malloc(sizeof(double) * (2 * KCAP * (size_t) e->colper + 2));
+        e->d_crecv = (double *) nla_dev_malloc(sizeof(double) * (2 * KCAP * (size_t) e->colper + 2) * (size_t) e->world);
         e->d_gsend = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->colper);
         e->d_grecv = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
         e->h_g = (double *) nla_host_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
         if (!e->d_csend || !e->d_crecv || !e->d_gsend || !e->d_grecv || !e->h_g) goto fail;
         if (nla_memset(e->d_gsend, 0, sizeof(double) * (size_t) e->colper, e->main) ||
-            nla_memset(e->d_csend, 0, sizeof(double) * 2 * KCAP * (size_t) e->colper, e->main)) goto fail;
+            nla_memset(e->d_csend, 0, sizeof(double) * (2 * KCAP * (size_t) e->colper + 2), e->main)) goto fail;
     }
     /* the slice's bounds (the whole vectors in a single-process run); pad entries are zero */
     if ((e->d_ctrl && nla_memset(e->d_ctrl, 0, nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX), e->main)) ||
@@ -523,12 +524,16 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
                                      d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         EVREC(e->ev1);
         CK(e, nla_k_crs_sh_mutate_pack(n, e->c0, e->nc, e->ld, e->colper, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
-                                       d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_csend, e->main));
-        if (nla_comm_allgather_dev(e->comm, e->d_csend, e->d_crecv, sizeof(double) * 2 * (size_t) K * (size_t) e->colper, e->main))
+                                       d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_csend, e->stop_in[0], e->stop_in[1], e->main));
+        if (nla_comm_allgather_dev(e->comm, e->d_csend, e->d_crecv, sizeof(double) * (2 * (size_t) K * (size_t) e->colper + 2), e->main))
             FAIL(e, "all-gather of the candidates failed: %s", nlopt_amd_comm_error(e->comm));
-        CK(e, nla_k_crs_sh_eval(OBJK(e), n, e->colper, first_block, K, d_tin, e->d_tout, KCAP - 1, e->d_crecv, e->d_fT, e->d_fM, e->d_status, e->main));
-        if (e->stats) e->stats->allgather_bytes += (uint64_t) e->world * 2 * (uint64_t) K * (uint64_t) e->colper * sizeof(double);
-        goto launched;
+        CK(e, nla_k_crs_sh_eval(OBJK(e), n, e->colper, first_block, K, d_tin, e->d_tout, KCAP - 1, e->d_crecv, e->world, e->d_fT, e->d_fM, e->d_status, e->main));
+        if (e->stats) e->stats->allgather_bytes += (uint64_t) e->world * (2 * (uint64_t) K * (uint64_t) e->colper + 2) * sizeof(double);
+        /* the K status records and, behind them, the ranks' agreed stop flags */
+        CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * ((size_t) K + 1), e->main));
+        CK(e, nla_stream_sync(e->main));
+        e->stop_out[0] = e->h_status[K].fT != 0.; e->stop_out[1] = e->h_status[K].fM != 0.;
+        goto have_status;
     }
     if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload && e->obj != -2) {
         /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
@@ -695,6 +700,8 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
 }
 
 static const char *op_last_error(void *ve) { return ((nla_crs_hip_engine *) ve)->err; }
+static void op_stop_flags_in(void *ve, int forced, int timed) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; e->stop_in[0] = forced; e->stop_in[1] = timed; }
+static void op_stop_flags_out(void *ve, int *forced, int *timed) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; *forced = e->stop_out[0]; *timed = e->stop_out[1]; }
 
 static int op_reset_slot(void *ve, uint64_t block)
 {
@@ -703,7 +710,8 @@ static int op_reset_slot(void *ve, uint64_t block)
 }
 
 const nla_crs_engine_ops nla_crs_hip_ops = {
-    op_init_population, op_max_slots, op_advance, op_chain, op_reset_slot, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error
+    op_init_population, op_max_slots, op_advance, op_chain, op_reset_slot, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error,
+    op_stop_flags_in, op_stop_flags_out
 };
 
 static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,

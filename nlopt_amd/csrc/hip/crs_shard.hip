@@ -42,13 +42,17 @@ __global__ __launch_bounds__(256) void crs_sh_init_rows_kernel(int n, int c0, in
 
 /* for every slot of the window that became complete in this pass: TM[q] = the slice of the local mutation that would follow the
  * trial's rejection (crs.c:139-146; w from the NEXT stream block at the slice's global coordinates), and the slices of both points
- * packed for the all-gather: SEND[(2a) * colper + i] = T_i, SEND[(2a+1) * colper + i] = M_i (i < nc; untouched for other slots) */
+ * packed for the all-gather: SEND[(2a) * colper + i] = T_i, SEND[(2a+1) * colper + i] = M_i (i < nc; untouched for other slots);
+ * SEND[2 K colper], [+1] = the rank's stop flags.  A rank's block of the all-gather is 2 K colper + 2 doubles. */
 __global__ __launch_bounds__(256) void crs_sh_mutate_pack_kernel(
     int n, int c0, int nc, int ld, int colper, const double *__restrict__ X, int64_t i0, const double *__restrict__ TX, double *__restrict__ TM,
     const uint32_t *__restrict__ words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *__restrict__ t_in,
-    const int32_t *__restrict__ t_out, int slot_mask, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ SEND)
+    const int32_t *__restrict__ t_out, int slot_mask, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ SEND,
+    double flag0, double flag1)
 {
     const int a = blockIdx.x;
+    /* behind the 2K slices: what this rank sees of the per-process stop conditions (force_stop, clock) — agreed by the evaluation kernel */
+    if (a == 0 && threadIdx.x == 0) { SEND[(size_t) 2 * K * colper] = flag0; SEND[(size_t) 2 * K * colper + 1] = flag1; }
     if (!(t_out[a] == n && t_in[a] != n)) return;                 /* uniform over the workgroup */
     const uint64_t block = first_block + (uint64_t) a;
     const int q = (int) (block & (uint64_t) slot_mask);
@@ -70,13 +74,14 @@ __global__ __launch_bounds__(256) void crs_sh_mutate_pack_kernel(
 }
 
 /* f of the gathered candidates + the status records of the pass (the evaluation half of crs_finish_kernel on assembled points):
- * RECV is rank-major, rank r's block holding 2K slices of colper doubles; coordinate g of a point lives in rank g / colper's block.
+ * RECV is rank-major, rank r's block holding 2K slices of colper doubles + its two stop flags; coordinate g of a point lives in rank
+ * g / colper's block.  status[K] (one record behind the window's) = the flags OR-ed over the ranks.
  * The reduction is nla_block_objective<OBJ, 8> over global coordinates — the order of crs_finish_kernel / crs_chain_kernel, so f is
  * what a single-GPU run computes, bit for bit. */
 template <int OBJ>
 __global__ __launch_bounds__(SH_WAVES * 64) void crs_sh_eval_kernel(
     int n, int colper, uint64_t first_block, int K, const int32_t *__restrict__ t_in, const int32_t *__restrict__ t_out, int slot_mask,
-    const double *__restrict__ RECV, double *__restrict__ fT_ring, double *__restrict__ fM_ring,
+    const double *__restrict__ RECV, int world, double *__restrict__ fT_ring, double *__restrict__ fM_ring,
     nla_crs_slot_status *__restrict__ status, double sign)
 {
     __shared__ double scratch[2 * SH_WAVES];
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(SH_WAVES * 64) void crs_sh_eval_kernel(
     double *ring = task == 0 ? fT_ring : fM_ring;
     double f = 0;
     if (newly) {
-        const size_t rank_stride = (size_t) 2 * (size_t) K * (size_t) colper, off = (size_t) (2 * a + task) * (size_t) colper;
+        const size_t rank_stride = (size_t) 2 * (size_t) K * (size_t) colper + 2, off = (size_t) (2 * a + task) * (size_t) colper;
         auto get = [&](int g) { return RECV[(size_t) (g / colper) * rank_stride + off + (size_t) (g % colper)]; };
         f = sign * nla_block_objective<OBJ, SH_WAVES>(n, get, scratch);
         if (tid == 0) ring[q] = f;
@@ -96,6 +101,15 @@ __global__ __launch_bounds__(SH_WAVES * 64) void crs_sh_eval_kernel(
     if (tid == 0) {
         if (task == 0) { status[a].fT = f; status[a].t = t1; status[a].pad = 0; }
         else status[a].fM = f;
+        if (blockIdx.x == 0) {                   /* record K: the ranks' stop flags OR-ed (fT: force_stop, fM: clock) */
+            const size_t rank_stride = (size_t) 2 * (size_t) K * (size_t) colper + 2;
+            double f0 = 0, f1 = 0;
+            for (int r = 0; r < world; ++r) {
+                if (RECV[(size_t) r * rank_stride + rank_stride - 2] != 0.) f0 = 1.;
+                if (RECV[(size_t) r * rank_stride + rank_stride - 1] != 0.) f1 = 1.;
+            }
+            status[K].fT = f0; status[K].fM = f1; status[K].t = 0; status[K].pad = 0;
+        }
     }
 }
 
@@ -112,26 +126,28 @@ extern "C" int nla_k_crs_sh_init_rows(int n, int c0, int nc, int ld, const doubl
 
 extern "C" int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colper, const double *X, int64_t i0, const double *TX, double *TM,
                                         const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in,
-                                        const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND, void *stream)
+                                        const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND,
+                                        int flag_forced, int flag_timed, void *stream)
 {
     if (K <= 0) return 0;
     if (nc > colper || nc > ld) return (int) hipErrorInvalidValue;
     hipLaunchKernelGGL(crs_sh_mutate_pack_kernel, dim3((unsigned) K), dim3(256), 0, (hipStream_t) stream, n, c0, nc, ld, colper, X, i0, TX, TM,
-                       words_ring, ring_blocks, first_block, K, t_in, t_out, slot_mask, lb, ub, SEND);
+                       words_ring, ring_blocks, first_block, K, t_in, t_out, slot_mask, lb, ub, SEND, flag_forced ? 1. : 0., flag_timed ? 1. : 0.);
     NLA_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out,
-                                 int slot_mask, const double *RECV, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *stream)
+                                 int slot_mask, const double *RECV, int world, double *fT_ring, double *fM_ring, nla_crs_slot_status *status,
+                                 void *stream)
 {
     if (K <= 0) return 0;
     const dim3 grid((unsigned) (2 * K)), block(SH_WAVES * 64);
     hipStream_t st = (hipStream_t) stream;
     const double sign = nla_obj_sign(&obj);
-    if (colper < 1) return (int) hipErrorInvalidValue;
+    if (colper < 1 || world < 1) return (int) hipErrorInvalidValue;
 #define CALL(O) hipLaunchKernelGGL((crs_sh_eval_kernel<O>), grid, block, 0, st, n, colper, first_block, K, t_in, t_out, slot_mask, RECV, \
-                                   fT_ring, fM_ring, status, sign)
+                                   world, fT_ring, fM_ring, status, sign)
     NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     NLA_LAUNCH_CHECK();

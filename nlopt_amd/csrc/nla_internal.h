@@ -124,6 +124,7 @@ nlopt_result nla_optimize_limited(nlopt_opt opt, double *x, double *minf, int ma
 int nla_comm_allgather_dev(nlopt_amd_comm *c, const void *d_send, void *d_recv, size_t bytes, void *stream);
 int nla_comm_allgather_host(nlopt_amd_comm *c, const void *h_send, void *h_recv, size_t bytes, void *stream);
 void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, int64_t *first, int64_t *mine);
+void nla_stop_view(const nla_stopping *stop, int forced, int timed, nla_stopping *view, int *force_store);
 const nla_stopping *nla_comm_agree_stop(nlopt_amd_comm *c, const nla_stopping *stop, nla_stopping *view, int *force_store);
 
 /* ---- MT19937 host side (mt_host.c) ------------------------------------------------------------ */
@@ -188,6 +189,11 @@ typedef struct {
     /* host-callback mode: mutate the slot's finished trial in place with the words of block+1 */
     int (*mutate_slot)(void *e, uint64_t block, int64_t i0);
     const char *(*last_error)(void *e);
+    /* collective passes (a column-sharded run): what this rank sees of the per-process stop conditions goes INTO the next pass
+     * (force_stop raised, clock run out) and comes back OR-ed over all ranks with that pass's status — the ranks' agreement rides
+     * on the candidates' all-gather instead of costing a collective of its own.  NULL where passes are not collective. */
+    void (*stop_flags_in)(void *e, int forced, int timed);
+    void (*stop_flags_out)(void *e, int *forced, int *timed);
 } nla_crs_engine_ops;
 
 typedef struct {

@@ -678,11 +678,13 @@ int nla_k_crs_sh_init_rows(int n, int c0, int nc, int ld, const double *lb, cons
 }
 int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colper, const double *X, int64_t i0, const double *TX, double *TM,
                              const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in,
-                             const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND, void *st)
+                             const int32_t *t_out, int slot_mask, const double *lb, const double *ub, double *SEND, int flag_forced, int flag_timed,
+                             void *st)
 {
     EMU_LAUNCH();
     (void) st;
     if (nc > colper || nc > ld) return EMU_ERR;
+    SEND[(size_t) 2 * K * colper] = flag_forced ? 1. : 0.; SEND[(size_t) 2 * K * colper + 1] = flag_timed ? 1. : 0.;
     for (int a = 0; a < K; ++a) {
         const uint64_t block = first_block + (uint64_t) a;
         const int q = (int) (block & (uint64_t) slot_mask);
@@ -704,7 +706,7 @@ int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colper, const do
     return 0;
 }
 int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
-                      const double *RECV, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
+                      const double *RECV, int world, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)
 {
     EMU_LAUNCH();
     const double sign = emu_obj_sign(&obj);
@@ -719,12 +721,18 @@ int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, c
         if (t1 == n && t_in[a] != n) {
             for (int task = 0; task < 2; ++task) {
                 for (int g = 0; g < n; ++g)
-                    p[g] = RECV[(size_t) (g / colper) * (size_t) 2 * (size_t) K * (size_t) colper + (size_t) (2 * a + task) * (size_t) colper + (size_t) (g % colper)];
+                    p[g] = RECV[(size_t) (g / colper) * ((size_t) 2 * (size_t) K * (size_t) colper + 2) + (size_t) (2 * a + task) * (size_t) colper + (size_t) (g % colper)];
                 f[task] = sign * nla_obj_eval_seq(obj, (unsigned) n, p, NULL);           /* crs.c:133 / :146 on the assembled point */
             }
             fT_ring[q] = f[0]; fM_ring[q] = f[1];
         } else if (t1 == n) { f[0] = fT_ring[q]; f[1] = fM_ring[q]; }
         status[a].fT = f[0]; status[a].fM = f[1]; status[a].t = t1; status[a].pad = 0;
+    }
+    {
+        const size_t rs = (size_t) 2 * (size_t) K * (size_t) colper + 2;
+        double f0 = 0, f1 = 0;
+        for (int r = 0; r < world; ++r) { if (RECV[(size_t) r * rs + rs - 2] != 0.) f0 = 1.; if (RECV[(size_t) r * rs + rs - 1] != 0.) f1 = 1.; }
+        status[K].fT = f0; status[K].fM = f1; status[K].t = 0; status[K].pad = 0;
     }
     free(p);
     return 0;

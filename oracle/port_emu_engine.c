@@ -175,7 +175,7 @@ static int emu_mutate_slot(void *ve, uint64_t block, int64_t i0)
 static const char *emu_err(void *ve) { (void) ve; return "emu"; }
 
 static const nla_crs_engine_ops emu_ops = { emu_init, emu_max_slots, emu_advance, emu_chain, emu_reset_slot, emu_commit, emu_read_slot,
-                                            emu_read_row, emu_mutate_slot, emu_err };
+                                            emu_read_row, emu_mutate_slot, emu_err, NULL, NULL };
 
 /* Run the PRODUCT's CRS driver over the emulated engine.  RNG = the oracle generator (orc_srand
  * beforehand).  host_eval != 0 exercises the host-callback path with the zoo callback. */
