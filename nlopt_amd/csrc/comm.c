@@ -35,9 +35,12 @@ static struct {
 static pthread_once_t rccl_once = PTHREAD_ONCE_INIT;
 static void rccl_load_once(void)
 {
-    R.dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!R.dl) R.dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!R.dl) R.dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    /* NLA_RCCL_LIBRARY=<path>: the collective library to bind instead of the system's librccl (a site's own RCCL build; the tests
+     * point it at a mock that checks the all-gather contract, so that this transport runs with several ranks without GPUs) */
+    const char *path = getenv("NLA_RCCL_LIBRARY");
+    R.dl = path && *path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.dl && !(path && *path)) R.dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.dl && !(path && *path)) R.dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!R.dl) return;
     R.get_uid = (fn_get_uid) dlsym(R.dl, "ncclGetUniqueId");
     R.init_rank = (fn_init_rank) dlsym(R.dl, "ncclCommInitRank");

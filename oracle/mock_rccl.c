@@ -1,0 +1,134 @@
+/* mock_rccl.c — TEST INFRASTRUCTURE: a stand-in for librccl's all-gather so that the RCCL TRANSPORT of nlopt_amd/csrc/comm.c (the
+ * branch one-GPU boxes can only run with one rank) executes with 2-3 ranks on a machine without GPUs, over the emulated device layer
+ * (whose "device" pointers are host memory).  It implements the contract of the four entry points comm.c binds, as NCCL documents it:
+ *   ncclGetUniqueId     a 128-byte id made by rank 0 and handed to every rank by the launcher
+ *   ncclCommInitRank    collective over the nranks processes holding the same id
+ *   ncclAllGather       recvbuff (nranks * sendcount elements, rank-major) := every rank's sendbuff; IN PLACE when
+ *                       sendbuff == recvbuff + rank * sendcount; every rank must pass the same count / datatype, and all ranks must
+ *                       issue their collectives in the same order
+ *   ncclCommDestroy
+ * and it CHECKS what a real run cannot tell you until it hangs or corrupts: that all ranks of a collective pass the same byte count
+ * (error 5, ncclInvalidUsage, otherwise), that an overlapping sendbuff is exactly the in-place position, and (sequence numbers) that
+ * the ranks are in the same collective.  Transport: a POSIX shared-memory segment named by the id; ranks meet at sense-reversing
+ * spin barriers.  The stream argument is ignored: the emulated device layer is synchronous.  Nothing of the product links this. */
+#define _GNU_SOURCE
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+
+#define SLOT_BYTES (4u << 20)           /* payload moved per round and rank */
+#define MAXR 16
+
+typedef struct { char internal[128]; } mock_uid;
+typedef struct {
+    volatile int arrived, sense;        /* barrier */
+    volatile uint64_t count[MAXR], seq[MAXR];
+    int nranks;
+} shm_hdr;
+typedef struct { int rank, nranks, local_sense; uint64_t seq; shm_hdr *h; char *slots; size_t map_bytes; char name[132]; } mock_comm;
+
+/* what this process asked of the mock: all-gathers, how many of them in place, bytes sent — read by the tests to make sure the
+ * RCCL branch (not the host-callback transport) carried the run */
+static long n_allgather, n_inplace, n_bytes;
+void mock_rccl_stats(long out[3]) { out[0] = n_allgather; out[1] = n_inplace; out[2] = n_bytes; }
+
+static void barrier(mock_comm *c)
+{
+    shm_hdr *h = c->h;
+    c->local_sense = !c->local_sense;
+    if (__atomic_add_fetch(&h->arrived, 1, __ATOMIC_ACQ_REL) == c->nranks) {
+        __atomic_store_n(&h->arrived, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&h->sense, c->local_sense, __ATOMIC_RELEASE);
+    } else {
+        struct timespec t0, t;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        while (__atomic_load_n(&h->sense, __ATOMIC_ACQUIRE) != c->local_sense) {
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            if (t.tv_sec - t0.tv_sec > 120) { fprintf(stderr, "mock_rccl: rank %d waited 120 s at a barrier (ranks out of step?)\n", c->rank); abort(); }
+            usleep(20);
+        }
+    }
+}
+
+int ncclGetUniqueId(mock_uid *id)
+{
+    memset(id, 0, sizeof *id);
+    snprintf(id->internal, sizeof id->internal, "/nla_mock_rccl_%d_%ld", (int) getpid(), (long) time(NULL));
+    return 0;
+}
+const char *ncclGetErrorString(int e) { return e == 5 ? "invalid usage (mock_rccl: ranks disagree)" : (e ? "mock_rccl error" : "no error"); }
+
+int ncclCommInitRank(void **comm, int nranks, mock_uid id, int rank)
+{
+    mock_comm *c;
+    int fd;
+    if (nranks < 1 || nranks > MAXR || rank < 0 || rank >= nranks) return 4;
+    c = (mock_comm *) calloc(1, sizeof *c);
+    if (!c) return 1;
+    c->rank = rank; c->nranks = nranks;
+    snprintf(c->name, sizeof c->name, "%s", id.internal);
+    c->map_bytes = 4096 + (size_t) nranks * SLOT_BYTES;
+    fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t) c->map_bytes)) { free(c); return 2; }
+    c->h = (shm_hdr *) mmap(NULL, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (c->h == MAP_FAILED) { free(c); return 2; }
+    c->slots = (char *) c->h + 4096;
+    if (rank == 0) c->h->nranks = nranks;             /* (a fresh segment is zero-filled: barrier state starts at 0) */
+    barrier(c);
+    *comm = c;
+    return 0;
+}
+
+int ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, int datatype, void *comm, void *stream)
+{
+    mock_comm *c = (mock_comm *) comm;
+    const size_t bytes = sendcount;                    /* comm.c always passes ncclUint8 */
+    const char *send = (const char *) sendbuff;
+    char *recv = (char *) recvbuff;
+    (void) stream;
+    if (!c || datatype != 1) return 4;
+    /* an overlapping send buffer must be exactly the in-place one */
+    if (send < recv + (size_t) c->nranks * bytes && send + bytes > recv && send != recv + (size_t) c->rank * bytes) {
+        fprintf(stderr, "mock_rccl: rank %d: sendbuff overlaps recvbuff but is not recvbuff + rank * count\n", c->rank);
+        return 5;
+    }
+    ++n_allgather; n_bytes += (long) bytes;
+    if (send == recv + (size_t) c->rank * bytes) ++n_inplace;
+    ++c->seq;
+    c->h->count[c->rank] = bytes; c->h->seq[c->rank] = c->seq;
+    barrier(c);
+    for (int r = 0; r < c->nranks; ++r)
+        if (c->h->count[r] != bytes || c->h->seq[r] != c->seq) {
+            fprintf(stderr, "mock_rccl: collective %llu: rank %d passes %zu bytes, rank %d passes %llu (collective %llu)\n",
+                    (unsigned long long) c->seq, c->rank, bytes, r, (unsigned long long) c->h->count[r], (unsigned long long) c->h->seq[r]);
+            barrier(c);
+            return 5;
+        }
+    for (size_t off = 0; off < bytes || off == 0; off += SLOT_BYTES) {
+        const size_t m = bytes - off < SLOT_BYTES ? bytes - off : SLOT_BYTES;
+        if (m) memcpy(c->slots + (size_t) c->rank * SLOT_BYTES, send + off, m);
+        barrier(c);
+        for (int r = 0; r < c->nranks; ++r)
+            if (m && !(r == c->rank && send == recv + (size_t) r * bytes)) memcpy(recv + (size_t) r * bytes + off, c->slots + (size_t) r * SLOT_BYTES, m);
+        barrier(c);
+        if (bytes == 0) break;
+    }
+    return 0;
+}
+
+int ncclCommDestroy(void *comm)
+{
+    mock_comm *c = (mock_comm *) comm;
+    if (!c) return 0;
+    barrier(c);
+    munmap((void *) c->h, c->map_bytes);
+    if (c->rank == 0) shm_unlink(c->name);
+    free(c);
+    return 0;
+}

@@ -24,7 +24,16 @@ def main():
         # the product's host drivers over the CPU stand-in for the device layer (oracle/emu_device.c): test-side switch only
         nlopt_amd.LIB_PATH = os.path.join(ROOT, "oracle", "libnlopt_amd_emu.so")
     import _oracle as O
-    comm = nlopt_amd.Comm.from_torch_distributed()
+    if os.environ.get("NLA_TEST_MOCK_RCCL"):
+        # the library's RCCL transport (comm.c: ncclCommInitRank / ncclAllGather on "device" buffers) bound to oracle/libmockrccl.so, which
+        # moves the data through shared memory and checks the collective contract; the unique id travels over the gloo group as the
+        # launcher of a real run would hand it on
+        os.environ["NLA_RCCL_LIBRARY"] = os.path.join(ROOT, "oracle", "libmockrccl.so")
+        uid = [nlopt_amd.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = nlopt_amd.Comm.rccl(rank, world, uid[0])
+    else:
+        comm = nlopt_amd.Comm.from_torch_distributed()
     res = {}
     if case == "comm":
         # partition covers [0, count) exactly once; all-gather returns every rank's block in rank order
@@ -276,6 +285,11 @@ def main():
         res = dict(checked=np.array([checked]))
     else:
         raise SystemExit("unknown case " + case)
+    if os.environ.get("NLA_TEST_MOCK_RCCL"):        # the same library instance comm.c dlopen()ed: how much of the run it carried
+        import ctypes as C
+        st = (C.c_long * 3)()
+        C.CDLL(os.environ["NLA_RCCL_LIBRARY"]).mock_rccl_stats(st)
+        res["rccl_calls"] = np.array(list(st))
     np.savez(out + ".rank%d.npz" % rank, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -17,7 +17,7 @@ def pytest_configure(config):
     if not os.path.exists(lib):
         import nlopt_amd
         nlopt_amd.build()
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port", "emu", "emudev"], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port", "emu", "emudev", "mockrccl"], check=True)
     if os.path.isdir("/root/reference/src"):
         ref = os.path.join(ROOT, "oracle", "_ref")
         if not os.path.exists(os.path.join(ref, "libnlopt_ref.so")):

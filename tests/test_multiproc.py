@@ -1,11 +1,15 @@
 """world_size-2 tests on CPU (gloo): the collective layer of the multi-GPU runs (nlopt_amd/csrc/comm.c) and the
 product's CRS driver with the initial population produced in rank blocks and all-gathered (over the CPU
 emulation of the device engine — no GPU here; the device version of the same paths is tests/test_gpu_multiproc.py)."""
+import os
+
 import numpy as np
 import pytest
 
 import _oracle as O
 from _mp_launch import run_world
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_comm_partition_and_allgather_world2():
@@ -190,3 +194,80 @@ def test_crs_column_sharded_ranks_leave_together(a):
     assert res[0]["ret"][0] == want and res[1]["ret"][0] == want
     assert res[0]["nevals"][0] == res[1]["nevals"][0] and 400 < res[0]["nevals"][0] < 2000000
     assert np.array_equal(res[0]["x"], res[1]["x"]) and res[0]["minf"][0] == res[1]["minf"][0]
+
+
+# ---- the RCCL transport itself with several ranks: comm.c's ncclAllGather branch over a mock librccl (oracle/mock_rccl.c) -----------
+MOCK = dict(NLA_TEST_EMU_DEVICE="1", NLA_TEST_MOCK_RCCL="1")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case,a", [
+    ("gpu_crs", dict(obj="rastrigin", n=10, pop=100, seed=42, maxeval=1400)),                                   # column-sharded: candidates per pass, initial f in place
+    ("gpu_crs", dict(obj="levy", n=9, pop=0, seed=12345, maxeval=1200, xtol_rel=1e-4)),                         # + whole points gathered for the host (xtol)
+    ("gpu_crs", dict(obj="griewank", n=8, pop=61, seed=7, maxeval=900, params={"amd_shard": 0})),               # replicas: rows and f all-gathered IN PLACE
+    ("gpu_isres", dict(obj="rastrigin", n=12, pop=60, seed=5, maxeval=6 * 60, ncon=2)),                         # f / penalties in place, ranking bits in place, stop agreement (host data)
+    ("gpu_mlsl", dict(obj="ackley", n=6, pop=25, seed=7, maxeval=2500)),                                        # minimisers of a batch, distance minima (host data)
+], ids=["crs_sharded", "crs_sharded_xtol", "crs_replicas_inplace", "isres", "mlsl"])
+def test_rccl_transport_with_several_ranks_over_the_mock(world, case, a):
+    """comm.c's RCCL branch (ncclCommInitRank, ncclAllGather on device buffers incl. the in-place form, host data staged through
+    device buffers) has only ever run with ONE rank on hardware (one GPU per box).  Here it runs with 2-3 ranks: librccl is replaced by
+    a mock that moves the bytes through shared memory and enforces NCCL's contract — same byte count on every rank, same collective
+    order, an overlapping send buffer exactly at recvbuff + rank * count — over the emulated device.  Every rank must reproduce the
+    single-process run."""
+    s = run_world(case, dict(a, sharded=False), world=1, extra_env=EMU)[0]
+    for d in run_world(case, a, world=world, extra_env=MOCK):
+        assert d["ret"][0] == s["ret"][0] and d["nevals"][0] == s["nevals"][0] and d["minf"][0] == s["minf"][0]
+        assert np.array_equal(d["x"], s["x"]) and np.array_equal(d["f"], s["f"]) and np.array_equal(d["row"], s["row"])
+        assert d["after"][0] == s["after"][0]
+        assert d["collectives"][0] >= 2
+        calls, inplace, nbytes = d["rccl_calls"]
+        assert calls == d["collectives"][0] and nbytes > 0, "the run's collectives did not go through ncclAllGather"
+        if case != "gpu_mlsl":
+            assert inplace >= 1                                   # the initial f values (CRS) / f and penalties (ISRES) are gathered in place
+
+
+def _mock_rank(path, uid, rank, world, count, misplace, q):
+    import ctypes as C
+    L = C.CDLL(path)
+    class Uid(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    u = Uid(); C.memmove(C.byref(u), uid, 128)
+    comm = C.c_void_p()
+    assert L.ncclCommInitRank(C.byref(comm), world, u, rank) == 0
+    recv = np.zeros(world * 64, dtype=np.uint8)
+    send = np.full(64, rank + 1, dtype=np.uint8)
+    if misplace:                                         # "in place" at the wrong offset
+        rc = L.ncclAllGather(recv.ctypes.data + ((rank + 1) % world) * count + 1, recv.ctypes.data, count, 1, comm, None)
+    else:
+        rc = L.ncclAllGather(send.ctypes.data, recv.ctypes.data, count, 1, comm, None)
+    q.put((rank, rc, recv[: world * count].tolist()))
+    if rc == 0:
+        L.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("what", ["agree", "counts_differ", "misplaced_in_place"])
+def test_the_mock_rccl_enforces_the_allgather_contract(what):
+    """the checker checks: ranks that agree get every rank's bytes rank-major; ranks that pass different counts, or an overlapping send
+    buffer that is not recvbuff + rank * count, get ncclInvalidUsage (5) instead of silently wrong data"""
+    import ctypes as C
+    import multiprocessing as mp
+    path = os.path.join(ROOT, "oracle", "libmockrccl.so")
+    uid = C.create_string_buffer(128)
+    assert C.CDLL(path).ncclGetUniqueId(uid) == 0
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_mock_rank, args=(path, uid.raw, r, 2, 8 if (what != "counts_differ" or r == 0) else 16,
+                                               what == "misplaced_in_place", q)) for r in range(2)]
+    for p in ps: p.start()
+    got = sorted(q.get(timeout=60) for _ in ps)
+    for p in ps: p.join(30)
+    if what == "agree":
+        assert [g[1] for g in got] == [0, 0] and got[0][2] == got[1][2] == [1] * 8 + [2] * 8
+    else:
+        assert all(g[1] == 5 for g in got)
+    try:
+        os.unlink("/dev/shm" + uid.value.decode())
+    except OSError:
+        pass
