@@ -74,6 +74,8 @@ int nlopt_amd_rccl_unique_id(void *id128)
     return 0;
 }
 
+static int need_dev(nlopt_amd_comm *c, size_t bytes);
+
 nlopt_amd_comm *nlopt_amd_comm_create_rccl(int rank, int world, const void *id128)
 {
     nlopt_amd_comm *c;
@@ -84,6 +86,8 @@ nlopt_amd_comm *nlopt_amd_comm_create_rccl(int rank, int world, const void *id12
     c->rank = rank; c->world = world;
     memcpy(&id, id128, sizeof id);
     if (R.init_rank(&c->rccl, world, id, rank) || !c->rccl) { free(c); return NULL; }
+    if (need_dev(c, 64)) c->err[0] = 0;         /* staging for the small exchanges (ready / stop agreement) now, while there is memory: a rank
+                                                 * that later runs out must still be able to say so (nla_comm_agree_ready); grown on demand */
     return c;
 }
 
@@ -222,6 +226,66 @@ const nla_stopping *nla_comm_agree_stop(nlopt_amd_comm *c, const nla_stopping *s
     free(all);
     nla_stop_view(stop, forced, timed, view, force_store);
     return view;
+}
+
+/* Multi-rank runs: a rank whose set-up failed (out of device memory, no device visible) must not leave its peers waiting in the
+ * run's first collective — they would wait for ever.  So set-up ends with one small exchange: every rank says whether it is ready,
+ * and all of them go on only if all are.  Returns `ok` for a single process, otherwise 1 iff every rank reported ok (0 also when the
+ * exchange itself failed). */
+int nla_comm_agree_ready(nlopt_amd_comm *c, int ok) { return nla_comm_agree_same(c, ok, 0) > 0; }
+
+/* The same exchange carrying a fingerprint of what this rank was asked to do (nla_problem_fingerprint): one job over several
+ * ranks means the identical problem, stopping criteria and generator state on every rank — ranks seeded differently would take
+ * different decisions and pass each other in the collectives (a hang, or worse, a result).  Returns 1 = all ready and the same,
+ * 0 = some rank is not ready (or the exchange failed), -1 = all ready but the fingerprints differ. */
+int nla_comm_agree_same(nlopt_amd_comm *c, int ok, uint64_t fingerprint)
+{
+    uint64_t stack[2 * 128], *all = stack, mine[2];
+    int r, res = 1;
+    const int world = nlopt_amd_comm_world(c);
+    if (world <= 1) return ok ? 1 : 0;
+    mine[0] = ok ? 1 : 0; mine[1] = fingerprint;
+    if (world > 128 && !(all = (uint64_t *) malloc(sizeof mine * (size_t) world))) return 0;
+    if (nla_comm_allgather_host(c, mine, all, sizeof mine, NULL)) res = 0;
+    else {
+        for (r = 0; r < world; ++r) if (!all[2 * r]) res = 0;
+        for (r = 0; r < world && res == 1; ++r) if (all[2 * r + 1] != fingerprint) res = -1;
+    }
+    if (all != stack) free(all);
+    return res;
+}
+
+/* what must be identical on every rank of one job: algorithm, dimension, population, objective, box, starting point, the stopping
+ * criteria every rank tests on its own (NOT maxtime / force_stop: those are agreed collectively while the run goes on) and the
+ * calling thread's MT19937 state (FNV-1a over the bytes) */
+static uint64_t fnv(uint64_t h, const void *p, size_t bytes)
+{
+    const unsigned char *b = (const unsigned char *) p;
+    while (bytes--) { h ^= *b++; h *= 1099511628211ULL; }
+    return h;
+}
+uint64_t nla_problem_fingerprint(int algorithm, int n, int population, int obj, const double *lb, const double *ub, const double *x,
+                                 const nla_stopping *stop)
+{
+    uint64_t h = 14695981039346656037ULL;
+    uint32_t mt[NLA_MT_N];
+    int head[5], pos = 0;
+    head[0] = algorithm; head[1] = n; head[2] = population; head[3] = obj; head[4] = stop ? stop->maxeval : 0;
+    h = fnv(h, head, sizeof head);
+    if (lb) h = fnv(h, lb, sizeof(double) * (size_t) n);
+    if (ub) h = fnv(h, ub, sizeof(double) * (size_t) n);
+    if (x) h = fnv(h, x, sizeof(double) * (size_t) n);
+    if (stop) {
+        double t[4];
+        t[0] = stop->minf_max; t[1] = stop->ftol_rel; t[2] = stop->ftol_abs; t[3] = stop->xtol_rel;
+        h = fnv(h, t, sizeof t);
+        if (stop->xtol_abs) h = fnv(h, stop->xtol_abs, sizeof(double) * (size_t) n);
+        if (stop->x_weights) h = fnv(h, stop->x_weights, sizeof(double) * (size_t) n);
+    }
+    nla_mt_export(mt, &pos);
+    h = fnv(h, mt, sizeof mt);
+    h = fnv(h, &pos, sizeof pos);
+    return h ? h : 1;
 }
 
 /* *stop with its two per-process conditions replaced by agreed verdicts */

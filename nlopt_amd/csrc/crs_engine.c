@@ -323,15 +323,20 @@ static int op_init_population_sharded(nla_crs_hip_engine *e, const double *x0, d
     double *d_lbf = NULL, *d_ubf = NULL, *d_x0 = NULL;                 /* whole-row bounds and starting guess (evaluation only) */
     const double *lbh = NULL, *ubh = NULL;
     int rc = -1;
-    if (!ev || !ev_ag0 || !ev_ag1 || !h_row) { snprintf(e->err, sizeof e->err, "out of memory (init)"); goto out; }
-    if (e->world > ROWPAD) { snprintf(e->err, sizeof e->err, "more than %d ranks are not supported", ROWPAD); goto out; }
+    if (e->world > ROWPAD) { snprintf(e->err, sizeof e->err, "more than %d ranks are not supported", ROWPAD); goto out; }   /* (the same on every rank) */
     if (rows_per_chunk < 1) rows_per_chunk = 1;
     if (rows_per_chunk > e->N - 1) rows_per_chunk = e->N - 1 > 0 ? e->N - 1 : 1;
     e->d_initwords = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * (size_t) (rows_per_chunk * (int64_t) wpr));
     d_lbf = (double *) nla_dev_malloc(sizeof(double) * (size_t) n);
     d_ubf = (double *) nla_dev_malloc(sizeof(double) * (size_t) n);
     d_x0 = (double *) nla_dev_malloc(sizeof(double) * (size_t) n);
-    if (!e->d_initwords || !d_lbf || !d_ubf || !d_x0) { snprintf(e->err, sizeof e->err, "out of device memory (init)"); goto out; }
+    {   /* all ranks go into the all-gather below, or none (comm.c, nla_comm_agree_ready) */
+        const int mine = ev && ev_ag0 && ev_ag1 && h_row && e->d_initwords && d_lbf && d_ubf && d_x0;
+        if (!nla_comm_agree_ready(e->comm, mine) || !mine) {
+            snprintf(e->err, sizeof e->err, "%s", mine ? "another rank ran out of memory (init)" : "out of memory (init)");
+            goto out;
+        }
+    }
     lbh = e->h_lb_full; ubh = e->h_ub_full;
     if (nla_memcpy_h2d(d_lbf, lbh, sizeof(double) * (size_t) n, e->main) || nla_memcpy_h2d(d_ubf, ubh, sizeof(double) * (size_t) n, e->main) ||
         nla_memcpy_h2d(d_x0, x0, sizeof(double) * (size_t) n, e->main)) { snprintf(e->err, sizeof e->err, "H2D (init) failed"); goto out; }
@@ -382,9 +387,8 @@ static int op_init_population(void *ve, const double *x0, double *F)
     int64_t rows_per_chunk = (int64_t) (INIT_CHUNK_WORDS / wpr), r0;
     void *ev, *ev_ag0 = NULL, *ev_ag1 = NULL;
     if (e->sharded) return op_init_population_sharded(e, x0, F);
+    if (world > ROWPAD) FAIL(e, "more than %d ranks are not supported", ROWPAD);          /* (the same on every rank) */
     ev = nla_event_create();
-    if (!ev) FAIL(e, "event create failed");
-    if (world > ROWPAD) { nla_event_destroy(ev); FAIL(e, "more than %d ranks are not supported", ROWPAD); }
     if (rows_per_chunk < 1) rows_per_chunk = 1;
     if (rows_per_chunk > per) rows_per_chunk = per;
     if (last > first) {
@@ -393,7 +397,13 @@ static int op_init_population(void *ve, const double *x0, double *F)
             nla_dev_free(e->d_initwords);
             e->d_initwords = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * need);
             e->initwords_cap = e->d_initwords ? need : 0;
-            if (!e->d_initwords) { nla_event_destroy(ev); FAIL(e, "out of device memory (init words)"); }
+        }
+    }
+    {   /* several ranks: all of them go into the all-gathers below, or none (comm.c, nla_comm_agree_ready) */
+        const int mine = ev && (last <= first || e->d_initwords);
+        if (!nla_comm_agree_ready(e->comm, mine) || !mine) {
+            nla_event_destroy(ev);
+            FAIL(e, "%s", mine ? "another rank ran out of memory (init)" : (ev ? "out of device memory (init words)" : "event create failed"));
         }
     }
     /* row 0 = the caller's starting guess (crs.c:204) */
@@ -714,7 +724,7 @@ const nla_crs_engine_ops nla_crs_hip_ops = {
     op_stop_flags_in, op_stop_flags_out
 };
 
-static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub,
+static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, const double *x,
                                     nla_stopping *stop, int population, nla_crs_problem *pb, nla_crs_hip_engine **eout)
 {
     int64_t N = population ? (int64_t) population : 10 * ((int64_t) n + 1);     /* crs.c:172-179 */
@@ -747,6 +757,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
     }
     if (nla_dev_count() <= 0) {
         nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
+        nla_comm_agree_ready(opt ? opt->comm : NULL, 0);
         return NLOPT_FAILURE;
     }
     {
@@ -757,6 +768,16 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
                           (!opt || nlopt_get_param(opt, "amd_shard", 1) != 0);
         if (shard) { pb->forward = 0; pb->comm = comm; }
         *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
+    }
+    /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
+    if (opt && nlopt_amd_comm_world(opt->comm) > 1) {
+        const int all = nla_comm_agree_same(opt->comm, *eout != NULL, nla_problem_fingerprint(NLOPT_GN_CRS2_LM, n, (int) N, pb->obj, lb, ub, x, stop));
+        if (all <= 0 && *eout) {
+            nla_crs_hip_engine_destroy(*eout, 0); *eout = NULL;
+            if (all < 0) { nla_stop_msg(stop, NLA_MSG_RANKS_DIFFER); return NLOPT_INVALID_ARGS; }
+            nla_stop_msg(stop, "nlopt_amd: another rank could not set up its device engine");
+            return NLOPT_FAILURE;
+        }
     }
     if (!*eout) {
         nla_stop_msg(stop, "nlopt_amd: could not create the device engine (out of device memory?)");
@@ -776,7 +797,7 @@ nlopt_result nla_crs_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data, 
     nla_crs_hip_engine *e;
     nlopt_result ret;
     uint64_t words = 0;
-    ret = crs_open_common(opt, n, f, f_data, lb, ub, stop, population, &pb, &e);
+    ret = crs_open_common(opt, n, f, f_data, lb, ub, x, stop, population, &pb, &e);
     if (ret != NLOPT_SUCCESS) return ret;
     ret = nla_crs_run(&nla_crs_hip_ops, e, &pb, x, minf, &words);
     if (pb.stats) pb.stats->mt_words = words;
@@ -811,7 +832,7 @@ nlopt_amd_crs_session *nlopt_amd_crs_open(nlopt_opt opt, double *x, double *minf
     if (ret == NLOPT_SUCCESS) {
         pop = opt->stochastic_population > 0 ? (int) opt->stochastic_population
                                              : (nla_stochastic_population > 0 ? nla_stochastic_population : 0);
-        ret = crs_open_common(opt, (int) opt->n, opt->f, opt->f_data, opt->lb, opt->ub, &h->stop, pop, &h->pb, &h->e);
+        ret = crs_open_common(opt, (int) opt->n, opt->f, opt->f_data, opt->lb, opt->ub, x, &h->stop, pop, &h->pb, &h->e);
     }
     if (ret != NLOPT_SUCCESS) { if (ret_out) *ret_out = ret; free(h); return NULL; }
     h->S = nla_crs_begin(&nla_crs_hip_ops, h->e, &h->pb, x, minf, &ret);

@@ -44,6 +44,10 @@ typedef struct {
     int64_t per, popcap;            /* candidates per rank, per * world >= pop (all-gather wants equal blocks) */
     int bits_two_pass;              /* A/B switch: ranking words through a buffer + isres_bits_kernel instead of the fused kernel */
     void *st, *ev0, *ev1;
+    void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
+    int overlap;                    /* opt-in ("amd_isres_overlap" / NLA_ISRES_OVERLAP=1): generator work beside the latency-bound kernels */
+    int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
+    uint64_t spec_made, spec_used;  /* ... how often, and how often the evolve phase could take them */
     nla_mtstream *mts;
     uint64_t words_used;
     double *d_lb, *d_ub, *d_X, *d_S, *d_F, *d_PEN, *d_GPEN, *d_scratch, *d_z;
@@ -71,6 +75,7 @@ typedef struct {
 static void dev_free_all(isres_dev *d)
 {
     if (d->st) nla_stream_sync(d->st);
+    if (d->rs) nla_stream_sync(d->rs);
     if (d->mts) { nla_mtstream_finish(d->mts, d->words_used); nla_mtstream_destroy(d->mts); }
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_X); nla_dev_free(d->d_S); nla_dev_free(d->d_F);
     nla_dev_free(d->d_PEN); nla_dev_free(d->d_GPEN); nla_dev_free(d->d_scratch); nla_dev_free(d->d_z); nla_dev_free(d->d_FEAS);
@@ -81,6 +86,7 @@ static void dev_free_all(isres_dev *d)
     nla_host_free(d->h_F); nla_host_free(d->h_PEN); nla_host_free(d->h_GPEN); nla_host_free(d->h_X); nla_host_free(d->h_FEAS);
     nla_host_free(d->h_swapped); nla_host_free(d->h_progress);
     nla_event_destroy(d->ev0); nla_event_destroy(d->ev1);
+    if (d->rs && d->rs != d->st) nla_stream_destroy(d->rs);
     if (d->st) nla_stream_destroy(d->st);
 }
 
@@ -106,7 +112,18 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     { const char *e = getenv("NLA_ISRES_BITS_TWO_PASS"); d->bits_two_pass = e && atoi(e) > 0; }
     d->ev0 = nla_event_create(); d->ev1 = nla_event_create();      /* device time of the ranking kernel for the stats */
     if (!d->st || !d->ev0 || !d->ev1) return -1;
-    d->mts = nla_mtstream_create(d->st);
+    /* OVERLAP (opt-in until it has been measured): the generator — segment-state jumps, ranking bits, the evolve phase's deviates —
+     * works on a stream of its own, beside the kernels of the generation that are bound by latency, not by throughput:
+     *   rank counting (196 workgroups)            ||  the ranking's jumps + words -> bits
+     *   the ranking pipeline (782 lone wavefronts) ||  the deviates of the evolve phase, generated AHEAD at the stream position the
+     *                                                  ranking will leave if it takes all pop sweeps (it does unless a sweep swaps
+     *                                                  nothing, isres.c:227; otherwise they are thrown away and generated again)
+     *   the evolve rounds (serial look-up chains)  ||  the segment states the NEXT ranking's words start from
+     * Every hand-over between the two streams is a host synchronisation of the producing stream (the driver synchronises at these
+     * points anyway): nothing is ordered by events, and with overlap off rs IS st — the default path is the one-stream code. */
+    d->rs = d->overlap ? nla_stream_create() : d->st;
+    if (!d->rs) return -1;
+    d->mts = nla_mtstream_create(d->rs);
     if (!d->mts) return -1;
 #define A(ptr, T, count) do { d->ptr = (T *) nla_dev_malloc(sizeof(T) * (size_t) (count)); if (!d->ptr) ok = 0; } while (0)
     A(d_lb, double, ld); A(d_ub, double, ld); A(d_X, double, pop * ld); A(d_S, double, pop * ld);
@@ -145,18 +162,20 @@ static int dev_init_population(isres_dev *d, const double *x0)
     const uint64_t wpi = 2ULL * (uint64_t) d->n;
     int64_t per = (int64_t) (d->wchunk / wpi), k0;
     if (per < 1) DFAIL(d, "dimension too large for the word buffer");
-    DCK(d, nla_memcpy_h2d(d->d_scratch, x0, sizeof(double) * (size_t) d->n, d->st));
+    DCK(d, nla_memcpy_h2d(d->d_scratch, x0, sizeof(double) * (size_t) d->n, d->rs));
     for (k0 = 0; k0 < d->pop; k0 += per) {
         const int64_t cnt = d->pop - k0 < per ? d->pop - k0 : per;
         if (nla_mtstream_fill(d->mts, d->words_used + wpi * (uint64_t) k0, wpi * (uint64_t) cnt, d->d_words)) DFAIL(d, "MT stream fill failed");
-        DCK(d, nla_k_isres_init(d->n, d->ld, d->d_lb, d->d_ub, d->d_words, k0, cnt, d->d_scratch, d->d_X, d->d_S, d->st));
-        DCK(d, nla_stream_sync(d->st));
+        DCK(d, nla_k_isres_init(d->n, d->ld, d->d_lb, d->d_ub, d->d_words, k0, cnt, d->d_scratch, d->d_X, d->d_S, d->rs));
+        DCK(d, nla_stream_sync(d->rs));
     }
     d->words_used += wpi * (uint64_t) d->pop;
     return 0;
 }
 
 /* selection (isres.c:202-229); *sweeps_out = ranking sweeps actually taken (0 on the sort path) */
+static int dev_more_deviates(isres_dev *d, uint64_t phase_word0, int64_t *attempts_done, int64_t nattempts, int64_t *zcount);
+
 static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double *t_rng, nlopt_amd_stats *st)
 {
     const int64_t pop = d->pop, popm1 = pop - 1;
@@ -181,7 +200,7 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
             /* words -> bits in one kernel, all of this rank's sweeps in one launch (hip/mt_kernels.hip, mt_rankbits_kernel):
              * the words are never written to memory */
             if (last > first) {
-                DCK(d, nla_memset(d->d_bits + (size_t) first * (size_t) d->rowwords, 0, sizeof(uint64_t) * (size_t) (last - first) * (size_t) d->rowwords, d->st));
+                DCK(d, nla_memset(d->d_bits + (size_t) first * (size_t) d->rowwords, 0, sizeof(uint64_t) * (size_t) (last - first) * (size_t) d->rowwords, d->rs));
                 if (nla_mtstream_rankbits(d->mts, d->words_used, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) first,
                                           2ULL * (uint64_t) popm1 * (uint64_t) (last - first), popm1, d->rowwords, d->d_bits))
                     DFAIL(d, "MT stream ranking bits failed");
@@ -191,14 +210,16 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
             const int64_t nr = last - r0 < rows_per ? last - r0 : rows_per;
             if (nla_mtstream_fill(d->mts, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) r0, 2ULL * (uint64_t) popm1 * (uint64_t) nr, d->d_words))
                 DFAIL(d, "MT stream fill failed");
-            DCK(d, nla_k_isres_bits(d->d_words, r0, (int) nr, pop, d->d_bits, d->st));
+            DCK(d, nla_k_isres_bits(d->d_words, r0, (int) nr, pop, d->d_bits, d->rs));
         }
         if (world > 1 && nla_comm_allgather_dev(d->comm, d->d_bits + (size_t) (d->per * rank) * (size_t) d->rowwords, d->d_bits,
-                                                sizeof(uint64_t) * (size_t) d->per * (size_t) d->rowwords, d->st))
+                                                sizeof(uint64_t) * (size_t) d->per * (size_t) d->rowwords, d->rs))
             DFAIL(d, "all-gather of the ranking bits failed: %s", nlopt_amd_comm_error(d->comm));
     }
-    DCK(d, nla_stream_sync(d->st));
+    DCK(d, nla_stream_sync(d->rs));                /* the bits are there ... */
+    if (d->rs != d->st) DCK(d, nla_stream_sync(d->st));      /* ... and so are the packed elements (rank counting ran beside them) */
     *t_rng += nla_seconds() - t0;
+    d->spec_valid = 0;
     for (;;) {
         DCK(d, nla_memcpy_h2d(d->d_progress, d->h_progress, sizeof(int) * (size_t) (d->units + 1), d->st));
         DCK(d, nla_memset(d->d_ticket, 0, sizeof(int), d->st));
@@ -206,6 +227,17 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         DCK(d, nla_k_isres_stochrank(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank, d->st));
         if (d->ev1) nla_event_record(d->ev1, d->st);
         DCK(d, nla_memcpy_d2h(d->h_swapped, d->d_swapped, (size_t) nsweeps, d->st));
+        if (d->overlap && nsweeps == pop && !d->spec_valid) {
+            /* while the pipeline runs: the evolve phase's deviates from where the stream will stand after pop sweeps */
+            const int64_t expect = d->pop * (1 + 2 * (int64_t) d->n);
+            const double t1 = nla_seconds();
+            d->spec_word0 = d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) pop;
+            d->spec_attempts = 0; d->spec_zcount = 0;
+            DCK(d, nla_memset(d->d_ztotal, 0, sizeof(int64_t), d->rs));
+            if (dev_more_deviates(d, d->spec_word0, &d->spec_attempts, (int64_t) (1.35 * (double) expect / 0.785) + 4096, &d->spec_zcount)) return -1;
+            d->spec_valid = 1; ++d->spec_made;
+            *t_rng += nla_seconds() - t1;
+        }
         DCK(d, nla_stream_sync(d->st));
         if (st && d->ev0 && d->ev1) {
             const float ms = nla_event_elapsed_ms(d->ev0, d->ev1);
@@ -219,6 +251,7 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
     }
     *sweeps_out = nsweeps;
     d->words_used += 2ULL * (uint64_t) popm1 * (uint64_t) nsweeps;
+    if (d->spec_valid && d->spec_word0 != d->words_used) d->spec_valid = 0;     /* the ranking stopped early: those were the wrong words */
     return 0;
 }
 
@@ -281,9 +314,9 @@ static int dev_more_deviates(isres_dev *d, uint64_t phase_word0, int64_t *attemp
         if (*zcount + a > d->zcap) a = d->zcap - *zcount;
         if (a <= 0) DFAIL(d, "deviate buffer exhausted");
         if (nla_mtstream_fill(d->mts, phase_word0 + 4ULL * (uint64_t) *attempts_done, 4ULL * (uint64_t) a, d->d_words)) DFAIL(d, "MT stream fill failed");
-        DCK(d, nla_k_isres_nrand(d->d_words, a, *attempts_done, d->d_counts, d->d_ztotal, *zcount, d->d_z, d->d_zatt, d->st));
-        DCK(d, nla_memcpy_d2h(&zt, d->d_ztotal, sizeof zt, d->st));
-        DCK(d, nla_stream_sync(d->st));
+        DCK(d, nla_k_isres_nrand(d->d_words, a, *attempts_done, d->d_counts, d->d_ztotal, *zcount, d->d_z, d->d_zatt, d->rs));
+        DCK(d, nla_memcpy_d2h(&zt, d->d_ztotal, sizeof zt, d->rs));
+        DCK(d, nla_stream_sync(d->rs));
         *zcount = zt;
         *attempts_done += a;
         nattempts -= a;
@@ -298,9 +331,14 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
     const int64_t expect = d->pop * (1 + 2 * (int64_t) d->n);
     int64_t attempts_done = 0, zcount = 0, state[16] = { 0 }, last_att;
     double t0 = nla_seconds();
-    int phase;
-    DCK(d, nla_memset(d->d_ztotal, 0, sizeof(int64_t), d->st));
-    if (dev_more_deviates(d, word0, &attempts_done, (int64_t) (1.35 * (double) expect / 0.785) + 4096, &zcount)) return -1;
+    int phase, reserved = 0;
+    if (d->spec_valid && d->spec_word0 == word0) {             /* generated beside the ranking pipeline (overlap) */
+        attempts_done = d->spec_attempts; zcount = d->spec_zcount; ++d->spec_used;
+    } else {
+        DCK(d, nla_memset(d->d_ztotal, 0, sizeof(int64_t), d->rs));
+        if (dev_more_deviates(d, word0, &attempts_done, (int64_t) (1.35 * (double) expect / 0.785) + 4096, &zcount)) return -1;
+    }
+    d->spec_valid = 0;
     *t_rng += nla_seconds() - t0;
     if (d->parallel_evolve) DCK(d, nla_k_isres_inverse(d->pop, d->d_irank, d->d_inv, d->st));
     for (phase = 0; phase < 2; ++phase) {
@@ -320,6 +358,13 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
                 DCK(d, nla_k_isres_evolve_rounds(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z,
                                                  d->d_irank, d->d_inv, d->d_X, d->d_S, d->d_scratch, d->d_state, d->d_rho, d->d_ws, rounds, d->st));
                 d->ev_rounds += (uint64_t) rounds;
+                if (d->overlap && !reserved) {
+                    /* beside the rounds: the segment states behind the NEXT ranking's words (those of this phase's deviates generated
+                     * so far + pop sweeps: a little more than it will need) */
+                    reserved = 1;
+                    if (d->pop > 1 && nla_mtstream_reserve(d->mts, word0 + 4ULL * (uint64_t) attempts_done + 2ULL * (uint64_t) (d->pop - 1) * (uint64_t) d->pop))
+                        DFAIL(d, "MT stream reserve failed");
+                }
             } else
                 DCK(d, nla_k_isres_evolve(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z, d->d_irank,
                                           d->d_X, d->d_S, d->d_scratch, d->d_state, d->st));
@@ -348,7 +393,7 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
             if (!d->parallel_evolve || state[0] >= kend) break;
         }
     }
-    if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve2: rounds enqueued %llu, serial fallbacks %llu\n", (unsigned long long) d->ev_rounds, (unsigned long long) d->ev_fallbacks);
+    if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve2: rounds enqueued %llu, serial fallbacks %llu; overlap %d: deviates generated ahead %llu times, used %llu times\n", (unsigned long long) d->ev_rounds, (unsigned long long) d->ev_fallbacks, d->overlap, (unsigned long long) d->spec_made, (unsigned long long) d->spec_used);
     if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve: fixpoint rounds %lld for %lld individuals, deviates %lld; cycles stage %lld eval %lld scan %lld fin %lld all %lld\n", (long long) state[3], (long long) d->pop, (long long) state[1], (long long) state[4], (long long) state[5], (long long) state[6], (long long) state[7], (long long) state[8]);
     if (state[1] <= 0) DFAIL(d, "evolve consumed no deviates");
     DCK(d, nla_memcpy_d2h(&last_att, d->d_zatt + (state[1] - 1), sizeof last_att, d->st));
@@ -403,6 +448,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         if (nla_isinf(lb[j]) || nla_isinf(ub[j])) { nla_stop_msg(stop, "isres requires a finite search region"); return NLOPT_INVALID_ARGS; }
     if (nla_dev_count() <= 0) {
         nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
+        nla_comm_agree_ready(opt ? opt->comm : NULL, 0);
         return NLOPT_FAILURE;
     }
     if (population > (1 << 20)) { nla_stop_msg(stop, "nlopt_amd: ISRES populations above 2^20 are not supported"); return NLOPT_INVALID_ARGS; }
@@ -413,7 +459,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     D.obj = D.ev.kind == NLA_EVAL_DEVICE ? D.ev.obj : -1;
     dev_eval = D.ev.kind != NLA_EVAL_HOST && !(opt && nlopt_get_param(opt, "amd_host_eval", 0) != 0);
     con = (nla_dev_constraint *) calloc((size_t) (m + p + 1), sizeof *con);
-    if (!con) { nla_stop_msg(stop, "nlopt_amd: out of memory"); return NLOPT_OUT_OF_MEMORY; }
+    if (!con) { nla_stop_msg(stop, "nlopt_amd: out of memory"); nla_comm_agree_ready(opt ? opt->comm : NULL, 0); return NLOPT_OUT_OF_MEMORY; }
     for (c = 0; c < m + p; ++c) {
         const nla_constraint *cc = c < m ? fc + c : h + (c - m);
         if (cc->m > maxdim) maxdim = cc->m;
@@ -423,15 +469,23 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         } else dev_eval = 0;
     }
     results = (double *) malloc(sizeof(double) * maxdim);
-    if (!results) { nla_stop_msg(stop, "nlopt_amd: out of memory"); free(con); return NLOPT_OUT_OF_MEMORY; }
+    if (!results) { nla_stop_msg(stop, "nlopt_amd: out of memory"); free(con); nla_comm_agree_ready(opt ? opt->comm : NULL, 0); return NLOPT_OUT_OF_MEMORY; }
 
     D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
     D.comm = opt ? opt->comm : NULL;
+    D.overlap = (opt && nlopt_get_param(opt, "amd_isres_overlap", 0) != 0) || (getenv("NLA_ISRES_OVERLAP") && atoi(getenv("NLA_ISRES_OVERLAP")) > 0);
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */
-    if (dev_alloc(&D, lb, ub, con)) {
-        nla_stop_msg(stop, "nlopt_amd: could not create the ISRES device state (out of device memory?)");
-        dev_free_all(&D); free(con); free(results);
-        return NLOPT_OUT_OF_MEMORY;
+    {   /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
+        const int mine = dev_alloc(&D, lb, ub, con) == 0;
+        const int all = nlopt_amd_comm_world(D.comm) > 1
+            ? nla_comm_agree_same(D.comm, mine, nla_problem_fingerprint(NLOPT_GN_ISRES, n, population, D.obj + 100 * (m + p), lb, ub, x, stop)) : mine;
+        if (all <= 0 || !mine) {
+            if (!mine) nla_stop_msg(stop, "nlopt_amd: could not create the ISRES device state (out of device memory?)");
+            else if (all < 0) nla_stop_msg(stop, NLA_MSG_RANKS_DIFFER);
+            else nla_stop_msg(stop, "nlopt_amd: another rank could not set up its ISRES device state");
+            dev_free_all(&D); free(con); free(results);
+            return !mine ? NLOPT_OUT_OF_MEMORY : (all < 0 ? NLOPT_INVALID_ARGS : NLOPT_FAILURE);
+        }
     }
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
     if (dev_init_population(&D, x)) DEVFAIL();

@@ -246,7 +246,11 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         nla_stop_msg(stop, "%s", local_opt->errmsg ? local_opt->errmsg : "invalid LD_MMA parameter");
         return (nlopt_result) i;
     }
-    if (nla_dev_count() <= 0) { nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)"); return NLOPT_FAILURE; }
+    if (nla_dev_count() <= 0) {
+        nla_stop_msg(stop, "nlopt_amd: no HIP device visible (this library has no CPU fallback)");
+        nla_comm_agree_ready((opt && !use_cobyla) ? opt->comm : NULL, 0);
+        return NLOPT_FAILURE;
+    }
     nla_evaluator_resolve(&D.ev, opt, f, f_data);
     D.obj = D.ev.kind == NLA_EVAL_DEVICE ? D.ev.obj : -1;
     host = D.ev.kind == NLA_EVAL_HOST || use_cobyla;
@@ -272,7 +276,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     mf = nla_lbfgs_default_mf(n, (int) local_opt->vector_storage, 0);
 
     D.st = nla_stream_create();
-    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); mfree(&D); return NLOPT_OUT_OF_MEMORY; }
+    /* several ranks: set-up ends with an exchange of "ready" (comm.c, nla_comm_agree_ready) — a rank that fails below says so there
+     * instead of leaving the others in the run's first collective */
+    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); nla_comm_agree_ready(D.comm, 0); mfree(&D); return NLOPT_OUT_OF_MEMORY; }
     D.d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (size_t) D.N);
@@ -291,6 +297,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
+        nla_comm_agree_ready(D.comm, 0);
         mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
         return NLOPT_OUT_OF_MEMORY;
     }
@@ -300,6 +307,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             D.d_V = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 32 * (size_t) n);
             if (!D.d_V || nla_memcpy_h2d(D.d_V, V, sizeof(uint32_t) * 32 * (size_t) n, D.st) || nla_stream_sync(D.st)) {
                 nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
+                nla_comm_agree_ready(D.comm, 0);
                 free(V); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
                 return NLOPT_OUT_OF_MEMORY;
             }
@@ -311,6 +319,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         D.d_dx = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
         if (!D.d_dx || nla_memcpy_h2d(D.d_dx, local_opt->dx, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) {
             nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
+            nla_comm_agree_ready(D.comm, 0);
             mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
             return NLOPT_OUT_OF_MEMORY;
         }
@@ -332,8 +341,13 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
                    : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);
     if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode_for(opt, local_opt, &D.ev), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
-    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
+    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); nla_comm_agree_ready(D.comm, 0); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_local_ctx_set_stats(D.lb, st);
+    }
+    if (D.world > 1) {
+        const int all = nla_comm_agree_same(D.comm, 1, nla_problem_fingerprint(lds ? NLOPT_G_MLSL_LDS : NLOPT_G_MLSL, n, D.N, D.obj + 100 * (int) local_opt->algorithm, lb, ub, x, stop));
+        if (all < 0) { nla_stop_msg(stop, NLA_MSG_RANKS_DIFFER); ret = NLOPT_INVALID_ARGS; goto done; }
+        if (all == 0) { nla_stop_msg(stop, "nlopt_amd: another rank could not set up its MLSL device state"); ret = NLOPT_FAILURE; goto done; }
     }
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)

@@ -114,6 +114,13 @@ int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint3
                              g_first, count, d_out, s->stream);
 }
 
+/* build the segment states up to stream word rel_last (relative to the run's first word) now — asynchronously on the generator's
+ * stream — so that a later fill / rankbits up to there finds them ready (ISRES overlap mode: beside the evolve rounds) */
+int nla_mtstream_reserve(nla_mtstream *s, uint64_t rel_last)
+{
+    return ensure_states(s, ((uint64_t) s->base_consumed + rel_last) / NLA_MT_SEG_WORDS);
+}
+
 /* the ranking bits of stream words [rel_first, rel_first + count) (relative to the run's first word, as nla_mtstream_fill),
  * rel_rank0 = the ranking's first word: see nla_k_mt_rankbits */
 int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *d_bits)

@@ -125,6 +125,11 @@ int nla_comm_allgather_dev(nlopt_amd_comm *c, const void *d_send, void *d_recv, 
 int nla_comm_allgather_host(nlopt_amd_comm *c, const void *h_send, void *h_recv, size_t bytes, void *stream);
 void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, int64_t *first, int64_t *mine);
 void nla_stop_view(const nla_stopping *stop, int forced, int timed, nla_stopping *view, int *force_store);
+int nla_comm_agree_ready(nlopt_amd_comm *c, int ok);      /* end of a multi-rank set-up: 1 iff every rank is ready */
+int nla_comm_agree_same(nlopt_amd_comm *c, int ok, uint64_t fingerprint);   /* 1 ready and identical jobs, 0 some rank not ready, -1 ranks were given different jobs */
+uint64_t nla_problem_fingerprint(int algorithm, int n, int population, int obj, const double *lb, const double *ub, const double *x,
+                                 const nla_stopping *stop);
+#define NLA_MSG_RANKS_DIFFER "nlopt_amd: the ranks of this communicator were given different problems (dimension, population, bounds, starting point, stopping criteria or nlopt_srand seed): one job needs them identical"
 const nla_stopping *nla_comm_agree_stop(nlopt_amd_comm *c, const nla_stopping *stop, nla_stopping *view, int *force_store);
 
 /* ---- MT19937 host side (mt_host.c) ------------------------------------------------------------ */
@@ -153,6 +158,7 @@ uint64_t nla_mtstream_origin(const nla_mtstream *s); /* global index of the firs
 /* out[i] = stream word (origin + rel_first + i), i < count; device pointer, async on `stream` */
 int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint32_t *d_out);
 int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *d_bits);
+int nla_mtstream_reserve(nla_mtstream *s, uint64_t rel_last);
 /* leave the calling thread's generator as if it had drawn `consumed` words since create */
 int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed);
 

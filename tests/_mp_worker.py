@@ -108,8 +108,12 @@ def main():
         if args.get("xtol_rel"):
             o.set_xtol_rel(args["xtol_rel"])
         o.enable_trace(args["maxeval"] + 4096)
-        nlopt_amd.srand(seed)
+        nlopt_amd.srand(seed + (rank if args.get("seed_by_rank") else 0))     # seed_by_rank: the user's mistake of seeding the ranks differently
+        if args.get("x0_by_rank"):
+            xs = list(np.array(xs, dtype=float) + 1e-3 * rank)
         x, minf, ret = o.optimize_raw(xs)
+        if args.get("want_errmsg"):
+            res_msg = o.get_errmsg() or ""
         if args.get("twice"):                        # the same object again, generator continuing: a second, different run
             first_run = (x.copy(), minf, ret, o.get_numevals())
             x, minf, ret = o.optimize_raw(xs)
@@ -121,6 +125,67 @@ def main():
                    stats_allgather_bytes=np.array([o.stats()["allgather_bytes"]], dtype=np.uint64), rounds=np.array([o.stats()["rounds"]]))
         if args.get("twice"):
             res.update(res_first)
+        if args.get("want_errmsg"):
+            res["errmsg"] = np.array(res_msg)
+    elif case == "fault_setup":
+        # one rank's set-up fails (an allocation of the run's set-up phase, each in turn): every rank must come back with an error — none
+        # may be left waiting in a collective — and the communicator must still serve the next, clean run
+        import ctypes as C
+        import torch
+        L = nlopt_amd.lib()
+        L.orc_emu_fail_alloc_at.argtypes = [C.c_long]
+        L.orc_emu_allocs.restype = C.c_long
+        seen = []                                    # (payload bytes, allocations so far) of every collective of the current run
+
+        def allgather(b):
+            seen.append((len(b), L.orc_emu_allocs()))
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+            out = torch.empty(world * t.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, t)
+            return out.numpy().tobytes()
+        comm = nlopt_amd.Comm.host(rank, world, allgather)
+        alg, n, fail_rank = args["alg"], args["n"], args["fail_rank"]
+        xs, lo, hi = O.golden_x0("rastrigin", n)
+
+        def run(fail_at):
+            a = {"crs": nlopt_amd.GN_CRS2_LM, "crs_replicas": nlopt_amd.GN_CRS2_LM, "isres": nlopt_amd.GN_ISRES, "mlsl": nlopt_amd.G_MLSL_LDS}[alg]
+            o = nlopt_amd.Opt(a, n)
+            o.set_lower_bounds(lo); o.set_upper_bounds(hi); o.set_min_objective(nlopt_amd.objective("rastrigin"))
+            o.set_maxeval(args["maxeval"]); o.set_population(args["pop"])
+            if alg == "crs_replicas":
+                o.set_param("amd_shard", 0)
+            if alg == "isres":
+                o.add_blocksum_constraints(2, 1e-8)
+            if alg == "mlsl":
+                loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, n)
+                loc.set_ftol_rel(1e-6)
+                L.nlopt_set_local_optimizer(o._h, loc._h)
+            o.set_comm(comm)
+            nlopt_amd.srand(args["seed"])
+            del seen[:]
+            L.orc_emu_fail_alloc_at(fail_at if rank == fail_rank else 0)
+            x, minf, ret = o.optimize_raw(xs)
+            L.orc_emu_fail_alloc_at(0)
+            return ret, minf, np.array(x), o.get_numevals(), o.get_errmsg() or ""
+        import gc
+        L.orc_emu_live.restype = C.c_long
+        base = run(0)
+        gc.collect()
+        live0 = L.orc_emu_live()                     # (the communicator's own staging buffers live as long as it does)
+        # the allocations of the failing rank's set-up = those made before the last "ready" exchange (16-byte payload, comm.c)
+        ready = [al for (nb, al) in seen if nb == 16]
+        nset = [ready[-1] if ready else 0]
+        dist.broadcast_object_list(nset, src=fail_rank)
+        rets, msgs = [], []
+        for k in range(1, nset[0] + 1):
+            r = run(k)
+            rets.append(r[0]); msgs.append(r[4])
+        again = run(0)
+        gc.collect()
+        res_live = L.orc_emu_live() - live0          # device-layer objects the failed set-ups left behind
+        res = dict(live=np.array([res_live]), base_ret=np.array([base[0]]), base_minf=np.array([base[1]]), base_x=base[2], base_nevals=np.array([base[3]]),
+                   nset=np.array(nset), nready=np.array([len(ready)]), rets=np.array(rets), msgs=np.array(msgs),
+                   again_ret=np.array([again[0]]), again_minf=np.array([again[1]]), again_x=again[2], again_nevals=np.array([again[3]]))
     elif case == "gpu_crs_rate":
         # tools/shard_probe.py: the trial-phase rate of one CRS2_LM job (population initialisation untimed), as bench.py measures it
         import ctypes as C

@@ -45,7 +45,7 @@ def test_crs_driver_sharded_init_world2_matches_oracle(obj, n, pop, seed, maxeva
         assert d["ret"][0] == p["ret"] and d["nevals"][0] == p["nevals"] and d["words"][0] == p["words"]
         assert np.array_equal(d["row"], p["trace"]["row"]) and np.array_equal(d["accepted"], p["trace"]["accepted"])
         assert np.array_equal(d["f"], p["trace"]["f"]) and np.array_equal(d["x"], p["x"]) and d["minf"][0] == p["minf"]
-        assert d["collectives"][0] == 2         # rows + f, once
+        assert d["collectives"][0] == 2         # rows + f, once (the engine emulation of oracle/port_emu_engine.c has no set-up exchange)
 
 
 # ---- the product's ISRES / MLSL host drivers over the CPU stand-in for the device layer (oracle/emu_device.c) -------------------
@@ -71,7 +71,8 @@ def test_isres_driver_over_emulated_device_matches_oracle(world, obj, n, pop, se
         assert np.array_equal(d["f"], p["ftrace"][:len(d["f"])]) and len(d["f"]) == len(p["ftrace"])
         if world > 1:
             # + one all-gather of the ranking bits in every generation that ranks stochastically (some infeasible individual)
-            assert 5 * gens <= d["collectives"][0] <= 6 * gens and (ncon > 0 or d["collectives"][0] == 5 * gens)
+            c = d["collectives"][0] - 1            # (the set-up's "ready" exchange)
+            assert 5 * gens <= c <= 6 * gens and (ncon > 0 or c == 5 * gens)
 
 
 @pytest.mark.parametrize("world", [1, 2])
@@ -142,7 +143,7 @@ def test_crs_column_sharding_can_be_switched_off_and_falls_back_to_replicas():
     p = O.run_port_crs("rastrigin", 10, 100, 42, maxeval=700, trace_cap=5000)
     for d in res:
         assert np.array_equal(d["f"], p["trace"]["f"]) and np.array_equal(d["x"], p["x"])
-        assert d["collectives"][0] == 2           # the row-sharded initialisation only: rows + values
+        assert d["collectives"][0] == 4           # the row-sharded initialisation only: rows + values (+ the set-up's two "ready" exchanges)
     # n < world columns cannot be dealt: replicas as well
     res = run_world("gpu_crs", dict(obj="sphere", n=2, pop=20, seed=1, maxeval=300), world=3, extra_env=EMU)
     p = O.run_port_crs("sphere", 2, 20, 1, maxeval=300, trace_cap=5000)
@@ -271,3 +272,61 @@ def test_the_mock_rccl_enforces_the_allgather_contract(what):
         os.unlink("/dev/shm" + uid.value.decode())
     except OSError:
         pass
+
+
+# ---- one rank's set-up fails: nobody is left waiting ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("alg,world,fail_rank", [("crs", 2, 1), ("crs", 3, 0), ("crs_replicas", 2, 0), ("isres", 2, 1), ("mlsl", 2, 1), ("mlsl", 3, 2)])
+def test_a_rank_whose_setup_fails_takes_the_others_with_it(alg, world, fail_rank):
+    """every device / pinned allocation of ONE rank's set-up is made to fail in turn (emulated device layer).  Without an agreement at the
+    end of set-up the other ranks would enter the run's first all-gather and wait for ever (this test would time out); with it
+    (comm.c, nla_comm_agree_ready) every rank returns an error — the failing one OUT_OF_MEMORY, the others FAILURE naming the reason —
+    and the communicator serves the next run, which equals the first"""
+    a = dict(alg=alg, n=8, pop=40, maxeval=500, seed=3, fail_rank=fail_rank)
+    out = run_world("fault_setup", a, world=world, extra_env=EMU, timeout=600)
+    nset = int(out[0]["nset"][0])
+    assert nset >= 8 and all(int(d["nready"][0]) >= 1 for d in out), (nset, [int(d["nready"][0]) for d in out])
+    for r, d in enumerate(out):
+        assert d["base_ret"][0] > 0 and d["again_ret"][0] == d["base_ret"][0]
+        assert d["again_minf"][0] == d["base_minf"][0] and np.array_equal(d["again_x"], d["base_x"]) and d["again_nevals"][0] == d["base_nevals"][0]
+        assert d["base_minf"][0] == out[0]["base_minf"][0] and np.array_equal(d["base_x"], out[0]["base_x"])
+        assert len(d["rets"]) == nset
+        assert d["live"][0] == 0, "rank %d: %d device-layer objects left behind by the failed set-ups" % (r, d["live"][0])
+    for k in range(nset):
+        rets = [int(d["rets"][k]) for d in out]
+        assert all(x < 0 for x in rets), "allocation %d of rank %d failed: results %r" % (k + 1, fail_rank, rets)
+        assert rets[fail_rank] in (-3, -1)
+        for r, d in enumerate(out):
+            assert str(d["msgs"][k]), (k, r)
+            if r != fail_rank:
+                assert rets[r] == -1 and "another rank" in str(d["msgs"][k]), (k, r, rets, str(d["msgs"][k]))
+
+
+@pytest.mark.parametrize("case,a", [
+    ("gpu_crs", dict(obj="rastrigin", n=10, pop=100, seed=42, maxeval=1400)),
+    ("gpu_crs", dict(obj="rastrigin", n=10, pop=100, seed=42, maxeval=1400, params={"amd_shard": 0})),
+    ("gpu_isres", dict(obj="rastrigin", n=12, pop=60, seed=5, maxeval=360, ncon=2)),
+    ("gpu_mlsl", dict(obj="ackley", n=6, pop=25, seed=7, maxeval=2500)),
+], ids=["crs_sharded", "crs_replicas", "isres", "mlsl"])
+@pytest.mark.parametrize("mistake", ["seed_by_rank", "x0_by_rank"])
+def test_ranks_given_different_jobs_are_told_so(case, a, mistake):
+    """one job over several ranks needs the identical problem and generator state on every rank; ranks seeded differently (the classic
+    mistake: seed = base + rank) or started from different points would take different decisions and pass each other in the
+    collectives.  The set-up's exchange carries a fingerprint of the job: every rank returns NLOPT_INVALID_ARGS and says why."""
+    for d in run_world(case, dict(a, want_errmsg=True, **{mistake: True}), world=2, extra_env=EMU, timeout=120):
+        assert d["ret"][0] == -2 and d["nevals"][0] == 0
+        assert "different problems" in str(d["errmsg"]) and "nlopt_srand" in str(d["errmsg"])
+
+
+@pytest.mark.parametrize("world,env", [(1, {}), (1, {"NLA_EMU_EVOLVE2": "1"}), (2, {"NLA_EMU_EVOLVE2": "1"}), (3, {})])
+@pytest.mark.parametrize("obj,n,pop,seed,ncon,gens", [("rastrigin", 12, 60, 5, 2, 6), ("sphere", 6, 30, 5, 1, 40), ("ackley", 20, 45, 2, 3, 5)])
+def test_isres_overlap_mode_changes_nothing(world, env, obj, n, pop, seed, ncon, gens):
+    """ISRES with "amd_isres_overlap" = 1 (opt-in, isres_driver.c): the generator works on a second stream — ranking bits beside the
+    rank counting, the evolve phase's deviates generated AHEAD beside the ranking pipeline (thrown away when the ranking stops
+    early: the sphere case does, late in its run), the next ranking's segment states beside the evolve rounds.  The bookkeeping
+    (stream positions of the speculation, what is reused and what is redone) must leave every candidate, the result and the
+    generator where the oracle has them.  (The emulated device is synchronous: what this cannot see is a missing synchronisation.)"""
+    a = dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=gens * pop, ncon=ncon, params={"amd_isres_overlap": 1})
+    p = O.run_port_isres(obj, n, pop, seed, nineq=ncon, maxeval=gens * pop)
+    for d in run_world("gpu_isres", a, world=world, extra_env=dict(EMU, **env)):
+        _check_against_oracle(d, p)
+        assert np.array_equal(d["f"], p["ftrace"][:len(d["f"])]) and len(d["f"]) == len(p["ftrace"])
