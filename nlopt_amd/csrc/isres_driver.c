@@ -45,7 +45,7 @@ typedef struct {
     int bits_two_pass;              /* A/B switch: ranking words through a buffer + isres_bits_kernel instead of the fused kernel */
     void *st, *ev0, *ev1;
     void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
-    int overlap;                    /* opt-in ("amd_isres_overlap" / NLA_ISRES_OVERLAP=1): generator work beside the latency-bound kernels */
+    int overlap;                    /* default; "amd_isres_overlap" = 0 / NLA_ISRES_OVERLAP=0 turn it off: generator work beside the latency-bound kernels */
     int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
     uint64_t spec_made, spec_used;  /* ... how often, and how often the evolve phase could take them */
     nla_mtstream *mts;
@@ -112,7 +112,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     { const char *e = getenv("NLA_ISRES_BITS_TWO_PASS"); d->bits_two_pass = e && atoi(e) > 0; }
     d->ev0 = nla_event_create(); d->ev1 = nla_event_create();      /* device time of the ranking kernel for the stats */
     if (!d->st || !d->ev0 || !d->ev1) return -1;
-    /* OVERLAP (opt-in until it has been measured): the generator — segment-state jumps, ranking bits, the evolve phase's deviates —
+    /* OVERLAP (measured on MI355X, config 3: 72.9 -> 65.3 ms per generation; profiles/r03_isres_overlap_ab.txt): the generator — segment-state jumps, ranking bits, the evolve phase's deviates —
      * works on a stream of its own, beside the kernels of the generation that are bound by latency, not by throughput:
      *   rank counting (196 workgroups)            ||  the ranking's jumps + words -> bits
      *   the ranking pipeline (782 lone wavefronts) ||  the deviates of the evolve phase, generated AHEAD at the stream position the
@@ -120,7 +120,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
      *                                                  nothing, isres.c:227; otherwise they are thrown away and generated again)
      *   the evolve rounds (serial look-up chains)  ||  the segment states the NEXT ranking's words start from
      * Every hand-over between the two streams is a host synchronisation of the producing stream (the driver synchronises at these
-     * points anyway): nothing is ordered by events, and with overlap off rs IS st — the default path is the one-stream code. */
+     * points anyway): nothing is ordered by events, and with overlap off rs IS st — the one-stream code of rounds 1-2. */
     d->rs = d->overlap ? nla_stream_create() : d->st;
     if (!d->rs) return -1;
     d->mts = nla_mtstream_create(d->rs);
@@ -473,7 +473,8 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
 
     D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
     D.comm = opt ? opt->comm : NULL;
-    D.overlap = (opt && nlopt_get_param(opt, "amd_isres_overlap", 0) != 0) || (getenv("NLA_ISRES_OVERLAP") && atoi(getenv("NLA_ISRES_OVERLAP")) > 0);
+    D.overlap = opt ? nlopt_get_param(opt, "amd_isres_overlap", 1) != 0 : 1;            /* 0: the one-stream generation */
+    if (getenv("NLA_ISRES_OVERLAP")) D.overlap = atoi(getenv("NLA_ISRES_OVERLAP")) > 0;     /* A/B switch for the bench */
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */
     {   /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
         const int mine = dev_alloc(&D, lb, ub, con) == 0;

@@ -107,18 +107,18 @@ def test_full_size_config3_parallel_evolve_equals_the_serial_chain(monkeypatch):
     assert a["stats"]["mt_words"] == b["stats"]["mt_words"] and a["stats"]["rank_sweeps"] == 2 * 50000
 
 
-@pytest.mark.skipif(not os.environ.get("NLA_TEST_EXPERIMENTAL"), reason="opt-in mode not yet validated on hardware (tools/r04_isres_overlap.sh runs it)")
 @pytest.mark.parametrize("obj,n,pop,seed,nineq,neq,kw", [
     ("rastrigin", 64, 1400, 42, 4, 0, dict(maxeval=7000)),
     ("rastrigin", 256, 5000, 42, 4, 0, dict(maxeval=15000)),
     ("sphere", 3, 65, 5, 1, 0, dict(maxeval=2600)),               # swap-free sweeps late in the run: deviates generated ahead are thrown away
     ("rastrigin", 256, 50000, 42, 4, 0, dict(maxeval=150000)),    # BASELINE config 3 at full size
 ])
-def test_overlap_mode_changes_nothing(obj, n, pop, seed, nineq, neq, kw):
-    """"amd_isres_overlap" = 1 (isres_driver.c): the generator on a stream of its own — rank counting || ranking bits, the ranking
-    pipeline || the evolve phase's deviates generated ahead, the evolve rounds || the next ranking's segment states.  Same candidates,
-    same result, same stream position as the one-stream run."""
-    a = run_amd(obj, n, pop, seed, nineq, neq, **kw)
+def test_overlap_mode_changes_nothing(obj, n, pop, seed, nineq, neq, kw, monkeypatch):
+    """the default (isres_driver.c, "amd_isres_overlap"): the generator on a stream of its own — rank counting || ranking bits, the
+    ranking pipeline || the evolve phase's deviates generated ahead, the evolve rounds || the next ranking's segment states.  Same
+    candidates, same result, same stream position as the one-stream run ("amd_isres_overlap" = 0)."""
+    monkeypatch.delenv("NLA_ISRES_OVERLAP", raising=False)
+    a = run_amd(obj, n, pop, seed, nineq, neq, params={"amd_isres_overlap": 0}, **kw)
     b = run_amd(obj, n, pop, seed, nineq, neq, params={"amd_isres_overlap": 1}, **kw)
     assert a["ret"] == b["ret"] and a["nevals"] == b["nevals"] and a["minf"] == b["minf"]
     assert np.array_equal(a["trace"]["f"], b["trace"]["f"]) and np.array_equal(a["x"], b["x"])

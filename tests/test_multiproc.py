@@ -320,13 +320,14 @@ def test_ranks_given_different_jobs_are_told_so(case, a, mistake):
 @pytest.mark.parametrize("world,env", [(1, {}), (1, {"NLA_EMU_EVOLVE2": "1"}), (2, {"NLA_EMU_EVOLVE2": "1"}), (3, {})])
 @pytest.mark.parametrize("obj,n,pop,seed,ncon,gens", [("rastrigin", 12, 60, 5, 2, 6), ("sphere", 6, 30, 5, 1, 40), ("ackley", 20, 45, 2, 3, 5)])
 def test_isres_overlap_mode_changes_nothing(world, env, obj, n, pop, seed, ncon, gens):
-    """ISRES with "amd_isres_overlap" = 1 (opt-in, isres_driver.c): the generator works on a second stream — ranking bits beside the
+    """ISRES with "amd_isres_overlap" = 1 (the default since it was measured; = 0 also run here, isres_driver.c): the generator works on a second stream — ranking bits beside the
     rank counting, the evolve phase's deviates generated AHEAD beside the ranking pipeline (thrown away when the ranking stops
     early: the sphere case does, late in its run), the next ranking's segment states beside the evolve rounds.  The bookkeeping
     (stream positions of the speculation, what is reused and what is redone) must leave every candidate, the result and the
     generator where the oracle has them.  (The emulated device is synchronous: what this cannot see is a missing synchronisation.)"""
-    a = dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=gens * pop, ncon=ncon, params={"amd_isres_overlap": 1})
     p = O.run_port_isres(obj, n, pop, seed, nineq=ncon, maxeval=gens * pop)
-    for d in run_world("gpu_isres", a, world=world, extra_env=dict(EMU, **env)):
-        _check_against_oracle(d, p)
-        assert np.array_equal(d["f"], p["ftrace"][:len(d["f"])]) and len(d["f"]) == len(p["ftrace"])
+    for ov in ((1, 0) if world == 1 else (1,)):
+        a = dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=gens * pop, ncon=ncon, params={"amd_isres_overlap": ov})
+        for d in run_world("gpu_isres", a, world=world, extra_env=dict(EMU, **env)):
+            _check_against_oracle(d, p)
+            assert np.array_equal(d["f"], p["ftrace"][:len(d["f"])]) and len(d["f"]) == len(p["ftrace"])

@@ -4,7 +4,7 @@
 #   gpurun --timeout 600 -- 'bash tools/r04_isres_overlap.sh'
 # Make it the default (isres_driver.c: D.overlap) only if the tests are green AND the generation is faster.
 mkdir -p gpurun_out/r04_overlap
-NLA_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_isres.py -x -q -m gpu -k "overlap" 2>&1 | tail -5 | tee gpurun_out/r04_overlap/tests.log
+timeout 300 python -m pytest tests/test_gpu_isres.py -x -q -m gpu -k "overlap" 2>&1 | tail -5 | tee gpurun_out/r04_overlap/tests.log
 for ov in 0 1 0 1; do
     NLA_ISRES_OVERLAP=$ov timeout 120 python bench.py --workload isres --steps 3 --warmup 1 2>/dev/null | tail -1 > gpurun_out/r04_overlap/bench_ov$ov.json
     python -c "
