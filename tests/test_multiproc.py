@@ -215,6 +215,8 @@ def test_rccl_transport_with_several_ranks_over_the_mock(world, case, a):
     a mock that moves the bytes through shared memory and enforces NCCL's contract — same byte count on every rank, same collective
     order, an overlapping send buffer exactly at recvbuff + rank * count — over the emulated device.  Every rank must reproduce the
     single-process run."""
+    if world == 3 and (a.get("xtol_rel") or case == "gpu_mlsl" or (a.get("params") or {}).get("amd_shard") == 0):
+        pytest.skip("three ranks: the sharded CRS2_LM and the ISRES case are enough (suite time)")
     s = run_world(case, dict(a, sharded=False), world=1, extra_env=EMU)[0]
     for d in run_world(case, a, world=world, extra_env=MOCK):
         assert d["ret"][0] == s["ret"][0] and d["nevals"][0] == s["nevals"][0] and d["minf"][0] == s["minf"][0]
