@@ -484,6 +484,7 @@ int nla_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream);
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int nla_memset(void *dst, int value, size_t bytes, void *stream);
 void *nla_stream_create(void);
+void *nla_stream_create_background(void);       /* lowest dispatch priority of the device (hipStreamCreateWithPriority): gap-filling work */
 void nla_stream_destroy(void *stream);
 int nla_stream_sync(void *stream);
 int nla_stream_query(void *stream);             /* 0: all work done, -1: still running, otherwise the hipError_t */

@@ -148,6 +148,16 @@ extern "C" void *nla_stream_create(void)
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     return (void *) s;
 }
+/* a stream whose kernels are dispatched after those of ordinary streams when both have work ready: for background work that
+ * should fill the gaps another stream's latency-bound kernels leave, without taking compute units from its throughput-bound ones */
+extern "C" void *nla_stream_create_background(void)
+{
+    hipStream_t s = nullptr;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void) hipGetLastError(); least = 0; }
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) { (void) hipGetLastError(); return nla_stream_create(); }
+    return (void *) s;
+}
 extern "C" void nla_stream_destroy(void *stream) { if (stream) (void) hipStreamDestroy((hipStream_t) stream); }
 extern "C" int nla_stream_sync(void *stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
 

@@ -121,7 +121,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
      *   the evolve rounds (serial look-up chains)  ||  the segment states the NEXT ranking's words start from
      * Every hand-over between the two streams is a host synchronisation of the producing stream (the driver synchronises at these
      * points anyway): nothing is ordered by events, and with overlap off rs IS st — the one-stream code of rounds 1-2. */
-    d->rs = d->overlap ? nla_stream_create() : d->st;
+    d->rs = !d->overlap ? d->st : (getenv("NLA_ISRES_RS_BACKGROUND") && atoi(getenv("NLA_ISRES_RS_BACKGROUND")) > 0 ? nla_stream_create_background() : nla_stream_create());
     if (!d->rs) return -1;
     d->mts = nla_mtstream_create(d->rs);
     if (!d->mts) return -1;

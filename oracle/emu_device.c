@@ -58,6 +58,7 @@ int nla_memcpy_d2h(void *dst, const void *src, size_t bytes, void *st) { (void) 
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *st) { (void) st; if (bytes) memmove(dst, src, bytes); return 0; }
 int nla_memset(void *dst, int value, size_t bytes, void *st) { (void) st; if (bytes) memset(dst, value, bytes); return 0; }
 void *nla_stream_create(void) { return emu_alloc(1); }
+void *nla_stream_create_background(void) { return emu_alloc(1); }
 void nla_stream_destroy(void *st) { emu_release(st); }
 int nla_stream_sync(void *st) { (void) st; return 0; }
 int nla_stream_query(void *st) { (void) st; return 0; }
