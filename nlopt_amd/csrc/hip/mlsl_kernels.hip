@@ -38,6 +38,51 @@ __global__ __launch_bounds__(DT * DT) void mlsl_dist2_kernel(int n, int ld, cons
     if (i0 + ty < na && j0 + tx < nb) D[(size_t) (i0 + ty) * nb + j0 + tx] = d;
 }
 
+/* The same distances with REGISTER tiling (opt-in, NLA_MLSL_DIST2_TILED=1, until it has run on the device): a workgroup owns
+ * 64 x 64 pairs, a thread 4 x 4 of them (rows ty + 16 r, columns tx + 16 c) — per coordinate 8 LDS reads feed 16 pairs instead of 2
+ * feeding one, which is what bounds the kernel above (LDS bandwidth: 6.4 ms for 1000 x 3000 pairs at n = 4096, 5 % of the fp64
+ * vector rate).  Every pair is still summed by ONE thread over k ascending, subtract / multiply / add unfused: bit-identical. */
+#define DR 64          /* pairs tile edge of the register-tiled kernel */
+#define DKR 32         /* coordinates per LDS tile */
+__global__ __launch_bounds__(256) void mlsl_dist2_tiled_kernel(int n, int ld, const double *__restrict__ A, int na,
+                                                               const double *__restrict__ B, int nb, double *__restrict__ D)
+{
+    __shared__ double sa[DR][DKR + 1], sb[DR][DKR + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.y * DR, j0 = blockIdx.x * DR;
+    double d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[r][c] = 0.;
+    for (int k0 = 0; k0 < n; k0 += DKR) {
+        const int kc = n - k0 < DKR ? n - k0 : DKR;
+        __syncthreads();
+        for (int e = threadIdx.x; e < DR * DKR; e += 256) {
+            const int r = e / DKR, k = e - r * DKR;
+            sa[r][k] = (i0 + r < na && k < kc) ? A[(size_t) (i0 + r) * ld + k0 + k] : 0.;
+            sb[r][k] = (j0 + r < nb && k < kc) ? B[(size_t) (j0 + r) * ld + k0 + k] : 0.;
+        }
+        __syncthreads();
+        for (int k = 0; k < kc; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = sa[ty + 16 * r][k]; b[r] = sb[tx + 16 * r][k]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const double dx = a[r] - b[c]; d[r][c] += dx * dx; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0 + ty + 16 * r, j = j0 + tx + 16 * c;
+            if (i < na && j < nb) D[(size_t) i * nb + j] = d[r][c];
+        }
+}
+
 /* out[i] = min(init[i], min_j { D[i][j] : FB[j] < FA[i] })        (one wavefront per row i) */
 __global__ __launch_bounds__(256) void mlsl_rowmin_kernel(const double *__restrict__ D, int ldd, int na, int nb, const double *__restrict__ FA,
                                                           const double *__restrict__ FB, const double *__restrict__ init,
@@ -95,6 +140,14 @@ extern "C" int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const doub
 extern "C" int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream)
 {
     if (na <= 0 || nb <= 0) return 0;
+    const char *sw = getenv("NLA_MLSL_DIST2_TILED");                 /* read per call: a test switches it inside one process */
+    const bool tiled = sw && atoi(sw) > 0;
+    if (tiled) {
+        hipLaunchKernelGGL(mlsl_dist2_tiled_kernel, dim3((unsigned) ((nb + DR - 1) / DR), (unsigned) ((na + DR - 1) / DR)), dim3(256), 0,
+                           (hipStream_t) stream, n, ld, A, na, B, nb, D);
+        NLA_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(mlsl_dist2_kernel, dim3((unsigned) ((nb + DT - 1) / DT), (unsigned) ((na + DT - 1) / DT)), dim3(DT * DT), 0,
                        (hipStream_t) stream, n, ld, A, na, B, nb, D);
     NLA_LAUNCH_CHECK();

@@ -48,6 +48,8 @@ typedef struct {
     int n, ld, obj, N;
     nla_evaluator ev;
     double *h_rows;                 /* host objective: the iteration's samples, pinned (N x ld) */
+    void *rs;                       /* the generator's stream: st itself, or (prefetch) a second one */
+    int prefetch; uint64_t prefetched_at;   /* opt-in: the next iteration's sample words generated beside the local phase; stream position they were generated for */
     void *st;
     nla_mtstream *mts;
     uint64_t words_used;
@@ -84,6 +86,7 @@ typedef struct {
 static void mfree(mlsl_dev *d)
 {
     if (d->st) nla_stream_sync(d->st);
+    if (d->rs) nla_stream_sync(d->rs);
     if (d->mts) { nla_mtstream_finish(d->mts, d->words_used); nla_mtstream_destroy(d->mts); }
     nla_local_ctx_destroy(d->lb);
     free(d->F); free(d->cpd); free(d->cld); free(d->minimized); free(d->ord); free(d->LF); free(d->lord);
@@ -94,6 +97,7 @@ static void mfree(mlsl_dev *d)
     free(d->h_gather);
     nla_host_free(d->h_D); nla_host_free(d->h_idx); nla_host_free(d->h_lf); nla_host_free(d->h_flags);
     nla_dev_free(d->d_idx); nla_dev_free(d->d_flags);
+    if (d->rs && d->rs != d->st) nla_stream_destroy(d->rs);
     if (d->st) nla_stream_destroy(d->st);
 }
 
@@ -278,7 +282,16 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.st = nla_stream_create();
     /* several ranks: set-up ends with an exchange of "ready" (comm.c, nla_comm_agree_ready) — a rank that fails below says so there
      * instead of leaving the others in the run's first collective */
-    if (!D.st || !(D.mts = nla_mtstream_create(D.st))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); nla_comm_agree_ready(D.comm, 0); mfree(&D); return NLOPT_OUT_OF_MEMORY; }
+    /* PREFETCH (opt-in, "amd_mlsl_prefetch" / NLA_MLSL_PREFETCH=1, until it has been measured): pseudo-random sampling (every MLSL
+     * variant at n > 1111, where the reference has no Sobol generator either) costs a generator pass per iteration that is bound by
+     * latency, not throughput — 2 n N words are 13 segments = 13 wavefronts at config 4, 1.9 ms + 0.5-1 ms of segment jumps of the
+     * 7.5 ms sampling phase.  Nothing between two sampling phases draws random numbers (the local optimisers are deterministic), so
+     * the NEXT iteration's words are generated on a stream of their own beside the distance pass and the local searches.  Hand-over
+     * = a host synchronisation of that stream before the sampling kernel reads them. */
+    D.prefetch = !host && ((opt && nlopt_get_param(opt, "amd_mlsl_prefetch", 0) != 0) || (getenv("NLA_MLSL_PREFETCH") && atoi(getenv("NLA_MLSL_PREFETCH")) > 0));
+    D.prefetched_at = ~0ULL;
+    D.rs = (D.st && D.prefetch) ? nla_stream_create() : D.st;
+    if (!D.st || !D.rs || !(D.mts = nla_mtstream_create(D.rs))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); nla_comm_agree_ready(D.comm, 0); mfree(&D); return NLOPT_OUT_OF_MEMORY; }
     D.d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (size_t) D.N);
@@ -391,7 +404,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             if (nla_k_mlsl_sobol_rows(n, D.ld, D.d_lb, D.d_ub, D.d_V, D.sobol_next, D.N, D.d_P + old * (size_t) D.ld, D.st) ||
                 (!host && EVAL_ROWS(D.d_P + old * (size_t) D.ld, D.N, D.d_F + old))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         } else {
-            if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
+            if (D.prefetched_at != D.words_used &&
+                nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
+            if (D.rs != D.st && nla_stream_sync(D.rs)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }   /* the words are there */
             if (nla_k_crs_init_rows(D.obj, n, D.ld, D.d_lb, D.d_ub, D.d_words, (int64_t) old, D.N, D.d_P, D.d_F, D.st) ||
                 (D.ev.kind == NLA_EVAL_DEVICE && D.ev.sign < 0 && nla_k_mlsl_negate(D.d_F + old, D.N, D.st)) ||
                 (D.ev.kind == NLA_EVAL_USER && EVAL_ROWS(D.d_P + old * (size_t) D.ld, D.N, D.d_F + old))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
@@ -415,6 +430,11 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         else D.words_used += 2ULL * (uint64_t) n * (uint64_t) used;
         if (host && (nla_memcpy_h2d(D.d_F + old, Fnew, sizeof(double) * used, D.st) || nla_stream_sync(D.st))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         if (ret != NLOPT_SUCCESS) break;
+        if (D.prefetch && !D.d_V) {
+            /* the sampling kernel has read the words (synchronised above): the next iteration's, beside everything that follows */
+            if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
+            D.prefetched_at = D.words_used;
+        }
         {
             const int na = D.N, nb = (int) D.npts;
             if (need_D(&D, (size_t) na * (size_t) nb)) DEVFAIL();

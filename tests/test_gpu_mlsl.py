@@ -155,3 +155,37 @@ def test_mlsl_lds_sobol_sampling_matches_the_oracle(obj, n, ns, seed, kw):
         assert len(fs) == len(p["fsamp"])
     m = min(len(fs), len(p["fsamp"]), ns or 4)          # the first iteration's samples do not depend on any local search
     assert np.all(np.abs(fs[:m] - p["fsamp"][:m]) <= 1e-10 * np.maximum(np.abs(p["fsamp"][:m]), 1.0))
+
+
+def _dist2_reference(A, B):
+    """mlsl.c's distance2 for every pair: one accumulator per pair over k ascending, (a - b) * (a - b) then add, nothing fused"""
+    d = np.zeros((A.shape[0], B.shape[0]))
+    for k in range(A.shape[1]):
+        dx = A[:, k][:, None] - B[:, k][None, :]
+        d += dx * dx
+    return d
+
+
+@pytest.mark.parametrize("variant", ["default", "tiled"])
+@pytest.mark.parametrize("n,na,nb", [(4096, 70, 130), (257, 64, 64), (5, 1, 3), (33, 129, 65), (512, 200, 1000)])
+def test_pair_distance_kernel_is_the_sequential_sum(variant, n, na, nb, monkeypatch):
+    """mlsl_dist2_kernel (hip/mlsl_kernels.hip): the squared distance of every (new point, point) pair, bit for bit the serial sum of
+    mlsl.c:119-125 — what the closest-point tests (`cpd <= R*R`, mlsl.c:208-209) are decided on.  Ragged tile edges, n not a multiple
+    of the coordinate tile.  "tiled" = the register-tiled variant (NLA_MLSL_DIST2_TILED=1), opt-in until it has run on the device."""
+    if not __import__("os").environ.get("NLA_TEST_EXPERIMENTAL"):
+        # written after round 3's GPU minutes were spent: checked against the emulated device only so far.  Not collected into the
+        # default suite before it has passed on the device once (tools/r04_first_call.sh): a direct bit-for-bit test of a kernel that
+        # only end-to-end tests covered could stop the driver's `-x` run early
+        pytest.skip("not yet run on the device (NLA_TEST_EXPERIMENTAL=1 to include it)")
+    monkeypatch.setenv("NLA_MLSL_DIST2_TILED", "1" if variant == "tiled" else "0")
+    L = nlopt_amd.lib()
+    L.nla_k_mlsl_dist2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(n * 1000 + na)
+    ld = (n + 1) & ~1
+    A = np.zeros((na, ld)); B = np.zeros((nb, ld))
+    A[:, :n] = rng.uniform(-32.768, 32.768, (na, n)); B[:, :n] = rng.uniform(-32.768, 32.768, (nb, n))
+    B[0, :n] = A[0, :n]                                   # a zero distance
+    dA, dB, dD = nlopt_amd.DevBuf.from_array(A), nlopt_amd.DevBuf.from_array(B), nlopt_amd.DevBuf(8 * na * nb)
+    assert L.nla_k_mlsl_dist2(n, ld, dA.ptr, na, dB.ptr, nb, dD.ptr, None) == 0 and L.nla_stream_sync(None) == 0
+    got = dD.to_array(np.float64, na * nb).reshape(na, nb)
+    assert np.array_equal(got, _dist2_reference(A[:, :n], B[:, :n])) and got[0, 0] == 0.0
