@@ -5,7 +5,7 @@
 # real device or the real library file — the reference's client programs and CLI linked against libnlopt_amd.so, user kernels
 # (code objects), the chain kernel's own test, RCCL itself, wall-clock tests and the tests that interrupt a device-resident search from outside (the emulated device is
 # synchronous: such a search would never end) — and the full-size cases (hours on a CPU).
-#   bash tools/gpu_suite_on_emu.sh [extra pytest args]        (~12 min with 6 workers; 400+ tests)
+#   bash tools/gpu_suite_on_emu.sh [extra pytest args]        (2-3 min with 6 workers; 400+ tests)
 cd "$(dirname "$0")/.." || exit 1
 make -s -C oracle port emu emudev mockrccl || exit 1
 PYTHONPATH=tests NLA_TEST_EMU_DEVICE=1 python -m pytest -p _emu_plugin tests -m gpu -q -p no:cacheprovider -n "${JOBS:-6}" --timeout 600 --tb=line -rf \
@@ -15,6 +15,7 @@ PYTHONPATH=tests NLA_TEST_EMU_DEVICE=1 python -m pytest -p _emu_plugin tests -m 
     --deselect tests/test_gpu_multiproc.py::test_rccl_transport_one_rank \
     --deselect tests/test_gpu_isres.py::test_full_size_config3_parallel_evolve_equals_the_serial_chain \
     --deselect tests/test_gpu_crs.py::test_full_size_invariants_at_the_metric_configuration \
+    --deselect "tests/test_gpu_isres.py::test_overlap_mode_changes_nothing[rastrigin-256-50000-42-4-0-kw3]" \
     --deselect tests/test_gpu_stops.py::test_maxtime_stops_the_run \
     --deselect tests/test_gpu_stops.py::test_maxtime_is_observed_inside_a_device_resident_local_search \
     --deselect tests/test_gpu_stops.py::test_force_stop_from_another_thread_ends_a_device_resident_search "$@"
