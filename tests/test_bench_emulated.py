@@ -57,7 +57,8 @@ def test_bench_line_has_the_contracts_keys(argv):
 
 
 @pytest.mark.skipif(not os.path.exists(EMU), reason="emulated library not built")
-def test_bench_line_at_two_ranks_reports_replicas_and_the_one_job_config5_block_apart():
+@pytest.mark.parametrize("transport", ["host", "rccl_mock"])
+def test_bench_line_at_two_ranks_reports_replicas_and_the_one_job_config5_block_apart(transport):
     """--gpus 2 --workload crs: value = the sum over independent replicas (scaling weak); BASELINE config 5 — the one CRS job with
     multi-rank work in it (sharded initial population, all-gathered) — stands in its own block.  Two gloo ranks
     over the emulated device layer, toy sizes."""
@@ -70,6 +71,8 @@ def test_bench_line_at_two_ranks_reports_replicas_and_the_one_job_config5_block_
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if transport == "rccl_mock":        # the one-job blocks through comm.c's RCCL branch (ncclAllGather of oracle/libmockrccl.so), as on a node
+            env["NLA_RCCL_LIBRARY"] = os.path.join(ROOT, "oracle", "libmockrccl.so")
         procs.append(subprocess.Popen([sys.executable, "-c", SNIPPET % (ROOT, EMU, argv)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True, cwd=ROOT, env=env))
     outs = [p.communicate(timeout=600) for p in procs]
