@@ -81,6 +81,7 @@ int ncclCommInitRank(void **comm, int nranks, mock_uid id, int rank)
     c->slots = (char *) c->h + 4096;
     if (rank == 0) c->h->nranks = nranks;             /* (a fresh segment is zero-filled: barrier state starts at 0) */
     barrier(c);
+    if (rank == 0) shm_unlink(c->name);               /* every rank has mapped it: the name can go (nothing is left behind by a rank that never calls ncclCommDestroy) */
     *comm = c;
     return 0;
 }
@@ -128,7 +129,6 @@ int ncclCommDestroy(void *comm)
     if (!c) return 0;
     barrier(c);
     munmap((void *) c->h, c->map_bytes);
-    if (c->rank == 0) shm_unlink(c->name);
     free(c);
     return 0;
 }
