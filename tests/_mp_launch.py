@@ -2,6 +2,7 @@
 import json
 import os
 import socket
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -40,4 +41,6 @@ def run_world(case, args=None, world=2, timeout=600, extra_env=None):
         logs.append(o.decode(errors="replace"))
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-4000:])
-    return [dict(np.load(out + ".rank%d.npz" % r)) for r in range(world)]
+    res = [dict(np.load(out + ".rank%d.npz" % r)) for r in range(world)]
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
