@@ -510,6 +510,9 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                      # `achieved` counts the bytes of every slot a launch STARTED (all of them are gathered in full); what the chain then
                      # CONSUMED (a slot behind a rejected one is a mutation block, a new best point restarts the window) is less:
                      "achieved_useful": useful_gbs, "frac_useful": (useful_gbs / HBM_PEAK_GBS) if useful_gbs else None,
+                     # the guide's figure for what the part sustains on a streaming read (MI355X_MICROARCH.md: "8 TB/s peak (spec);
+                     # ~6.3 TB/s achievable"); `frac` above stays against the spec peak
+                     "achievable": 6300.0, "frac_of_achievable": (achieved / 6300.0) if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_note": ("NOT measured in this run: HBM bytes per launch read from the committed rocprofv3 PMC passes of the same "
                                       "command (profiles/, FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE)") if traffic else None,
