@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnlopt_amd.so")
+LIB_PATH = os.environ.get("NLOPT_AMD_LIB") or os.path.join(_HERE, "lib", "libnlopt_amd.so")    # NLOPT_AMD_LIB: an instrumented build (tools/)
 
 # nlopt_algorithm values (include/nlopt.h; ABI)
 GN_CRS2_LM, GN_MLSL, GD_MLSL, GN_MLSL_LDS, GD_MLSL_LDS = 19, 20, 21, 22, 23

@@ -8,8 +8,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "lib", "obj")
-LIB = os.path.join(HERE, "lib", "libnlopt_amd.so")
+# NLOPT_AMD_VARIANT=<name>[:-Dflag ...] builds an instrumented library of its own beside the product (lib/libnlopt_amd_<name>.so,
+# objects in lib/obj_<name>) — tools/lbfgs_prof.py uses "prof:-DNLA_LB_PROF"; nothing loads it unless NLOPT_AMD_LIB points there
+_VAR = os.environ.get("NLOPT_AMD_VARIANT", "")
+_VNAME, _VFLAGS = (_VAR.split(":", 1) + [""])[:2] if _VAR else ("", "")
+OBJ = os.path.join(HERE, "lib", "obj" + ("_" + _VNAME if _VNAME else ""))
+LIB = os.path.join(HERE, "lib", "libnlopt_amd" + ("_" + _VNAME if _VNAME else "") + ".so")
 
 HIP_SRC = ["hip/devrt.hip", "hip/mt_kernels.hip", "hip/crs_kernels.hip", "hip/crs_chain.hip", "hip/crs_shard.hip", "hip/isres_kernels.hip", "hip/isres_evolve2.hip", "hip/lbfgs_kernels.hip", "hip/mma_kernels.hip", "hip/mlsl_kernels.hip", "hip/esch_kernels.hip"]
 C_SRC = ["mt_host.c", "mtstream.c", "stopping.c", "objfuncs.c", "api_general.c", "api_options.c", "api_optimize.c",
@@ -17,8 +21,8 @@ C_SRC = ["mt_host.c", "mtstream.c", "stopping.c", "objfuncs.c", "api_general.c",
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off everywhere: population rows and trial points must be bit-identical to the
 # reference, which is built with it (CMakeLists.txt:280-284).
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
-C_FLAGS = ["-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-fvisibility=default"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"] + _VFLAGS.split()
+C_FLAGS = ["-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-fvisibility=default"] + _VFLAGS.split()
 
 
 def _newer(src, dst, extra=()):

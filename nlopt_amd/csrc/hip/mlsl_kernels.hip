@@ -5,46 +5,23 @@
  *   dist2        |a_i - b_j|^2 for all pairs of two point sets — the reference's distance2
  *                (mlsl.c:118-127) inside find_closest_pt / find_closest_lm / pts_update_newpt /
  *                pts_update_newlm (:131-194), N_new x |pts| x n flops per iteration, the sampling
- *                phase's hot spot.  LDS-tiled 16x16 pairs per workgroup; every pair is summed by one
- *                thread over k in ascending order without FMA, i.e. in the reference's order:
- *                distances are bit-identical to the CPU's.
+ *                phase's hot spot.  LDS- and register-tiled (64x64 pairs per workgroup, 4x4 per thread);
+ *                every pair is summed by one thread over k in ascending order without FMA, i.e. in the
+ *                reference's order: distances are bit-identical to the CPU's.
  *   masked mins  closest_pt_d / closest_lm_d updates: min over the partner set restricted to
  *                partners with strictly smaller f (mlsl.c:133,147,164,184).
  */
 #include "dev_common.h"
 #include "../../../include/nlopt_amd.h"
 
-#define DT 16          /* pairs tile edge */
-#define DK 64          /* coordinates per LDS tile */
-
-__global__ __launch_bounds__(DT * DT) void mlsl_dist2_kernel(int n, int ld, const double *__restrict__ A, int na,
-                                                             const double *__restrict__ B, int nb, double *__restrict__ D)
-{
-    __shared__ double sa[DT][DK + 1], sb[DT][DK + 1];
-    const int tx = threadIdx.x % DT, ty = threadIdx.x / DT;     /* pair (i0+ty, j0+tx) */
-    const int i0 = blockIdx.y * DT, j0 = blockIdx.x * DT;
-    double d = 0.;
-    for (int k0 = 0; k0 < n; k0 += DK) {
-        const int kc = n - k0 < DK ? n - k0 : DK;
-        __syncthreads();
-        for (int e = threadIdx.x; e < DT * DK; e += DT * DT) {
-            const int r = e / DK, k = e - r * DK;
-            sa[r][k] = (i0 + r < na && k < kc) ? A[(size_t) (i0 + r) * ld + k0 + k] : 0.;
-            sb[r][k] = (j0 + r < nb && k < kc) ? B[(size_t) (j0 + r) * ld + k0 + k] : 0.;
-        }
-        __syncthreads();
-        for (int k = 0; k < kc; ++k) { const double dx = sa[ty][k] - sb[tx][k]; d += dx * dx; }
-    }
-    if (i0 + ty < na && j0 + tx < nb) D[(size_t) (i0 + ty) * nb + j0 + tx] = d;
-}
-
-/* The same distances with REGISTER tiling (opt-in, NLA_MLSL_DIST2_TILED=1, until it has run on the device): a workgroup owns
- * 64 x 64 pairs, a thread 4 x 4 of them (rows ty + 16 r, columns tx + 16 c) — per coordinate 8 LDS reads feed 16 pairs instead of 2
- * feeding one, which is what bounds the kernel above (LDS bandwidth: 6.4 ms for 1000 x 3000 pairs at n = 4096, 5 % of the fp64
- * vector rate).  Every pair is still summed by ONE thread over k ascending, subtract / multiply / add unfused: bit-identical. */
+/* A workgroup owns 64 x 64 pairs, a thread 4 x 4 of them (rows ty + 16 r, columns tx + 16 c): per coordinate 8 LDS reads feed 16
+ * pairs.  (Rounds 1-3 ran one pair per thread on 16 x 16 tiles — two LDS reads per pair and coordinate, bound by LDS bandwidth:
+ * 6.4 ms for 1000 x 3000 pairs at n = 4096; measured on the MI355X in round 4 (gpurun_out/r04_first): the sampling phase of
+ * config 4 went 9.4 -> 7.6 ms per iteration, the direct bit-for-bit test and the MLSL files green, and the old kernel was deleted.)
+ * Every pair is summed by ONE thread over k ascending, subtract / multiply / add unfused: bit-identical to distance2. */
 #define DR 64          /* pairs tile edge of the register-tiled kernel */
 #define DKR 32         /* coordinates per LDS tile */
-__global__ __launch_bounds__(256) void mlsl_dist2_tiled_kernel(int n, int ld, const double *__restrict__ A, int na,
+__global__ __launch_bounds__(256) void mlsl_dist2_kernel(int n, int ld, const double *__restrict__ A, int na,
                                                                const double *__restrict__ B, int nb, double *__restrict__ D)
 {
     __shared__ double sa[DR][DKR + 1], sb[DR][DKR + 1];
@@ -140,15 +117,7 @@ extern "C" int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const doub
 extern "C" int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream)
 {
     if (na <= 0 || nb <= 0) return 0;
-    const char *sw = getenv("NLA_MLSL_DIST2_TILED");                 /* read per call: a test switches it inside one process */
-    const bool tiled = sw && atoi(sw) > 0;
-    if (tiled) {
-        hipLaunchKernelGGL(mlsl_dist2_tiled_kernel, dim3((unsigned) ((nb + DR - 1) / DR), (unsigned) ((na + DR - 1) / DR)), dim3(256), 0,
-                           (hipStream_t) stream, n, ld, A, na, B, nb, D);
-        NLA_LAUNCH_CHECK();
-        return 0;
-    }
-    hipLaunchKernelGGL(mlsl_dist2_kernel, dim3((unsigned) ((nb + DT - 1) / DT), (unsigned) ((na + DT - 1) / DT)), dim3(DT * DT), 0,
+    hipLaunchKernelGGL(mlsl_dist2_kernel, dim3((unsigned) ((nb + DR - 1) / DR), (unsigned) ((na + DR - 1) / DR)), dim3(256), 0,
                        (hipStream_t) stream, n, ld, A, na, B, nb, D);
     NLA_LAUNCH_CHECK();
     return 0;

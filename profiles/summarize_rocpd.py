@@ -1,5 +1,7 @@
 """Turn rocprofv3's rocpd sqlite output (ROCm 7.2 default) into the text summaries committed here.
-usage: python profiles/summarize_rocpd.py <results.db> [--pmc]"""
+usage: python profiles/summarize_rocpd.py <results.db> [--pmc | --timeline [first_row [rows]]]
+--timeline: every kernel dispatch in start order — start offset (us), duration (us), gap to the previous END on any queue (us),
+queue / stream ids where the view has them, name — what the per-kernel sums cannot show: idle gaps and overlap."""
 import sqlite3
 import sys
 
@@ -15,6 +17,22 @@ def main():
         print("kernel,counter,dispatches,sum,avg_per_dispatch")
         for r in cur.execute(q):
             print("%s,%s,%d,%.6g,%.6g" % (r[0].split("(")[0], r[1], r[2], r[3], r[4]))
+        return
+    if "--timeline" in sys.argv:
+        i = sys.argv.index("--timeline")
+        first = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 0
+        count = int(sys.argv[i + 2]) if len(sys.argv) > i + 2 else 100000
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        extra = [c for c in ("queue_id", "stream_id", "grid_x", "workgroup_x", "grid_size", "workgroup_size") if c in cols]
+        rows = list(cur.execute("select start, end, name%s from kernels order by start" % "".join(", " + c for c in extra)))
+        print("# columns of kernels:", cols)
+        print("idx,start_us,dur_us,gap_us,%sname" % "".join(c + "," for c in extra))
+        t0, last_end = (rows[0][0], rows[0][0]) if rows else (0, 0)
+        for k, r in enumerate(rows):
+            if first <= k < first + count:
+                print("%d,%.1f,%.1f,%.1f,%s%s" % (k, (r[0] - t0) / 1e3, (r[1] - r[0]) / 1e3, (r[0] - last_end) / 1e3,
+                                                  "".join(str(v) + "," for v in r[3:]), r[2].split("(")[0]))
+            last_end = max(last_end, r[1])
         return
     rows = list(cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                             "from kernels group by name order by sum(end-start) desc"))

@@ -166,18 +166,11 @@ def _dist2_reference(A, B):
     return d
 
 
-@pytest.mark.parametrize("variant", ["default", "tiled"])
-@pytest.mark.parametrize("n,na,nb", [(4096, 70, 130), (257, 64, 64), (5, 1, 3), (33, 129, 65), (512, 200, 1000)])
-def test_pair_distance_kernel_is_the_sequential_sum(variant, n, na, nb, monkeypatch):
+@pytest.mark.parametrize("n,na,nb", [(4096, 70, 130), (257, 64, 64), (5, 1, 3), (33, 129, 65), (512, 200, 1000), (1, 1, 1), (64, 63, 193)])
+def test_pair_distance_kernel_is_the_sequential_sum(n, na, nb):
     """mlsl_dist2_kernel (hip/mlsl_kernels.hip): the squared distance of every (new point, point) pair, bit for bit the serial sum of
     mlsl.c:119-125 — what the closest-point tests (`cpd <= R*R`, mlsl.c:208-209) are decided on.  Ragged tile edges, n not a multiple
-    of the coordinate tile.  "tiled" = the register-tiled variant (NLA_MLSL_DIST2_TILED=1), opt-in until it has run on the device."""
-    if not __import__("os").environ.get("NLA_TEST_EXPERIMENTAL"):
-        # written after round 3's GPU minutes were spent: checked against the emulated device only so far.  Not collected into the
-        # default suite before it has passed on the device once (tools/r04_first_call.sh): a direct bit-for-bit test of a kernel that
-        # only end-to-end tests covered could stop the driver's `-x` run early
-        pytest.skip("not yet run on the device (NLA_TEST_EXPERIMENTAL=1 to include it)")
-    monkeypatch.setenv("NLA_MLSL_DIST2_TILED", "1" if variant == "tiled" else "0")
+    of the coordinate tile (round 4: ran on the device, the register-tiled kernel became the only one)."""
     L = nlopt_amd.lib()
     L.nla_k_mlsl_dist2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(n * 1000 + na)

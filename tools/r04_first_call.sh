@@ -8,7 +8,7 @@
 # the skip in the test.
 #   gpurun --timeout 600 -- 'bash tools/r04_first_call.sh'
 mkdir -p gpurun_out/r04_first
-NLA_TEST_EXPERIMENTAL=1 timeout 120 python -m pytest tests/test_gpu_mlsl.py -x -q -m gpu -k pair_distance 2>&1 | tail -3 | tee gpurun_out/r04_first/dist2_tests.log
+timeout 120 python -m pytest tests/test_gpu_mlsl.py -x -q -m gpu -k pair_distance 2>&1 | tail -3 | tee gpurun_out/r04_first/dist2_tests.log
 NLA_MLSL_DIST2_TILED=1 timeout 300 python -m pytest tests/test_gpu_mlsl.py tests/test_gpu_exact_local.py tests/test_gpu_fullsize.py -q -m gpu -k "mlsl or MLSL" 2>&1 | tail -3 | tee gpurun_out/r04_first/mlsl_tiled.log
 NLA_MLSL_PREFETCH=1 timeout 300 python -m pytest tests/test_gpu_mlsl.py tests/test_gpu_exact_local.py tests/test_gpu_fullsize.py tests/test_gpu_multiproc.py -q -m gpu -k "mlsl or MLSL" 2>&1 | tail -3 | tee gpurun_out/r04_first/mlsl_prefetch.log
 for pf in 0 1 0 1; do
@@ -25,3 +25,5 @@ import json
 d = json.load(open('gpurun_out/r04_first/bench_t$t.json'))
 print('tiled=$t', round(d['value']), 'evals/s', round(d['ms_per_step'], 2), 'ms/iteration', d.get('phases'))"
 done 2>&1 | tee gpurun_out/r04_first/ab.log
+# multi-rank ISRES with the overlap mode on (the default), on the device
+timeout 300 python -m pytest tests/test_gpu_multiproc.py -q -m gpu -k isres 2>&1 | tail -3 | tee gpurun_out/r04_first/isres_multirank.log
