@@ -42,30 +42,6 @@ struct lb_saved {
 
 #define LB_EPT 16                  /* coordinates per thread held in registers by the direction loops (n <= 4096) */
 
-/* -DNLA_LB_PROF (tools/lbfgs_prof.py builds a library of its own with it; the shipped one has none of this): where a search's
- * time goes, per phase, in 10 ns ticks of the constant-rate clock (s_memrealtime), accumulated by every workgroup for itself */
-#ifdef NLA_LB_PROF
-#define LB_PROF_PHASES 12
-#define LB_PROF_CAP 4096
-__device__ unsigned long long nla_lb_prof[LB_PROF_CAP][LB_PROF_PHASES + 4];
-#define PROF_DECL unsigned long long pf_acc[LB_PROF_PHASES] = {}, pf_last = wall_clock64(), pf_iters = 0
-#define PROF(i) do { const unsigned long long pf_t = wall_clock64(); pf_acc[i] += pf_t - pf_last; pf_last = pf_t; } while (0)
-#define PROF_ITER ++pf_iters
-#define PROF_STORE do { if (tid == 0 && inst < LB_PROF_CAP) { for (int pf_i = 0; pf_i < LB_PROF_PHASES; ++pf_i) nla_lb_prof[inst][pf_i] = pf_acc[pf_i]; \
-        nla_lb_prof[inst][LB_PROF_PHASES] = pf_iters; nla_lb_prof[inst][LB_PROF_PHASES + 1] = nevals; nla_lb_prof[inst][LB_PROF_PHASES + 2] = cols; \
-        nla_lb_prof[inst][LB_PROF_PHASES + 3] = __smid(); } } while (0)
-extern "C" int nla_lbfgs_prof_read(unsigned long long *out, int count)
-{
-    if (count > LB_PROF_CAP) count = LB_PROF_CAP;
-    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(nla_lb_prof), sizeof(unsigned long long) * (LB_PROF_PHASES + 4) * (size_t) count);
-}
-#else
-#define PROF_DECL
-#define PROF(i)
-#define PROF_ITER
-#define PROF_STORE
-#endif
-
 __device__ __forceinline__ void lb_project(int n, double *x, const int *ix, const double *xl, const double *xu, double eps9)   /* pcbs04 */
 {
     for (int i = threadIdx.x; i < n; i += LB_T) {
@@ -238,7 +214,6 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         FOUT = E.EF[inst];                                                                                              \
     } else FOUT = lb_objgrad<EXT ? 0 : OBJ>(n, x, gf, S, oscratch, P.exact, XB, P.sign)
 
-    PROF_DECL;
     if (xtol_rel <= 0.) xtol_rel = 1e-16;                                    /* plis.c:202-214 */
     ls.minf_max = P.minf_max; ls.ftol_rel = P.ftol_rel <= 0. ? 1e-14 : P.ftol_rel; ls.ftol_abs = P.ftol_abs; ls.maxeval = P.maxeval;
     if (tolg <= 0.) tolg = 1e-8;
@@ -273,17 +248,13 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     __syncthreads();
     lb_add_active(n, x, ix, xl, xu);
     __syncthreads();
-    PROF(0);
     LB_EVAL(0, resume_first, fval);
-    PROF(6);
     if (P.ftrace && tid == 0 && nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + nevals] = fval;
     ++nevals; ++c.nfg;
     if (!EXT && P.abort) tmo = lb_poll_abort(P.abort) == 100;
     if (tmo) c.iterm = 100;                                                  /* plis.c:263 */
 
     while (c.iterm != 100) {
-        PROF_ITER;
-        PROF(0);
         /* pytrcg: largest free gradient component, largest wrong-signed multiplier on an active bound */
         {
             double gm = 0, um = 0;
@@ -316,7 +287,6 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             if (lb_block_isum(rel, S) > 1) c.irest = LB_MAX(c.irest, 1);
         }
         __syncthreads();
-        PROF(1);
     direction:
         gnorm = sqrt(MDOT(gf, gf));
         if (c.irest == 0) {
@@ -328,7 +298,6 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 else {
                     if (tid == 0) COLU(1) = 1. / b;
                     cols += k;
-                    PROF(2);
                     if (n <= LB_T * LB_EPT && !P.exact) {
                         __syncthreads();                       /* COLU(1) visible */
                         snorm = lb_strang_in_registers(n, k, mf, head, ld, ix, gf, s, hx, hg, ucol, vcol, b);
@@ -353,7 +322,6 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                         }
                         snorm = sqrt(MDOT(s, s));
                     }
-                    PROF(3);
                     head = (head + mf - 1) % mf;                             /* mxdrsu: every column one older */
                 }
             }
@@ -392,7 +360,6 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             }
             rmax = lb_block_min(rm, S);
         }
-        PROF(4);
         if (rmax != 0.) {
             q.f = fval; q.fo = fo; q.p = p; q.po = po; q.minf_est = minf_est; q.maxf = maxf; q.rmin = rmin; q.rmax = rmax;
             q.tols = 1e-4; q.tolp = .8; q.kd = kd; q.ld = -1; q.nit = c.nit; q.kit = c.kit; q.nred = nred; q.mred = 10;
@@ -407,13 +374,10 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 __syncthreads();
                 lb_project(n, x, ix, xl, xu, eps9);
                 __syncthreads();
-                PROF(5);
                 LB_EVAL(1, resume_linesearch, q.f);
-                PROF(6);
                 if (P.ftrace && tid == 0 && nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + nevals] = q.f;
                 ++nevals; ++c.nfg;
                 q.p = MDOT(gf, s);
-                PROF(7);
             }
             fval = q.f; p = q.p; kd = q.kd; nred = q.nred; maxst = q.maxst; c.iters = q.iters;
             if (c.iters <= 0) {                                              /* zero step: restore and restart */
@@ -454,14 +418,11 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 }
             }
         }
-        PROF(8);
         for (int i = tid; i < n; i += LB_T) if (ix[i] < 0) ix[i] = -ix[i];   /* mxvine */
         __syncthreads();
         lb_add_active(n, x, ix, xl, xu);
         __syncthreads();
-        PROF(9);
     }
-    PROF_STORE;
     if (tid == 0) {
         out[inst].f = fval; out[inst].ret = lb_result_of_iterm(c.iterm); out[inst].nevals = nevals; out[inst].iterm = c.iterm; out[inst].cols = cols;
         if (EXT) E.req[inst].state = 2;
@@ -478,6 +439,10 @@ extern "C" size_t nla_lbfgs_hist_doubles(int ld, int mf, int count) { return (si
 
 extern "C" size_t nla_lbfgs_save_bytes(void) { return sizeof(lb_saved); }
 
+extern "C" int nla_lbfgs_resident_supported(int obj, int n, const nla_lbfgs_params *params);
+extern "C" int nla_k_lbfgs_batch_resident(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X, double *work,
+                                          double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out, void *stream);
+
 extern "C" int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
                                  double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
                                  const nla_local_ext *ext, void *stream)
@@ -487,6 +452,10 @@ extern "C" int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, cons
     nla_lbfgs_params P = *params;
     nla_local_ext E = {};
     if (P.sign == 0.) P.sign = 1.;
+    /* a device objective, n <= 4096, tree sums: the resident kernel (lbfgs_resident.hip) — the same search bit for bit;
+     * exact == 2 ("amd_lbfgs_streaming"): tree sums on THIS kernel, for the test that compares the two */
+    if (nla_lbfgs_resident_supported(obj, n, &P)) return nla_k_lbfgs_batch_resident(obj, n, ld, mf, count, lb, ub, X, work, hist, &P, out, stream);
+    if (P.exact == 2) P.exact = 0;
     if (obj == NLA_OBJ_EXTERNAL) {
         if (!ext || !ext->req || !ext->EX || !ext->EG || !ext->EF || !ext->save) return (int) hipErrorInvalidValue;
         E = *ext;

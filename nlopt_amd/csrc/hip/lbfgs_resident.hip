@@ -1,0 +1,612 @@
+/* lbfgs_resident.hip — the batched NLOPT_LD_LBFGS search (Luksan's PLIS, src/algs/luksan/plis.c:106-417) for n <= 4096 with a
+ * compiled-in device objective, tree-reduction sums: the kernel config 4 runs (G_MLSL + LD_LBFGS, Ackley n = 4096).
+ *
+ * Why a second kernel (round 4).  The phase profile of lbfgs_batch_kernel (lbfgs_kernels.hip) on the MI355X
+ * (profiles/r04_lbfgs_phase_profile_streaming.txt) showed that the Strang recurrences — the part the roofline model prices — were 20 % of a
+ * search; the rest were the short vector loops around them (project, pytrcs, pytrcd, the line search's x update ...), each 10-50 us
+ * although it moves 100 KB: the vectors lived in global memory, a thread walked its 16 coordinates with a load -> store round trip
+ * per coordinate (the compiler may not move a load above a store that might alias it), i.e. 16 dependent HBM/L2 latencies per loop;
+ * and the scalar state of the line search (some 60 doubles, uniform but held in VGPRs) pushed the kernel to 62-107 spilled registers.
+ * Here:
+ *   x and the gradient live in LDS (2 x 32 KB per workgroup, two workgroups per CU), the bound type ix as bytes in LDS;
+ *   the search direction s lives in REGISTERS for the whole search (thread t owns coordinates t, t + 256, ...: 16 values);
+ *   what stays in global memory (the history columns; xl / xu, read-only after the set-up) is loaded 16 independent loads at a time;
+ *   the scalar state (line search PS1L01, termination PYFUT1, counters) is ONE copy in LDS that thread 0 advances between two
+ *   barriers — the other threads read the few values they need (the step r, the next phase) after the barrier;
+ *   two sums that are needed at the same point share one reduction (|g|^2 with x1.g1, |s|^2 with g.s, |x|_1 with |dx|_1).
+ * Every sum keeps the summation tree of lbfgs_batch_kernel's default mode (thread-strided partials in coordinate order,
+ * xor-butterfly per wavefront, wavefronts in order), every per-element formula and the order of the scalar logic are the same:
+ * the two kernels produce bit-identical searches (tests/test_gpu_lbfgs.py::test_resident_kernel_is_the_streaming_kernel), so the
+ * parity statement of the streaming kernel carries over — sums differ from the reference's sequential ones by rounding only;
+ * "amd_exact_dot" = 1 (reference order, bit for bit) runs on lbfgs_batch_kernel.
+ *
+ * Roofline: the history stream, 32 k n bytes per iteration (k columns, two matrices, a dot and an axpy pass each) — the only
+ * HBM traffic left besides xl / xu; bound by the two dependent workgroup reductions per history column.
+ */
+#include "local_common.h"
+#include <limits.h>
+#include "../lbfgs_scalar.h"
+#include "../../../include/nlopt_amd.h"
+
+#define LR_E 16                        /* coordinates per thread */
+#define LR_NMAX (LB_T * LR_E)          /* 4096 */
+
+/* the one copy of a search's scalar state (LDS) */
+struct lr_ctl {
+    lb_ls_state lss; lb_ls_io q; lb_counters c; lb_stop ls;
+    double gmax, umax, fval, fo, p, po, gnorm, snorm, rmax, rmin, b, xtol_rel, tolg;
+    int kd, nred, maxst, xstop, nevals, k, cols, head, forced, tmo, go;
+};
+struct lr_red { double v[2][LB_W][2]; int iv[2][LB_W]; };
+enum { LR_EXIT = 1, LR_RELEASE, LR_CONTINUE, LR_STRANG, LR_STEEPEST, LR_AGAIN, LR_LS_EVAL, LR_RESTORE, LR_PYTRCD, LR_NO_STEP, LR_XTOL_ABS };
+
+#ifdef NLA_LB_PROF     /* tools/lbfgs_prof.py: per-phase device time of every search (10 ns ticks); the shipped library has none of this */
+#define LB_PROF_PHASES 12
+#define LB_PROF_CAP 4096
+__device__ unsigned long long nla_lb_prof[LB_PROF_CAP][LB_PROF_PHASES + 4];
+#define PROF_DECL unsigned long long pf_acc[LB_PROF_PHASES] = {}, pf_last = wall_clock64(), pf_iters = 0
+#define PROF(i) do { const unsigned long long pf_t = wall_clock64(); pf_acc[i] += pf_t - pf_last; pf_last = pf_t; } while (0)
+#define PROF_ITER ++pf_iters
+#define PROF_STORE do { if (tid == 0 && inst < LB_PROF_CAP) { for (int pf_i = 0; pf_i < LB_PROF_PHASES; ++pf_i) nla_lb_prof[inst][pf_i] = pf_acc[pf_i]; \
+        nla_lb_prof[inst][LB_PROF_PHASES] = pf_iters; nla_lb_prof[inst][LB_PROF_PHASES + 1] = C.nevals; nla_lb_prof[inst][LB_PROF_PHASES + 2] = C.cols; \
+        nla_lb_prof[inst][LB_PROF_PHASES + 3] = 0; } } while (0)
+extern "C" int nla_lbfgs_prof_read(unsigned long long *out, int count)
+{
+    if (count > LB_PROF_CAP) count = LB_PROF_CAP;
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(nla_lb_prof), sizeof(unsigned long long) * (LB_PROF_PHASES + 4) * (size_t) count);
+}
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_ITER
+#define PROF_STORE
+#endif
+
+/* two reductions at once, ONE barrier: the partials alternate between two LDS slots (`par`, uniform), so a wavefront may already
+ * write the next reduction's partial while a slower one still reads this one's — the next write to the SAME slot is two
+ * reductions later, behind the barrier in between, which every thread passes only after it has read this one's.  The sums are
+ * lb_block_sum's (local_common.h): xor-butterfly per wavefront, wavefronts in order; the maxima lb_block_max's. */
+template <bool MAX>
+__device__ __forceinline__ void lr_reduce2(double &a, double &b, lr_red &R, int &par)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double oa = __shfl_xor(a, m, 64), ob = __shfl_xor(b, m, 64);
+        if (MAX) { a = oa > a ? oa : a; b = ob > b ? ob : b; }
+        else { a += oa; b += ob; }
+    }
+    if ((threadIdx.x & 63) == 0) { R.v[par][threadIdx.x >> 6][0] = a; R.v[par][threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    a = R.v[par][0][0]; b = R.v[par][0][1];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) {
+        const double oa = R.v[par][w][0], ob = R.v[par][w][1];
+        if (MAX) { a = oa > a ? oa : a; b = ob > b ? ob : b; }
+        else { a += oa; b += ob; }
+    }
+    par ^= 1;
+}
+template <bool MAX>
+__device__ __forceinline__ double lr_reduce1(double a, lr_red &R, int &par)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const double oa = __shfl_xor(a, m, 64); if (MAX) a = oa > a ? oa : a; else a += oa; }
+    if ((threadIdx.x & 63) == 0) R.v[par][threadIdx.x >> 6][0] = a;
+    __syncthreads();
+    a = R.v[par][0][0];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) { const double oa = R.v[par][w][0]; if (MAX) a = oa > a ? oa : a; else a += oa; }
+    par ^= 1;
+    return a;
+}
+__device__ __forceinline__ int lr_reduce_isum(int a, lr_red &R, int &par)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+    if ((threadIdx.x & 63) == 0) R.iv[par][threadIdx.x >> 6] = a;
+    __syncthreads();
+    a = R.iv[par][0];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) a += R.iv[par][w];
+    par ^= 1;
+    return a;
+}
+
+/* objective and gradient of the point in LDS (x -> g), the formulas and the summation tree of lb_objgrad (local_common.h) */
+template <int OBJ>
+__device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, lr_red &R, int &par, double sign)
+{
+    const int tid = threadIdx.x;
+    nla_obj_part t = nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, tid, LB_T, [&](int i) { return x[i]; }));
+    if ((tid & 63) == 0) { R.v[par][tid >> 6][0] = t.a; R.v[par][tid >> 6][1] = t.b; }
+    __syncthreads();
+    t.a = R.v[par][0][0]; t.b = R.v[par][0][1];
+#pragma unroll
+    for (int w = 1; w < LB_W; ++w) { nla_obj_part o; o.a = R.v[par][w][0]; o.b = R.v[par][w][1]; t = nla_obj_combine<OBJ>(t, o); }
+    par ^= 1;
+    double f = nla_obj_finish<OBJ>(n, t, [&](int i) { return x[i]; });
+    if (OBJ == NLA_OBJ_RASTRIGIN) {
+        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) g[i] = 2 * x[i] + 10.0 * NLA_PI2 * sin(NLA_PI2 * x[i]);
+    } else if (OBJ == NLA_OBJ_ACKLEY) {
+        const double r = sqrt(t.a / (unsigned) n), e1 = exp(-0.2 * r), e2 = exp(t.b / (unsigned) n);
+        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) {
+            double gi = e2 * NLA_PI2 * sin(NLA_PI2 * x[i]) / (unsigned) n;
+            if (r > 0) gi += 4.0 * e1 * x[i] / ((unsigned) n * r);
+            g[i] = gi;
+        }
+    } else if (OBJ == NLA_OBJ_GRIEWANK) {
+        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) {
+            const double sq = sqrt(i + 1.);
+            g[i] = x[i] * 0.0005 + t.b * tan(x[i] / sq) / sq;
+        }
+    } else if (OBJ == NLA_OBJ_ROSENBROCK) {
+        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) {
+            double gi = 0;
+            if (i > 0) { const double a = x[i] - x[i - 1] * x[i - 1]; gi = 200 * a; }
+            if (i + 1 < n) { const double a = x[i + 1] - x[i] * x[i], b = 1 - x[i]; gi += -400 * a * x[i] - 2 * b; }
+            g[i] = gi;
+        }
+    } else if (OBJ == NLA_OBJ_LEVY) {
+        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) {
+            double gi = 0;
+            if (i == 0) gi = 2 * NLA_PI3 * sin(NLA_PI3 * x[0]) * cos(NLA_PI3 * x[0]);
+            if (i == n - 1) {
+                const double a = x[n - 1] - 1, b = 1 + nla_sqr(sin(NLA_PI2 * x[n - 1]));
+                gi += b + a * 2 * NLA_PI2 * sin(NLA_PI2 * x[n - 1]) * cos(NLA_PI2 * x[n - 1]);
+            }
+            if (i + 1 < n) { const double a = x[i] - 1, b = 1 + nla_sqr(sin(NLA_PI3 * x[i + 1])); gi += 2 * a * b; }
+            if (i > 0) { const double a = x[i - 1] - 1; gi += 2 * NLA_PI3 * nla_sqr(a) * sin(NLA_PI3 * x[i]) * cos(NLA_PI3 * x[i]); }
+            g[i] = gi;
+        }
+    } else {
+        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) g[i] = 2 * x[i];
+    }
+    if (sign < 0) {
+        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) g[i] = -g[i];
+        f = -f;
+    }
+    __syncthreads();            /* every thread has read its neighbours' x: the point may change again */
+    return f;
+}
+
+/* thread 0, when PS1L01 reports the line search finished (q.isys == 0): take its results over (plis.c:395-403) */
+__device__ __forceinline__ int lr_line_search_finished(lr_ctl &C)
+{
+    C.fval = C.q.f; C.p = C.q.p; C.kd = C.q.kd; C.nred = C.q.nred; C.maxst = C.q.maxst; C.c.iters = C.q.iters;
+    if (C.c.iters <= 0) { C.fval = C.fo; C.p = C.po; C.c.irest = LB_MAX(C.c.irest, 1); return LR_RESTORE; }      /* zero step: restore and restart */
+    return LR_PYTRCD;
+}
+
+#define LR_FOR(e) _Pragma("unroll") for (int e = 0; e < LR_E; ++e)
+#define LR_I(e) (tid + (unsigned) (e) * LB_T)          /* coordinate e of this thread */
+
+/* Global memory goes through BUFFER instructions: one descriptor (4 SGPRs: base, size) per vector, the thread's byte offset
+ * tid * 8 in ONE VGPR for every access of the kernel, the coordinate's 2 KB stride in the scalar offset.  The plain-pointer form
+ * made the compiler keep a 64-bit address per (vector, coordinate) alive across the whole search loop — ~130 VGPRs of hoisted
+ * addresses, which it then spilled (round 4, first version of this kernel: 256 VGPRs + 500 B of scratch per lane).  The descriptor's
+ * size is the vector's n * 8 bytes: a coordinate >= n loads 0.0 and its store is dropped by the hardware's bounds check, so
+ * the loops need no `i < n` branches (coordinates >= n carry x = g = 0 and the bound type "fixed" in LDS: they add +0.0). */
+#ifdef NLA_SIMT_EMU
+struct lr_buf { char *base; unsigned bytes; };
+static inline lr_buf lr_make_buf(const void *p, unsigned bytes) { lr_buf b = { (char *) p, bytes }; return b; }
+static inline double lr_bload(lr_buf b, unsigned voff, unsigned soff) { double v = 0.; if (voff + soff + 8 <= b.bytes) memcpy(&v, b.base + voff + soff, 8); return v; }
+static inline void lr_bstore(double v, lr_buf b, unsigned voff, unsigned soff) { if (voff + soff + 8 <= b.bytes) memcpy(b.base + voff + soff, &v, 8); }
+#define LR_UNIFORM(x) (x)
+#define LR_SCHED_FENCE() do { } while (0)
+#else
+typedef __amdgpu_buffer_rsrc_t lr_buf;
+typedef unsigned lr_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lr_buf lr_make_buf(const void *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *) p, 0, bytes, 0x00020000); }
+__device__ __forceinline__ double lr_bload(lr_buf b, unsigned voff, unsigned soff) { return __builtin_bit_cast(double, (lr_v2u) __builtin_amdgcn_raw_buffer_load_b64(b, voff, soff, 0)); }
+__device__ __forceinline__ void lr_bstore(double v, lr_buf b, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lr_v2u, v), b, voff, soff, 0); }
+/* the instruction scheduler may not move anything across this point: a refill of a column array must stay BEHIND the last use of
+ * the values it replaces, or the compiler needs a second set of registers for the array (and copies it every iteration) */
+#define LR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define LR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)          /* a workgroup-uniform value read from LDS: tell the compiler (scalar branches, scalar address arithmetic) */
+#endif
+#define LR_LD(buf, e) lr_bload(buf, voff, (unsigned) (e) * (LB_T * 8u))
+#define LR_ST(v, buf, e) lr_bstore(v, buf, voff, (unsigned) (e) * (LB_T * 8u))
+
+template <int OBJ>
+__global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbfgs_resident_kernel(
+    int n, int ld, int mf, int count, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ X,
+    double *__restrict__ work, double *__restrict__ hist, nla_lbfgs_params P, nla_lbfgs_result *__restrict__ out)
+{
+    /* one LDS block with the scalar state FIRST: its fields then sit at small constant addresses (ds instructions carry a 16-bit
+     * offset); behind the 64 KB of vectors every field needed an address register of its own, which the compiler kept alive
+     * across the whole search and spilled */
+    __shared__ struct { lr_ctl C; lr_red R; signed char six[LR_NMAX]; double sx[LR_NMAX], sg[LR_NMAX]; } L;
+    lr_ctl &C = L.C;
+    lr_red &R = L.R;
+    signed char *const six = L.six;
+    double *const sx = L.sx, *const sg = L.sg;
+    const int inst = blockIdx.x;
+    const unsigned tid = threadIdx.x, voff = tid * 8u, nbytes = (unsigned) n * 8u;
+    if (inst >= count) return;
+    double *xl = work + (size_t) inst * 4 * ld + 2 * (size_t) ld, *xu = xl + ld;     /* the layout of lbfgs_batch_kernel's `work` */
+    double *hx = hist + (size_t) inst * 2 * (size_t) mf * ld, *hg = hx + (size_t) mf * ld;
+    double *ucol = work + (size_t) count * 4 * ld + (size_t) inst * 2 * mf, *vcol = ucol + mf;
+    const lr_buf bxl = lr_make_buf(xl, nbytes), bxu = lr_make_buf(xu, nbytes);
+    const double eta9 = 1e120, eps8 = 1., eps9 = 1e-8, alf1 = 1e-10, alf2 = 1e10, told = 1e-4, xmax = 1e16, maxf = 1e20, minf_est = -HUGE_VAL;
+    int par = 0, go;
+    double sr[LR_E];                    /* the search direction, this thread's coordinates */
+    PROF_DECL;
+    /* column "i-th newest" of the ring (the reference shifts all columns every iteration, mxdrsu, mssubs.c:503-524); head < mf, i <= mf */
+#define COLIDX(h, i) ((h) + (i) - 1 < mf ? (h) + (i) - 1 : (h) + (i) - 1 - mf)
+#define COLX(h, i) lr_make_buf(hx + (size_t) COLIDX(h, i) * ld, nbytes)
+#define COLG(h, i) lr_make_buf(hg + (size_t) COLIDX(h, i) * ld, nbytes)
+#define COLU(h, i) (ucol[COLIDX(h, i)])
+    /* pcbs04 (DO_PROJECT != 0) then pyadc0 (DO_PROJECT < 2) on this thread's coordinates (both touch one coordinate at a time: no
+     * barrier between them) */
+#define LR_PROJECT_AND_ACTIVATE(DO_PROJECT) do {                                                                             \
+        double l_[LR_E], u_[LR_E];                                                                                          \
+        LR_FOR(e) { l_[e] = LR_LD(bxl, e); u_[e] = LR_LD(bxu, e); }                                                         \
+        LR_FOR(e) {                                                                                                         \
+            const unsigned i = LR_I(e);                                                                                     \
+            int ii = six[i], t = ii < 0 ? -ii : ii;                                                                         \
+            double v = sx[i];                                                                                               \
+            if (DO_PROJECT) {                                                                                               \
+                if ((t == 1 || t == 3 || t == 4) && v <= l_[e] + eps9 * LB_MAX(fabs(l_[e]), 1.)) v = l_[e];                \
+                if ((t == 2 || t == 3 || t == 4) && v >= u_[e] - eps9 * LB_MAX(fabs(u_[e]), 1.)) v = u_[e];                \
+            }                                                                                                               \
+            if (DO_PROJECT < 2) {                                                                                           \
+                if (t >= 5) ii = -t;                                                                                        \
+                else if ((t == 1 || t == 3 || t == 4) && v <= l_[e]) { v = l_[e]; ii = (t == 4) ? -3 : -t; }                \
+                else if ((t == 2 || t == 3 || t == 4) && v >= u_[e]) { v = u_[e]; ii = (t == 3) ? -4 : -t; }                \
+                six[i] = (signed char) ii;                                                                                  \
+            }                                                                                                               \
+            sx[i] = v;                                                                                                      \
+        }                                                                                                                   \
+    } while (0)
+
+    {                                                                        /* plis.c:463-469, 232-241 */
+        const lr_buf blb = lr_make_buf(lb, nbytes), bub = lr_make_buf(ub, nbytes), bX = lr_make_buf(X + (size_t) inst * ld, nbytes);
+        const lr_buf bx1 = lr_make_buf(hx, nbytes), bg1 = lr_make_buf(hg, nbytes);
+        double l0[LR_E], u0[LR_E], x0[LR_E];
+        LR_FOR(e) { l0[e] = LR_LD(blb, e); u0[e] = LR_LD(bub, e); x0[e] = LR_LD(bX, e); }
+        LR_FOR(e) {
+            const unsigned i = LR_I(e);
+            const int lbu = l0[e] <= -0.99 * HUGE_VAL, ubu = u0[e] >= 0.99 * HUGE_VAL;
+            int t = lbu ? (ubu ? 0 : 2) : (ubu ? 1 : (l0[e] == u0[e] ? 5 : 3));
+            double l = l0[e], u = u0[e];
+            if ((t == 3 || t == 4) && u <= l) { u = l; t = 5; }
+            else if (t == 5 || t == 6) { l = x0[e]; u = x0[e]; t = 5; }
+            if (i >= (unsigned) n) { t = -5; x0[e] = 0.; }                  /* no such coordinate: x = g = 0, "fixed" — every loop below passes over it */
+            six[i] = (signed char) t; sx[i] = x0[e]; sg[i] = 0.; sr[e] = 0.;
+            LR_ST(l, bxl, e); LR_ST(u, bxu, e);
+            LR_ST(0., bx1, e); LR_ST(0., bg1, e);      /* the reference zero-fills xo (plis.c:475); column 1 is read before it is written */
+        }
+    }
+    if (tid == 0) {
+        memset(&C, 0, sizeof C);
+        C.xtol_rel = P.xtol_rel <= 0. ? 1e-16 : P.xtol_rel;                  /* plis.c:202-214 */
+        C.tolg = P.tolg <= 0. ? 1e-8 : P.tolg;
+        C.ls.minf_max = P.minf_max; C.ls.ftol_rel = P.ftol_rel <= 0. ? 1e-14 : P.ftol_rel; C.ls.ftol_abs = P.ftol_abs; C.ls.maxeval = P.maxeval;
+        C.fo = minf_est; C.rmax = eta9; C.kd = 1;
+        C.c.ites = 1; C.c.mtesx = 2; C.c.mtesf = 2; C.c.iters = 2; C.c.ires1 = 999; C.c.ires2 = 0; C.c.kd = 1;
+        C.c.mit = INT_MAX; C.c.mfg = P.maxeval > 0 ? P.maxeval : INT_MAX;
+        C.c.kit = -(C.c.ires1 * n + C.c.ires2);
+    }
+    LR_PROJECT_AND_ACTIVATE(1);
+    __syncthreads();
+    PROF(0);
+    {
+        const double f = lr_objgrad<OBJ>(n, sx, sg, R, par, P.sign);
+        if (tid == 0) {
+            C.fval = f;
+            if (P.ftrace && C.nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + C.nevals] = f;
+            ++C.nevals; ++C.c.nfg;
+            if (P.abort && *(const volatile int32_t *) P.abort == 100) { C.tmo = 1; C.c.iterm = 100; }     /* plis.c:263 */
+        }
+    }
+    PROF(6);
+
+    for (;;) {
+        PROF_ITER;
+        /* pytrcg: largest free gradient component, largest wrong-signed multiplier on an active bound */
+        {
+            double gm = 0, um = 0;
+            LR_FOR(e) {
+                const double t = sg[LR_I(e)];
+                const int ii = six[LR_I(e)];
+                if (ii >= 0) gm = LB_MAX(gm, fabs(t));
+                else if (ii <= -5) { }
+                else if (ii == -1 || ii == -3) { if (-t > um) um = -t; }
+                else if (ii == -2 || ii == -4) { if (t > um) um = t; }
+            }
+            lr_reduce2<true>(gm, um, R, par);
+            if (tid == 0) {
+                int g_ = LR_CONTINUE;
+                if (C.c.iterm == 100) g_ = LR_EXIT;                          /* the time limit hit during the first evaluation */
+                else {
+                    C.gmax = gm; C.umax = um; C.c.kd = C.kd;
+                    if (P.abort) { const int ab = *(const volatile int32_t *) P.abort; C.forced = ab == -999; C.tmo = ab == 100; }
+                    lb_pyfut1(n, C.fval, &C.fo, um, gm, C.xstop, &C.ls, C.forced, C.nevals, C.tolg, &C.c);
+                    if (C.c.iterm != 0) g_ = LR_EXIT;
+                    else if (C.tmo) { C.c.iterm = 100; g_ = LR_EXIT; }       /* plis.c:273 */
+                    else if (C.rmax > 0. && um > eps8 * gm) g_ = LR_RELEASE;
+                }
+                C.go = g_;
+            }
+            __syncthreads();
+            go = LR_UNIFORM(C.go);
+        }
+        if (go == LR_EXIT) break;
+        if (go == LR_RELEASE) {                                              /* pyrmc0: release wrong-signed active bounds */
+            int rel = 0;
+            LR_FOR(e) {
+                const int t = six[LR_I(e)];
+                if (t >= 0 || t <= -5) continue;
+                if ((t == -1 || t == -3) && -sg[LR_I(e)] <= 0.) continue;
+                if ((t == -2 || t == -4) && sg[LR_I(e)] <= 0.) continue;
+                ++rel;
+                six[LR_I(e)] = (signed char) LB_MIN(-t, 3);
+            }
+            rel = lr_reduce_isum(rel, R, par);
+            if (tid == 0 && rel > 1) C.c.irest = LB_MAX(C.c.irest, 1);       /* read again by thread 0 only, below */
+        }
+        PROF(1);
+    direction:
+        {
+            /* |g|^2 and x1.g1 (column 1 = the newest pair) over the free coordinates, one reduction */
+            const int head = LR_UNIFORM(C.head);
+            double cx[LR_E], cg[LR_E], gg = 0, bb = 0;
+            {
+                const lr_buf px = COLX(head, 1), pg = COLG(head, 1);
+                LR_FOR(e) { cx[e] = LR_LD(px, e); cg[e] = LR_LD(pg, e); }
+            }
+            LR_FOR(e) if (six[LR_I(e)] >= 0) { const double gv = sg[LR_I(e)]; gg += gv * gv; bb += cx[e] * cg[e]; }
+            lr_reduce2<false>(gg, bb, R, par);
+            if (tid == 0) {
+                int g_ = LR_STEEPEST;
+                C.gnorm = sqrt(gg);
+                if (C.c.irest == 0) {
+                    const int k = LB_MIN(C.c.nit - C.c.kit, mf);
+                    if (k <= 0) C.c.irest = LB_MAX(C.c.irest, 1);
+                    else if (bb <= 0.) C.c.irest = LB_MAX(C.c.irest, 1);
+                    else { COLU(head, 1) = 1. / bb; C.cols += k; C.k = k; C.b = bb; g_ = LR_STRANG; }
+                }
+                if (g_ == LR_STEEPEST) {                                      /* steepest descent */
+                    C.snorm = C.gnorm;
+                    if (C.c.kit < C.c.nit) C.c.kit = C.c.nit;
+                    else { C.c.iterm = -10; if (C.c.iters < 0) C.c.iterm = C.c.iters - 5; }
+                }
+                C.go = g_;
+            }
+            __syncthreads();
+            go = LR_UNIFORM(C.go);
+        }
+        PROF(2);
+        {
+            double ssq = 0, pp = 0;
+            unsigned live = 0;
+            LR_FOR(e) { sr[e] = 0.; if (six[LR_I(e)] >= 0) { live |= 1u << e; sr[e] = -sg[LR_I(e)]; } }       /* mxuneg */
+            if (go == LR_STRANG) {
+                /* the two Strang loops (mxdrcb / mxdrcf, mssubs.c:353-441): the next column is on its way while this one's dot
+                 * product is reduced; one barrier per column.  (A column's values on coordinates that are not free are loaded but
+                 * never used: `live` masks every sum and update, as mxudot / mxudir's ix test does.) */
+                const int head = LR_UNIFORM(C.head), k = LR_UNIFORM(C.k);
+                const double b = C.b;
+                /* two register arrays, not four: a column's x-part is dead once its dot product has been formed, its g-part once
+                 * the axpy is done — each is refilled at that point with the NEXT column's, which then has a whole iteration
+                 * (a reduction and a vector pass) to arrive */
+                double ca[LR_E], cb[LR_E], u1, un;          /* (un, vn: the next column's scalars, fetched with it) */
+#define LR_LOAD(arr, buf_) do { const lr_buf q_ = buf_; LR_FOR(e) arr[e] = LR_LD(q_, e); } while (0)
+                LR_LOAD(ca, COLX(head, 1));
+                LR_LOAD(cb, COLG(head, 1));
+                u1 = COLU(head, 1);
+                for (int j = 1; j <= k; ++j) {                       /* mxdrcb */
+                    double t = 0;
+                    LR_FOR(e) if (live & (1u << e)) t += sr[e] * ca[e];
+                    /* the refills are UNCONDITIONAL (the last iteration loads its own column once more): a conditional refill makes
+                     * "old or new" a second register array with a copy per iteration */
+                    const int jn = j < k ? j + 1 : j;
+                    LR_SCHED_FENCE();
+                    LR_LOAD(ca, COLX(head, jn)); un = COLU(head, jn);
+                    const double v = u1 * lr_reduce1<false>(t, R, par);
+                    if (tid == 0) vcol[j - 1] = v;
+                    LR_FOR(e) if (live & (1u << e)) sr[e] = sr[e] + (-v) * cb[e];
+                    LR_SCHED_FENCE();
+                    LR_LOAD(cb, COLG(head, jn));
+                    u1 = un;
+                }
+                /* ca: g of column k for the first forward dot product, on its way during the scaling; cb: g of column 1 */
+                LR_LOAD(cb, COLG(head, 1));
+                LR_LOAD(ca, COLG(head, k));
+                {
+                    double t = 0;
+                    LR_FOR(e) if (live & (1u << e)) t += cb[e] * cb[e];
+                    LR_SCHED_FENCE();
+                    LR_LOAD(cb, COLX(head, k));
+                    const double a = lr_reduce1<false>(t, R, par);
+                    if (a > 0.) { const double sc = b / a; LR_FOR(e) sr[e] = sr[e] * sc; }
+                }
+                u1 = COLU(head, k);
+                double v1 = vcol[k - 1], vn;
+                for (int j = k; j >= 1; --j) {                       /* mxdrcf */
+                    double t = 0;
+                    LR_FOR(e) if (live & (1u << e)) t += sr[e] * ca[e];
+                    const int jp = j > 1 ? j - 1 : j;
+                    LR_SCHED_FENCE();
+                    LR_LOAD(ca, COLG(head, jp)); un = COLU(head, jp); vn = vcol[jp - 1];
+                    const double tt = u1 * lr_reduce1<false>(t, R, par);
+                    const double w = v1 - tt;
+                    LR_FOR(e) if (live & (1u << e)) sr[e] = sr[e] + w * cb[e];
+                    LR_SCHED_FENCE();
+                    LR_LOAD(cb, COLX(head, jp));
+                    u1 = un; v1 = vn;
+                }
+                LR_FOR(e) if (live & (1u << e)) ssq += sr[e] * sr[e];
+            }
+            PROF(3);
+            LR_FOR(e) if (live & (1u << e)) pp += sg[LR_I(e)] * sr[e];
+            lr_reduce2<false>(ssq, pp, R, par);
+            if (tid == 0) {
+                int g_ = LR_CONTINUE;
+                if (go == LR_STRANG) { C.snorm = sqrt(ssq); C.head = C.head > 0 ? C.head - 1 : mf - 1; }    /* mxdrsu: every column one older */
+                if (C.kd > 0) C.p = pp;
+                if (C.snorm <= 0.) C.c.irest = LB_MAX(C.c.irest, 1);
+                else if (C.p + told * C.gnorm * C.snorm <= 0.) C.c.irest = 0;
+                else C.c.irest = LB_MAX(C.c.irest, 1);
+                if (C.c.irest == 0) {
+                    C.nred = 0;
+                    C.rmin = alf1 * C.gnorm / C.snorm;
+                    C.rmax = LB_MIN(alf2 * C.gnorm / C.snorm, xmax / C.snorm);
+                }
+                if (C.c.iterm != 0) g_ = LR_EXIT;
+                else if (C.tmo) { C.c.iterm = 100; g_ = LR_EXIT; }                               /* plis.c:371 */
+                else if (C.c.irest != 0) g_ = LR_AGAIN;
+                else { C.q.fp = C.fo; C.fo = C.fval; C.po = C.p; }
+                C.go = g_;
+            }
+            __syncthreads();
+            go = LR_UNIFORM(C.go);
+        }
+        if (go == LR_EXIT) break;
+        if (go == LR_AGAIN) goto direction;
+        /* pytrcs: save x, g in column 1; zero s on active bounds; largest step inside the box */
+        {
+            const int head = LR_UNIFORM(C.head);
+            const lr_buf cx = COLX(head, 1), cg = COLG(head, 1);
+            double rm = C.rmax, l_[LR_E], u_[LR_E];
+            LR_FOR(e) { l_[e] = LR_LD(bxl, e); u_[e] = LR_LD(bxu, e); }
+            LR_FOR(e) {
+                const unsigned i = LR_I(e);
+                const int ii = six[i];
+                const double xv = sx[i];
+                LR_ST(xv, cx, e); LR_ST(sg[i], cg, e);
+                if (ii < 0) sr[e] = 0.;
+                else {
+                    if ((ii == 1 || ii >= 3) && sr[e] < -1. / eta9) rm = LB_MIN(rm, (l_[e] - xv) / sr[e]);
+                    if ((ii == 2 || ii >= 3) && sr[e] > 1. / eta9) rm = LB_MIN(rm, (u_[e] - xv) / sr[e]);
+                }
+                if ((e & 3) == 3) LR_SCHED_FENCE();      /* four coordinates' divisions in flight, not all 32 (registers) */
+            }
+            rm = -lr_reduce1<true>(-rm, R, par);
+            if (tid == 0) {
+                int g_ = LR_NO_STEP;
+                C.rmax = rm;
+                if (rm != 0.) {
+                    lb_ls_io *q = &C.q;
+                    q->f = C.fval; q->fo = C.fo; q->p = C.p; q->po = C.po; q->minf_est = minf_est; q->maxf = maxf; q->rmin = C.rmin; q->rmax = rm;
+                    q->tols = 1e-4; q->tolp = .8; q->kd = C.kd; q->ld = -1; q->nit = C.c.nit; q->kit = C.c.kit; q->nred = C.nred; q->mred = 10;
+                    q->maxst = C.maxst; q->iest = 0; q->inits = 2; q->iters = C.c.iters; q->kters = 3; q->mes = 4; q->isys = 0;
+                    lb_ps1l01(q, &C.lss);
+                    g_ = q->isys == 0 ? lr_line_search_finished(C) : LR_LS_EVAL;
+                }
+                C.go = g_;
+            }
+            __syncthreads();
+            go = LR_UNIFORM(C.go);
+        }
+        PROF(4);
+        while (go == LR_LS_EVAL) {
+            {
+                const int head = LR_UNIFORM(C.head);
+                const double r = C.q.r;
+                const lr_buf xs = COLX(head, 1);
+                double xo[LR_E];
+                LR_FOR(e) xo[e] = LR_LD(xs, e);
+                LR_FOR(e) if (six[LR_I(e)] >= 0) sx[LR_I(e)] = xo[e] + r * sr[e];
+            }
+            LR_PROJECT_AND_ACTIVATE(2);
+            __syncthreads();
+            PROF(5);
+            const double f = lr_objgrad<OBJ>(n, sx, sg, R, par, P.sign);
+            PROF(6);
+            double pp = 0;
+            LR_FOR(e) if (six[LR_I(e)] >= 0) pp += sg[LR_I(e)] * sr[e];
+            pp = lr_reduce1<false>(pp, R, par);
+            if (tid == 0) {
+                int g_ = LR_LS_EVAL;
+                C.q.f = f;
+                if (P.ftrace && C.nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + C.nevals] = f;
+                ++C.nevals; ++C.c.nfg;
+                C.q.p = pp;
+                lb_ps1l01(&C.q, &C.lss);
+                if (C.q.isys == 0) g_ = lr_line_search_finished(C);
+                C.go = g_;
+            }
+            __syncthreads();
+            go = LR_UNIFORM(C.go);
+            PROF(7);
+        }
+        if (go == LR_RESTORE) {
+            const int head = LR_UNIFORM(C.head);
+            const lr_buf cx = COLX(head, 1), cg = COLG(head, 1);
+            double a_[LR_E], b_[LR_E];
+            LR_FOR(e) { a_[e] = LR_LD(cx, e); b_[e] = LR_LD(cg, e); }
+            LR_FOR(e) { sx[LR_I(e)] = a_[e]; sg[LR_I(e)] = b_[e]; }
+            __syncthreads();
+            goto direction;
+        }
+        if (go == LR_PYTRCD) {
+            /* pytrcd: column 1 := differences (zero on active coordinates); nlopt_stop_dx(x, dx) */
+            const int head = LR_UNIFORM(C.head);
+            const lr_buf dx = COLX(head, 1), dg = COLG(head, 1);
+            double nx = 0, ndx = 0, a_[LR_E], b_[LR_E];
+            LR_FOR(e) { a_[e] = LR_LD(dx, e); b_[e] = LR_LD(dg, e); }
+            LR_FOR(e) {
+                const unsigned i = LR_I(e);
+                double ddx = sx[i] - a_[e], ddg = sg[i] - b_[e];
+                if (six[i] < 0) { ddx = 0.; ddg = 0.; }
+                LR_ST(ddx, dx, e); LR_ST(ddg, dg, e);
+                a_[e] = ddx;
+            }
+            if (P.x_weights) {                                                /* nlopt_stop_dx's weighted norms (stop.c:37-57) */
+                const lr_buf bw = lr_make_buf(P.x_weights, nbytes);
+                LR_FOR(e) { const double w = LR_LD(bw, e); nx += w * fabs(sx[LR_I(e)]); ndx += w * fabs(a_[e]); }
+            } else LR_FOR(e) { nx += fabs(sx[LR_I(e)]); ndx += fabs(a_[e]); }
+            lr_reduce2<false>(nx, ndx, R, par);
+            if (tid == 0) {
+                C.po = C.q.r * C.po; C.p = C.q.r * C.p;
+                C.xstop = ndx < C.xtol_rel * nx;                              /* nlopt_stop_dx, stop.c:110-120 */
+                C.go = (!C.xstop && P.xtol_abs) ? LR_XTOL_ABS : LR_CONTINUE;
+            }
+            __syncthreads();
+            if (LR_UNIFORM(C.go) == LR_XTOL_ABS) {
+                const lr_buf bt = lr_make_buf(P.xtol_abs, nbytes);
+                int viol = 0;
+                LR_FOR(e) { const double ta = LR_LD(bt, e); if (LR_I(e) < (unsigned) n) viol += fabs(a_[e]) >= ta; }
+                viol = lr_reduce_isum(viol, R, par);
+                if (tid == 0) C.xstop = viol == 0;                            /* read by thread 0 only (pyfut1) */
+            }
+        }
+        PROF(8);
+        LR_FOR(e) if (six[LR_I(e)] < 0) six[LR_I(e)] = (signed char) -six[LR_I(e)];       /* mxvine */
+        LR_PROJECT_AND_ACTIVATE(0);
+        PROF(9);
+    }
+    {
+        const lr_buf bX = lr_make_buf(X + (size_t) inst * ld, nbytes);
+        LR_FOR(e) LR_ST(sx[LR_I(e)], bX, e);
+    }
+    PROF_STORE;
+    if (tid == 0) {
+        out[inst].f = C.fval; out[inst].ret = lb_result_of_iterm(C.c.iterm); out[inst].nevals = C.nevals; out[inst].iterm = C.c.iterm; out[inst].cols = C.cols;
+    }
+#undef COLX
+#undef COLG
+#undef COLU
+#undef COLIDX
+}
+
+extern "C" int nla_lbfgs_resident_supported(int obj, int n, const nla_lbfgs_params *params)
+{
+    return obj >= 0 && n <= LR_NMAX && params->exact == 0;
+}
+
+extern "C" int nla_k_lbfgs_batch_resident(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
+                                          double *work, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out, void *stream)
+{
+    if (count <= 0) return 0;
+    hipStream_t st = (hipStream_t) stream;
+    nla_lbfgs_params P = *params;
+    if (P.sign == 0.) P.sign = 1.;
+    if (!nla_lbfgs_resident_supported(obj, n, &P)) return (int) hipErrorInvalidValue;
+#define CALL(O) hipLaunchKernelGGL((lbfgs_resident_kernel<O>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out)
+    NLA_OBJ_DISPATCH(obj, CALL)
+#undef CALL
+    NLA_LAUNCH_CHECK();
+    return 0;
+}

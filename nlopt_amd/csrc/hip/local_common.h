@@ -5,7 +5,9 @@
 #define NLA_LOCAL_COMMON_H
 #include "dev_common.h"
 
-#define LB_T 256
+#ifndef LB_T
+#define LB_T 256                  /* (tools/simt_emu builds may shrink the workgroup: -DLB_T=128) */
+#endif
 #define LB_W (LB_T / 64)
 
 struct lb_shared {

@@ -161,6 +161,9 @@ int nla_exact_mode(nlopt_opt opt) { return opt && nlopt_get_param(opt, "amd_exac
 int nla_exact_mode_for(nlopt_opt opt, nlopt_opt also, const nla_evaluator *ev)
 {
     const int set_a = opt && nlopt_has_param(opt, "amd_exact_dot"), set_b = also && nlopt_has_param(also, "amd_exact_dot");
-    if (set_a || set_b) return (set_a && nla_exact_mode(opt)) || (set_b && nla_exact_mode(also));
-    return ev && ev->kind == NLA_EVAL_HOST;
+    int exact = (set_a || set_b) ? ((set_a && nla_exact_mode(opt)) || (set_b && nla_exact_mode(also))) : (ev && ev->kind == NLA_EVAL_HOST);
+    /* "amd_lbfgs_streaming" != 0: LD_LBFGS with tree sums on the streaming kernel (hip/lbfgs_kernels.hip) instead of the resident one
+     * (hip/lbfgs_resident.hip) — the two are bit-identical, which is what the switch exists to show (tests/test_gpu_lbfgs.py) */
+    if (!exact && ((opt && nlopt_get_param(opt, "amd_lbfgs_streaming", 0) != 0) || (also && nlopt_get_param(also, "amd_lbfgs_streaming", 0) != 0))) return 2;
+    return exact;
 }

@@ -95,3 +95,73 @@ def test_lbfgs_host_callback_is_served():
     o.set_ftol_rel(1e-12)
     x, minf, ret = o.optimize_raw(np.full(3, 0.5))
     assert ret > 0 and minf < 1e-20 and np.allclose(x, 0.25) and o.get_numevals() == len(calls) >= 2
+
+
+# ---- the two batch kernels against each other, at the kernel-level C-ABI -------------------------------------------------------
+class _Params(C.Structure):
+    _fields_ = [("minf_max", C.c_double), ("ftol_rel", C.c_double), ("ftol_abs", C.c_double), ("xtol_rel", C.c_double), ("tolg", C.c_double),
+                ("maxeval", C.c_int32), ("exact", C.c_int32), ("sign", C.c_double), ("xtol_abs", C.c_void_p), ("x_weights", C.c_void_p),
+                ("abort", C.c_void_p), ("ftrace", C.c_void_p), ("ftrace_cap", C.c_int64)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("f", C.c_double), ("ret", C.c_int32), ("nevals", C.c_int32), ("iterm", C.c_int32), ("cols", C.c_int32)]
+
+
+def _batch(streaming, obj, n, starts, lov, hiv, mf, ftol_rel=1e-8, maxeval=0, sign=1.0, xtol_abs=None, weights=None, cap=1500):
+    """nla_k_lbfgs_batch on `starts` (count x n): exact = 2 keeps the tree sums on the streaming kernel (lbfgs_kernels.hip), exact = 0
+    takes the resident kernel (lbfgs_resident.hip) where it applies"""
+    L = nlopt_amd.lib()
+    D = nlopt_amd.DevBuf
+    count, ld = starts.shape[0], (n + 1) & ~1
+    X = np.zeros((count, ld)); X[:, :n] = starts
+    dX, dlb, dub = D.from_array(X), D.from_array(lov), D.from_array(hiv)
+    dwork = D.from_array(np.zeros(count * (4 * ld + 2 * mf)))
+    diw, dhist = D.from_array(np.zeros(count * ld, dtype=np.int32)), D.from_array(np.full(count * 2 * mf * ld, np.nan))
+    dft, dres = D.from_array(np.full(count * cap, np.nan)), D(C.sizeof(_Result) * count)
+    dta = D.from_array(xtol_abs) if xtol_abs is not None else None
+    dw = D.from_array(weights) if weights is not None else None
+    P = _Params(-np.inf, ftol_rel, 0.0, 0.0, 0.0, maxeval, 2 if streaming else 0, sign, dta.ptr if dta else None, dw.ptr if dw else None, None, dft.ptr, cap)
+    vp = C.c_void_p
+    L.nla_k_lbfgs_batch.argtypes = [C.c_int] * 5 + [vp] * 6 + [C.POINTER(_Params), vp, vp, vp]
+    assert L.nla_k_lbfgs_batch(nlopt_amd.OBJECTIVES[obj], n, ld, mf, count, dlb.ptr, dub.ptr, dX.ptr, dwork.ptr, diw.ptr, dhist.ptr, C.byref(P),
+                               dres.ptr, None, None) == 0 and L.nla_stream_sync(None) == 0
+    res = np.frombuffer(dres.to_array(np.uint8, C.sizeof(_Result) * count).tobytes(), dtype=[("f", "f8"), ("ret", "i4"), ("nevals", "i4"), ("iterm", "i4"), ("cols", "i4")])
+    out = dict(x=dX.to_array(np.float64, count * ld).reshape(count, ld)[:, :n].copy(), res=res.copy(), ftrace=dft.to_array(np.float64, count * cap).reshape(count, cap))
+    for b in (dX, dlb, dub, dwork, diw, dhist, dft, dres, dta, dw):
+        if b is not None:
+            b.free()
+    return out
+
+
+@pytest.mark.parametrize("obj,n,count,mf,kw", [
+    ("ackley", 4096, 6, 320, {}),                            # the config-4 shape
+    ("ackley", 300, 3, 400, {}), ("rastrigin", 40, 2, 5, {}), ("rosenbrock", 10, 2, 400, {}), ("griewank", 257, 2, 3, {}),
+    ("levy", 33, 2, 400, {}), ("sphere", 5, 2, 400, {}), ("rastrigin", 513, 2, 4, {}), ("rastrigin", 4095, 2, 7, {}),
+    ("ackley", 600, 2, 400, dict(maxeval=9)), ("griewank", 64, 3, 50, dict(sign=-1.0, maxeval=40)),
+    ("rastrigin", 100, 2, 30, dict(weights=True)), ("ackley", 77, 2, 30, dict(xtol_abs=True)),
+])
+def test_resident_kernel_is_the_streaming_kernel(obj, n, count, mf, kw):
+    """lbfgs_resident_kernel (x / g in LDS, direction in registers, the scalar state advanced by thread 0) must be
+    lbfgs_batch_kernel's tree-sum search BIT FOR BIT: f of every evaluation, minimiser, result code, evaluation and column counts —
+    with coordinates on their bounds from the start, a fixed coordinate, short histories that wrap, maximisation, weights,
+    xtol_abs.  (The same comparison runs on the CPU in tools/lbfgs_emu_check.py; the streaming kernel's own parity tests are above.)"""
+    rng = np.random.default_rng(n * 7 + count)
+    _, lo, hi = O.golden_x0(obj, n)
+    lov, hiv = np.full(n, lo), np.full(n, hi)
+    starts = rng.uniform(lo, hi, (count, n))
+    starts[0, : max(1, n // 7)] = hi
+    if n > 8:
+        lov[3] = hiv[3] = 0.5 * (lo + hi)
+        starts[:, 3] = lov[3]
+    kw = dict(kw)
+    if kw.pop("weights", False):
+        kw["weights"] = rng.uniform(0.5, 2.0, n)
+    if kw.pop("xtol_abs", False):
+        kw["xtol_abs"] = np.full(n, 1e-3)
+    a = _batch(True, obj, n, starts, lov, hiv, mf, **kw)
+    b = _batch(False, obj, n, starts, lov, hiv, mf, **kw)
+    assert np.array_equal(a["res"], b["res"]), (a["res"], b["res"])
+    assert np.array_equal(a["ftrace"], b["ftrace"], equal_nan=True)
+    assert np.array_equal(a["x"], b["x"])
+    assert (a["res"]["nevals"] > 1).all()
