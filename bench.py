@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("crs", "isres", "mlsl"), default="crs")
+    ap.add_argument("--exact", action="store_true",
+                    help="mlsl: the local optimiser sums in the reference's order (\"amd_exact_dot\" = 1: iterates bit-identical to the reference's); default: workgroup tree sums")
     ap.add_argument("--local", choices=("lbfgs", "mma"), default="lbfgs",
                     help="mlsl: lbfgs = G_MLSL_LDS with an explicit LD_LBFGS (config 4); mma = GD_MLSL_LDS with its default local optimiser LD_MMA")
     ap.add_argument("--n", type=int, default=0)
@@ -133,22 +135,23 @@ def cpu_baseline_crs(obj, n, pop_sample, trials, seed):
 
 
 def cpu_baseline_isres(obj, n, pop_sample, seed, ncon=4):
-    """ISRES on the CPU is dominated by the O(pop^2) stochastic ranking (isres.c:207-228), so evals/s falls ~1/pop:
-    the sample runs 2 generations at a smaller population and reports that rate plus its pop-scaled estimate."""
+    """ISRES on the CPU is dominated by the O(pop^2) stochastic ranking (isres.c:207-228): evals/s falls ~1/pop, so a smaller
+    population says little.  The sample is ONE whole generation (evaluate, rank, evolve) of the real reference at the population
+    it is given — at the benchmark's pop = 5e4 that is ~85-110 s on one core — timed in this run on this host: maxeval = pop + 1
+    ends the run at the second evaluation of generation 2."""
     import _oracle as O
-    gens = 2
     t0 = time.perf_counter()
     if O.have_ref():
-        r = O.run_ref_isres(obj, n, pop_sample, seed, nineq=ncon, maxeval=gens * pop_sample, record=False)
+        r = O.run_ref_isres(obj, n, pop_sample, seed, nineq=ncon, maxeval=pop_sample + 1, record=False)
         kind = "reference"
     else:
-        r = O.run_port_isres(obj, n, pop_sample, seed, nineq=ncon, maxeval=gens * pop_sample, record=False)
+        r = O.run_port_isres(obj, n, pop_sample, seed, nineq=ncon, maxeval=pop_sample + 1, record=False)
         kind = "port"
     dt = time.perf_counter() - t0
-    return dict(value=r["nevals"] / dt, unit="evals/s", cores=1, kind=kind,
-                sample="NLOPT_GN_ISRES %s n=%d + %d inequality constraints at pop=%d (NOT the benchmark's pop): %d evals = %d generations "
-                       "in %.1f s, 1 thread; ranking work per generation grows as pop^2" % (obj, n, ncon, pop_sample, r["nevals"], gens, dt),
-                sample_pop=pop_sample)
+    return dict(value=pop_sample / dt, unit="evals/s", cores=1, kind=kind,
+                sample="NLOPT_GN_ISRES %s n=%d + %d inequality constraints at pop=%d: one whole generation (%d evaluations, the stochastic ranking, "
+                       "the mutation) in %.1f s, 1 thread" % (obj, n, ncon, pop_sample, pop_sample, dt),
+                sample_pop=pop_sample, seconds_per_generation=dt)
 
 
 def cpu_baseline_mlsl(obj, n, nsamples, seed, maxeval, local="lbfgs"):
@@ -573,13 +576,15 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         # cpu_baseline
         out["other_workloads"] = {}
         import copy
-        for wl, steps, warm in (("isres", 3, 1), ("mlsl", 2, 1)):
+        for key, wl, steps, warm, exact in (("isres", "isres", 3, 1, False), ("mlsl", "mlsl", 2, 1, False), ("mlsl_exact_order", "mlsl", 2, 1, True)):
             try:
                 b = copy.copy(a)
-                b.workload, b.steps, b.warmup = wl, steps, warm
+                b.workload, b.steps, b.warmup, b.exact = wl, steps, warm, exact
                 b.n, b.pop, b.obj = {"isres": (256, 50000, "rastrigin"), "mlsl": (4096, 1000, "ackley")}[wl]
                 b.local, b.cpu_sample_pop = "lbfgs", 0
-                out["other_workloads"][wl] = bench_generational(b, nlopt_amd, L, 0, 1, None, sync_all, reduce)
+                if exact:
+                    b.no_cpu_baseline = True          # the same CPU run as the default mode's line
+                out["other_workloads"][key] = bench_generational(b, nlopt_amd, L, 0, 1, None, sync_all, reduce)
             except (Exception, SystemExit) as e:
                 out["other_workloads"][wl] = {"error": repr(e)}
     if not a.no_cpu_baseline and world == 1:                  # the CPU baseline is timed on rank 0 of the 1-GPU run only
@@ -608,6 +613,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
         o = nlopt_amd.Opt(nlopt_amd.G_MLSL_LDS, n)
         loc = nlopt_amd.Opt(nlopt_amd.LD_LBFGS, n)
         loc.set_ftol_rel(1e-8)
+        if getattr(a, "exact", False):
+            loc.set_param("amd_exact_dot", 1)
         L.nlopt_set_local_optimizer(o._h, loc._h)
     o.set_lower_bounds(lo)
     o.set_upper_bounds(hi)
@@ -675,7 +682,9 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
         kern, launches = ("mma_batch_kernel" if a.local == "mma" else "lbfgs_batch_kernel"), int(d["lbfgs_launches"])
         name = "GD_MLSL_LDS + default LD_MMA" if a.local == "mma" else "G_MLSL_LDS + LD_LBFGS"
         metric = "candidate-evals/sec, %s n=%d, %d samples per iteration" % (name, n, pop)
-        wl = "NLOPT_%s(ftol_rel 1e-8) %s n=%d, %d samples/iteration, seed=%d; step = 1 MLSL iteration" % (name.replace(" + ", " + NLOPT_").replace("default ", ""), a.obj, n, pop, a.seed)
+        mode = ("amd_exact_dot=1: every sum of the local search in the reference's sequential order, iterates bit-identical to the reference's"
+                if getattr(a, "exact", False) else "default mode: workgroup tree sums in the local search, iterates equal to the reference's to rounding")
+        wl = "NLOPT_%s(ftol_rel 1e-8) %s n=%d, %d samples/iteration, seed=%d; %s; step = 1 MLSL iteration" % (name.replace(" + ", " + NLOPT_").replace("default ", ""), a.obj, n, pop, a.seed, mode)
         phases = {"sampling_s_per_iter": d["t_eval_s"] / K, "local_phase_s_per_iter": d["t_evolve_s"] / K,
                   "local_searches": int(d["accepted"]), "sample_evals": int(d["evals_trial"]), "local_evals": int(d["evals_mutation"])}
     achieved = (bytes_dom / 1e9) / t_dom if t_dom > 0 else None
@@ -704,16 +713,9 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
     if not a.no_cpu_baseline and world == 1:
         try:
             if a.workload == "isres":
-                out["cpu_baseline"] = cpu_baseline_isres(a.obj, n, a.cpu_sample_pop or 10000, a.seed, ncon)
-                out["cpu_baseline"]["estimate_at_benchmark_pop"] = out["cpu_baseline"]["value"] * out["cpu_baseline"]["sample_pop"] / pop
-                # the reference timed AT the benchmark's population is a 3-minute job (the ranking is O(pop^2) on one core): measured once,
-                # committed, and quoted here with its label — not timed in this run, not on this host
-                oc = os.path.join(ROOT, "profiles", "r03_isres_cpu_at_pop.json")
-                if (n, pop, a.obj, ncon) == (256, 50000, "rastrigin", 4) and os.path.exists(oc):
-                    rec = json.load(open(oc))
-                    out["cpu_baseline"]["on_config_committed"] = {k: rec[k] for k in ("evals_per_s", "seconds_per_full_generation", "machine", "what", "cores", "kind")}
-                    out["cpu_baseline"]["on_config_committed"]["source"] = "profiles/r03_isres_cpu_at_pop.json (NOT measured in this run)"
-                    out["speedup_vs_cpu_on_config_committed"] = out["value"] / rec["evals_per_s"]
+                out["cpu_baseline"] = cpu_baseline_isres(a.obj, n, a.cpu_sample_pop or pop, a.seed, ncon)
+                if out["cpu_baseline"]["sample_pop"] != pop:
+                    out["cpu_baseline"]["estimate_at_benchmark_pop"] = out["cpu_baseline"]["value"] * out["cpu_baseline"]["sample_pop"] / pop
             else:
                 out["cpu_baseline"] = cpu_baseline_mlsl(a.obj, n, pop, a.seed, 30000, a.local)
             if out["cpu_baseline"]["value"]:

@@ -112,12 +112,43 @@ __device__ __forceinline__ int lr_reduce_isum(int a, lr_red &R, int &par)
     return a;
 }
 
+/* sin and cos of one argument at once: Ackley and Rastrigin need cos(2 pi x) for f and sin(2 pi x) for the gradient of the SAME
+ * coordinates — one argument reduction and one pair of polynomials instead of two (the device library's sincos returns exactly
+ * the two values its sin and cos return: tests/test_gpu_lbfgs.py::test_device_sincos_is_sin_and_cos; glibc's does NOT
+ * (../objfuncs.h), so the CPU emulation calls them separately) */
+__device__ __forceinline__ void lr_sincos(double a, double *sn, double *cs)
+{
+#ifdef NLA_SIMT_EMU
+    *sn = nla_libm_sin(a); *cs = nla_libm_cos(a);      /* (behind the wrappers gcc cannot merge the two into glibc's sincos) */
+#else
+    sincos(a, sn, cs);
+#endif
+}
+
 /* objective and gradient of the point in LDS (x -> g), the formulas and the summation tree of lb_objgrad (local_common.h) */
 template <int OBJ>
 __device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, lr_red &R, int &par, double sign)
 {
     const int tid = threadIdx.x;
-    nla_obj_part t = nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, tid, LB_T, [&](int i) { return x[i]; }));
+    constexpr bool FUSED = OBJ == NLA_OBJ_RASTRIGIN || OBJ == NLA_OBJ_ACKLEY;
+    double sn[FUSED ? LR_E : 1];
+    nla_obj_part t;
+    if (FUSED) {                   /* nla_obj_partial's sums (thread-strided, coordinate order) with the sines kept for the gradient */
+        t.a = 0; t.b = 0;
+#pragma unroll
+        for (int e = 0; e < LR_E; ++e) {
+            const int i = tid + e * LB_T;
+            sn[FUSED ? e : 0] = 0.;
+            if (i < n) {
+                const double xv = x[i];
+                double cs;
+                lr_sincos(NLA_PI2 * xv, &sn[FUSED ? e : 0], &cs);
+                if (OBJ == NLA_OBJ_RASTRIGIN) t.a += xv * xv - 10.0 * cs;
+                else { t.a += nla_sqr(xv); t.b += cs; }
+            }
+        }
+    } else t = nla_obj_partial<OBJ>(n, tid, LB_T, [&](int i) { return x[i]; });
+    t = nla_obj_wave_reduce<OBJ>(t);
     if ((tid & 63) == 0) { R.v[par][tid >> 6][0] = t.a; R.v[par][tid >> 6][1] = t.b; }
     __syncthreads();
     t.a = R.v[par][0][0]; t.b = R.v[par][0][1];
@@ -126,13 +157,18 @@ __device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, 
     par ^= 1;
     double f = nla_obj_finish<OBJ>(n, t, [&](int i) { return x[i]; });
     if (OBJ == NLA_OBJ_RASTRIGIN) {
-        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) g[i] = 2 * x[i] + 10.0 * NLA_PI2 * sin(NLA_PI2 * x[i]);
+#pragma unroll
+        for (int e = 0; e < LR_E; ++e) { const int i = tid + e * LB_T; if (i < n) g[i] = 2 * x[i] + 10.0 * NLA_PI2 * sn[FUSED ? e : 0]; }
     } else if (OBJ == NLA_OBJ_ACKLEY) {
         const double r = sqrt(t.a / (unsigned) n), e1 = exp(-0.2 * r), e2 = exp(t.b / (unsigned) n);
-        _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) {
-            double gi = e2 * NLA_PI2 * sin(NLA_PI2 * x[i]) / (unsigned) n;
-            if (r > 0) gi += 4.0 * e1 * x[i] / ((unsigned) n * r);
-            g[i] = gi;
+#pragma unroll
+        for (int e = 0; e < LR_E; ++e) {
+            const int i = tid + e * LB_T;
+            if (i < n) {
+                double gi = e2 * NLA_PI2 * sn[FUSED ? e : 0] / (unsigned) n;
+                if (r > 0) gi += 4.0 * e1 * x[i] / ((unsigned) n * r);
+                g[i] = gi;
+            }
         }
     } else if (OBJ == NLA_OBJ_GRIEWANK) {
         _Pragma("unroll 1") for (int i = tid; i < n; i += LB_T) {
@@ -169,6 +205,23 @@ __device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, 
     return f;
 }
 
+/* development / test aid: sin, cos and sincos of the device library for n arguments (tests/test_gpu_lbfgs.py) */
+__global__ void lr_debug_sincos_kernel(int n, const double *a, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s2, c2;
+    sincos(a[i], &s2, &c2);
+    out[4 * (size_t) i] = sin(a[i]); out[4 * (size_t) i + 1] = cos(a[i]); out[4 * (size_t) i + 2] = s2; out[4 * (size_t) i + 3] = c2;
+}
+extern "C" int nla_k_debug_sincos(int n, const double *a, double *out, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(lr_debug_sincos_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, n, a, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
 /* thread 0, when PS1L01 reports the line search finished (q.isys == 0): take its results over (plis.c:395-403) */
 __device__ __forceinline__ int lr_line_search_finished(lr_ctl &C)
 {
@@ -193,6 +246,7 @@ static inline double lr_bload(lr_buf b, unsigned voff, unsigned soff) { double v
 static inline void lr_bstore(double v, lr_buf b, unsigned voff, unsigned soff) { if (voff + soff + 8 <= b.bytes) memcpy(b.base + voff + soff, &v, 8); }
 #define LR_UNIFORM(x) (x)
 #define LR_SCHED_FENCE() do { } while (0)
+#define LR_WAVE_ALL(p) simt_wave_all(p)
 #else
 typedef __amdgpu_buffer_rsrc_t lr_buf;
 typedef unsigned lr_v2u __attribute__((ext_vector_type(2)));
@@ -202,6 +256,7 @@ __device__ __forceinline__ void lr_bstore(double v, lr_buf b, unsigned voff, uns
 /* the instruction scheduler may not move anything across this point: a refill of a column array must stay BEHIND the last use of
  * the values it replaces, or the compiler needs a second set of registers for the array (and copies it every iteration) */
 #define LR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define LR_WAVE_ALL(p) (__all(p) != 0)
 #define LR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)          /* a workgroup-uniform value read from LDS: tell the compiler (scalar branches, scalar address arithmetic) */
 #endif
 #define LR_LD(buf, e) lr_bload(buf, voff, (unsigned) (e) * (LB_T * 8u))
@@ -223,10 +278,12 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const int inst = blockIdx.x;
     const unsigned tid = threadIdx.x, voff = tid * 8u, nbytes = (unsigned) n * 8u;
     if (inst >= count) return;
-    double *xl = work + (size_t) inst * 4 * ld + 2 * (size_t) ld, *xu = xl + ld;     /* the layout of lbfgs_batch_kernel's `work` */
     double *hx = hist + (size_t) inst * 2 * (size_t) mf * ld, *hg = hx + (size_t) mf * ld;
     double *ucol = work + (size_t) count * 4 * ld + (size_t) inst * 2 * mf, *vcol = ucol + mf;
-    const lr_buf bxl = lr_make_buf(xl, nbytes), bxu = lr_make_buf(xu, nbytes);
+    /* PLIS's own copies of the bounds (xl / xu, plis.c:232-241,463-469) differ from lb / ub only on coordinates of type 5 (fixed:
+     * lb == ub, or an empty interval), and no formula below reads a type-5 coordinate's bounds — so the box is read from lb / ub
+     * themselves: ONE pair of vectors for all searches of the batch (cache-resident) instead of a copy per search */
+    const lr_buf bxl = lr_make_buf(lb, nbytes), bxu = lr_make_buf(ub, nbytes);
     const double eta9 = 1e120, eps8 = 1., eps9 = 1e-8, alf1 = 1e-10, alf2 = 1e10, told = 1e-4, xmax = 1e16, maxf = 1e20, minf_est = -HUGE_VAL;
     int par = 0, go;
     double sr[LR_E];                    /* the search direction, this thread's coordinates */
@@ -260,20 +317,17 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     } while (0)
 
     {                                                                        /* plis.c:463-469, 232-241 */
-        const lr_buf blb = lr_make_buf(lb, nbytes), bub = lr_make_buf(ub, nbytes), bX = lr_make_buf(X + (size_t) inst * ld, nbytes);
+        const lr_buf bX = lr_make_buf(X + (size_t) inst * ld, nbytes);
         const lr_buf bx1 = lr_make_buf(hx, nbytes), bg1 = lr_make_buf(hg, nbytes);
         double l0[LR_E], u0[LR_E], x0[LR_E];
-        LR_FOR(e) { l0[e] = LR_LD(blb, e); u0[e] = LR_LD(bub, e); x0[e] = LR_LD(bX, e); }
+        LR_FOR(e) { l0[e] = LR_LD(bxl, e); u0[e] = LR_LD(bxu, e); x0[e] = LR_LD(bX, e); }
         LR_FOR(e) {
             const unsigned i = LR_I(e);
             const int lbu = l0[e] <= -0.99 * HUGE_VAL, ubu = u0[e] >= 0.99 * HUGE_VAL;
             int t = lbu ? (ubu ? 0 : 2) : (ubu ? 1 : (l0[e] == u0[e] ? 5 : 3));
-            double l = l0[e], u = u0[e];
-            if ((t == 3 || t == 4) && u <= l) { u = l; t = 5; }
-            else if (t == 5 || t == 6) { l = x0[e]; u = x0[e]; t = 5; }
+            if ((t == 3 || t == 4) && u0[e] <= l0[e]) t = 5;               /* (xl = xu = lb there; type 5: never read) */
             if (i >= (unsigned) n) { t = -5; x0[e] = 0.; }                  /* no such coordinate: x = g = 0, "fixed" — every loop below passes over it */
             six[i] = (signed char) t; sx[i] = x0[e]; sg[i] = 0.; sr[e] = 0.;
-            LR_ST(l, bxl, e); LR_ST(u, bxu, e);
             LR_ST(0., bx1, e); LR_ST(0., bg1, e);      /* the reference zero-fills xo (plis.c:475); column 1 is read before it is written */
         }
     }
@@ -320,7 +374,10 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 if (C.c.iterm == 100) g_ = LR_EXIT;                          /* the time limit hit during the first evaluation */
                 else {
                     C.gmax = gm; C.umax = um; C.c.kd = C.kd;
-                    if (P.abort) { const int ab = *(const volatile int32_t *) P.abort; C.forced = ab == -999; C.tmo = ab == 100; }
+                    /* the host's abort flag (pinned host memory: a PCIe round trip that the whole workgroup waits for) is looked at on
+                     * every 4th iteration: a time limit or a forced stop is honoured at most 3 iterations (~0.2 ms) later than the
+                     * reference's per-iteration test (plis.c:263,273,371, pssubs.c:914) would — it is an asynchronous event either way */
+                    if (P.abort && (C.c.nit & 3) == 0) { const int ab = *(const volatile int32_t *) P.abort; C.forced = ab == -999; C.tmo = ab == 100; }
                     lb_pyfut1(n, C.fval, &C.fo, um, gm, C.xstop, &C.ls, C.forced, C.nevals, C.tolg, &C.c);
                     if (C.c.iterm != 0) g_ = LR_EXIT;
                     else if (C.tmo) { C.c.iterm = 100; g_ = LR_EXIT; }       /* plis.c:273 */
@@ -379,27 +436,91 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         PROF(2);
         {
             double ssq = 0, pp = 0;
-            unsigned live = 0;
-            LR_FOR(e) { sr[e] = 0.; if (six[LR_I(e)] >= 0) { live |= 1u << e; sr[e] = -sg[LR_I(e)]; } }       /* mxuneg */
+            unsigned live = 0, nvalid = 0;               /* bit e: coordinate e of this thread is free / exists */
+            LR_FOR(e) { sr[e] = 0.; if (LR_I(e) < (unsigned) n) nvalid |= 1u << e; if (six[LR_I(e)] >= 0) { live |= 1u << e; sr[e] = -sg[LR_I(e)]; } }       /* mxuneg */
             if (go == LR_STRANG) {
                 /* the two Strang loops (mxdrcb / mxdrcf, mssubs.c:353-441): the next column is on its way while this one's dot
                  * product is reduced; one barrier per column.  (A column's values on coordinates that are not free are loaded but
                  * never used: `live` masks every sum and update, as mxudot / mxudir's ix test does.) */
                 const int head = LR_UNIFORM(C.head), k = LR_UNIFORM(C.k);
-                const double b = C.b;
-                /* two register arrays, not four: a column's x-part is dead once its dot product has been formed, its g-part once
-                 * the axpy is done — each is refilled at that point with the NEXT column's, which then has a whole iteration
-                 * (a reduction and a vector pass) to arrive */
-                double ca[LR_E], cb[LR_E], u1, un;          /* (un, vn: the next column's scalars, fetched with it) */
+                const bool all_free = LR_WAVE_ALL(live == nvalid);          /* wave-uniform: no coordinate of this wavefront sits on a bound */
 #define LR_LOAD(arr, buf_) do { const lr_buf q_ = buf_; LR_FOR(e) arr[e] = LR_LD(q_, e); } while (0)
+                if (all_free) {
+                /* The usual case, without masks: a coordinate that does not exist (>= n) has sr = 0 and its column entries load as
+                 * 0.0 (bounds-checked buffer), so it adds +0.0 and stays 0 — the sums are the masked ones bit for bit.
+                 * Software pipeline, two columns deep.  A column's x-part is dead once its dot product has been formed, its g-part
+                 * once the axpy is done: each array is refilled at that point with the column TWO steps ahead, which then has two
+                 * whole steps (two reductions, four vector passes) to arrive — the history comes from HBM / the memory-side cache
+                 * (~2 us away with 300 searches streaming; one step is ~0.6 us of work).  Two sets of arrays (a0/b0 for odd steps,
+                 * a1/b1 for even ones), the loop unrolled by two so that no array is ever copied.  The refills are UNCONDITIONAL
+                 * (past the end they fetch the last column once more): a conditional refill makes "old or new" a second register
+                 * array with a copy per step; the scheduling fences keep a refill behind the last use of what it replaces. */
+                double a0[LR_E], b0[LR_E], a1[LR_E], b1[LR_E], u0, u1, un;
+#define LR_BACK_STEP(j_, A, B, U) do {                              /* mxdrcb, column j_ */                                  \
+        double t_ = 0;                                                                                                      \
+        LR_FOR(e) t_ += sr[e] * A[e];                                                                                       \
+        const int jn_ = (j_) + 2 <= k ? (j_) + 2 : k;                                                                       \
+        LR_SCHED_FENCE();                                                                                                   \
+        LR_LOAD(A, COLX(head, jn_)); un = COLU(head, jn_);                                                                  \
+        const double v_ = U * lr_reduce1<false>(t_, R, par);                                                                \
+        if (tid == 0) vcol[(j_) - 1] = v_;                                                                                  \
+        LR_FOR(e) sr[e] = sr[e] + (-v_) * B[e];                                                                             \
+        LR_SCHED_FENCE();                                                                                                   \
+        LR_LOAD(B, COLG(head, jn_));                                                                                        \
+        U = un;                                                                                                             \
+    } while (0)
+#define LR_FWD_STEP(j_, A, B, U, V) do {                            /* mxdrcf, column j_: A = its g-part, B = its x-part */  \
+        double t_ = 0;                                                                                                      \
+        LR_FOR(e) t_ += sr[e] * A[e];                                                                                       \
+        const int jp_ = (j_) - 2 >= 1 ? (j_) - 2 : 1;                                                                       \
+        LR_SCHED_FENCE();                                                                                                   \
+        LR_LOAD(A, COLG(head, jp_)); un = COLU(head, jp_); const double vn_ = vcol[jp_ - 1];                                \
+        const double tt_ = U * lr_reduce1<false>(t_, R, par);                                                               \
+        const double w_ = V - tt_;                                                                                          \
+        LR_FOR(e) sr[e] = sr[e] + w_ * B[e];                                                                                \
+        LR_SCHED_FENCE();                                                                                                   \
+        LR_LOAD(B, COLX(head, jp_));                                                                                        \
+        U = un; V = vn_;                                                                                                    \
+    } while (0)
+                {
+                    const int j2 = k >= 2 ? 2 : 1;
+                    LR_LOAD(a0, COLX(head, 1)); LR_LOAD(b0, COLG(head, 1)); u0 = COLU(head, 1);
+                    LR_LOAD(a1, COLX(head, j2)); LR_LOAD(b1, COLG(head, j2)); u1 = COLU(head, j2);
+                }
+                for (int j = 1; j <= k; j += 2) {
+                    LR_BACK_STEP(j, a0, b0, u0);
+                    if (j + 1 <= k) LR_BACK_STEP(j + 1, a1, b1, u1);
+                }
+                {
+                    /* g of column 1 for the scaling; meanwhile the forward loop's first two columns (k, k - 1) are on their way */
+                    const int k2 = k >= 2 ? k - 1 : 1;
+                    LR_SCHED_FENCE();
+                    LR_LOAD(b1, COLG(head, 1));
+                    LR_LOAD(a0, COLG(head, k)); LR_LOAD(b0, COLX(head, k)); u0 = COLU(head, k);
+                    LR_LOAD(a1, COLG(head, k2)); u1 = COLU(head, k2);
+                    double t = 0;
+                    LR_FOR(e) t += b1[e] * b1[e];
+                    LR_SCHED_FENCE();
+                    LR_LOAD(b1, COLX(head, k2));
+                    const double a = lr_reduce1<false>(t, R, par);
+                    if (a > 0.) { const double sc = C.b / a; LR_FOR(e) sr[e] = sr[e] * sc; }
+                    double v0 = vcol[k - 1], v1 = vcol[k2 - 1];
+                    for (int j = k; j >= 1; j -= 2) {
+                        LR_FWD_STEP(j, a0, b0, u0, v0);
+                        if (j - 1 >= 1) LR_FWD_STEP(j - 1, a1, b1, u1, v1);
+                    }
+                }
+                } else {
+                /* some coordinate of this wavefront is on a bound: every sum and update masked by `live`, as mxudot / mxudir's ix test
+                 * does (a column's values on such coordinates are loaded but never used); the pipeline one column deep — the
+                 * sixteen mask tests take the registers the second pair of arrays would need */
+                double ca[LR_E], cb[LR_E], u1, un;
                 LR_LOAD(ca, COLX(head, 1));
                 LR_LOAD(cb, COLG(head, 1));
                 u1 = COLU(head, 1);
                 for (int j = 1; j <= k; ++j) {                       /* mxdrcb */
                     double t = 0;
                     LR_FOR(e) if (live & (1u << e)) t += sr[e] * ca[e];
-                    /* the refills are UNCONDITIONAL (the last iteration loads its own column once more): a conditional refill makes
-                     * "old or new" a second register array with a copy per iteration */
                     const int jn = j < k ? j + 1 : j;
                     LR_SCHED_FENCE();
                     LR_LOAD(ca, COLX(head, jn)); un = COLU(head, jn);
@@ -410,7 +531,6 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                     LR_LOAD(cb, COLG(head, jn));
                     u1 = un;
                 }
-                /* ca: g of column k for the first forward dot product, on its way during the scaling; cb: g of column 1 */
                 LR_LOAD(cb, COLG(head, 1));
                 LR_LOAD(ca, COLG(head, k));
                 {
@@ -419,7 +539,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                     LR_SCHED_FENCE();
                     LR_LOAD(cb, COLX(head, k));
                     const double a = lr_reduce1<false>(t, R, par);
-                    if (a > 0.) { const double sc = b / a; LR_FOR(e) sr[e] = sr[e] * sc; }
+                    if (a > 0.) { const double sc = C.b / a; LR_FOR(e) sr[e] = sr[e] * sc; }
                 }
                 u1 = COLU(head, k);
                 double v1 = vcol[k - 1], vn;
@@ -435,6 +555,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                     LR_SCHED_FENCE();
                     LR_LOAD(cb, COLX(head, jp));
                     u1 = un; v1 = vn;
+                }
                 }
                 LR_FOR(e) if (live & (1u << e)) ssq += sr[e] * sr[e];
             }

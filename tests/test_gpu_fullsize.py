@@ -212,3 +212,30 @@ def test_config4_mlsl_ackley_n4096_default_mode_first_iteration():
     drift = np.abs(fl["accepted"] - g["eloc"][:nloc1])
     print("default mode: %d local searches in iteration 1, evaluation-count drift: max %d, mean %.3f, identical %d" %
           (nloc1, drift.max(), drift.mean(), int((drift == 0).sum())))
+
+
+def test_config4_mlsl_ackley_n4096_default_mode_all_iterations():
+    """the default (tree-reduction) mode over the WHOLE fixture run — three iterations' samples and 861 local searches in the
+    reference: every sample of every iteration is the reference's (the local searches draw no random numbers), every iteration
+    starts the same number of searches, each reaches the reference's minimum to 1e-8 with an evaluation count within +-4.  Only
+    where maxeval cuts the run may differ (the counts drift by a few evaluations per search): the last search is not compared."""
+    g = load("mlsl_ackley_n4096_N1000")
+    a = run_mlsl(g, exact=False)
+    t = a["trace"]
+    ns = int(g["nsamp"])
+    fs = t[t["kind"] == 3]["f"]
+    m = min(len(fs), len(g["fsamp"]))
+    assert m >= 3 * ns - 8 and close(fs[:m], g["fsamp"][:m], 1.0)                        # the samples of all three iterations
+    fl = t[t["kind"] == 4]
+    k = min(len(fl), len(g["floc"])) - 1
+    assert k >= len(g["floc"]) - 4
+    assert np.all(np.abs(fl["f"][:k] - g["floc"][:k]) <= 1e-8 * np.maximum(np.abs(g["floc"][:k]), 1.0))
+    drift = np.abs(fl["accepted"][:k] - g["eloc"][:k])
+    assert drift.max() <= 4
+    # the same number of searches between consecutive sampling phases (iteration boundaries = where kind switches back to 3)
+    kinds = t["kind"][(t["kind"] == 3) | (t["kind"] == 4)]
+    bounds = np.flatnonzero((kinds[1:] == 3) & (kinds[:-1] == 4))
+    per_iter = [int((kinds[:b + 1] == 4).sum()) for b in bounds]
+    assert len(per_iter) >= 2 and per_iter[0] > 0 and per_iter[1] > per_iter[0]
+    print("default mode, whole run: %d searches compared, evaluation-count drift max %d mean %.3f identical %d; searches by the end of iterations %s"
+          % (k, drift.max(), drift.mean(), int((drift == 0).sum()), per_iter))

@@ -165,3 +165,21 @@ def test_resident_kernel_is_the_streaming_kernel(obj, n, count, mf, kw):
     assert np.array_equal(a["ftrace"], b["ftrace"], equal_nan=True)
     assert np.array_equal(a["x"], b["x"])
     assert (a["res"]["nevals"] > 1).all()
+
+
+def test_device_sincos_is_sin_and_cos():
+    """lbfgs_resident.hip computes Ackley's / Rastrigin's cos(2 pi x) (for f) and sin(2 pi x) (for the gradient) with ONE sincos call;
+    the streaming kernel and the population kernels call cos and sin.  The device library must return the same bits either way:
+    1e6 arguments over the objectives' argument range (|2 pi x| <= 206) and beyond, plus the awkward ones."""
+    L = nlopt_amd.lib()
+    rng = np.random.default_rng(12)
+    a = np.concatenate([rng.uniform(-206.0, 206.0, 600000), rng.uniform(-4e3, 4e3, 200000), rng.uniform(-1e-3, 1e-3, 100000), rng.uniform(-1e9, 1e9, 100000),
+                        6.283185307179586 * rng.uniform(-32.768, 32.768, 100000),
+                        np.array([0.0, -0.0, np.pi, -np.pi, np.pi / 2, 1e-300, 1e22, np.inf, -np.inf, np.nan, 0.5939350286162490 * 6.283185307179586])])
+    dA, dO = nlopt_amd.DevBuf.from_array(a), nlopt_amd.DevBuf(8 * 4 * len(a))
+    L.nla_k_debug_sincos.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.nla_k_debug_sincos(len(a), dA.ptr, dO.ptr, None) == 0 and L.nla_stream_sync(None) == 0
+    o = dO.to_array(np.float64, 4 * len(a)).reshape(-1, 4)
+    assert np.array_equal(o[:, 0], o[:, 2], equal_nan=True) and np.array_equal(o[:, 1], o[:, 3], equal_nan=True)
+    assert np.isfinite(o[:-4]).all() and o[len(a) - 11, 1] == 1.0 and o[len(a) - 11, 0] == 0.0          # the row of a = 0.0
+    dA.free(); dO.free()

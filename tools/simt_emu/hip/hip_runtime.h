@@ -72,6 +72,18 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64)
     std::memcpy(&out, &raw, sizeof(T));
     return out;
 }
+/* __all() over the 64 work-items of a wavefront (every work-item of the workgroup must call it) */
+static inline bool simt_wave_all(bool p)
+{
+    static thread_local int which = 0;
+    simt::xch(which)[threadIdx.x] = p ? 1 : 0;
+    simt::barrier().wait();
+    bool all = true;
+    const unsigned w0 = threadIdx.x & ~63u;
+    for (unsigned l = w0; l < w0 + 64 && l < blockDim.x; ++l) all = all && simt::xch(which)[l] != 0;
+    which ^= 1;
+    return all;
+}
 static inline unsigned long long wall_clock64() { return 0; }
 static inline unsigned __smid() { return 0; }
 
