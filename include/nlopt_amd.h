@@ -125,6 +125,10 @@ typedef int (*nlopt_amd_allgather_fn)(void *ctx, const void *h_send, void *h_rec
 int nlopt_amd_rccl_unique_id(void *id128);                                   /* 0 = ok */
 nlopt_amd_comm *nlopt_amd_comm_create_rccl(int rank, int world, const void *id128);
 nlopt_amd_comm *nlopt_amd_comm_create_host(int rank, int world, nlopt_amd_allgather_fn fn, void *ctx);
+/* ranks on ONE node without a collective library: a POSIX shared-memory segment `name` ("/...", the same on every rank, unique to the
+ * job) with per-rank slots of slot_bytes (0: 16 MiB; larger contributions travel in pieces) and a barrier; device data are copied
+ * straight into / out of the (registered) slots.  Rank 0 creates the segment, the others wait for it. */
+nlopt_amd_comm *nlopt_amd_comm_create_shm(int rank, int world, const char *name, size_t slot_bytes);
 void nlopt_amd_comm_destroy(nlopt_amd_comm *c);
 int nlopt_amd_comm_rank(const nlopt_amd_comm *c);
 int nlopt_amd_comm_world(const nlopt_amd_comm *c);
@@ -476,9 +480,12 @@ void *nla_dev_malloc(size_t bytes);
 void nla_dev_free(void *p);
 void *nla_dev_malloc_uncached(size_t bytes);    /* MTYPE UC device memory: coherent between workgroups / XCDs without cache maintenance */
 void nla_debug_uncached_stats(long out[4]);     /* [0] uncached allocations made, [1] returned to the driver (never, with the pool), [2] pooled blocks, [3] in use */
-void nla_dev_free_uncached(void *p);            /* back to the library's pool: uncached blocks are never returned to the driver while the process lives (devrt.hip) */
+void nla_dev_free_uncached(void *p);            /* back to the library's pool (per device; nothing returns to the driver while an uncached block of the device is in use; idle blocks above 1 GiB are trimmed when the last one is released — devrt.hip) */
+size_t nlopt_amd_release_device_memory(void);   /* gives every idle pooled block back to the driver (between the large runs of a long-lived process); bytes released */
 void *nla_host_malloc(size_t bytes);            /* pinned */
 void nla_host_free(void *p);
+int nla_host_register(void *p, size_t bytes);   /* caller-owned host memory made page-locked and device-visible (the shm transport's segment); 0 = ok */
+void nla_host_unregister(void *p);
 int nla_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream);
 int nla_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream);
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);

@@ -319,6 +319,15 @@ class Comm:
         return cls(lib().nlopt_amd_comm_create_rccl(int(rank), int(world), C.cast(buf, C.c_void_p)))
 
     @classmethod
+    def shm(cls, rank, world, name, slot_bytes=0):
+        """ranks on one node over a POSIX shared-memory segment (comm.c: copy in, one barrier, copy out; device data go straight
+        into / out of the registered slots).  `name`: "/..." — the same on every rank, unique to the job."""
+        L = lib()
+        L.nlopt_amd_comm_create_shm.restype = C.c_void_p
+        L.nlopt_amd_comm_create_shm.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        return cls(L.nlopt_amd_comm_create_shm(int(rank), int(world), name.encode(), int(slot_bytes)))
+
+    @classmethod
     def host(cls, rank, world, allgather):
         """host transport: allgather(send: bytes) -> bytes of length world*len(send), rank-major"""
         def _cb(ctx, send, recv, nbytes):

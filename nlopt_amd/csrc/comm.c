@@ -3,18 +3,31 @@
  * is partitioned over the ranks; the only exchange the algorithms need is an ALL-GATHER (SURVEY.md
  * §8e: f / penalty of the candidates, rows of new population members, local minima).
  *
- * Two transports behind one interface:
+ * Three transports behind one interface:
  *   RCCL   ncclAllGather on device buffers over xGMI.  librccl is dlopen()ed on first use so that
  *          single-GPU programs never load or initialise it; the 128-byte unique id is created on
  *          rank 0 (nlopt_amd_rccl_unique_id) and handed to every rank by the launcher.
  *   host   a user-supplied all-gather on host buffers (MPI, gloo, ...); device data are staged
  *          through pinned memory.  This is what the world_size-2 tests use.
+ *   shm    ranks on ONE node without a collective library: a POSIX shared-memory segment holds two sets of per-rank slots and a
+ *          barrier; an all-gather is "copy in, one barrier, copy out" (the sets alternate, so the next call's writes cannot meet
+ *          this call's reads).  The segment is registered with the device runtime, so device data go D2H straight into the rank's
+ *          slot and H2D straight out of the slot set (rank-major = the receive layout) — no second staging copy, no Python in the
+ *          exchange: what tools/shard_probe.py times a sharded pass over, and a fallback where RCCL cannot be used.
  *
  * The reference has no counterpart (it is single-threaded).
  */
 #include "nla_internal.h"
+#include "nla_switches.h"
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,7 +50,7 @@ static void rccl_load_once(void)
 {
     /* NLA_RCCL_LIBRARY=<path>: the collective library to bind instead of the system's librccl (a site's own RCCL build; the tests
      * point it at a mock that checks the all-gather contract, so that this transport runs with several ranks without GPUs) */
-    const char *path = getenv("NLA_RCCL_LIBRARY");
+    const char *path = NLA_DBG_ENV("NLA_RCCL_LIBRARY");
     R.dl = path && *path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!R.dl && !(path && *path)) R.dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!R.dl && !(path && *path)) R.dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -55,9 +68,26 @@ static int rccl_load(void)                                    /* any thread may 
     return R.dl ? 0 : -1;
 }
 
+/* the shared segment: header, then 2 sets x world slots of `slot` bytes */
+typedef struct {
+    _Atomic uint32_t magic;             /* set last by rank 0: the segment is initialised */
+    uint32_t world;
+    uint64_t slot;
+    _Atomic uint32_t arrived, generation;
+    _Atomic uint32_t attached, detached;
+    char pad[64 - 40];
+} shm_header;
+#define SHM_MAGIC 0x6e6c6173u
+typedef struct {
+    shm_header *h; char *slots; size_t bytes_mapped, slot;
+    int owner, registered; unsigned parity;
+    char name[96];
+} shm_state;
+
 struct nlopt_amd_comm_s {
     int rank, world;
-    void *rccl;                         /* ncclComm_t, or NULL: host transport */
+    void *rccl;                         /* ncclComm_t, or NULL: host / shm transport */
+    shm_state *shm;                     /* shm transport */
     nlopt_amd_allgather_fn fn; void *ctx;
     void *h_send, *h_recv; size_t h_cap;          /* pinned staging (host transport / host data over RCCL) */
     void *d_send, *d_recv; size_t d_cap;          /* device staging for host data over RCCL */
@@ -101,10 +131,121 @@ nlopt_amd_comm *nlopt_amd_comm_create_host(int rank, int world, nlopt_amd_allgat
     return c;
 }
 
+/* ---- shm transport ------------------------------------------------------------------------------------------------------ */
+static int shm_barrier(nlopt_amd_comm *c)
+{
+    shm_header *h = c->shm->h;
+    const uint32_t g = atomic_load_explicit(&h->generation, memory_order_acquire);
+    unsigned spins = 0;
+    struct timespec t0, t1;
+    if (atomic_fetch_add_explicit(&h->arrived, 1, memory_order_acq_rel) + 1 == (uint32_t) c->world) {
+        atomic_store_explicit(&h->arrived, 0, memory_order_relaxed);
+        atomic_store_explicit(&h->generation, g + 1, memory_order_release);
+        return 0;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    while (atomic_load_explicit(&h->generation, memory_order_acquire) == g) {
+        if (++spins < 2000) { __builtin_ia32_pause(); continue; }
+        sched_yield();
+        if ((spins & 1023) == 0) {                       /* a rank that died must not hang the others for ever */
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (t1.tv_sec - t0.tv_sec > 600) { snprintf(c->err, sizeof c->err, "shm transport: a rank did not reach the barrier within 600 s"); return -1; }
+        }
+    }
+    return 0;
+}
+/* host buffers: every rank's `bytes` into its slot of the current set, one barrier, the set out in rank order; payloads larger than a
+ * slot go in pieces */
+static int shm_allgather(void *ctx, const void *send, void *recv, size_t bytes)
+{
+    nlopt_amd_comm *c = (nlopt_amd_comm *) ctx;
+    shm_state *s = c->shm;
+    size_t off = 0;
+    do {
+        const size_t part = bytes - off < s->slot ? bytes - off : s->slot;
+        char *set = s->slots + (size_t) (s->parity & 1) * (size_t) c->world * s->slot;
+        int r;
+        if (part) memcpy(set + (size_t) c->rank * s->slot, (const char *) send + off, part);
+        if (shm_barrier(c)) return -1;
+        for (r = 0; r < c->world; ++r) if (part) memcpy((char *) recv + (size_t) r * bytes + off, set + (size_t) r * s->slot, part);
+        ++s->parity;
+        off += part;
+    } while (off < bytes);
+    return 0;
+}
+static void shm_close(shm_state *s)
+{
+    if (!s) return;
+    if (s->h) {
+        if (s->registered) nla_host_unregister(s->h);
+        /* the last rank to leave removes the name (rank 0 alone could pull it away under a rank that has not opened it yet) */
+        if (atomic_fetch_add_explicit(&s->h->detached, 1, memory_order_acq_rel) + 1 == s->h->world) shm_unlink(s->name);
+        munmap(s->h, s->bytes_mapped);
+    }
+    free(s);
+}
+/* `name`: a POSIX shared-memory name ("/something") every rank of the job passes identically and no other job uses; slot_bytes: the
+ * largest single contribution moved in one piece (larger ones are split; 0 = 16 MiB).  Rank 0 creates the segment, the others wait
+ * for it (up to 120 s).  All ranks must live on one node. */
+nlopt_amd_comm *nlopt_amd_comm_create_shm(int rank, int world, const char *name, size_t slot_bytes)
+{
+    nlopt_amd_comm *c;
+    shm_state *s;
+    size_t total;
+    int fd = -1, tries;
+    if (world < 1 || rank < 0 || rank >= world || !name || name[0] != '/' || strlen(name) >= sizeof s->name) return NULL;
+    if (!slot_bytes) slot_bytes = (size_t) 16 << 20;
+    slot_bytes = (slot_bytes + 4095) & ~(size_t) 4095;
+    total = sizeof(shm_header) + 2 * (size_t) world * slot_bytes;
+    total = (total + 4095) & ~(size_t) 4095;
+    c = (nlopt_amd_comm *) calloc(1, sizeof *c);
+    s = (shm_state *) calloc(1, sizeof *s);
+    if (!c || !s) { free(c); free(s); return NULL; }
+    c->rank = rank; c->world = world; c->shm = s; c->fn = shm_allgather; c->ctx = c;
+    snprintf(s->name, sizeof s->name, "%s", name);
+    s->slot = slot_bytes; s->bytes_mapped = total; s->owner = rank == 0;
+    if (rank == 0) {
+        shm_unlink(name);                                /* a stale segment of a run that crashed */
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t) total)) { if (fd >= 0) { close(fd); shm_unlink(name); } free(c); free(s); return NULL; }
+    } else {
+        for (tries = 0; tries < 120000 && fd < 0; ++tries) {
+            struct stat sb;
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0 && (fstat(fd, &sb) || (size_t) sb.st_size < total)) { close(fd); fd = -1; }      /* created, not sized yet */
+            if (fd < 0) usleep(1000);
+        }
+        if (fd < 0) { free(c); free(s); return NULL; }
+    }
+    s->h = (shm_header *) mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (s->h == MAP_FAILED) { s->h = NULL; if (rank == 0) shm_unlink(name); free(c); free(s); return NULL; }
+    s->slots = (char *) s->h + sizeof(shm_header);
+    if (rank == 0) {
+        s->h->world = (uint32_t) world; s->h->slot = slot_bytes;
+        atomic_store_explicit(&s->h->arrived, 0, memory_order_relaxed);
+        atomic_store_explicit(&s->h->generation, 0, memory_order_relaxed);
+        atomic_store_explicit(&s->h->attached, 0, memory_order_relaxed);
+        atomic_store_explicit(&s->h->detached, 0, memory_order_relaxed);
+        atomic_store_explicit(&s->h->magic, SHM_MAGIC, memory_order_release);
+    } else {
+        for (tries = 0; tries < 120000 && atomic_load_explicit(&s->h->magic, memory_order_acquire) != SHM_MAGIC; ++tries) usleep(1000);
+        if (atomic_load_explicit(&s->h->magic, memory_order_acquire) != SHM_MAGIC || s->h->world != (uint32_t) world || s->h->slot != slot_bytes) {
+            munmap(s->h, total); free(c); free(s); return NULL;                   /* another job's segment, or ranks that disagree */
+        }
+    }
+    atomic_fetch_add_explicit(&s->h->attached, 1, memory_order_acq_rel);
+    /* device copies straight into / out of the slots (no device: the transport still serves host data) */
+    s->registered = nla_dev_count() > 0 && nla_host_register(s->h, total) == 0;
+    if (shm_barrier(c)) { shm_close(s); free(c); return NULL; }                   /* everyone is attached before anyone may leave */
+    return c;
+}
+
 void nlopt_amd_comm_destroy(nlopt_amd_comm *c)
 {
     if (!c) return;
     if (c->rccl) R.destroy(c->rccl);
+    shm_close(c->shm);
     nla_host_free(c->h_send); nla_host_free(c->h_recv);
     nla_dev_free(c->d_send); nla_dev_free(c->d_recv);
     free(c);
@@ -166,6 +307,19 @@ int nla_comm_allgather_dev(nlopt_amd_comm *c, const void *d_send, void *d_recv, 
         rc = R.allgather(d_send, d_recv, bytes, RCCL_UINT8, c->rccl, stream);
         if (rc) snprintf(c->err, sizeof c->err, "ncclAllGather failed: %s", R.errstr ? R.errstr(rc) : "?");
         return rc;
+    }
+    if (c->shm && c->shm->registered && bytes <= c->shm->slot && bytes > 0) {
+        /* the slots are pinned, device-visible memory: D2H into this rank's slot, one barrier, H2D of every rank's slot */
+        shm_state *s = c->shm;
+        char *set = s->slots + (size_t) (s->parity & 1) * (size_t) c->world * s->slot;
+        int r;
+        if (nla_memcpy_d2h(set + (size_t) c->rank * s->slot, d_send, bytes, stream) || nla_stream_sync(stream)) { snprintf(c->err, sizeof c->err, "staging copy failed"); return -1; }
+        if (shm_barrier(c)) return -1;
+        for (r = 0; r < c->world; ++r)
+            if (nla_memcpy_h2d((char *) d_recv + (size_t) r * bytes, set + (size_t) r * s->slot, bytes, stream)) { snprintf(c->err, sizeof c->err, "staging copy failed"); return -1; }
+        ++s->parity;
+        if (nla_stream_sync(stream)) { snprintf(c->err, sizeof c->err, "staging copy failed"); return -1; }
+        return 0;
     }
     if (need_host(c, bytes)) return -1;
     if (nla_memcpy_d2h(c->h_send, d_send, bytes, stream) || nla_stream_sync(stream)) { snprintf(c->err, sizeof c->err, "staging copy failed"); return -1; }

@@ -14,6 +14,7 @@
  * orders main after rng.
  */
 #include "nla_internal.h"
+#include "nla_switches.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -184,17 +185,17 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
      * CUs were the last to finish every pass.  With 2^28 words per batch (32768 blocks at n = 4096: 2.1 GB of words + 1 GB of
      * positions in the ring, of 288 GB) it runs a few per cent of the time. */
     {
-        const char *lg = getenv("NLA_CRS_BATCH_LOG2");                /* development switch */
+        const char *lg = NLA_DBG_ENV("NLA_CRS_BATCH_LOG2");                /* development switch */
         const int lg2 = lg ? atoi(lg) : 28;
         B = (size_t) ((1ULL << (lg2 >= 20 && lg2 <= 31 ? lg2 : 28)) / (2ULL * (uint64_t) n));
     }
     if (B > 65536) B = 65536;
     if (B < 2 * KCAP) B = 2 * KCAP;
     e->B = (int) B;
-    if (getenv("NLA_CRS_PASS_LOG")) e->pass_log = fopen(getenv("NLA_CRS_PASS_LOG"), "a");
+    if (NLA_DBG_ENV("NLA_CRS_PASS_LOG")) e->pass_log = fopen(NLA_DBG_ENV("NLA_CRS_PASS_LOG"), "a");
     e->main = nla_stream_create();
     /* NLA_ONE_STREAM (A/B switch for debugging stream-ordering problems): the generator work on the main stream too */
-    e->rng = getenv("NLA_ONE_STREAM") ? e->main : nla_stream_create();      /* (restricting this stream to a subset of the CUs — hipExtStreamCreateWithCUMask, every 4th / 16th CU — was measured:
+    e->rng = NLA_DBG_ENV("NLA_ONE_STREAM") ? e->main : nla_stream_create();      /* (restricting this stream to a subset of the CUs — hipExtStreamCreateWithCUMask, every 4th / 16th CU — was measured:
                                         *  43.0 -> 43.1 k evals/s; what the digest kernels cost the gather is memory traffic, not CUs) */
     if (!e->main || !e->rng) goto fail;
     e->mts = nla_mtstream_create(e->rng);
@@ -213,7 +214,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     }
     /* trial points and the chain kernel's control block: uncached memory where the workgroups of one launch read each other's
      * (device-resolved windows); ordinary memory for the conservative passes, whose kernels meet only at launch boundaries */
-    e->uncached = (forward && obj >= 0) || getenv("NLA_UC_ALWAYS") != NULL;       /* (NLA_UC_ALWAYS: round 2's allocation pattern, A/B) */
+    e->uncached = (forward && obj >= 0) || NLA_DBG_ENV("NLA_UC_ALWAYS") != NULL;       /* (NLA_UC_ALWAYS: round 2's allocation pattern, A/B) */
     e->d_TX = (double *) (e->uncached ? nla_dev_malloc_uncached : nla_dev_malloc)(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_TM = (double *) (e->uncached ? nla_dev_malloc_uncached : nla_dev_malloc)(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_fT = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP);
@@ -237,8 +238,8 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         e->h_fwcnt = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX);
         e->h_fwrec = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX * CHAIN_FWCAP);
     }
-    e->direct_status = !getenv("NLA_CRS_COPY_STATUS");
-    e->force_upload = getenv("NLA_CRS_UPLOAD") != NULL;
+    e->direct_status = !NLA_DBG_ENV("NLA_CRS_COPY_STATUS");
+    e->force_upload = NLA_DBG_ENV("NLA_CRS_UPLOAD") != NULL;
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1 ||
         (e->uncached && obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
@@ -277,7 +278,7 @@ static void dump_init(nla_crs_hip_engine *e, size_t nwords)
     if (w && x && !nla_memcpy_d2h(w, e->d_initwords, sizeof(uint32_t) * nwords, e->main) &&
         !nla_memcpy_d2h(x, e->d_X, sizeof(double) * nx, e->main) && !nla_memcpy_d2h(x + nx, e->d_F, sizeof(double) * (size_t) e->N, e->main) &&
         !nla_stream_sync(e->main)) {
-        snprintf(path, sizeof path, "%s/init_last.bin", getenv("NLA_CRS_DEBUG_DIR"));
+        snprintf(path, sizeof path, "%s/init_last.bin", NLA_DBG_ENV("NLA_CRS_DEBUG_DIR"));
         if ((fp = fopen(path, "wb"))) {
             fwrite(hdr, sizeof hdr, 1, fp); fwrite(w, sizeof(uint32_t), nwords, fp); fwrite(x, sizeof(double), nx + (size_t) e->N, fp);
             fclose(fp);
@@ -450,7 +451,7 @@ static int op_init_population(void *ve, const double *x0, double *F)
         nla_event_destroy(ev_ag0); nla_event_destroy(ev_ag1);
         if (rc) FAIL(e, "init sync failed: %s", nla_dev_error_string(rc));
     }
-    if (getenv("NLA_CRS_DEBUG_DIR") && world == 1 && rows_per_chunk >= per && !e->sharded) dump_init(e, (size_t) (wpr * (uint64_t) (e->N - 1)));
+    if (NLA_DBG_ENV("NLA_CRS_DEBUG_DIR") && world == 1 && rows_per_chunk >= per && !e->sharded) dump_init(e, (size_t) (wpr * (uint64_t) (e->N - 1)));
     nla_dev_free(e->d_initwords); e->d_initwords = NULL; e->initwords_cap = 0;
     /* start digesting the first batch of trial blocks while the host builds its ordered set */
     if (ensure_blocks(e, 0, 0)) return -1;
@@ -752,7 +753,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         /* the device-resolved windows pay a few microseconds per block for the in-kernel chain: worth it where a trial's gather
          * takes longer than that (n >= 2048: 33 MB per trial) */
         pb->forward = nlopt_get_param(opt, "amd_forward", n >= 2048 ? 1 : 0) != 0;
-        if (getenv("NLA_CRS_FORWARD")) pb->forward = atoi(getenv("NLA_CRS_FORWARD"));                 /* A/B switch for the bench */
+        pb->forward = nla_dbg_int("NLA_CRS_FORWARD", pb->forward);                 /* A/B switch for the bench */
         if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
     }
     if (nla_dev_count() <= 0) {

@@ -49,6 +49,7 @@
  * behind a pick that nobody overwrites was the larger part of the wait time at a 9 % rejection rate.
  */
 #include "crs_common.h"
+#include "../nla_switches.h"
 #include <stdlib.h>
 #include "../../../include/nlopt_amd.h"
 
@@ -329,7 +330,7 @@ extern "C" size_t nla_crs_chain_ctrl_bytes(int K, int nW)
 static bool chain_vec2(int n, int ld)
 {
     static int force1 = -1;              /* experiment switch: NLA_CHAIN_VEC1=1 -> 64-coordinate chunks everywhere */
-    if (force1 < 0) { const char *s = getenv("NLA_CHAIN_VEC1"); force1 = (s && atoi(s) > 0) ? 1 : 0; }
+    if (force1 < 0) { const char *s = NLA_DBG_ENV("NLA_CHAIN_VEC1"); force1 = (s && atoi(s) > 0) ? 1 : 0; }
     return !force1 && (n % 2 == 0) && (ld % 2 == 0) && n >= 128;
 }
 

@@ -4,6 +4,7 @@
  * layer").  There is no CPU fallback anywhere: with no visible device nla_dev_count() returns 0
  * and the optimisers fail with NLOPT_FAILURE and an errmsg. */
 #include <hip/hip_runtime.h>
+#include "../nla_switches.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../../include/nlopt_amd.h"
@@ -21,7 +22,7 @@ extern "C" int nla_dev_set(int dev) { return (int) hipSetDevice(dev); }
 static int alloc_fill(void)
 {
     static int fill = -2;
-    if (fill == -2) { const char *e = getenv("NLA_DEV_MALLOC_FILL"); fill = e ? (atoi(e) & 255) : -1; }
+    if (fill == -2) { const char *e = NLA_DBG_ENV("NLA_DEV_MALLOC_FILL"); fill = e ? (atoi(e) & 255) : -1; }      /* (nla_switches.h) */
     return fill;
 }
 extern "C" void *nla_dev_malloc(size_t bytes)
@@ -35,71 +36,136 @@ extern "C" void nla_dev_free(void *p) { if (p) (void) hipFree(p); }
 /* device memory no cache holds on to (MTYPE UC): what one workgroup stores any other workgroup loads, on whichever XCD it runs,
  * without cache maintenance — for the small buffers the workgroups of hip/crs_chain.hip hand results to each other through.
  *
- * These blocks are NEVER given back to the driver while the process lives: a released block goes to a free list and the next
- * request of at most its size gets it again.  Round 2 allocated and freed them per run, and runs then saw — rarely, a few cache
- * lines at a time — stale contents in ORDINARY allocations made afterwards ("the intermittent divergence"): memory that
- * has been mapped uncached must not come back as cached memory (or the other way round) while caches may still hold its lines. */
+ * A POOL, because of round 2's intermittent divergence: runs that allocated these buffers and gave them back to the
+ * driver at their end made later ORDINARY allocations show — rarely, a few cache lines at a time — stale contents: memory that has
+ * been mapped uncached must not come back as cached memory while caches may still hold its lines (tools/uc_stale_repro.hip is the
+ * stand-alone form of that experiment).  Rules:
+ *   - a released block goes to the free list of ITS DEVICE and is handed out again to a request it fits without wasting more than
+ *     half of it (size classes: a 512 MB trial-point block is not given to a 1 KB request);
+ *   - blocks are whole 2 MB pages of their own with a guard page on either side: no ordinary allocation shares a page-table
+ *     fragment with an uncached one;
+ *   - nothing goes back to the driver while ANY uncached block of that device is in use.  When the last one has been released and
+ *     more than NLA_UC_IDLE_CAP bytes sit idle, the largest idle blocks are freed down to the cap — after a hipDeviceSynchronize(),
+ *     i.e. with no kernel of this process in flight and the caches written back at the last kernel's end; nlopt_amd_release_device_memory()
+ *     does the same down to zero (a long-lived process that is done with its n >= 2048 runs). */
 #include <mutex>
-struct uc_block { void *p; size_t bytes; bool busy; };
+#include <vector>
+#define NLA_UC_IDLE_CAP ((size_t) 1 << 30)
+struct uc_block { void *p, *raw; size_t bytes; int dev; bool busy; };
 static std::mutex uc_mu;
-static uc_block uc_pool[64];
-static int uc_n = 0;
+static std::vector<uc_block> uc_pool;
 static long uc_raw_allocs = 0, uc_driver_frees = 0;       /* what tests/test_gpu_crs.py watches: see nla_debug_uncached_stats */
-static bool uc_pool_on()
+static int uc_switch(const char *name, int dflt)          /* development switches, read once (nla_switches.h: none in the shipped library) */
 {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("NLA_UC_POOL"); on = (e && atoi(e) == 0) ? 0 : 1; }    /* NLA_UC_POOL=0: the round-2 behaviour (A/B) */
-    return on != 0;
+    const char *e = NLA_DBG_ENV(name);
+    return e ? atoi(e) : dflt;
+}
+static bool uc_pool_on() { static const int on = uc_switch("NLA_UC_POOL", 1); return on != 0; }            /* 0: round 2's alloc / free per run (A/B) */
+static bool uc_disabled() { static const int off = uc_switch("NLA_NO_UNCACHED", 0); return off != 0; }     /* ordinary memory instead (A/B) */
+/* frees idle blocks of `dev`, largest first, until at most `keep` idle bytes remain; caller holds uc_mu and has made sure no block of
+ * the device is busy */
+static void uc_trim_locked(int dev, size_t keep)
+{
+    size_t idle = 0;
+    for (const uc_block &b : uc_pool) if (b.dev == dev && !b.busy) idle += b.bytes;
+    if (idle <= keep) return;
+    (void) hipDeviceSynchronize();
+    while (idle > keep) {
+        int big = -1;
+        for (int i = 0; i < (int) uc_pool.size(); ++i)
+            if (uc_pool[i].dev == dev && !uc_pool[i].busy && (big < 0 || uc_pool[i].bytes > uc_pool[big].bytes)) big = i;
+        if (big < 0) break;
+        idle -= uc_pool[big].bytes;
+        (void) hipFree(uc_pool[big].raw);
+        ++uc_driver_frees;
+        uc_pool.erase(uc_pool.begin() + big);
+    }
 }
 extern "C" void *nla_dev_malloc_uncached(size_t bytes)
 {
     void *p = nullptr;
+    int dev = 0;
     if (!bytes) bytes = 1;
-    if (getenv("NLA_NO_UNCACHED")) return nla_dev_malloc(bytes);         /* A/B switch (debugging): ordinary memory instead */
-    if (uc_pool_on()) {
+    if (uc_disabled()) return nla_dev_malloc(bytes);
+    if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    if (!uc_pool_on()) {
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+        std::lock_guard<std::mutex> g(uc_mu);
+        ++uc_raw_allocs;
+        return p;
+    }
+    const size_t two = (size_t) 2 << 20, want = (bytes + two - 1) / two * two;
+    {
         std::lock_guard<std::mutex> g(uc_mu);
         int best = -1;
-        for (int i = 0; i < uc_n; ++i)
-            if (!uc_pool[i].busy && uc_pool[i].bytes >= bytes && (best < 0 || uc_pool[i].bytes < uc_pool[best].bytes)) best = i;
-        if (best >= 0) { uc_pool[best].busy = true; return uc_pool[best].p; }
+        for (int i = 0; i < (int) uc_pool.size(); ++i) {
+            const uc_block &b = uc_pool[i];
+            if (b.dev == dev && !b.busy && b.bytes >= want && b.bytes <= 2 * want && (best < 0 || b.bytes < uc_pool[best].bytes)) best = i;
+        }
+        if (best >= 0) { uc_pool[best].busy = true; p = uc_pool[best].p; bytes = uc_pool[best].bytes; }
     }
-    if (uc_pool_on()) {
-        /* whole 2 MB pages of its own, with a guard page on either side: no ordinary allocation shares a page-table fragment with
-         * an uncached one */
-        const size_t two = (size_t) 2 << 20, want = (bytes + two - 1) / two * two;
+    if (!p) {
         void *raw = nullptr;
         if (hipExtMallocWithFlags(&raw, want + 2 * two, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
         p = (void *) (((uintptr_t) raw + two + two - 1) / two * two);
         bytes = want;
-    } else if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
-    { std::lock_guard<std::mutex> g(uc_mu); ++uc_raw_allocs; }
-    if (alloc_fill() >= 0 && (hipMemset(p, alloc_fill(), bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void) hipGetLastError();
-    if (uc_pool_on()) {
         std::lock_guard<std::mutex> g(uc_mu);
-        if (uc_n < 64) { uc_pool[uc_n].p = p; uc_pool[uc_n].bytes = bytes; uc_pool[uc_n].busy = true; ++uc_n; }
-        /* (a full table: the block is simply never pooled — and, by the rule above, never freed either: see nla_dev_free_uncached) */
+        ++uc_raw_allocs;
+        uc_pool.push_back(uc_block{p, raw, want, dev, true});
     }
+    if (alloc_fill() >= 0 && (hipMemset(p, alloc_fill(), bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) (void) hipGetLastError();
     return p;
 }
 extern "C" void nla_dev_free_uncached(void *p)
 {
     if (!p) return;
-    if (getenv("NLA_NO_UNCACHED")) { (void) hipFree(p); return; }
-    if (uc_pool_on()) {
-        std::lock_guard<std::mutex> g(uc_mu);
-        for (int i = 0; i < uc_n; ++i) if (uc_pool[i].p == p) { uc_pool[i].busy = false; return; }
-        return;                                   /* not in the table (it was full): kept until the process ends */
+    if (uc_disabled()) { (void) hipFree(p); return; }
+    std::lock_guard<std::mutex> g(uc_mu);
+    if (!uc_pool_on()) { ++uc_driver_frees; (void) hipFree(p); return; }
+    for (uc_block &b : uc_pool)
+        if (b.p == p) {
+            b.busy = false;
+            bool any_busy = false;
+            for (const uc_block &o : uc_pool) any_busy = any_busy || (o.dev == b.dev && o.busy);
+            if (!any_busy) {
+                int cur = 0;
+                const int dev = b.dev;
+                if (hipGetDevice(&cur) == hipSuccess && (cur == dev || hipSetDevice(dev) == hipSuccess)) {
+                    uc_trim_locked(dev, NLA_UC_IDLE_CAP);
+                    if (cur != dev) (void) hipSetDevice(cur);
+                } else (void) hipGetLastError();
+            }
+            return;
+        }
+}
+/* gives every idle uncached block (of every device) back to the driver — for a long-lived process between its large runs; blocks in
+ * use stay.  Returns the bytes released.  (include/nlopt_amd.h) */
+extern "C" size_t nlopt_amd_release_device_memory(void)
+{
+    std::lock_guard<std::mutex> g(uc_mu);
+    size_t before = 0, after = 0;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    for (const uc_block &b : uc_pool) if (!b.busy) before += b.bytes;
+    std::vector<int> devs;
+    for (const uc_block &b : uc_pool) {
+        bool seen = false, busy = false;
+        for (int d : devs) seen = seen || d == b.dev;
+        for (const uc_block &o : uc_pool) busy = busy || (o.dev == b.dev && o.busy);
+        if (!seen && !busy) devs.push_back(b.dev);
     }
-    { std::lock_guard<std::mutex> g(uc_mu); ++uc_driver_frees; }
-    (void) hipFree(p);
+    for (int d : devs) if (d == cur || hipSetDevice(d) == hipSuccess) uc_trim_locked(d, 0);
+    (void) hipSetDevice(cur);
+    for (const uc_block &b : uc_pool) if (!b.busy) after += b.bytes;
+    return before - after;
 }
 /* [0] uncached allocations obtained from the driver so far, [1] of them returned to it, [2] blocks in the pool, [3] of them in use */
 extern "C" void nla_debug_uncached_stats(long out[4])
 {
     std::lock_guard<std::mutex> g(uc_mu);
     int busy = 0;
-    for (int i = 0; i < uc_n; ++i) busy += uc_pool[i].busy ? 1 : 0;
-    out[0] = uc_raw_allocs; out[1] = uc_driver_frees; out[2] = uc_n; out[3] = busy;
+    for (const uc_block &b : uc_pool) busy += b.busy ? 1 : 0;
+    out[0] = uc_raw_allocs; out[1] = uc_driver_frees; out[2] = (long) uc_pool.size(); out[3] = busy;
 }
 /* development aid (tools/stress_crs.py --uc-churn): one raw uncached allocation, written once, given straight back to the driver —
  * what every round-2 run did with its trial-point buffers */
@@ -120,6 +186,13 @@ extern "C" void *nla_host_malloc(size_t bytes)
     return p;
 }
 extern "C" void nla_host_free(void *p) { if (p) (void) hipHostFree(p); }
+/* host memory the caller owns (the shm transport's segment) made page-locked and device-visible */
+extern "C" int nla_host_register(void *p, size_t bytes)
+{
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void) hipGetLastError(); return -1; }
+    return 0;
+}
+extern "C" void nla_host_unregister(void *p) { if (p && hipHostUnregister(p) != hipSuccess) (void) hipGetLastError(); }
 
 extern "C" int nla_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream)
 {

@@ -14,7 +14,8 @@
  *   low word   [0,12) individual, low 12 bits | [12,32) dense rank of f
  *   high word  [0,8) individual, high 8 bits  | [8,28) dense rank of penalty | bit 31: penalty == 0
  * (dense rank = number of strictly smaller values, so integer compares reproduce the reference's
- * fp64 compares including ties); populations up to 2^20.
+ * fp64 compares including ties); populations up to 2^20 — larger ones only without constraints, where no generation ranks
+ * stochastically (the sort by f needs no packed elements).
  */
 #include "dev_common.h"
 #include "../../../include/nlopt_amd.h"
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void isres_rank_count_kernel(int64_t pop, cons
         }
     }
     if (live) {
-        elems[k] = isres_pack((uint32_t) k, rf, rp, pk == 0);
+        if (pop <= (1 << ISRES_IDX_BITS)) elems[k] = isres_pack((uint32_t) k, rf, rp, pk == 0);
         sorted[ps] = (int32_t) k;
     }
 }
@@ -737,7 +738,8 @@ extern "C" int nla_k_isres_eval(int obj, int n, int ld, const double *X, int64_t
 extern "C" int nla_k_isres_rank_count(int64_t pop, const double *F, const double *PEN, uint64_t *elems, int32_t *sorted, void *stream)
 {
     if (pop <= 0) return 0;
-    if (pop > (1 << ISRES_IDX_BITS)) return (int) hipErrorInvalidValue;
+    /* above 2^20 individuals only `sorted` (the stable sort by f: all a generation without penalties needs, isres.c:203-204) is
+     * meaningful: the packed elements have 20 bits per field, and the driver admits such populations only without constraints */
     hipLaunchKernelGGL(isres_rank_count_kernel, dim3((unsigned) ((pop + 255) / 256)), dim3(256), 0, (hipStream_t) stream, pop, F, PEN, elems, sorted);
     NLA_LAUNCH_CHECK();
     return 0;

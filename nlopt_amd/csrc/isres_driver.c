@@ -27,6 +27,7 @@
  * run on the device.  There is no CPU fallback for the device work.
  */
 #include "nla_internal.h"
+#include "nla_switches.h"
 #include "objfuncs.h"
 #include <math.h>
 #include <stdio.h>
@@ -45,6 +46,7 @@ typedef struct {
     int bits_two_pass;              /* A/B switch: ranking words through a buffer + isres_bits_kernel instead of the fused kernel */
     void *st, *ev0, *ev1;
     void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
+    int evolve_serial;              /* "amd_isres_evolve_serial" != 0: the one-workgroup evolve kernel (the parallel one's reference in the tests) */
     int overlap;                    /* default; "amd_isres_overlap" = 0 / NLA_ISRES_OVERLAP=0 turn it off: generator work beside the latency-bound kernels */
     int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
     uint64_t spec_made, spec_used;  /* ... how often, and how often the evolve phase could take them */
@@ -109,7 +111,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
         while (d->wchunk < need && d->wchunk < WORD_CHUNK_MAX) d->wchunk <<= 1;
     }
     d->st = nla_stream_create();
-    { const char *e = getenv("NLA_ISRES_BITS_TWO_PASS"); d->bits_two_pass = e && atoi(e) > 0; }
+    { const char *e = NLA_DBG_ENV("NLA_ISRES_BITS_TWO_PASS"); d->bits_two_pass = e && atoi(e) > 0; }
     d->ev0 = nla_event_create(); d->ev1 = nla_event_create();      /* device time of the ranking kernel for the stats */
     if (!d->st || !d->ev0 || !d->ev1) return -1;
     /* OVERLAP (measured on MI355X, config 3: 72.9 -> 65.3 ms per generation; profiles/r03_isres_overlap_ab.txt): the generator — segment-state jumps, ranking bits, the evolve phase's deviates —
@@ -121,7 +123,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
      *   the evolve rounds (serial look-up chains)  ||  the segment states the NEXT ranking's words start from
      * Every hand-over between the two streams is a host synchronisation of the producing stream (the driver synchronises at these
      * points anyway): nothing is ordered by events, and with overlap off rs IS st — the one-stream code of rounds 1-2. */
-    d->rs = !d->overlap ? d->st : (getenv("NLA_ISRES_RS_BACKGROUND") && atoi(getenv("NLA_ISRES_RS_BACKGROUND")) > 0 ? nla_stream_create_background() : nla_stream_create());
+    d->rs = !d->overlap ? d->st : (nla_dbg_int("NLA_ISRES_RS_BACKGROUND", 0) > 0 ? nla_stream_create_background() : nla_stream_create());
     if (!d->rs) return -1;
     d->mts = nla_mtstream_create(d->rs);
     if (!d->mts) return -1;
@@ -129,12 +131,14 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     A(d_lb, double, ld); A(d_ub, double, ld); A(d_X, double, pop * ld); A(d_S, double, pop * ld);
     A(d_F, double, d->popcap); A(d_PEN, double, d->popcap); A(d_GPEN, double, d->popcap); A(d_FEAS, int32_t, d->popcap);
     A(d_irank, int32_t, pop); A(d_scratch, double, 3 * ld);
-    A(d_streams, uint64_t, (size_t) (d->units + 1) * pop); A(d_progress, int, d->units + 1); A(d_ticket, int, 1);
-    A(d_swapped, uint8_t, pop); A(d_bits, uint64_t, (size_t) d->popcap * (size_t) d->rowwords);      /* (equal blocks of `per` rows for the all-gather) */
+    /* the stochastic ranking's pipeline state and uniform bits (pop^2 / 8 bytes each) only where a penalty can be nonzero: without
+     * constraints every generation sorts by f (isres.c:203-204), and the population may then be as large as the rows fit */
+    A(d_streams, uint64_t, (size_t) ((d->m + d->p > 0 ? d->units : 0) + 1) * pop); A(d_progress, int, d->units + 1); A(d_ticket, int, 1);
+    A(d_swapped, uint8_t, pop); A(d_bits, uint64_t, d->m + d->p > 0 ? (size_t) d->popcap * (size_t) d->rowwords : 1);      /* (equal blocks of `per` rows for the all-gather) */
     A(d_words, uint32_t, d->wchunk); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
     A(d_counts, int32_t, d->wchunk / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
     A(d_con, nla_dev_constraint, d->m + d->p + 1);
-    d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !getenv("NLA_ISRES_EVOLVE_SERIAL");
+    d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !d->evolve_serial && !NLA_DBG_ENV("NLA_ISRES_EVOLVE_SERIAL");
     if (d->parallel_evolve) {
         A(d_inv, int32_t, pop); A(d_rho, double, 4);
         d->d_ws = nla_dev_malloc(nla_isres_evolve2_ws_bytes(d->n));
@@ -393,8 +397,8 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
             if (!d->parallel_evolve || state[0] >= kend) break;
         }
     }
-    if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve2: rounds enqueued %llu, serial fallbacks %llu; overlap %d: deviates generated ahead %llu times, used %llu times\n", (unsigned long long) d->ev_rounds, (unsigned long long) d->ev_fallbacks, d->overlap, (unsigned long long) d->spec_made, (unsigned long long) d->spec_used);
-    if (getenv("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve: fixpoint rounds %lld for %lld individuals, deviates %lld; cycles stage %lld eval %lld scan %lld fin %lld all %lld\n", (long long) state[3], (long long) d->pop, (long long) state[1], (long long) state[4], (long long) state[5], (long long) state[6], (long long) state[7], (long long) state[8]);
+    if (NLA_DBG_ENV("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve2: rounds enqueued %llu, serial fallbacks %llu; overlap %d: deviates generated ahead %llu times, used %llu times\n", (unsigned long long) d->ev_rounds, (unsigned long long) d->ev_fallbacks, d->overlap, (unsigned long long) d->spec_made, (unsigned long long) d->spec_used);
+    if (NLA_DBG_ENV("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve: fixpoint rounds %lld for %lld individuals, deviates %lld; cycles stage %lld eval %lld scan %lld fin %lld all %lld\n", (long long) state[3], (long long) d->pop, (long long) state[1], (long long) state[4], (long long) state[5], (long long) state[6], (long long) state[7], (long long) state[8]);
     if (state[1] <= 0) DFAIL(d, "evolve consumed no deviates");
     DCK(d, nla_memcpy_d2h(&last_att, d->d_zatt + (state[1] - 1), sizeof last_att, d->st));
     DCK(d, nla_stream_sync(d->st));
@@ -451,7 +455,13 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         nla_comm_agree_ready(opt ? opt->comm : NULL, 0);
         return NLOPT_FAILURE;
     }
-    if (population > (1 << 20)) { nla_stop_msg(stop, "nlopt_amd: ISRES populations above 2^20 are not supported"); return NLOPT_INVALID_ARGS; }
+    /* the stochastic ranking packs (individual, rank of f, rank of penalty) into 64 bits, 20 bits each (hip/isres_kernels.hip), and its
+     * uniforms' bits take pop^2 / 8 bytes (137 GB at 2^20); without constraints no generation ranks stochastically (all penalties
+     * are 0: isres.c:203-204 sorts by f) and the population is only bounded by what the rows need in memory */
+    if (population > (1 << 20) && m + p > 0) {
+        nla_stop_msg(stop, "nlopt_amd: ISRES with nonlinear constraints supports populations up to 2^20 (the stochastic ranking's state grows as population^2)");
+        return NLOPT_INVALID_ARGS;
+    }
 
     /* can everything be evaluated on the device? */
     memset(&D, 0, sizeof D);
@@ -473,8 +483,9 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
 
     D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
     D.comm = opt ? opt->comm : NULL;
+    D.evolve_serial = opt ? nlopt_get_param(opt, "amd_isres_evolve_serial", 0) != 0 : 0;
     D.overlap = opt ? nlopt_get_param(opt, "amd_isres_overlap", 1) != 0 : 1;            /* 0: the one-stream generation */
-    if (getenv("NLA_ISRES_OVERLAP")) D.overlap = atoi(getenv("NLA_ISRES_OVERLAP")) > 0;     /* A/B switch for the bench */
+    D.overlap = nla_dbg_int("NLA_ISRES_OVERLAP", D.overlap) > 0;     /* A/B switch for the bench */
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */
     {   /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
         const int mine = dev_alloc(&D, lb, ub, con) == 0;
@@ -612,7 +623,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         t0 = nla_seconds();
         {
             int has_nan = 0;
-            if (!getenv("NLA_ISRES_NO_NAN_HOST"))           /* (A/B switch for the tests: without the host selection a NaN generation differs) */
+            if (!NLA_DBG_ENV("NLA_ISRES_NO_NAN_HOST"))           /* (A/B switch for the tests: without the host selection a NaN generation differs) */
             for (k = 0; k < D.pop && !has_nan; ++k) has_nan = (D.h_F[k] != D.h_F[k]) || (D.h_PEN[k] != D.h_PEN[k]);
             if (has_nan ? host_rank_with_nan(&D, all_feasible, &sweeps) : dev_rank(&D, all_feasible, &sweeps, &t_rng, st)) DEVFAIL();
         }

@@ -32,6 +32,7 @@
  * index, sobol.c; no MT words are drawn in that mode).
  */
 #include "nla_internal.h"
+#include "nla_switches.h"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -288,7 +289,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
      * 7.5 ms sampling phase.  Nothing between two sampling phases draws random numbers (the local optimisers are deterministic), so
      * the NEXT iteration's words are generated on a stream of their own beside the distance pass and the local searches.  Hand-over
      * = a host synchronisation of that stream before the sampling kernel reads them. */
-    D.prefetch = !host && ((opt && nlopt_get_param(opt, "amd_mlsl_prefetch", 0) != 0) || (getenv("NLA_MLSL_PREFETCH") && atoi(getenv("NLA_MLSL_PREFETCH")) > 0));
+    D.prefetch = !host && ((opt && nlopt_get_param(opt, "amd_mlsl_prefetch", 0) != 0) || nla_dbg_int("NLA_MLSL_PREFETCH", 0) > 0);
     D.prefetched_at = ~0ULL;
     D.rs = (D.st && D.prefetch) ? nla_stream_create() : D.st;
     if (!D.st || !D.rs || !(D.mts = nla_mtstream_create(D.rs))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); nla_comm_agree_ready(D.comm, 0); mfree(&D); return NLOPT_OUT_OF_MEMORY; }

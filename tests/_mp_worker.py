@@ -32,6 +32,9 @@ def main():
         uid = [nlopt_amd.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = nlopt_amd.Comm.rccl(rank, world, uid[0])
+    elif os.environ.get("NLA_TEST_SHM"):
+        # the library's own shared-memory transport (comm.c): no Python in the exchange; the gloo group only starts the ranks together
+        comm = nlopt_amd.Comm.shm(rank, world, "/nla_test_%s" % os.environ["MASTER_PORT"], int(os.environ.get("NLA_TEST_SHM_SLOT", "0")))
     else:
         comm = nlopt_amd.Comm.from_torch_distributed()
     res = {}

@@ -94,14 +94,13 @@ def test_isres_matches_oracle_larger(obj, n, pop, seed, nineq, neq, kw):
     assert a["stats"]["generations"] >= 1
 
 
-def test_full_size_config3_parallel_evolve_equals_the_serial_chain(monkeypatch):
+def test_full_size_config3_parallel_evolve_equals_the_serial_chain():
     """BASELINE config 3 at full size (n = 256, pop = 5e4, 4 inequality constraints; the CPU reference needs ~86 s per
     generation there): the multi-start look-up evolve (hip/isres_evolve2.hip) and the serial chain kernel must give the
     same population trajectory — same f of every candidate, same best point, same stream position."""
     kw = dict(maxeval=150000)
     a = run_amd("rastrigin", 256, 50000, 42, 4, 0, **kw)
-    monkeypatch.setenv("NLA_ISRES_EVOLVE_SERIAL", "1")
-    b = run_amd("rastrigin", 256, 50000, 42, 4, 0, **kw)
+    b = run_amd("rastrigin", 256, 50000, 42, 4, 0, params={"amd_isres_evolve_serial": 1}, **kw)
     assert a["ret"] == b["ret"] and a["nevals"] == b["nevals"] == 150000
     assert np.array_equal(a["trace"]["f"], b["trace"]["f"]) and np.array_equal(a["x"], b["x"]) and a["minf"] == b["minf"]
     assert a["stats"]["mt_words"] == b["stats"]["mt_words"] and a["stats"]["rank_sweeps"] == 2 * 50000
@@ -201,3 +200,30 @@ def test_stochastic_ranking_kernels_against_serial_loop(pop, seed):
     # the stable sort by f used when everything is feasible
     order = sorted(range(pop), key=lambda k: (f[k], k))
     assert list(dsorted.to_array(np.int32, pop)) == order
+
+
+def test_population_above_2pow20_without_constraints():
+    """isres.c:86-93 puts no limit on the population.  Without constraints no generation ranks stochastically (every penalty is 0:
+    the selection is the sort by f, isres.c:203-204), so the 2^20 limit of the packed ranking elements does not apply: 2^20 + 1000
+    individuals, one generation and the start of the second, every evaluation against the real reference (or the port)."""
+    obj, n, pop, seed = "rosenbrock", 2, (1 << 20) + 1000, 9
+    me = pop + 3000
+    a = run_amd(obj, n, pop, seed, maxeval=me, trace_cap=me + 16)
+    p = O.run_ref_isres(obj, n, pop, seed, maxeval=me) if O.have_ref() else O.run_port_isres(obj, n, pop, seed, maxeval=me)
+    fp = p["fseq"] if "fseq" in p else p["ftrace"]
+    assert a["ret"] == p["ret"] == nlopt_amd.MAXEVAL_REACHED and a["nevals"] == p["nevals"] == me, a["err"]
+    fa = a["trace"]["f"]
+    assert len(fa) == len(fp) == me
+    assert np.all(np.abs(fa - fp) <= 1e-10 * np.maximum(np.abs(fp), np.abs(fp).mean()))
+    assert abs(a["minf"] - p["minf"]) <= 1e-10 * max(abs(p["minf"]), 1e-300) and np.allclose(a["x"], p["x"], rtol=1e-9, atol=1e-12)
+
+
+def test_population_above_2pow20_with_constraints_says_so():
+    o = nlopt_amd.Opt(nlopt_amd.GN_ISRES, 4)
+    o.set_lower_bounds(-1.0); o.set_upper_bounds(1.0)
+    o.set_min_objective(nlopt_amd.objective("sphere"))
+    o.add_blocksum_constraints(2, 1e-8)
+    o.set_population((1 << 20) + 1)
+    o.set_maxeval(10)
+    x, minf, ret = o.optimize_raw(np.zeros(4))
+    assert ret == nlopt_amd.INVALID_ARGS and "2^20" in o.get_errmsg()

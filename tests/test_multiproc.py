@@ -355,3 +355,37 @@ def test_mlsl_prefetch_of_the_next_samples_changes_nothing(world, obj, n, ns, se
         samp, loc = d["kind"] == 3, d["kind"] == 4
         assert np.array_equal(d["f"][samp], p["fsamp"][:samp.sum()]) and samp.sum() in (len(p["fsamp"]), len(p["fsamp"]) - 1)
         assert np.array_equal(d["f"][loc], p["floc"]) and np.array_equal(d["accepted"][loc], p["eloc"])
+
+
+# ---- the library's shared-memory transport (comm.c, nlopt_amd_comm_create_shm): no Python in the exchange ---------------------------
+@pytest.mark.parametrize("world,slot", [(2, 0), (3, 0), (3, 4096)])
+def test_shm_transport_allgather(world, slot):
+    """the same contract as the gloo transport's (partition, rank-major all-gather, counters) — with a 4 KB slot the 300 001-byte
+    payload travels in 74 pieces through the two alternating slot sets"""
+    res = run_world("comm", world=world, extra_env=dict(NLA_TEST_SHM="1", NLA_TEST_SHM_SLOT=str(slot)))
+    for r, d in enumerate(res):
+        assert np.array_equal(d["gathered"], np.array([np.arange(5.0) + 100.0 * q for q in range(world)]))
+        assert d["big_ok"][0] == 1
+        assert d["counters"][0] == 2 and d["counters"][1] == world * (40 + 300001)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("obj,n,pop,seed,maxeval,extra", [SHARDED_CRS[0], SHARDED_CRS[3]])
+def test_crs_column_sharded_over_the_shm_transport(world, obj, n, pop, seed, maxeval, extra):
+    """the column-sharded CRS2_LM run with the candidates exchanged through the shared-memory transport: the oracle's run bit for bit"""
+    kw = {k: v for k, v in extra.items() if k in ("ftol_rel", "xtol_rel")}
+    res = run_world("gpu_crs", dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=maxeval, **extra), world=world, extra_env=dict(EMU, NLA_TEST_SHM="1"))
+    p = O.run_port_crs(obj, n, pop, seed, maxeval=maxeval, trace_cap=maxeval + 4096, **kw)
+    for d in res:
+        assert d["ret"][0] == p["ret"] and d["nevals"][0] == p["nevals"] and d["minf"][0] == p["minf"] and np.array_equal(d["x"], p["x"])
+        for key in ("f", "row", "kind", "accepted"):
+            assert np.array_equal(d[key], p["trace"][key]), key
+        assert d["collectives"][0] >= d["rounds"][0] and d["stats_allgather_bytes"][0] > 0
+
+
+def test_isres_over_the_shm_transport_world3():
+    obj, n, pop, seed, ncon, gens = "rastrigin", 12, 60, 5, 2, 6
+    res = run_world("gpu_isres", dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=gens * pop, ncon=ncon), world=3, extra_env=dict(EMU, NLA_TEST_SHM="1", NLA_TEST_SHM_SLOT="4096"))
+    p = O.run_port_isres(obj, n, pop, seed, nineq=ncon, maxeval=gens * pop)
+    for d in res:
+        _check_against_oracle(d, p)

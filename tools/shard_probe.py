@@ -1,6 +1,7 @@
 """What does a pass of the column-sharded CRS2_LM cost?  (development aid, run on the MI355X box)
 
-The GPU box has ONE GPU, so the ranks of a sharded job share it (host transport over gloo): the gather of a pass is not faster
+The GPU box has ONE GPU, so the ranks of a sharded job share it (round 4: over the library's own shared-memory transport, comm.c —
+round 3's figure of 226 ms per pass was the Python / gloo hop of the test transport, not the library): the gather of a pass is not faster
 than on one rank — what this measures is everything else a sharded pass adds (the candidates' pack / all-gather / evaluation, the
 stop agreement, the pointer-based list upload) next to the single-process conservative passes and the chain kernel, at the metric
 configuration and at BASELINE config 5's population.  profiles/r03_shard_probe.txt; DESIGN.md section 6 builds its 8-GPU
@@ -18,12 +19,14 @@ n = 4096
 for pop, evals in ((100000, 6000), (400000, 6000)):
     base = dict(obj="griewank", n=n, pop=pop, seed=42, evals=evals)
     rows = []
-    for label, world, params in (("1 rank, chain kernel (default)", 1, {}),
-                                 ("1 rank, conservative passes", 1, {"amd_forward": 0}),
-                                 ("2 ranks sharing the GPU, column-sharded (host transport)", 2, {}),
-                                 ("2 ranks sharing the GPU, replicas (amd_shard=0)", 2, {"amd_shard": 0})):
+    SHM = dict(NLA_TEST_SHM="1")
+    for label, world, params, env in (("1 rank, chain kernel (default)", 1, {}, {}),
+                                      ("1 rank, conservative passes", 1, {"amd_forward": 0}, {}),
+                                      ("2 ranks sharing the GPU, column-sharded, shm transport (comm.c)", 2, {}, SHM),
+                                      ("3 ranks sharing the GPU, column-sharded, shm transport (comm.c)", 3, {}, SHM),
+                                      ("2 ranks sharing the GPU, replicas (amd_shard=0), shm transport", 2, {"amd_shard": 0}, SHM)):
         try:
-            res = run_world("gpu_crs_rate", dict(base, params=params), world=world, timeout=600)
+            res = run_world("gpu_crs_rate", dict(base, params=params), world=world, timeout=600, extra_env=env)
             d = res[0]
             rows.append(dict(case=label, pop=pop, evals_per_s=float(d["evals_per_s"][0]), passes=int(d["passes"][0]), us_per_pass=1e6 * float(d["dt"][0]) / max(int(d["passes"][0]), 1),
                              evals_per_pass=float(d["evals"][0]) / max(int(d["passes"][0]), 1), t_init_s=float(d["t_init"][0]),
