@@ -453,9 +453,10 @@ extern "C" int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, cons
     nla_local_ext E = {};
     if (P.sign == 0.) P.sign = 1.;
     /* a device objective, n <= 4096, tree sums: the resident kernel (lbfgs_resident.hip) — the same search bit for bit;
-     * exact == 2 ("amd_lbfgs_streaming"): tree sums on THIS kernel, for the test that compares the two */
+     * exact == 2 / 3 ("amd_lbfgs_streaming"): tree sums / the reference's order on THIS kernel, for the tests that compare the two */
     if (nla_lbfgs_resident_supported(obj, n, &P)) return nla_k_lbfgs_batch_resident(obj, n, ld, mf, count, lb, ub, X, work, hist, &P, out, stream);
     if (P.exact == 2) P.exact = 0;
+    if (P.exact == 3) P.exact = 1;                 /* the reference's summation order on THIS kernel */
     if (obj == NLA_OBJ_EXTERNAL) {
         if (!ext || !ext->req || !ext->EX || !ext->EG || !ext->EF || !ext->save) return (int) hipErrorInvalidValue;
         E = *ext;

@@ -25,6 +25,7 @@
  */
 #include "local_common.h"
 #include <limits.h>
+#include <type_traits>
 #include "../lbfgs_scalar.h"
 #include "../../../include/nlopt_amd.h"
 
@@ -112,6 +113,52 @@ __device__ __forceinline__ int lr_reduce_isum(int a, lr_red &R, int &par)
     return a;
 }
 
+/* ---- sums in the REFERENCE'S order ("amd_exact_dot" = 1): one accumulator over i = 0 .. n-1 (mssubs.c:601-641 mxudot, stop.c:37-57,
+ * the zoo's loops).  The coordinates come in blocks of LB_T consecutive ones (thread t holds t + LB_T e): a block's terms are
+ * staged in LDS, every wavefront then adds them up in order for itself — 64 terms per LDS read, handed to the accumulator one by
+ * one with v_readlane (the value travels through scalar registers: no LDS traffic in the dependent chain) — so all threads hold the
+ * bit-identical sum the sequential host loop produces.  Two staging sets used in turn: ONE barrier per block.  Two sums (or a sum
+ * and a product: Griewank) run as two independent chains in one pass. */
+struct lr_xbuf { double a[2][LB_T], b[2][LB_T]; };
+struct lr_nobuf { };
+__device__ __forceinline__ double lr_lane(double v, int l)
+{
+#ifdef NLA_SIMT_EMU
+    (void) l; return v;
+#else
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+#endif
+}
+template <bool PROD>
+__device__ __forceinline__ void lr_seq2(int nterms, double &ra, double &rb, const double (&ta)[LR_E], const double (&tb)[LR_E], lr_xbuf &XB, int &xpar)
+{
+    const unsigned tid = threadIdx.x;
+    double a = ra, b = rb;
+#pragma unroll
+    for (int e = 0; e < LR_E; ++e) {
+        const int m = nterms - e * LB_T;                 /* terms in this block (uniform) */
+        if (m > 0) {
+            const int mm = m < LB_T ? m : LB_T;
+            XB.a[xpar][tid] = ta[e]; XB.b[xpar][tid] = tb[e];
+            __syncthreads();
+#ifdef NLA_SIMT_EMU
+            for (int i = 0; i < mm; ++i) { a += XB.a[xpar][i]; if (PROD) b *= XB.b[xpar][i]; else b += XB.b[xpar][i]; }
+#else
+            for (int c = 0; c < mm; c += 64) {
+                const double va = XB.a[xpar][c + (tid & 63)], vb = XB.b[xpar][c + (tid & 63)];
+                if (mm - c >= 64) {
+#pragma unroll
+                    for (int l = 0; l < 64; ++l) { a += lr_lane(va, l); if (PROD) b *= lr_lane(vb, l); else b += lr_lane(vb, l); }
+                } else for (int l = 0; l < mm - c; ++l) { a += lr_lane(va, l); if (PROD) b *= lr_lane(vb, l); else b += lr_lane(vb, l); }
+            }
+#endif
+            xpar ^= 1;
+        }
+    }
+    ra = a; rb = b;
+}
+template <bool PROD> __device__ __forceinline__ void lr_seq2(int, double &, double &, const double (&)[LR_E], const double (&)[LR_E], lr_nobuf &, int &) { }
+
 /* sin and cos of one argument at once: Ackley and Rastrigin need cos(2 pi x) for f and sin(2 pi x) for the gradient of the SAME
  * coordinates — one argument reduction and one pair of polynomials instead of two (the device library's sincos returns exactly
  * the two values its sin and cos return: tests/test_gpu_lbfgs.py::test_device_sincos_is_sin_and_cos; glibc's does NOT
@@ -126,14 +173,43 @@ __device__ __forceinline__ void lr_sincos(double a, double *sn, double *cs)
 }
 
 /* objective and gradient of the point in LDS (x -> g), the formulas and the summation tree of lb_objgrad (local_common.h) */
-template <int OBJ>
-__device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, lr_red &R, int &par, double sign)
+template <int OBJ, bool EXACT, class XBuf>
+__device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, lr_red &R, int &par, double sign, XBuf &XB, int &xpar)
 {
     const int tid = threadIdx.x;
     constexpr bool FUSED = OBJ == NLA_OBJ_RASTRIGIN || OBJ == NLA_OBJ_ACKLEY;
     double sn[FUSED ? LR_E : 1];
     nla_obj_part t;
-    if (FUSED) {                   /* nla_obj_partial's sums (thread-strided, coordinate order) with the sines kept for the gradient */
+    if constexpr (EXACT) {
+        /* f in the host callback's summation order (../objfuncs.h nla_obj_eval_seq; local_common.h lb_obj_exact): one accumulator over i
+         * ascending with the accumulator's start value as there; t = the sums the gradient formulas need */
+        constexpr bool PROD = OBJ == NLA_OBJ_GRIEWANK;
+        double ta[LR_E], tb[LR_E], ia = 0., ib = PROD ? 1. : 0.;
+        int nt = n;
+        if (OBJ == NLA_OBJ_RASTRIGIN) ia = 10.0 * n;
+        if (OBJ == NLA_OBJ_GRIEWANK) ia = 1.;
+        if (OBJ == NLA_OBJ_ROSENBROCK || OBJ == NLA_OBJ_LEVY) nt = n - 1;
+        if (OBJ == NLA_OBJ_LEVY) ia = nla_levy_head(x[0], x[n - 1]);
+#pragma unroll
+        for (int e = 0; e < LR_E; ++e) {
+            const int i = tid + e * LB_T;
+            ta[e] = 0.; tb[e] = PROD ? 1. : 0.; sn[FUSED ? e : 0] = 0.;
+            if (i < nt) {
+                const double xv = x[i];
+                if (FUSED) {
+                    double cs;
+                    lr_sincos(NLA_PI2 * xv, &sn[FUSED ? e : 0], &cs);
+                    if (OBJ == NLA_OBJ_RASTRIGIN) ta[e] = xv * xv - 10.0 * cs;
+                    else { ta[e] = nla_sqr(xv); tb[e] = cs; }
+                } else if (OBJ == NLA_OBJ_GRIEWANK) { ta[e] = nla_griewank_sum_term(xv); tb[e] = nla_griewank_prod_term(xv, (unsigned) i); }
+                else if (OBJ == NLA_OBJ_ROSENBROCK) ta[e] = nla_rosenbrock_term(xv, x[i + 1]);
+                else if (OBJ == NLA_OBJ_LEVY) ta[e] = nla_levy_term(xv, x[i + 1]);
+                else ta[e] = nla_sqr(xv);
+            }
+        }
+        lr_seq2<PROD>(nt, ia, ib, ta, tb, XB, xpar);
+        t.a = ia; t.b = (OBJ == NLA_OBJ_ACKLEY || PROD) ? ib : 0.;
+    } else if (FUSED) {                   /* nla_obj_partial's sums (thread-strided, coordinate order) with the sines kept for the gradient */
         t.a = 0; t.b = 0;
 #pragma unroll
         for (int e = 0; e < LR_E; ++e) {
@@ -148,14 +224,19 @@ __device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, 
             }
         }
     } else t = nla_obj_partial<OBJ>(n, tid, LB_T, [&](int i) { return x[i]; });
-    t = nla_obj_wave_reduce<OBJ>(t);
-    if ((tid & 63) == 0) { R.v[par][tid >> 6][0] = t.a; R.v[par][tid >> 6][1] = t.b; }
-    __syncthreads();
-    t.a = R.v[par][0][0]; t.b = R.v[par][0][1];
+    double f;
+    if constexpr (EXACT) {
+        f = OBJ == NLA_OBJ_ACKLEY ? nla_ackley_finish(t.a, t.b, (unsigned) n) : (OBJ == NLA_OBJ_GRIEWANK ? t.a - t.b : t.a);
+    } else {
+        t = nla_obj_wave_reduce<OBJ>(t);
+        if ((tid & 63) == 0) { R.v[par][tid >> 6][0] = t.a; R.v[par][tid >> 6][1] = t.b; }
+        __syncthreads();
+        t.a = R.v[par][0][0]; t.b = R.v[par][0][1];
 #pragma unroll
-    for (int w = 1; w < LB_W; ++w) { nla_obj_part o; o.a = R.v[par][w][0]; o.b = R.v[par][w][1]; t = nla_obj_combine<OBJ>(t, o); }
-    par ^= 1;
-    double f = nla_obj_finish<OBJ>(n, t, [&](int i) { return x[i]; });
+        for (int w = 1; w < LB_W; ++w) { nla_obj_part o; o.a = R.v[par][w][0]; o.b = R.v[par][w][1]; t = nla_obj_combine<OBJ>(t, o); }
+        par ^= 1;
+        f = nla_obj_finish<OBJ>(n, t, [&](int i) { return x[i]; });
+    }
     if (OBJ == NLA_OBJ_RASTRIGIN) {
 #pragma unroll
         for (int e = 0; e < LR_E; ++e) { const int i = tid + e * LB_T; if (i < n) g[i] = 2 * x[i] + 10.0 * NLA_PI2 * sn[FUSED ? e : 0]; }
@@ -262,7 +343,7 @@ __device__ __forceinline__ void lr_bstore(double v, lr_buf b, unsigned voff, uns
 #define LR_LD(buf, e) lr_bload(buf, voff, (unsigned) (e) * (LB_T * 8u))
 #define LR_ST(v, buf, e) lr_bstore(v, buf, voff, (unsigned) (e) * (LB_T * 8u))
 
-template <int OBJ>
+template <int OBJ, bool EXACT>
 __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbfgs_resident_kernel(
     int n, int ld, int mf, int count, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ X,
     double *__restrict__ work, double *__restrict__ hist, nla_lbfgs_params P, nla_lbfgs_result *__restrict__ out)
@@ -270,7 +351,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     /* one LDS block with the scalar state FIRST: its fields then sit at small constant addresses (ds instructions carry a 16-bit
      * offset); behind the 64 KB of vectors every field needed an address register of its own, which the compiler kept alive
      * across the whole search and spilled */
-    __shared__ struct { lr_ctl C; lr_red R; signed char six[LR_NMAX]; double sx[LR_NMAX], sg[LR_NMAX]; } L;
+    __shared__ struct { lr_ctl C; lr_red R; typename std::conditional<EXACT, lr_xbuf, lr_nobuf>::type XB; signed char six[LR_NMAX]; double sx[LR_NMAX], sg[LR_NMAX]; } L;
     lr_ctl &C = L.C;
     lr_red &R = L.R;
     signed char *const six = L.six;
@@ -285,7 +366,8 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
      * themselves: ONE pair of vectors for all searches of the batch (cache-resident) instead of a copy per search */
     const lr_buf bxl = lr_make_buf(lb, nbytes), bxu = lr_make_buf(ub, nbytes);
     const double eta9 = 1e120, eps8 = 1., eps9 = 1e-8, alf1 = 1e-10, alf2 = 1e10, told = 1e-4, xmax = 1e16, maxf = 1e20, minf_est = -HUGE_VAL;
-    int par = 0, go;
+    int par = 0, xpar = 0, go;
+    (void) xpar;
     double sr[LR_E];                    /* the search direction, this thread's coordinates */
     PROF_DECL;
     /* column "i-th newest" of the ring (the reference shifts all columns every iteration, mxdrsu, mssubs.c:503-524); head < mf, i <= mf */
@@ -314,6 +396,24 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             }                                                                                                               \
             sx[i] = v;                                                                                                      \
         }                                                                                                                   \
+    } while (0)
+
+    /* a sum (two sums) over this thread's coordinates e where MASK holds: the workgroup tree, or the reference's order (EXACT) */
+#define LR_SUM2(ra, rb, MASK, TA, TB) do {                                                                                  \
+        ra = 0.; rb = 0.;                                                                                                   \
+        if constexpr (EXACT) {                                                                                              \
+            double ta_[LR_E], tb_[LR_E];                                                                                    \
+            LR_FOR(e) { ta_[e] = 0.; tb_[e] = 0.; if (MASK) { ta_[e] = (TA); tb_[e] = (TB); } }                             \
+            lr_seq2<false>(n, ra, rb, ta_, tb_, L.XB, xpar);                                                                \
+        } else { LR_FOR(e) if (MASK) { ra += (TA); rb += (TB); } lr_reduce2<false>(ra, rb, R, par); }                        \
+    } while (0)
+#define LR_SUM1(ra, MASK, TA) do {                                                                                          \
+        ra = 0.;                                                                                                            \
+        if constexpr (EXACT) {                                                                                              \
+            double ta_[LR_E], tb_[LR_E], rb_ = 0.;                                                                          \
+            LR_FOR(e) { ta_[e] = 0.; tb_[e] = 0.; if (MASK) ta_[e] = (TA); }                                                \
+            lr_seq2<false>(n, ra, rb_, ta_, tb_, L.XB, xpar);                                                               \
+        } else { LR_FOR(e) if (MASK) ra += (TA); ra = lr_reduce1<false>(ra, R, par); }                                       \
     } while (0)
 
     {                                                                        /* plis.c:463-469, 232-241 */
@@ -345,7 +445,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     __syncthreads();
     PROF(0);
     {
-        const double f = lr_objgrad<OBJ>(n, sx, sg, R, par, P.sign);
+        const double f = lr_objgrad<OBJ, EXACT>(n, sx, sg, R, par, P.sign, L.XB, xpar);
         if (tid == 0) {
             C.fval = f;
             if (P.ftrace && C.nevals < P.ftrace_cap) P.ftrace[(size_t) inst * P.ftrace_cap + C.nevals] = f;
@@ -412,8 +512,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 const lr_buf px = COLX(head, 1), pg = COLG(head, 1);
                 LR_FOR(e) { cx[e] = LR_LD(px, e); cg[e] = LR_LD(pg, e); }
             }
-            LR_FOR(e) if (six[LR_I(e)] >= 0) { const double gv = sg[LR_I(e)]; gg += gv * gv; bb += cx[e] * cg[e]; }
-            lr_reduce2<false>(gg, bb, R, par);
+            LR_SUM2(gg, bb, six[LR_I(e)] >= 0, sg[LR_I(e)] * sg[LR_I(e)], cx[e] * cg[e]);
             if (tid == 0) {
                 int g_ = LR_STEEPEST;
                 C.gnorm = sqrt(gg);
@@ -445,7 +544,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 const int head = LR_UNIFORM(C.head), k = LR_UNIFORM(C.k);
                 const bool all_free = LR_WAVE_ALL(live == nvalid);          /* wave-uniform: no coordinate of this wavefront sits on a bound */
 #define LR_LOAD(arr, buf_) do { const lr_buf q_ = buf_; LR_FOR(e) arr[e] = LR_LD(q_, e); } while (0)
-                if (all_free) {
+                if (!EXACT && all_free) {
                 /* The usual case, without masks: a coordinate that does not exist (>= n) has sr = 0 and its column entries load as
                  * 0.0 (bounds-checked buffer), so it adds +0.0 and stays 0 — the sums are the masked ones bit for bit.
                  * Software pipeline, two columns deep.  A column's x-part is dead once its dot product has been formed, its g-part
@@ -519,12 +618,14 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 LR_LOAD(cb, COLG(head, 1));
                 u1 = COLU(head, 1);
                 for (int j = 1; j <= k; ++j) {                       /* mxdrcb */
-                    double t = 0;
-                    LR_FOR(e) if (live & (1u << e)) t += sr[e] * ca[e];
+                    double t;
                     const int jn = j < k ? j + 1 : j;
+                    if constexpr (EXACT) LR_SUM1(t, live & (1u << e), sr[e] * ca[e]);
+                    else { t = 0; LR_FOR(e) if (live & (1u << e)) t += sr[e] * ca[e]; }
                     LR_SCHED_FENCE();
                     LR_LOAD(ca, COLX(head, jn)); un = COLU(head, jn);
-                    const double v = u1 * lr_reduce1<false>(t, R, par);
+                    if constexpr (!EXACT) t = lr_reduce1<false>(t, R, par);
+                    const double v = u1 * t;
                     if (tid == 0) vcol[j - 1] = v;
                     LR_FOR(e) if (live & (1u << e)) sr[e] = sr[e] + (-v) * cb[e];
                     LR_SCHED_FENCE();
@@ -534,22 +635,26 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 LR_LOAD(cb, COLG(head, 1));
                 LR_LOAD(ca, COLG(head, k));
                 {
-                    double t = 0;
-                    LR_FOR(e) if (live & (1u << e)) t += cb[e] * cb[e];
+                    double t;
+                    if constexpr (EXACT) LR_SUM1(t, live & (1u << e), cb[e] * cb[e]);
+                    else { t = 0; LR_FOR(e) if (live & (1u << e)) t += cb[e] * cb[e]; }
                     LR_SCHED_FENCE();
                     LR_LOAD(cb, COLX(head, k));
-                    const double a = lr_reduce1<false>(t, R, par);
+                    if constexpr (!EXACT) t = lr_reduce1<false>(t, R, par);
+                    const double a = t;
                     if (a > 0.) { const double sc = C.b / a; LR_FOR(e) sr[e] = sr[e] * sc; }
                 }
                 u1 = COLU(head, k);
                 double v1 = vcol[k - 1], vn;
                 for (int j = k; j >= 1; --j) {                       /* mxdrcf */
-                    double t = 0;
-                    LR_FOR(e) if (live & (1u << e)) t += sr[e] * ca[e];
+                    double t;
                     const int jp = j > 1 ? j - 1 : j;
+                    if constexpr (EXACT) LR_SUM1(t, live & (1u << e), sr[e] * ca[e]);
+                    else { t = 0; LR_FOR(e) if (live & (1u << e)) t += sr[e] * ca[e]; }
                     LR_SCHED_FENCE();
                     LR_LOAD(ca, COLG(head, jp)); un = COLU(head, jp); vn = vcol[jp - 1];
-                    const double tt = u1 * lr_reduce1<false>(t, R, par);
+                    if constexpr (!EXACT) t = lr_reduce1<false>(t, R, par);
+                    const double tt = u1 * t;
                     const double w = v1 - tt;
                     LR_FOR(e) if (live & (1u << e)) sr[e] = sr[e] + w * cb[e];
                     LR_SCHED_FENCE();
@@ -557,11 +662,9 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                     u1 = un; v1 = vn;
                 }
                 }
-                LR_FOR(e) if (live & (1u << e)) ssq += sr[e] * sr[e];
             }
             PROF(3);
-            LR_FOR(e) if (live & (1u << e)) pp += sg[LR_I(e)] * sr[e];
-            lr_reduce2<false>(ssq, pp, R, par);
+            LR_SUM2(ssq, pp, live & (1u << e), sr[e] * sr[e], sg[LR_I(e)] * sr[e]);      /* (|s|^2 is only looked at after the recurrences) */
             if (tid == 0) {
                 int g_ = LR_CONTINUE;
                 if (go == LR_STRANG) { C.snorm = sqrt(ssq); C.head = C.head > 0 ? C.head - 1 : mf - 1; }    /* mxdrsu: every column one older */
@@ -633,11 +736,10 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             LR_PROJECT_AND_ACTIVATE(2);
             __syncthreads();
             PROF(5);
-            const double f = lr_objgrad<OBJ>(n, sx, sg, R, par, P.sign);
+            const double f = lr_objgrad<OBJ, EXACT>(n, sx, sg, R, par, P.sign, L.XB, xpar);
             PROF(6);
-            double pp = 0;
-            LR_FOR(e) if (six[LR_I(e)] >= 0) pp += sg[LR_I(e)] * sr[e];
-            pp = lr_reduce1<false>(pp, R, par);
+            double pp;
+            LR_SUM1(pp, six[LR_I(e)] >= 0, sg[LR_I(e)] * sr[e]);
             if (tid == 0) {
                 int g_ = LR_LS_EVAL;
                 C.q.f = f;
@@ -676,9 +778,10 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             }
             if (P.x_weights) {                                                /* nlopt_stop_dx's weighted norms (stop.c:37-57) */
                 const lr_buf bw = lr_make_buf(P.x_weights, nbytes);
-                LR_FOR(e) { const double w = LR_LD(bw, e); nx += w * fabs(sx[LR_I(e)]); ndx += w * fabs(a_[e]); }
-            } else LR_FOR(e) { nx += fabs(sx[LR_I(e)]); ndx += fabs(a_[e]); }
-            lr_reduce2<false>(nx, ndx, R, par);
+                double w_[LR_E];
+                LR_FOR(e) w_[e] = LR_LD(bw, e);
+                LR_SUM2(nx, ndx, true, w_[e] * fabs(sx[LR_I(e)]), w_[e] * fabs(a_[e]));
+            } else LR_SUM2(nx, ndx, true, fabs(sx[LR_I(e)]), fabs(a_[e]));
             if (tid == 0) {
                 C.po = C.q.r * C.po; C.p = C.q.r * C.p;
                 C.xstop = ndx < C.xtol_rel * nx;                              /* nlopt_stop_dx, stop.c:110-120 */
@@ -714,7 +817,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 
 extern "C" int nla_lbfgs_resident_supported(int obj, int n, const nla_lbfgs_params *params)
 {
-    return obj >= 0 && n <= LR_NMAX && params->exact == 0;
+    return obj >= 0 && n <= LR_NMAX && (params->exact == 0 || params->exact == 1);       /* exact 2 / 3: the streaming kernel asked for by name */
 }
 
 extern "C" int nla_k_lbfgs_batch_resident(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
@@ -725,7 +828,8 @@ extern "C" int nla_k_lbfgs_batch_resident(int obj, int n, int ld, int mf, int co
     nla_lbfgs_params P = *params;
     if (P.sign == 0.) P.sign = 1.;
     if (!nla_lbfgs_resident_supported(obj, n, &P)) return (int) hipErrorInvalidValue;
-#define CALL(O) hipLaunchKernelGGL((lbfgs_resident_kernel<O>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out)
+#define CALL(O) do { if (P.exact) hipLaunchKernelGGL((lbfgs_resident_kernel<O, true>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out); \
+                     else hipLaunchKernelGGL((lbfgs_resident_kernel<O, false>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out); } while (0)
     NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     NLA_LAUNCH_CHECK();

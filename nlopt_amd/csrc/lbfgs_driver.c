@@ -168,7 +168,7 @@ static int launch(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, cons
     if (c->alg == 1) {
         nla_mma_params P = c->mma;
         P.minf_max = prm->minf_max; P.ftol_rel = prm->ftol_rel; P.ftol_abs = prm->ftol_abs; P.xtol_rel = prm->xtol_rel; P.maxeval = prm->maxeval;
-        P.exact = c->exact == 1; P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.x_weights = c->d_x_weights; P.abort = c->h_abort;
+        P.exact = (c->exact & 1); P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.x_weights = c->d_x_weights; P.abort = c->h_abort;
         P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap;
         return nla_k_mma_batch(obj, c->n, c->ld, count, c->d_lb, c->d_ub, c->d_sigma_init, c->d_X, c->d_work, &P, c->d_res, ext, c->st);
     } else {

@@ -164,6 +164,6 @@ int nla_exact_mode_for(nlopt_opt opt, nlopt_opt also, const nla_evaluator *ev)
     int exact = (set_a || set_b) ? ((set_a && nla_exact_mode(opt)) || (set_b && nla_exact_mode(also))) : (ev && ev->kind == NLA_EVAL_HOST);
     /* "amd_lbfgs_streaming" != 0: LD_LBFGS with tree sums on the streaming kernel (hip/lbfgs_kernels.hip) instead of the resident one
      * (hip/lbfgs_resident.hip) — the two are bit-identical, which is what the switch exists to show (tests/test_gpu_lbfgs.py) */
-    if (!exact && ((opt && nlopt_get_param(opt, "amd_lbfgs_streaming", 0) != 0) || (also && nlopt_get_param(also, "amd_lbfgs_streaming", 0) != 0))) return 2;
+    if ((opt && nlopt_get_param(opt, "amd_lbfgs_streaming", 0) != 0) || (also && nlopt_get_param(also, "amd_lbfgs_streaming", 0) != 0)) return exact ? 3 : 2;
     return exact;
 }

@@ -108,9 +108,9 @@ class _Result(C.Structure):
     _fields_ = [("f", C.c_double), ("ret", C.c_int32), ("nevals", C.c_int32), ("iterm", C.c_int32), ("cols", C.c_int32)]
 
 
-def _batch(streaming, obj, n, starts, lov, hiv, mf, ftol_rel=1e-8, maxeval=0, sign=1.0, xtol_abs=None, weights=None, cap=1500):
-    """nla_k_lbfgs_batch on `starts` (count x n): exact = 2 keeps the tree sums on the streaming kernel (lbfgs_kernels.hip), exact = 0
-    takes the resident kernel (lbfgs_resident.hip) where it applies"""
+def _batch(streaming, obj, n, starts, lov, hiv, mf, ftol_rel=1e-8, maxeval=0, sign=1.0, xtol_abs=None, weights=None, cap=1500, exact=False):
+    """nla_k_lbfgs_batch on `starts` (count x n): params.exact = 2 / 3 keeps the tree sums / the reference-order sums on the streaming
+    kernel (lbfgs_kernels.hip), 0 / 1 takes the resident kernel (lbfgs_resident.hip) where it applies"""
     L = nlopt_amd.lib()
     D = nlopt_amd.DevBuf
     count, ld = starts.shape[0], (n + 1) & ~1
@@ -121,7 +121,8 @@ def _batch(streaming, obj, n, starts, lov, hiv, mf, ftol_rel=1e-8, maxeval=0, si
     dft, dres = D.from_array(np.full(count * cap, np.nan)), D(C.sizeof(_Result) * count)
     dta = D.from_array(xtol_abs) if xtol_abs is not None else None
     dw = D.from_array(weights) if weights is not None else None
-    P = _Params(-np.inf, ftol_rel, 0.0, 0.0, 0.0, maxeval, 2 if streaming else 0, sign, dta.ptr if dta else None, dw.ptr if dw else None, None, dft.ptr, cap)
+    P = _Params(-np.inf, ftol_rel, 0.0, 0.0, 0.0, maxeval, (3 if streaming else 1) if exact else (2 if streaming else 0), sign,
+                dta.ptr if dta else None, dw.ptr if dw else None, None, dft.ptr, cap)
     vp = C.c_void_p
     L.nla_k_lbfgs_batch.argtypes = [C.c_int] * 5 + [vp] * 6 + [C.POINTER(_Params), vp, vp, vp]
     assert L.nla_k_lbfgs_batch(nlopt_amd.OBJECTIVES[obj], n, ld, mf, count, dlb.ptr, dub.ptr, dX.ptr, dwork.ptr, diw.ptr, dhist.ptr, C.byref(P),
@@ -134,6 +135,7 @@ def _batch(streaming, obj, n, starts, lov, hiv, mf, ftol_rel=1e-8, maxeval=0, si
     return out
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["tree_sums", "reference_order"])
 @pytest.mark.parametrize("obj,n,count,mf,kw", [
     ("ackley", 4096, 6, 320, {}),                            # the config-4 shape
     ("ackley", 300, 3, 400, {}), ("rastrigin", 40, 2, 5, {}), ("rosenbrock", 10, 2, 400, {}), ("griewank", 257, 2, 3, {}),
@@ -141,9 +143,9 @@ def _batch(streaming, obj, n, starts, lov, hiv, mf, ftol_rel=1e-8, maxeval=0, si
     ("ackley", 600, 2, 400, dict(maxeval=9)), ("griewank", 64, 3, 50, dict(sign=-1.0, maxeval=40)),
     ("rastrigin", 100, 2, 30, dict(weights=True)), ("ackley", 77, 2, 30, dict(xtol_abs=True)),
 ])
-def test_resident_kernel_is_the_streaming_kernel(obj, n, count, mf, kw):
+def test_resident_kernel_is_the_streaming_kernel(obj, n, count, mf, kw, exact):
     """lbfgs_resident_kernel (x / g in LDS, direction in registers, the scalar state advanced by thread 0) must be
-    lbfgs_batch_kernel's tree-sum search BIT FOR BIT: f of every evaluation, minimiser, result code, evaluation and column counts —
+    lbfgs_batch_kernel's search BIT FOR BIT, in both summation modes (workgroup tree; the reference's sequential order): f of every evaluation, minimiser, result code, evaluation and column counts —
     with coordinates on their bounds from the start, a fixed coordinate, short histories that wrap, maximisation, weights,
     xtol_abs.  (The same comparison runs on the CPU in tools/lbfgs_emu_check.py; the streaming kernel's own parity tests are above.)"""
     rng = np.random.default_rng(n * 7 + count)
@@ -159,8 +161,8 @@ def test_resident_kernel_is_the_streaming_kernel(obj, n, count, mf, kw):
         kw["weights"] = rng.uniform(0.5, 2.0, n)
     if kw.pop("xtol_abs", False):
         kw["xtol_abs"] = np.full(n, 1e-3)
-    a = _batch(True, obj, n, starts, lov, hiv, mf, **kw)
-    b = _batch(False, obj, n, starts, lov, hiv, mf, **kw)
+    a = _batch(True, obj, n, starts, lov, hiv, mf, exact=exact, **kw)
+    b = _batch(False, obj, n, starts, lov, hiv, mf, exact=exact, **kw)
     assert np.array_equal(a["res"], b["res"]), (a["res"], b["res"])
     assert np.array_equal(a["ftrace"], b["ftrace"], equal_nan=True)
     assert np.array_equal(a["x"], b["x"])

@@ -38,14 +38,14 @@ def build():
                     "-o", OUT] + srcs + ["-lpthread"], check=True)
 
 
-def run(L, streaming, obj, n, starts, lo, hi, mf, ftol_rel=1e-8, maxeval=0, sign=1.0, xtol_abs=None, weights=None, trace_cap=600):
+def run(L, streaming, obj, n, starts, lo, hi, mf, ftol_rel=1e-8, maxeval=0, sign=1.0, xtol_abs=None, weights=None, trace_cap=1400, exact=False):
     count, ld = starts.shape[0], (n + 1) & ~1
     X = np.zeros((count, ld)); X[:, :n] = starts
     lb = np.ascontiguousarray(lo, dtype=np.float64); ub = np.ascontiguousarray(hi, dtype=np.float64)
     work = np.zeros(count * (4 * ld + 2 * mf)); iwork = np.zeros(count * ld, dtype=np.int32); hist = np.full(count * 2 * mf * ld, np.nan)
     ft = np.full((count, trace_cap), np.nan)
     res = (Result * count)()
-    P = Params(-np.inf, ftol_rel, 0.0, 0.0, 0.0, maxeval, 2 if streaming else 0, sign,
+    P = Params(-np.inf, ftol_rel, 0.0, 0.0, 0.0, maxeval, (3 if streaming else 1) if exact else (2 if streaming else 0), sign,
                xtol_abs.ctypes.data if xtol_abs is not None else None, weights.ctypes.data if weights is not None else None, None,
                ft.ctypes.data, trace_cap)
     vp = C.c_void_p
@@ -78,16 +78,30 @@ def main():
         m = mf or min(max(1310720 // n, 10), 400)
         a = run(L, True, obj, n, starts, lov, hiv, m, maxeval=maxeval)
         b = run(L, False, obj, n, starts, lov, hiv, m, maxeval=maxeval)
-        same = (np.array_equal(a["x"], b["x"]) and np.array_equal(a["f"], b["f"]) and a["ret"] == b["ret"] and a["nevals"] == b["nevals"] and
-                a["iterm"] == b["iterm"] and a["cols"] == b["cols"] and np.array_equal(a["ftrace"], b["ftrace"], equal_nan=True))
+
+        def identical(a, b):
+            return (np.array_equal(a["x"], b["x"]) and np.array_equal(a["f"], b["f"]) and a["ret"] == b["ret"] and a["nevals"] == b["nevals"] and
+                    a["iterm"] == b["iterm"] and a["cols"] == b["cols"] and np.array_equal(a["ftrace"], b["ftrace"], equal_nan=True))
+        same = identical(a, b)
+        # the reference's summation order: streaming kernel (exact = 3) against the resident kernel (exact = 1), and — the emulated device's
+        # libm being the host's — against the oracle's search evaluation by evaluation, bit for bit
+        xa = run(L, True, obj, n, starts, lov, hiv, m, maxeval=maxeval, exact=True)
+        xb = run(L, False, obj, n, starts, lov, hiv, m, maxeval=maxeval, exact=True)
+        xsame = identical(xa, xb)
+        oracle_same = True
         # the oracle's sequential-order search from the same starts (tolerance: the summation order differs)
         orc = []
         for s in range(count):
             p = O.run_port_lbfgs(obj, n, x0=starts[s], ftol_rel=1e-8, maxeval=maxeval, mf=mf or 0, lb=lov, ub=hiv)
             orc.append((p["minf"], p["nevals"], p["ret"]))
+            ft = xb["ftrace"][s][: p["nevals"]]
+            if not (xb["nevals"][s] == p["nevals"] and np.array_equal(ft, p["fseq"][: len(ft)]) and np.array_equal(xb["x"][s], p["x"])):
+                oracle_same = False          # (Levy: the device's gradient expression groups its four terms differently from the host loop's accumulation)
         near = all(abs(orc[s][0] - b["f"][s]) <= 1e-7 * max(1.0, abs(orc[s][0])) or abs(orc[s][1] - b["nevals"][s]) > 4 for s in range(count))
-        print("%-10s n=%-4d mf=%-4d: streaming f=%s evals=%s ret=%s | resident identical: %s | oracle (minf, evals, ret) %s %s" %
-              (obj, n, m, np.array2string(a["f"], precision=12), a["nevals"], a["ret"], same, orc, "" if near else "  <-- differs from the oracle"))
+        print("%-10s n=%-4d mf=%-4d: streaming f=%s evals=%s ret=%s | resident identical: %s | exact order: resident == streaming: %s, == the oracle bit for bit: %s | oracle (minf, evals, ret) %s %s" %
+              (obj, n, m, np.array2string(a["f"], precision=12), a["nevals"], a["ret"], same, xsame, oracle_same, orc, "" if near else "  <-- differs from the oracle"))
+        if not xsame:
+            bad += 1
         if not same:
             bad += 1
             for s in range(count):
