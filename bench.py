@@ -679,7 +679,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
     else:
         t_dom = d["t_lbfgs_ms"] / 1e3
         bytes_dom = float(d["lbfgs_bytes"])
-        kern, launches = ("mma_batch_kernel" if a.local == "mma" else "lbfgs_batch_kernel"), int(d["lbfgs_launches"])
+        # the kernel the searches run on: the resident one up to n = 4096 with a device objective (hip/lbfgs_resident.hip), else the streaming one
+        kern, launches = ("mma_batch_kernel" if a.local == "mma" else ("lbfgs_resident_kernel" if n <= 4096 else "lbfgs_batch_kernel")), int(d["lbfgs_launches"])
         name = "GD_MLSL_LDS + default LD_MMA" if a.local == "mma" else "G_MLSL_LDS + LD_LBFGS"
         metric = "candidate-evals/sec, %s n=%d, %d samples per iteration" % (name, n, pop)
         mode = ("amd_exact_dot=1: every sum of the local search in the reference's sequential order, iterates bit-identical to the reference's"
@@ -690,7 +691,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
     achieved = (bytes_dom / 1e9) / t_dom if t_dom > 0 else None
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of the same command (BASELINE's shapes only)
     std = (a.workload == "isres" and (n, pop, a.obj) == (256, 50000, "rastrigin")) or (a.workload == "mlsl" and (n, pop, a.obj) == (4096, 1000, "ackley"))
-    traffic_dom, traffic_src = pmc_traffic(kern.split(" ")[0].split("<")[0]) if (std and a.workload == "mlsl") else (None, None)
+    # (the PMC passes on record are of the default summation mode)
+    traffic_dom, traffic_src = pmc_traffic(kern.split(" ")[0].split("<")[0]) if (std and a.workload == "mlsl" and not getattr(a, "exact", False)) else (None, None)
     out = {
         "metric": metric, "value": evals_all / dt_max, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * dt_max / K, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,

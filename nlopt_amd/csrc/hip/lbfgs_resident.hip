@@ -158,6 +158,35 @@ __device__ __forceinline__ void lr_seq2(int nterms, double &ra, double &rb, cons
     ra = a; rb = b;
 }
 template <bool PROD> __device__ __forceinline__ void lr_seq2(int, double &, double &, const double (&)[LR_E], const double (&)[LR_E], lr_nobuf &, int &) { }
+/* one sum (the recurrences' dot products: the chain's three instructions per term are what a column costs in this mode) */
+__device__ __forceinline__ double lr_seq1(int nterms, const double (&ta)[LR_E], lr_xbuf &XB, int &xpar)
+{
+    const unsigned tid = threadIdx.x;
+    double a = 0.;
+#pragma unroll
+    for (int e = 0; e < LR_E; ++e) {
+        const int m = nterms - e * LB_T;
+        if (m > 0) {
+            const int mm = m < LB_T ? m : LB_T;
+            XB.a[xpar][tid] = ta[e];
+            __syncthreads();
+#ifdef NLA_SIMT_EMU
+            for (int i = 0; i < mm; ++i) a += XB.a[xpar][i];
+#else
+            for (int c = 0; c < mm; c += 64) {
+                const double va = XB.a[xpar][c + (tid & 63)];
+                if (mm - c >= 64) {
+#pragma unroll
+                    for (int l = 0; l < 64; ++l) a += lr_lane(va, l);
+                } else for (int l = 0; l < mm - c; ++l) a += lr_lane(va, l);
+            }
+#endif
+            xpar ^= 1;
+        }
+    }
+    return a;
+}
+__device__ __forceinline__ double lr_seq1(int, const double (&)[LR_E], lr_nobuf &, int &) { return 0.; }
 
 /* sin and cos of one argument at once: Ackley and Rastrigin need cos(2 pi x) for f and sin(2 pi x) for the gradient of the SAME
  * coordinates — one argument reduction and one pair of polynomials instead of two (the device library's sincos returns exactly
@@ -410,9 +439,9 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #define LR_SUM1(ra, MASK, TA) do {                                                                                          \
         ra = 0.;                                                                                                            \
         if constexpr (EXACT) {                                                                                              \
-            double ta_[LR_E], tb_[LR_E], rb_ = 0.;                                                                          \
-            LR_FOR(e) { ta_[e] = 0.; tb_[e] = 0.; if (MASK) ta_[e] = (TA); }                                                \
-            lr_seq2<false>(n, ra, rb_, ta_, tb_, L.XB, xpar);                                                               \
+            double ta_[LR_E];                                                                                               \
+            LR_FOR(e) { ta_[e] = 0.; if (MASK) ta_[e] = (TA); }                                                             \
+            ra = lr_seq1(n, ta_, L.XB, xpar);                                                                               \
         } else { LR_FOR(e) if (MASK) ra += (TA); ra = lr_reduce1<false>(ra, R, par); }                                       \
     } while (0)
 

@@ -137,6 +137,22 @@ extern "C" int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const
     return 0;
 }
 
+/* out[a * nc + b] = D[rows[a] * ldd + cols[b]]: the distances between the minimisers of a batch's searches (rows of the batch's distance
+ * matrix) and the batch's own start points (columns) — all the commit walk on the host needs of that matrix (mlsl_driver.c) */
+__global__ __launch_bounds__(256) void mlsl_gather_pairs_kernel(const double *__restrict__ D, int ldd, const int64_t *__restrict__ rows, int nr,
+                                                                 const int64_t *__restrict__ cols, int nc, double *__restrict__ out)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
+    if (b < nc && a < nr) out[(size_t) a * nc + b] = D[(size_t) rows[a] * (size_t) ldd + (size_t) cols[b]];
+}
+extern "C" int nla_k_mlsl_gather_pairs(const double *D, int ldd, const int64_t *rows, int nr, const int64_t *cols, int nc, double *out, void *stream)
+{
+    if (nr <= 0 || nc <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_gather_pairs_kernel, dim3((unsigned) ((nc + 255) / 256), (unsigned) nr), dim3(256), 0, (hipStream_t) stream, D, ldd, rows, nr, cols, nc, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
 /* rows by index: dst row c := src row idx[c] (the start points of a batch of local searches, mlsl.c:399-404; the accepted minima
  * joining the set of local minima, mlsl.c:410-414) — one launch instead of one copy operation per row */
 __global__ __launch_bounds__(256) void mlsl_gather_rows_kernel(int n, int ld, const double *__restrict__ src, const int64_t *__restrict__ idx,

@@ -70,8 +70,11 @@ typedef struct {
     uint32_t *d_V; uint32_t sobol_next;   /* LDS mode: direction table on the device, index of the next point (1-based) */
     size_t dcap;                    /* doubles in d_D */
     nla_local_ctx *lb;
-    double *h_D;                    /* pinned: batch x npts distances */
+    double *h_D;                    /* pinned: one row of npts distances (the rerun of a single search) */
     size_t hcap;
+    double *h_S, *d_S;              /* bmax x bmax: distance between minimiser c' and start point c of a batch — all the commit walk reads of the batch's matrix */
+    double *h_lfall, *d_lfall;      /* bmax: f of the accepted minima by gathered row, +inf for the others (the device-side pts_update_newlm) */
+    int64_t *h_gi, *d_gi;           /* bmax: gathered row of candidate c */
     double *h_gather; size_t gcap;  /* several ranks: world x count doubles for the element-wise min of the distance minima */
     /* per-batch lists, pinned host side + device side: [idx of all candidates: bmax][idx of this rank's: BATCH_MAX]
      * [gathered-row index of the accepted minima: bmax] as int64, then the accepted minima's f (bmax doubles); flags: bmax int32 */
@@ -97,7 +100,8 @@ static void mfree(mlsl_dev *d)
     nla_host_free(d->h_rows);
     free(d->h_gather);
     nla_host_free(d->h_D); nla_host_free(d->h_idx); nla_host_free(d->h_lf); nla_host_free(d->h_flags);
-    nla_dev_free(d->d_idx); nla_dev_free(d->d_flags);
+    nla_host_free(d->h_S); nla_host_free(d->h_lfall); nla_host_free(d->h_gi);
+    nla_dev_free(d->d_idx); nla_dev_free(d->d_flags); nla_dev_free(d->d_S); nla_dev_free(d->d_lfall); nla_dev_free(d->d_gi);
     if (d->rs && d->rs != d->st) nla_stream_destroy(d->rs);
     if (d->st) nla_stream_destroy(d->st);
 }
@@ -301,6 +305,12 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.h_idx = (int64_t *) nla_host_malloc(sizeof(int64_t) * (size_t) (2 * bmax + BATCH_MAX));
     D.d_idx = (int64_t *) nla_dev_malloc(sizeof(int64_t) * (size_t) (2 * bmax + BATCH_MAX));
     D.h_lf = (double *) nla_host_malloc(sizeof(double) * (size_t) bmax);
+    D.h_S = (double *) nla_host_malloc(sizeof(double) * (size_t) bmax * (size_t) bmax);
+    D.d_S = (double *) nla_dev_malloc(sizeof(double) * (size_t) bmax * (size_t) bmax);
+    D.h_lfall = (double *) nla_host_malloc(sizeof(double) * (size_t) bmax);
+    D.d_lfall = (double *) nla_dev_malloc(sizeof(double) * (size_t) bmax);
+    D.h_gi = (int64_t *) nla_host_malloc(sizeof(int64_t) * (size_t) bmax);
+    D.d_gi = (int64_t *) nla_dev_malloc(sizeof(int64_t) * (size_t) bmax);
     D.h_flags = (int32_t *) nla_host_malloc(sizeof(int32_t) * (size_t) bmax);
     D.d_flags = (int32_t *) nla_dev_malloc(sizeof(int32_t) * (size_t) bmax);
     Fnew = (double *) malloc(sizeof(double) * (size_t) D.N);
@@ -308,7 +318,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
     cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
-    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         nla_comm_agree_ready(D.comm, 0);
@@ -532,27 +542,38 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             }
             }
             {
+                /* the distances of the batch's minimisers to every point stay on the device (na x npts: 12 MB at config 4); the commit walk
+                 * below only needs those to the batch's OWN start points (whether an earlier commit of the batch disqualified a later
+                 * candidate, mlsl.c:180-194 seen from :196-221) — nb x nb values — and pts_update_newlm for all the other points is an
+                 * order-independent min that one launch computes once the accepted set is known */
                 const size_t na = (size_t) per * (size_t) D.world;
                 if (need_D(&D, na * D.npts)) DEVFAIL();
-                if (na * D.npts > D.hcap) {
+                if (D.npts > D.hcap) {
                     nla_host_free(D.h_D);
-                    D.hcap = 2 * (size_t) bmax * D.npts;
+                    D.hcap = 2 * D.npts;
                     D.h_D = (double *) nla_host_malloc(sizeof(double) * D.hcap);
                     if (!D.h_D) { D.hcap = 0; snprintf(D.err, sizeof D.err, "out of pinned memory"); DEVFAIL(); }
                 }
-                if (nla_k_mlsl_dist2(n, D.ld, D.d_LX, (int) na, D.d_P, (int) D.npts, D.d_D, D.st) ||
-                    nla_memcpy_d2h(D.h_D, D.d_D, sizeof(double) * na * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+                for (c = 0; c < nb; ++c) D.h_gi[c] = (int64_t) GI(c);
+                if (nla_memcpy_h2d(D.d_gi, D.h_gi, sizeof(int64_t) * (size_t) nb, D.st) ||
+                    nla_k_mlsl_dist2(n, D.ld, D.d_LX, (int) na, D.d_P, (int) D.npts, D.d_D, D.st) ||
+                    nla_k_mlsl_gather_pairs(D.d_D, (int) D.npts, D.d_gi, nb, D.d_idx, nb, D.d_S, D.st) ||
+                    nla_memcpy_d2h(D.h_S, D.d_S, sizeof(double) * (size_t) nb * (size_t) nb, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+                for (c = 0; c < (int) na; ++c) D.h_lfall[c] = HUGE_VAL;
             }
             if (grow_lms(&D, D.nlms + (size_t) nb)) DEVFAIL();
             nacc = 0; nlms0 = D.nlms;
             /* commit in walk order */
             for (c = 0; c < nb && ret == NLOPT_SUCCESS; ++c) {
                 const size_t r = D.ord[cand[c]];
-                int pot = !(D.cld[r] <= (dlm * R) * (dlm * R));               /* may have changed since the batch was formed */
-                double lf;
-                int calls;
+                double lf, cl = D.cld[r];
+                int calls, pot, cp;
                 const size_t g = GI(c);
-                size_t k;
+                /* closest_lm_d of this start as the serial order would see it now: the minima committed earlier in this batch count
+                 * (pts_update_newlm, mlsl.c:180-194: those with smaller f than the point's, if closer) */
+                for (cp = 0; cp < c; ++cp)
+                    if (D.h_lfall[GI(cp)] < D.F[r] && D.h_S[(size_t) cp * (size_t) nb + (size_t) c] < cl) cl = D.h_S[(size_t) cp * (size_t) nb + (size_t) c];
+                pot = !(cl <= (dlm * R) * (dlm * R));
                 /* nodes between the previous candidate and this one were visited and skipped */
                 remaining -= (int) (cand[c] + 1 - idx);
                 idx = cand[c] + 1;
@@ -576,8 +597,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                     if (nla_memcpy_d2d(nla_local_ctx_X(D.lb), D.d_P + r * (size_t) D.ld, sizeof(double) * (size_t) n, D.st) ||
                         nla_local_ctx_run(D.lb, 1, &p1, &r1, &lstop, NULL) ||
                         nla_memcpy_d2d(D.d_LX + g * (size_t) D.ld, nla_local_ctx_X(D.lb), sizeof(double) * (size_t) n, D.st) ||
-                        nla_k_mlsl_dist2(n, D.ld, D.d_LX + g * (size_t) D.ld, 1, D.d_P, (int) D.npts, D.d_D, D.st) ||
-                        nla_memcpy_d2h(D.h_D + g * D.npts, D.d_D, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "local-search rerun failed"); DEVFAIL(); }
+                        nla_k_mlsl_dist2(n, D.ld, D.d_LX + g * (size_t) D.ld, 1, D.d_P, (int) D.npts, D.d_D + g * D.npts, D.st) ||
+                        nla_memcpy_d2h(D.h_D, D.d_D + g * D.npts, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "local-search rerun failed"); DEVFAIL(); }
+                    for (cp = 0; cp < nb; ++cp) D.h_S[(size_t) c * (size_t) nb + (size_t) cp] = D.h_D[D.ord[cand[cp]]];     /* this minimiser moved: its row of the pairs */
                     res[g] = r1;
                 }
                 calls = use_mma ? res[g].iterm : res[g].nevals;                /* objective calls the search made (MMA: iterm) */
@@ -594,6 +616,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                  * batch was made before the walk; res[] stays valid until the batch's closing synchronisation) */
                 D.h_idx[bmax + BATCH_MAX + nacc] = (int64_t) g;
                 D.h_lf[nacc] = lf;
+                D.h_lfall[g] = lf;
                 ++nacc;
                 D.LF[D.nlms] = lf;
                 ord_insert(D.lord, D.nlms, D.LF, D.nlms);
@@ -602,12 +625,17 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 else if (lf < stop->minf_max) ret = NLOPT_MINF_MAX_REACHED;
                 else if (nla_stop_evals(stop)) ret = NLOPT_MAXEVAL_REACHED;
                 else if (nla_stop_time(sp)) ret = NLOPT_MAXTIME_REACHED;
-                else {
-                    const double *dr = D.h_D + g * D.npts;              /* pts_update_newlm, mlsl.c:180-194 */
-                    for (k = 0; k < D.npts; ++k)
-                        if (D.F[k] > lf && !D.minimized[k] && dr[k] < D.cld[k]) D.cld[k] = dr[k];
-                }
+                /* (pts_update_newlm for this minimum: with the batch's other accepted minima, in one launch below.  A minimum whose commit
+                 * ends the run updated nothing in the reference either — the stop tests come first, mlsl.c:417-425 — so it is left out.) */
+                if (ret != NLOPT_SUCCESS) D.h_lfall[g] = HUGE_VAL;
             }
+            /* pts_update_newlm (mlsl.c:180-194) for every accepted minimum of the batch at once: closest_lm_d[k] = min over the accepted
+             * minima with smaller f than point k of their distance to k — a min, so the order of the commits does not matter.  (The
+             * reference skips minimised points; their closest_lm_d is never read again, mlsl.c:200, so no flag is consulted here.) */
+            if (nacc > 0 && (nla_memcpy_h2d(D.d_lfall, D.h_lfall, sizeof(double) * (size_t) per * (size_t) D.world, D.st) ||
+                             nla_memcpy_h2d(D.d_cpd, D.cld, sizeof(double) * D.npts, D.st) ||
+                             nla_k_mlsl_colmin(D.d_D, (int) D.npts, per * D.world, (int) D.npts, D.d_lfall, D.d_F, NULL, D.d_cpd, D.st) ||
+                             nla_memcpy_d2h(D.cld, D.d_cpd, sizeof(double) * D.npts, D.st))) { snprintf(D.err, sizeof D.err, "closest-minimum update failed"); DEVFAIL(); }
             /* the batch's accepted minima join the device-side set in acceptance order: one gather launch */
             if (nacc > 0 && (nla_memcpy_h2d(D.d_idx + bmax + BATCH_MAX, D.h_idx + bmax + BATCH_MAX, sizeof(int64_t) * (size_t) nacc, D.st) ||
                              nla_k_mlsl_gather_rows(n, D.ld, D.d_LX, D.d_idx + bmax + BATCH_MAX, nacc, D.d_LM + nlms0 * (size_t) D.ld, D.st) ||
