@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("crs", "isres", "mlsl"), default="crs")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
+                    help="nlopt_set_param on the optimiser (and on MLSL's local optimiser): the library's A/B switches, e.g. amd_mlsl_prefetch=1, amd_isres_gated=0")
     ap.add_argument("--exact", action="store_true",
                     help="mlsl: the local optimiser sums in the reference's order (\"amd_exact_dot\" = 1: iterates bit-identical to the reference's); default: workgroup tree sums")
     ap.add_argument("--local", choices=("lbfgs", "mma"), default="lbfgs",
@@ -620,6 +622,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
     o.set_upper_bounds(hi)
     o.set_min_objective(nlopt_amd.objective(a.obj))
     o.set_population(pop)
+    for kv in getattr(a, "param", []) or []:
+        o.set_param(kv.split("=", 1)[0], float(kv.split("=", 1)[1]))
     if a.workload == "isres":
         o.add_blocksum_constraints(ncon, 1e-8)
     if world > 1:

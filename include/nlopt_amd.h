@@ -329,6 +329,12 @@ int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_
  * Out: swapped[i] = sweep i exchanged something; irank[pos] = individual. */
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                           int *ticket, uint8_t *swapped, int32_t *irank, void *stream);
+/* the same with the rows of `bits` still being produced by launches on another stream, in blocks of rows_per_gate sweeps: unit u (sweeps
+ * 64u .. 64u+63) waits until gate[block of its last sweep] == gate_value before it reads a row; nla_k_set_flag(gate + c, gate_value,
+ * that stream) behind block c's launches opens it.  gate == NULL: no waiting. */
+int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
+                                uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream);
+int nla_k_set_flag(int *d_flag, int value, void *stream);
 
 /* replaces: nlopt_nrand(0,1), mt19937ar.c:216-232, for a run of 4-word attempts: appends the
  * accepted deviates of attempts [attempt_base, attempt_base+nattempts) (words = their words) to

@@ -201,7 +201,8 @@ __device__ __forceinline__ void sr_st(uint64_t *p, uint64_t v) { __hip_atomic_st
 
 __global__ __launch_bounds__(64) void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__restrict__ streams,
                                                               int *__restrict__ progress, const uint64_t *__restrict__ bits,
-                                                              int64_t rowwords, int *__restrict__ ticket, uint8_t *__restrict__ swapped_out)
+                                                              int64_t rowwords, int *__restrict__ ticket, uint8_t *__restrict__ swapped_out,
+                                                              const int *__restrict__ gate, int rows_per_gate, int gate_value)
 {
     __shared__ int s_unit;
     const int lane = threadIdx.x;
@@ -222,6 +223,18 @@ __global__ __launch_bounds__(64) void isres_stochrank_kernel(int64_t pop, int64_
     uint32_t swv = 0;                                        /* bit 31: this stage swapped at least once */
     const uint32_t amask = active ? 0x80000000u : 0u;
     auto clampw = [&](int w) { return w < 0 ? 0 : (w > rw1 ? rw1 : w); };
+    if (gate) {
+        /* the rows of uniform bits are still being produced, in blocks of rows_per_gate sweeps, by launches on another stream
+         * (isres_driver.c, "amd_isres_gated"): gate[c] == gate_value once block c is complete.  This unit reads rows 64 unit ..
+         * 64 unit + 63: wait for the block of the last one BEFORE the first load of a row (a load ahead of the flag could leave a
+         * stale line in this CU's cache), then make the other stream's stores visible */
+        int64_t lastrow = unit * 64 + 63;
+        if (lastrow > nsweeps - 1) lastrow = nsweeps - 1;
+        if (lastrow < 0) lastrow = 0;
+        const int *g = gate + lastrow / rows_per_gate;
+        if (lane == 0) while (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_value) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     uint64_t wa = brow[clampw(-1 - half)], wb = brow[clampw(0 - half)], wp = brow[clampw(1 - half)];
     const int nblk = (ipop + 63) / 64 + 2;      /* the last output leaves lane 63 at tick pop + 126 */
     for (int b = 0; b < nblk; ++b) {
@@ -755,15 +768,32 @@ extern "C" int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nr
     return 0;
 }
 
+__global__ void isres_set_flag_kernel(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+/* *d_flag := value, in stream order (the gate of a block of ranking bits: everything enqueued before it on the stream is complete) */
+extern "C" int nla_k_set_flag(int *d_flag, int value, void *stream)
+{
+    hipLaunchKernelGGL(isres_set_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t) stream, d_flag, value);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
+                                           int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream);
 extern "C" int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                                      int *ticket, uint8_t *swapped, int32_t *irank, void *stream)
+{
+    return nla_k_isres_stochrank_gated(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, NULL, 1, 0, stream);
+}
+extern "C" int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
+                                           int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream)
 {
     hipStream_t st = (hipStream_t) stream;
     if (pop <= 0) return 0;
     const int64_t units = (nsweeps + 63) / 64;
     const int64_t rowwords = (pop - 1 + 63) / 64;
     if (units > 0 && pop > 1) {
-        hipLaunchKernelGGL(isres_stochrank_kernel, dim3((unsigned) units), dim3(64), 0, st, pop, nsweeps, streams, progress, bits, rowwords, ticket, swapped);
+        hipLaunchKernelGGL(isres_stochrank_kernel, dim3((unsigned) units), dim3(64), 0, st, pop, nsweeps, streams, progress, bits, rowwords, ticket, swapped,
+                           gate, rows_per_gate > 0 ? rows_per_gate : 1, gate_value);
         NLA_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(isres_unpack_kernel, dim3((unsigned) ((pop + 255) / 256)), dim3(256), 0, st, pop,

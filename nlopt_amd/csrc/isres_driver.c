@@ -46,6 +46,8 @@ typedef struct {
     int bits_two_pass;              /* A/B switch: ranking words through a buffer + isres_bits_kernel instead of the fused kernel */
     void *st, *ev0, *ev1;
     void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
+    int gated;                      /* "amd_isres_gated" (default 1; one rank, generator on its own stream): the ranking pipeline starts while its bits are still produced */
+    int *d_gate; int gate_value;    /* ISRES_GATES flags: block c of the ranking bits is complete when d_gate[c] == gate_value (a new value every generation) */
     int evolve_serial;              /* "amd_isres_evolve_serial" != 0: the one-workgroup evolve kernel (the parallel one's reference in the tests) */
     int overlap;                    /* default; "amd_isres_overlap" = 0 / NLA_ISRES_OVERLAP=0 turn it off: generator work beside the latency-bound kernels */
     int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
@@ -71,6 +73,7 @@ typedef struct {
     char err[200];
 } isres_dev;
 
+#define ISRES_GATES 16                   /* blocks of sweeps the ranking bits are produced in when the pipeline starts beside them */
 #define DFAIL(d, ...) do { snprintf((d)->err, sizeof (d)->err, __VA_ARGS__); return -1; } while (0)
 #define DCK(d, call) do { int rc_ = (call); if (rc_) DFAIL(d, "%.90s failed: %.60s", #call, nla_dev_error_string(rc_)); } while (0)
 
@@ -82,7 +85,7 @@ static void dev_free_all(isres_dev *d)
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_X); nla_dev_free(d->d_S); nla_dev_free(d->d_F);
     nla_dev_free(d->d_PEN); nla_dev_free(d->d_GPEN); nla_dev_free(d->d_scratch); nla_dev_free(d->d_z); nla_dev_free(d->d_FEAS);
     nla_dev_free(d->d_irank); nla_dev_free(d->d_counts); nla_dev_free(d->d_progress); nla_dev_free(d->d_ticket);
-    nla_dev_free(d->d_swapped); nla_dev_free(d->d_streams); nla_dev_free(d->d_bits); nla_dev_free(d->d_zatt);
+    nla_dev_free(d->d_swapped); nla_dev_free(d->d_streams); nla_dev_free(d->d_bits); nla_dev_free(d->d_zatt); nla_dev_free(d->d_gate);
     nla_dev_free(d->d_ztotal); nla_dev_free(d->d_state); nla_dev_free(d->d_words); nla_dev_free(d->d_con);
     nla_dev_free(d->d_inv); nla_dev_free(d->d_rho); nla_dev_free(d->d_ws);
     nla_host_free(d->h_F); nla_host_free(d->h_PEN); nla_host_free(d->h_GPEN); nla_host_free(d->h_X); nla_host_free(d->h_FEAS);
@@ -138,6 +141,8 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     A(d_words, uint32_t, d->wchunk); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
     A(d_counts, int32_t, d->wchunk / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
     A(d_con, nla_dev_constraint, d->m + d->p + 1);
+    A(d_gate, int, ISRES_GATES);
+    if (d->d_gate && nla_memset(d->d_gate, 0, sizeof(int) * ISRES_GATES, d->st)) ok = 0;
     d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !d->evolve_serial && !NLA_DBG_ENV("NLA_ISRES_EVOLVE_SERIAL");
     if (d->parallel_evolve) {
         A(d_inv, int32_t, pop); A(d_rho, double, 4);
@@ -185,6 +190,13 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
     const int64_t pop = d->pop, popm1 = pop - 1;
     int64_t nsweeps = pop, rows_per, r0, i;
     double t0;
+    /* GATED (round 4): the bits of the pop sweeps are produced in ISRES_GATES blocks of whole sweeps on the generator's stream, a flag
+     * behind each block; the ranking pipeline is launched at once on the main stream and each of its units waits for the block of its
+     * own rows (hip/isres_kernels.hip).  The pipeline's unit u starts ~190 ticks (14 us) after unit u - 1 and the generator makes 64 rows
+     * in ~12 us, so the bits stay just ahead of the units: the 9.6 ms of generation disappear behind the 15 ms of the pipeline
+     * (config 3).  One rank with the generator on its own stream only (several ranks all-gather the complete bits first). */
+    const int gated = d->gated && d->rs != d->st && nlopt_amd_comm_world(d->comm) == 1 && !d->bits_two_pass && d->d_gate != NULL;
+    const int64_t rows_per_gate = ((pop + ISRES_GATES - 1) / ISRES_GATES + 63) / 64 * 64;
     *sweeps_out = 0;
     DCK(d, nla_k_isres_rank_count(pop, d->d_F, d->d_PEN, d->d_streams, d->d_irank, d->st));
     if (all_feasible || popm1 <= 0) return 0;      /* irank = stable sort by f (or the single individual) */
@@ -200,7 +212,17 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         const int world = nlopt_amd_comm_world(d->comm), rank = nlopt_amd_comm_rank(d->comm);
         const int64_t first = world > 1 ? (d->per * rank < pop ? d->per * rank : pop) : 0;
         const int64_t last = world > 1 ? (first + d->per < pop ? first + d->per : pop) : pop;
-        if (!d->bits_two_pass) {
+        if (gated) {
+            ++d->gate_value;
+            DCK(d, nla_memset(d->d_bits, 0, sizeof(uint64_t) * (size_t) pop * (size_t) d->rowwords, d->rs));
+            for (r0 = 0; r0 < pop; r0 += rows_per_gate) {
+                const int64_t nr = pop - r0 < rows_per_gate ? pop - r0 : rows_per_gate;
+                if (nla_mtstream_rankbits(d->mts, d->words_used, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) r0,
+                                          2ULL * (uint64_t) popm1 * (uint64_t) nr, popm1, d->rowwords, d->d_bits))
+                    DFAIL(d, "MT stream ranking bits failed");
+                DCK(d, nla_k_set_flag(d->d_gate + r0 / rows_per_gate, d->gate_value, d->rs));
+            }
+        } else if (!d->bits_two_pass) {
             /* words -> bits in one kernel, all of this rank's sweeps in one launch (hip/mt_kernels.hip, mt_rankbits_kernel):
              * the words are never written to memory */
             if (last > first) {
@@ -220,15 +242,18 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
                                                 sizeof(uint64_t) * (size_t) d->per * (size_t) d->rowwords, d->rs))
             DFAIL(d, "all-gather of the ranking bits failed: %s", nlopt_amd_comm_error(d->comm));
     }
-    DCK(d, nla_stream_sync(d->rs));                /* the bits are there ... */
-    if (d->rs != d->st) DCK(d, nla_stream_sync(d->st));      /* ... and so are the packed elements (rank counting ran beside them) */
+    if (!gated) {
+        DCK(d, nla_stream_sync(d->rs));                /* the bits are there ... */
+        if (d->rs != d->st) DCK(d, nla_stream_sync(d->st));      /* ... and so are the packed elements (rank counting ran beside them) */
+    }
     *t_rng += nla_seconds() - t0;
     d->spec_valid = 0;
     for (;;) {
         DCK(d, nla_memcpy_h2d(d->d_progress, d->h_progress, sizeof(int) * (size_t) (d->units + 1), d->st));
         DCK(d, nla_memset(d->d_ticket, 0, sizeof(int), d->st));
         if (d->ev0) nla_event_record(d->ev0, d->st);
-        DCK(d, nla_k_isres_stochrank(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank, d->st));
+        DCK(d, nla_k_isres_stochrank_gated(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank,
+                                           gated ? d->d_gate : NULL, (int) rows_per_gate, d->gate_value, d->st));
         if (d->ev1) nla_event_record(d->ev1, d->st);
         DCK(d, nla_memcpy_d2h(d->h_swapped, d->d_swapped, (size_t) nsweeps, d->st));
         if (d->overlap && nsweeps == pop && !d->spec_valid) {
@@ -484,6 +509,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
     D.comm = opt ? opt->comm : NULL;
     D.evolve_serial = opt ? nlopt_get_param(opt, "amd_isres_evolve_serial", 0) != 0 : 0;
+    D.gated = opt ? nlopt_get_param(opt, "amd_isres_gated", 1) != 0 : 1;
     D.overlap = opt ? nlopt_get_param(opt, "amd_isres_overlap", 1) != 0 : 1;            /* 0: the one-stream generation */
     D.overlap = nla_dbg_int("NLA_ISRES_OVERLAP", D.overlap) > 0;     /* A/B switch for the bench */
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */

@@ -480,6 +480,16 @@ int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_
     }
     return 0;
 }
+int nla_k_set_flag(int *d_flag, int value, void *st) { EMU_LAUNCH(); (void) st; *d_flag = value; return 0; }
+int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
+                          uint8_t *swapped, int32_t *irank, void *st);
+/* (launches run synchronously here: by the time the ranking is "launched", every block of bits enqueued before it is complete) */
+int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
+                                uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *st)
+{
+    if (gate) for (int64_t r = 0; r < nsweeps; r += rows_per_gate) if (gate[r / rows_per_gate] != gate_value) return 1;
+    return nla_k_isres_stochrank(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, st);
+}
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                           uint8_t *swapped, int32_t *irank, void *st)
 {
