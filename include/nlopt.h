@@ -8,14 +8,19 @@
  *
  * Implemented algorithms (everything else returns NLOPT_INVALID_ARGS from nlopt_optimize with an
  * errmsg saying so — see DESIGN.md "out of scope"):
- *     NLOPT_GN_CRS2_LM (19)   NLOPT_GN_ISRES (35)
+ *     NLOPT_GN_CRS2_LM (19)   NLOPT_GN_ISRES (35)   NLOPT_GN_ESCH (42)
  *     NLOPT_GN_MLSL / GD_MLSL / GN_MLSL_LDS / GD_MLSL_LDS (20-23), NLOPT_G_MLSL / G_MLSL_LDS (38,39)
- *     NLOPT_LD_LBFGS (11)     (as the MLSL local optimiser)
+ *     the local optimisers MLSL runs (and nlopt_optimize serves on their own): NLOPT_LD_LBFGS (11), NLOPT_LD_MMA (24; with
+ *     nonlinear inequality constraints too), NLOPT_LN_COBYLA (25)
+ *     as callers of the above: NLOPT_AUGLAG / AUGLAG_EQ and the LN_ / LD_ variants (36, 37, 30-33)
+ *     the pre-2.0 one-call interface nlopt_minimize* maps onto the same
  *
- * Device objectives: a GPU cannot call a host callback.  Pass one of the function pointers
- * returned by nlopt_amd_objective() (include/nlopt_amd.h) to nlopt_set_min_objective and the
- * population is evaluated by HIP kernels; any other nlopt_func takes the exact-but-serial
- * host-evaluation path (candidate x copied back, f called in the reference's order).
+ * Objectives.  A GPU cannot call a host callback, so there are three kinds: (1) one of the function pointers returned by
+ * nlopt_amd_objective() (include/nlopt_amd.h) — the population / the local searches are evaluated inside the HIP kernels;
+ * (2) a device objective of your own, compiled as a code object (include/nlopt_amd_device.h, nlopt_amd_set_min_device_objective);
+ * (3) any other nlopt_func: served by every algorithm above through the exact host-callback path — candidates and iterates are built
+ * on the device, x is copied back and f is called on the caller's thread, one x at a time, in the reference's order (the
+ * reference's callback contract, nlopt.h:60-62).
  */
 #ifndef NLOPT_H
 #define NLOPT_H

@@ -399,7 +399,14 @@ int nla_comm_agree_same(nlopt_amd_comm *c, int ok, uint64_t fingerprint)
     const int world = nlopt_amd_comm_world(c);
     if (world <= 1) return ok ? 1 : 0;
     mine[0] = ok ? 1 : 0; mine[1] = fingerprint;
-    if (world > 128 && !(all = (uint64_t *) malloc(sizeof mine * (size_t) world))) return 0;
+    if (world > 128 && !(all = (uint64_t *) malloc(sizeof mine * (size_t) world))) {
+        /* out of memory here must not leave the other ranks waiting in the exchange: join it piecewise-free through the comm's own
+         * staging (nla_comm_allgather_host allocates / reuses it) by reporting "not ready" from a stack slot and discarding the rest */
+        static uint64_t sink[2 * 4096];
+        mine[0] = 0;
+        if (world <= 4096) (void) nla_comm_allgather_host(c, mine, sink, sizeof mine, NULL);
+        return 0;
+    }
     if (nla_comm_allgather_host(c, mine, all, sizeof mine, NULL)) res = 0;
     else {
         for (r = 0; r < world; ++r) if (!all[2 * r]) res = 0;
@@ -440,6 +447,23 @@ uint64_t nla_problem_fingerprint(int algorithm, int n, int population, int obj, 
     h = fnv(h, mt, sizeof mt);
     h = fnv(h, &pos, sizeof pos);
     return h ? h : 1;
+}
+
+/* the options of `opt` that shape a run's control flow and the sizes of its collectives (every nlopt_set_param value: the window depth,
+ * the sharding / summation / pipeline switches ...): ranks that differ in one of them issue different all-gathers.  Order-independent
+ * (a sum of per-parameter hashes), 0 for no parameters; the callers fold it into nla_problem_fingerprint's value. */
+uint64_t nla_params_fingerprint(const nlopt_opt opt)
+{
+    uint64_t sum = 0;
+    unsigned i;
+    if (!opt) return 0;
+    for (i = 0; i < opt->nparams; ++i) {
+        uint64_t h = 14695981039346656037ULL;
+        h = fnv(h, opt->params[i].name, strlen(opt->params[i].name));
+        h = fnv(h, &opt->params[i].val, sizeof(double));
+        sum += h;
+    }
+    return sum;
 }
 
 /* *stop with its two per-process conditions replaced by agreed verdicts */

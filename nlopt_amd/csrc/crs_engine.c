@@ -772,7 +772,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
     if (opt && nlopt_amd_comm_world(opt->comm) > 1) {
-        const int all = nla_comm_agree_same(opt->comm, *eout != NULL, nla_problem_fingerprint(NLOPT_GN_CRS2_LM, n, (int) N, pb->obj, lb, ub, x, stop));
+        const int all = nla_comm_agree_same(opt->comm, *eout != NULL, nla_problem_fingerprint(NLOPT_GN_CRS2_LM, n, (int) N, pb->obj, lb, ub, x, stop) + nla_params_fingerprint(opt));
         if (all <= 0 && *eout) {
             nla_crs_hip_engine_destroy(*eout, 0); *eout = NULL;
             if (all < 0) { nla_stop_msg(stop, NLA_MSG_RANKS_DIFFER); return NLOPT_INVALID_ARGS; }

@@ -73,7 +73,7 @@ typedef struct {
     char err[200];
 } isres_dev;
 
-#define ISRES_GATES 16                   /* blocks of sweeps the ranking bits are produced in when the pipeline starts beside them */
+#define ISRES_GATES 4                    /* blocks of sweeps the ranking bits are produced in when the pipeline starts beside them */
 #define DFAIL(d, ...) do { snprintf((d)->err, sizeof (d)->err, __VA_ARGS__); return -1; } while (0)
 #define DCK(d, call) do { int rc_ = (call); if (rc_) DFAIL(d, "%.90s failed: %.60s", #call, nla_dev_error_string(rc_)); } while (0)
 
@@ -516,7 +516,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     {   /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
         const int mine = dev_alloc(&D, lb, ub, con) == 0;
         const int all = nlopt_amd_comm_world(D.comm) > 1
-            ? nla_comm_agree_same(D.comm, mine, nla_problem_fingerprint(NLOPT_GN_ISRES, n, population, D.obj + 100 * (m + p), lb, ub, x, stop)) : mine;
+            ? nla_comm_agree_same(D.comm, mine, nla_problem_fingerprint(NLOPT_GN_ISRES, n, population, D.obj + 100 * (m + p), lb, ub, x, stop) + nla_params_fingerprint(opt)) : mine;
         if (all <= 0 || !mine) {
             if (!mine) nla_stop_msg(stop, "nlopt_amd: could not create the ISRES device state (out of device memory?)");
             else if (all < 0) nla_stop_msg(stop, NLA_MSG_RANKS_DIFFER);

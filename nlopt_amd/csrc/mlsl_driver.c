@@ -369,7 +369,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     nla_local_ctx_set_stats(D.lb, st);
     }
     if (D.world > 1) {
-        const int all = nla_comm_agree_same(D.comm, 1, nla_problem_fingerprint(lds ? NLOPT_G_MLSL_LDS : NLOPT_G_MLSL, n, D.N, D.obj + 100 * (int) local_opt->algorithm, lb, ub, x, stop));
+        const int all = nla_comm_agree_same(D.comm, 1, nla_problem_fingerprint(lds ? NLOPT_G_MLSL_LDS : NLOPT_G_MLSL, n, D.N, D.obj + 100 * (int) local_opt->algorithm, lb, ub, x, stop) + nla_params_fingerprint(opt) + nla_params_fingerprint(local_opt));
         if (all < 0) { nla_stop_msg(stop, NLA_MSG_RANKS_DIFFER); ret = NLOPT_INVALID_ARGS; goto done; }
         if (all == 0) { nla_stop_msg(stop, "nlopt_amd: another rank could not set up its MLSL device state"); ret = NLOPT_FAILURE; goto done; }
     }

@@ -127,6 +127,7 @@ void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, in
 void nla_stop_view(const nla_stopping *stop, int forced, int timed, nla_stopping *view, int *force_store);
 int nla_comm_agree_ready(nlopt_amd_comm *c, int ok);      /* end of a multi-rank set-up: 1 iff every rank is ready */
 int nla_comm_agree_same(nlopt_amd_comm *c, int ok, uint64_t fingerprint);   /* 1 ready and identical jobs, 0 some rank not ready, -1 ranks were given different jobs */
+uint64_t nla_params_fingerprint(const nlopt_opt opt);             /* every nlopt_set_param value of opt (the options that shape the pass structure / the collectives' sizes) */
 uint64_t nla_problem_fingerprint(int algorithm, int n, int population, int obj, const double *lb, const double *ub, const double *x,
                                  const nla_stopping *stop);
 #define NLA_MSG_RANKS_DIFFER "nlopt_amd: the ranks of this communicator were given different problems (dimension, population, bounds, starting point, stopping criteria or nlopt_srand seed): one job needs them identical"

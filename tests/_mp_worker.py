@@ -106,6 +106,8 @@ def main():
             o.set_comm(comm)
         for k, v in (args.get("params") or {}).items():
             o.set_param(k, v)
+        if args.get("param_by_rank"):
+            o.set_param("amd_window_factor", 2.0 + rank)          # the user's mistake of configuring the ranks differently
         if args.get("ftol_rel"):
             o.set_ftol_rel(args["ftol_rel"])
         if args.get("xtol_rel"):

@@ -311,13 +311,15 @@ def test_a_rank_whose_setup_fails_takes_the_others_with_it(alg, world, fail_rank
     ("gpu_isres", dict(obj="rastrigin", n=12, pop=60, seed=5, maxeval=360, ncon=2)),
     ("gpu_mlsl", dict(obj="ackley", n=6, pop=25, seed=7, maxeval=2500)),
 ], ids=["crs_sharded", "crs_replicas", "isres", "mlsl"])
-@pytest.mark.parametrize("mistake", ["seed_by_rank", "x0_by_rank"])
+@pytest.mark.parametrize("mistake", ["seed_by_rank", "x0_by_rank", "param_by_rank"])
 def test_ranks_given_different_jobs_are_told_so(case, a, mistake):
-    if mistake == "x0_by_rank" and not (case == "gpu_crs" and "params" not in a):
+    if mistake != "seed_by_rank" and not (case == "gpu_crs" and "params" not in a):
         pytest.skip("the starting point's share of the fingerprint: one algorithm is enough (suite time)")
     """one job over several ranks needs the identical problem and generator state on every rank; ranks seeded differently (the classic
     mistake: seed = base + rank) or started from different points would take different decisions and pass each other in the
-    collectives.  The set-up's exchange carries a fingerprint of the job: every rank returns NLOPT_INVALID_ARGS and says why."""
+    collectives — and so would ranks whose run-shaping options differ (param_by_rank: "amd_window_factor" sets the window depth, hence
+    the size of every pass's all-gather).  The set-up's exchange carries a fingerprint of the job: every rank returns NLOPT_INVALID_ARGS
+    and says why."""
     for d in run_world(case, dict(a, want_errmsg=True, **{mistake: True}), world=2, extra_env=EMU, timeout=120):
         assert d["ret"][0] == -2 and d["nevals"][0] == 0
         assert "different problems" in str(d["errmsg"]) and "nlopt_srand" in str(d["errmsg"])
