@@ -240,6 +240,7 @@ def pmc_traffic(kernel_prefix):
 # ------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    CRS_PARAMS[:] = list(getattr(a, "param", []) or [])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -291,6 +292,9 @@ def main():
         dist.destroy_process_group()
 
 
+CRS_PARAMS = []        # --param NAME=VALUE of the command line (the library's A/B switches), applied to every CRS2_LM object of crs_measure
+
+
 def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, sync_all, max_spec=0, variant=0, comm=None):
     """open a CRS2_LM run (population initialisation untimed), W warm-up steps, K timed steps; returns the raw numbers.
     comm: ONE job over the communicator's ranks (population sharded by coordinate), every rank with the same seed"""
@@ -305,6 +309,8 @@ def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, 
         o.set_param("amd_max_spec", max_spec)
     if variant:
         o.set_param("amd_gather_variant", variant)
+    for kv in CRS_PARAMS:
+        o.set_param(kv.split("=", 1)[0], float(kv.split("=", 1)[1]))
     if comm is not None:
         o.set_comm(comm)
     nlopt_amd.srand(seed)

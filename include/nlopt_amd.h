@@ -258,6 +258,15 @@ int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, c
                           nla_crs_slot_status *status, void *stream);
 int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
                           const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *stream);
+/* nla_k_crs_commit_args + nla_k_crs_advance_args in ONE launch: the ncommit (<= 16) staged commits — distinct rows, none of their
+ * source slots among this pass's own K slots — are copied by extra workgroups at the end of the grid, and every read of such a row
+ * by the gather (a pick, or the best row a fresh slot starts from) is forwarded to the slot it is being copied from */
+int nla_k_crs_advance_commit_args(int n, int ld, double *X, int64_t i0, const int32_t *jn_ring,
+                                  const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                                  uint64_t first_block, int K, const int64_t *h_W, int nW,
+                                  const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                                  double *TX, const double *TM, int ncommit, const int32_t *h_slot, const int32_t *h_kind,
+                                  const int64_t *h_row, int variant, void *stream);
 
 /* ---- CRS2_LM over several GPUs: the population sharded by COORDINATE (hip/crs_shard.hip) -----------------------------------------
  * Rank r holds columns [r * colper, r * colper + nc) of every row (colper = ceil(n / world); local index i = global column c0 + i;

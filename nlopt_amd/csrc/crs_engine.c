@@ -20,6 +20,7 @@
 #include <string.h>
 
 #define INIT_CHUNK_WORDS (1ULL << 28)      /* 1 GiB of stream words per init pass */
+#define NLA_KC_MAX 16                 /* commits an advance launch can carry (hip/crs_kernels.hip) */
 #define KCAP 1024                          /* slot ring (power of two) */
 /* the objective id as the kernel launchers take it: a compiled-in objective under nlopt_set_max_objective delivers -f (e->sign) */
 #define OBJK(e) (((e)->obj >= 0 && (e)->sign < 0) ? ((e)->obj | NLA_OBJ_NEGATE) : (e)->obj)
@@ -59,6 +60,7 @@ struct nla_crs_hip_engine {
     nla_crs_slot_status *d_status, *h_status;
     int32_t h_t[KCAP];             /* picks summed so far, per slot (host-authoritative) */
     int npending;                  /* commits staged on the host, not yet written to X */
+    int fuse_commit;               /* "amd_fuse_commit" (default 1): staged commits done inside the next pass's advance launch */
     int32_t pend_slot[KCAP], pend_kind[KCAP];
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
@@ -549,11 +551,24 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     if (K <= NLA_KARG_MAX && nW <= NLA_KARG_MAX && e->npending <= NLA_KARG_MAX && !e->force_upload && e->obj != -2) {
         /* small lists (the usual case): W, the resume points and the staged commits travel as kernel arguments — no copy in
          * front of the pass */
-        if (e->npending) {
+        /* the staged commits ride in the advance launch (hip/crs_kernels.hip, crs_fwd: copied by extra workgroups, reads of those rows
+         * forwarded to the slots they come from) unless one of their source slots is a slot of this pass's own window — the ring
+         * wrapped onto it — or there are too many: then the commit launch of its own in front, as before */
+        int fuse = e->fuse_commit && e->npending > 0 && e->npending <= NLA_KC_MAX;
+        for (int c = 0; fuse && c < e->npending; ++c)
+            for (int a = 0; a < K; ++a)
+                if ((int32_t) ((first_block + (uint64_t) a) & (KCAP - 1)) == e->pend_slot[c]) { fuse = 0; break; }
+        if (e->npending && !fuse) {
             CK(e, nla_k_crs_commit_args(n, e->ld, e->d_X, e->d_TX, e->d_TM, e->npending, e->pend_slot, e->pend_kind, e->pend_row, e->main));
             e->npending = 0;
         }
         EVREC(e->ev0);
+        if (fuse) {
+            CK(e, nla_k_crs_advance_commit_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
+                                                t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->npending, e->pend_slot,
+                                                e->pend_kind, e->pend_row, e->variant, e->main));
+            e->npending = 0;
+        } else
         CK(e, nla_k_crs_advance_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
                                      t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         EVREC(e->ev1);
@@ -769,6 +784,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
                           (!opt || nlopt_get_param(opt, "amd_shard", 1) != 0);
         if (shard) { pb->forward = 0; pb->comm = comm; }
         *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
+        if (*eout) (*eout)->fuse_commit = !opt || nlopt_get_param(opt, "amd_fuse_commit", 1) != 0;
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
     if (opt && nlopt_amd_comm_world(opt->comm) > 1) {

@@ -131,16 +131,53 @@ __global__ __launch_bounds__(64) void crs_vitter_kernel(int n, int64_t N, const 
 #define NLA_KA_MAX 128
 struct crs_lists { int inl; int32_t t_in[NLA_KA_MAX]; int64_t W[NLA_KA_MAX]; };
 struct crs_commits { int inl; int32_t slot[NLA_KA_MAX], kind[NLA_KA_MAX]; int64_t row[NLA_KA_MAX]; };
+/* The commits staged since the previous pass, done BY the advance launch instead of by a launch of their own in front of it (round 4:
+ * one launch and its gap less per pass — 2.7 + 3.8 us of a 30 us pass at n = 512): nc extra workgroups at the end of the grid copy
+ * the accepted points from their trial-point slots (src = kind << 16 | slot: TX if kind == 1, TM otherwise) into rows row[c] of X, and
+ * every READ of such a row by the gather workgroups of the same launch — a pick, or the best row a fresh slot starts from — is
+ * FORWARDED to the slot it is being copied from, so no workgroup reads a row that another one is writing.  The host guarantees the
+ * rows are distinct and no source slot is one of this pass's own slots (crs_engine.c). */
+#define NLA_KC_MAX 16
+struct crs_fwd { int nc; int32_t src[NLA_KC_MAX]; int64_t row[NLA_KC_MAX]; };
+
+typedef const __attribute__((address_space(4))) crs_fwd *crs_kernarg_fwd;
+__device__ __forceinline__ int32_t crs_fwd_of(crs_kernarg_fwd Fk, int64_t r)
+{
+    int32_t s_ = -1;
+    const int nc = Fk->nc;
+    for (int c = 0; c < nc; ++c) if (Fk->row[c] == r) s_ = Fk->src[c];
+    return s_;
+}
+__device__ __forceinline__ const char *crs_row_ptr(int32_t code, const double *X, const double *TX, const double *TM, int ld)      /* wave-uniform */
+{
+    if (code >= 0) return reinterpret_cast<const char *>(X + (size_t) code * (size_t) ld);
+    const int sc = -(code + 1);
+    return reinterpret_cast<const char *>(((sc >> 16) == 1 ? TX : TM) + (size_t) (sc & 0xffff) * (size_t) ld);
+}
 
 template <int VEC, int U, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
+    const crs_fwd F_first_kernel_argument,      /* read through the kernarg segment (offset 0), never by name: indexing the by-value copy with a
+                                                 * run-time c makes the compiler move it to scratch memory (see crs_chain.hip) */
     int n, int ncol, int ld, const double *__restrict__ X, int64_t i0, const int32_t *__restrict__ jn_ring,
     const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, uint32_t ring_blocks,
     uint64_t first_block, int K, const int64_t *__restrict__ W, int nW,
     const int32_t *__restrict__ t_in, int32_t *__restrict__ t_out, int slot_mask, int chunks,
-    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX, const crs_lists L)
+    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX, const crs_lists L,
+    double *__restrict__ Xw, const double *__restrict__ TM)
 {
     typedef typename VecT<VEC>::T V;
+    const crs_kernarg_fwd Fk = (crs_kernarg_fwd) __builtin_amdgcn_kernarg_segment_ptr();
+    (void) F_first_kernel_argument;
+#define F (*Fk)
+    if ((int) blockIdx.x >= K * chunks) {       /* a staged commit (crs.c:153): accepted point -> its row of X */
+        const int c = (int) blockIdx.x - K * chunks;
+        const int sc = F.src[c];
+        const double *src = ((sc >> 16) == 1 ? TX : TM) + (size_t) (sc & 0xffff) * (size_t) ld;
+        double *dst = Xw + (size_t) F.row[c] * (size_t) ld;
+        for (int i = threadIdx.x; i < ncol; i += WAVES * 64) dst[i] = src[i];
+        return;
+    }
     static_assert(U <= 64, "one lane per row of a batch");
     __shared__ V sacc[64];
     __shared__ int32_t srow[NLA_ADV_RCAP];
@@ -171,6 +208,10 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
         if (t < n - 1) { r = p[t]; r += (r >= i0 ? 1 : 0); } else r = al;
         return (int32_t) r;
     };
+    /* (row r of X as this launch may read it: the row itself, or — if a commit of this launch is writing it — the slot it comes from,
+     * encoded as -(1 + src) in the staged pick list AFTER the plan below has searched the list by row number: crs_fwd_of / crs_row_ptr) */
+#define fwd_of(r_) crs_fwd_of(Fk, (int64_t) (r_))
+#define row_ptr(code_) crs_row_ptr((code_), X, TX, TM, ld)
     const int cnt0 = (n - t0 < NLA_ADV_RCAP) ? n - t0 : NLA_ADV_RCAP;
     for (int i = threadIdx.x; i < cnt0; i += WAVES * 64) srow[i] = pick_row(t0 + i);
     __syncthreads();
@@ -210,14 +251,21 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
         if (chunk == 0 && threadIdx.x == 0) t_out[a] = t0;
         return;
     }
+    if (F.nc > 0) {                         /* (uniform) forward the staged picks that a commit of this launch is writing */
+        const int lim = (e - t0 < cnt0) ? e - t0 : cnt0;
+        for (int i = threadIdx.x; i < lim; i += WAVES * 64) { const int32_t s_ = fwd_of(srow[i]); if (s_ >= 0) srow[i] = -(1 + s_); }
+    }
     /* n rows are summed; ncol coordinates of them are held here (ncol == n: the whole rows; a column slice on several GPUs, crs_shard.hip) */
     const int col = (chunk * 64 + lane) * VEC;
     const bool active = col < ncol;
     const size_t colc = active ? (size_t) col : 0;
     const double *Xc = X + colc;
     double *accrow = TX + (size_t) q * (size_t) ld + colc;
-    if (wave == 0)                          /* x := best (crs.c:69), or resume */
-        sacc[lane] = (t0 == 0) ? ldv<VEC>(Xc + (size_t) i0 * (size_t) ld) : ldv<VEC>(accrow);
+    if (wave == 0) {                        /* x := best (crs.c:69), or resume */
+        const int32_t sb_ = (t0 == 0 && F.nc > 0) ? fwd_of(i0) : -1;
+        const double *bestc = sb_ >= 0 ? reinterpret_cast<const double *>(row_ptr(-(1 + sb_))) + colc : Xc + (size_t) i0 * (size_t) ld;
+        sacc[lane] = (t0 == 0) ? ldv<VEC>(bestc) : ldv<VEC>(accrow);
+    }
 
     const double hneg = -(0.5 * n);         /* x -= xi*(0.5*n)  ==  x += xi*(-(0.5*n)), exactly */
     const uint32_t lane_off = (uint32_t) (colc * sizeof(double));
@@ -226,7 +274,11 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
         const int cnt = (e - seg0 < NLA_ADV_RCAP) ? e - seg0 : NLA_ADV_RCAP;
         nla_lds_barrier();                  /* the previous segment's row list is no longer needed */
         if (seg0 != t0)                     /* (the first segment was staged for the plan) */
-            for (int i = threadIdx.x; i < cnt; i += WAVES * 64) srow[i] = pick_row(seg0 + i);
+            for (int i = threadIdx.x; i < cnt; i += WAVES * 64) {
+                int32_t r_ = pick_row(seg0 + i);
+                if (F.nc > 0) { const int32_t s_ = fwd_of(r_); if (s_ >= 0) r_ = -(1 + s_); }
+                srow[i] = r_;
+            }
         if (threadIdx.x == 0) *turn = 0;
         nla_lds_barrier();
         const int nb = (cnt + U - 1) / U;
@@ -236,8 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
             const int32_t myrow = srow[mine];
 #pragma unroll
             for (int u = 0; u < U; ++u) {        /* unconditional: lanes past the end hold the last row */
-                const int64_t r = (int64_t) __builtin_amdgcn_readlane(myrow, u);
-                const char *rowp = reinterpret_cast<const char *>(X + (size_t) r * (size_t) ld);   /* wave-uniform */
+                const char *rowp = row_ptr(__builtin_amdgcn_readlane(myrow, u));   /* wave-uniform: the row of X, or the slot a commit of this launch copies it from */
                 v[u] = *reinterpret_cast<const V *>(rowp + lane_off);
             }
         };
@@ -286,6 +337,9 @@ __global__ __launch_bounds__(WAVES * 64) void crs_advance_kernel(
         }
     }
     if (chunk == 0 && threadIdx.x == 0) t_out[a] = e;
+#undef F
+#undef fwd_of
+#undef row_ptr
 }
 
 /* finish kernel: for every slot of the window that became complete in this pass, f of the trial
@@ -450,7 +504,8 @@ static int crs_advance_launch(int n, int ncol, int ld, const double *X, int64_t 
                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                               uint64_t first_block, int K, const int64_t *W, int nW,
                               const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                              double *TX, int variant, const crs_lists &L, void *stream);
+                              double *TX, int variant, const crs_lists &L, void *stream, const crs_fwd *fwd = nullptr, double *Xw = nullptr,
+                              const double *TM = nullptr);
 extern "C" int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                                  const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                                  uint64_t first_block, int K, const int64_t *W, int nW,
@@ -491,13 +546,36 @@ extern "C" int nla_k_crs_advance_args(int n, int ld, const double *X, int64_t i0
     return crs_advance_launch(n, n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, nullptr, nW, nullptr, t_out, slot_mask,
                               lb, ub, TX, variant, L, stream);
 }
+/* nla_k_crs_advance_args with the staged commits (ncommit <= 16 distinct rows; no source slot among this pass's own slots) done
+ * inside the same launch and the reads of those rows forwarded: replaces nla_k_crs_commit_args + nla_k_crs_advance_args */
+extern "C" int nla_k_crs_advance_commit_args(int n, int ld, double *X, int64_t i0, const int32_t *jn_ring,
+                                             const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
+                                             uint64_t first_block, int K, const int64_t *h_W, int nW,
+                                             const int32_t *h_t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
+                                             double *TX, const double *TM, int ncommit, const int32_t *h_slot, const int32_t *h_kind,
+                                             const int64_t *h_row, int variant, void *stream)
+{
+    if (K > NLA_KA_MAX || nW > NLA_KA_MAX || ncommit > NLA_KC_MAX || ncommit < 0) return (int) hipErrorInvalidValue;
+    crs_lists L;
+    crs_fwd F;
+    L.inl = 1;
+    for (int a = 0; a < K; ++a) L.t_in[a] = h_t_in[a];
+    for (int j = 0; j < nW; ++j) L.W[j] = h_W[j];
+    F.nc = ncommit;
+    for (int c = 0; c < ncommit; ++c) { F.src[c] = (h_kind[c] << 16) | (h_slot[c] & 0xffff); F.row[c] = h_row[c]; }
+    return crs_advance_launch(n, n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, nullptr, nW, nullptr, t_out, slot_mask,
+                              lb, ub, TX, variant, L, stream, &F, X, TM);
+}
 static int crs_advance_launch(int n, int ncol, int ld, const double *X, int64_t i0, const int32_t *jn_ring,
                               const int32_t *pos_ring, const int32_t *last_ring, uint32_t ring_blocks,
                               uint64_t first_block, int K, const int64_t *W, int nW,
                               const int32_t *t_in, int32_t *t_out, int slot_mask, const double *lb, const double *ub,
-                              double *TX, int variant, const crs_lists &L, void *stream)
+                              double *TX, int variant, const crs_lists &L, void *stream, const crs_fwd *fwd, double *Xw, const double *TM)
 {
     if (K <= 0) return 0;
+    crs_fwd F;
+    F.nc = 0;
+    if (fwd) F = *fwd;
     hipStream_t st = (hipStream_t) stream;
     /* variant = [1 if thin][WAVES][U as two digits]; thin = one coordinate per lane (64-coordinate chunks:
      * twice the workgroups per slot, for when few slots must spread over the whole chip) */
@@ -506,9 +584,9 @@ static int crs_advance_launch(int n, int ncol, int ld, const double *X, int64_t 
     if (variant >= 10000) { vec2 = false; variant -= 10000; }
     const int cpw = vec2 ? 128 : 64;
     const int chunks = (ncol + cpw - 1) / cpw;
-    const dim3 grid((unsigned) ((long) chunks * K));
-#define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, n, ncol, ld, X, i0, jn_ring, \
-        pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX, L)
+    const dim3 grid((unsigned) ((long) chunks * K + F.nc));
+#define ADV(VEC, UU, WV) hipLaunchKernelGGL((crs_advance_kernel<VEC, UU, WV>), grid, dim3(WV * 64), 0, st, F, n, ncol, ld, X, i0, jn_ring, \
+        pos_ring, last_ring, ring_blocks, first_block, K, W, nW, t_in, t_out, slot_mask, chunks, lb, ub, TX, L, Xw, TM)
     if (vec2) {
         switch (variant) {
         case 116: ADV(2, 16, 1); break;

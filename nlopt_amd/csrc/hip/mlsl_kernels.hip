@@ -22,7 +22,7 @@
 #define DR 64          /* pairs tile edge of the register-tiled kernel */
 #define DKR 32         /* coordinates per LDS tile */
 __global__ __launch_bounds__(256) void mlsl_dist2_kernel(int n, int ld, const double *__restrict__ A, int na,
-                                                               const double *__restrict__ B, int nb, double *__restrict__ D)
+                                                         const double *__restrict__ B, int nb, double *__restrict__ D)
 {
     __shared__ double sa[DR][DKR + 1], sb[DR][DKR + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -32,15 +32,30 @@ __global__ __launch_bounds__(256) void mlsl_dist2_kernel(int n, int ld, const do
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[r][c] = 0.;
+    /* the NEXT coordinate tile travels from global memory into registers while this one is being summed out of LDS (a thread stages
+     * 8 + 8 values per tile: element q * 256 + tid of the 64 x 32 tile, row = e / 32 — a wavefront reads two 256-byte row pieces) */
+    constexpr int PER = DR * DKR / 256;
+    double pa[PER], pb[PER];
+    auto fetch = [&](int k0) {
+        const int kc = n - k0 < DKR ? n - k0 : DKR;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = q * 256 + (int) threadIdx.x, r = e / DKR, k = e - r * DKR;
+            pa[q] = (i0 + r < na && k < kc) ? A[(size_t) (i0 + r) * ld + k0 + k] : 0.;
+            pb[q] = (j0 + r < nb && k < kc) ? B[(size_t) (j0 + r) * ld + k0 + k] : 0.;
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < n; k0 += DKR) {
         const int kc = n - k0 < DKR ? n - k0 : DKR;
-        __syncthreads();
-        for (int e = threadIdx.x; e < DR * DKR; e += 256) {
-            const int r = e / DKR, k = e - r * DKR;
-            sa[r][k] = (i0 + r < na && k < kc) ? A[(size_t) (i0 + r) * ld + k0 + k] : 0.;
-            sb[r][k] = (j0 + r < nb && k < kc) ? B[(size_t) (j0 + r) * ld + k0 + k] : 0.;
+        __syncthreads();                       /* the previous tile has been read by everyone */
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = q * 256 + (int) threadIdx.x, r = e / DKR, k = e - r * DKR;
+            sa[r][k] = pa[q]; sb[r][k] = pb[q];
         }
         __syncthreads();
+        if (k0 + DKR < n) fetch(k0 + DKR);
         for (int k = 0; k < kc; ++k) {
             double a[4], b[4];
 #pragma unroll

@@ -93,7 +93,7 @@ static void mfree(mlsl_dev *d)
     if (d->rs) nla_stream_sync(d->rs);
     if (d->mts) { nla_mtstream_finish(d->mts, d->words_used); nla_mtstream_destroy(d->mts); }
     nla_local_ctx_destroy(d->lb);
-    free(d->F); free(d->cpd); free(d->cld); free(d->minimized); free(d->ord); free(d->LF); free(d->lord);
+    free(d->F); nla_host_free(d->cpd); nla_host_free(d->cld); nla_host_free(d->minimized); free(d->ord); free(d->LF); free(d->lord);
     nla_dev_free(d->d_lb); nla_dev_free(d->d_ub); nla_dev_free(d->d_P); nla_dev_free(d->d_F); nla_dev_free(d->d_cpd);
     nla_dev_free(d->d_LM); nla_dev_free(d->d_LF); nla_dev_free(d->d_D); nla_dev_free(d->d_tmp); nla_dev_free(d->d_min);
     nla_dev_free(d->d_words); nla_dev_free(d->d_LX); nla_dev_free(d->d_V); nla_dev_free(d->d_dx);
@@ -106,6 +106,16 @@ static void mfree(mlsl_dev *d)
     if (d->st) nla_stream_destroy(d->st);
 }
 
+/* host arrays that travel to / from the device every iteration live in PINNED memory: a copy from pageable memory is staged by the
+ * runtime and was seen to hold the main stream's work back until the generator's stream had drained (the sample prefetch did not
+ * overlap anything, profiles/r04_mlsl_prefetch_timeline.txt) */
+static void *pinned_regrow(void *old, size_t old_bytes, size_t new_bytes)
+{
+    void *p = nla_host_malloc(new_bytes);
+    if (p && old && old_bytes) memcpy(p, old, old_bytes);
+    if (p) nla_host_free(old);
+    return p;
+}
 static int grow_pts(mlsl_dev *d, size_t need)
 {
     size_t ncap = d->cap ? d->cap : 1024;
@@ -114,9 +124,15 @@ static int grow_pts(mlsl_dev *d, size_t need)
     if (need <= d->cap) return 0;
     while (ncap < need) ncap *= 2;
     d->F = (double *) realloc(d->F, sizeof(double) * ncap);
-    d->cpd = (double *) realloc(d->cpd, sizeof(double) * ncap);
-    d->cld = (double *) realloc(d->cld, sizeof(double) * ncap);
-    d->minimized = (int32_t *) realloc(d->minimized, sizeof(int32_t) * ncap);
+    {
+        double *c1 = (double *) pinned_regrow(d->cpd, sizeof(double) * d->cap, sizeof(double) * ncap);
+        double *c2 = (double *) pinned_regrow(d->cld, sizeof(double) * d->cap, sizeof(double) * ncap);
+        int32_t *m1 = (int32_t *) pinned_regrow(d->minimized, sizeof(int32_t) * d->cap, sizeof(int32_t) * ncap);
+        if (c1) d->cpd = c1;
+        if (c2) d->cld = c2;
+        if (m1) d->minimized = m1;
+        if (!c1 || !c2 || !m1) MFAIL(d, "out of pinned memory growing the point set");
+    }
     d->ord = (size_t *) realloc(d->ord, sizeof(size_t) * ncap);
     nP = (double *) nla_dev_malloc(sizeof(double) * ncap * (size_t) d->ld);
     nF = (double *) nla_dev_malloc(sizeof(double) * ncap);
@@ -313,7 +329,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.d_gi = (int64_t *) nla_dev_malloc(sizeof(int64_t) * (size_t) bmax);
     D.h_flags = (int32_t *) nla_host_malloc(sizeof(int32_t) * (size_t) bmax);
     D.d_flags = (int32_t *) nla_dev_malloc(sizeof(int32_t) * (size_t) bmax);
-    Fnew = (double *) malloc(sizeof(double) * (size_t) D.N);
+    Fnew = (double *) nla_host_malloc(sizeof(double) * (size_t) D.N);        /* pinned: the samples' values come back every iteration */
     if (host) D.h_rows = (double *) nla_host_malloc(sizeof(double) * (size_t) D.N * (size_t) D.ld);
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
@@ -322,7 +338,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         nla_comm_agree_ready(D.comm, 0);
-        mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
+        mfree(&D); nla_host_free(Fnew); free(res); free(res_mine); free(cand);
         return NLOPT_OUT_OF_MEMORY;
     }
     if (lds) {                                                                 /* d.s = nlopt_sobol_create(n), mlsl.c:306 */
@@ -332,7 +348,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             if (!D.d_V || nla_memcpy_h2d(D.d_V, V, sizeof(uint32_t) * 32 * (size_t) n, D.st) || nla_stream_sync(D.st)) {
                 nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
                 nla_comm_agree_ready(D.comm, 0);
-                free(V); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
+                free(V); mfree(&D); nla_host_free(Fnew); free(res); free(res_mine); free(cand);
                 return NLOPT_OUT_OF_MEMORY;
             }
             D.sobol_next = nla_sobol_skip_count((unsigned) (10 * n + D.N)) + 1;  /* nlopt_sobol_skip(d.s, 10n+N, .), mlsl.c:332 */
@@ -344,7 +360,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         if (!D.d_dx || nla_memcpy_h2d(D.d_dx, local_opt->dx, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) {
             nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
             nla_comm_agree_ready(D.comm, 0);
-            mfree(&D); free(Fnew); free(res); free(res_mine); free(cand);
+            mfree(&D); nla_host_free(Fnew); free(res); free(res_mine); free(cand);
             return NLOPT_OUT_OF_MEMORY;
         }
     }
@@ -365,7 +381,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
                    : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);
     if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode_for(opt, local_opt, &D.ev), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
-    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); nla_comm_agree_ready(D.comm, 0); mfree(&D); free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
+    if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); nla_comm_agree_ready(D.comm, 0); mfree(&D); nla_host_free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_local_ctx_set_stats(D.lb, st);
     }
     if (D.world > 1) {
@@ -662,6 +678,6 @@ done:
     if (st) st->mt_words = D.words_used;
     if (use_cobyla) { local_opt->f = lo_f; local_opt->f_data = lo_fdata; nla_host_free(cob_x); }   /* (the wrapper's data live on this stack) */
     mfree(&D);
-    free(Fnew); free(res); free(res_mine); free(cand);
+    nla_host_free(Fnew); free(res); free(res_mine); free(cand);
     return ret;
 }

@@ -824,6 +824,17 @@ int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const doub
     EMU_LAUNCH();
     return nla_k_crs_commit(n, ld, X, TX, TM, ncommit, h_slot, h_kind, h_row, st);
 }
+int nla_k_crs_advance_commit_args(int n, int ld, double *X, int64_t i0, const int32_t *jn_ring, const int32_t *pos_ring, const int32_t *last_ring,
+                                  uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *h_W, int nW, const int32_t *h_t_in, int32_t *t_out,
+                                  int slot_mask, const double *lb, const double *ub, double *TX, const double *TM, int ncommit,
+                                  const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, int variant, void *st)
+{
+    /* (one launch on the device, with the rows' reads forwarded; here simply one after the other: the same values) */
+    int rc = nla_k_crs_commit_args(n, ld, X, TX, TM, ncommit, h_slot, h_kind, h_row, st);
+    if (rc) return rc;
+    return nla_k_crs_advance_args(n, ld, X, i0, jn_ring, pos_ring, last_ring, ring_blocks, first_block, K, h_W, nW, h_t_in, t_out, slot_mask, lb, ub,
+                                  TX, variant, st);
+}
 int nla_k_crs_mutate(int n, const double *best, double *p, const uint32_t *words, const double *lb, const double *ub, void *st)
 {
     EMU_LAUNCH();

@@ -18,6 +18,34 @@ def main():
         for r in cur.execute(q):
             print("%s,%s,%d,%.6g,%.6g" % (r[0].split("(")[0], r[1], r[2], r[3], r[4]))
         return
+    if "--api" in sys.argv:
+        # host-side API calls (rocprofv3 --hip-trace): per function count / total / average, then the calls in start order with the host
+        # time between the END of one call and the START of the next (what the application itself spent)
+        names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        cand = [t for t in names if t.lower() in ("regions", "hip_api", "api", "regions_and_samples")] or [t for t in names if "region" in t.lower()]
+        print("# tables/views:", names)
+        for t in cand[:1]:
+            cols = [r[1] for r in cur.execute("pragma table_info(%s)" % t)]
+            print("# %s columns:" % t, cols)
+            if not {"name", "start", "end"} <= set(cols):
+                continue
+            rows = list(cur.execute("select name, start, end from %s order by start" % t))
+            agg = {}
+            for nm, st, en in rows:
+                a = agg.setdefault(nm, [0, 0])
+                a[0] += 1; a[1] += en - st
+            print("function,calls,total_us,avg_us")
+            for nm, (c, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+                print("%s,%d,%.1f,%.2f" % (nm, c, tot / 1e3, tot / 1e3 / c))
+            lim = int(sys.argv[sys.argv.index("--api") + 1]) if len(sys.argv) > sys.argv.index("--api") + 1 else 0
+            if lim:
+                mid = len(rows) // 2
+                print("idx,start_us,dur_us,host_gap_before_us,name")
+                last = rows[mid][1]
+                for k, (nm, st, en) in enumerate(rows[mid:mid + lim]):
+                    print("%d,%.1f,%.1f,%.1f,%s" % (k, (st - rows[mid][1]) / 1e3, (en - st) / 1e3, (st - last) / 1e3, nm))
+                    last = en
+        return
     if "--timeline" in sys.argv:
         i = sys.argv.index("--timeline")
         first = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 0
