@@ -135,3 +135,33 @@ def test_mma_with_maxtime_only_is_accepted_and_needs_a_device():
         assert ret == nlopt_amd.FAILURE and "no HIP device" in o.get_errmsg()
     else:
         assert ret in (nlopt_amd.MAXTIME_REACHED, nlopt_amd.SUCCESS, nlopt_amd.XTOL_REACHED, nlopt_amd.FTOL_REACHED)
+
+
+def test_hot_kernels_use_no_scratch_memory():
+    """the code objects' own metadata (tools/kernel_resources.py: llvm-readelf --notes on the gfx950 ELF of every built object): the
+    kernels on the benchmarked paths keep their state in registers / LDS — `.private_segment_fixed_size` is 0 for the CRS2_LM gather /
+    chain / finish kernels, the resident L-BFGS kernel in both summation modes, the MLSL, MMA and ISRES evolve kernels.  (A by-value
+    kernel argument indexed at run time, or a lambda captured by another lambda, silently moves state to scratch: this is the guard.)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir(os.path.join(root, "nlopt_amd", "lib", "obj")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        import pytest
+        pytest.skip("no object files / no llvm-readelf here")
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels()
+    assert len(ks) > 100
+    must = ("crs_advance_kernel", "crs_chain_kernel", "crs_finish_kernel", "crs_vitter_kernel", "lbfgs_resident_kernel", "mlsl_dist2_kernel",
+            "mma_batch_kernel", "ev2_scan_kernel", "isres_stochrank_kernel", "mt_rankbits_kernel")
+    seen = set()
+    for k in ks:
+        for m in must:
+            if m in k["name"]:
+                seen.add(m)
+                assert k["scratch"] == "0" and k["vgpr_spill"] == "0", (k["name"], k["scratch"], k["vgpr_spill"])
+    assert seen == set(must), set(must) - seen
+    # two workgroups of the resident L-BFGS kernel share a CU: at most 256 registers and 80 KB of LDS each
+    for k in ks:
+        if "lbfgs_resident_kernel" in k["name"]:
+            assert int(k["vgpr"]) + int(k["agpr"]) <= 256 and int(k["lds"]) <= 80 * 1024, k
