@@ -682,7 +682,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
         metric = "candidate-evals/sec, ISRES n=%d pop=%d, %d inequality constraints" % (n, pop, ncon)
         wl = "NLOPT_GN_ISRES %s n=%d pop=%d + %d block-sum inequality constraints, seed=%d; step = 1 generation" % (a.obj, n, pop, ncon, a.seed)
         phases = {"eval_s_per_gen": d["t_eval_s"] / K, "rank_s_per_gen": d["t_rank_s"] / K, "evolve_s_per_gen": d["t_evolve_s"] / K,
-                  "rng_s_per_gen_inside_rank_and_evolve": d["t_rng_s"] / K, "rank_sweeps_per_gen": d["rank_sweeps"] / K,
+                  "rng_s_per_gen_inside_rank_and_evolve": d["t_rng_s"] / K, "rank_sweeps_per_gen": d["rank_sweeps"] / K, "evolve_rounds_per_gen": d["evolve_rounds"] / K,
+                  "evolve_rounds_enqueued_per_gen": d["evolve_rounds_enqueued"] / K,
                   # isres_driver.c "amd_isres_overlap": the generator on a stream of its own beside the latency-bound kernels (the
                   # default; NLA_ISRES_OVERLAP=0 gives the one-stream generation: 72.9 vs 65.3 ms, profiles/r03_isres_overlap_ab.txt)
                   "generator_on_its_own_stream": os.environ.get("NLA_ISRES_OVERLAP", "1") != "0"}

@@ -100,6 +100,9 @@ typedef struct {
      * every rank received (0 on a single rank) */
     double t_allgather_ms;
     uint64_t allgather_bytes;
+    /* ISRES evolve (hip/isres_evolve2.hip): rounds of stage / scan / chain / write enqueued, and those of them that had
+     * individuals left to resolve (a batch of rounds is enqueued before the host looks at the state again) */
+    uint64_t evolve_rounds_enqueued, evolve_rounds;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 

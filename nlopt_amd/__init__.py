@@ -39,7 +39,8 @@ class Stats(C.Structure):
                 ("rank_sweeps", C.c_uint64), ("t_eval_s", C.c_double), ("t_rank_s", C.c_double), ("t_evolve_s", C.c_double),
                 ("t_rng_s", C.c_double), ("lbfgs_launches", C.c_uint64), ("lbfgs_bytes", C.c_uint64), ("t_lbfgs_ms", C.c_double),
                 ("t_stochrank_ms", C.c_double), ("stochrank_launches", C.c_uint64), ("stochrank_ticks", C.c_uint64),
-                ("t_allgather_ms", C.c_double), ("allgather_bytes", C.c_uint64)]
+                ("t_allgather_ms", C.c_double), ("allgather_bytes", C.c_uint64),
+                ("evolve_rounds_enqueued", C.c_uint64), ("evolve_rounds", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -93,7 +93,7 @@ struct nla_crs_hip_engine {
 };
 
 #define FAIL(e, ...) do { snprintf((e)->err, sizeof (e)->err, __VA_ARGS__); return -1; } while (0)
-#define CK(e, call) do { int rc_ = (call); if (rc_) FAIL(e, "%s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
+#define CK(e, call) do { int rc_ = (call); if (rc_) FAIL(e, "%.160s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
 
 /* can n coordinates be dealt over `world` ranks in equal blocks of ceil(n / world) with nobody left empty? */
 int nla_crs_can_shard(int n, int world)

@@ -161,15 +161,18 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
             if (a == cnext) { if (c < 64) Ti[(size_t) c * EVD + d] = (int16_t) red; ++c; cnext += chunk; }
             if (res != 0) continue;
             if (cur + 1 >= zwlen) { res = zw_cut ? -2 : -1; continue; }
-            double s2 = sg[a] * exp(taup_rand + A.tau * zw[cur]);
+            /* the lane's chain is serial — deviate index -> sigma' (an fp64 exp) -> the first draw inside the box -> next index — and with
+             * one wavefront per SIMD nothing hides its latency: the first draw is fetched together with the deviate of sigma', not after the exp */
+            const double zs = zw[cur], z1 = zw[cur + 1];
+            double s2 = sg[a] * exp(taup_rand + A.tau * zs);
             if (s2 > smax[a]) s2 = smax[a];
             const double xa = xi[a], l = lo[a], h = hi[a];
             int t = 1;
-            for (;;) {
-                const double xn = xa + s2 * zw[cur + t];
-                if (!(xn < l || xn > h)) break;
+            double xn = xa + s2 * z1;
+            while (xn < l || xn > h) {
                 ++t;
                 if (cur + t >= zwlen) { res = zw_cut ? -2 : -1; break; }
+                xn = xa + s2 * zw[cur + t];
             }
             cur += 1 + t; red += t - 1;
         }
@@ -179,49 +182,106 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
 }
 
 /* ---- chain ------------------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(256) void ev2_chain_kernel(ev2_args A)
+/* One workgroup of 1024: all of it copies the E table into LDS (16 bytes per thread and step, everything in flight at once); wavefront 0
+ * then walks the block.  The walk is one dependent chain — start of individual i -> its E entry -> start of i + 1 — and a lone wavefront
+ * issues one instruction every four cycles, so what counts is the number of instructions per individual and that no memory latency sits
+ * between them.  It runs on the SCALAR unit out of registers: the per-individual inputs (mutated-coordinate count; window origin relative
+ * to the block's first deviate, pushed out of every window when the individual is past the end or variation's dependency forbids it) sit
+ * in the lanes of four registers and come out with v_readlane; the individual's E row (256 entries = 8 bytes per lane) is fetched from
+ * LDS four individuals AHEAD and the one entry the chain needs comes out with v_readlane too; the exact starts go into a lane of a
+ * register and leave in one parallel store; the sums for rho are formed after the walk from the same registers. */
+__device__ __forceinline__ long long ev2_uniform64(long long v)
+{
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v & 0xffffffffll));
+    const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) ((unsigned long long) v >> 32));
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
 {
     extern __shared__ int16_t sE[];                            /* EVM x EVD */
-    __shared__ int s_na[EVM];
-    __shared__ long long s_b[EVM];
     const int tid = threadIdx.x;
     if (A.state[2] || A.state[10]) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing: its write kernel idles */
-    const int64_t k0 = A.state[0], kend = A.phase == 0 ? A.pop : A.survivors;
+    const int64_t k0 = ev2_uniform64(A.state[0]), kend = A.phase == 0 ? A.pop : A.survivors;
     if (k0 >= kend) { if (tid == 0) A.state[9] = 0; return; }
-    for (int q = tid; q < EVM; q += 256) { s_na[q] = A.ws_nact[q]; s_b[q] = A.ws_base[q]; }
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(A.E);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(sE);
-        for (int q = tid; q < EVM * EVD / 2; q += 256) dst[q] = src[q];
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.E);            /* (E is 256-byte aligned in the workspace) */
+        uint4 *dst = reinterpret_cast<uint4 *>(sE);
+#pragma unroll
+        for (int q = 0; q < EVM * EVD / 8 / 1024; ++q) dst[q * 1024 + tid] = src[q * 1024 + tid];
+    }
+    static_assert(EVM == 256 && EVD == 256 && (EVM * EVD / 8) % 1024 == 0, "the chain kernel holds the block in four registers per lane, a row in 8 bytes per lane");
+    const long long pos0 = ev2_uniform64(A.state[1]);
+    const int OUT = 0x40000000;                                /* a window origin no start of this block can be within EVD of */
+    int na_v[4], b_v[4], st_v[4];
+    if (tid < 64) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int q = c * 64 + tid;
+            na_v[c] = A.ws_nact[q]; st_v[c] = 0;
+            const long long brel = A.ws_base[q] - pos0;
+            /* the row isres.c:260 reads (physical row k + 1) must not be rewritten inside this block before k: the walk ends at a
+             * survivor k whose row k + 1 belongs to an earlier survivor of the block (straight-line: the index is clamped, not guarded) */
+            const long long k = k0 + q, k1 = k + 1 < A.pop ? k + 1 : A.pop - 1;
+            const long long o = A.inv[k1];
+            const bool dep = A.phase == 1 && k + 1 < A.pop && o >= k0 && o < k;
+            const bool stop = na_v[c] < 0 || dep || brel >= OUT || brel <= -OUT;
+            b_v[c] = stop ? OUT : (int) brel;
+        }
     }
     __syncthreads();
-    if (tid != 0) return;
-    long long pos = A.state[1], rsum = 0, asum = 0;
-    int r = 0, ranout = 0;
-    for (int i = 0; i < EVM; ++i) {
-        const int na = s_na[i];
-        if (na < 0) break;
-        const long long k = k0 + i;
-        if (A.phase == 1 && k + 1 < A.pop) {                   /* the row isres.c:260 reads must not be rewritten inside this block before k */
-            const long long o = A.inv[k + 1];
-            if (o >= k0 && o < k) break;
+    if (tid >= 64) return;
+    const uint2 *rows = reinterpret_cast<const uint2 *>(sE);   /* row i: entries 4 lane .. 4 lane + 3 in rows[i * 64 + lane] */
+    int pos = 0, r = 0, elast = 0;                             /* pos: relative to pos0 (at most 256 x 32767) */
+    uint2 nx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nx[u] = rows[u * 64 + tid];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll 1
+        for (int g = 0; g < 16; ++g) {
+            uint2 cu[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cu[u] = nx[u];
+            const int inext = c * 64 + g * 4 + 4 < EVM ? c * 64 + g * 4 + 4 : EVM - 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nx[u] = rows[(inext + u) * 64 + tid];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = g * 4 + u;
+                const unsigned d = (unsigned) (pos - __builtin_amdgcn_readlane(b_v[c], l));
+                if (d >= (unsigned) EVD) { elast = d >= 0xc0000000u && d < 0xd0000000u ? -11 : -10; goto done; }
+                const int wx = __builtin_amdgcn_readlane((int) cu[u].x, (int) (d >> 2)), wy = __builtin_amdgcn_readlane((int) cu[u].y, (int) (d >> 2));
+                const int w = (d & 2u) ? wy : wx;
+                const int e = (int) (int16_t) (w >> ((d & 1u) << 4));
+                if (e < 0) { elast = e; goto done; }
+                if (tid == l) st_v[c] = pos;
+                pos += e;
+                ++r;
+            }
         }
-        const long long d = pos - s_b[i];
-        if (d < 0 || d >= EVD) break;
-        const int e = sE[i * EVD + (int) d];
-        if (e == -2) { ranout = 1; break; }
-        if (e < 0) break;
-        A.ws_start[i] = pos;
-        pos += e; rsum += e - 1 - 2 * na; asum += na;
-        ++r;
     }
+done:
+    long long asum = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c * 64 + tid < r) { A.ws_start[c * 64 + tid] = pos0 + st_v[c]; asum += na_v[c]; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) asum += __shfl_xor(asum, m, 64);
+    if (tid != 0) return;
+    const long long rsum = (long long) pos - r - 2 * asum;     /* = sum over the resolved of (consumed - 1 - 2 mutated) = their redraws */
     A.state[12] = k0;
     A.state[0] = k0 + r;
-    A.state[1] = pos;
+    A.state[1] = pos0 + pos;
     A.state[9] = r;
     A.state[11] += 1;
-    if (ranout) A.state[2] = 1;
+    if (elast == -2) A.state[2] = 1;
     else if (r == 0) A.state[10] = 1;                           /* not even the exactly-started first individual resolved: serial fallback */
+#ifdef NLA_EV2_REASONS                                          /* development build (NLOPT_AMD_VARIANT="reasons:-DNLA_EV2_REASONS"): what ended the walks; isres_driver.c prints it per phase */
+    A.state[3] += elast == -10; A.state[4] += elast == -11; A.state[5] += elast == -1; A.state[6] += elast == 0; A.state[7] += r;
+    { long long a2 = 0; for (int i = 0; i < r; ++i) a2 += A.ws_nact[i]; A.state[13] += a2 != asum; A.state[15] += a2 - asum; }
+#endif
     A.rho[2 * A.phase] = 0.9 * A.rho[2 * A.phase] + (double) rsum;
     A.rho[2 * A.phase + 1] = 0.9 * A.rho[2 * A.phase + 1] + (double) asum;
 }
@@ -339,7 +399,7 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(ev2_stage_kernel, dim3(EVM), dim3(256), 0, st, A);
         hipLaunchKernelGGL(ev2_scan_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);
-        hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(256), lds_chain, st, A);
+        hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(1024), lds_chain, st, A);
         hipLaunchKernelGGL(ev2_write_kernel, dim3(EVM), dim3(64), lds_write, st, A);
     }
     NLA_LAUNCH_CHECK();

@@ -58,7 +58,7 @@ typedef struct {
     int32_t *d_FEAS, *d_irank, *d_counts, *d_inv;
     double *d_rho; void *d_ws;           /* parallel evolve (hip/isres_evolve2.hip): redraw statistics, block workspace */
     int parallel_evolve;
-    uint64_t ev_rounds, ev_fallbacks;
+    uint64_t ev_rounds, ev_fallbacks, ev_real;
     int *d_progress, *d_ticket;
     uint8_t *d_swapped;
     uint64_t *d_streams, *d_bits;
@@ -373,7 +373,7 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
     for (phase = 0; phase < 2; ++phase) {
         const int64_t kend = phase == 0 ? d->pop : d->survivors;
         state[0] = phase == 0 ? d->survivors : 0;
-        state[2] = 0; state[9] = 0; state[10] = 0; state[14] = 0;
+        state[2] = 0; state[9] = 0; state[10] = 0; state[11] = 0; state[14] = 0;
         DCK(d, nla_memcpy_h2d(d->d_state, state, sizeof state, d->st));
         if (d->parallel_evolve && phase == 1)                  /* memcpy(x0, xs, n) before the variation loop (isres.c:253) */
             DCK(d, nla_memcpy_d2d(d->d_scratch, d->d_X, sizeof(double) * (size_t) d->n, d->st));
@@ -421,6 +421,12 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
             }
             if (!d->parallel_evolve || state[0] >= kend) break;
         }
+        d->ev_real += (uint64_t) state[11];                    /* rounds of this phase that resolved something */
+#ifdef NLA_EV2_REASONS
+        fprintf(stderr, "evolve phase %d: rounds %lld, stopped by window %lld, by end/dependency %lld, by a candidate that left its deviates %lld, full blocks %lld, resolved %lld\n", phase, (long long) state[11], (long long) state[3], (long long) state[4], (long long) state[5], (long long) state[6], (long long) state[7]);
+        fprintf(stderr, "   rounds whose mutated-coordinate sum differs from the direct sum: %lld, total difference %lld\n", (long long) state[13], (long long) state[15]);
+        state[3] = state[4] = state[5] = state[6] = state[7] = state[13] = state[15] = 0;
+#endif
     }
     if (NLA_DBG_ENV("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve2: rounds enqueued %llu, serial fallbacks %llu; overlap %d: deviates generated ahead %llu times, used %llu times\n", (unsigned long long) d->ev_rounds, (unsigned long long) d->ev_fallbacks, d->overlap, (unsigned long long) d->spec_made, (unsigned long long) d->spec_used);
     if (NLA_DBG_ENV("NLA_ISRES_DEBUG")) fprintf(stderr, "evolve: fixpoint rounds %lld for %lld individuals, deviates %lld; cycles stage %lld eval %lld scan %lld fin %lld all %lld\n", (long long) state[3], (long long) d->pop, (long long) state[1], (long long) state[4], (long long) state[5], (long long) state[6], (long long) state[7], (long long) state[8]);
@@ -656,7 +662,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         if (st) { st->t_rank_s += nla_seconds() - t0; st->rank_sweeps += (uint64_t) sweeps; }
         t0 = nla_seconds();
         if (dev_evolve(&D, taup, tau, &t_rng)) DEVFAIL();
-        if (st) { st->t_evolve_s += nla_seconds() - t0; st->t_rng_s += t_rng; ++st->generations; st->mt_words = D.words_used; }
+        if (st) { st->t_evolve_s += nla_seconds() - t0; st->t_rng_s += t_rng; ++st->generations; st->mt_words = D.words_used; st->evolve_rounds_enqueued = D.ev_rounds; st->evolve_rounds = D.ev_real; }
     }
 done:
     if (st) st->mt_words = D.words_used;
