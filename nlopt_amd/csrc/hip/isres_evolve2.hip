@@ -60,8 +60,11 @@ __global__ __launch_bounds__(256) void ev2_stage_kernel(ev2_args A)
     __shared__ int s_cnt[4], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
     const int n = A.n, ld = A.ld;
-    if (A.state[2] || A.state[10]) return;
-    const int64_t k = A.state[0] + i, kend = A.phase == 0 ? A.pop : A.survivors;
+    /* (the words of the state a kernel needs are read together at its top: every dependent round trip to memory is 1-2 us of a
+     * kernel that lasts 5-70 us and runs ~250 times per generation) */
+    const int64_t st0 = A.state[0], st2 = A.state[2], st10 = A.state[10];
+    if (st2 || st10) return;
+    const int64_t k = st0 + i, kend = A.phase == 0 ? A.pop : A.survivors;
     if (k >= kend) { if (tid == 0) A.ws_nact[i] = -1; return; }
     const int64_t rk = A.irank[k];
     int32_t *act = A.ws_act + (size_t) i * n;
@@ -112,11 +115,12 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
     __shared__ long long s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
     const int n = A.n;
-    if (A.state[2] || A.state[10]) return;
+    const int64_t st1 = A.state[1], st2 = A.state[2], st10 = A.state[10];
     const int na = A.ws_nact[i];
+    const double rho_r = A.rho[2 * A.phase], rho_a = A.rho[2 * A.phase + 1];
+    if (st2 || st10) return;
     if (na < 0) return;
-    const double sa_ = A.rho[2 * A.phase + 1];
-    const double rhoc = sa_ > 0 ? A.rho[2 * A.phase] / sa_ : 0.0;
+    const double rhoc = rho_a > 0 ? rho_r / rho_a : 0.0;
     /* predicted start: the exact start of the block + what the individuals before this one consume at least
      * (1 + 2 per mutated coordinate) + the expected redraws */
     {
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
         __syncthreads();
         if (tid == 0) {
             const long long ab = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-            s_base = A.state[1] + i + 2 * ab + (long long) floor(rhoc * (double) ab) - EVD / 2;
+            s_base = st1 + i + 2 * ab + (long long) floor(rhoc * (double) ab) - EVD / 2;
             A.ws_base[i] = s_base;
         }
         __syncthreads();
@@ -162,11 +166,15 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
             if (res != 0) continue;
             if (cur + 1 >= zwlen) { res = zw_cut ? -2 : -1; continue; }
             /* the lane's chain is serial — deviate index -> sigma' (an fp64 exp) -> the first draw inside the box -> next index — and with
-             * one wavefront per SIMD nothing hides its latency: the first draw is fetched together with the deviate of sigma', not after the exp */
-            const double zs = zw[cur], z1 = zw[cur + 1];
-            double s2 = sg[a] * exp(taup_rand + A.tau * zs);
-            if (s2 > smax[a]) s2 = smax[a];
-            const double xa = xi[a], l = lo[a], h = hi[a];
+             * one wavefront per SIMD nothing hides its latency: the seven LDS reads of a coordinate are issued together, one wait in the
+             * chain instead of three.  (Counting the draws with sigma' from v_exp_f32 and a slack around the bounds, exact expressions
+             * only for draws inside the slack, was slower — 89 us against 70 us per round: with 5 % of the lanes redrawing every wavefront
+             * goes round the draw loop twice, and the three-exit loop's mask bookkeeping costs more than the exp saves;
+             * profiles/r04_isres_chain_walk.txt.) */
+            double zs = zw[cur], z1 = zw[cur + 1], sa = sg[a], sm_ = smax[a], xa = xi[a], l = lo[a], h = hi[a];
+            asm volatile("" : "+v"(zs), "+v"(z1), "+v"(sa), "+v"(sm_), "+v"(xa), "+v"(l), "+v"(h));   /* (all seven reads issued here: the compiler would sink z1 and the bounds below the exp) */
+            double s2 = sa * exp(taup_rand + A.tau * zs);
+            if (s2 > sm_) s2 = sm_;
             int t = 1;
             double xn = xa + s2 * z1;
             while (xn < l || xn > h) {
@@ -201,8 +209,10 @@ __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
 {
     extern __shared__ int16_t sE[];                            /* EVM x EVD */
     const int tid = threadIdx.x;
-    if (A.state[2] || A.state[10]) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing: its write kernel idles */
-    const int64_t k0 = ev2_uniform64(A.state[0]), kend = A.phase == 0 ? A.pop : A.survivors;
+    const int64_t st0 = A.state[0], st1 = A.state[1], st2 = A.state[2], st10 = A.state[10], st11 = A.state[11];
+    const double rho_r = A.rho[2 * A.phase], rho_a = A.rho[2 * A.phase + 1];
+    if (st2 || st10) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing: its write kernel idles */
+    const int64_t k0 = ev2_uniform64(st0), kend = A.phase == 0 ? A.pop : A.survivors;
     if (k0 >= kend) { if (tid == 0) A.state[9] = 0; return; }
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.E);            /* (E is 256-byte aligned in the workspace) */
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
         for (int q = 0; q < EVM * EVD / 8 / 1024; ++q) dst[q * 1024 + tid] = src[q * 1024 + tid];
     }
     static_assert(EVM == 256 && EVD == 256 && (EVM * EVD / 8) % 1024 == 0, "the chain kernel holds the block in four registers per lane, a row in 8 bytes per lane");
-    const long long pos0 = ev2_uniform64(A.state[1]);
+    const long long pos0 = ev2_uniform64(st1);
     const int OUT = 0x40000000;                                /* a window origin no start of this block can be within EVD of */
     int na_v[4], b_v[4], st_v[4];
     if (tid < 64) {
@@ -275,15 +285,15 @@ done:
     A.state[0] = k0 + r;
     A.state[1] = pos0 + pos;
     A.state[9] = r;
-    A.state[11] += 1;
+    A.state[11] = st11 + 1;
     if (elast == -2) A.state[2] = 1;
     else if (r == 0) A.state[10] = 1;                           /* not even the exactly-started first individual resolved: serial fallback */
 #ifdef NLA_EV2_REASONS                                          /* development build (NLOPT_AMD_VARIANT="reasons:-DNLA_EV2_REASONS"): what ended the walks; isres_driver.c prints it per phase */
     A.state[3] += elast == -10; A.state[4] += elast == -11; A.state[5] += elast == -1; A.state[6] += elast == 0; A.state[7] += r;
     { long long a2 = 0; for (int i = 0; i < r; ++i) a2 += A.ws_nact[i]; A.state[13] += a2 != asum; A.state[15] += a2 - asum; }
 #endif
-    A.rho[2 * A.phase] = 0.9 * A.rho[2 * A.phase] + (double) rsum;
-    A.rho[2 * A.phase + 1] = 0.9 * A.rho[2 * A.phase + 1] + (double) asum;
+    A.rho[2 * A.phase] = 0.9 * rho_r + (double) rsum;
+    A.rho[2 * A.phase + 1] = 0.9 * rho_a + (double) asum;
 }
 
 /* ---- write ------------------------------------------------------------------------------------------------------- */
@@ -293,10 +303,11 @@ __global__ __launch_bounds__(64) void ev2_write_kernel(ev2_args A)
     const int lane = threadIdx.x, i = blockIdx.x;
     const int n = A.n, ld = A.ld;
     /* state[9] / [12] were written by the chain kernel of this round; a round that was skipped leaves state[9] = 0 */
-    if (i >= A.state[9]) return;
-    const int64_t k = A.state[12] + i, rk = A.irank[k];
+    const int64_t st9 = A.state[9], st12 = A.state[12];
     const int na = A.ws_nact[i];
-    const int64_t start = A.ws_start[i];
+    const int64_t start = A.ws_start[i], wbase = A.ws_base[i];
+    if (i >= st9) return;
+    const int64_t k = st12 + i, rk = A.irank[k];
     double *xi = sm, *sg = sm + n, *lo = sm + 2 * n, *hi = sm + 3 * n, *smax = sm + 4 * n, *xo = sm + 5 * n, *so = sm + 6 * n, *zw = sm + 7 * n;
     const double sqn = sqrt((double) n);
     const int32_t *act = A.ws_act + (size_t) i * n;
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(64) void ev2_write_kernel(ev2_args A)
     {
         /* the exact start is candidate dtrue of the scan's window: its lane left the redraw count before every chunk in T */
         const double ALPHA = 0.2;
-        const int dtrue = (int) (start - A.ws_base[i]);
+        const int dtrue = (int) (start - wbase);
         const int chunk = (na + 63) >> 6;
         const int a0 = lane * chunk < na ? lane * chunk : na, a1 = a0 + chunk < na ? a0 + chunk : na;
         const double taup_rand = A.taup * zw[0];
