@@ -259,6 +259,12 @@ int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, c
                           const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
                           const double *lb, const double *ub, double *fT_ring, double *fM_ring,
                           nla_crs_slot_status *status, void *stream);
+/* the same with a doorbell for a spinning host: status and bell in pinned host memory, bell_count a zeroed device word */
+int nla_k_crs_finish_args_bell(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                          const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                          const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
+                          const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                          nla_crs_slot_status *status, uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *stream);
 int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
                           const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *stream);
 /* nla_k_crs_commit_args + nla_k_crs_advance_args in ONE launch: the ncommit (<= 16) staged commits — distinct rows, none of their

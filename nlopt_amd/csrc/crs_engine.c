@@ -70,6 +70,9 @@ struct nla_crs_hip_engine {
     unsigned pass_no; int timed;
     int uncached;                  /* TX / TM / ctrl are uncached memory (the chain kernel may run) */
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
+    int doorbell;                  /* ... and rings a word there when the last record is visible: the host spins on it instead of sleeping in a
+                                    * stream synchronisation ("amd_doorbell", default 1) */
+    uint32_t *h_bell, *d_bellcount, bell_seq;
     /* device-resolved windows (hip/crs_chain.hip): control block, the walk's lists when they do not fit the kernel arguments,
      * what every slot took from where (pinned, written by the kernel) */
     void *d_ctrl;
@@ -150,7 +153,7 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_up); nla_dev_free(e->d_tout); nla_dev_free(e->d_status);
     nla_dev_free(e->d_list); nla_host_free(e->h_list); nla_host_free(e->h_fTM);
     nla_dev_free(e->d_Wf); nla_host_free(e->h_fwcnt); nla_host_free(e->h_fwrec);
-    nla_host_free(e->h_up); nla_host_free(e->h_status);
+    nla_host_free(e->h_up); nla_host_free(e->h_status); nla_host_free(e->h_bell); nla_dev_free(e->d_bellcount);
     nla_dev_free(e->d_csend); nla_dev_free(e->d_crecv); nla_dev_free(e->d_gsend); nla_dev_free(e->d_grecv); nla_host_free(e->h_g);
     nla_event_destroy(e->ev0); nla_event_destroy(e->ev1);
     if (e->rng != e->main) nla_stream_destroy(e->rng);
@@ -241,9 +244,12 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         e->h_fwrec = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX * CHAIN_FWCAP);
     }
     e->direct_status = !NLA_DBG_ENV("NLA_CRS_COPY_STATUS");
+    e->h_bell = (uint32_t *) nla_host_malloc(64);
+    e->d_bellcount = (uint32_t *) nla_dev_malloc(64);
+    e->doorbell = 1;
     e->force_upload = NLA_DBG_ENV("NLA_CRS_UPLOAD") != NULL;
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
-        !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->ev0 || !e->ev1 ||
+        !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->h_bell || !e->d_bellcount || !e->ev0 || !e->ev1 ||
         (e->uncached && obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
     if (e->sharded) {
         e->d_csend = (double *) nla_dev_malloc(sizeof(double) * (2 * KCAP * (size_t) e->colper + 2));
@@ -256,6 +262,8 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
             nla_memset(e->d_csend, 0, sizeof(double) * (2 * KCAP * (size_t) e->colper + 2), e->main)) goto fail;
     }
     /* the slice's bounds (the whole vectors in a single-process run); pad entries are zero */
+    *e->h_bell = 0;
+    if (nla_memset(e->d_bellcount, 0, 64, e->main)) goto fail;
     if ((e->d_ctrl && nla_memset(e->d_ctrl, 0, nla_crs_chain_ctrl_bytes(CHAIN_KMAX, CHAIN_KMAX), e->main)) ||
         nla_memset(e->d_lb, 0, sizeof(double) * (size_t) e->ld, e->main) || nla_memset(e->d_ub, 0, sizeof(double) * (size_t) e->ld, e->main) ||
         nla_memcpy_h2d(e->d_lb, lb + e->c0, sizeof(double) * (size_t) e->nc, e->main) ||
@@ -509,6 +517,24 @@ static int flush_commits(nla_crs_hip_engine *e)
     return 0;
 }
 
+/* spin until the finish kernel's doorbell shows `seq` (1: it did not within 20 ms — the caller synchronises the stream instead) */
+static int bell_wait(nla_crs_hip_engine *e, uint32_t seq)
+{
+    unsigned spins = 0;
+    double t0 = 0;
+    while (__atomic_load_n(e->h_bell, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((++spins & 4095u) == 0) {
+            const double t = nla_seconds();
+            if (t0 == 0) t0 = t;
+            else if (t - t0 > 0.02) return 1;
+        }
+    }
+    return 0;
+}
+
 static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from, int64_t i0, const int64_t *W, int nW,
                       nla_crs_slot_status *status)
 {
@@ -572,6 +598,17 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         CK(e, nla_k_crs_advance_args(n, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, W, nW,
                                      t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         EVREC(e->ev1);
+        if (e->direct_status && e->doorbell) {
+            /* the finish kernel writes the K records straight into the pinned host buffer and rings: the pass is over for the host
+             * when the bell shows this pass's number — no copy-back, no stream synchronisation (its wake-up is a third of a 30 us pass
+             * at n = 512); a bell that does not come within 20 ms falls back to the synchronisation, which reports what happened */
+            const uint32_t seq = ++e->bell_seq ? e->bell_seq : ++e->bell_seq;
+            CK(e, nla_k_crs_finish_args_bell(OBJK(e), n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
+                                             t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->h_status, e->d_bellcount,
+                                             e->h_bell, seq, e->main));
+            if (bell_wait(e, seq)) CK(e, nla_stream_sync(e->main));
+            goto have_status;
+        }
         CK(e, nla_k_crs_finish_args(OBJK(e), n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                                     t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM,
                                     e->direct_status ? e->h_status : e->d_status, e->main));
@@ -785,6 +822,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         if (shard) { pb->forward = 0; pb->comm = comm; }
         *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
         if (*eout) (*eout)->fuse_commit = !opt || nlopt_get_param(opt, "amd_fuse_commit", 1) != 0;
+        if (*eout) (*eout)->doorbell = !opt || nlopt_get_param(opt, "amd_doorbell", 1) != 0;
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
     if (opt && nlopt_amd_comm_world(opt->comm) > 1) {

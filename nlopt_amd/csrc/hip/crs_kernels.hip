@@ -352,7 +352,8 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
     const uint32_t *__restrict__ words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
     const int32_t *__restrict__ t_in, const int32_t *__restrict__ t_out, int slot_mask,
     const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ fT_ring,
-    double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status, const crs_lists L, double sign)
+    double *__restrict__ fM_ring, nla_crs_slot_status *__restrict__ status, const crs_lists L, double sign,
+    uint32_t *__restrict__ bell_count, uint32_t *__restrict__ bell, uint32_t bell_seq)
 {
     __shared__ double scratch[2 * NLA_FIN_WAVES];
     const int tid = threadIdx.x;
@@ -392,6 +393,16 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
             } else if (t1 == n && OBJ >= 0) f = fM_ring[q];
         }
         if (tid == 0) status[a].fM = f;
+    }
+    /* the doorbell (bell != NULL: status is pinned host memory and the host is spinning on *bell instead of sleeping in a stream
+     * synchronisation, whose wake-up costs more than this kernel at small n): every workgroup's thread 0 — the one that wrote its
+     * part of a status record — makes it visible system-wide and counts itself; the last one resets the count and rings */
+    if (bell && tid == 0) {
+        __threadfence_system();
+        if (atomicAdd(bell_count, 1u) == gridDim.x - 1u) {
+            atomicExch(bell_count, 0u);
+            __hip_atomic_store(bell, bell_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -621,7 +632,8 @@ static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0
                              const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                              const int32_t *t_in, const int32_t *t_out, int slot_mask,
                              const double *lb, const double *ub, double *fT_ring, double *fM_ring,
-                             nla_crs_slot_status *status, const crs_lists &L, void *stream);
+                             nla_crs_slot_status *status, const crs_lists &L, void *stream, uint32_t *bell_count = nullptr,
+                             uint32_t *bell = nullptr, uint32_t bell_seq = 0);
 extern "C" int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
                                 const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                                 const int32_t *t_in, const int32_t *t_out, int slot_mask,
@@ -647,11 +659,27 @@ extern "C" int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, in
     return crs_finish_launch(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, nullptr, t_out, slot_mask, lb, ub, fT_ring,
                              fM_ring, status, L, stream);
 }
+/* ... and with the doorbell: `status` and `bell` are pinned host memory, `bell_count` a zeroed device word; the last workgroup of
+ * the launch stores bell_seq into *bell after every status record is visible to the host (crs_engine.c spins on it) */
+extern "C" int nla_k_crs_finish_args_bell(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
+                                          const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
+                                          const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
+                                          const double *lb, const double *ub, double *fT_ring, double *fM_ring,
+                                          nla_crs_slot_status *status, uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *stream)
+{
+    if (K > NLA_KA_MAX || !bell_count || !bell) return (int) hipErrorInvalidValue;
+    crs_lists L;
+    L.inl = 1;
+    for (int a = 0; a < K; ++a) L.t_in[a] = h_t_in[a];
+    return crs_finish_launch(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, nullptr, t_out, slot_mask, lb, ub, fT_ring,
+                             fM_ring, status, L, stream, bell_count, bell, bell_seq);
+}
 static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM,
                              const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                              const int32_t *t_in, const int32_t *t_out, int slot_mask,
                              const double *lb, const double *ub, double *fT_ring, double *fM_ring,
-                             nla_crs_slot_status *status, const crs_lists &L, void *stream)
+                             nla_crs_slot_status *status, const crs_lists &L, void *stream, uint32_t *bell_count, uint32_t *bell,
+                             uint32_t bell_seq)
 {
     if (K <= 0) return 0;
     const dim3 grid((unsigned) (2 * K)), block(NLA_FIN_WAVES * 64);
@@ -659,13 +687,13 @@ static int crs_finish_launch(int obj, int n, int ld, const double *X, int64_t i0
     const double sign = nla_obj_sign(&obj);
     if (obj == -2) {
         hipLaunchKernelGGL((crs_finish_kernel<-2>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
-                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign);
+                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign, bell_count, bell, bell_seq);
     } else if (obj < 0) {
         hipLaunchKernelGGL((crs_finish_kernel<-1>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks,
-                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign);
+                           first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign, bell_count, bell, bell_seq);
     } else {
 #define CALL(O) hipLaunchKernelGGL((crs_finish_kernel<O>), grid, block, 0, st, n, ld, X, i0, TX, TM, words_ring, ring_blocks, \
-                                   first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign)
+                                   first_block, K, t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, L, sign, bell_count, bell, bell_seq)
         NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     }

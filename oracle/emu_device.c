@@ -809,6 +809,17 @@ int nla_k_crs_finish_args(int obj, int n, int ld, const double *X, int64_t i0, c
     EMU_LAUNCH();
     return nla_k_crs_finish(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, h_t_in, t_out, slot_mask, lb, ub, fT_ring, fM_ring, status, st);
 }
+int nla_k_crs_finish_args_bell(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
+                               uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *h_t_in, const int32_t *t_out, int slot_mask,
+                               const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status,
+                               uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *st)
+{
+    const int rc = nla_k_crs_finish_args(obj, n, ld, X, i0, TX, TM, words_ring, ring_blocks, first_block, K, h_t_in, t_out, slot_mask, lb, ub,
+                                         fT_ring, fM_ring, status, st);
+    (void) bell_count;
+    if (!rc) __atomic_store_n(bell, bell_seq, __ATOMIC_RELEASE);
+    return rc;
+}
 int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *slot, const int32_t *kind,
                      const int64_t *row, void *st)
 {
