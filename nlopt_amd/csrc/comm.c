@@ -75,7 +75,8 @@ typedef struct {
     uint64_t slot;
     _Atomic uint32_t arrived, generation;
     _Atomic uint32_t attached, detached;
-    char pad[64 - 40];
+    _Atomic uint32_t aborted;           /* nla_comm_abort: a rank gave up in the middle of a job; every barrier from now on fails */
+    char pad[64 - 44];
 } shm_header;
 #define SHM_MAGIC 0x6e6c6173u
 typedef struct {
@@ -138,6 +139,7 @@ static int shm_barrier(nlopt_amd_comm *c)
     const uint32_t g = atomic_load_explicit(&h->generation, memory_order_acquire);
     unsigned spins = 0;
     struct timespec t0, t1;
+    if (atomic_load_explicit(&h->aborted, memory_order_acquire)) { snprintf(c->err, sizeof c->err, "shm transport: a rank aborted the job"); return -1; }
     if (atomic_fetch_add_explicit(&h->arrived, 1, memory_order_acq_rel) + 1 == (uint32_t) c->world) {
         atomic_store_explicit(&h->arrived, 0, memory_order_relaxed);
         atomic_store_explicit(&h->generation, g + 1, memory_order_release);
@@ -146,6 +148,7 @@ static int shm_barrier(nlopt_amd_comm *c)
     clock_gettime(CLOCK_MONOTONIC, &t0);
     while (atomic_load_explicit(&h->generation, memory_order_acquire) == g) {
         if (++spins < 2000) { __builtin_ia32_pause(); continue; }
+        if (atomic_load_explicit(&h->aborted, memory_order_acquire)) { snprintf(c->err, sizeof c->err, "shm transport: a rank aborted the job"); return -1; }
         sched_yield();
         if ((spins & 1023) == 0) {                       /* a rank that died must not hang the others for ever */
             clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -251,6 +254,15 @@ void nlopt_amd_comm_destroy(nlopt_amd_comm *c)
     free(c);
 }
 
+/* A rank that fails in the middle of a multi-rank job where it cannot say so through the job's own exchange (the device is gone, an
+ * allocation failed between two collectives) calls this before it leaves: on the shm transport every rank waiting in, or arriving at, a
+ * barrier returns an error instead of waiting for it; the RCCL and callback transports have no such channel (their peers wait for the
+ * transport's own timeout) — the per-pass error flag of the sharded CRS run (crs_engine.c) covers what can still be said in band. */
+void nla_comm_abort(nlopt_amd_comm *c)
+{
+    if (c && c->shm && c->shm->h) atomic_store_explicit(&c->shm->h->aborted, 1, memory_order_release);
+}
+
 int nlopt_amd_comm_rank(const nlopt_amd_comm *c) { return c ? c->rank : 0; }
 int nlopt_amd_comm_world(const nlopt_amd_comm *c) { return c ? c->world : 1; }
 const char *nlopt_amd_comm_error(const nlopt_amd_comm *c) { return c ? c->err : ""; }
@@ -293,6 +305,16 @@ static int need_dev(nlopt_amd_comm *c, size_t bytes)
     c->d_recv = nla_dev_malloc(c->d_cap);
     if (!c->d_send || !c->d_recv) { c->d_cap = 0; snprintf(c->err, sizeof c->err, "out of device memory for the collective staging"); return -1; }
     return 0;
+}
+
+/* Set-up time: make sure an all-gather of `bytes` per rank will not have to allocate its staging later — an allocation that fails on
+ * one rank in the middle of a job leaves the others in the collective it could not join (0 ok, -1 out of memory: say so in the
+ * set-up's agreement) */
+int nla_comm_reserve(nlopt_amd_comm *c, size_t bytes)
+{
+    if (!c || c->world <= 1 || c->rccl) return 0;
+    if (c->shm && c->shm->registered && bytes <= c->shm->slot) return 0;
+    return need_host(c, bytes);
 }
 
 /* device buffers: d_recv (world*bytes, rank-major) := all-gather of every rank's d_send (bytes).

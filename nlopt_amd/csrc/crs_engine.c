@@ -258,6 +258,11 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         e->d_grecv = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
         e->h_g = (double *) nla_host_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
         if (!e->d_csend || !e->d_crecv || !e->d_gsend || !e->d_grecv || !e->h_g) goto fail;
+        {   /* the communicator's staging for the largest exchange of the run — a pass's candidates, or a rank's share of the initial
+             * values — now, while a failure can still be agreed on (the set-up's "ready" exchange), not inside a collective */
+            size_t big = sizeof(double) * (2 * KCAP * (size_t) e->colper + 2), ini = sizeof(double) * (size_t) ((e->N - 1 + e->world - 1) / e->world);
+            if (nla_comm_reserve(comm, big > ini ? big : ini)) goto fail;
+        }
         if (nla_memset(e->d_gsend, 0, sizeof(double) * (size_t) e->colper, e->main) ||
             nla_memset(e->d_csend, 0, sizeof(double) * (2 * KCAP * (size_t) e->colper + 2), e->main)) goto fail;
     }
@@ -305,11 +310,16 @@ static void dump_init(nla_crs_hip_engine *e, size_t nwords)
 /* a whole point from its column slices: every rank contributes the nc coordinates it holds of the row at `src`, all-gathered */
 static int gather_point(nla_crs_hip_engine *e, const double *src, double *x)
 {
-    CK(e, nla_memcpy_d2d(e->d_gsend, src, sizeof(double) * (size_t) e->nc, e->main));
-    if (nla_comm_allgather_dev(e->comm, e->d_gsend, e->d_grecv, sizeof(double) * (size_t) e->colper, e->main))
+    /* (a rank that fails here cannot tell the others in band — they are waiting in this very exchange: nla_comm_abort) */
+#define GP(call, what) do { int rc_ = (call); if (rc_) { snprintf(e->err, sizeof e->err, "%s failed: %s", what, nla_dev_error_string(rc_)); nla_comm_abort(e->comm); return -1; } } while (0)
+    GP(nla_memcpy_d2d(e->d_gsend, src, sizeof(double) * (size_t) e->nc, e->main), "gather_point: D2D");
+    if (nla_comm_allgather_dev(e->comm, e->d_gsend, e->d_grecv, sizeof(double) * (size_t) e->colper, e->main)) {
+        nla_comm_abort(e->comm);
         FAIL(e, "all-gather of a point's slices failed: %s", nlopt_amd_comm_error(e->comm));
-    CK(e, nla_memcpy_d2h(e->h_g, e->d_grecv, sizeof(double) * (size_t) e->colper * (size_t) e->world, e->main));
-    CK(e, nla_stream_sync(e->main));
+    }
+    GP(nla_memcpy_d2h(e->h_g, e->d_grecv, sizeof(double) * (size_t) e->colper * (size_t) e->world, e->main), "gather_point: D2H");
+    GP(nla_stream_sync(e->main), "gather_point: synchronisation");
+#undef GP
     for (int r = 0; r < e->world; ++r) {
         const int c0 = r * e->colper, cnt = e->n - c0 < e->colper ? e->n - c0 : e->colper;
         memcpy(x + c0, e->h_g + (size_t) r * (size_t) e->colper, sizeof(double) * (size_t) cnt);
@@ -333,7 +343,7 @@ static int op_init_population_sharded(nla_crs_hip_engine *e, const double *x0, d
     double *h_row = (double *) calloc((size_t) (e->ld > n ? e->ld : n), sizeof(double));
     double *d_lbf = NULL, *d_ubf = NULL, *d_x0 = NULL;                 /* whole-row bounds and starting guess (evaluation only) */
     const double *lbh = NULL, *ubh = NULL;
-    int rc = -1;
+    int rc = -1, stage_ok = 0;
     if (e->world > ROWPAD) { snprintf(e->err, sizeof e->err, "more than %d ranks are not supported", ROWPAD); goto out; }   /* (the same on every rank) */
     if (rows_per_chunk < 1) rows_per_chunk = 1;
     if (rows_per_chunk > e->N - 1) rows_per_chunk = e->N - 1 > 0 ? e->N - 1 : 1;
@@ -350,28 +360,42 @@ static int op_init_population_sharded(nla_crs_hip_engine *e, const double *x0, d
     }
     lbh = e->h_lb_full; ubh = e->h_ub_full;
     if (nla_memcpy_h2d(d_lbf, lbh, sizeof(double) * (size_t) n, e->main) || nla_memcpy_h2d(d_ubf, ubh, sizeof(double) * (size_t) n, e->main) ||
-        nla_memcpy_h2d(d_x0, x0, sizeof(double) * (size_t) n, e->main)) { snprintf(e->err, sizeof e->err, "H2D (init) failed"); goto out; }
+        nla_memcpy_h2d(d_x0, x0, sizeof(double) * (size_t) n, e->main)) { snprintf(e->err, sizeof e->err, "H2D (init) failed"); goto agree2; }
     /* row 0 = the caller's starting guess (crs.c:204): its slice (pad zero), and its value from the whole point */
     memcpy(h_row, x0 + e->c0, sizeof(double) * (size_t) e->nc);
     if (nla_memcpy_h2d(e->d_X, h_row, sizeof(double) * (size_t) e->ld, e->main) ||
-        nla_k_eval(OBJK(e), n, n, d_x0, 1, e->d_F, e->main) || nla_stream_sync(e->main)) { snprintf(e->err, sizeof e->err, "row 0 failed"); goto out; }
+        nla_k_eval(OBJK(e), n, n, d_x0, 1, e->d_F, e->main) || nla_stream_sync(e->main)) { snprintf(e->err, sizeof e->err, "row 0 failed"); goto agree2; }
     for (r0 = 1; r0 < e->N; r0 += rows_per_chunk) {
         const int64_t nr = e->N - r0 < rows_per_chunk ? e->N - r0 : rows_per_chunk;
         const int64_t lo = first > r0 ? first : r0, hi = last < r0 + nr ? last : r0 + nr;       /* this rank's rows inside the chunk */
-        if (r0 > 1 && (nla_event_record(ev, e->main) || nla_stream_wait_event(e->rng, ev))) { snprintf(e->err, sizeof e->err, "event failed"); goto out; }
-        if (nla_mtstream_fill(e->mts, wpr * (uint64_t) (r0 - 1), wpr * (uint64_t) nr, e->d_initwords)) { snprintf(e->err, sizeof e->err, "MT stream fill failed (init)"); goto out; }
-        if (nla_event_record(ev, e->rng) || nla_stream_wait_event(e->main, ev)) { snprintf(e->err, sizeof e->err, "event failed"); goto out; }
+        if (r0 > 1 && (nla_event_record(ev, e->main) || nla_stream_wait_event(e->rng, ev))) { snprintf(e->err, sizeof e->err, "event failed"); goto agree2; }
+        if (nla_mtstream_fill(e->mts, wpr * (uint64_t) (r0 - 1), wpr * (uint64_t) nr, e->d_initwords)) { snprintf(e->err, sizeof e->err, "MT stream fill failed (init)"); goto agree2; }
+        if (nla_event_record(ev, e->rng) || nla_stream_wait_event(e->main, ev)) { snprintf(e->err, sizeof e->err, "event failed"); goto agree2; }
         if (nla_k_crs_sh_init_rows(n, e->c0, e->nc, e->ld, e->d_lb, e->d_ub, e->d_initwords, r0, nr, e->d_X, e->main) ||
             (hi > lo && nla_k_crs_init_rows(OBJK(e), n, n, d_lbf, d_ubf, e->d_initwords + (size_t) (lo - r0) * (size_t) wpr, lo, hi - lo, NULL, e->d_F, e->main))) {
-            snprintf(e->err, sizeof e->err, "init kernel launch failed"); goto out;
+            snprintf(e->err, sizeof e->err, "init kernel launch failed"); goto agree2;
         }
+    }
+    stage_ok = 1;
+agree2:
+    /* every rank arrives here, whatever happened to it since the first agreement (H2D copies, fills, launches): all of them go
+     * into the all-gather of the values, or none — a rank that failed alone would leave the others waiting in it */
+    if (!nla_comm_agree_ready(e->comm, stage_ok) || !stage_ok) {
+        if (stage_ok) snprintf(e->err, sizeof e->err, "another rank failed while it initialised its slice of the population");
+        goto out;
     }
     nla_event_record(ev_ag0, e->main);
     if (nla_comm_allgather_dev(e->comm, e->d_F + first, e->d_F + 1, sizeof(double) * (size_t) per, e->main)) {
-        snprintf(e->err, sizeof e->err, "all-gather of the initial values failed: %s", nlopt_amd_comm_error(e->comm)); goto out;
+        snprintf(e->err, sizeof e->err, "all-gather of the initial values failed: %s", nlopt_amd_comm_error(e->comm)); nla_comm_abort(e->comm); goto out;
     }
     nla_event_record(ev_ag1, e->main);
-    if (nla_memcpy_d2h(F, e->d_F, sizeof(double) * (size_t) e->N, e->main) || nla_stream_sync(e->main)) { snprintf(e->err, sizeof e->err, "D2H F failed"); goto out; }
+    {   /* ... and all of them leave the initialisation together */
+        const int mine = !(nla_memcpy_d2h(F, e->d_F, sizeof(double) * (size_t) e->N, e->main) || nla_stream_sync(e->main));
+        if (!nla_comm_agree_ready(e->comm, mine) || !mine) {
+            snprintf(e->err, sizeof e->err, "%s", mine ? "another rank could not read back the initial values" : "D2H F failed");
+            goto out;
+        }
+    }
     if (e->stats) {
         e->stats->t_allgather_ms += (double) nla_event_elapsed_ms(ev_ag0, ev_ag1);
         e->stats->allgather_bytes += (uint64_t) e->world * (uint64_t) per * sizeof(double);
@@ -557,20 +581,39 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         /* one rank of a column-sharded run: the same pass on the slice; the slices of the candidates that completed (trial point and
          * mutation) are all-gathered and every rank evaluates the assembled points — identical status records on every rank */
         const int ncol = (e->ld % 2 == 0 && e->nc % 2 != 0) ? e->nc + 1 : e->nc;      /* (an even count lets the gather take coordinate pairs; the pad column is zero) */
-        if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, NULL, NULL)) return -1;
+        /* A failure on this rank alone must not leave the others waiting in the all-gather: it is REMEMBERED, the rank still packs
+         * (whatever its slots hold) and joins the exchange with the value 2 in its first flag word, and every rank — this one
+         * included — sees it in record K and leaves the pass with the same error.  Only a rank that cannot even pack and send gives
+         * up out of band (nla_comm_abort: the shm transport's barriers fail; the other transports have no such channel). */
+        int lerr = 0;
+#define SOFT(call) do { if (!lerr) { int rc_ = (call); if (rc_) { lerr = 1; snprintf(e->err, sizeof e->err, "%.160s failed: %s", #call, nla_dev_error_string(rc_)); } } } while (0)
+#define HARD(call) do { int rc_ = (call); if (rc_) { if (!lerr) snprintf(e->err, sizeof e->err, "%.160s failed: %s", #call, nla_dev_error_string(rc_)); nla_comm_abort(e->comm); return -1; } } while (0)
+        if (upload_and_commit(e, W, nW, t_in, K, &d_W, &d_tin, NULL, NULL)) { lerr = 1; d_tin = e->d_tout; }      /* (message set; any device array of K ints serves the pack) */
+        if (nla_dbg_int("NLA_CRS_FAIL_RANK", -1) == e->rank && (int64_t) e->pass_no == (int64_t) nla_dbg_int("NLA_CRS_FAIL_PASS", -1)) {
+            lerr = 1; snprintf(e->err, sizeof e->err, "injected failure (NLA_CRS_FAIL_RANK / NLA_CRS_FAIL_PASS)");
+        }
         EVREC(e->ev0);
-        CK(e, nla_k_crs_advance_cols(n, ncol, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
-                                     d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
+        SOFT(nla_k_crs_advance_cols(n, ncol, e->ld, e->d_X, i0, e->d_jn, e->d_pos, e->d_last, ring, first_block, K, d_W, nW,
+                                    d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->variant, e->main));
         EVREC(e->ev1);
-        CK(e, nla_k_crs_sh_mutate_pack(n, e->c0, e->nc, e->ld, e->colper, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
-                                       d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_csend, e->stop_in[0], e->stop_in[1], e->main));
-        if (nla_comm_allgather_dev(e->comm, e->d_csend, e->d_crecv, sizeof(double) * (2 * (size_t) K * (size_t) e->colper + 2), e->main))
-            FAIL(e, "all-gather of the candidates failed: %s", nlopt_amd_comm_error(e->comm));
-        CK(e, nla_k_crs_sh_eval(OBJK(e), n, e->colper, first_block, K, d_tin, e->d_tout, KCAP - 1, e->d_crecv, e->world, e->d_fT, e->d_fM, e->d_status, e->main));
+        HARD(nla_k_crs_sh_mutate_pack(n, e->c0, e->nc, e->ld, e->colper, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
+                                      d_tin, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_csend, lerr ? 2 : e->stop_in[0], e->stop_in[1], e->main));
+        if (nla_comm_allgather_dev(e->comm, e->d_csend, e->d_crecv, sizeof(double) * (2 * (size_t) K * (size_t) e->colper + 2), e->main)) {
+            nla_comm_abort(e->comm);
+            if (!lerr) snprintf(e->err, sizeof e->err, "all-gather of the candidates failed: %s", nlopt_amd_comm_error(e->comm));
+            return -1;
+        }
+        HARD(nla_k_crs_sh_eval(OBJK(e), n, e->colper, first_block, K, d_tin, e->d_tout, KCAP - 1, e->d_crecv, e->world, e->d_fT, e->d_fM, e->d_status, e->main));
         if (e->stats) e->stats->allgather_bytes += (uint64_t) e->world * (2 * (uint64_t) K * (uint64_t) e->colper + 2) * sizeof(double);
-        /* the K status records and, behind them, the ranks' agreed stop flags */
-        CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * ((size_t) K + 1), e->main));
-        CK(e, nla_stream_sync(e->main));
+        /* the K status records and, behind them, the ranks' agreed stop flags (and whether any rank failed) */
+        HARD(nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * ((size_t) K + 1), e->main));
+        HARD(nla_stream_sync(e->main));
+#undef SOFT
+#undef HARD
+        if (e->h_status[K].t != 0) {
+            if (!lerr) snprintf(e->err, sizeof e->err, "another rank failed in the middle of a sharded pass");
+            return -1;
+        }
         e->stop_out[0] = e->h_status[K].fT != 0.; e->stop_out[1] = e->h_status[K].fM != 0.;
         goto have_status;
     }
@@ -763,7 +806,7 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
 }
 
 static const char *op_last_error(void *ve) { return ((nla_crs_hip_engine *) ve)->err; }
-static void op_stop_flags_in(void *ve, int forced, int timed) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; e->stop_in[0] = forced; e->stop_in[1] = timed; }
+static void op_stop_flags_in(void *ve, int forced, int timed) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; e->stop_in[0] = forced != 0; e->stop_in[1] = timed != 0; }
 static void op_stop_flags_out(void *ve, int *forced, int *timed) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; *forced = e->stop_out[0]; *timed = e->stop_out[1]; }
 
 static int op_reset_slot(void *ve, uint64_t block)

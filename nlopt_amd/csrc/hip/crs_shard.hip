@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void crs_sh_init_rows_kernel(int n, int c0, in
 /* for every slot of the window that became complete in this pass: TM[q] = the slice of the local mutation that would follow the
  * trial's rejection (crs.c:139-146; w from the NEXT stream block at the slice's global coordinates), and the slices of both points
  * packed for the all-gather: SEND[(2a) * colper + i] = T_i, SEND[(2a+1) * colper + i] = M_i (i < nc; untouched for other slots);
- * SEND[2 K colper], [+1] = the rank's stop flags.  A rank's block of the all-gather is 2 K colper + 2 doubles. */
+ * SEND[2 K colper], [+1] = the rank's stop flags (the first one 2 instead of 0 / 1: this rank failed in the pass).  A rank's block of the all-gather is 2 K colper + 2 doubles. */
 __global__ __launch_bounds__(256) void crs_sh_mutate_pack_kernel(
     int n, int c0, int nc, int ld, int colper, const double *__restrict__ X, int64_t i0, const double *__restrict__ TX, double *__restrict__ TM,
     const uint32_t *__restrict__ words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *__restrict__ t_in,
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void crs_sh_mutate_pack_kernel(
 
 /* f of the gathered candidates + the status records of the pass (the evaluation half of crs_finish_kernel on assembled points):
  * RECV is rank-major, rank r's block holding 2K slices of colper doubles + its two stop flags; coordinate g of a point lives in rank
- * g / colper's block.  status[K] (one record behind the window's) = the flags OR-ed over the ranks.
+ * g / colper's block.  status[K] (one record behind the window's) = the flags OR-ed over the ranks, t = 1 if a rank reported a failure.
  * The reduction is nla_block_objective<OBJ, 8> over global coordinates — the order of crs_finish_kernel / crs_chain_kernel, so f is
  * what a single-GPU run computes, bit for bit. */
 template <int OBJ>
@@ -106,11 +106,13 @@ __global__ __launch_bounds__(SH_WAVES * 64) void crs_sh_eval_kernel(
         if (blockIdx.x == 0) {                   /* record K: the ranks' stop flags OR-ed (fT: force_stop, fM: clock) */
             const size_t rank_stride = (size_t) 2 * (size_t) K * (size_t) colper + 2;
             double f0 = 0, f1 = 0;
+            int failed = 0;                      /* a rank whose first flag word is 2 failed in this pass (crs_engine.c): everyone leaves */
             for (int r = 0; r < world; ++r) {
                 if (RECV[(size_t) r * rank_stride + rank_stride - 2] != 0.) f0 = 1.;
+                if (RECV[(size_t) r * rank_stride + rank_stride - 2] == 2.) failed = 1;
                 if (RECV[(size_t) r * rank_stride + rank_stride - 1] != 0.) f1 = 1.;
             }
-            status[K].fT = f0; status[K].fM = f1; status[K].t = 0; status[K].pad = 0;
+            status[K].fT = f0; status[K].fM = f1; status[K].t = failed; status[K].pad = 0;
         }
     }
 }
@@ -134,7 +136,7 @@ extern "C" int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colpe
     if (K <= 0) return 0;
     if (nc > colper || nc > ld) return (int) hipErrorInvalidValue;
     hipLaunchKernelGGL(crs_sh_mutate_pack_kernel, dim3((unsigned) K), dim3(256), 0, (hipStream_t) stream, n, c0, nc, ld, colper, X, i0, TX, TM,
-                       words_ring, ring_blocks, first_block, K, t_in, t_out, slot_mask, lb, ub, SEND, flag_forced ? 1. : 0., flag_timed ? 1. : 0.);
+                       words_ring, ring_blocks, first_block, K, t_in, t_out, slot_mask, lb, ub, SEND, (double) flag_forced, flag_timed ? 1. : 0.);
     NLA_LAUNCH_CHECK();
     return 0;
 }

@@ -125,6 +125,8 @@ int nla_comm_allgather_dev(nlopt_amd_comm *c, const void *d_send, void *d_recv, 
 int nla_comm_allgather_host(nlopt_amd_comm *c, const void *h_send, void *h_recv, size_t bytes, void *stream);
 void nla_comm_partition(const nlopt_amd_comm *c, int64_t count, int64_t *per, int64_t *first, int64_t *mine);
 void nla_stop_view(const nla_stopping *stop, int forced, int timed, nla_stopping *view, int *force_store);
+int nla_comm_reserve(nlopt_amd_comm *c, size_t bytes);     /* set-up: staging for all-gathers of up to `bytes` per rank */
+void nla_comm_abort(nlopt_amd_comm *c);                    /* a rank leaves a multi-rank job out of band (shm transport: the others' barriers fail) */
 int nla_comm_agree_ready(nlopt_amd_comm *c, int ok);      /* end of a multi-rank set-up: 1 iff every rank is ready */
 int nla_comm_agree_same(nlopt_amd_comm *c, int ok, uint64_t fingerprint);   /* 1 ready and identical jobs, 0 some rank not ready, -1 ranks were given different jobs */
 uint64_t nla_params_fingerprint(const nlopt_opt opt);             /* every nlopt_set_param value of opt (the options that shape the pass structure / the collectives' sizes) */

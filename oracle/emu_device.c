@@ -704,7 +704,7 @@ int nla_k_crs_sh_mutate_pack(int n, int c0, int nc, int ld, int colper, const do
     EMU_LAUNCH();
     (void) st;
     if (nc > colper || nc > ld) return EMU_ERR;
-    SEND[(size_t) 2 * K * colper] = flag_forced ? 1. : 0.; SEND[(size_t) 2 * K * colper + 1] = flag_timed ? 1. : 0.;
+    SEND[(size_t) 2 * K * colper] = (double) flag_forced; SEND[(size_t) 2 * K * colper + 1] = flag_timed ? 1. : 0.;
     for (int a = 0; a < K; ++a) {
         const uint64_t block = first_block + (uint64_t) a;
         const int q = (int) (block & (uint64_t) slot_mask);
@@ -751,8 +751,13 @@ int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, c
     {
         const size_t rs = (size_t) 2 * (size_t) K * (size_t) colper + 2;
         double f0 = 0, f1 = 0;
-        for (int r = 0; r < world; ++r) { if (RECV[(size_t) r * rs + rs - 2] != 0.) f0 = 1.; if (RECV[(size_t) r * rs + rs - 1] != 0.) f1 = 1.; }
-        status[K].fT = f0; status[K].fM = f1; status[K].t = 0; status[K].pad = 0;
+        int failed = 0;
+        for (int r = 0; r < world; ++r) {
+            if (RECV[(size_t) r * rs + rs - 2] != 0.) f0 = 1.;
+            if (RECV[(size_t) r * rs + rs - 2] == 2.) failed = 1;
+            if (RECV[(size_t) r * rs + rs - 1] != 0.) f1 = 1.;
+        }
+        status[K].fT = f0; status[K].fM = f1; status[K].t = failed; status[K].pad = 0;
     }
     free(p);
     return 0;

@@ -175,6 +175,7 @@ def main():
         import gc
         L.orc_emu_live.restype = C.c_long
         base = run(0)
+        run(0)                                       # (again: the communicator's staging was allocated by the first run and stays — the count below is that of every later run)
         gc.collect()
         live0 = L.orc_emu_live()                     # (the communicator's own staging buffers live as long as it does)
         # the allocations of the failing rank's set-up = those made before the last "ready" exchange (16-byte payload, comm.c)

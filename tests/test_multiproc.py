@@ -199,6 +199,23 @@ def test_crs_column_sharded_ranks_leave_together(a):
     assert np.array_equal(res[0]["x"], res[1]["x"]) and res[0]["minf"][0] == res[1]["minf"][0]
 
 
+@pytest.mark.parametrize("world,fail_rank,transport", [(2, 1, "gloo"), (3, 0, "gloo"), (2, 0, "shm"), (3, 2, "shm")])
+def test_crs_column_sharded_rank_that_fails_in_a_pass_takes_the_others_with_it(world, fail_rank, transport):
+    """ONE rank fails in the middle of a sharded pass (injected after its set-up was agreed: debug switch of the emulated-device build).
+    It still packs and joins the pass's all-gather with the failure value in its flag word, so every rank sees it in the pass's own
+    exchange and returns NLOPT_FAILURE after the same pass — nobody is left waiting in an all-gather (this test would time out)"""
+    cfg = dict(obj="rastrigin", n=16, pop=200, seed=7, maxeval=4000, want_errmsg=1)
+    env = dict(EMU, NLA_CRS_FAIL_RANK=str(fail_rank), NLA_CRS_FAIL_PASS="6")
+    if transport == "shm":
+        env["NLA_TEST_SHM"] = "1"
+    res = run_world("gpu_crs", cfg, world=world, extra_env=env, timeout=300)
+    assert all(d["ret"][0] == -1 for d in res), [int(d["ret"][0]) for d in res]
+    assert len({int(d["nevals"][0]) for d in res}) == 1 and 200 < res[0]["nevals"][0] < 4000
+    for r, d in enumerate(res):
+        msg = str(d["errmsg"])
+        assert ("injected failure" in msg) if r == fail_rank else ("another rank failed" in msg), (r, msg)
+
+
 # ---- the RCCL transport itself with several ranks: comm.c's ncclAllGather branch over a mock librccl (oracle/mock_rccl.c) -----------
 MOCK = dict(NLA_TEST_EMU_DEVICE="1", NLA_TEST_MOCK_RCCL="1")
 
