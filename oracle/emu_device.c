@@ -620,7 +620,7 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
         if (state[2] || state[10] || first >= kend) continue;
         if (emu_forced_handover(first, phase)) { state[10] = 1; continue; }
         for (limit = first + 1; limit < stop && !emu_forced_handover(limit, phase); ++limit) { }
-        state[14] = limit;
+        state[14] = limit; state[11] += 1;
         rc = nla_k_isres_evolve(n, ld, phase, pop, survivors, zcount, taup, tau, lb, ub, z, irank, X, S, (double *) x0c, state, st);
         state[14] = 0;
         if (rc) return rc;
