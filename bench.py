@@ -502,7 +502,8 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     useful_gbs = (used * 8.0 * n * (n + 1) / (world if sharded else 1) / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
     # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) from n = 2048 on, the conservative passes below
     # (and always the conservative passes, on column slices, in a sharded job)
-    chain = n >= 2048 and os.environ.get("NLA_CRS_FORWARD", "1") != "0" and not sharded
+    fw = [kv.split("=", 1)[1] for kv in CRS_PARAMS if kv.split("=", 1)[0] == "amd_forward"]         # (--param amd_forward=0/1: the A/B switch)
+    chain = (float(fw[-1]) != 0 if fw else n >= 2048) and not sharded
     gkernel = "crs_chain_kernel" if chain else "crs_advance_kernel"
     traffic, traffic_src = pmc_traffic(gkernel) if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
     out = {
@@ -685,8 +686,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                   "rng_s_per_gen_inside_rank_and_evolve": d["t_rng_s"] / K, "rank_sweeps_per_gen": d["rank_sweeps"] / K, "evolve_rounds_per_gen": d["evolve_rounds"] / K,
                   "evolve_rounds_enqueued_per_gen": d["evolve_rounds_enqueued"] / K,
                   # isres_driver.c "amd_isres_overlap": the generator on a stream of its own beside the latency-bound kernels (the
-                  # default; NLA_ISRES_OVERLAP=0 gives the one-stream generation: 72.9 vs 65.3 ms, profiles/r03_isres_overlap_ab.txt)
-                  "generator_on_its_own_stream": os.environ.get("NLA_ISRES_OVERLAP", "1") != "0"}
+                  # default; --param amd_isres_overlap=0 gives the one-stream generation: 72.9 vs 65.3 ms, profiles/r03_isres_overlap_ab.txt)
+                  "generator_on_its_own_stream": not any(kv.replace(" ", "") in ("amd_isres_overlap=0", "amd_isres_overlap=0.0") for kv in (getattr(a, "param", []) or []))}
     else:
         t_dom = d["t_lbfgs_ms"] / 1e3
         bytes_dom = float(d["lbfgs_bytes"])

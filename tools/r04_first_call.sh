@@ -1,4 +1,6 @@
 #!/bin/bash
+# (HISTORICAL: the NLA_* environment switches this script sets exist only in -DNLA_DEBUG_SWITCHES builds since later in round 4; the
+#  product reads nlopt_set_param values instead — "amd_mlsl_prefetch"; the tiled pair-distance kernel is the only one)
 # Round 4, first GPU call: what round 3 wrote after its GPU minutes were spent.
 #  (1) the pair-distance kernel's direct bit-for-bit test, both variants (tests/test_gpu_mlsl.py, NLA_TEST_EXPERIMENTAL=1);
 #  (2) the MLSL files with the register-tiled variant forced on (NLA_MLSL_DIST2_TILED=1);
