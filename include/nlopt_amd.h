@@ -509,7 +509,6 @@ void nla_debug_uncached_stats(long out[4]);     /* [0] uncached allocations made
 void nla_dev_free_uncached(void *p);            /* back to the library's pool (per device; nothing returns to the driver while an uncached block of the device is in use; idle blocks above 1 GiB are trimmed when the last one is released — devrt.hip) */
 size_t nlopt_amd_release_device_memory(void);   /* gives every idle pooled block back to the driver (between the large runs of a long-lived process); bytes released */
 void *nla_host_malloc(size_t bytes);            /* pinned */
-void *nla_host_malloc_coherent(size_t bytes);   /* pinned and coherent: the device writes it while the host reads it (a doorbell and its records) */
 void nla_host_free(void *p);
 int nla_host_register(void *p, size_t bytes);   /* caller-owned host memory made page-locked and device-visible (the shm transport's segment); 0 = ok */
 void nla_host_unregister(void *p);

@@ -228,7 +228,7 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->d_tout = (int32_t *) nla_dev_malloc(sizeof(int32_t) * KCAP);
     e->d_status = (nla_crs_slot_status *) nla_dev_malloc(sizeof(nla_crs_slot_status) * (KCAP + 1));
     e->h_up = (char *) nla_host_malloc(UPLOAD_BYTES);
-    e->h_status = (nla_crs_slot_status *) nla_host_malloc_coherent(sizeof(nla_crs_slot_status) * (KCAP + 1));
+    e->h_status = (nla_crs_slot_status *) nla_host_malloc(sizeof(nla_crs_slot_status) * (KCAP + 1));
     e->ev0 = nla_event_create();
     e->ev1 = nla_event_create();
     if (obj == -2) {
@@ -244,7 +244,8 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         e->h_fwrec = (uint32_t *) nla_host_malloc(sizeof(uint32_t) * CHAIN_KMAX * CHAIN_FWCAP);
     }
     e->direct_status = !NLA_DBG_ENV("NLA_CRS_COPY_STATUS");
-    e->h_bell = (uint32_t *) nla_host_malloc_coherent(64);
+    e->h_bell = (uint32_t *) nla_host_malloc(64);       /* (explicitly coherent pinned memory measured equal within noise, profiles/r04_crs_doorbell_ab.txt: the
+                                                          * finish kernel's system-scope fence is what makes the records visible before the bell) */
     e->d_bellcount = (uint32_t *) nla_dev_malloc(64);
     e->doorbell = 1;
     e->force_upload = NLA_DBG_ENV("NLA_CRS_UPLOAD") != NULL;

@@ -185,14 +185,6 @@ extern "C" void *nla_host_malloc(size_t bytes)
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     return p;
 }
-/* pinned memory the device writes WHILE the host reads it (a kernel's doorbell and the records it announces, crs_engine.c): coherent
- * (fine-grained) whatever HIP_HOST_COHERENT says — the device's stores go to the host's memory, not into its L2 until the kernel ends */
-extern "C" void *nla_host_malloc_coherent(size_t bytes)
-{
-    void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocCoherent) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
-    return p;
-}
 extern "C" void nla_host_free(void *p) { if (p) (void) hipHostFree(p); }
 /* host memory the caller owns (the shm transport's segment) made page-locked and device-visible */
 extern "C" int nla_host_register(void *p, size_t bytes)

@@ -52,7 +52,6 @@ void *nla_dev_malloc_uncached(size_t bytes) { return emu_alloc(bytes); }
 void nla_dev_free_uncached(void *p) { nla_dev_free(p); }
 void nla_debug_uncached_stats(long out[4]) { out[0] = out[1] = out[2] = out[3] = 0; }
 void *nla_host_malloc(size_t bytes) { return emu_alloc(bytes); }
-void *nla_host_malloc_coherent(size_t bytes) { return emu_alloc(bytes); }
 void nla_host_free(void *p) { emu_release(p); }
 int nla_host_register(void *p, size_t bytes) { (void) p; (void) bytes; return 0; }      /* "device" memory is host memory here */
 void nla_host_unregister(void *p) { (void) p; }
