@@ -233,6 +233,16 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
                     uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                     const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
                     nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream);
+/* the same launch with flags.  NLA_CHAIN_RESOLVER: the chain (crs.c:135-156: the decisions between evaluations) is advanced by one
+ * dedicated wavefront out of registers (hip/crs_chain_resolver.h) instead of by the evaluating workgroups under a lock — one more
+ * workgroup in the grid: ticket_base then counts nla_crs_chain_tickets(n, ld, K, flags) per earlier launch.  Same outputs. */
+#define NLA_CHAIN_RESOLVER 1
+uint32_t nla_crs_chain_tickets(int n, int ld, int K, int flags);
+int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                       const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                       uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                       const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                       nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int flags, void *stream);
 
 /* replaces: the evaluation of the trial (crs.c:133) and the local mutation + its evaluation
  * (crs.c:139-146, K5) for the slots completed by the preceding nla_k_crs_advance (same window):

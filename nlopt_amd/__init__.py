@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("NLOPT_AMD_LIB") or os.path.join(_HERE, "lib", "libnlo
 GN_CRS2_LM, GN_MLSL, GD_MLSL, GN_MLSL_LDS, GD_MLSL_LDS = 19, 20, 21, 22, 23
 LD_LBFGS, LD_MMA, GN_ISRES, G_MLSL, G_MLSL_LDS, GN_ESCH = 11, 24, 35, 38, 39, 42
 LN_COBYLA = 25
+CHAIN_RESOLVER = 1          # nla_k_crs_chain_ex flag NLA_CHAIN_RESOLVER (include/nlopt_amd.h)
 # nlopt_result values
 FAILURE, INVALID_ARGS, OUT_OF_MEMORY, ROUNDOFF_LIMITED, FORCED_STOP = -1, -2, -3, -4, -5
 SUCCESS, STOPVAL_REACHED, FTOL_REACHED, XTOL_REACHED, MAXEVAL_REACHED, MAXTIME_REACHED = 1, 2, 3, 4, 5, 6
@@ -189,6 +190,9 @@ def lib():
     L.nla_dev_free_uncached.restype = None
     L.nla_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_double, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp,
                                   C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_int, vp]
+    L.nla_k_crs_chain_ex.argtypes = L.nla_k_crs_chain.argtypes[:-1] + [C.c_int, vp]       # ..., fwcap, flags, stream
+    L.nla_crs_chain_tickets.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.nla_crs_chain_tickets.restype = C.c_uint32
     L.nla_crs_chain_ctrl_bytes.argtypes = [C.c_int, C.c_int]
     L.nla_crs_chain_ctrl_bytes.restype = C.c_size_t
     L.nla_crs_chain_chunks.argtypes = [C.c_int, C.c_int]

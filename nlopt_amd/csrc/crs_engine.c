@@ -77,6 +77,7 @@ struct nla_crs_hip_engine {
      * what every slot took from where (pinned, written by the kernel) */
     void *d_ctrl;
     uint32_t ticket_base;
+    int chain_flags;               /* "amd_chain_resolver" (default 0): NLA_CHAIN_RESOLVER — the chain advanced by a dedicated wavefront */
     uint32_t *h_fwcnt, *h_fwrec;
     double *d_Wf;
     int force_upload;              /* NLA_CRS_UPLOAD: the pass's lists through the H2D copy even when they fit the kernel arguments (A/B switch) */
@@ -785,12 +786,12 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     }
     CK(e, nla_event_record(e->ev0, e->main));
     {
-        const int rc = nla_k_crs_chain(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf, nW,
-                                       on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status, e->h_fwcnt,
-                                       e->h_fwrec, fwcap, e->main);
+        const int rc = nla_k_crs_chain_ex(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf,
+                                          nW, on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status, e->h_fwcnt,
+                                          e->h_fwrec, fwcap, e->chain_flags, e->main);
         if (rc) FAIL(e, "nla_k_crs_chain failed: %s", nla_dev_error_string(rc));
     }
-    e->ticket_base += (uint32_t) nla_crs_chain_chunks(n, e->ld) * (uint32_t) K;
+    e->ticket_base += nla_crs_chain_tickets(n, e->ld, K, e->chain_flags);
     CK(e, nla_event_record(e->ev1, e->main));
     CK(e, nla_stream_sync(e->main));              /* status and records were written into pinned host memory by the kernel */
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
@@ -867,6 +868,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
         if (*eout) (*eout)->fuse_commit = !opt || nlopt_get_param(opt, "amd_fuse_commit", 1) != 0;
         if (*eout) (*eout)->doorbell = !opt || nlopt_get_param(opt, "amd_doorbell", 1) != 0;
+        if (*eout) (*eout)->chain_flags = (opt && nlopt_get_param(opt, "amd_chain_resolver", 0) != 0) ? NLA_CHAIN_RESOLVER : 0;
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
     if (opt && nlopt_amd_comm_world(opt->comm) > 1) {

@@ -54,6 +54,7 @@
 #include "../../../include/nlopt_amd.h"
 
 #define CH_EXTRA 32                      /* accepted values that landed among the window's worst rows */
+#include <stddef.h>
 
 /* control block of one launch (device memory, zeroed before the launch except `ticket`, which only grows) */
 struct chain_ctrl {
@@ -62,6 +63,12 @@ struct chain_ctrl {
 };
 /* behind the control block: fv[2K] doubles (fT, fM of every slot, for the resolver — the status records themselves may live in
  * pinned host memory), then the u32 arrays done[K], evald[K], rowstate[nW] */
+
+/* RES = 1 (launch flag NLA_CHAIN_RESOLVER): the fv area holds one 16-byte record per slot instead (crs_chain_resolver.h), evald is unused */
+#include "crs_chain_resolver.h"
+static_assert(offsetof(chain_ctrl, next) == 4 * CH_CTRL_NEXT && offsetof(chain_ctrl, halt) == 4 * CH_CTRL_HALT && offsetof(chain_ctrl, naccept) == 4 * CH_CTRL_NACCEPT &&
+              offsetof(chain_ctrl, wp) == 4 * CH_CTRL_WP && offsetof(chain_ctrl, nextra) == 4 * CH_CTRL_NEXTRA && offsetof(chain_ctrl, pk) == 4 * CH_CTRL_PK &&
+              sizeof(chain_ctrl) % 16 == 0, "crs_chain_resolver.h addresses the control block by word");
 
 #define NLA_KA_MAX 128                   /* list length that still travels as kernel arguments (2 KB of the 4 KB there are) */
 struct chain_lists { int inl; int64_t W[NLA_KA_MAX]; double Wf[NLA_KA_MAX]; };
@@ -115,7 +122,7 @@ __device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate
     }
 }
 
-template <int VEC, int U, int WAVES, int OBJ>
+template <int VEC, int U, int WAVES, int OBJ, int RES>
 __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     const chain_lists L_first_kernel_argument,  /* read through the kernarg segment below, never by name: indexing the by-value copy
                                                  * with a run-time j makes the compiler move all 1.5 KB of it to scratch memory */
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *__restrict__ Wd, const double *__restrict__ Wfd, int nW,
     int slot_mask, int chunks, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX,
     double *__restrict__ TM, chain_ctrl *__restrict__ ctrl, uint32_t ticket_base, nla_crs_slot_status *__restrict__ status,
-    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, double sign)
+    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, double sign, uint64_t resolver_timeout)
 {
     typedef const __attribute__((address_space(4))) chain_lists *kernarg_lists;
     const kernarg_lists Lk = (kernarg_lists) __builtin_amdgcn_kernarg_segment_ptr();       /* explicit arguments start at offset 0 */
@@ -145,7 +152,17 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     const double *Wf = Lk->inl ? (const double *) Lk->Wf : Wfd;
     if (threadIdx.x == 0) { s_ticket = (int) (atomicAdd(&ctrl->ticket, 1u) - ticket_base); s_nrec = 0; }
     __syncthreads();
-    const int wg = s_ticket;
+    if constexpr (RES != 0) {
+        /* the first workgroup to run is the resolver: wavefront 0 advances the chain for the whole launch, the others leave.  Every
+         * slot's workgroups hold later tickets, so whatever they wait for is running already */
+        if (s_ticket == 0) {
+            if (wave == 0)
+                chain_resolver_wave(reinterpret_cast<uint32_t *>(ctrl), reinterpret_cast<const uint64_t *>(fv), rowstate, K, nW, W, Wf, f_best, i0,
+                                    resolver_timeout);
+            return;
+        }
+    } else (void) resolver_timeout;
+    const int wg = s_ticket - RES;
     const int a = wg / chunks, chunk = wg % chunks;             /* front slot first: producers before consumers */
     const uint64_t block = first_block + (uint64_t) a;
     const uint32_t rb = (uint32_t) (block % ring_blocks);
@@ -313,11 +330,18 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         __syncthreads();
         if (tid == 0) {
             status[a].fT = fT; status[a].fM = fM; status[a].t = n; status[a].pad = 0;
-            fv[2 * a] = fT; fv[2 * a + 1] = fM;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            st_agent(&evald[a], 1u);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            chain_resolve(ctrl, evald, rowstate, fv, K, nW, W, Wf, f_best, i0);
+            if constexpr (RES != 0) {
+                /* the record IS the flag (a word is nonzero once written); TX / TM of the slot have landed (the waits above) */
+                uint64_t *rec = reinterpret_cast<uint64_t *>(fv) + 2 * (size_t) a;
+                __hip_atomic_store(rec, ch_bits_of_f(fT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rec + 1, ch_bits_of_f(fM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                fv[2 * a] = fT; fv[2 * a + 1] = fM;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                st_agent(&evald[a], 1u);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                chain_resolve(ctrl, evald, rowstate, fv, K, nW, W, Wf, f_best, i0);
+            }
         }
     }
 }
@@ -341,14 +365,19 @@ extern "C" int nla_crs_chain_chunks(int n, int ld)
     return (n + cpw - 1) / cpw;
 }
 
-extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
-                               const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
-                               uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
-                               const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
-                               nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream)
+extern "C" uint32_t nla_crs_chain_tickets(int n, int ld, int K, int flags)
+{
+    return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + ((flags & NLA_CHAIN_RESOLVER) ? 1u : 0u);
+}
+
+extern "C" int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                                  const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                                  uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                                  const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                                  nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int flags, void *stream)
 {
     if (K <= 0) return 0;
-    if (K > 256 || nW > 256 || nW < 0 || obj < 0) return (int) hipErrorInvalidValue;
+    if (K > 256 || nW > 256 || nW < 0 || obj < 0 || (flags & ~NLA_CHAIN_RESOLVER)) return (int) hipErrorInvalidValue;
     const double sign = nla_obj_sign(&obj);
     /* rows of TX / TM start on a 128-byte line: a line that holds the end of one slot's row and the start of the next one's could
      * sit in a CU's vector L1 from the read of the first and serve a stale start of the second (consumers take no L1 invalidate) */
@@ -364,14 +393,17 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
     }
     const bool vec2 = chain_vec2(n, ld);
     const int chunks = nla_crs_chain_chunks(n, ld);
-    const dim3 grid((unsigned) ((long) chunks * K));
+    const bool res = (flags & NLA_CHAIN_RESOLVER) != 0;
+    const dim3 grid((unsigned) ((long) chunks * K) + (res ? 1u : 0u));
+    const uint64_t res_timeout = 200000000ull;                /* 2 s of the 100 MHz clock without a single evaluation arriving */
     chain_ctrl *c = (chain_ctrl *) ctrl;
     /* everything but the ticket counter starts from zero */
     hipError_t e = hipMemsetAsync((char *) ctrl + sizeof(uint32_t), 0, nla_crs_chain_ctrl_bytes(K, nW) - sizeof(uint32_t), st);
     if (e != hipSuccess) return (int) e;
-#define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
+#define CHAIN_R(VEC, UU, WV, O, R) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O, R>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
         pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
-        fwcnt, fwrec, fwcap, sign)
+        fwcnt, fwrec, fwcap, sign, res_timeout)
+#define CHAIN(VEC, UU, WV, O) do { if (res) CHAIN_R(VEC, UU, WV, O, 1); else CHAIN_R(VEC, UU, WV, O, 0); } while (0)
 #define CHAIN_SHAPE(O)                                                                   \
     if (vec2) {                                                                          \
         if (n >= 2048) CHAIN(2, 32, 8, O); else if (n >= 512) CHAIN(2, 16, 4, O); else CHAIN(2, 16, 2, O); \
@@ -381,6 +413,17 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
     NLA_OBJ_DISPATCH(obj, CHAIN_SHAPE)
 #undef CHAIN_SHAPE
 #undef CHAIN
+#undef CHAIN_R
     NLA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                               const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                               uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                               const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                               nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream)
+{
+    return nla_k_crs_chain_ex(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host,
+                              slot_mask, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, 0, stream);
 }

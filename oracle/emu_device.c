@@ -782,6 +782,17 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
                     TX, TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL, NULL);
     return 0;
 }
+/* the launch flags change who advances the chain on the device, not what comes out */
+uint32_t nla_crs_chain_tickets(int n, int ld, int K, int flags) { return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + (uint32_t) (flags & 1); }
+int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
+                       const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W,
+                       const double *Wf, int nW, int w_on_host, int slot_mask, const double *lb, const double *ub, double *TX, double *TM, void *ctrl,
+                       uint32_t ticket_base, nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int flags, void *st)
+{
+    if (flags & ~1) return EMU_ERR;
+    return nla_k_crs_chain(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host, slot_mask,
+                           lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, st);
+}
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
                      uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
                      const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)

@@ -1,0 +1,53 @@
+"""STAGED (-m gpu, not collected by `pytest tests/`): the dedicated chain resolver of the device-resolved CRS2_LM windows
+(hip/crs_chain_resolver.h, launch flag NLA_CHAIN_RESOLVER, `nlopt_set_param(opt, "amd_chain_resolver", 1)`).
+
+The code was written at the end of round 4 with no GPU minutes left: hipcc builds it, the default kernels' machine code is unchanged
+(checked instruction by instruction), its decision logic is checked on the CPU (tools/chain_resolver_check.cpp through
+tests/test_host_logic.py) — but it HAS NOT RUN ON AN MI355X.  It is off by default, and these tests are kept out of the driver's
+`pytest tests/ -m gpu` run until they have been green on a device once (tests/conftest.py: collect_ignore_glob); then this file moves
+up into tests/ as it is.  Run it with      python -m pytest tests/staged/test_gpu_chain_resolver.py -q -m gpu
+(tools/r05_first_call.sh does, before anything else)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import nlopt_amd
+from test_gpu_crs import GOLD, assert_same_run, run_amd
+from test_gpu_kernels import chain_kernel_case
+
+pytestmark = pytest.mark.gpu
+RES = {"amd_forward": 1, "amd_chain_resolver": 1}
+
+
+@pytest.mark.parametrize("obj,n,N,K,i0", [("rastrigin", 10, 100, 7, 0), ("rastrigin", 10, 11, 9, 10), ("griewank", 64, 70, 60, 33),
+                                          ("ackley", 257, 600, 40, 599), ("levy", 128, 140, 130, 17), ("rosenbrock", 512, 700, 256, 3),
+                                          ("griewank", 4096, 4200, 24, 4199), ("sphere", 2, 9, 8, 4), ("griewank", 2048, 2100, 20, 77),
+                                          ("ackley", 300, 320, 30, 5), ("ackley", 9000, 9100, 6, 5), ("rastrigin", 1000, 1100, 200, 1)])
+def test_chain_kernel_with_the_dedicated_resolver(L, obj, n, N, K, i0):
+    """the launch of test_gpu_kernels.py::test_chain_kernel_resolves_the_window_like_the_sequential_statement with the chain advanced by
+    the resolver wavefront: bit-exact points, the same records of who read what from whom, the same rowstate words and counters"""
+    chain_kernel_case(L, obj, n, N, K, i0, nlopt_amd.CHAIN_RESOLVER)
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_golden_runs_with_the_resolver(name):
+    """the golden CRS2_LM cases (fixtures from the real reference) with every window resolved on the device by the resolver wavefront"""
+    g = GOLD[name]
+    kw = dict(g["kwargs"])
+    a = run_amd(g["obj"], g["n"], g["pop"], g["seed"], trace_cap=200000, params=RES, **kw)
+    p = O.run_port_crs(g["obj"], g["n"], g["pop"], g["seed"], trace_cap=200000, **kw)
+    assert a["ret"] == g["ret"] and a["nevals"] == g["nevals"] and [float(v).hex() for v in a["x"]] == g["x"]
+    assert_same_run(a, p)
+
+
+@pytest.mark.parametrize("obj,n,pop,maxeval", [("rastrigin", 512, 100000, 2500), ("rastrigin", 64, 2000, 9000), ("griewank", 4096, 4200, 1200),
+                                               ("griewank", 2048, 100000, 1500), ("levy", 300, 5000, 3000)])
+def test_the_resolver_changes_nothing_but_who_advances_the_chain(obj, n, pop, maxeval):
+    """same device, same gather and evaluation kernels: a run with the resolver is bit-identical to the run with the lock version, and
+    the device's predictions are as good (what the host could not verify and recomputed stays rare)"""
+    a = run_amd(obj, n, pop, 42, maxeval=maxeval, trace_cap=20000, params={"amd_forward": 1})
+    b = run_amd(obj, n, pop, 42, maxeval=maxeval, trace_cap=20000, params=RES)
+    assert np.array_equal(a["trace"]["row"], b["trace"]["row"]) and np.array_equal(a["trace"]["f"], b["trace"]["f"])
+    assert np.array_equal(a["x"], b["x"]) and a["minf"] == b["minf"] and a["nevals"] == b["nevals"]
+    sa, sb = a["stats"], b["stats"]
+    assert sb["slots_invalid"] <= sa["slots_invalid"] + 0.02 * sb["slots_launched"] + 4, (sa, sb)

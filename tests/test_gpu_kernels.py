@@ -174,12 +174,18 @@ class SlotStatus(C.Structure):
                                           ("griewank", 4096, 4200, 24, 4199), ("sphere", 2, 9, 8, 4), ("griewank", 2048, 2100, 20, 77),
                                           ("ackley", 300, 320, 30, 5), ("ackley", 9000, 9100, 6, 5), ("rastrigin", 1000, 1100, 200, 1)])
 def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, n, N, K, i0):
+    chain_kernel_case(L, obj, n, N, K, i0, 0)
+
+
+def chain_kernel_case(L, obj, n, N, K, i0, flags):
     """nla_k_crs_chain (hip/crs_chain.hip): one launch computes every slot of the window, evaluates it, replays the accept / reject
     chain on the window's worst rows and lets later slots read what the chain says a worst row holds at their turn.  Against the
     sequential statement orc_k_crs_chain: bit-exact trial points and mutations, f within 1e-10, the same records of what every
     slot read from where.  Small populations (N barely above n) make every slot depend on MANY earlier slots of the same launch:
     the in-kernel waiting, evaluation and resolution are what is tested.  The objective values of the rows are random, so the
-    chain has rejections, accepted mutations and values landing among the worst rows again."""
+    chain has rejections, accepted mutations and values landing among the worst rows again.
+    flags != 0: the same launch through nla_k_crs_chain_ex (NLA_CHAIN_RESOLVER = 1: the chain advanced by a dedicated wavefront,
+    hip/crs_chain_resolver.h) — same outputs, same control-block words."""
     P = O.port()
     ring = 2 * K + 3
     first = 3 * ring + 2
@@ -222,9 +228,14 @@ def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, 
     dst = DevBuf(C.sizeof(St) * K)
     dcnt, drec = DevBuf.from_array(np.zeros(K, np.uint32)), DevBuf.from_array(np.zeros(K * fwcap, np.uint32))
     for rep in range(2):                        # twice on the same control block: the ticket base carries over
-        assert L.nla_k_crs_chain(oid, n, ld, dX.ptr, i0, fbest, dj.ptr, dp.ptr, dl.ptr, dw.ptr, ring, first, K, dW.ptr, dWf.ptr, nW, 0, mask,
-                                 dlb.ptr, dub.ptr, dTX.ptr, dTM.ptr, dctrl.ptr, rep * K * L.nla_crs_chain_chunks(n, ld), dst.ptr, dcnt.ptr,
-                                 drec.ptr, fwcap, None) == 0
+        if flags:
+            assert L.nla_k_crs_chain_ex(oid, n, ld, dX.ptr, i0, fbest, dj.ptr, dp.ptr, dl.ptr, dw.ptr, ring, first, K, dW.ptr, dWf.ptr, nW, 0, mask,
+                                        dlb.ptr, dub.ptr, dTX.ptr, dTM.ptr, dctrl.ptr, rep * L.nla_crs_chain_tickets(n, ld, K, flags), dst.ptr, dcnt.ptr,
+                                        drec.ptr, fwcap, flags, None) == 0
+        else:
+            assert L.nla_k_crs_chain(oid, n, ld, dX.ptr, i0, fbest, dj.ptr, dp.ptr, dl.ptr, dw.ptr, ring, first, K, dW.ptr, dWf.ptr, nW, 0, mask,
+                                     dlb.ptr, dub.ptr, dTX.ptr, dTM.ptr, dctrl.ptr, rep * K * L.nla_crs_chain_chunks(n, ld), dst.ptr, dcnt.ptr,
+                                     drec.ptr, fwcap, None) == 0
         assert L.nla_stream_sync(None) == 0
         raw = dst.to_array(np.uint8, C.sizeof(St) * K)
         st = np.frombuffer(raw.tobytes(), dtype=[("fT", "f8"), ("fM", "f8"), ("t", "i4"), ("pad", "i4")])

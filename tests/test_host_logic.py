@@ -192,3 +192,28 @@ def test_host_callbacks_are_bit_identical_to_the_oracles():
             va, vb = fa(n, dp(x), None, None), fb(n, dp(x), None, None)
             assert va == vb == fa(n, dp(x), dp(ga), None) == fb(n, dp(x), dp(gb), None)
             assert np.array_equal(ga, gb)
+
+
+def test_dedicated_chain_resolver_takes_the_lock_versions_decisions():
+    """hip/crs_chain_resolver.h ("amd_chain_resolver": the accept / reject chain of a device-resolved window advanced by one wavefront
+    out of registers) compiled by g++ with the wavefront primitives emulated — 64 threads in lockstep, a feeder thread publishing the
+    slots' records out of order and partly only after the chain has passed an earlier slot: the rowstate words, next / pk and the final
+    counters equal the sequential statement of chain_resolve() (crs_chain.hip) for drawn windows with ties, NaNs, values landing among
+    the worst rows, new bests and lists shorter than the window; the watchdog halts a window nobody evaluates
+    (tools/chain_resolver_check.cpp).  The device's memory model is not what this checks: tests/staged/test_gpu_chain_resolver.py."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++ here")
+    out = os.path.join(root, "tools", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "chain_resolver_check.%d" % os.getpid())
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(root, "nlopt_amd", "csrc", "hip"),
+                    os.path.join(root, "tools", "chain_resolver_check.cpp"), "-o", exe], check=True)
+    try:
+        for seed in (1, 2):
+            r = subprocess.run([exe, "120", str(seed)], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and r.stdout.startswith("ok 120"), r.stdout + r.stderr
+    finally:
+        os.remove(exe)
