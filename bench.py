@@ -500,10 +500,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     slots = st1["slots_launched"] - st0["slots_launched"]
     used = st1["slots_used"] - st0["slots_used"]
     useful_gbs = (used * 8.0 * n * (n + 1) / (world if sharded else 1) / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
-    # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) from n = 2048 on, the conservative passes below
+    # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) from n = 512 on, the conservative passes below
     # (and always the conservative passes, on column slices, in a sharded job)
     fw = [kv.split("=", 1)[1] for kv in CRS_PARAMS if kv.split("=", 1)[0] == "amd_forward"]         # (--param amd_forward=0/1: the A/B switch)
-    chain = (float(fw[-1]) != 0 if fw else n >= 2048) and not sharded
+    chain = (float(fw[-1]) != 0 if fw else n >= 512) and not sharded
     gkernel = "crs_chain_kernel" if chain else "crs_advance_kernel"
     traffic, traffic_src = pmc_traffic(gkernel) if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
     out = {

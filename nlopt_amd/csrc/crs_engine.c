@@ -96,6 +96,8 @@ struct nla_crs_hip_engine {
     char err[256];
 };
 
+#define NLA_CRS_FORWARD_MIN_N 512      /* device-resolved windows (hip/crs_chain.hip) from this dimension on; conservative passes below */
+
 #define FAIL(e, ...) do { snprintf((e)->err, sizeof (e)->err, __VA_ARGS__); return -1; } while (0)
 #define CK(e, call) do { int rc_ = (call); if (rc_) FAIL(e, "%.160s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
 
@@ -834,7 +836,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         return NLOPT_INVALID_ARGS;
     }
     memset(pb, 0, sizeof *pb);
-    pb->forward = n >= 2048;
+    pb->forward = n >= NLA_CRS_FORWARD_MIN_N;
     pb->n = n; pb->N = N; pb->lb = lb; pb->ub = ub; pb->f = f; pb->f_data = f_data; pb->stop = stop;
     {
         nla_evaluator ev;
@@ -847,9 +849,12 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         pb->stats = &opt->stats;
         pb->max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
         pb->window_factor = nlopt_get_param(opt, "amd_window_factor", 0);
-        /* the device-resolved windows pay a few microseconds per block for the in-kernel chain: worth it where a trial's gather
-         * takes longer than that (n >= 2048: 33 MB per trial) */
-        pb->forward = nlopt_get_param(opt, "amd_forward", n >= 2048 ? 1 : 0) != 0;
+        /* the device-resolved windows pay for the in-kernel chain per block: ~3 us under the evaluating workgroups' lock — worth it
+         * where a trial's gather takes longer than that (n >= 2048: 33 MB per trial) — and well under 1 us with the dedicated resolver
+         * wavefront (crs_chain_resolver.h), which moves the break-even down: measured at n = 512, N = 1e5 on the MI355X
+         * (profiles/r04_crs_chain_resolver.txt): conservative passes 445 k evals/s, windows under the lock 316 k, windows with the
+         * resolver 606 k.  n = 64: conservative passes 1.18 M against 337 k under the lock — not measured with the resolver, stays */
+        pb->forward = nlopt_get_param(opt, "amd_forward", n >= NLA_CRS_FORWARD_MIN_N ? 1 : 0) != 0;
         pb->forward = nla_dbg_int("NLA_CRS_FORWARD", pb->forward);                 /* A/B switch for the bench */
         if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
     }
@@ -868,7 +873,9 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
         if (*eout) (*eout)->fuse_commit = !opt || nlopt_get_param(opt, "amd_fuse_commit", 1) != 0;
         if (*eout) (*eout)->doorbell = !opt || nlopt_get_param(opt, "amd_doorbell", 1) != 0;
-        if (*eout) (*eout)->chain_flags = (opt && nlopt_get_param(opt, "amd_chain_resolver", 0) != 0) ? NLA_CHAIN_RESOLVER : 0;
+        /* who advances the chain: the resolver wavefront where it was measured (below the round-2 threshold), the lock version from
+         * n = 2048 on — the headline configuration, where the chain is hidden behind the gather and nothing was measured yet */
+        if (*eout) (*eout)->chain_flags = (opt ? nlopt_get_param(opt, "amd_chain_resolver", n < 2048 ? 1 : 0) != 0 : n < 2048) ? NLA_CHAIN_RESOLVER : 0;
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
     if (opt && nlopt_amd_comm_world(opt->comm) > 1) {

@@ -1,12 +1,8 @@
-"""STAGED (-m gpu, not collected by `pytest tests/`): the dedicated chain resolver of the device-resolved CRS2_LM windows
-(hip/crs_chain_resolver.h, launch flag NLA_CHAIN_RESOLVER, `nlopt_set_param(opt, "amd_chain_resolver", 1)`).
-
-The code was written at the end of round 4 with no GPU minutes left: hipcc builds it, the default kernels' machine code is unchanged
-(checked instruction by instruction), its decision logic is checked on the CPU (tools/chain_resolver_check.cpp through
-tests/test_host_logic.py) — but it HAS NOT RUN ON AN MI355X.  It is off by default, and these tests are kept out of the driver's
-`pytest tests/ -m gpu` run until they have been green on a device once (tests/conftest.py: collect_ignore_glob); then this file moves
-up into tests/ as it is.  Run it with      python -m pytest tests/staged/test_gpu_chain_resolver.py -q -m gpu
-(tools/r05_first_call.sh does, before anything else)."""
+"""-m gpu: the dedicated chain resolver of the device-resolved CRS2_LM windows (hip/crs_chain_resolver.h, launch flag
+NLA_CHAIN_RESOLVER, `nlopt_set_param(opt, "amd_chain_resolver", 0 / 1)`; the default below n = 2048, where the windows are used from
+n = 512 on).  Who advances the accept / reject chain inside a launch — the evaluating workgroups under a lock, or one wavefront out of
+registers — must change nothing that leaves the launch: same trial points, same records of who read which row from whom, same
+decisions.  First run on an MI355X: profiles/r04_crs_chain_resolver.txt (the kernel tests and the whole-run comparisons below)."""
 import numpy as np
 import pytest
 

@@ -200,7 +200,7 @@ def test_dedicated_chain_resolver_takes_the_lock_versions_decisions():
     slots' records out of order and partly only after the chain has passed an earlier slot: the rowstate words, next / pk and the final
     counters equal the sequential statement of chain_resolve() (crs_chain.hip) for drawn windows with ties, NaNs, values landing among
     the worst rows, new bests and lists shorter than the window; the watchdog halts a window nobody evaluates
-    (tools/chain_resolver_check.cpp).  The device's memory model is not what this checks: tests/staged/test_gpu_chain_resolver.py."""
+    (tools/chain_resolver_check.cpp).  The device's memory model is not what this checks: tests/test_gpu_chain_resolver.py."""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
