@@ -537,6 +537,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                    "newbest": int(st1["slots_newbest"] - st0["slots_newbest"]),
                    "role": int(st1["slots_role"] - st0["slots_role"]),
                    "accepted": int(st1["accepted"] - st0["accepted"])},
+        # where the trial phase's wall time goes on the host's side (seconds over the timed steps): inside the engine call (launches, waiting
+        # for the device, copies out of pinned memory), in the in-order walk over the finished slots, the rest = preparing the pass
+        "host_split": {"trial_s": st1["t_trial_s"] - st0["t_trial_s"], "engine_s": st1["t_engine_s"] - st0["t_engine_s"],
+                       "walk_s": st1["t_walk_s"] - st0["t_walk_s"], "gather_kernel_s": g_ms / 1e3, "passes": int(st1["rounds"] - st0["rounds"])},
         "init": {"evals": pop, "seconds": t_init, "init_evals_per_s": pop / t_init},
         "final_result": int(fret), "minf": m["minf"],
     }
@@ -552,7 +556,12 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                       "value": m2["evals"] / m2["dt"], "unit": "evals/s",
                       "roofline_frac": (gb / 1e9) / (gms / 1e3) / HBM_PEAK_GBS if gms > 0 else None,
                       "avg_launch_ms": gms / gl if gl else None, "algorithmic_bytes_per_trial": 8 * n2 * (n2 + 1),
-                      "init_evals_per_s": 100000 / m2["t_init"]}
+                      "init_evals_per_s": 100000 / m2["t_init"],
+                      "path": ("device-resolved windows (crs_chain_kernel), the chain advanced by the resolver wavefront: the default for 512 <= n < 2048"
+                               if n2 >= 512 else "conservative passes (crs_advance_kernel + crs_finish_kernel): the default below n = 512"),
+                      "trials_consumed_per_launch": (s1["slots_used"] - s0["slots_used"]) / gl if gl else None,
+                      "host_split": {"trial_s": s1["t_trial_s"] - s0["t_trial_s"], "engine_s": s1["t_engine_s"] - s0["t_engine_s"],
+                                     "walk_s": s1["t_walk_s"] - s0["t_walk_s"], "gather_kernel_s": gms / 1e3, "passes": int(s1["rounds"] - s0["rounds"])}}
                 if not a.no_cpu_baseline:
                     cb = cpu_baseline_crs("rastrigin", n2, 20000, 4000, a.seed)
                     e2["cpu_baseline"] = cb

@@ -103,6 +103,10 @@ typedef struct {
     /* ISRES evolve (hip/isres_evolve2.hip): rounds of stage / scan / chain / write enqueued, and those of them that had
      * individuals left to resolve (a batch of rounds is enqueued before the host looks at the state again) */
     uint64_t evolve_rounds_enqueued, evolve_rounds;
+    /* CRS2_LM trial phase, where the wall time of a pass / window goes on the HOST's side: inside the engine call (uploads, launches,
+     * waiting for the device, copies out of pinned memory) and in the driver's in-order walk over the finished slots (verification of
+     * the device's chain, the order statistics, stop tests, staging of the commits).  t_trial_s - the two = preparing the pass. */
+    double t_engine_s, t_walk_s;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 

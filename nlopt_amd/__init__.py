@@ -41,7 +41,8 @@ class Stats(C.Structure):
                 ("t_rng_s", C.c_double), ("lbfgs_launches", C.c_uint64), ("lbfgs_bytes", C.c_uint64), ("t_lbfgs_ms", C.c_double),
                 ("t_stochrank_ms", C.c_double), ("stochrank_launches", C.c_uint64), ("stochrank_ticks", C.c_uint64),
                 ("t_allgather_ms", C.c_double), ("allgather_bytes", C.c_uint64),
-                ("evolve_rounds_enqueued", C.c_uint64), ("evolve_rounds", C.c_uint64)]
+                ("evolve_rounds_enqueued", C.c_uint64), ("evolve_rounds", C.c_uint64),
+                ("t_engine_s", C.c_double), ("t_walk_s", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

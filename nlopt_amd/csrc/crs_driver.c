@@ -361,6 +361,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             K = (int) (S->fresh_from - S->block);
         nW = K < N ? K : (int) N;
         nW = os_topk(&rs->os, nW, W);
+        const double t_eng0 = st ? nla_seconds() : 0.;
         if (S->forward) {
             /* every slot of the window is computed in this launch; what an earlier window left unconsumed is dropped */
             if (st && S->fresh_from > S->block) st->slots_invalid += S->fresh_from - S->block;
@@ -380,7 +381,9 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             }
         }
         wend = S->block + (uint64_t) K;
+        const double t_walk0 = st ? nla_seconds() : 0.;
         if (st) {
+            st->t_engine_s += t_walk0 - t_eng0;
             ++st->rounds;
             for (a = 0; a < K; ++a) {          /* algorithmic bytes this pass moved: 8n per row summed */
                 const uint64_t b = S->block + (uint64_t) a;
@@ -496,6 +499,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             }
             if (ops->commit(e, m, cblock, ckind, crow)) { engine_failed(S); return S->ret; }
         }
+        if (st) st->t_walk_s += nla_seconds() - t_walk0;
     }
     if (st) st->t_trial_s += nla_seconds() - t0;
     S->ret = ret;
