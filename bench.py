@@ -499,7 +499,11 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
     slots = st1["slots_launched"] - st0["slots_launched"]
     used = st1["slots_used"] - st0["slots_used"]
-    useful_gbs = (used * 8.0 * n * (n + 1) / (world if sharded else 1) / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
+    # below n = 2048 the engine times a SAMPLE of the launches (one pass in 8, one window in 4): bytes and time are of the same launches,
+    # the consumed trials are of all passes — scaled to the sample
+    passes = st1["rounds"] - st0["rounds"]
+    timed_share = (g_launch / passes) if passes else 1.0
+    useful_gbs = (used * timed_share * 8.0 * n * (n + 1) / (world if sharded else 1) / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
     # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) from n = 512 on, the conservative passes below
     # (and always the conservative passes, on column slices, in a sharded job)
     fw = [kv.split("=", 1)[1] for kv in CRS_PARAMS if kv.split("=", 1)[0] == "amd_forward"]         # (--param amd_forward=0/1: the A/B switch)
@@ -531,7 +535,8 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                      "launches": int(g_launch), "avg_launch_ms": (g_ms / g_launch) if g_launch else None,
                      "algorithmic_bytes_per_trial": 8 * n * (n + 1),
                      "avg_algorithmic_bytes_per_launch": (g_bytes / g_launch) if g_launch else None,
-                     "avg_trials_consumed_per_launch": (used / g_launch) if g_launch else None},
+                     "avg_trials_consumed_per_launch": (used * timed_share / g_launch) if g_launch else None,
+                     "launches_timed_of_passes": [int(g_launch), int(passes)]},
         "window": {"slots_started": int(slots), "slots_used": int(used), "slots_recomputed_or_dropped": int(st1["slots_invalid"] - st0["slots_invalid"]),
                    "useful_frac": (used / slots) if slots else None,
                    "newbest": int(st1["slots_newbest"] - st0["slots_newbest"]),
@@ -559,7 +564,7 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                       "init_evals_per_s": 100000 / m2["t_init"],
                       "path": ("device-resolved windows (crs_chain_kernel), the chain advanced by the resolver wavefront: the default for 512 <= n < 2048"
                                if n2 >= 512 else "conservative passes (crs_advance_kernel + crs_finish_kernel): the default below n = 512"),
-                      "trials_consumed_per_launch": (s1["slots_used"] - s0["slots_used"]) / gl if gl else None,
+                      "trials_consumed_per_pass": (s1["slots_used"] - s0["slots_used"]) / max(1, s1["rounds"] - s0["rounds"]),
                       "host_split": {"trial_s": s1["t_trial_s"] - s0["t_trial_s"], "engine_s": s1["t_engine_s"] - s0["t_engine_s"],
                                      "walk_s": s1["t_walk_s"] - s0["t_walk_s"], "gather_kernel_s": gms / 1e3, "passes": int(s1["rounds"] - s0["rounds"])}}
                 if not a.no_cpu_baseline:

@@ -362,6 +362,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
         nW = K < N ? K : (int) N;
         nW = os_topk(&rs->os, nW, W);
         const double t_eng0 = st ? nla_seconds() : 0.;
+        const uint64_t gl0 = st ? st->gather_launches : 0;
         if (S->forward) {
             /* every slot of the window is computed in this launch; what an earlier window left unconsumed is dropped */
             if (st && S->fresh_from > S->block) st->slots_invalid += S->fresh_from - S->block;
@@ -370,9 +371,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             if (ops->chain(e, S->block, K, rs->os.best, rs->F[rs->os.best], W, S->Wf, nW, status, S->fwcnt, S->fwrec, FWCAP)) { engine_failed(S); return S->ret; }
         } else
         {
-            const uint64_t gl0 = st ? st->gather_launches : 0;
             if (!S->forward && ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status)) { engine_failed(S); return S->ret; }
-            timed_pass = !st || st->gather_launches != gl0;        /* the engine times the gather of every pass, or of a sample of them: bytes follow */
             if (pb->comm && ops->stop_flags_in && ops->stop_flags_out) {
                 int forced = 0, timed = 0;
                 ops->stop_flags_out(e, &forced, &timed);
@@ -380,6 +379,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 rs->sp = &S->view;
             }
         }
+        timed_pass = !st || st->gather_launches != gl0;            /* the engine times the gather of every pass, or of a sample of them: bytes follow */
         wend = S->block + (uint64_t) K;
         const double t_walk0 = st ? nla_seconds() : 0.;
         if (st) {
