@@ -366,6 +366,12 @@ int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *
  * that stream) behind block c's launches opens it.  gate == NULL: no waiting. */
 int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                                 uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream);
+/* the same with flags.  NLA_STOCHRANK_PREFETCH: a unit reads the upstream counter and loads its next block of inputs during the
+ * current block, and moves its own counter a few ticks into the next one (hip/isres_kernels.hip, isres_stochrank_kernel<1>): the
+ * same elements in the same order, the memory round trips off the head of the blocks. */
+#define NLA_STOCHRANK_PREFETCH 1
+int nla_k_isres_stochrank_ex(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
+                             uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, int flags, void *stream);
 int nla_k_set_flag(int *d_flag, int value, void *stream);
 
 /* replaces: nlopt_nrand(0,1), mt19937ar.c:216-232, for a run of 4-word attempts: appends the

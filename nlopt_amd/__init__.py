@@ -20,6 +20,7 @@ GN_CRS2_LM, GN_MLSL, GD_MLSL, GN_MLSL_LDS, GD_MLSL_LDS = 19, 20, 21, 22, 23
 LD_LBFGS, LD_MMA, GN_ISRES, G_MLSL, G_MLSL_LDS, GN_ESCH = 11, 24, 35, 38, 39, 42
 LN_COBYLA = 25
 CHAIN_RESOLVER = 1          # nla_k_crs_chain_ex flag NLA_CHAIN_RESOLVER (include/nlopt_amd.h)
+STOCHRANK_PREFETCH = 1      # nla_k_isres_stochrank_ex flag NLA_STOCHRANK_PREFETCH
 # nlopt_result values
 FAILURE, INVALID_ARGS, OUT_OF_MEMORY, ROUNDOFF_LIMITED, FORCED_STOP = -1, -2, -3, -4, -5
 SUCCESS, STOPVAL_REACHED, FTOL_REACHED, XTOL_REACHED, MAXEVAL_REACHED, MAXTIME_REACHED = 1, 2, 3, 4, 5, 6
@@ -202,6 +203,7 @@ def lib():
     L.nla_k_isres_rank_count.argtypes = [C.c_int64, vp, vp, vp, vp, vp]
     L.nla_k_isres_bits.argtypes = [vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     L.nla_k_isres_stochrank.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+    L.nla_k_isres_stochrank_ex.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]   # ..., gate, rows_per_gate, gate_value, flags, stream
     L.nla_k_crs_commit.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_mutate.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
     L.nla_mt_jump_poly_words.argtypes = [C.c_uint64, vp]

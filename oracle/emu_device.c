@@ -490,6 +490,13 @@ int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams,
     if (gate) for (int64_t r = 0; r < nsweeps; r += rows_per_gate) if (gate[r / rows_per_gate] != gate_value) return 1;
     return nla_k_isres_stochrank(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, st);
 }
+/* the launch flags change when a unit issues its loads and stores on the device, not what comes out */
+int nla_k_isres_stochrank_ex(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket, uint8_t *swapped,
+                             int32_t *irank, const int *gate, int rows_per_gate, int gate_value, int flags, void *st)
+{
+    if (flags & ~1) return EMU_ERR;
+    return nla_k_isres_stochrank_gated(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, gate, rows_per_gate, gate_value, st);
+}
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                           uint8_t *swapped, int32_t *irank, void *st)
 {

@@ -11,6 +11,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# tests/staged/: GPU tests of opt-in code that has not run on a device yet (see the file headers) — collected only when named
+collect_ignore_glob = ["staged/*"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     lib = os.path.join(ROOT, "nlopt_amd", "lib", "libnlopt_amd.so")
