@@ -217,3 +217,26 @@ def test_dedicated_chain_resolver_takes_the_lock_versions_decisions():
             assert r.returncode == 0 and r.stdout.startswith("ok 120"), r.stdout + r.stderr
     finally:
         os.remove(exe)
+
+
+def test_stochastic_ranking_kernels_in_lockstep_emulation():
+    """hip/isres_stochrank.h — isres_stochrank_kernel (the default) and isres_stochrank_pre_kernel (its read-ahead variant, opt-in
+    "amd_isres_rank_prefetch", not yet run on a device) — compiled by g++ with the wavefront primitives emulated: the 64 lanes of a unit
+    are threads in lockstep (DPP wave shifts, v_readfirstlane), all units of the pipeline run at once, some of them slowed down so that
+    the read-ahead kernel's prefetches both hit and miss.  Both kernels reproduce the reference's double loop (isres.c:206-228): final
+    order, per-sweep "swapped" flags, every unit's counter at pop (tools/stochrank_check.cpp)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++ here")
+    out = os.path.join(root, "tools", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "stochrank_check.%d" % os.getpid())
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(root, "nlopt_amd", "csrc", "hip"),
+                    os.path.join(root, "tools", "stochrank_check.cpp"), "-o", exe], check=True)
+    try:
+        r = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
+    finally:
+        os.remove(exe)
