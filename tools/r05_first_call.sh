@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round 5, first GPU call: what round 4 wrote after its GPU minutes were spent, in the order of what depends on what.
+#  (1) the whole -m gpu suite: the device-resolved CRS2_LM windows with the resolver wavefront became the default for 512 <= n < 2048 in
+#      round 4's last GPU call; the full suite has not run on a device since (only tests/test_gpu_chain_resolver.py's kernel tests and
+#      whole-run comparisons did: profiles/r04_crs_chain_resolver.txt);
+#  (2) the staged read-ahead kernel of the ISRES ranking pipeline (tests/staged/test_gpu_isres_rank_prefetch.py) and its A/B on config 3
+#      (bench.py --workload isres --param amd_isres_rank_prefetch=1).  Green + faster: default 1 in isres_driver.c, the file moves to tests/;
+#  (3) CRS2_LM A/Bs, one line each (bench.py prints host_split = engine call / in-order walk / gather kernel per run):
+#        n = 512: default | amd_max_spec=256 | amd_chain_resolver=0 | amd_forward=0
+#        n = 64, 128, 256: default (conservative passes) | amd_forward=1 amd_chain_resolver=1 [amd_max_spec=256]
+#        n = 4096 (headline): default (lock version) | amd_chain_resolver=1 | amd_chain_resolver=1 amd_max_spec=256
+#      The thresholds in crs_engine.c (NLA_CRS_FORWARD_MIN_N = 512; resolver below 2048) are where something was measured, not where the
+#      break-evens are: move them to what these lines say;
+#  (4) the driver's default bench line.
+#   gpurun --timeout 1500 -- 'bash tools/r05_first_call.sh'
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05_first; mkdir -p $O
+timeout -k 5 600 python -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $O/gpu_suite.log 2>&1; echo "suite rc=$? $(tail -1 $O/gpu_suite.log)"
+timeout -k 5 240 python -X faulthandler -m pytest tests/staged/test_gpu_isres_rank_prefetch.py -x -q -m gpu -p no:cacheprovider > $O/staged_isres.log 2>&1; echo "staged isres rc=$? $(tail -1 $O/staged_isres.log)"
+line() {   # line <label> <bench args...>
+    local label=$1; shift
+    timeout -k 5 150 python bench.py "$@" 2>/dev/null | tail -1 > $O/last.json
+    python - "$label" <<'PY' | tee -a $O/ab.log
+import json, sys
+try:
+    d = json.load(open("gpurun_out/r05_first/last.json"))
+    hs = d.get("host_split") or {}
+    print("%-58s %9.0f evals/s  %8.3f ms/step  frac %s  host: engine %.3f walk %.3f kernel %.3f s over %s passes  %s" % (
+        sys.argv[1], d["value"], d["ms_per_step"], (d.get("roofline") or {}).get("frac"), hs.get("engine_s", 0), hs.get("walk_s", 0),
+        hs.get("gather_kernel_s", 0), hs.get("passes"), d.get("phases", "")))
+except Exception as e:
+    print(sys.argv[1], "FAILED", repr(e))
+PY
+}
+for rep in 1 2; do
+  line "isres config 3 default"                      --workload isres --no-cpu-baseline
+  line "isres config 3 amd_isres_rank_prefetch=1"     --workload isres --no-cpu-baseline --param amd_isres_rank_prefetch=1
+done
+for n in 512; do
+  line "crs n=$n default (windows + resolver)"        --n $n --obj rastrigin --headline-only --no-cpu-baseline
+  line "crs n=$n amd_max_spec=256"                    --n $n --obj rastrigin --headline-only --no-cpu-baseline --max-spec 256
+  line "crs n=$n amd_chain_resolver=0"                --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_chain_resolver=0
+  line "crs n=$n amd_forward=0"                       --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=0
+done
+for n in 64 128 256; do
+  line "crs n=$n default (conservative passes)"       --n $n --obj rastrigin --headline-only --no-cpu-baseline
+  line "crs n=$n windows + resolver"                  --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=1 --param amd_chain_resolver=1
+  line "crs n=$n windows + resolver, 256 slots"       --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=1 --param amd_chain_resolver=1 --max-spec 256
+done
+for rep in 1 2; do
+  line "crs headline default (lock version)"          --headline-only --no-cpu-baseline --steps 10 --warmup 2
+  line "crs headline amd_chain_resolver=1"            --headline-only --no-cpu-baseline --steps 10 --warmup 2 --param amd_chain_resolver=1
+  line "crs headline resolver, 256 slots"             --headline-only --no-cpu-baseline --steps 10 --warmup 2 --param amd_chain_resolver=1 --max-spec 256
+done
+timeout -k 5 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$? $(head -c 300 $O/bench_default.json)"
