@@ -402,6 +402,15 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
                               const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
                               double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
                               void *stream);
+/* the same with flags.  NLA_EVOLVE_FAST_SCAN: the scan counts an individual's redraws with sigma' formed from staged factors (one exp
+ * per staged deviate instead of one per candidate start and coordinate) and a margin around the bounds; draws inside the margin take
+ * the exact expressions, so E, T and everything downstream are bit-identical to the flag-less call (hip/isres_scan_fast.h).  Written at
+ * the end of round 4 without a device at hand: off by default ("amd_isres_fast_scan"), GPU tests staged under tests/staged/. */
+#define NLA_EVOLVE_FAST_SCAN 1
+int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                                 const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
+                                 double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
+                                 int flags, void *stream);
 
 /* ---- the batched local optimisers: common pieces ---------------------------------------------------- */
 /* External evaluation: the objective of a local search is not one of the compiled-in device objectives but a host callback

@@ -21,6 +21,7 @@ LD_LBFGS, LD_MMA, GN_ISRES, G_MLSL, G_MLSL_LDS, GN_ESCH = 11, 24, 35, 38, 39, 42
 LN_COBYLA = 25
 CHAIN_RESOLVER = 1          # nla_k_crs_chain_ex flag NLA_CHAIN_RESOLVER (include/nlopt_amd.h)
 STOCHRANK_PREFETCH = 1      # nla_k_isres_stochrank_ex flag NLA_STOCHRANK_PREFETCH
+EVOLVE_FAST_SCAN = 1        # nla_k_isres_evolve_rounds_ex flag NLA_EVOLVE_FAST_SCAN
 # nlopt_result values
 FAILURE, INVALID_ARGS, OUT_OF_MEMORY, ROUNDOFF_LIMITED, FORCED_STOP = -1, -2, -3, -4, -5
 SUCCESS, STOPVAL_REACHED, FTOL_REACHED, XTOL_REACHED, MAXEVAL_REACHED, MAXTIME_REACHED = 1, 2, 3, 4, 5, 6
@@ -204,6 +205,11 @@ def lib():
     L.nla_k_isres_bits.argtypes = [vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     L.nla_k_isres_stochrank.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     L.nla_k_isres_stochrank_ex.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]   # ..., gate, rows_per_gate, gate_value, flags, stream
+    L.nla_isres_evolve2_ws_bytes.restype = C.c_size_t
+    L.nla_isres_evolve2_ws_bytes.argtypes = [C.c_int]
+    L.nla_k_isres_inverse.argtypes = [C.c_int64, vp, vp, vp]
+    L.nla_k_isres_evolve_rounds_ex.argtypes = ([C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double] + [vp] * 11 +
+                                               [C.c_int, C.c_int, vp])   # ..., lb, ub, z, irank, inv, X, S, x0c, state, rho, ws, rounds, flags, stream
     L.nla_k_crs_commit.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_mutate.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
     L.nla_mt_jump_poly_words.argtypes = [C.c_uint64, vp]

@@ -613,11 +613,12 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
 int nla_isres_evolve2_supported(int n) { return getenv("NLA_EMU_EVOLVE2") != NULL && n <= 1150; }
 size_t nla_isres_evolve2_ws_bytes(int n) { (void) n; return 16; }
 static int emu_forced_handover(int64_t k, int phase) { return (((uint32_t) k * 2654435761u + (uint32_t) phase * 977u) >> 7) % 53u == 0; }
-int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
-                              const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
-                              double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
+int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                                 const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
+                                 double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, int flags, void *st)
 {
     EMU_LAUNCH();
+    if (flags & ~NLA_EVOLVE_FAST_SCAN) return 1;              /* (the flag changes how the device counts, not what: nothing to emulate) */
     const int64_t kend = phase == 0 ? pop : survivors;
     (void) inv; (void) rho; (void) ws;
     for (int r = 0; r < rounds; ++r) {
@@ -634,6 +635,12 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
         state[9] = state[0] - first;
     }
     return 0;
+}
+int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                              const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
+                              double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
+{
+    return nla_k_isres_evolve_rounds_ex(n, ld, phase, pop, survivors, zcount, taup, tau, lb, ub, z, irank, inv, X, S, x0c, state, rho, ws, rounds, 0, st);
 }
 
 /* ---- CRS2_LM (hip/crs_kernels.hip): the per-kernel CPU references of port_kernels.c behind the launchers' ring / slot addressing,

@@ -219,6 +219,30 @@ def test_dedicated_chain_resolver_takes_the_lock_versions_decisions():
         os.remove(exe)
 
 
+def test_fast_evolve_scan_counts_what_the_exact_scan_counts():
+    """hip/isres_scan_fast.h — the lane walk of ev2_scan_fast_kernel (opt-in "amd_isres_fast_scan", not yet run on a device): sigma' from
+    staged factors and a decision with a margin, the exact expressions inside the margin — compiled by g++ against the exact scan's lane
+    walk: the same E entry and T column for every candidate start of drawn individuals, with the fast path's exps off by up to 6 ulp,
+    bounds planted 0-3 ulp from draws, parents on their bounds, empty boxes, sigma = 0, windows that end early; and on ordinary
+    individuals not one draw needs the exact path (tools/scan_fast_check.cpp)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++ here")
+    out = os.path.join(root, "tools", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "scan_fast_check.%d" % os.getpid())
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "nlopt_amd", "csrc", "hip"),
+                    os.path.join(root, "tools", "scan_fast_check.cpp"), "-o", exe], check=True)
+    try:
+        for args in (["1500", "1"], ["1500", "2"], ["1500", "3", "plain"]):
+            r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and r.stdout.startswith("ok 1500"), r.stdout + r.stderr
+    finally:
+        os.remove(exe)
+
+
 def test_stochastic_ranking_kernels_in_lockstep_emulation():
     """hip/isres_stochrank.h — isres_stochrank_kernel (the default) and isres_stochrank_pre_kernel (its read-ahead variant, opt-in
     "amd_isres_rank_prefetch", not yet run on a device) — compiled by g++ with the wavefront primitives emulated: the 64 lanes of a unit

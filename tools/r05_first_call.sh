@@ -5,6 +5,9 @@
 #      whole-run comparisons did: profiles/r04_crs_chain_resolver.txt);
 #  (2) the staged read-ahead kernel of the ISRES ranking pipeline (tests/staged/test_gpu_isres_rank_prefetch.py) and its A/B on config 3
 #      (bench.py --workload isres --param amd_isres_rank_prefetch=1).  Green + faster: default 1 in isres_driver.c, the file moves to tests/;
+#  (2b) the staged evolve scan with the exp off the serial chain (tests/staged/test_gpu_isres_fast_scan.py: the launcher with and without the
+#      flag writes the same rows, state and workspace; whole runs bit-identical) and its A/B (--param amd_isres_fast_scan=1; the phases
+#      field of the line splits rank / evolve).  Green + faster: default 1 in isres_driver.c, the file moves to tests/;
 #  (3) CRS2_LM A/Bs, one line each (bench.py prints host_split = engine call / in-order walk / gather kernel per run):
 #        n = 512: default | amd_max_spec=256 | amd_chain_resolver=0 | amd_forward=0
 #        n = 64, 128, 256: default (conservative passes) | amd_forward=1 amd_chain_resolver=1 [amd_max_spec=256]
@@ -17,6 +20,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05_first; mkdir -p $O
 timeout -k 5 600 python -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $O/gpu_suite.log 2>&1; echo "suite rc=$? $(tail -1 $O/gpu_suite.log)"
 timeout -k 5 240 python -X faulthandler -m pytest tests/staged/test_gpu_isres_rank_prefetch.py -x -q -m gpu -p no:cacheprovider > $O/staged_isres.log 2>&1; echo "staged isres rc=$? $(tail -1 $O/staged_isres.log)"
+timeout -k 5 300 python -X faulthandler -m pytest tests/staged/test_gpu_isres_fast_scan.py -x -q -m gpu -p no:cacheprovider > $O/staged_isres_scan.log 2>&1; echo "staged isres fast scan rc=$? $(tail -1 $O/staged_isres_scan.log)"
 line() {   # line <label> <bench args...>
     local label=$1; shift
     timeout -k 5 150 python bench.py "$@" 2>/dev/null | tail -1 > $O/last.json
@@ -35,6 +39,8 @@ PY
 for rep in 1 2; do
   line "isres config 3 default"                      --workload isres --no-cpu-baseline
   line "isres config 3 amd_isres_rank_prefetch=1"     --workload isres --no-cpu-baseline --param amd_isres_rank_prefetch=1
+  line "isres config 3 amd_isres_fast_scan=1"         --workload isres --no-cpu-baseline --param amd_isres_fast_scan=1
+  line "isres config 3 fast scan + rank prefetch"     --workload isres --no-cpu-baseline --param amd_isres_fast_scan=1 --param amd_isres_rank_prefetch=1
 done
 for n in 512; do
   line "crs n=$n default (windows + resolver)"        --n $n --obj rastrigin --headline-only --no-cpu-baseline
