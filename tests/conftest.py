@@ -42,7 +42,7 @@ GPU_ORDER = ["test_gpu_crs", "test_gpu_fullsize", "test_gpu_kernels", "test_gpu_
 
 
 def pytest_collection_modifyitems(session, config, items):
-    if os.environ.get("NLA_TEST_KEEP_ORDER"):         # (tools/hunt.sh replays the round-2 collection order with it)
+    if os.environ.get("NLA_TEST_KEEP_ORDER"):         # (tools/history/hunt.sh replays the round-2 collection order with it)
         return
     rank = {m: i for i, m in enumerate(GPU_ORDER)}
 

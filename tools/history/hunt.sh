@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box script: reproduce / bisect the intermittent CRS2_LM divergence of the round-2 driver run (development aid).
-#   tools/hunt.sh <loopsA> <secondsB> <secondsC> <fullsuite 0|1>
-cd "$(dirname "$0")/.."
+#   tools/history/hunt.sh <loopsA> <secondsB> <secondsC> <fullsuite 0|1>
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 LA=${1:-20}; SB=${2:-180}; SC=${3:-0}; FULL=${4:-1}
 echo "== phase A: the round-2 driver's process, $LA times (cobyla -> cpp_client -> crs in one process)" > gpurun_out/hunt.log

@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU-box script: A/B the intermittent CRS2_LM divergence.  Round-robin over variants of the round-2 driver's process
-# (cobyla -> cpp_client -> crs in one pytest process), LOOPS times each:   tools/hunt2.sh <loops> "<VAR=1>" "<VAR=1>" ...
+# (cobyla -> cpp_client -> crs in one pytest process), LOOPS times each:   tools/history/hunt2.sh <loops> "<VAR=1>" "<VAR=1>" ...
 # ("-" = baseline, no variable)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 LOOPS=$1; shift
 echo "== hunt2: $LOOPS loops each of: $*" > gpurun_out/hunt2.log

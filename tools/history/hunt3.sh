@@ -3,7 +3,7 @@
 #   1  product as fixed (uncached blocks pooled, never freed) + deliberate raw uncached alloc/write/free between runs  -> provokes it if that is the cause
 #   2  product as fixed, no provocation                                                                              -> must be clean
 #   3  round-2 behaviour (NLA_UC_POOL=0 + uncached buffers for every run: NLA_CRS_FORWARD_MEM=1), no provocation      -> the baseline rate
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 S=${1:-100}
 echo "== hunt3" > gpurun_out/hunt3.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 evidence on the MI355X box: the driver's exact GPU suite command, the default bench line, rocprofv3 kernel traces + PMC passes
-# (headline CRS, L-BFGS / MLSL, the small-n CRS passes), the shard probe.     tools/r03_final.sh [suite 0|1]
+# (headline CRS, L-BFGS / MLSL, the small-n CRS passes), the shard probe.     tools/history/r03_final.sh [suite 0|1]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03; mkdir -p $O
 if [ "${1:-1}" = "1" ]; then

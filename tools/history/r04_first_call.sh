@@ -8,7 +8,7 @@
 #  (4) A/B of config 4 (bench.py --workload mlsl): the sampling phase is where the distances are (6.4 of 7.5 ms per iteration).
 # If (1) and (2) are green and (4) is faster: make the tiled kernel the default (hip/mlsl_kernels.hip, nla_k_mlsl_dist2) and drop
 # the skip in the test.
-#   gpurun --timeout 600 -- 'bash tools/r04_first_call.sh'
+#   gpurun --timeout 600 -- 'bash tools/history/r04_first_call.sh'
 mkdir -p gpurun_out/r04_first
 timeout 120 python -m pytest tests/test_gpu_mlsl.py -x -q -m gpu -k pair_distance 2>&1 | tail -3 | tee gpurun_out/r04_first/dist2_tests.log
 NLA_MLSL_DIST2_TILED=1 timeout 300 python -m pytest tests/test_gpu_mlsl.py tests/test_gpu_exact_local.py tests/test_gpu_fullsize.py -q -m gpu -k "mlsl or MLSL" 2>&1 | tail -3 | tee gpurun_out/r04_first/mlsl_tiled.log
