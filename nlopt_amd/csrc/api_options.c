@@ -15,7 +15,7 @@ static double *dup_doubles(const double *src, unsigned n)
     double *d;
     if (!src) return NULL;
     d = (double *) malloc(sizeof(double) * (n ? n : 1));
-    if (d) memcpy(d, src, sizeof(double) * n);
+    if (d && n) memcpy(d, src, sizeof(double) * n);
     return d;
 }
 
@@ -228,7 +228,7 @@ nlopt_result nlopt_get_lower_bounds(const nlopt_opt opt, double *lb)
 {
     nla_unset_errmsg(opt);
     if (!opt || (opt->n && !lb)) return NLOPT_INVALID_ARGS;
-    memcpy(lb, opt->lb, sizeof(double) * opt->n);
+    if (opt->n) memcpy(lb, opt->lb, sizeof(double) * opt->n);     /* (n = 0: both pointers may be NULL, which memcpy must not be given) */
     return NLOPT_SUCCESS;
 }
 nlopt_result nlopt_set_upper_bounds(nlopt_opt opt, const double *ub)
@@ -260,7 +260,7 @@ nlopt_result nlopt_get_upper_bounds(const nlopt_opt opt, double *ub)
 {
     nla_unset_errmsg(opt);
     if (!opt || (opt->n && !ub)) return NLOPT_INVALID_ARGS;
-    memcpy(ub, opt->ub, sizeof(double) * opt->n);
+    if (opt->n) memcpy(ub, opt->ub, sizeof(double) * opt->n);
     return NLOPT_SUCCESS;
 }
 
@@ -369,7 +369,7 @@ nlopt_result nlopt_set_xtol_abs(nlopt_opt opt, const double *tol)
     nla_unset_errmsg(opt);
     if (!tol) { free(opt->xtol_abs); opt->xtol_abs = NULL; return NLOPT_SUCCESS; }
     if (ensure_vec(opt, &opt->xtol_abs) != NLOPT_SUCCESS) return NLOPT_OUT_OF_MEMORY;
-    memcpy(opt->xtol_abs, tol, sizeof(double) * opt->n);
+    if (opt->n) memcpy(opt->xtol_abs, tol, sizeof(double) * opt->n);
     return NLOPT_SUCCESS;
 }
 nlopt_result nlopt_set_xtol_abs1(nlopt_opt opt, double tol)
@@ -472,7 +472,7 @@ nlopt_result nlopt_set_initial_step(nlopt_opt opt, const double *dx)
     if (!dx) { free(opt->dx); opt->dx = NULL; return NLOPT_SUCCESS; }
     for (i = 0; i < opt->n; ++i) if (dx[i] == 0) return fail_msg(opt, NLOPT_INVALID_ARGS, "zero step size");
     if (!opt->dx && nlopt_set_initial_step1(opt, 1) == NLOPT_OUT_OF_MEMORY) return NLOPT_OUT_OF_MEMORY;
-    memcpy(opt->dx, dx, sizeof(double) * opt->n);
+    if (opt->n) memcpy(opt->dx, dx, sizeof(double) * opt->n);
     return NLOPT_SUCCESS;
 }
 nlopt_result nlopt_set_default_initial_step(nlopt_opt opt, const double *x)
@@ -502,11 +502,11 @@ nlopt_result nlopt_get_initial_step(const nlopt_opt opt, const double *x, double
     if (!opt) return NLOPT_INVALID_ARGS;
     nla_unset_errmsg(opt);
     if (!opt->n) return NLOPT_SUCCESS;
-    if (opt->dx) { memcpy(dx, opt->dx, sizeof(double) * opt->n); return NLOPT_SUCCESS; }
+    if (opt->dx) { if (opt->n) memcpy(dx, opt->dx, sizeof(double) * opt->n); return NLOPT_SUCCESS; }
     {   /* x-dependent default: compute, hand out, do not keep */
         nlopt_result ret = nlopt_set_default_initial_step(opt, x);
         if (ret != NLOPT_SUCCESS) return ret;
-        memcpy(dx, opt->dx, sizeof(double) * opt->n);
+        if (opt->n) memcpy(dx, opt->dx, sizeof(double) * opt->n);
         free(opt->dx); opt->dx = NULL;
     }
     return NLOPT_SUCCESS;

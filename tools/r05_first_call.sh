@@ -3,6 +3,9 @@
 #  (1) the whole -m gpu suite: the device-resolved CRS2_LM windows with the resolver wavefront became the default for 512 <= n < 2048 in
 #      round 4's last GPU call; the full suite has not run on a device since (only tests/test_gpu_chain_resolver.py's kernel tests and
 #      whole-run comparisons did: profiles/r04_crs_chain_resolver.txt);
+#  (1b) tests/staged/test_gpu_chain_resolver_small.py: the windows + resolver forced on where they are not the default (golden cases, drawn
+#      configurations with n < 512 and populations barely above n) — 40 tests that have only run over the emulated device.  Green: they
+#      move back into tests/test_gpu_chain_resolver.py;
 #  (2) the staged read-ahead kernel of the ISRES ranking pipeline (tests/staged/test_gpu_isres_rank_prefetch.py) and its A/B on config 3
 #      (bench.py --workload isres --param amd_isres_rank_prefetch=1).  Green + faster: default 1 in isres_driver.c, the file moves to tests/;
 #  (2b) the staged evolve scan with the exp off the serial chain (tests/staged/test_gpu_isres_fast_scan.py: the launcher with and without the
@@ -19,6 +22,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05_first; mkdir -p $O
 timeout -k 5 600 python -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $O/gpu_suite.log 2>&1; echo "suite rc=$? $(tail -1 $O/gpu_suite.log)"
+timeout -k 5 300 python -X faulthandler -m pytest tests/staged/test_gpu_chain_resolver_small.py -x -q -m gpu -p no:cacheprovider > $O/staged_resolver_small.log 2>&1; echo "staged resolver at small n rc=$? $(tail -1 $O/staged_resolver_small.log)"
 timeout -k 5 240 python -X faulthandler -m pytest tests/staged/test_gpu_isres_rank_prefetch.py -x -q -m gpu -p no:cacheprovider > $O/staged_isres.log 2>&1; echo "staged isres rc=$? $(tail -1 $O/staged_isres.log)"
 timeout -k 5 300 python -X faulthandler -m pytest tests/staged/test_gpu_isres_fast_scan.py -x -q -m gpu -p no:cacheprovider > $O/staged_isres_scan.log 2>&1; echo "staged isres fast scan rc=$? $(tail -1 $O/staged_isres_scan.log)"
 line() {   # line <label> <bench args...>
