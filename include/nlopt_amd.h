@@ -171,6 +171,10 @@ int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src_states, uint32_t *ds
  * segment seg_first+s; the nseg segments must cover [g_first, g_first+count). */
 int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg,
                       uint64_t g_first, uint64_t count, uint32_t *out, void *stream);
+/* the same for a stream cut into segments of seg_regens regenerations (a power of two <= NLA_MT_SEG_REGENS; seg_states / seg_first in
+ * units of THAT segment length): more, shorter segments = more wavefronts for a caller that fills few words at a time */
+int nla_k_mt_generate_seg(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_first, uint64_t count, uint32_t *out,
+                          int seg_regens, void *stream);
 /* replaces: the ranking's nlopt_urand calls (isres.c:210, mt19937ar.c:194-198) — words [g_first, g_first + count) of the stream
  * (global word indices; g_rank0 = the ranking's first word, (g_first - g_rank0) even) reduced on the fly to the bits u < 0.45:
  * step s = (g - g_rank0) / 2 sets bit (s % popm1) of row (s / popm1) of `bits` (rows of `rowwords` u64, ZEROED by the caller).

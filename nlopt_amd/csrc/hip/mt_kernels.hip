@@ -75,6 +75,51 @@ __global__ __launch_bounds__(64) void mt_generate_kernel(const uint32_t *__restr
     }
 }
 
+/* the same with the segment length as an argument (nla_k_mt_generate_seg; "amd_mlsl_seg_regens"): a stream user that needs few words per
+ * fill — MLSL draws 8 M words per iteration, 13 segments of the default length: 13 wavefronts walking 1024 regenerations each, ~3 ms of
+ * latency on an idle device — can cut its stream into shorter segments and get as many more wavefronts.  A kernel of its own so that
+ * mt_generate_kernel's loop keeps its compile-time bound (and its machine code). */
+__global__ __launch_bounds__(64) void mt_generate_seg_kernel(const uint32_t *__restrict__ seg_states, uint64_t seg_first,
+                                                              uint64_t g_first, uint64_t count, uint32_t *__restrict__ out, int seg_regens)
+{
+    __shared__ uint32_t mt[MT_N];
+    const int lane = threadIdx.x;
+    const uint64_t seg = seg_first + blockIdx.x;
+    const uint64_t g_end = g_first + count;
+    const uint64_t g0 = seg * ((uint64_t) MT_N * (uint64_t) seg_regens);
+
+    for (int i = lane; i < MT_N; i += 64) mt[i] = seg_states[(size_t) blockIdx.x * MT_N + i];
+    __syncthreads();
+
+    for (int r = 0; r < seg_regens; ++r) {
+        const uint64_t gb = g0 + (uint64_t) r * MT_N;
+        if (gb >= g_end) break;
+        if (gb + MT_N > g_first) {
+            for (int i = lane; i < MT_N; i += 64) {
+                const uint64_t g = gb + i;
+                if (g >= g_first && g < g_end) out[g - g_first] = mt_temper(mt[i]);
+            }
+        }
+        for (int k = lane; k < MT_N - MT_M; k += 64) {                       /* 0 .. 226 (the three phases of mt_generate_kernel) */
+            uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k + MT_M]);
+            mt[k] = v;
+        }
+        __syncthreads();
+        for (int k = MT_N - MT_M + lane; k < 2 * (MT_N - MT_M); k += 64) {     /* 227 .. 453 */
+            uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]);
+            mt[k] = v;
+        }
+        __syncthreads();
+        for (int k = 2 * (MT_N - MT_M) + lane; k < MT_N - 1; k += 64) {        /* 454 .. 622 */
+            uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]);
+            mt[k] = v;
+        }
+        __syncthreads();
+        if (lane == 0) mt[MT_N - 1] = mt_twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+        __syncthreads();
+    }
+}
+
 /* dst = block array J words after src, g = t^J mod phi:  y_j = XOR_{i : g_i} x[i + j], j < 624, over the untempered word
  * sequence x[0 .. 19937 + 623] that continues src.  One 640-thread workgroup per state.  The sequence is walked in WINDOWS of
  * JUMP_CHUNK polynomial bits: the window holds x[c .. c + JUMP_CHUNK + 624) — thread j's terms of the chunk — and is extended
@@ -247,6 +292,16 @@ extern "C" int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first,
     if (nseg <= 0 || count == 0) return 0;
     hipLaunchKernelGGL(mt_generate_kernel, dim3(nseg), dim3(64), 0, (hipStream_t) stream,
                        seg_states, seg_first, g_first, count, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nla_k_mt_generate_seg(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_first, uint64_t count,
+                                     uint32_t *out, int seg_regens, void *stream)
+{
+    if (seg_regens < 1 || seg_regens > NLA_MT_SEG_REGENS || (seg_regens & (seg_regens - 1))) return (int) hipErrorInvalidValue;
+    if (nseg <= 0 || count == 0) return 0;
+    hipLaunchKernelGGL(mt_generate_seg_kernel, dim3(nseg), dim3(64), 0, (hipStream_t) stream, seg_states, seg_first, g_first, count, out, seg_regens);
     NLA_LAUNCH_CHECK();
     return 0;
 }

@@ -312,7 +312,14 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.prefetch = !host && ((opt && nlopt_get_param(opt, "amd_mlsl_prefetch", 0) != 0) || nla_dbg_int("NLA_MLSL_PREFETCH", 0) > 0);
     D.prefetched_at = ~0ULL;
     D.rs = (D.st && D.prefetch) ? nla_stream_create() : D.st;
-    if (!D.st || !D.rs || !(D.mts = nla_mtstream_create(D.rs))) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); nla_comm_agree_ready(D.comm, 0); mfree(&D); return NLOPT_OUT_OF_MEMORY; }
+    {
+        /* "amd_mlsl_seg_regens" (default NLA_MT_SEG_REGENS = 1024: the stream layout every other algorithm uses; NOT YET RUN ON A DEVICE with
+         * another value): the segment length of this run's stream — 64 makes 205 wavefronts of the 13 above.  The words are the same. */
+        int seg = opt ? (int) nlopt_get_param(opt, "amd_mlsl_seg_regens", NLA_MT_SEG_REGENS) : NLA_MT_SEG_REGENS;
+        if (seg < 1 || seg > NLA_MT_SEG_REGENS || (seg & (seg - 1))) seg = NLA_MT_SEG_REGENS;
+        if (D.st && D.rs) D.mts = seg == NLA_MT_SEG_REGENS ? nla_mtstream_create(D.rs) : nla_mtstream_create_seg(D.rs, seg);
+    }
+    if (!D.st || !D.rs || !D.mts) { nla_stop_msg(stop, "nlopt_amd: could not create the device stream / generator state"); nla_comm_agree_ready(D.comm, 0); mfree(&D); return NLOPT_OUT_OF_MEMORY; }
     D.d_lb = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_ub = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
     D.d_words = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * 2 * (size_t) n * (size_t) D.N);

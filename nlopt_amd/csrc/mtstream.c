@@ -16,6 +16,8 @@
 
 struct nla_mtstream {
     void *stream;
+    int seg_regens;             /* regenerations per segment: NLA_MT_SEG_REGENS, or the caller's shorter power of two (nla_mtstream_create_seg) */
+    uint64_t seg_words;         /* 624 * seg_regens */
     uint32_t base[NLA_MT_N];
     int base_consumed;
     uint32_t *d_states;         /* nstates x 624 */
@@ -26,11 +28,18 @@ struct nla_mtstream {
 
 static int log2_int(unsigned v) { int k = 0; while ((1u << k) < v) ++k; return k; }
 
-nla_mtstream *nla_mtstream_create(void *stream)
+/* A stream whose segments are seg_regens regenerations long (a power of two, 1 .. NLA_MT_SEG_REGENS): the same words at the same
+ * offsets — only how many wavefronts produce them changes (and how many jump-ahead states are built: one per segment).  Only _fill
+ * serves such a stream (the fused ranking-bits kernel is ISRES's, which wants the long segments). */
+nla_mtstream *nla_mtstream_create_seg(void *stream, int seg_regens)
 {
-    nla_mtstream *s = (nla_mtstream *) calloc(1, sizeof *s);
+    nla_mtstream *s;
+    if (seg_regens < 1 || seg_regens > NLA_MT_SEG_REGENS || (seg_regens & (seg_regens - 1))) return NULL;
+    s = (nla_mtstream *) calloc(1, sizeof *s);
     if (!s) return NULL;
     s->stream = stream;
+    s->seg_regens = seg_regens;
+    s->seg_words = (uint64_t) NLA_MT_N * (uint64_t) seg_regens;
     nla_mt_export(s->base, &s->base_consumed);
     s->cap_states = 64;
     s->d_states = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * NLA_MT_N * (size_t) s->cap_states);
@@ -42,6 +51,8 @@ nla_mtstream *nla_mtstream_create(void *stream)
     s->round_base = 1;
     return s;
 }
+
+nla_mtstream *nla_mtstream_create(void *stream) { return nla_mtstream_create_seg(stream, NLA_MT_SEG_REGENS); }
 
 void nla_mtstream_destroy(nla_mtstream *s)
 {
@@ -70,7 +81,7 @@ static const uint64_t *dev_poly(nla_mtstream *s, int k)
 
 static int ensure_states(nla_mtstream *s, uint64_t seg_needed)
 {
-    const int seg_log = log2_int(NLA_MT_SEG_REGENS);
+    const int seg_log = log2_int((unsigned) s->seg_regens);
     if (seg_needed >= (1ULL << 30)) return -1;
     while ((uint64_t) s->nstates <= seg_needed) {
         int done, cnt, want;
@@ -107,9 +118,11 @@ int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint3
     uint64_t g_first, seg0, seg1;
     if (!count) return 0;
     g_first = (uint64_t) s->base_consumed + rel_first;
-    seg0 = g_first / NLA_MT_SEG_WORDS;
-    seg1 = (g_first + count - 1) / NLA_MT_SEG_WORDS;
+    seg0 = g_first / s->seg_words;
+    seg1 = (g_first + count - 1) / s->seg_words;
     if (ensure_states(s, seg1)) return -1;
+    if (s->seg_regens != NLA_MT_SEG_REGENS)
+        return nla_k_mt_generate_seg(s->d_states + (size_t) seg0 * NLA_MT_N, seg0, (int) (seg1 - seg0 + 1), g_first, count, d_out, s->seg_regens, s->stream);
     return nla_k_mt_generate(s->d_states + (size_t) seg0 * NLA_MT_N, seg0, (int) (seg1 - seg0 + 1),
                              g_first, count, d_out, s->stream);
 }
@@ -118,7 +131,7 @@ int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint3
  * stream — so that a later fill / rankbits up to there finds them ready (ISRES overlap mode: beside the evolve rounds) */
 int nla_mtstream_reserve(nla_mtstream *s, uint64_t rel_last)
 {
-    return ensure_states(s, ((uint64_t) s->base_consumed + rel_last) / NLA_MT_SEG_WORDS);
+    return ensure_states(s, ((uint64_t) s->base_consumed + rel_last) / s->seg_words);
 }
 
 /* the ranking bits of stream words [rel_first, rel_first + count) (relative to the run's first word, as nla_mtstream_fill),
@@ -127,6 +140,7 @@ int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_firs
 {
     uint64_t g_first, seg0, seg1;
     if (!count) return 0;
+    if (s->seg_regens != NLA_MT_SEG_REGENS) return -1;          /* (the fused kernel knows the default segment length only) */
     g_first = (uint64_t) s->base_consumed + rel_first;
     seg0 = g_first / NLA_MT_SEG_WORDS;
     seg1 = (g_first + count - 1) / NLA_MT_SEG_WORDS;
@@ -148,13 +162,13 @@ int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed)
 {
     const uint64_t g = (uint64_t) s->base_consumed + consumed;
     const uint64_t blk = g / NLA_MT_N;
-    const uint64_t seg = blk / NLA_MT_SEG_REGENS;
+    const uint64_t seg = blk / (uint64_t) s->seg_regens;
     uint32_t mt[NLA_MT_N];
     uint64_t r;
     if (seg < (uint64_t) s->nstates) {
         if (nla_memcpy_d2h(mt, s->d_states + (size_t) seg * NLA_MT_N, sizeof mt, s->stream) ||
             nla_stream_sync(s->stream)) return -1;
-        for (r = blk % NLA_MT_SEG_REGENS; r > 0; --r) nla_mt_regen(mt);
+        for (r = blk % (uint64_t) s->seg_regens; r > 0; --r) nla_mt_regen(mt);
     } else {
         nla_mt_advance_blocks_host(s->base, blk, mt);
     }

@@ -155,6 +155,7 @@ void nla_mt_advance_blocks_host(const uint32_t src[NLA_MT_N], uint64_t regens, u
 /* ---- device word stream (mtstream.c): the host generator continued on the GPU ---------------- */
 typedef struct nla_mtstream nla_mtstream;
 nla_mtstream *nla_mtstream_create(void *stream);     /* snapshots the calling thread's generator */
+nla_mtstream *nla_mtstream_create_seg(void *stream, int seg_regens);   /* ... cut into segments of seg_regens regenerations (power of two <= NLA_MT_SEG_REGENS); fill only */
 void nla_mtstream_destroy(nla_mtstream *s);
 void nla_mtstream_host_state(nla_mtstream *s, uint64_t rel_word, uint32_t mt[NLA_MT_N], int *pos);
 uint64_t nla_mtstream_origin(const nla_mtstream *s); /* global index of the first unconsumed word */

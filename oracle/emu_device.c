@@ -86,16 +86,18 @@ int nla_k_mt_jump(const uint64_t *poly, const uint32_t *src, uint32_t *dst, int 
     for (int i = 0; i < count; ++i) nla_mt_apply_jump_host(poly, src + (size_t) i * NLA_MT_N, dst + (size_t) i * NLA_MT_N);
     return 0;
 }
-int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_first, uint64_t count, uint32_t *out, void *st)
+int nla_k_mt_generate_seg(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_first, uint64_t count, uint32_t *out,
+                          int seg_regens, void *st)
 {
     EMU_LAUNCH();
     const uint64_t g_end = g_first + count;
     (void) st;
+    if (seg_regens < 1 || seg_regens > NLA_MT_SEG_REGENS || (seg_regens & (seg_regens - 1))) return 1;
     for (int s = 0; s < nseg; ++s) {
         uint32_t mt[NLA_MT_N];
-        const uint64_t g0 = (seg_first + (uint64_t) s) * NLA_MT_SEG_WORDS;
+        const uint64_t g0 = (seg_first + (uint64_t) s) * ((uint64_t) NLA_MT_N * (uint64_t) seg_regens);
         memcpy(mt, seg_states + (size_t) s * NLA_MT_N, sizeof mt);
-        for (int r = 0; r < NLA_MT_SEG_REGENS; ++r) {
+        for (int r = 0; r < seg_regens; ++r) {
             const uint64_t gb = g0 + (uint64_t) r * NLA_MT_N;
             if (gb >= g_end) break;
             if (gb + NLA_MT_N > g_first)
@@ -104,6 +106,11 @@ int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg, 
         }
     }
     return 0;
+}
+
+int nla_k_mt_generate(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_first, uint64_t count, uint32_t *out, void *st)
+{
+    return nla_k_mt_generate_seg(seg_states, seg_first, nseg, g_first, count, out, NLA_MT_SEG_REGENS, st);
 }
 
 int nla_k_mt_rankbits(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_rank0, uint64_t g_first, uint64_t count,

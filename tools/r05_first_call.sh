@@ -11,6 +11,8 @@
 #  (2b) the staged evolve scan with the exp off the serial chain (tests/staged/test_gpu_isres_fast_scan.py: the launcher with and without the
 #      flag writes the same rows, state and workspace; whole runs bit-identical) and its A/B (--param amd_isres_fast_scan=1; the phases
 #      field of the line splits rank / evolve).  Green + faster: default 1 in isres_driver.c, the file moves to tests/;
+#  (2c) MLSL's stream in shorter segments (tests/staged/test_gpu_mlsl_short_segments.py; --param amd_mlsl_seg_regens=...: sampling_s_per_iter
+#      in the phases field is what should move).  Green + faster: the best value becomes mlsl_driver.c's default;
 #  (3) CRS2_LM A/Bs, one line each (bench.py prints host_split = engine call / in-order walk / gather kernel per run):
 #        n = 512: default | amd_max_spec=256 | amd_chain_resolver=0 | amd_forward=0
 #        n = 64, 128, 256: default (conservative passes) | amd_forward=1 amd_chain_resolver=1 [amd_max_spec=256]
@@ -40,6 +42,10 @@ except Exception as e:
     print(sys.argv[1], "FAILED", repr(e))
 PY
 }
+timeout -k 5 300 python -X faulthandler -m pytest tests/staged/test_gpu_mlsl_short_segments.py -x -q -m gpu -p no:cacheprovider > $O/staged_mlsl_seg.log 2>&1; echo "staged mlsl short segments rc=$? $(tail -1 $O/staged_mlsl_seg.log)"
+for seg in 1024 256 64 16; do
+  line "mlsl config 4 amd_mlsl_seg_regens=$seg"          --workload mlsl --no-cpu-baseline --param amd_mlsl_seg_regens=$seg
+done
 for rep in 1 2; do
   line "isres config 3 default"                      --workload isres --no-cpu-baseline
   line "isres config 3 amd_isres_rank_prefetch=1"     --workload isres --no-cpu-baseline --param amd_isres_rank_prefetch=1
