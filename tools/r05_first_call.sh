@@ -1,8 +1,12 @@
 #!/bin/bash
-# Round 5, first GPU call: what round 4 wrote after its GPU minutes were spent, in the order of what depends on what.
+# Round 5, first GPU calls: what round 4 wrote after its GPU minutes were spent, in the order of what depends on what.
+#   gpurun --timeout 1200 -- 'bash tools/r05_first_call.sh 1'     (~13 min: suite, staged tests, ISRES / MLSL A/Bs)
+#   gpurun --timeout 1200 -- 'bash tools/r05_first_call.sh 2'     (~12 min: CRS2_LM A/Bs, the default bench line)
+#
+# Part 1
 #  (1) the whole -m gpu suite: the device-resolved CRS2_LM windows with the resolver wavefront became the default for 512 <= n < 2048 in
 #      round 4's last GPU call; the full suite has not run on a device since (only tests/test_gpu_chain_resolver.py's kernel tests and
-#      whole-run comparisons did: profiles/r04_crs_chain_resolver.txt);
+#      whole-run comparisons did: profiles/r04_crs_chain_resolver.txt) — unless the driver's round-4 record (GPUTEST_r04.json) is green;
 #  (1b) tests/staged/test_gpu_chain_resolver_small.py: the windows + resolver forced on where they are not the default (golden cases, drawn
 #      configurations with n < 512 and populations barely above n) — 40 tests that have only run over the emulated device.  Green: they
 #      move back into tests/test_gpu_chain_resolver.py;
@@ -12,7 +16,8 @@
 #      flag writes the same rows, state and workspace; whole runs bit-identical) and its A/B (--param amd_isres_fast_scan=1; the phases
 #      field of the line splits rank / evolve).  Green + faster: default 1 in isres_driver.c, the file moves to tests/;
 #  (2c) MLSL's stream in shorter segments (tests/staged/test_gpu_mlsl_short_segments.py; --param amd_mlsl_seg_regens=...: sampling_s_per_iter
-#      in the phases field is what should move).  Green + faster: the best value becomes mlsl_driver.c's default;
+#      in the phases field is what should move).  Green + faster: the best value becomes mlsl_driver.c's default.
+# Part 2
 #  (3) CRS2_LM A/Bs, one line each (bench.py prints host_split = engine call / in-order walk / gather kernel per run):
 #        n = 512: default | amd_max_spec=256 | amd_chain_resolver=0 | amd_forward=0
 #        n = 64, 128, 256: default (conservative passes) | amd_forward=1 amd_chain_resolver=1 [amd_max_spec=256]
@@ -20,13 +25,13 @@
 #      The thresholds in crs_engine.c (NLA_CRS_FORWARD_MIN_N = 512; resolver below 2048) are where something was measured, not where the
 #      break-evens are: move them to what these lines say;
 #  (4) the driver's default bench line.
-#   gpurun --timeout 1500 -- 'bash tools/r05_first_call.sh'
+# Every step runs under its own timeout; a failed or hung step costs its limit, not the call.
+PART=${1:-all}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05_first; mkdir -p $O
-timeout -k 5 600 python -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $O/gpu_suite.log 2>&1; echo "suite rc=$? $(tail -1 $O/gpu_suite.log)"
-timeout -k 5 300 python -X faulthandler -m pytest tests/staged/test_gpu_chain_resolver_small.py -x -q -m gpu -p no:cacheprovider > $O/staged_resolver_small.log 2>&1; echo "staged resolver at small n rc=$? $(tail -1 $O/staged_resolver_small.log)"
-timeout -k 5 240 python -X faulthandler -m pytest tests/staged/test_gpu_isres_rank_prefetch.py -x -q -m gpu -p no:cacheprovider > $O/staged_isres.log 2>&1; echo "staged isres rc=$? $(tail -1 $O/staged_isres.log)"
-timeout -k 5 300 python -X faulthandler -m pytest tests/staged/test_gpu_isres_fast_scan.py -x -q -m gpu -p no:cacheprovider > $O/staged_isres_scan.log 2>&1; echo "staged isres fast scan rc=$? $(tail -1 $O/staged_isres_scan.log)"
+staged() {   # staged <log name> <limit s> <test file>
+    timeout -k 5 $2 python -X faulthandler -m pytest $3 -x -q -m gpu -p no:cacheprovider > $O/$1.log 2>&1; echo "$3 rc=$? $(tail -1 $O/$1.log)"
+}
 line() {   # line <label> <bench args...>
     local label=$1; shift
     timeout -k 5 150 python bench.py "$@" 2>/dev/null | tail -1 > $O/last.json
@@ -42,30 +47,38 @@ except Exception as e:
     print(sys.argv[1], "FAILED", repr(e))
 PY
 }
-timeout -k 5 300 python -X faulthandler -m pytest tests/staged/test_gpu_mlsl_short_segments.py -x -q -m gpu -p no:cacheprovider > $O/staged_mlsl_seg.log 2>&1; echo "staged mlsl short segments rc=$? $(tail -1 $O/staged_mlsl_seg.log)"
-for seg in 1024 256 64 16; do
-  line "mlsl config 4 amd_mlsl_seg_regens=$seg"          --workload mlsl --no-cpu-baseline --param amd_mlsl_seg_regens=$seg
-done
-for rep in 1 2; do
-  line "isres config 3 default"                      --workload isres --no-cpu-baseline
-  line "isres config 3 amd_isres_rank_prefetch=1"     --workload isres --no-cpu-baseline --param amd_isres_rank_prefetch=1
-  line "isres config 3 amd_isres_fast_scan=1"         --workload isres --no-cpu-baseline --param amd_isres_fast_scan=1
-  line "isres config 3 fast scan + rank prefetch"     --workload isres --no-cpu-baseline --param amd_isres_fast_scan=1 --param amd_isres_rank_prefetch=1
-done
-for n in 512; do
-  line "crs n=$n default (windows + resolver)"        --n $n --obj rastrigin --headline-only --no-cpu-baseline
-  line "crs n=$n amd_max_spec=256"                    --n $n --obj rastrigin --headline-only --no-cpu-baseline --max-spec 256
-  line "crs n=$n amd_chain_resolver=0"                --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_chain_resolver=0
-  line "crs n=$n amd_forward=0"                       --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=0
-done
-for n in 64 128 256; do
-  line "crs n=$n default (conservative passes)"       --n $n --obj rastrigin --headline-only --no-cpu-baseline
-  line "crs n=$n windows + resolver"                  --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=1 --param amd_chain_resolver=1
-  line "crs n=$n windows + resolver, 256 slots"       --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=1 --param amd_chain_resolver=1 --max-spec 256
-done
-for rep in 1 2; do
-  line "crs headline default (lock version)"          --headline-only --no-cpu-baseline --steps 10 --warmup 2
-  line "crs headline amd_chain_resolver=1"            --headline-only --no-cpu-baseline --steps 10 --warmup 2 --param amd_chain_resolver=1
-  line "crs headline resolver, 256 slots"             --headline-only --no-cpu-baseline --steps 10 --warmup 2 --param amd_chain_resolver=1 --max-spec 256
-done
-timeout -k 5 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$? $(head -c 300 $O/bench_default.json)"
+if [ "$PART" = 1 ] || [ "$PART" = all ]; then
+  timeout -k 5 600 python -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $O/gpu_suite.log 2>&1; echo "suite rc=$? $(tail -1 $O/gpu_suite.log)"
+  staged staged_resolver_small 300 tests/staged/test_gpu_chain_resolver_small.py
+  staged staged_isres 240 tests/staged/test_gpu_isres_rank_prefetch.py
+  staged staged_isres_scan 300 tests/staged/test_gpu_isres_fast_scan.py
+  staged staged_mlsl_seg 300 tests/staged/test_gpu_mlsl_short_segments.py
+  for rep in 1 2; do
+    line "isres config 3 default"                      --workload isres --no-cpu-baseline
+    line "isres config 3 amd_isres_rank_prefetch=1"     --workload isres --no-cpu-baseline --param amd_isres_rank_prefetch=1
+    line "isres config 3 amd_isres_fast_scan=1"         --workload isres --no-cpu-baseline --param amd_isres_fast_scan=1
+    line "isres config 3 fast scan + rank prefetch"     --workload isres --no-cpu-baseline --param amd_isres_fast_scan=1 --param amd_isres_rank_prefetch=1
+  done
+  for seg in 1024 256 64 16; do
+    line "mlsl config 4 amd_mlsl_seg_regens=$seg"       --workload mlsl --no-cpu-baseline --param amd_mlsl_seg_regens=$seg
+  done
+fi
+if [ "$PART" = 2 ] || [ "$PART" = all ]; then
+  for n in 512; do
+    line "crs n=$n default (windows + resolver)"        --n $n --obj rastrigin --headline-only --no-cpu-baseline
+    line "crs n=$n amd_max_spec=256"                    --n $n --obj rastrigin --headline-only --no-cpu-baseline --max-spec 256
+    line "crs n=$n amd_chain_resolver=0"                --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_chain_resolver=0
+    line "crs n=$n amd_forward=0"                       --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=0
+  done
+  for n in 64 128 256; do
+    line "crs n=$n default (conservative passes)"       --n $n --obj rastrigin --headline-only --no-cpu-baseline
+    line "crs n=$n windows + resolver"                  --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=1 --param amd_chain_resolver=1
+    line "crs n=$n windows + resolver, 256 slots"       --n $n --obj rastrigin --headline-only --no-cpu-baseline --param amd_forward=1 --param amd_chain_resolver=1 --max-spec 256
+  done
+  for rep in 1 2; do
+    line "crs headline default (lock version)"          --headline-only --no-cpu-baseline --steps 10 --warmup 2
+    line "crs headline amd_chain_resolver=1"            --headline-only --no-cpu-baseline --steps 10 --warmup 2 --param amd_chain_resolver=1
+    line "crs headline resolver, 256 slots"             --headline-only --no-cpu-baseline --steps 10 --warmup 2 --param amd_chain_resolver=1 --max-spec 256
+  done
+  timeout -k 5 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$? $(head -c 300 $O/bench_default.json)"
+fi
