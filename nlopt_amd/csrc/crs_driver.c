@@ -44,11 +44,25 @@
 #include <string.h>
 
 /* ---- ordered set over rows keyed (f, row): max-heap for the worst + tracked argmin ----------- */
+/* What the chain asks of it: the worst row (crs.c:134 reads the tree's maximum), "the worst row got a smaller value" once per accepted
+ * trial (crs.c:153-154: the node is re-inserted), the K worst rows in order once per window, the best row.  The walk below runs on the
+ * host between two launches — the device idles meanwhile — and with a binary heap of row indices keyed through F[] the sift-down
+ * after an acceptance was most of it: 17 levels x three dependent cache misses (two child indices, two values) = 0.5 us per accepted
+ * trial at N = 1e5, 61 of the 73 us between two 128-slot windows (measured over the emulated device, round 4).  So: a 4-ARY heap with
+ * the KEY STORED IN THE NODE, the four children of a node in ONE 64-byte line (node i lives in slot i + 3 of a 64-byte-aligned array:
+ * children 4i+1 .. 4i+4 are slots 4i+4 .. 4i+7), and the grandchildren's lines prefetched while the children are compared: 9 levels,
+ * one miss each, overlapped.  The order is the same total order (f, then row index: crs_compare, crs.c:51-56), so the worst row, the
+ * K worst in order and every decision are what the binary heap — and the reference's red-black tree — give. */
+typedef struct { double f; int64_t row; } osnode;
 typedef struct {
-    const double *F;
-    int64_t *heap, nheap, best;
-    int64_t *cand;      /* scratch for top-k */
+    const double *F;     /* the rows' values (the copy everything else reads); a node's f is F[row] */
+    osnode *node;        /* 64-byte aligned; heap position i is node[i + 3] */
+    void *mem;
+    int64_t nheap, best;
+    void *cand;          /* scratch for top-k: 2 K + 2 candidates ... */
+    int64_t *gpos;       /* ... and 4 (K + 1) positions: the sorted children of every visited node */
 } ordset;
+#define OSN(s, i) ((s)->node[(i) + 3])
 
 static inline int key_less(const double *F, int64_t a, int64_t b)       /* crs_compare, crs.c:51-56 */
 {
@@ -56,71 +70,220 @@ static inline int key_less(const double *F, int64_t a, int64_t b)       /* crs_c
     if (F[a] > F[b]) return 0;
     return a < b;
 }
+static inline int node_less(const osnode a, const osnode b)              /* the same on keys held in the nodes */
+{
+    if (a.f < b.f) return 1;
+    if (a.f > b.f) return 0;
+    return a.row < b.row;
+}
+
+static int os_alloc(ordset *s, int64_t N, int kmax)
+{
+    s->mem = malloc(sizeof(osnode) * (size_t) (N + 8) + 64);
+    s->cand = malloc(32 * (size_t) (2 * kmax + 4));          /* (sizeof(oscand) = 24) */
+    s->gpos = (int64_t *) malloc(sizeof(int64_t) * 4 * (size_t) (kmax + 2));
+    if (!s->mem || !s->cand || !s->gpos) return -1;
+    s->node = (osnode *) (((uintptr_t) s->mem + 63u) & ~(uintptr_t) 63u);
+    s->nheap = 0; s->best = 0;
+    return 0;
+}
+static void os_free(ordset *s) { free(s->mem); free(s->cand); free(s->gpos); s->mem = NULL; s->cand = NULL; s->gpos = NULL; s->node = NULL; }
+static inline int64_t os_worst(const ordset *s) { return OSN(s, 0).row; }
 
 static void os_push(ordset *s, int64_t row)
 {
+    const osnode v = { s->F[row], row };
     int64_t pos = s->nheap++;
     while (pos > 0) {
-        int64_t par = (pos - 1) / 2;
-        if (!key_less(s->F, s->heap[par], row)) break;
-        s->heap[pos] = s->heap[par];
+        const int64_t par = (pos - 1) / 4;
+        if (!node_less(OSN(s, par), v)) break;
+        OSN(s, pos) = OSN(s, par);
         pos = par;
     }
-    s->heap[pos] = row;
+    OSN(s, pos) = v;
     if (s->nheap == 1 || key_less(s->F, row, s->best)) s->best = row;
 }
 
-static void os_top_changed(ordset *s)        /* key of heap[0] decreased: restore the heap */
+static void os_top_changed(ordset *s)        /* F[worst row] decreased: take the new key, restore the heap */
 {
-    int64_t pos = 0, v = s->heap[0];
+    const int64_t n = s->nheap;
+    int64_t pos = 0;
+    osnode v = OSN(s, 0);
+    v.f = s->F[v.row];
     for (;;) {
-        int64_t c = 2 * pos + 1;
-        if (c >= s->nheap) break;
-        if (c + 1 < s->nheap && key_less(s->F, s->heap[c], s->heap[c + 1])) ++c;
-        if (!key_less(s->F, v, s->heap[c])) break;
-        s->heap[pos] = s->heap[c];
-        pos = c;
+        const int64_t c = 4 * pos + 1;
+        int64_t m = c, q, end = c + 4 < n ? c + 4 : n;
+        if (c >= n) break;
+        if (16 * pos + 5 < n) {              /* the sixteen grandchildren: four lines, one of which the next level reads */
+            const char *g = (const char *) &OSN(s, 16 * pos + 5);
+            __builtin_prefetch(g); __builtin_prefetch(g + 64); __builtin_prefetch(g + 128); __builtin_prefetch(g + 192);
+        }
+        for (q = c + 1; q < end; ++q) if (node_less(OSN(s, m), OSN(s, q))) m = q;
+        if (!node_less(v, OSN(s, m))) break;
+        OSN(s, pos) = OSN(s, m);
+        pos = m;
     }
-    s->heap[pos] = v;
+    OSN(s, pos) = v;
 }
 
-/* the k largest rows, worst first, without disturbing the heap: best-first walk over heap nodes */
-static int os_topk(ordset *s, int k, int64_t *out)
+/* the k largest rows, worst first, without disturbing the heap: best-first walk over heap nodes.  The candidates are kept in a small
+ * binary max-heap with their keys inline; the four children of a visited node enter it ONE AT A TIME — sorted once, the largest now,
+ * each next one when its elder sibling is taken — so a visit costs two insertions, not four. */
+typedef struct { osnode key; int32_t grp, idx; } oscand;
+static int os_topk(ordset *s, int k, int64_t *out, int64_t *out_pos, double *out_f)
 {
-    int64_t *c = s->cand;      /* small max-heap of heap positions */
-    int nc = 0, got = 0;
-    if (s->nheap == 0) return 0;
-    c[nc++] = 0;
+    oscand *c = (oscand *) s->cand;          /* 2 k + 2 candidates, then the sibling groups: 4 positions per visited node */
+    int64_t *gpos = s->gpos;
+    int nc = 0, got = 0, ng = 0;
+    if (s->nheap == 0 || k <= 0) return 0;
+#define CAND_PUSH(KEY, G, I) do { const osnode kv_ = (KEY); int pos_ = nc++;                                    \
+        while (pos_ > 0) { const int par_ = (pos_ - 1) / 2; if (!node_less(c[par_].key, kv_)) break; c[pos_] = c[par_]; pos_ = par_; } \
+        c[pos_].key = kv_; c[pos_].grp = (G); c[pos_].idx = (I); } while (0)
+    gpos[0] = 0; gpos[1] = gpos[2] = gpos[3] = -1; ng = 1;       /* group 0: the root alone */
+    CAND_PUSH(OSN(s, 0), 0, 0);
     while (got < k && nc > 0) {
-        int64_t p = c[0];
-        out[got++] = s->heap[p];
+        const oscand top = c[0];
+        const int64_t p = gpos[4 * top.grp + top.idx];
+        if (out_pos) out_pos[got] = p;
+        if (out_f) out_f[got] = top.key.f;
+        out[got++] = top.key.row;
         /* pop */
-        int64_t lastp = c[--nc];
-        if (nc > 0) {
-            int pos = 0;
-            for (;;) {
-                int ch = 2 * pos + 1;
-                if (ch >= nc) break;
-                if (ch + 1 < nc && key_less(s->F, s->heap[c[ch]], s->heap[c[ch + 1]])) ++ch;
-                if (!key_less(s->F, s->heap[lastp], s->heap[c[ch]])) break;
-                c[pos] = c[ch];
-                pos = ch;
+        {
+            const oscand last = c[--nc];
+            if (nc > 0) {
+                int pos = 0;
+                for (;;) {
+                    int ch = 2 * pos + 1;
+                    if (ch >= nc) break;
+                    if (ch + 1 < nc && node_less(c[ch].key, c[ch + 1].key)) ++ch;
+                    if (!node_less(last.key, c[ch].key)) break;
+                    c[pos] = c[ch];
+                    pos = ch;
+                }
+                c[pos] = last;
             }
-            c[pos] = lastp;
         }
-        for (int64_t child = 2 * p + 1; child <= 2 * p + 2; ++child) {
-            if (child >= s->nheap) break;
-            int pos = nc++;
-            while (pos > 0) {
-                int par = (pos - 1) / 2;
-                if (!key_less(s->F, s->heap[c[par]], s->heap[child])) break;
-                c[pos] = c[par];
-                pos = par;
+        if (got == k) break;
+        if (top.idx < 3 && gpos[4 * top.grp + top.idx + 1] >= 0)                       /* its next sibling */
+            CAND_PUSH(OSN(s, gpos[4 * top.grp + top.idx + 1]), top.grp, top.idx + 1);
+        if (4 * p + 1 < s->nheap) {                                                    /* its children, largest first */
+            int64_t *g = gpos + 4 * ng;
+            const int64_t c0 = 4 * p + 1, end = c0 + 4 < s->nheap ? c0 + 4 : s->nheap;
+            int m = 0, i, j;
+            for (int64_t q = c0; q < end; ++q) {
+                for (i = m; i > 0 && node_less(OSN(s, g[i - 1]), OSN(s, q)); --i) g[i] = g[i - 1];
+                g[i] = q; ++m;
             }
-            c[pos] = child;
+            for (j = m; j < 4; ++j) g[j] = -1;
+            CAND_PUSH(OSN(s, g[0]), ng, 0);
+            ++ng;
         }
     }
+#undef CAND_PUSH
     return got;
+}
+
+/* Heap positions whose rows got smaller values (F[] holds them), `cnt` of them ordered by DECREASING LEVEL: restore the heap.
+ * Floyd's order — deeper nodes first — makes every sift-down meet valid sub-heaps; nodes of one level have disjoint subtrees, so
+ * their sift-downs are run INTERLEAVED, one level per turn each, the children's line of a hole prefetched a turn ahead: the misses of
+ * up to 64 walks overlap instead of queueing behind one another (a lone sift-down is nine dependent misses). */
+static void os_repair(ordset *s, const int64_t *posdesc, int cnt)
+{
+    const int64_t n = s->nheap;
+    int i = 0;
+    while (i < cnt) {
+        int64_t hole[64], lo = 0, hi = 1;
+        osnode v[64];
+        int nb = 0, b;
+        while (posdesc[i] >= hi) { lo = hi; hi = 4 * hi + 1; }          /* level of the deepest position left: [lo, hi) */
+        while (i < cnt && nb < 64 && posdesc[i] >= lo) {
+            hole[nb] = posdesc[i]; v[nb] = OSN(s, posdesc[i]); v[nb].f = s->F[v[nb].row];
+            if (4 * hole[nb] + 1 < n) __builtin_prefetch(&OSN(s, 4 * hole[nb] + 1));
+            ++nb; ++i;
+        }
+        while (nb > 0) {
+            for (b = 0; b < nb; ) {
+                const int64_t c = 4 * hole[b] + 1, end = c + 4 < n ? c + 4 : n;
+                int64_t m = c, q;
+                int settled = c >= n;
+                if (!settled) {
+                    for (q = c + 1; q < end; ++q) if (node_less(OSN(s, m), OSN(s, q))) m = q;
+                    settled = !node_less(v[b], OSN(s, m));
+                }
+                if (settled) { OSN(s, hole[b]) = v[b]; --nb; hole[b] = hole[nb]; v[b] = v[nb]; continue; }
+                OSN(s, hole[b]) = OSN(s, m);
+                hole[b] = m;
+                if (4 * m + 1 < n) __builtin_prefetch(&OSN(s, 4 * m + 1));
+                ++b;
+            }
+        }
+    }
+}
+
+/* ---- the worst row DURING a window's walk, without touching the heap ---------------------------------------------------------
+ * At the start of a window the nW worst rows are known in order (W, with their heap positions and values).  Only worst rows are ever
+ * replaced, so while the walk consumes the window the current worst row is W[wp], or a row replaced earlier in this window whose new
+ * value still lies above the list's last entry ("extras": the statement chain_resolve makes on the device, hip/crs_chain.hip) — no heap
+ * operation per accepted trial.  The heap is repaired ONCE per window for all the rows that changed (os_repair).  If the list runs out
+ * while rows outside it may be the worst (wp == nW, no extras), the tracker repairs the heap and hands over to it for the rest of
+ * the window (direct mode: the sift-down per acceptance that used to be the only mode). */
+typedef struct {
+    int nW, wp, nex, direct;
+    double thr_f; int64_t thr_row;          /* the list's last entry as it was when the window started */
+    int64_t *W, *pos, *ex;                  /* rows, their heap positions; rows among the extras (all Kmax long) */
+    int64_t *scratch;                       /* Kmax positions */
+    signed char *lev;                       /* Kmax heap levels */
+} wtrack;
+
+static void wt_flush(wtrack *t, ordset *s)
+{
+    /* rows W[0 .. wp) changed (the extras are among them): positions in decreasing order, then one repair */
+    int i, j, cnt = t->wp;
+    if (t->direct || cnt <= 0) { t->wp = 0; t->nex = 0; return; }
+    {   /* decreasing LEVEL is all os_repair needs (the nodes of a level are independent): a counting sort over the levels */
+        int lvcnt[40] = { 0 }, lvoff[40], nl = 0;
+        for (i = 0; i < cnt; ++i) { int64_t hi = 1; int l = 0; while (t->pos[i] >= hi) { hi = 4 * hi + 1; ++l; } t->lev[i] = (signed char) l; ++lvcnt[l]; if (l + 1 > nl) nl = l + 1; }
+        for (j = nl - 1, i = 0; j >= 0; --j) { lvoff[j] = i; i += lvcnt[j]; }
+        for (i = 0; i < cnt; ++i) t->scratch[lvoff[(int) t->lev[i]]++] = t->pos[i];
+    }
+    os_repair(s, t->scratch, cnt);
+    t->wp = 0; t->nex = 0;
+}
+
+static void wt_begin(wtrack *t, const ordset *s, int nW, const double *Wf)
+{
+    t->nW = nW; t->wp = 0; t->nex = 0; t->direct = 0;
+    if (nW > 0) { t->thr_f = Wf[nW - 1]; t->thr_row = t->W[nW - 1]; }
+    (void) s;
+}
+
+/* the current worst row; *xi = its index among the extras or -1 */
+static int64_t wt_worst(wtrack *t, ordset *s, int *xi)
+{
+    const double *F = s->F;
+    int64_t rw = -1;
+    int e;
+    *xi = -1;
+    if (t->direct) return os_worst(s);
+    if (t->wp < t->nW) rw = t->W[t->wp];
+    for (e = 0; e < t->nex; ++e) if (rw < 0 || key_less(F, rw, t->ex[e])) { rw = t->ex[e]; *xi = e; }
+    if (rw < 0) {                                             /* beyond the rows this window knows: the heap takes over */
+        wt_flush(t, s);
+        t->direct = 1;
+        return os_worst(s);
+    }
+    return rw;
+}
+
+/* row `worst` (what wt_worst returned, with its xi) has just been given a smaller value in F[] */
+static void wt_accepted(wtrack *t, ordset *s, int64_t worst, int xi)
+{
+    const double f = s->F[worst];
+    if (t->direct) { os_top_changed(s); return; }
+    if (xi >= 0) t->ex[xi] = t->ex[--t->nex];
+    else ++t->wp;
+    /* still above the list's last entry as it stood at the start of the window (key order: f, then row)? then it can be the worst again */
+    if (t->nW > 0 && (t->thr_f < f || (!(t->thr_f > f) && t->thr_row < worst))) t->ex[t->nex++] = worst;
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -197,6 +360,7 @@ struct nla_crs_session {
     uint64_t *cblock;
     int32_t *ckind;
     int64_t *W, *crow;
+    wtrack wt;                     /* the worst row during a window's walk (W is its list) */
     /* device-resolved windows */
     int forward;
     double *Wf;                    /* f of the rows W */
@@ -208,8 +372,8 @@ struct nla_crs_session {
 static void session_free(nla_crs_session *S)
 {
     if (!S) return;
-    free(S->rs.F); free(S->rs.os.heap); free(S->rs.os.cand); free(S->rs.xtmp);
-    free(S->status); free(S->tprev); free(S->W); free(S->cblock); free(S->ckind); free(S->crow);
+    free(S->rs.F); os_free(&S->rs.os); free(S->rs.xtmp);
+    free(S->status); free(S->tprev); free(S->W); free(S->wt.pos); free(S->wt.ex); free(S->wt.scratch); free(S->wt.lev); free(S->cblock); free(S->ckind); free(S->crow);
     free(S->Wf); free(S->fwcnt); free(S->fwrec); free(S->lastw);
     free(S);
 }
@@ -257,23 +421,27 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     rs->need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);
 
     rs->F = (double *) malloc(sizeof(double) * (size_t) N);
-    rs->os.heap = (int64_t *) malloc(sizeof(int64_t) * (size_t) N);
-    rs->os.cand = (int64_t *) malloc(sizeof(int64_t) * (size_t) (2 * S->Kmax + 8));
+    const int os_bad = os_alloc(&rs->os, N, S->Kmax);
     rs->xtmp = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
     S->status = (nla_crs_slot_status *) malloc(sizeof(nla_crs_slot_status) * (size_t) S->Kmax);
     S->tprev = (int32_t *) calloc(TRING, sizeof(int32_t));
     S->W = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
+    S->wt.pos = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
+    S->wt.ex = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
+    S->wt.scratch = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
+    S->wt.lev = (signed char *) malloc((size_t) S->Kmax);
+    S->wt.W = S->W;
     S->cblock = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) S->Kmax);
     S->ckind = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
     S->crow = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
+    S->Wf = (double *) malloc(sizeof(double) * (size_t) S->Kmax);
     if (S->forward) {
-        S->Wf = (double *) malloc(sizeof(double) * (size_t) S->Kmax);
         S->fwcnt = (uint32_t *) calloc((size_t) S->Kmax, sizeof(uint32_t));
         S->fwrec = (uint32_t *) calloc((size_t) S->Kmax * FWCAP, sizeof(uint32_t));
         S->lastw = (uint64_t *) calloc((size_t) N, sizeof(uint64_t));
     }
-    if (!rs->F || !rs->os.heap || !rs->os.cand || !rs->xtmp || !S->status || !S->tprev || !S->W || !S->cblock ||
-        !S->ckind || !S->crow || (S->forward && (!S->Wf || !S->fwcnt || !S->fwrec || !S->lastw))) {
+    if (!rs->F || os_bad || !rs->xtmp || !S->status || !S->tprev || !S->W || !S->wt.pos || !S->wt.ex || !S->wt.scratch || !S->wt.lev || !S->Wf || !S->cblock ||
+        !S->ckind || !S->crow || (S->forward && (!S->fwcnt || !S->fwrec || !S->lastw))) {
         session_free(S);
         *ret_out = NLOPT_OUT_OF_MEMORY;
         return NULL;
@@ -360,14 +528,15 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             S->fresh_from - S->block <= (uint64_t) S->Kmax)
             K = (int) (S->fresh_from - S->block);
         nW = K < N ? K : (int) N;
-        nW = os_topk(&rs->os, nW, W);
+        nW = os_topk(&rs->os, nW, W, S->wt.pos, S->Wf);
+        wt_begin(&S->wt, &rs->os, nW, S->Wf);
+        if (S->forward) for (a = 0; a < nW; ++a) __builtin_prefetch(&S->lastw[W[a]], 1);   /* the walk writes a record per replaced row */
         const double t_eng0 = st ? nla_seconds() : 0.;
         const uint64_t gl0 = st ? st->gather_launches : 0;
         if (S->forward) {
             /* every slot of the window is computed in this launch; what an earlier window left unconsumed is dropped */
             if (st && S->fresh_from > S->block) st->slots_invalid += S->fresh_from - S->block;
             S->fresh_from = S->block;
-            for (a = 0; a < nW; ++a) S->Wf[a] = rs->F[W[a]];
             if (ops->chain(e, S->block, K, rs->os.best, rs->F[rs->os.best], W, S->Wf, nW, status, S->fwcnt, S->fwrec, FWCAP)) { engine_failed(S); return S->ret; }
         } else
         {
@@ -398,7 +567,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
 
         while (j < K && ret == NLOPT_SUCCESS) {
             int64_t worst;
-            int kind = 1, accepted = 0;
+            int kind = 1, accepted = 0, xi = -1;
             double fcand;
             const uint64_t blk = S->block + (uint64_t) j;
             if (best_changed) break;
@@ -424,7 +593,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 }
             }
             if (st) ++st->slots_used;
-            worst = rs->os.heap[0];
+            worst = wt_worst(&S->wt, &rs->os, &xi);
             /* reflection trial of block blk */
             if (host_eval) {
                 if (ops->read_slot(e, blk, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
@@ -466,7 +635,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 }
                 /* memcpy(worst->k, d->p) + resort (crs.c:153-154); the row write is deferred */
                 rs->F[worst] = fcand;
-                os_top_changed(&rs->os);
+                wt_accepted(&S->wt, &rs->os, worst, xi);
                 trace_add(pb, fcand, worst, kind, 1);
                 if (st) ++st->accepted;
                 cblock[ncommit] = blk; ckind[ncommit] = host_eval ? 1 : kind; crow[ncommit] = worst; ++ncommit;
@@ -477,6 +646,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             }
             j += (kind == 2) ? 2 : 1;
         }
+        wt_flush(&S->wt, &rs->os);                      /* the heap takes the window's replacements, all at once */
         S->block += (uint64_t) j;
         if (best_changed) {
             /* every slot in flight started from the old best row: forget them all */

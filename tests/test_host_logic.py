@@ -219,6 +219,32 @@ def test_dedicated_chain_resolver_takes_the_lock_versions_decisions():
         os.remove(exe)
 
 
+def test_ordered_set_and_window_tracker_against_a_plain_array():
+    """crs_driver.c's ordered set (4-ary max-heap, keys in the nodes, batch repair once per window) and the tracker that names the worst
+    row during a window's walk without a heap operation per accepted trial — the file is #included by tools/ordset_check.c, so these are
+    the product's static functions — against the row with the largest (f, row) key of a plain array: populations with ties everywhere,
+    populations smaller than the window, walks that run past their list (hand-over to the heap), values landing among the window's worst
+    rows; after every window the heap is a heap over every row with node key == F[row]."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu = os.path.join(root, "oracle", "libnlopt_amd_emu.so")
+    if not shutil.which("gcc") or not os.path.exists(emu):
+        pytest.skip("no gcc / no emulated library here")
+    out = os.path.join(root, "tools", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "ordset_check.%d" % os.getpid())
+    subprocess.run(["gcc", "-O1", "-std=gnu11", "-ffp-contract=off", "-I", os.path.join(root, "nlopt_amd", "csrc"), "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tools", "ordset_check.c"), "-o", exe, "-L", os.path.join(root, "oracle"), "-l:libnlopt_amd_emu.so", "-lm",
+                    "-Wl,-rpath," + os.path.join(root, "oracle")], check=True)
+    try:
+        for seed in ("1", "2", "3"):
+            r = subprocess.run([exe, "250", seed], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and r.stdout.startswith("ok 250"), r.stdout + r.stderr
+    finally:
+        os.remove(exe)
+
+
 def test_fast_evolve_scan_counts_what_the_exact_scan_counts():
     """hip/isres_scan_fast.h — the lane walk of ev2_scan_fast_kernel (opt-in "amd_isres_fast_scan", not yet run on a device): sigma' from
     staged factors and a decision with a margin, the exact expressions inside the margin — compiled by g++ against the exact scan's lane

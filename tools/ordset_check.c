@@ -1,0 +1,111 @@
+/* tools/ordset_check.c — CPU check of the ordered set and the window tracker of crs_driver.c (development tooling; tests/test_host_logic.py
+ * builds and runs it).  The file is INCLUDED, so the static functions under test are the product's: os_push / os_topk / os_repair /
+ * os_top_changed (a 4-ary max-heap with the keys in the nodes) and wt_begin / wt_worst / wt_accepted / wt_flush (the worst row during a
+ * window's walk without a heap operation per accepted trial).  Against the obvious statement — the row with the largest (f, row) key of
+ * a plain array — for drawn populations with MANY TIES (values from a handful of integers), populations smaller than the window (the
+ * list is the whole population), windows that run past their list (the tracker hands over to the heap), values that land among the
+ * window's worst rows again and again (extras), acceptance rates from 5 % to 100 %; after every window the heap must be a heap, hold
+ * every row once, and every node's key must be F[row].
+ *   gcc -O1 -std=gnu11 -I nlopt_amd/csrc -I include tools/ordset_check.c -o tools/_build/ordset_check -L oracle -l:libnlopt_amd_emu.so -lm
+ *   tools/_build/ordset_check [rounds] [seed]        -> "ok ..." / the first difference; exit code 0 / 1 */
+#include "../nlopt_amd/csrc/crs_driver.c"
+#include <stdio.h>
+
+static uint64_t rs_ = 88172645463325252ULL;
+static uint64_t rnd(void) { rs_ ^= rs_ << 13; rs_ ^= rs_ >> 7; rs_ ^= rs_ << 17; return rs_; }
+static double urand(void) { return (double) (rnd() >> 11) * (1.0 / 9007199254740992.0); }
+
+static int64_t naive_worst(const double *F, int64_t N)
+{
+    int64_t w = 0;
+    for (int64_t i = 1; i < N; ++i) if (key_less(F, w, i)) w = i;
+    return w;
+}
+static const double *g_F;
+static int cmp_desc(const void *a, const void *b)
+{
+    const int64_t x = *(const int64_t *) a, y = *(const int64_t *) b;
+    return key_less(g_F, x, y) ? 1 : (key_less(g_F, y, x) ? -1 : 0);
+}
+
+static int check_heap(const ordset *s, int64_t N)
+{
+    char *seen = (char *) calloc((size_t) N, 1);
+    int bad = 0;
+    for (int64_t i = 0; i < s->nheap && !bad; ++i) {
+        const osnode v = OSN(s, i);
+        if (v.row < 0 || v.row >= N || seen[v.row]) { printf("node %ld holds row %ld (out of range or twice)\n", (long) i, (long) v.row); bad = 1; break; }
+        seen[v.row] = 1;
+        if (!(v.f == s->F[v.row])) { printf("node %ld: key %g, F[%ld] = %g\n", (long) i, v.f, (long) v.row, s->F[v.row]); bad = 1; }
+        if (i > 0 && node_less(OSN(s, (i - 1) / 4), v)) { printf("node %ld larger than its parent\n", (long) i); bad = 1; }
+    }
+    if (!bad && s->nheap != N) { printf("%ld nodes for %ld rows\n", (long) s->nheap, (long) N); bad = 1; }
+    free(seen);
+    return bad;
+}
+
+int main(int argc, char **argv)
+{
+    const int rounds = argc > 1 ? atoi(argv[1]) : 300;
+    unsigned long long windows = 0, accepts = 0, extras = 0, handovers = 0, ties = 0;
+    if (argc > 2) rs_ ^= strtoull(argv[2], NULL, 10) * 0x9E3779B97F4A7C15ULL;
+    for (int r = 0; r < rounds; ++r) {
+        const int64_t N = r % 9 == 0 ? 1 + (int64_t) (rnd() % 40) : 1 + (int64_t) (rnd() % 3000);
+        const int Kmax = 1 + (int) (rnd() % 300);
+        const int levels = r % 3 == 0 ? 3 : (r % 3 == 1 ? 50 : 0);          /* 3 / 50 distinct values (ties everywhere) / continuous */
+        double *F = (double *) malloc(sizeof(double) * (size_t) N);
+        int64_t *sorted = (int64_t *) malloc(sizeof(int64_t) * (size_t) N);
+        ordset os;
+        wtrack wt;
+        double *Wf = (double *) malloc(sizeof(double) * (size_t) Kmax);
+        memset(&os, 0, sizeof os); memset(&wt, 0, sizeof wt);
+        if (os_alloc(&os, N, Kmax)) return 2;
+        os.F = F;
+        wt.W = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax); wt.pos = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax);
+        wt.ex = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax); wt.scratch = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax);
+        wt.lev = (signed char *) malloc((size_t) Kmax);
+        for (int64_t i = 0; i < N; ++i) { F[i] = levels ? (double) (rnd() % (unsigned) levels) : urand(); os_push(&os, i); }
+        if (check_heap(&os, N)) { printf("after the pushes (round %d, N %ld)\n", r, (long) N); return 1; }
+        if (os.best != ({ int64_t b = 0; for (int64_t i = 1; i < N; ++i) if (key_less(F, i, b)) b = i; b; })) { printf("best row wrong after the pushes (round %d)\n", r); return 1; }
+        for (int w = 0; w < 12; ++w) {
+            const int K = 1 + (int) (rnd() % (unsigned) Kmax);
+            const double pacc = w % 4 == 0 ? 1.0 : (w % 4 == 1 ? 0.05 : urand());
+            const int mode = (int) (rnd() % 3);                                 /* where accepted values land: anywhere below / just below the worst / far below */
+            int nW = K < N ? K : (int) N, got, trials = K + (w % 5 == 0 ? K : 0);  /* some walks run past their list */
+            got = os_topk(&os, nW, wt.W, wt.pos, Wf);
+            for (int64_t i = 0; i < N; ++i) sorted[i] = i;
+            g_F = F; qsort(sorted, (size_t) N, sizeof(int64_t), cmp_desc);
+            if (got != nW) { printf("top-k returned %d of %d (round %d)\n", got, nW, r); return 1; }
+            for (int a = 0; a < nW; ++a)
+                if (wt.W[a] != sorted[a] || OSN(&os, wt.pos[a]).row != wt.W[a] || Wf[a] != F[wt.W[a]]) {
+                    printf("top-k entry %d: row %ld at node %ld (key %g), the %d-th worst row is %ld (round %d, N %ld, K %d)\n", a, (long) wt.W[a], (long) wt.pos[a], Wf[a], a, (long) sorted[a], r, (long) N, K);
+                    return 1;
+                }
+            wt_begin(&wt, &os, nW, Wf);
+            ++windows;
+            for (int t = 0; t < trials; ++t) {
+                int xi;
+                const int was_direct = wt.direct;
+                const int64_t worst = wt_worst(&wt, &os, &xi), nw = naive_worst(F, N);
+                if (!was_direct && wt.direct) ++handovers;
+                if (worst != nw) { printf("worst row %ld, the array says %ld (round %d window %d trial %d: N %ld K %d wp %d extras %d direct %d)\n", (long) worst, (long) nw, r, w, t, (long) N, K, wt.wp, wt.nex, wt.direct); return 1; }
+                if (urand() < pacc) {
+                    double v;
+                    if (levels) { v = F[worst] - (double) (mode == 1 ? 1 : 1 + rnd() % 3); ++ties; }
+                    else v = mode == 1 ? F[worst] * (1.0 - 1e-3 * urand()) : (mode == 2 ? F[worst] * 0.01 * urand() : F[worst] * urand());
+                    if (!(v < F[worst])) continue;
+                    F[worst] = v;
+                    { const int nex0 = wt.nex; wt_accepted(&wt, &os, worst, xi); if (wt.nex > nex0 - (xi >= 0)) ++extras; }
+                    ++accepts;
+                }
+            }
+            wt_flush(&wt, &os);
+            if (check_heap(&os, N)) { printf("after window %d of round %d (N %ld, K %d)\n", w, r, (long) N, K); return 1; }
+        }
+        free(F); free(sorted); free(Wf); os_free(&os); free(wt.W); free(wt.pos); free(wt.ex); free(wt.scratch); free(wt.lev);
+    }
+    if (!extras || !handovers || !ties) { printf("the draws never reached extras (%llu), a hand-over to the heap (%llu) or ties (%llu): the check checks too little\n", extras, handovers, ties); return 1; }
+    printf("ok %d populations, %llu windows, %llu accepted replacements (%llu landed among the window's worst rows, %llu with tied values), %llu hand-overs to the heap\n",
+           rounds, windows, accepts, extras, ties, handovers);
+    return 0;
+}
