@@ -88,7 +88,6 @@ static int os_alloc(ordset *s, int64_t N, int kmax)
     return 0;
 }
 static void os_free(ordset *s) { free(s->mem); free(s->cand); free(s->gpos); s->mem = NULL; s->cand = NULL; s->gpos = NULL; s->node = NULL; }
-static inline int64_t os_worst(const ordset *s) { return OSN(s, 0).row; }
 
 static void os_push(ordset *s, int64_t row)
 {
@@ -102,28 +101,6 @@ static void os_push(ordset *s, int64_t row)
     }
     OSN(s, pos) = v;
     if (s->nheap == 1 || key_less(s->F, row, s->best)) s->best = row;
-}
-
-static void os_top_changed(ordset *s)        /* F[worst row] decreased: take the new key, restore the heap */
-{
-    const int64_t n = s->nheap;
-    int64_t pos = 0;
-    osnode v = OSN(s, 0);
-    v.f = s->F[v.row];
-    for (;;) {
-        const int64_t c = 4 * pos + 1;
-        int64_t m = c, q, end = c + 4 < n ? c + 4 : n;
-        if (c >= n) break;
-        if (16 * pos + 5 < n) {              /* the sixteen grandchildren: four lines, one of which the next level reads */
-            const char *g = (const char *) &OSN(s, 16 * pos + 5);
-            __builtin_prefetch(g); __builtin_prefetch(g + 64); __builtin_prefetch(g + 128); __builtin_prefetch(g + 192);
-        }
-        for (q = c + 1; q < end; ++q) if (node_less(OSN(s, m), OSN(s, q))) m = q;
-        if (!node_less(v, OSN(s, m))) break;
-        OSN(s, pos) = OSN(s, m);
-        pos = m;
-    }
-    OSN(s, pos) = v;
 }
 
 /* the k largest rows, worst first, without disturbing the heap: best-first walk over heap nodes.  The candidates are kept in a small
@@ -220,70 +197,113 @@ static void os_repair(ordset *s, const int64_t *posdesc, int cnt)
     }
 }
 
-/* ---- the worst row DURING a window's walk, without touching the heap ---------------------------------------------------------
- * At the start of a window the nW worst rows are known in order (W, with their heap positions and values).  Only worst rows are ever
- * replaced, so while the walk consumes the window the current worst row is W[wp], or a row replaced earlier in this window whose new
- * value still lies above the list's last entry ("extras": the statement chain_resolve makes on the device, hip/crs_chain.hip) — no heap
- * operation per accepted trial.  The heap is repaired ONCE per window for all the rows that changed (os_repair).  If the list runs out
- * while rows outside it may be the worst (wp == nW, no extras), the tracker repairs the heap and hands over to it for the rest of
- * the window (direct mode: the sift-down per acceptance that used to be the only mode). */
+/* ---- the worst rows between two looks at the heap ------------------------------------------------------------------------------
+ * Only worst rows are ever replaced.  So after the heap has given its `cnt` worst rows in order (the RESERVOIR: a few windows' worth),
+ * the chain can be followed without touching it: the current worst row is the head of a sorted list T that starts as the reservoir;
+ * an accepted trial removes the head and, if its value still lies above the reservoir's last entry as it was when it was drawn (thr),
+ * puts the row back at its place in T — every row outside T is <= thr, and rows outside T do not change.  A window's list of worst
+ * rows (what the device is given, crs.c:134's tree maximum for every trial of the window) is T's first K entries.  The heap learns of
+ * the replacements in ONE batch (os_repair over the positions the rows had when the reservoir was drawn: the heap is not touched
+ * in between, so they still hold) right before the next reservoir is drawn — and that refresh is done while the device is busy with a
+ * window (tl_idle, called by the engine between its launch and its wait) whenever the list would not carry the window after: the
+ * sift-downs and the best-first extraction that used to sit between two launches are off the serial path.  A list that runs short
+ * anyway (window sizes jump) is refreshed on the spot. */
+typedef struct { double f; int64_t row, pos; int recorded; } topent;
 typedef struct {
-    int nW, wp, nex, direct;
-    double thr_f; int64_t thr_row;          /* the list's last entry as it was when the window started */
-    int64_t *W, *pos, *ex;                  /* rows, their heap positions; rows among the extras (all Kmax long) */
-    int64_t *scratch;                       /* Kmax positions */
-    signed char *lev;                       /* Kmax heap levels */
-} wtrack;
+    topent *T; int head, tail, cap;         /* sorted worst first: T[head .. tail) */
+    double thr_f; int64_t thr_row;          /* the reservoir's last entry when it was drawn */
+    int whole;                              /* the reservoir was the whole population: nothing lies outside T */
+    int64_t *chg; int nchg, chgcap;         /* heap positions of the rows replaced since the reservoir was drawn (each once) */
+    int64_t *rows, *pos; double *fs;        /* extraction buffers (cap entries) */
+    int64_t *scratch; signed char *lev;     /* repair order (chgcap entries) */
+    int inflight;                           /* slots of the window the device is working on (tl_idle) */
+    uint64_t refreshes, refreshes_idle;
+} toplist;
 
-static void wt_flush(wtrack *t, ordset *s)
+static void tl_free(toplist *t) { free(t->T); free(t->chg); free(t->rows); free(t->pos); free(t->fs); free(t->scratch); free(t->lev); memset(t, 0, sizeof *t); }
+static int tl_alloc(toplist *t, int kmax)
 {
-    /* rows W[0 .. wp) changed (the extras are among them): positions in decreasing order, then one repair */
-    int i, j, cnt = t->wp;
-    if (t->direct || cnt <= 0) { t->wp = 0; t->nex = 0; return; }
-    {   /* decreasing LEVEL is all os_repair needs (the nodes of a level are independent): a counting sort over the levels */
+    memset(t, 0, sizeof *t);
+    t->cap = 3 * kmax + 64;                 /* a reservoir of up to 3 windows */
+    t->chgcap = 4 * kmax + 128;
+    t->T = (topent *) malloc(sizeof(topent) * (size_t) (2 * t->cap));        /* room to slide: entries live in [head, tail) of 2 cap */
+    t->chg = (int64_t *) malloc(sizeof(int64_t) * (size_t) t->chgcap);
+    t->rows = (int64_t *) malloc(sizeof(int64_t) * (size_t) t->cap);
+    t->pos = (int64_t *) malloc(sizeof(int64_t) * (size_t) t->cap);
+    t->fs = (double *) malloc(sizeof(double) * (size_t) t->cap);
+    t->scratch = (int64_t *) malloc(sizeof(int64_t) * (size_t) t->chgcap);
+    t->lev = (signed char *) malloc((size_t) t->chgcap);
+    return (t->T && t->chg && t->rows && t->pos && t->fs && t->scratch && t->lev) ? 0 : -1;
+}
+
+/* the heap takes the replacements made since the last reservoir, then gives the `want` worst rows (at most cap) */
+static void tl_refresh(toplist *t, ordset *s, int want)
+{
+    int i, j, cnt = t->nchg, got;
+    if (cnt > 0) {   /* decreasing LEVEL is all os_repair needs (the nodes of a level are independent): a counting sort over the levels */
         int lvcnt[40] = { 0 }, lvoff[40], nl = 0;
-        for (i = 0; i < cnt; ++i) { int64_t hi = 1; int l = 0; while (t->pos[i] >= hi) { hi = 4 * hi + 1; ++l; } t->lev[i] = (signed char) l; ++lvcnt[l]; if (l + 1 > nl) nl = l + 1; }
+        for (i = 0; i < cnt; ++i) { int64_t hi = 1; int l = 0; while (t->chg[i] >= hi) { hi = 4 * hi + 1; ++l; } t->lev[i] = (signed char) l; ++lvcnt[l]; if (l + 1 > nl) nl = l + 1; }
         for (j = nl - 1, i = 0; j >= 0; --j) { lvoff[j] = i; i += lvcnt[j]; }
-        for (i = 0; i < cnt; ++i) t->scratch[lvoff[(int) t->lev[i]]++] = t->pos[i];
+        for (i = 0; i < cnt; ++i) t->scratch[lvoff[(int) t->lev[i]]++] = t->chg[i];
+        os_repair(s, t->scratch, cnt);
+        t->nchg = 0;
     }
-    os_repair(s, t->scratch, cnt);
-    t->wp = 0; t->nex = 0;
+    if (want > t->cap) want = t->cap;
+    if ((int64_t) want > s->nheap) want = (int) s->nheap;
+    got = os_topk(s, want, t->rows, t->pos, t->fs);
+    t->head = 0; t->tail = got;
+    for (i = 0; i < got; ++i) { t->T[i].f = t->fs[i]; t->T[i].row = t->rows[i]; t->T[i].pos = t->pos[i]; t->T[i].recorded = 0; }
+    t->whole = (int64_t) got == s->nheap;
+    if (got > 0) { t->thr_f = t->T[got - 1].f; t->thr_row = t->T[got - 1].row; }
+    ++t->refreshes;
 }
 
-static void wt_begin(wtrack *t, const ordset *s, int nW, const double *Wf)
+/* make sure the list holds the `need` worst rows (need <= N); `ahead`: how many to draw if it has to be drawn again */
+static void tl_need(toplist *t, ordset *s, int need, int ahead)
 {
-    t->nW = nW; t->wp = 0; t->nex = 0; t->direct = 0;
-    if (nW > 0) { t->thr_f = Wf[nW - 1]; t->thr_row = t->W[nW - 1]; }
-    (void) s;
+    if (t->tail - t->head >= need || (t->whole && t->tail - t->head >= (int) s->nheap)) return;
+    tl_refresh(t, s, ahead > need ? ahead : need);
 }
 
-/* the current worst row; *xi = its index among the extras or -1 */
-static int64_t wt_worst(wtrack *t, ordset *s, int *xi)
+static inline int64_t tl_worst(const toplist *t) { return t->T[t->head].row; }
+
+/* the device is working on a window of t->inflight slots whose list is T's head: if what will be left of T cannot carry the window
+ * after it, the heap takes the replacements made so far and gives the next reservoir NOW, beside the device.  The head of the new list
+ * is the window's list again (both are the worst rows in order), so the walk that follows consumes it as it would have the old one. */
+static void tl_idle(toplist *t, ordset *s)
 {
-    const double *F = s->F;
-    int64_t rw = -1;
-    int e;
-    *xi = -1;
-    if (t->direct) return os_worst(s);
-    if (t->wp < t->nW) rw = t->W[t->wp];
-    for (e = 0; e < t->nex; ++e) if (rw < 0 || key_less(F, rw, t->ex[e])) { rw = t->ex[e]; *xi = e; }
-    if (rw < 0) {                                             /* beyond the rows this window knows: the heap takes over */
-        wt_flush(t, s);
-        t->direct = 1;
-        return os_worst(s);
+    const int k = t->inflight;
+    if (k <= 0 || t->whole || t->tail - t->head - k >= k) return;
+    { const uint64_t r0 = t->refreshes; tl_refresh(t, s, 3 * k + 16); t->refreshes_idle += t->refreshes - r0; }
+}
+
+/* the head row has just been given a smaller value in F[] */
+static void tl_accepted(toplist *t, ordset *s)
+{
+    topent e = t->T[t->head++];
+    const double f = s->F[e.row];
+    if (!e.recorded) {
+        t->chg[t->nchg++] = e.pos;
+        e.recorded = 1;
     }
-    return rw;
-}
-
-/* row `worst` (what wt_worst returned, with its xi) has just been given a smaller value in F[] */
-static void wt_accepted(wtrack *t, ordset *s, int64_t worst, int xi)
-{
-    const double f = s->F[worst];
-    if (t->direct) { os_top_changed(s); return; }
-    if (xi >= 0) t->ex[xi] = t->ex[--t->nex];
-    else ++t->wp;
-    /* still above the list's last entry as it stood at the start of the window (key order: f, then row)? then it can be the worst again */
-    if (t->nW > 0 && (t->thr_f < f || (!(t->thr_f > f) && t->thr_row < worst))) t->ex[t->nex++] = worst;
+    /* still above the reservoir's last entry as it stood when it was drawn (key order: f, then row)?  then it is among the worst again */
+    if (t->whole || t->thr_f < f || (!(t->thr_f > f) && t->thr_row < e.row)) {
+        int lo = t->head, hi = t->tail;       /* first entry that is smaller than the new key: insert in front of it */
+        osnode k; k.f = f; k.row = e.row;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            osnode m; m.f = t->T[mid].f; m.row = t->T[mid].row;
+            if (node_less(m, k)) hi = mid; else lo = mid + 1;
+        }
+        if (t->tail == 2 * t->cap) {          /* slide the live part back to the front */
+            memmove(t->T, t->T + t->head, sizeof(topent) * (size_t) (t->tail - t->head));
+            lo -= t->head; t->tail -= t->head; t->head = 0;
+        }
+        memmove(t->T + lo + 1, t->T + lo, sizeof(topent) * (size_t) (t->tail - lo));
+        e.f = f;
+        t->T[lo] = e;
+        ++t->tail;
+    }
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -360,7 +380,7 @@ struct nla_crs_session {
     uint64_t *cblock;
     int32_t *ckind;
     int64_t *W, *crow;
-    wtrack wt;                     /* the worst row during a window's walk (W is its list) */
+    toplist tl;                    /* the worst rows between two looks at the heap (W is a window's copy of its head) */
     /* device-resolved windows */
     int forward;
     double *Wf;                    /* f of the rows W */
@@ -373,9 +393,15 @@ static void session_free(nla_crs_session *S)
 {
     if (!S) return;
     free(S->rs.F); os_free(&S->rs.os); free(S->rs.xtmp);
-    free(S->status); free(S->tprev); free(S->W); free(S->wt.pos); free(S->wt.ex); free(S->wt.scratch); free(S->wt.lev); free(S->cblock); free(S->ckind); free(S->crow);
+    free(S->status); free(S->tprev); free(S->W); tl_free(&S->tl); free(S->cblock); free(S->ckind); free(S->crow);
     free(S->Wf); free(S->fwcnt); free(S->fwrec); free(S->lastw);
     free(S);
+}
+
+static void crs_idle(void *arg)            /* from the engine, between handing a pass to the device and waiting for it */
+{
+    nla_crs_session *S = (nla_crs_session *) arg;
+    tl_idle(&S->tl, &S->rs.os);
 }
 
 static void engine_failed(nla_crs_session *S)
@@ -421,16 +447,12 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     rs->need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);
 
     rs->F = (double *) malloc(sizeof(double) * (size_t) N);
-    const int os_bad = os_alloc(&rs->os, N, S->Kmax);
+    const int os_bad = os_alloc(&rs->os, N, 3 * S->Kmax + 64);       /* (top-k scratch for a whole reservoir: tl_alloc's cap) */
     rs->xtmp = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
     S->status = (nla_crs_slot_status *) malloc(sizeof(nla_crs_slot_status) * (size_t) S->Kmax);
     S->tprev = (int32_t *) calloc(TRING, sizeof(int32_t));
     S->W = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
-    S->wt.pos = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
-    S->wt.ex = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
-    S->wt.scratch = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
-    S->wt.lev = (signed char *) malloc((size_t) S->Kmax);
-    S->wt.W = S->W;
+    const int tl_bad = tl_alloc(&S->tl, S->Kmax);
     S->cblock = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) S->Kmax);
     S->ckind = (int32_t *) malloc(sizeof(int32_t) * (size_t) S->Kmax);
     S->crow = (int64_t *) malloc(sizeof(int64_t) * (size_t) S->Kmax);
@@ -440,13 +462,14 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
         S->fwrec = (uint32_t *) calloc((size_t) S->Kmax * FWCAP, sizeof(uint32_t));
         S->lastw = (uint64_t *) calloc((size_t) N, sizeof(uint64_t));
     }
-    if (!rs->F || os_bad || !rs->xtmp || !S->status || !S->tprev || !S->W || !S->wt.pos || !S->wt.ex || !S->wt.scratch || !S->wt.lev || !S->Wf || !S->cblock ||
+    if (!rs->F || os_bad || !rs->xtmp || !S->status || !S->tprev || !S->W || tl_bad || !S->Wf || !S->cblock ||
         !S->ckind || !S->crow || (S->forward && (!S->fwcnt || !S->fwrec || !S->lastw))) {
         session_free(S);
         *ret_out = NLOPT_OUT_OF_MEMORY;
         return NULL;
     }
     rs->os.F = rs->F;
+    if (ops->set_idle) ops->set_idle(e, crs_idle, S);
 
     /* the device generates and (if it can) evaluates all N rows; the reference's stop tests run
      * after *every* evaluation, so replay them in row order and forget rows past the first stop */
@@ -528,11 +551,12 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             S->fresh_from - S->block <= (uint64_t) S->Kmax)
             K = (int) (S->fresh_from - S->block);
         nW = K < N ? K : (int) N;
-        nW = os_topk(&rs->os, nW, W, S->wt.pos, S->Wf);
-        wt_begin(&S->wt, &rs->os, nW, S->Wf);
+        tl_need(&S->tl, &rs->os, nW, 3 * K + 16);
+        for (a = 0; a < nW; ++a) { W[a] = S->tl.T[S->tl.head + a].row; S->Wf[a] = S->tl.T[S->tl.head + a].f; }
         if (S->forward) for (a = 0; a < nW; ++a) __builtin_prefetch(&S->lastw[W[a]], 1);   /* the walk writes a record per replaced row */
         const double t_eng0 = st ? nla_seconds() : 0.;
         const uint64_t gl0 = st ? st->gather_launches : 0;
+        S->tl.inflight = nW;                    /* (what crs_idle may assume the walk consumes of the list) */
         if (S->forward) {
             /* every slot of the window is computed in this launch; what an earlier window left unconsumed is dropped */
             if (st && S->fresh_from > S->block) st->slots_invalid += S->fresh_from - S->block;
@@ -548,6 +572,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 rs->sp = &S->view;
             }
         }
+        S->tl.inflight = 0;
         timed_pass = !st || st->gather_launches != gl0;            /* the engine times the gather of every pass, or of a sample of them: bytes follow */
         wend = S->block + (uint64_t) K;
         const double t_walk0 = st ? nla_seconds() : 0.;
@@ -567,7 +592,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
 
         while (j < K && ret == NLOPT_SUCCESS) {
             int64_t worst;
-            int kind = 1, accepted = 0, xi = -1;
+            int kind = 1, accepted = 0;
             double fcand;
             const uint64_t blk = S->block + (uint64_t) j;
             if (best_changed) break;
@@ -593,7 +618,8 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 }
             }
             if (st) ++st->slots_used;
-            worst = wt_worst(&S->wt, &rs->os, &xi);
+            if (S->tl.head == S->tl.tail) tl_need(&S->tl, &rs->os, 1, 3 * K + 16);     /* (a walk never outruns its window's list; kept for safety) */
+            worst = tl_worst(&S->tl);
             /* reflection trial of block blk */
             if (host_eval) {
                 if (ops->read_slot(e, blk, 1, rs->xtmp)) { engine_failed(S); return S->ret; }
@@ -635,7 +661,7 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
                 }
                 /* memcpy(worst->k, d->p) + resort (crs.c:153-154); the row write is deferred */
                 rs->F[worst] = fcand;
-                wt_accepted(&S->wt, &rs->os, worst, xi);
+                tl_accepted(&S->tl, &rs->os);
                 trace_add(pb, fcand, worst, kind, 1);
                 if (st) ++st->accepted;
                 cblock[ncommit] = blk; ckind[ncommit] = host_eval ? 1 : kind; crow[ncommit] = worst; ++ncommit;
@@ -646,7 +672,6 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             }
             j += (kind == 2) ? 2 : 1;
         }
-        wt_flush(&S->wt, &rs->os);                      /* the heap takes the window's replacements, all at once */
         S->block += (uint64_t) j;
         if (best_changed) {
             /* every slot in flight started from the old best row: forget them all */
@@ -687,6 +712,7 @@ nlopt_result nla_crs_end(nla_crs_session *S, uint64_t *words_used)
         engine_failed(S);
         ret = S->ret;
     }
+    if (S->rs.ops->set_idle) S->rs.ops->set_idle(S->rs.e, NULL, NULL);       /* the engine outlives the session */
     session_free(S);
     return ret;
 }

@@ -74,6 +74,7 @@ struct nla_crs_hip_engine {
     int doorbell;                  /* ... and rings a word there when the last record is visible: the host spins on it instead of sleeping in a
                                     * stream synchronisation ("amd_doorbell", default 1) */
     uint32_t *h_bell, *d_bellcount, bell_seq;
+    void (*idle_fn)(void *); void *idle_arg;   /* the driver's host work beside a pass (ops->set_idle) */
     /* device-resolved windows (hip/crs_chain.hip): control block, the walk's lists when they do not fit the kernel arguments,
      * what every slot took from where (pinned, written by the kernel) */
     void *d_ctrl;
@@ -612,6 +613,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         if (e->stats) e->stats->allgather_bytes += (uint64_t) e->world * (2 * (uint64_t) K * (uint64_t) e->colper + 2) * sizeof(double);
         /* the K status records and, behind them, the ranks' agreed stop flags (and whether any rank failed) */
         HARD(nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * ((size_t) K + 1), e->main));
+        if (e->idle_fn) e->idle_fn(e->idle_arg);
         HARD(nla_stream_sync(e->main));
 #undef SOFT
 #undef HARD
@@ -654,6 +656,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
             CK(e, nla_k_crs_finish_args_bell(OBJK(e), n, e->ld, e->d_X, i0, e->d_TX, e->d_TM, e->d_words, ring, first_block, K,
                                              t_in, e->d_tout, KCAP - 1, e->d_lb, e->d_ub, e->d_fT, e->d_fM, e->h_status, e->d_bellcount,
                                              e->h_bell, seq, e->main));
+            if (e->idle_fn) e->idle_fn(e->idle_arg);
             if (bell_wait(e, seq)) CK(e, nla_stream_sync(e->main));
             goto have_status;
         }
@@ -663,6 +666,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
         if (e->direct_status) {
             /* the finish kernel wrote the K records straight into the pinned host buffer (visible at kernel completion):
              * no copy-back operation behind it either */
+            if (e->idle_fn) e->idle_fn(e->idle_arg);
             CK(e, nla_stream_sync(e->main));
             goto have_status;
         }
@@ -686,6 +690,7 @@ launched:
         CK(e, nla_memcpy_d2h(e->h_fTM, e->d_fT, sizeof(double) * 2 * KCAP, e->main));
     }
     CK(e, nla_memcpy_d2h(e->h_status, e->d_status, sizeof(nla_crs_slot_status) * (size_t) K, e->main));
+    if (e->idle_fn) e->idle_fn(e->idle_arg);
     CK(e, nla_stream_sync(e->main));
     if (e->obj == -2)
         for (int a = 0; a < K; ++a) {
@@ -799,6 +804,7 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     }
     e->ticket_base += nla_crs_chain_tickets(n, e->ld, K, e->chain_flags);
     if (e->timed) CK(e, nla_event_record(e->ev1, e->main));
+    if (e->idle_fn) e->idle_fn(e->idle_arg);      /* the window is with the device: the driver's upkeep of its ordered set runs beside it */
     CK(e, nla_stream_sync(e->main));              /* status and records were written into pinned host memory by the kernel */
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
     memcpy(fwcnt, e->h_fwcnt, sizeof(uint32_t) * (size_t) K);
@@ -817,6 +823,8 @@ static const char *op_last_error(void *ve) { return ((nla_crs_hip_engine *) ve)-
 static void op_stop_flags_in(void *ve, int forced, int timed) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; e->stop_in[0] = forced != 0; e->stop_in[1] = timed != 0; }
 static void op_stop_flags_out(void *ve, int *forced, int *timed) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; *forced = e->stop_out[0]; *timed = e->stop_out[1]; }
 
+static void op_set_idle(void *ve, void (*fn)(void *), void *arg) { nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve; e->idle_fn = fn; e->idle_arg = arg; }
+
 static int op_reset_slot(void *ve, uint64_t block)
 {
     ((nla_crs_hip_engine *) ve)->h_t[block & (KCAP - 1)] = 0;
@@ -825,7 +833,7 @@ static int op_reset_slot(void *ve, uint64_t block)
 
 const nla_crs_engine_ops nla_crs_hip_ops = {
     op_init_population, op_max_slots, op_advance, op_chain, op_reset_slot, op_commit, op_read_slot, op_read_row, op_mutate_slot, op_last_error,
-    op_stop_flags_in, op_stop_flags_out
+    op_stop_flags_in, op_stop_flags_out, op_set_idle
 };
 
 static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_data, const double *lb, const double *ub, const double *x,

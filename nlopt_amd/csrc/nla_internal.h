@@ -204,6 +204,9 @@ typedef struct {
      * on the candidates' all-gather instead of costing a collective of its own.  NULL where passes are not collective. */
     void (*stop_flags_in)(void *e, int forced, int timed);
     void (*stop_flags_out)(void *e, int *forced, int *timed);
+    /* fn(arg) is called by advance / chain after the pass has been handed to the device and before the host starts waiting for it:
+     * host work that does not depend on the pass's results runs beside it (crs_driver.c: the ordered set's upkeep).  NULL: no such call. */
+    void (*set_idle)(void *e, void (*fn)(void *arg), void *arg);
 } nla_crs_engine_ops;
 
 typedef struct {

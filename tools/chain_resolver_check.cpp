@@ -63,7 +63,10 @@ CH_DEV uint64_t ch_ld64(const uint64_t *p) { return reinterpret_cast<const std::
 CH_DEV void ch_st32(uint32_t *p, uint32_t v) { reinterpret_cast<std::atomic<uint32_t> *>(p)->store(v, std::memory_order_release); }
 CH_DEV void ch_release() { std::atomic_thread_fence(std::memory_order_release); }
 CH_DEV void ch_sleep() { std::this_thread::yield(); }
-CH_DEV uint64_t ch_clock() { return emu::fake_clock.load(std::memory_order_relaxed); }
+/* the device reads its clock on the scalar unit: ONE value per wavefront.  Lanes that are threads must be given lane 0's reading — with a
+ * reading of their own, the lanes on either side of the watchdog's deadline part ways and the next exchange never completes (the
+ * intermittent hang of this check until round 4's third session) */
+CH_DEV uint64_t ch_clock() { return ch_exchange(emu::fake_clock.load(std::memory_order_relaxed), 0); }
 CH_DEV double ch_f_of_bits(uint64_t b) { b = ~b; double f; std::memcpy(&f, &b, sizeof f); return f; }
 
 #include "crs_chain_resolver.h"
@@ -194,11 +197,15 @@ int main(int argc, char **argv)
         std::vector<int64_t> W(nW, 3); std::vector<double> Wf(nW, 1.);
         std::vector<uint32_t> ctrl(8, 0), rowstate(nW, 0);
         std::vector<uint64_t> recs(2 * K, 0);
-        std::thread clock([&]() { for (int t = 0; t < 4000; ++t) { emu::fake_clock.fetch_add(1); std::this_thread::yield(); } emu::fake_clock.fetch_add(1u << 20); });
+        /* the clock runs until the wavefront has left — a clock that makes its jump and STOPS can do so before the lanes have read their
+         * starting time, and then the deadline never comes (the other half of this check's intermittent hang) */
+        std::atomic<int> lanes_gone{0};
+        std::thread clock([&]() { while (!lanes_gone.load(std::memory_order_acquire)) { emu::fake_clock.fetch_add(1000); std::this_thread::yield(); } });
         std::vector<std::thread> lanes;
         for (int l = 0; l < 64; ++l)
             lanes.emplace_back([&, l]() { emu::lane_id = l; emu::which = 0; chain_resolver_wave(ctrl.data(), recs.data(), rowstate.data(), K, nW, W.data(), Wf.data(), 0., 1, 100000); });
         for (auto &t : lanes) t.join();
+        lanes_gone.store(1, std::memory_order_release);
         clock.join();
         if (ctrl[CH_CTRL_PK] != 0xffffffffu || ctrl[CH_CTRL_HALT] != 1 || ctrl[CH_CTRL_NEXT] != (uint32_t) K + 2u) { printf("watchdog: no halt\n"); return 1; }
     }

@@ -1,7 +1,7 @@
 /* tools/ordset_check.c — CPU check of the ordered set and the window tracker of crs_driver.c (development tooling; tests/test_host_logic.py
- * builds and runs it).  The file is INCLUDED, so the static functions under test are the product's: os_push / os_topk / os_repair /
- * os_top_changed (a 4-ary max-heap with the keys in the nodes) and wt_begin / wt_worst / wt_accepted / wt_flush (the worst row during a
- * window's walk without a heap operation per accepted trial).  Against the obvious statement — the row with the largest (f, row) key of
+ * builds and runs it).  The file is INCLUDED, so the static functions under test are the product's: os_push / os_topk / os_repair (a 4-ary
+ * max-heap with the keys in the nodes) and tl_need / tl_worst / tl_accepted / tl_refresh / tl_idle (the worst rows between two looks at
+ * the heap: no heap operation per accepted trial, the heap's work done while a window is in flight).  Against the obvious statement — the row with the largest (f, row) key of
  * a plain array — for drawn populations with MANY TIES (values from a handful of integers), populations smaller than the window (the
  * list is the whole population), windows that run past their list (the tracker hands over to the heap), values that land among the
  * window's worst rows again and again (extras), acceptance rates from 5 % to 100 %; after every window the heap must be a heap, hold
@@ -47,7 +47,7 @@ static int check_heap(const ordset *s, int64_t N)
 int main(int argc, char **argv)
 {
     const int rounds = argc > 1 ? atoi(argv[1]) : 300;
-    unsigned long long windows = 0, accepts = 0, extras = 0, handovers = 0, ties = 0;
+    unsigned long long windows = 0, accepts = 0, reinserted = 0, refreshes = 0, idle = 0, ties = 0, whole = 0;
     if (argc > 2) rs_ ^= strtoull(argv[2], NULL, 10) * 0x9E3779B97F4A7C15ULL;
     for (int r = 0; r < rounds; ++r) {
         const int64_t N = r % 9 == 0 ? 1 + (int64_t) (rnd() % 40) : 1 + (int64_t) (rnd() % 3000);
@@ -56,56 +56,58 @@ int main(int argc, char **argv)
         double *F = (double *) malloc(sizeof(double) * (size_t) N);
         int64_t *sorted = (int64_t *) malloc(sizeof(int64_t) * (size_t) N);
         ordset os;
-        wtrack wt;
-        double *Wf = (double *) malloc(sizeof(double) * (size_t) Kmax);
-        memset(&os, 0, sizeof os); memset(&wt, 0, sizeof wt);
-        if (os_alloc(&os, N, Kmax)) return 2;
+        toplist tl;
+        memset(&os, 0, sizeof os);
+        if (os_alloc(&os, N, 3 * Kmax + 64) || tl_alloc(&tl, Kmax)) return 2;
         os.F = F;
-        wt.W = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax); wt.pos = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax);
-        wt.ex = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax); wt.scratch = (int64_t *) malloc(sizeof(int64_t) * (size_t) Kmax);
-        wt.lev = (signed char *) malloc((size_t) Kmax);
         for (int64_t i = 0; i < N; ++i) { F[i] = levels ? (double) (rnd() % (unsigned) levels) : urand(); os_push(&os, i); }
         if (check_heap(&os, N)) { printf("after the pushes (round %d, N %ld)\n", r, (long) N); return 1; }
         if (os.best != ({ int64_t b = 0; for (int64_t i = 1; i < N; ++i) if (key_less(F, i, b)) b = i; b; })) { printf("best row wrong after the pushes (round %d)\n", r); return 1; }
-        for (int w = 0; w < 12; ++w) {
+        for (int w = 0; w < 16; ++w) {
             const int K = 1 + (int) (rnd() % (unsigned) Kmax);
             const double pacc = w % 4 == 0 ? 1.0 : (w % 4 == 1 ? 0.05 : urand());
             const int mode = (int) (rnd() % 3);                                 /* where accepted values land: anywhere below / just below the worst / far below */
-            int nW = K < N ? K : (int) N, got, trials = K + (w % 5 == 0 ? K : 0);  /* some walks run past their list */
-            got = os_topk(&os, nW, wt.W, wt.pos, Wf);
+            const int nW = K < N ? K : (int) N;
+            const uint64_t r0 = tl.refreshes;
+            tl_need(&tl, &os, nW, 3 * K + 16);
+            /* the window's list = the nW worst rows of the plain array, in order */
             for (int64_t i = 0; i < N; ++i) sorted[i] = i;
             g_F = F; qsort(sorted, (size_t) N, sizeof(int64_t), cmp_desc);
-            if (got != nW) { printf("top-k returned %d of %d (round %d)\n", got, nW, r); return 1; }
+            if (tl.tail - tl.head < nW) { printf("the list holds %d rows, the window needs %d (round %d window %d)\n", tl.tail - tl.head, nW, r, w); return 1; }
             for (int a = 0; a < nW; ++a)
-                if (wt.W[a] != sorted[a] || OSN(&os, wt.pos[a]).row != wt.W[a] || Wf[a] != F[wt.W[a]]) {
-                    printf("top-k entry %d: row %ld at node %ld (key %g), the %d-th worst row is %ld (round %d, N %ld, K %d)\n", a, (long) wt.W[a], (long) wt.pos[a], Wf[a], a, (long) sorted[a], r, (long) N, K);
+                if (tl.T[tl.head + a].row != sorted[a] || tl.T[tl.head + a].f != F[sorted[a]]) {
+                    printf("list entry %d: row %ld (key %g), the %d-th worst row is %ld (round %d window %d, N %ld, K %d)\n", a, (long) tl.T[tl.head + a].row, tl.T[tl.head + a].f, a, (long) sorted[a], r, w, (long) N, K);
                     return 1;
                 }
-            wt_begin(&wt, &os, nW, Wf);
             ++windows;
-            for (int t = 0; t < trials; ++t) {
-                int xi;
-                const int was_direct = wt.direct;
-                const int64_t worst = wt_worst(&wt, &os, &xi), nw = naive_worst(F, N);
-                if (!was_direct && wt.direct) ++handovers;
-                if (worst != nw) { printf("worst row %ld, the array says %ld (round %d window %d trial %d: N %ld K %d wp %d extras %d direct %d)\n", (long) worst, (long) nw, r, w, t, (long) N, K, wt.wp, wt.nex, wt.direct); return 1; }
+            tl.inflight = K;
+            if (w % 2 == 0) { const uint64_t q0 = tl.refreshes; tl_idle(&tl, &os); idle += tl.refreshes - q0; }   /* the engine's call between launch and wait */
+            for (int t = 0; t < K; ++t) {
+                if (tl.head == tl.tail) tl_need(&tl, &os, 1, 3 * K + 16);
+                const int64_t worst = tl_worst(&tl), nw = naive_worst(F, N);
+                if (worst != nw) { printf("worst row %ld, the array says %ld (round %d window %d trial %d: N %ld K %d list %d whole %d)\n", (long) worst, (long) nw, r, w, t, (long) N, K, tl.tail - tl.head, tl.whole); return 1; }
                 if (urand() < pacc) {
                     double v;
                     if (levels) { v = F[worst] - (double) (mode == 1 ? 1 : 1 + rnd() % 3); ++ties; }
                     else v = mode == 1 ? F[worst] * (1.0 - 1e-3 * urand()) : (mode == 2 ? F[worst] * 0.01 * urand() : F[worst] * urand());
                     if (!(v < F[worst])) continue;
                     F[worst] = v;
-                    { const int nex0 = wt.nex; wt_accepted(&wt, &os, worst, xi); if (wt.nex > nex0 - (xi >= 0)) ++extras; }
+                    { const int len0 = tl.tail - tl.head; tl_accepted(&tl, &os); if (tl.tail - tl.head == len0) ++reinserted; }
                     ++accepts;
                 }
             }
-            wt_flush(&wt, &os);
-            if (check_heap(&os, N)) { printf("after window %d of round %d (N %ld, K %d)\n", w, r, (long) N, K); return 1; }
+            tl.inflight = 0;
+            refreshes += tl.refreshes - r0;
+            whole += tl.whole;
+            if (w % 5 == 4) {                   /* now and then: everything into the heap, and the heap must be a heap over every row */
+                tl_refresh(&tl, &os, 3 * K + 16);
+                if (check_heap(&os, N)) { printf("after window %d of round %d (N %ld, K %d)\n", w, r, (long) N, K); return 1; }
+            }
         }
-        free(F); free(sorted); free(Wf); os_free(&os); free(wt.W); free(wt.pos); free(wt.ex); free(wt.scratch); free(wt.lev);
+        free(F); free(sorted); os_free(&os); tl_free(&tl);
     }
-    if (!extras || !handovers || !ties) { printf("the draws never reached extras (%llu), a hand-over to the heap (%llu) or ties (%llu): the check checks too little\n", extras, handovers, ties); return 1; }
-    printf("ok %d populations, %llu windows, %llu accepted replacements (%llu landed among the window's worst rows, %llu with tied values), %llu hand-overs to the heap\n",
-           rounds, windows, accepts, extras, ties, handovers);
+    if (!reinserted || !refreshes || !idle || !ties || !whole) { printf("the draws never reached a re-insertion (%llu), a refresh (%llu), an idle refresh (%llu), ties (%llu) or a list that is the whole population (%llu): the check checks too little\n", reinserted, refreshes, idle, ties, whole); return 1; }
+    printf("ok %d populations, %llu windows, %llu accepted replacements (%llu back among the listed rows, %llu with tied values), %llu refreshes of the list (%llu while a window was in flight), %llu windows with the whole population listed\n",
+           rounds, windows, accepts, reinserted, ties, refreshes, idle, whole);
     return 0;
 }
