@@ -545,7 +545,11 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         # where the trial phase's wall time goes on the host's side (seconds over the timed steps): inside the engine call (launches, waiting
         # for the device, copies out of pinned memory), in the in-order walk over the finished slots, the rest = preparing the pass
         "host_split": {"trial_s": st1["t_trial_s"] - st0["t_trial_s"], "engine_s": st1["t_engine_s"] - st0["t_engine_s"],
-                       "walk_s": st1["t_walk_s"] - st0["t_walk_s"], "gather_kernel_s": g_ms / 1e3, "passes": int(st1["rounds"] - st0["rounds"])},
+                       "walk_s": st1["t_walk_s"] - st0["t_walk_s"], "gather_kernel_s": g_ms / 1e3, "passes": int(st1["rounds"] - st0["rounds"]),
+                       # the driver's ordered set: redraws of its list of worst rows, how many of them ran beside the device, their time
+                       "list_refreshes": int(st1["list_refreshes"] - st0["list_refreshes"]),
+                       "list_refreshes_beside_device": int(st1["list_refreshes_beside_device"] - st0["list_refreshes_beside_device"]),
+                       "list_refresh_s": st1["t_list_refresh_s"] - st0["t_list_refresh_s"]},
         "init": {"evals": pop, "seconds": t_init, "init_evals_per_s": pop / t_init},
         "final_result": int(fret), "minf": m["minf"],
     }
@@ -566,7 +570,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                                if n2 >= 512 else "conservative passes (crs_advance_kernel + crs_finish_kernel): the default below n = 512"),
                       "trials_consumed_per_pass": (s1["slots_used"] - s0["slots_used"]) / max(1, s1["rounds"] - s0["rounds"]),
                       "host_split": {"trial_s": s1["t_trial_s"] - s0["t_trial_s"], "engine_s": s1["t_engine_s"] - s0["t_engine_s"],
-                                     "walk_s": s1["t_walk_s"] - s0["t_walk_s"], "gather_kernel_s": gms / 1e3, "passes": int(s1["rounds"] - s0["rounds"])}}
+                                     "walk_s": s1["t_walk_s"] - s0["t_walk_s"], "gather_kernel_s": gms / 1e3, "passes": int(s1["rounds"] - s0["rounds"]),
+                                     "list_refreshes": int(s1["list_refreshes"] - s0["list_refreshes"]),
+                                     "list_refreshes_beside_device": int(s1["list_refreshes_beside_device"] - s0["list_refreshes_beside_device"]),
+                                     "list_refresh_s": s1["t_list_refresh_s"] - s0["t_list_refresh_s"]}}
                 if not a.no_cpu_baseline:
                     cb = cpu_baseline_crs("rastrigin", n2, 20000, 4000, a.seed)
                     e2["cpu_baseline"] = cb

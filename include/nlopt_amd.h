@@ -107,6 +107,11 @@ typedef struct {
      * waiting for the device, copies out of pinned memory) and in the driver's in-order walk over the finished slots (verification of
      * the device's chain, the order statistics, stop tests, staging of the commits).  t_trial_s - the two = preparing the pass. */
     double t_engine_s, t_walk_s;
+    /* ... and the driver's ordered set: how often the heap was brought up to date and the list of worst rows redrawn from it, how many
+     * of those times that happened beside the device (inside the engine call, between launch and wait) rather than between two launches,
+     * and the time it took (seconds; the part beside the device is inside t_engine_s, the rest outside both) */
+    uint64_t list_refreshes, list_refreshes_beside_device;
+    double t_list_refresh_s;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 

@@ -44,7 +44,8 @@ class Stats(C.Structure):
                 ("t_stochrank_ms", C.c_double), ("stochrank_launches", C.c_uint64), ("stochrank_ticks", C.c_uint64),
                 ("t_allgather_ms", C.c_double), ("allgather_bytes", C.c_uint64),
                 ("evolve_rounds_enqueued", C.c_uint64), ("evolve_rounds", C.c_uint64),
-                ("t_engine_s", C.c_double), ("t_walk_s", C.c_double)]
+                ("t_engine_s", C.c_double), ("t_walk_s", C.c_double),
+                ("list_refreshes", C.c_uint64), ("list_refreshes_beside_device", C.c_uint64), ("t_list_refresh_s", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

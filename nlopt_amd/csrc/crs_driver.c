@@ -218,6 +218,7 @@ typedef struct {
     int64_t *scratch; signed char *lev;     /* repair order (chgcap entries) */
     int inflight;                           /* slots of the window the device is working on (tl_idle) */
     uint64_t refreshes, refreshes_idle;
+    nlopt_amd_stats *st;                    /* or NULL */
 } toplist;
 
 static void tl_free(toplist *t) { free(t->T); free(t->chg); free(t->rows); free(t->pos); free(t->fs); free(t->scratch); free(t->lev); memset(t, 0, sizeof *t); }
@@ -240,6 +241,7 @@ static int tl_alloc(toplist *t, int kmax)
 static void tl_refresh(toplist *t, ordset *s, int want)
 {
     int i, j, cnt = t->nchg, got;
+    const double t_r0 = t->st ? nla_seconds() : 0.;
     if (cnt > 0) {   /* decreasing LEVEL is all os_repair needs (the nodes of a level are independent): a counting sort over the levels */
         int lvcnt[40] = { 0 }, lvoff[40], nl = 0;
         for (i = 0; i < cnt; ++i) { int64_t hi = 1; int l = 0; while (t->chg[i] >= hi) { hi = 4 * hi + 1; ++l; } t->lev[i] = (signed char) l; ++lvcnt[l]; if (l + 1 > nl) nl = l + 1; }
@@ -256,6 +258,7 @@ static void tl_refresh(toplist *t, ordset *s, int want)
     t->whole = (int64_t) got == s->nheap;
     if (got > 0) { t->thr_f = t->T[got - 1].f; t->thr_row = t->T[got - 1].row; }
     ++t->refreshes;
+    if (t->st) { ++t->st->list_refreshes; t->st->list_refreshes_beside_device += t->inflight > 0; t->st->t_list_refresh_s += nla_seconds() - t_r0; }
 }
 
 /* make sure the list holds the `need` worst rows (need <= N); `ahead`: how many to draw if it has to be drawn again */
@@ -469,6 +472,7 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
         return NULL;
     }
     rs->os.F = rs->F;
+    S->tl.st = st;
     if (ops->set_idle) ops->set_idle(e, crs_idle, S);
 
     /* the device generates and (if it can) evaluates all N rows; the reference's stop tests run
