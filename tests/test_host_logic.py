@@ -219,12 +219,12 @@ def test_dedicated_chain_resolver_takes_the_lock_versions_decisions():
         os.remove(exe)
 
 
-def test_ordered_set_and_window_tracker_against_a_plain_array():
-    """crs_driver.c's ordered set (4-ary max-heap, keys in the nodes, batch repair once per window) and the tracker that names the worst
-    row during a window's walk without a heap operation per accepted trial — the file is #included by tools/ordset_check.c, so these are
-    the product's static functions — against the row with the largest (f, row) key of a plain array: populations with ties everywhere,
-    populations smaller than the window, walks that run past their list (hand-over to the heap), values landing among the window's worst
-    rows; after every window the heap is a heap over every row with node key == F[row]."""
+def test_ordered_set_and_list_of_worst_rows_against_a_plain_array():
+    """crs_driver.c's ordered set (4-ary max-heap, keys in the nodes, batch repair) and the sorted list of worst rows the walk follows
+    between two looks at the heap (redrawn beside the device) — the file is #included by tools/ordset_check.c, so these are the product's
+    static functions — against the row with the largest (f, row) key of a plain array at every trial and the sorted array for every
+    window's list: populations with ties everywhere, populations smaller than the window, lists that run short, redraws while a window
+    is in flight, values landing among the listed rows; after a redraw the heap is a heap over every row with node key == F[row]."""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

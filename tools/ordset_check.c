@@ -1,11 +1,12 @@
-/* tools/ordset_check.c — CPU check of the ordered set and the window tracker of crs_driver.c (development tooling; tests/test_host_logic.py
- * builds and runs it).  The file is INCLUDED, so the static functions under test are the product's: os_push / os_topk / os_repair (a 4-ary
- * max-heap with the keys in the nodes) and tl_need / tl_worst / tl_accepted / tl_refresh / tl_idle (the worst rows between two looks at
- * the heap: no heap operation per accepted trial, the heap's work done while a window is in flight).  Against the obvious statement — the row with the largest (f, row) key of
- * a plain array — for drawn populations with MANY TIES (values from a handful of integers), populations smaller than the window (the
- * list is the whole population), windows that run past their list (the tracker hands over to the heap), values that land among the
- * window's worst rows again and again (extras), acceptance rates from 5 % to 100 %; after every window the heap must be a heap, hold
- * every row once, and every node's key must be F[row].
+/* tools/ordset_check.c — CPU check of the ordered set and the list of worst rows of crs_driver.c (development tooling;
+ * tests/test_host_logic.py builds and runs it).  The file is INCLUDED, so the static functions under test are the product's: os_push /
+ * os_topk / os_repair (a 4-ary max-heap with the keys in the nodes) and tl_need / tl_worst / tl_accepted / tl_refresh / tl_idle (the
+ * worst rows between two looks at the heap: no heap operation per accepted trial, the heap's work done while a window is in flight).
+ * Against the obvious statement — the row with the largest (f, row) key of a plain array, at EVERY trial, and the sorted array for
+ * every window's list — for drawn populations with MANY TIES (values from a handful of integers), populations smaller than the window
+ * (the list is the whole population), lists that run short (redrawn on the spot), redraws while a window is in flight, values that
+ * land among the listed rows again and again, acceptance rates from 5 % to 100 %; after a redraw the heap must be a heap, hold every row
+ * once, and every node's key must be F[row].
  *   gcc -O1 -std=gnu11 -I nlopt_amd/csrc -I include tools/ordset_check.c -o tools/_build/ordset_check -L oracle -l:libnlopt_amd_emu.so -lm
  *   tools/_build/ordset_check [rounds] [seed]        -> "ok ..." / the first difference; exit code 0 / 1 */
 #include "../nlopt_amd/csrc/crs_driver.c"
