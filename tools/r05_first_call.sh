@@ -62,6 +62,10 @@ if [ "$PART" = 1 ] || [ "$PART" = all ]; then
   for seg in 1024 256 64 16; do
     line "mlsl config 4 amd_mlsl_seg_regens=$seg"       --workload mlsl --no-cpu-baseline --param amd_mlsl_seg_regens=$seg
   done
+  # the generator working ahead on its own stream: never overlapped in round 4 because the distance scratch was freed and reallocated every
+  # iteration (hipFree waits for every stream); it doubles now (mlsl_driver.c need_D)
+  line "mlsl config 4 amd_mlsl_prefetch=1"              --workload mlsl --no-cpu-baseline --param amd_mlsl_prefetch=1
+  line "mlsl config 4 prefetch + seg_regens=64"         --workload mlsl --no-cpu-baseline --param amd_mlsl_prefetch=1 --param amd_mlsl_seg_regens=64
 fi
 if [ "$PART" = 2 ] || [ "$PART" = all ]; then
   for n in 512; do
