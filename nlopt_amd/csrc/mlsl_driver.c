@@ -180,12 +180,10 @@ static int grow_lms(mlsl_dev *d, size_t need)
  * a hipMalloc of tens of MB between the sampling kernel and the distance pass.  Now it doubles: a handful of reallocations per run. */
 static int need_D(mlsl_dev *d, size_t doubles)
 {
-    const size_t exact = doubles;
     if (doubles <= d->dcap) return 0;
     if (doubles < 2 * d->dcap) doubles = 2 * d->dcap;
     nla_dev_free(d->d_D);
     d->d_D = (double *) nla_dev_malloc(sizeof(double) * doubles);
-    if (!d->d_D && doubles > exact) { doubles = exact; d->d_D = (double *) nla_dev_malloc(sizeof(double) * doubles); }   /* (no room for the slack) */
     d->dcap = d->d_D ? doubles : 0;
     if (!d->d_D) MFAIL(d, "out of device memory (distance matrix)");
     return 0;
