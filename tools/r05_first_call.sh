@@ -40,9 +40,10 @@ import json, sys
 try:
     d = json.load(open("gpurun_out/r05_first/last.json"))
     hs = d.get("host_split") or {}
-    print("%-58s %9.0f evals/s  %8.3f ms/step  frac %s  host: engine %.3f walk %.3f kernel %.3f s over %s passes  %s" % (
+    print("%-58s %9.0f evals/s  %8.3f ms/step  frac %s  host: engine %.3f walk %.3f kernel %.3f s over %s passes, list redrawn %s times (%s beside the device, %.4f s)  %s" % (
         sys.argv[1], d["value"], d["ms_per_step"], (d.get("roofline") or {}).get("frac"), hs.get("engine_s", 0), hs.get("walk_s", 0),
-        hs.get("gather_kernel_s", 0), hs.get("passes"), d.get("phases", "")))
+        hs.get("gather_kernel_s", 0), hs.get("passes"), hs.get("list_refreshes"), hs.get("list_refreshes_beside_device"), hs.get("list_refresh_s", 0),
+        d.get("phases", "")))
 except Exception as e:
     print(sys.argv[1], "FAILED", repr(e))
 PY
