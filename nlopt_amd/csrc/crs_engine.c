@@ -808,7 +808,12 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     CK(e, nla_stream_sync(e->main));              /* status and records were written into pinned host memory by the kernel */
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
     memcpy(fwcnt, e->h_fwcnt, sizeof(uint32_t) * (size_t) K);
-    memcpy(fwrec, e->h_fwrec, sizeof(uint32_t) * (size_t) K * (size_t) fwcap);
+    /* only the records a slot wrote (most slots of a window read none or one of the window's worst rows): the buffer is pinned memory the
+     * device has just written — every line of it is a miss for the host — and the driver reads fwrec[a][0 .. min(fwcnt[a], fwcap)) only */
+    for (int a = 0; a < K; ++a) {
+        const uint32_t c = e->h_fwcnt[a] < (uint32_t) fwcap ? e->h_fwcnt[a] : (uint32_t) fwcap;
+        if (c) memcpy(fwrec + (size_t) a * (size_t) fwcap, e->h_fwrec + (size_t) a * (size_t) fwcap, sizeof(uint32_t) * (size_t) c);
+    }
     for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = n;
     if (e->timed) {
         float ms = nla_event_elapsed_ms(e->ev0, e->ev1);
