@@ -235,7 +235,8 @@ int nla_k_crs_advance(int n, int ld, const double *X, int64_t i0, const int32_t 
  * kind << 16  (kind 0: the row itself was read; 1 / 2: TX / TM of window slot `producer`) — the caller verifies them against
  * the chain it replays (a stop, or a value landing among the worst rows twice, are not modelled on the device).
  * ctrl: nla_crs_chain_ctrl_bytes(K, nW) bytes of device memory, zero before the first launch (the launcher re-zeroes all of it
- * but its ticket counter); ticket_base = workgroups launched by earlier calls on this ctrl = sum of K * nla_crs_chain_chunks.
+ * but its ticket counter); ticket_base = workgroups launched by earlier calls on this ctrl = sum of nla_crs_chain_tickets.
+ * A slot behind a trial that became the new best point may come back with status.t = 0 (not computed: it started from the old best row).
  * w_on_host != 0 (nW <= 128): W / Wf are host arrays and travel as kernel arguments.  f_best = f of row i0.
  * TX, TM and ctrl MUST be nla_dev_malloc_uncached memory: the workgroups hand trial points to each other through them; and
  * ld % 16 == 0 with TX / TM 128-byte aligned (no cache line shared by two slots) — the launcher refuses anything else. */
@@ -246,16 +247,9 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
                     uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                     const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
                     nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream);
-/* the same launch with flags.  NLA_CHAIN_RESOLVER: the chain (crs.c:135-156: the decisions between evaluations) is advanced by one
- * dedicated wavefront out of registers (hip/crs_chain_resolver.h) instead of by the evaluating workgroups under a lock — one more
- * workgroup in the grid: ticket_base then counts nla_crs_chain_tickets(n, ld, K, flags) per earlier launch.  Same outputs. */
-#define NLA_CHAIN_RESOLVER 1
-uint32_t nla_crs_chain_tickets(int n, int ld, int K, int flags);
-int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
-                       const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
-                       uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
-                       const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
-                       nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int flags, void *stream);
+/* workgroups one launch draws tickets for: K * nla_crs_chain_chunks + 1 (the resolver wavefront's workgroup, hip/crs_chain_resolver.h:
+ * the chain — crs.c:135-156, the decisions between evaluations — is advanced by one dedicated wavefront out of registers) */
+uint32_t nla_crs_chain_tickets(int n, int ld, int K);
 
 /* replaces: the evaluation of the trial (crs.c:133) and the local mutation + its evaluation
  * (crs.c:139-146, K5) for the slots completed by the preceding nla_k_crs_advance (same window):
@@ -375,12 +369,6 @@ int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *
  * that stream) behind block c's launches opens it.  gate == NULL: no waiting. */
 int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                                 uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream);
-/* the same with flags.  NLA_STOCHRANK_PREFETCH: a unit reads the upstream counter and loads its next block of inputs during the
- * current block, and moves its own counter a few ticks into the next one (hip/isres_kernels.hip, isres_stochrank_kernel<1>): the
- * same elements in the same order, the memory round trips off the head of the blocks. */
-#define NLA_STOCHRANK_PREFETCH 1
-int nla_k_isres_stochrank_ex(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
-                             uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, int flags, void *stream);
 int nla_k_set_flag(int *d_flag, int value, void *stream);
 
 /* replaces: nlopt_nrand(0,1), mt19937ar.c:216-232, for a run of 4-word attempts: appends the
@@ -411,15 +399,6 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
                               const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
                               double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
                               void *stream);
-/* the same with flags.  NLA_EVOLVE_FAST_SCAN: the scan counts an individual's redraws with sigma' formed from staged factors (one exp
- * per staged deviate instead of one per candidate start and coordinate) and a margin around the bounds; draws inside the margin take
- * the exact expressions, so E, T and everything downstream are bit-identical to the flag-less call (hip/isres_scan_fast.h).  Written at
- * the end of round 4 without a device at hand: off by default ("amd_isres_fast_scan"), GPU tests staged under tests/staged/. */
-#define NLA_EVOLVE_FAST_SCAN 1
-int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
-                                 const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
-                                 double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
-                                 int flags, void *stream);
 
 /* ---- the batched local optimisers: common pieces ---------------------------------------------------- */
 /* External evaluation: the objective of a local search is not one of the compiled-in device objectives but a host callback

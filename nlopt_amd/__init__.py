@@ -19,9 +19,6 @@ LIB_PATH = os.environ.get("NLOPT_AMD_LIB") or os.path.join(_HERE, "lib", "libnlo
 GN_CRS2_LM, GN_MLSL, GD_MLSL, GN_MLSL_LDS, GD_MLSL_LDS = 19, 20, 21, 22, 23
 LD_LBFGS, LD_MMA, GN_ISRES, G_MLSL, G_MLSL_LDS, GN_ESCH = 11, 24, 35, 38, 39, 42
 LN_COBYLA = 25
-CHAIN_RESOLVER = 1          # nla_k_crs_chain_ex flag NLA_CHAIN_RESOLVER (include/nlopt_amd.h)
-STOCHRANK_PREFETCH = 1      # nla_k_isres_stochrank_ex flag NLA_STOCHRANK_PREFETCH
-EVOLVE_FAST_SCAN = 1        # nla_k_isres_evolve_rounds_ex flag NLA_EVOLVE_FAST_SCAN
 # nlopt_result values
 FAILURE, INVALID_ARGS, OUT_OF_MEMORY, ROUNDOFF_LIMITED, FORCED_STOP = -1, -2, -3, -4, -5
 SUCCESS, STOPVAL_REACHED, FTOL_REACHED, XTOL_REACHED, MAXEVAL_REACHED, MAXTIME_REACHED = 1, 2, 3, 4, 5, 6
@@ -162,6 +159,7 @@ def lib():
     L.nla_dev_free.restype = None
     for nm in ("nla_memcpy_h2d", "nla_memcpy_d2h", "nla_memcpy_d2d"):
         getattr(L, nm).argtypes = [vp, vp, C.c_size_t, vp]
+    L.nla_memset.argtypes = [vp, C.c_int, C.c_size_t, vp]
     L.nla_stream_create.restype = vp
     L.nla_stream_destroy.argtypes = [vp]
     L.nla_stream_sync.argtypes = [vp]
@@ -194,8 +192,7 @@ def lib():
     L.nla_dev_free_uncached.restype = None
     L.nla_k_crs_chain.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_double, vp, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_int, vp, vp,
                                   C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_int, vp]
-    L.nla_k_crs_chain_ex.argtypes = L.nla_k_crs_chain.argtypes[:-1] + [C.c_int, vp]       # ..., fwcap, flags, stream
-    L.nla_crs_chain_tickets.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.nla_crs_chain_tickets.argtypes = [C.c_int, C.c_int, C.c_int]
     L.nla_crs_chain_tickets.restype = C.c_uint32
     L.nla_crs_chain_ctrl_bytes.argtypes = [C.c_int, C.c_int]
     L.nla_crs_chain_ctrl_bytes.restype = C.c_size_t
@@ -205,12 +202,12 @@ def lib():
     L.nla_k_isres_rank_count.argtypes = [C.c_int64, vp, vp, vp, vp, vp]
     L.nla_k_isres_bits.argtypes = [vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     L.nla_k_isres_stochrank.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
-    L.nla_k_isres_stochrank_ex.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]   # ..., gate, rows_per_gate, gate_value, flags, stream
+    L.nla_k_isres_stochrank_gated.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]   # ..., gate, rows_per_gate, gate_value, stream
     L.nla_isres_evolve2_ws_bytes.restype = C.c_size_t
     L.nla_isres_evolve2_ws_bytes.argtypes = [C.c_int]
     L.nla_k_isres_inverse.argtypes = [C.c_int64, vp, vp, vp]
-    L.nla_k_isres_evolve_rounds_ex.argtypes = ([C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double] + [vp] * 11 +
-                                               [C.c_int, C.c_int, vp])   # ..., lb, ub, z, irank, inv, X, S, x0c, state, rho, ws, rounds, flags, stream
+    L.nla_k_isres_evolve_rounds.argtypes = ([C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double] + [vp] * 11 +
+                                            [C.c_int, vp])   # ..., lb, ub, z, irank, inv, X, S, x0c, state, rho, ws, rounds, stream
     L.nla_k_crs_commit.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_mutate.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
     L.nla_mt_jump_poly_words.argtypes = [C.c_uint64, vp]

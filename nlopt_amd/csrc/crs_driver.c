@@ -444,7 +444,14 @@ nla_crs_session *nla_crs_begin(const nla_crs_engine_ops *ops, void *e, const nla
     /* measured (MI355X, n = 4096, N = 1e5, bench.py --max-spec): 39.9 k evals/s at 40 slots per launch, 40.7 k at 48, 41.6 k at 64,
      * 42.5 k at 96, 43.0 k at 128, 43.1 k at 160 / 192, 42.3 k at 256 — a longer window amortises the launch ramp and the 53 us of
      * host turnaround between windows; past 128 the slots recomputed because a value landed among the worst rows twice eat the gain */
-    if (S->forward && pb->max_spec <= 0 && S->Kmax > 128) S->Kmax = 128;
+    /* round 5, below n = 2048 (a window there is 0.1 - 0.2 ms: the turnaround between two windows is what counts): 256 slots — n = 64
+     * 1.44 -> 1.56 M evals/s, n = 128 1.32 -> 1.39 M, n = 256 1.03 -> 1.08 M, n = 512 unchanged (profiles/r05_staged_ab.txt) */
+    if (S->forward && pb->max_spec <= 0 && S->Kmax > (n >= 2048 ? 128 : 256)) S->Kmax = n >= 2048 ? 128 : 256;
+    /* a small population cannot feed a deep window: a value that is accepted lands among the window's K worst rows of N with probability
+     * ~ K / N, and past CH_EXTRA = 32 such values per window (or one landing twice) the device's resolution stops being verifiable and
+     * the rest of the window is dropped — K <= N / 16 keeps that to a few per window (N = 2000, n = 64: 27 % of the slots dropped at
+     * K = 256 over the emulated device, 3 % at 125) */
+    if (S->forward && pb->max_spec <= 0 && (int64_t) S->Kmax > N / 16) S->Kmax = N / 16 > 8 ? (int) (N / 16) : 8;
     S->runlen = 4.0;
     rs->ops = ops; rs->e = e; rs->pb = &S->pb; rs->x = x; rs->minf = minf;
     rs->need_x = (stop->xtol_rel > 0 || stop->xtol_abs != NULL);

@@ -79,7 +79,6 @@ struct nla_crs_hip_engine {
      * what every slot took from where (pinned, written by the kernel) */
     void *d_ctrl;
     uint32_t ticket_base;
-    int chain_flags;               /* "amd_chain_resolver" (default 0): NLA_CHAIN_RESOLVER — the chain advanced by a dedicated wavefront */
     uint32_t *h_fwcnt, *h_fwrec;
     double *d_Wf;
     int force_upload;              /* NLA_CRS_UPLOAD: the pass's lists through the H2D copy even when they fit the kernel arguments (A/B switch) */
@@ -98,7 +97,9 @@ struct nla_crs_hip_engine {
     char err[256];
 };
 
-#define NLA_CRS_FORWARD_MIN_N 512      /* device-resolved windows (hip/crs_chain.hip) from this dimension on; conservative passes below */
+#define NLA_CRS_FORWARD_MIN_N 1        /* device-resolved windows (hip/crs_chain.hip) from this dimension on — every dimension since round 5 (with the resolver
+                                        * wavefront the windows beat the conservative passes at n = 64 / 128 / 256 too: profiles/r05_staged_ab.txt); the
+                                        * conservative passes remain what host objectives, user kernels, column-sharded multi-rank jobs and "amd_forward" = 0 run on */
 
 #define FAIL(e, ...) do { snprintf((e)->err, sizeof (e)->err, __VA_ARGS__); return -1; } while (0)
 #define CK(e, call) do { int rc_ = (call); if (rc_) FAIL(e, "%.160s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
@@ -797,12 +798,12 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     e->timed = (n >= 2048 || e->pass_log || (e->pass_no++ % TIME_EVERY_WINDOW) == 0) && e->stats;
     if (e->timed) CK(e, nla_event_record(e->ev0, e->main));
     {
-        const int rc = nla_k_crs_chain_ex(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf,
-                                          nW, on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status, e->h_fwcnt,
-                                          e->h_fwrec, fwcap, e->chain_flags, e->main);
+        const int rc = nla_k_crs_chain(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf,
+                                       nW, on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status, e->h_fwcnt,
+                                       e->h_fwrec, fwcap, e->main);
         if (rc) FAIL(e, "nla_k_crs_chain failed: %s", nla_dev_error_string(rc));
     }
-    e->ticket_base += nla_crs_chain_tickets(n, e->ld, K, e->chain_flags);
+    e->ticket_base += nla_crs_chain_tickets(n, e->ld, K);
     if (e->timed) CK(e, nla_event_record(e->ev1, e->main));
     if (e->idle_fn) e->idle_fn(e->idle_arg);      /* the window is with the device: the driver's upkeep of its ordered set runs beside it */
     CK(e, nla_stream_sync(e->main));              /* status and records were written into pinned host memory by the kernel */
@@ -866,11 +867,9 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         pb->stats = &opt->stats;
         pb->max_spec = (int) nlopt_get_param(opt, "amd_max_spec", 0);
         pb->window_factor = nlopt_get_param(opt, "amd_window_factor", 0);
-        /* the device-resolved windows pay for the in-kernel chain per block: ~3 us under the evaluating workgroups' lock — worth it
-         * where a trial's gather takes longer than that (n >= 2048: 33 MB per trial) — and well under 1 us with the dedicated resolver
-         * wavefront (crs_chain_resolver.h), which moves the break-even down: measured at n = 512, N = 1e5 on the MI355X
-         * (profiles/r04_crs_chain_resolver.txt): conservative passes 445 k evals/s, windows under the lock 316 k, windows with the
-         * resolver 606 k.  n = 64: conservative passes 1.18 M against 337 k under the lock — not measured with the resolver, stays */
+        /* device-resolved windows (hip/crs_chain.hip, the chain advanced by the resolver wavefront) at every dimension.  Measured on the
+         * MI355X, N = 1e5 (profiles/r05_staged_ab.txt; conservative passes -> windows -> windows of 256 slots): n = 64 1.26 -> 1.44 -> 1.56 M
+         * evals/s, n = 128 1.07 -> 1.32 -> 1.39 M, n = 256 0.75 -> 1.03 -> 1.08 M, n = 512 (round 4) 445 -> 606 k */
         pb->forward = nlopt_get_param(opt, "amd_forward", n >= NLA_CRS_FORWARD_MIN_N ? 1 : 0) != 0;
         pb->forward = nla_dbg_int("NLA_CRS_FORWARD", pb->forward);                 /* A/B switch for the bench */
         if (nlopt_get_param(opt, "amd_host_eval", 0) != 0) pb->obj = -1;   /* force the host-callback path */
@@ -890,9 +889,6 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
         if (*eout) (*eout)->fuse_commit = !opt || nlopt_get_param(opt, "amd_fuse_commit", 1) != 0;
         if (*eout) (*eout)->doorbell = !opt || nlopt_get_param(opt, "amd_doorbell", 1) != 0;
-        /* who advances the chain: the resolver wavefront where it was measured (below the round-2 threshold), the lock version from
-         * n = 2048 on — the headline configuration, where the chain is hidden behind the gather and nothing was measured yet */
-        if (*eout) (*eout)->chain_flags = (opt ? nlopt_get_param(opt, "amd_chain_resolver", n < 2048 ? 1 : 0) != 0 : n < 2048) ? NLA_CHAIN_RESOLVER : 0;
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
     if (opt && nlopt_amd_comm_world(opt->comm) > 1) {

@@ -14,10 +14,17 @@
  *              reference's bit for bit).  Workgroups draw (slot, chunk) from a ticket counter, front slot first.
  *   evaluate   the workgroup that completes the LAST chunk of a slot evaluates f of the trial point, forms the mutation the
  *              reference would try after a rejection (crs.c:139-146, words of the next stream block) and evaluates it too.
- *   resolve    whoever finished an evaluation advances the chain as far as the evaluated slots reach, in block order, under
- *              a lock: f(T) < f(current worst)? else f(M) < f(worst)? — crs_trial's decisions on the window's list of worst
- *              rows (their f values come with the launch; a new value that lands among them is tracked) — and publishes, per
- *              worst row, who overwrote it (slot, trial or mutation) and how far the chain has got.
+ *   resolve    ONE DEDICATED WAVEFRONT (the holder of ticket 0; crs_chain_resolver.h) advances the chain as far as the evaluated
+ *              slots reach, in block order, out of its registers: f(T) < f(current worst)? else f(M) < f(worst)? — crs_trial's
+ *              decisions on the window's list of worst rows (their f values come with the launch; a new value that lands
+ *              among them is tracked) — and publishes, per worst row, who overwrote it (slot, trial or mutation) and how far
+ *              the chain has got.  (Rounds 2-4 had the evaluating workgroups do this under a lock: five dependent round
+ *              trips per slot; measured side by side on the MI355X in round 5 — n = 4096: 43.7 k -> 45.7 k evals/s, n = 512:
+ *              316 k -> 676 k, profiles/r05_staged_ab.txt — and deleted.)
+ *   new best   a trial that becomes the new best point ends the window: every later slot started its sum from the old best
+ *              row (crs.c:69).  The resolver publishes the slot in ctrl->halt; workgroups that draw a ticket for a later
+ *              slot after that leave at once (their slot's status says "not computed"), so the launch ends as soon as the
+ *              ~8 slots in flight have drained instead of gathering the rest of the window for nothing.
  *   consume    a slot whose next pick is one of the worst rows ahead of it waits until that row's fate is known: overwritten
  *              by an earlier block -> read the writer's point (TX / TM of that slot, final before it was published);
  *              chain already past this slot's predecessors without touching the row -> read the row itself.
@@ -54,6 +61,8 @@
 #include "../../../include/nlopt_amd.h"
 
 #define CH_EXTRA 32                      /* accepted values that landed among the window's worst rows */
+#define CH_FWAVES 8                      /* f is reduced as a workgroup of 8 wavefronts reduces it (= NLA_FIN_WAVES of crs_kernels.hip, SH_WAVES of crs_shard.hip):
+                                          * windows, conservative passes and column-sharded jobs give the same f bit for bit at every n */
 #include <stddef.h>
 
 /* control block of one launch (device memory, zeroed before the launch except `ticket`, which only grows) */
@@ -64,7 +73,7 @@ struct chain_ctrl {
 /* behind the control block: fv[2K] doubles (fT, fM of every slot, for the resolver — the status records themselves may live in
  * pinned host memory), then the u32 arrays done[K], evald[K], rowstate[nW] */
 
-/* RES = 1 (launch flag NLA_CHAIN_RESOLVER): the fv area holds one 16-byte record per slot instead (crs_chain_resolver.h), evald is unused */
+/* the fv area holds one 16-byte record per slot (crs_chain_resolver.h: ~bits(fT), ~bits(fM)); evald is unused (the lock version's flag) */
 #include "crs_chain_resolver.h"
 static_assert(offsetof(chain_ctrl, next) == 4 * CH_CTRL_NEXT && offsetof(chain_ctrl, halt) == 4 * CH_CTRL_HALT && offsetof(chain_ctrl, naccept) == 4 * CH_CTRL_NACCEPT &&
               offsetof(chain_ctrl, wp) == 4 * CH_CTRL_WP && offsetof(chain_ctrl, nextra) == 4 * CH_CTRL_NEXTRA && offsetof(chain_ctrl, pk) == 4 * CH_CTRL_PK &&
@@ -76,53 +85,7 @@ struct chain_lists { int inl; int64_t W[NLA_KA_MAX]; double Wf[NLA_KA_MAX]; };
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-/* crs_trial's decisions for the evaluated slots at the front of the unresolved part (one thread, under the lock) */
-__device__ void chain_resolve(chain_ctrl *c, uint32_t *evald, uint32_t *rowstate, const double *fv, int K, int nW,
-                              const int64_t *W, const double *Wf, double f_best, int64_t i0)
-{
-    for (;;) {
-        if (atomicCAS(&c->lock, 0u, 1u) != 0u) return;          /* the holder re-checks after it lets go */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        uint32_t j = c->next;
-        while (j < (uint32_t) K && !c->halt && ld_agent(&evald[j])) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            /* the current worst: the next untouched row of the list, or a value that landed among them */
-            double fw = -HUGE_VAL; int64_t rw = -1; int xi = -1;
-            if (c->wp < (uint32_t) nW) { fw = Wf[c->wp]; rw = W[c->wp]; }
-            for (uint32_t e = 0; e < c->nextra; ++e)
-                if (rw < 0 || c->xf[e] > fw || (c->xf[e] == fw && c->xrow[e] > rw)) { fw = c->xf[e]; rw = c->xrow[e]; xi = (int) e; }
-            if (rw < 0) { c->halt = 1; break; }                 /* beyond the rows this launch knows */
-            const double fT = fv[2 * j], fM = fv[2 * j + 1];
-            int kind = 0;
-            double fnew = 0;
-            if (fT < fw) { kind = 1; fnew = fT; }               /* crs.c:135 */
-            else if (fM < fw) { kind = 2; fnew = fM; }           /* the mutation of crs.c:139-146, accepted at :135 */
-            if (kind) {
-                if (xi >= 0) { c->xf[xi] = c->xf[c->nextra - 1]; c->xrow[xi] = c->xrow[c->nextra - 1]; --c->nextra; }   /* (its row's first writer stays on record) */
-                else { st_agent(&rowstate[c->wp], 1u | ((uint32_t) kind << 1) | (j << 3)); ++c->wp; }
-                ++c->naccept;
-                /* the new value may itself be among the worst that are left */
-                if (nW > 0 && (fnew > Wf[nW - 1] || (fnew == Wf[nW - 1] && rw > W[nW - 1]))) {
-                    if (c->nextra == CH_EXTRA) c->halt = 1;
-                    else { c->xf[c->nextra] = fnew; c->xrow[c->nextra] = rw; ++c->nextra; }
-                }
-                if (fnew < f_best || (fnew == f_best && rw < i0)) c->halt = 1;   /* a new best: everything behind started from the old one */
-            }
-            j += (kind == 1) ? 1u : 2u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            st_agent(&c->next, j);
-            st_agent(&c->pk, j | ((j - c->wp) << 16));
-        }
-        if (c->halt) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); st_agent(&c->next, (uint32_t) K + 2u); st_agent(&c->pk, 0xffffffffu); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(&c->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");       /* unlock before the re-check (the arriving side: publish, fence, try the lock) */
-        const uint32_t nx = ld_agent(&c->next);
-        if (!(nx < (uint32_t) K && ld_agent(&evald[nx]))) return;
-    }
-}
-
-template <int VEC, int U, int WAVES, int OBJ, int RES>
+template <int VEC, int U, int WAVES, int OBJ>
 __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     const chain_lists L_first_kernel_argument,  /* read through the kernarg segment below, never by name: indexing the by-value copy
                                                  * with a run-time j makes the compiler move all 1.5 KB of it to scratch memory */
@@ -141,29 +104,36 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     __shared__ V sacc[64];
     __shared__ int32_t srow[NLA_ADV_RCAP];
     __shared__ int s_turn, s_ticket, s_last;
-    __shared__ uint32_t s_nrec;
-    __shared__ double scratch[2 * WAVES];
+    __shared__ uint32_t s_nrec, s_halt;
+    __shared__ double scratch[2 * CH_FWAVES];
     volatile __attribute__((address_space(3))) int *turn = (volatile __attribute__((address_space(3))) int *) &s_turn;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     double *fv = reinterpret_cast<double *>(ctrl + 1);
-    uint32_t *done = reinterpret_cast<uint32_t *>(fv + 2 * (size_t) K), *evald = done + K, *rowstate = evald + K;
+    uint32_t *done = reinterpret_cast<uint32_t *>(fv + 2 * (size_t) K), *rowstate = done + 2 * (size_t) K;     /* (done[K], K unused words, rowstate[nW]) */
     const int64_t *W = Lk->inl ? (const int64_t *) Lk->W : Wd;
     const double *Wf = Lk->inl ? (const double *) Lk->Wf : Wfd;
-    if (threadIdx.x == 0) { s_ticket = (int) (atomicAdd(&ctrl->ticket, 1u) - ticket_base); s_nrec = 0; }
+    if (threadIdx.x == 0) { s_ticket = (int) (atomicAdd(&ctrl->ticket, 1u) - ticket_base); s_nrec = 0; s_halt = ld_agent(&ctrl->halt); }
     __syncthreads();
-    if constexpr (RES != 0) {
-        /* the first workgroup to run is the resolver: wavefront 0 advances the chain for the whole launch, the others leave.  Every
-         * slot's workgroups hold later tickets, so whatever they wait for is running already */
-        if (s_ticket == 0) {
-            if (wave == 0)
-                chain_resolver_wave(reinterpret_cast<uint32_t *>(ctrl), reinterpret_cast<const uint64_t *>(fv), rowstate, K, nW, W, Wf, f_best, i0,
-                                    resolver_timeout);
+    /* the first workgroup to run is the resolver: wavefront 0 advances the chain for the whole launch, the others leave.  Every
+     * slot's workgroups hold later tickets, so whatever they wait for is running already */
+    if (s_ticket == 0) {
+        if (wave == 0)
+            chain_resolver_wave(reinterpret_cast<uint32_t *>(ctrl), reinterpret_cast<const uint64_t *>(fv), rowstate, K, nW, W, Wf, f_best, i0,
+                                resolver_timeout);
+        return;
+    }
+    const int wg = s_ticket - 1;
+    const int a = wg / chunks, chunk = wg % chunks;             /* front slot first: producers before consumers */
+    {
+        /* a new best point at slot j ended the window (ctrl->halt = 2 | (j + 1) << 8): this slot started from the old best row and
+         * will be dropped — do not gather it.  (read once, by the thread that drew the ticket: the whole workgroup stays or leaves) */
+        const uint32_t h = s_halt;
+        if ((h & 2u) && (uint32_t) a >= (h >> 8)) {
+            if (threadIdx.x == 0) { status[a].t = 0; if (chunk == 0) fwcnt[a] = 0; }
             return;
         }
-    } else (void) resolver_timeout;
-    const int wg = s_ticket - RES;
-    const int a = wg / chunks, chunk = wg % chunks;             /* front slot first: producers before consumers */
+    }
     const uint64_t block = first_block + (uint64_t) a;
     const uint32_t rb = (uint32_t) (block % ring_blocks);
     const int q = (int) (block & (uint64_t) slot_mask);
@@ -318,30 +288,22 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n;
         double *m = TM + (size_t) q * (size_t) ld;
         auto getx = [&](int i) { return __builtin_nontemporal_load(x + i); };
-        const double fT = sign * nla_block_objective<OBJ, WAVES>(n, getx, scratch);
+        const double fT = sign * nla_block_objective_as<OBJ, WAVES, CH_FWAVES>(n, getx, scratch);
         auto mut = [&](int i) {        /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
             const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
             const double wv = nla_urand_from(0., 1., ww.x, ww.y);
             return nla_clamp_box(xb[i] * (1 + wv) - wv * getx(i), lb[i], ub[i]);
         };
         for (int i = tid; i < n; i += WAVES * 64) m[i] = mut(i);
-        const double fM = sign * nla_block_objective<OBJ, WAVES>(n, mut, scratch);
+        const double fM = sign * nla_block_objective_as<OBJ, WAVES, CH_FWAVES>(n, mut, scratch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* every wave's part of m[] has landed before lane 0 publishes the slot */
         __syncthreads();
         if (tid == 0) {
             status[a].fT = fT; status[a].fM = fM; status[a].t = n; status[a].pad = 0;
-            if constexpr (RES != 0) {
-                /* the record IS the flag (a word is nonzero once written); TX / TM of the slot have landed (the waits above) */
-                uint64_t *rec = reinterpret_cast<uint64_t *>(fv) + 2 * (size_t) a;
-                __hip_atomic_store(rec, ch_bits_of_f(fT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(rec + 1, ch_bits_of_f(fM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                fv[2 * a] = fT; fv[2 * a + 1] = fM;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                st_agent(&evald[a], 1u);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-                chain_resolve(ctrl, evald, rowstate, fv, K, nW, W, Wf, f_best, i0);
-            }
+            /* the record IS the flag (a word is nonzero once written); TX / TM of the slot have landed (the waits above) */
+            uint64_t *rec = reinterpret_cast<uint64_t *>(fv) + 2 * (size_t) a;
+            __hip_atomic_store(rec, ch_bits_of_f(fT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + 1, ch_bits_of_f(fM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -365,19 +327,19 @@ extern "C" int nla_crs_chain_chunks(int n, int ld)
     return (n + cpw - 1) / cpw;
 }
 
-extern "C" uint32_t nla_crs_chain_tickets(int n, int ld, int K, int flags)
+extern "C" uint32_t nla_crs_chain_tickets(int n, int ld, int K)
 {
-    return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + ((flags & NLA_CHAIN_RESOLVER) ? 1u : 0u);
+    return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + 1u;         /* the slots' workgroups + the resolver's */
 }
 
-extern "C" int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
-                                  const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
-                                  uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
-                                  const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
-                                  nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int flags, void *stream)
+extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                               const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                               uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                               const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                               nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream)
 {
     if (K <= 0) return 0;
-    if (K > 256 || nW > 256 || nW < 0 || obj < 0 || (flags & ~NLA_CHAIN_RESOLVER)) return (int) hipErrorInvalidValue;
+    if (K > 256 || nW > 256 || nW < 0 || obj < 0) return (int) hipErrorInvalidValue;
     const double sign = nla_obj_sign(&obj);
     /* rows of TX / TM start on a 128-byte line: a line that holds the end of one slot's row and the start of the next one's could
      * sit in a CU's vector L1 from the read of the first and serve a stale start of the second (consumers take no L1 invalidate) */
@@ -393,17 +355,15 @@ extern "C" int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64
     }
     const bool vec2 = chain_vec2(n, ld);
     const int chunks = nla_crs_chain_chunks(n, ld);
-    const bool res = (flags & NLA_CHAIN_RESOLVER) != 0;
-    const dim3 grid((unsigned) ((long) chunks * K) + (res ? 1u : 0u));
+    const dim3 grid((unsigned) ((long) chunks * K) + 1u);
     const uint64_t res_timeout = 200000000ull;                /* 2 s of the 100 MHz clock without a single evaluation arriving */
     chain_ctrl *c = (chain_ctrl *) ctrl;
     /* everything but the ticket counter starts from zero */
     hipError_t e = hipMemsetAsync((char *) ctrl + sizeof(uint32_t), 0, nla_crs_chain_ctrl_bytes(K, nW) - sizeof(uint32_t), st);
     if (e != hipSuccess) return (int) e;
-#define CHAIN_R(VEC, UU, WV, O, R) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O, R>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
+#define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
         pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
         fwcnt, fwrec, fwcap, sign, res_timeout)
-#define CHAIN(VEC, UU, WV, O) do { if (res) CHAIN_R(VEC, UU, WV, O, 1); else CHAIN_R(VEC, UU, WV, O, 0); } while (0)
 #define CHAIN_SHAPE(O)                                                                   \
     if (vec2) {                                                                          \
         if (n >= 2048) CHAIN(2, 32, 8, O); else if (n >= 512) CHAIN(2, 16, 4, O); else CHAIN(2, 16, 2, O); \
@@ -413,17 +373,6 @@ extern "C" int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64
     NLA_OBJ_DISPATCH(obj, CHAIN_SHAPE)
 #undef CHAIN_SHAPE
 #undef CHAIN
-#undef CHAIN_R
     NLA_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
-                               const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
-                               uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
-                               const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
-                               nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream)
-{
-    return nla_k_crs_chain_ex(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host,
-                              slot_mask, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, 0, stream);
 }

@@ -1,7 +1,7 @@
 /* crs_chain_resolver.h — the accept / reject chain of a device-resolved CRS2_LM window (crs.c:125-156) advanced by ONE
- * DEDICATED WAVEFRONT out of registers (crs_chain.hip, launch flag NLA_CHAIN_RESOLVER; "amd_chain_resolver").
+ * DEDICATED WAVEFRONT out of registers (crs_chain.hip).
  *
- * Why: chain_resolve() in crs_chain.hip is run by whichever workgroup has just evaluated a slot, under a lock, on a control block
+ * Why: rounds 2-4 had whichever workgroup had just evaluated a slot advance the chain under a lock, on a control block
  * in uncached device memory — the lock, `next`, `evald[j]`, `wp`, the two f values and the re-check after the unlock are five to
  * six DEPENDENT round trips to memory per slot, ≈ 3 us (profiles/r04_crs_forward_small_n.txt).  At n = 4096 a slot's gather takes
  * 20 us and hides that; at n = 512 the window's 128 slots are gathered and evaluated in ≈ 15 us and then wait 128 x 3 us for the
@@ -14,9 +14,10 @@
  * (zero = not yet; the one f whose complement is zero is the all-ones NaN, stored as another NaN), so the evaluating workgroup
  * publishes with two plain stores and the resolver needs no second load.
  *
- * The decisions are chain_resolve()'s, statement for statement; the host still verifies every one of them (crs_driver.c).  The
- * wavefront gives up (halt: every waiting slot proceeds, the host recomputes what it cannot verify) when nothing was evaluated for
- * `timeout` ticks of the 100 MHz clock — a launch can be slow, it cannot hang on the resolver.
+ * The decisions are crs_trial's (crs.c:125-156), statement for statement (stated sequentially in oracle/port_kernels.c and in
+ * tools/chain_resolver_check.cpp); the host still verifies every one of them (crs_driver.c).  The wavefront gives up (halt: every
+ * waiting slot proceeds, the host recomputes what it cannot verify) when nothing was evaluated for `timeout` ticks of the 100 MHz
+ * clock since the last evaluation arrived — a launch can be slow, it cannot hang on the resolver.
  *
  * This header is compiled twice: by hipcc into crs_chain_kernel<..., RES = 1>, and by g++ into tools/chain_resolver_check.cpp,
  * where 64 threads play the wavefront in lockstep and a feeder thread plays the evaluating workgroups (CH_* primitives below). */
@@ -97,7 +98,7 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
     };
     const double f_last = nW > 0 ? list_f((uint32_t) nW - 1u) : 0.;
     const int64_t r_last = nW > 0 ? list_row((uint32_t) nW - 1u) : -1;
-    const uint64_t t0 = ch_clock();
+    uint64_t t0 = ch_clock();
     while (next < (uint32_t) K && !halt) {
         const uint32_t s = next + (uint32_t) lane;
         uint64_t rt = 0, rm = 0;
@@ -149,12 +150,16 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
                         ++nextra;
                     }
                 }
-                if (fnew < f_best || (fnew == f_best && rw < i0)) halt = 1;   /* a new best: everything behind started from the old one */
+                if (fnew < f_best || (fnew == f_best && rw < i0)) {           /* a new best: everything behind started from the old one */
+                    halt = 2u | ((j + 1u) << 8);
+                    if (lane == 0) ch_st32(&ctrl_words[CH_CTRL_HALT], halt);  /* at once: workgroups that draw a ticket for a later slot leave (crs_chain.hip) */
+                }
             }
             i += (kind == 1) ? 1u : 2u;
         }
         next += i;
         idle = 0;
+        t0 = ch_clock();                                         /* the timeout counts from the last evaluation that arrived */
         if (halt) break;
         ch_release();                                            /* the run's rowstate stores have landed before `next` moves */
         if (lane == 0) {
@@ -165,8 +170,8 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
     ch_release();
     if (lane == 0) {
         if (halt) { ch_st32(&ctrl_words[CH_CTRL_NEXT], (uint32_t) K + 2u); ch_st32(&ctrl_words[CH_CTRL_PK], 0xffffffffu); }
-        ch_st32(&ctrl_words[CH_CTRL_HALT], halt);               /* for post-mortems: nothing on the device reads these */
-        ch_st32(&ctrl_words[CH_CTRL_NACCEPT], naccept);
+        ch_st32(&ctrl_words[CH_CTRL_HALT], halt);               /* 0 ran to the end, 1 gave up (list exhausted, too many landed values, timeout), 2 | (j + 1) << 8: new best at slot j */
+        ch_st32(&ctrl_words[CH_CTRL_NACCEPT], naccept);         /* for post-mortems: nothing on the device reads these three */
         ch_st32(&ctrl_words[CH_CTRL_WP], wp);
         ch_st32(&ctrl_words[CH_CTRL_NEXTRA], nextra);
     }

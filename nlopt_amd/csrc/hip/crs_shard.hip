@@ -19,7 +19,7 @@
 #include "dev_common.h"
 #include "../../../include/nlopt_amd.h"
 
-#define SH_WAVES 8                       /* = NLA_FIN_WAVES of crs_kernels.hip and the chain kernel's WAVES at n >= 2048: the same f reduction */
+#define SH_WAVES 8                       /* = NLA_FIN_WAVES of crs_kernels.hip = CH_FWAVES of crs_chain.hip: the same f reduction */
 
 /* rows [row_first, row_first + nrows) of the slice from the stream: local column i = global c0 + i, i < nc; pad columns [nc, ld)
  * are zero (the vectorised gather-sum may run over one of them).  One wavefront per row. */

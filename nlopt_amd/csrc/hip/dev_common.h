@@ -156,6 +156,32 @@ __device__ __forceinline__ double nla_block_objective(int n, Get get, double *sc
     return nla_obj_finish<OBJ>(n, t, get);
 }
 
+/* the same f, bit for bit, as nla_block_objective<OBJ, VW> gives in a workgroup of VW wavefronts — computed by a workgroup of WAVES <= VW
+ * wavefronts: each wavefront plays the virtual wavefronts wave, wave + WAVES, ... (same elements per lane, same butterfly), the partial
+ * results are combined in the same order.  `scratch` = 2*VW doubles.  (The CRS2_LM chain kernel runs 1 - 8 wavefronts per workgroup
+ * depending on n; the finish kernel of the conservative passes and the column-sharded job always 8: one reduction for all of them.) */
+template <int OBJ, int WAVES, int VW, class Get>
+__device__ __forceinline__ double nla_block_objective_as(int n, Get get, double *scratch)
+{
+    static_assert(WAVES <= VW, "more wavefronts than virtual ones");
+    const int lane = threadIdx.x & (NLA_WAVE - 1), wave = threadIdx.x >> 6;
+    __syncthreads();                      /* scratch may still be read from a previous call */
+    for (int vw = wave; vw < VW; vw += WAVES) {
+        const nla_obj_part t = nla_obj_wave_reduce<OBJ>(nla_obj_partial<OBJ>(n, vw * NLA_WAVE + lane, NLA_WAVE * VW, get));
+        if (lane == 0) { scratch[2 * vw] = t.a; scratch[2 * vw + 1] = t.b; }
+    }
+    __syncthreads();
+    nla_obj_part t;
+    t.a = scratch[0]; t.b = scratch[1];
+#pragma unroll
+    for (int w = 1; w < VW; ++w) {
+        nla_obj_part o;
+        o.a = scratch[2 * w]; o.b = scratch[2 * w + 1];
+        t = nla_obj_combine<OBJ>(t, o);
+    }
+    return nla_obj_finish<OBJ>(n, t, get);
+}
+
 #define NLA_OBJ_DISPATCH(obj, CALL)                                   \
     switch (obj) {                                                    \
     case NLA_OBJ_RASTRIGIN:  { CALL(NLA_OBJ_RASTRIGIN);  } break;     \

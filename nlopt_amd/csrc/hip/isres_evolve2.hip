@@ -189,61 +189,6 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
     }
 }
 
-/* ---- scan, exp off the serial chain (launch flag NLA_EVOLVE_FAST_SCAN; isres_scan_fast.h says why the counts are the exact scan's) ---- */
-#include "isres_scan_fast.h"
-__global__ __launch_bounds__(256) void ev2_scan_fast_kernel(ev2_args A)
-{
-    extern __shared__ double sm[];
-    __shared__ long long s_red[4];
-    __shared__ long long s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
-    const int n = A.n;
-    const int64_t st1 = A.state[1], st2 = A.state[2], st10 = A.state[10];
-    const int na = A.ws_nact[i];
-    const double rho_r = A.rho[2 * A.phase], rho_a = A.rho[2 * A.phase + 1];
-    if (st2 || st10) return;
-    if (na < 0) return;
-    const double rhoc = rho_a > 0 ? rho_r / rho_a : 0.0;
-    {                                                           /* the predicted start: ev2_scan_kernel's */
-        long long acc = 0;
-        for (int q = tid; q < i; q += 256) acc += A.ws_nact[q];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-        if (lane == 0) s_red[wave] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            const long long ab = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-            s_base = st1 + i + 2 * ab + (long long) floor(rhoc * (double) ab) - EVD / 2;
-            A.ws_base[i] = s_base;
-        }
-        __syncthreads();
-    }
-    const int64_t base = s_base;
-    const int ZW = EVD + 3 * na + 65;
-    double *xi = sm, *sg = sm + n, *lo = sm + 2 * n, *hi = sm + 3 * n, *smax = sm + 4 * n, *tol = sm + 5 * n, *zw = sm + 6 * n, *ezw = zw + ZW;
-    const double sqn = sqrt((double) n);
-    const int32_t *act = A.ws_act + (size_t) i * n;
-    const double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n;
-    for (int a = tid; a < na; a += 256) {
-        const int j = act[a];
-        const double l = A.lb[j], h = A.ub[j], xa = wxi[a];
-        xi[a] = xa; sg[a] = wsg[a]; lo[a] = l; hi[a] = h; smax[a] = (h - l) / sqn; tol[a] = sf_tol(l, h, xa);
-    }
-    const int64_t avail = A.zcount - base;
-    const int zwlen = (int) (avail < ZW ? (avail < 0 ? 0 : avail) : ZW);
-    const bool zw_cut = avail < ZW;
-    /* the staged deviates and, once per deviate instead of once per lane and coordinate, exp(tau z) */
-    for (int q = tid; q < zwlen; q += 256) { const int64_t g = base + q; const double zv = g >= 0 ? A.z[g] : 0.0; zw[q] = zv; ezw[q] = sf_stage_e(A.tau, zv); }
-    __syncthreads();
-    {
-        const int d = tid;                                      /* blockDim.x == EVD */
-        const int e = ev2_walk_fast(na, d, zwlen, zw_cut, base + d < 0, A.taup, A.tau, zw, ezw, xi, sg, lo, hi, smax, tol,
-                                    A.T + (size_t) i * 64 * EVD + d, EVD, nullptr);
-        A.E[(size_t) i * EVD + d] = (int16_t) (e > 32767 ? -1 : e);
-    }
-}
-
-/* ---- chain ------------------------------------------------------------------------------------------------------- */
 /* One workgroup of 1024: all of it copies the E table into LDS (16 bytes per thread and step, everything in flight at once); wavefront 0
  * then walks the block.  The walk is one dependent chain — start of individual i -> its E entry -> start of i + 1 — and a lone wavefront
  * issues one instruction every four cycles, so what counts is the number of instructions per individual and that no memory latency sits
@@ -429,13 +374,12 @@ extern "C" int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *i
     return 0;
 }
 
-extern "C" int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
                                             const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
                                             double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
-                                            int flags, void *stream)
+                                            void *stream)
 {
-    if (!nla_isres_evolve2_supported(n) || (flags & ~NLA_EVOLVE_FAST_SCAN)) return (int) hipErrorInvalidValue;
-    const bool fast = (flags & NLA_EVOLVE_FAST_SCAN) != 0;
+    if (!nla_isres_evolve2_supported(n)) return (int) hipErrorInvalidValue;
     ev2_args A;
     A.n = n; A.ld = ld; A.phase = phase; A.pop = pop; A.survivors = survivors; A.zcount = zcount; A.taup = taup; A.tau = tau;
     A.lb = lb; A.ub = ub; A.z = z; A.irank = irank; A.inv = inv; A.X = X; A.S = S; A.x0c = x0c; A.state = state; A.rho = rho;
@@ -450,13 +394,12 @@ extern "C" int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t po
     A.T = (int16_t *) take(sizeof(int16_t) * EVM * 64 * EVD);
     A.ws_base = (int64_t *) take(sizeof(int64_t) * EVM);
     A.ws_start = (int64_t *) take(sizeof(int64_t) * EVM);
-    const size_t lds_scan = fast ? sizeof(double) * (size_t) (6 * n + 2 * EV2_ZW(n)) : sizeof(double) * (size_t) (5 * n + EV2_ZW(n));
+    const size_t lds_scan = sizeof(double) * (size_t) (5 * n + EV2_ZW(n));
     const size_t lds_write = sizeof(double) * (size_t) (7 * n + EV2_ZW(n));
     const size_t lds_chain = sizeof(int16_t) * EVM * EVD;
     static bool attr_set = false;
     if (!attr_set) {
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipGetLastError();
@@ -465,19 +408,10 @@ extern "C" int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t po
     hipStream_t st = (hipStream_t) stream;
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(ev2_stage_kernel, dim3(EVM), dim3(256), 0, st, A);
-        if (fast) hipLaunchKernelGGL(ev2_scan_fast_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);
-        else hipLaunchKernelGGL(ev2_scan_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);
+        hipLaunchKernelGGL(ev2_scan_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);
         hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(1024), lds_chain, st, A);
         hipLaunchKernelGGL(ev2_write_kernel, dim3(EVM), dim3(64), lds_write, st, A);
     }
     NLA_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
-                                         const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
-                                         double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
-                                         void *stream)
-{
-    return nla_k_isres_evolve_rounds_ex(n, ld, phase, pop, survivors, zcount, taup, tau, lb, ub, z, irank, inv, X, S, x0c, state, rho, ws, rounds, 0, stream);
 }

@@ -685,28 +685,16 @@ extern "C" int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *str
 {
     return nla_k_isres_stochrank_gated(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, NULL, 1, 0, stream);
 }
-extern "C" int nla_k_isres_stochrank_ex(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
-                                        uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, int flags, void *stream);
 extern "C" int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                                            int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream)
 {
-    return nla_k_isres_stochrank_ex(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, gate, rows_per_gate, gate_value, 0, stream);
-}
-extern "C" int nla_k_isres_stochrank_ex(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
-                                        uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, int flags, void *stream)
-{
     hipStream_t st = (hipStream_t) stream;
     if (pop <= 0) return 0;
-    if (flags & ~NLA_STOCHRANK_PREFETCH) return (int) hipErrorInvalidValue;
     const int64_t units = (nsweeps + 63) / 64;
     const int64_t rowwords = (pop - 1 + 63) / 64;
     if (units > 0 && pop > 1) {
-        if (flags & NLA_STOCHRANK_PREFETCH)
-            hipLaunchKernelGGL(isres_stochrank_pre_kernel, dim3((unsigned) units), dim3(64), 0, st, pop, nsweeps, streams, progress, bits, rowwords, ticket,
-                               swapped, gate, rows_per_gate > 0 ? rows_per_gate : 1, gate_value);
-        else
-            hipLaunchKernelGGL(isres_stochrank_kernel, dim3((unsigned) units), dim3(64), 0, st, pop, nsweeps, streams, progress, bits, rowwords, ticket,
-                               swapped, gate, rows_per_gate > 0 ? rows_per_gate : 1, gate_value);
+        hipLaunchKernelGGL(isres_stochrank_kernel, dim3((unsigned) units), dim3(64), 0, st, pop, nsweeps, streams, progress, bits, rowwords, ticket,
+                           swapped, gate, rows_per_gate > 0 ? rows_per_gate : 1, gate_value);
         NLA_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(isres_unpack_kernel, dim3((unsigned) ((pop + 255) / 256)), dim3(256), 0, st, pop,

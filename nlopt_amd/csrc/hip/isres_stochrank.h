@@ -1,10 +1,11 @@
 /* isres_stochrank.h — the two kernels of the ISRES stochastic-ranking pipeline (isres.c:206-228 as a systolic pipeline; the comment in
- * isres_kernels.hip in front of the include describes it): isres_stochrank_kernel, what runs by default, and isres_stochrank_pre_kernel,
- * its read-ahead variant.  A header of their own because it is compiled twice: by hipcc as part of isres_kernels.hip (SR_KERNEL,
+ * isres_kernels.hip in front of the include describes it).  A header of its own because it is compiled twice: by hipcc as part of isres_kernels.hip (SR_KERNEL,
  * SR_SHARED_INT and SR_WAIT_VMCNT0 expand to the device constructs they replace — the machine code is what it was before the
  * kernels moved here), and by g++ into tools/stochrank_check.cpp, where the 64 lanes of a unit are threads in lockstep, the DPP shifts
- * and v_readfirstlane exchanges between barriers, all units of a small pipeline run at once, and both kernels must reproduce the
- * reference's double loop. */
+ * and v_readfirstlane exchanges between barriers, all units of a small pipeline run at once, and the kernel must reproduce the
+ * reference's double loop.  (Round 4's read-ahead variant — poll / load / store moved off the head of the 64-tick blocks — ran on the
+ * MI355X in round 5: same results, 54.99 against 55.31 ms per generation at config 3, i.e. nothing: the tick is not waiting for
+ * memory.  Deleted; profiles/r05_staged_ab.txt.) */
 #ifndef NLA_ISRES_STOCHRANK_H
 #define NLA_ISRES_STOCHRANK_H
 #ifndef SR_KERNEL
@@ -110,160 +111,6 @@ SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__
                 }
             }
         }
-    }
-    if (active) swapped_out[stage] = (uint8_t) (swv >> 31);
-}
-
-/* isres_stochrank_kernel with its memory traffic moved off the head of the blocks (launch flag NLA_STOCHRANK_PREFETCH, "amd_isres_rank_prefetch"; written at the end of round 4 with no GPU minutes left, NOT
- * YET RUN ON A DEVICE, off by default).  A kernel of its own — the tick is the one above, repeated — so that the default kernel's machine
- * code stays what was validated.  In the kernel above a block
- * begins with two dependent round trips — lane 0 polls the upstream progress counter, then every lane loads its input element — and
- * ends with a third, the wait for the output stores to land before the unit's own counter moves: ~2.4 us of stalls around 2.75 us
- * of ticks, which is the 80 ns per tick measured against the 43 ns its 26 instructions need.  With PRE, within block b (ticks 0..63):
- *   tick SR_STORE_AT  the outputs that completed at tick 62 of block b-1 (kept in two registers since) are stored
- *   tick SR_POLL_AT   lane 0 reads the upstream counter
- *   tick SR_PUB_AT    the stores of SR_STORE_AT have landed (the wait is still there, it no longer stalls): this unit's counter moves
- *   tick SR_LOAD_AT   if the counter read at SR_POLL_AT covers block b+1, its 64 inputs are loaded (poll -> wait -> load as before:
- *                     nothing is loaded before a counter value that covers it has been seen)
- * so that no memory operation is younger than ~20 ticks (~1 us) when something waits for it — loads and stores share ONE counter
- * (vmcnt), and the compiler's waits are conservative, so a store issued just before a block's head would be waited for there.  A
- * prefetch that comes too early falls back to the blocking poll of the plain kernel, which delays this unit — i.e. gives it the slack
- * that makes its following prefetches succeed.  The price is pipeline depth: a unit publishes ~30 ticks later and polls ~56 ticks
- * earlier than it needs the data, ~50 ticks more lag per unit (+39 k ticks at pop = 5e4 on top of 199 k) against ~46 instead of 80 ns
- * per tick.  Same elements, same order, same results: only when loads and stores are issued changes. */
-#define SR_STORE_AT 2
-#define SR_POLL_AT 4
-#define SR_PUB_AT 24
-#define SR_LOAD_AT 40
-SR_KERNEL void isres_stochrank_pre_kernel(int64_t pop, int64_t nsweeps, uint64_t *__restrict__ streams,
-                                                              int *__restrict__ progress, const uint64_t *__restrict__ bits,
-                                                              int64_t rowwords, int *__restrict__ ticket, uint8_t *__restrict__ swapped_out,
-                                                              const int *__restrict__ gate, int rows_per_gate, int gate_value)
-{
-    SR_SHARED_INT(s_unit);
-    const int lane = threadIdx.x;
-    if (lane == 0) s_unit = atomicAdd(ticket, 1);
-    __syncthreads();
-    const int64_t unit = s_unit;
-    const int64_t stage = unit * 64 + lane;
-    const bool active = stage < nsweeps;
-    const uint64_t *in = streams + (size_t) unit * (size_t) pop;
-    uint64_t *out = streams + (size_t) (unit + 1) * (size_t) pop;
-    int *prog_in = progress + unit, *prog_out = progress + unit + 1;
-    const uint64_t *brow = bits + (size_t) (active ? stage : 0) * (size_t) rowwords;
-    const int ipop = (int) pop, rw1 = (int) rowwords - 1;
-    const int half = lane >> 5;                 /* row word of the window of block b starts at word b - 1 - half */
-    const int cut = (63 - 2 * lane) & 63;       /* ... at this bit (1..63, never 0) */
-    uint32_t c_lo = 0, c_hi = 0, o_lo = 0, o_hi = 0;         /* carry and output element of this stage ("-inf"), as two words */
-    uint32_t vin_lo = 0, vin_hi = 0, ob_lo = 0, ob_hi = 0;   /* the unit's inputs / outputs of the current block, one per lane */
-    uint32_t swv = 0;                                        /* bit 31: this stage swapped at least once */
-    const uint32_t amask = active ? 0x80000000u : 0u;
-    auto clampw = [&](int w) { return w < 0 ? 0 : (w > rw1 ? rw1 : w); };
-    if (gate) {
-        /* the rows of uniform bits are still being produced, in blocks of rows_per_gate sweeps, by launches on another stream
-         * (isres_driver.c, "amd_isres_gated"): gate[c] == gate_value once block c is complete.  This unit reads rows 64 unit ..
-         * 64 unit + 63: wait for the block of the last one BEFORE the first load of a row (a load ahead of the flag could leave a
-         * stale line in this CU's cache), then make the other stream's stores visible */
-        int64_t lastrow = unit * 64 + 63;
-        if (lastrow > nsweeps - 1) lastrow = nsweeps - 1;
-        if (lastrow < 0) lastrow = 0;
-        const int *g = gate + lastrow / rows_per_gate;
-        if (lane == 0) while (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_value) __builtin_amdgcn_s_sleep(8);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    uint64_t wa = brow[clampw(-1 - half)], wb = brow[clampw(0 - half)], wp = brow[clampw(1 - half)];
-    const int nblk = (ipop + 63) / 64 + 2;      /* the last output leaves lane 63 at tick pop + 126 */
-    int pre_prog = 0, pend_prog = -1, hold_base = -1;   /* lane 0's early reading of the upstream counter; this unit's counter value still to be
-                                                         * stored; first element of the held output block (-1: none) */
-    uint64_t pre_in = 0, hold = 0;              /* the next block's inputs, one per lane, valid if pre_ok; a completed output block */
-    bool pre_ok = false, pre_polled = false;
-    for (int b = 0; b < nblk; ++b) {
-        const int tb = b * 64;
-        /* u < PF bits of ticks tb .. tb+63 of this stage: row bits tb - 2 lane - 1 + k */
-        const uint64_t win = (wa >> cut) | (wb << (64 - cut));
-        wa = wb; wb = wp;
-        wp = brow[clampw(b + 2 - half)];        /* (used two blocks from now: the load has a whole block to land) */
-        /* the unit's next 64 inputs; past the end of the stream: +inf */
-        uint64_t inb = ((uint64_t) SR_PINF_HI << 32) | SR_PINF_LO;
-        if (tb < ipop) {
-            if (pre_ok) inb = pre_in;    /* loaded during the previous block */
-            else {
-                const int need = tb + 64 < ipop ? tb + 64 : ipop;
-                if (lane == 0) while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (tb + lane < ipop) inb = sr_ld(in + tb + lane);
-            }
-        }
-        pre_ok = false; pre_polled = false;
-        vin_lo = (uint32_t) inb; vin_hi = (uint32_t) (inb >> 32);
-        auto half_block = [&](const int h) __attribute__((always_inline)) {
-            const uint32_t wcur = h ? (uint32_t) (win >> 32) : (uint32_t) win;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                /* input: lane 0 from the unit's input block, the others from their left neighbour's output of the previous tick */
-                const uint32_t x_lo = sr_dpp(vin_lo, o_lo, 0), x_hi = sr_dpp(vin_hi, o_hi, 0);
-                vin_lo = sr_dpp(vin_lo, vin_lo, 1); vin_hi = sr_dpp(vin_hi, vin_hi, 1);
-                /* by fval if u < PF (bit k of the window: isres.c:210) or both penalties are zero (bit 31 of both high words),
-                 * else by penalty (:211-212, :220) — sign bits instead of booleans: the tick stays straight-line integer code */
-                const uint32_t usef = (wcur << (31 - k)) | (c_hi & x_hi);
-                const int32_t df = (int32_t) (x_lo >> 12) - (int32_t) (c_lo >> 12);                    /* < 0: fval[carry] > fval[x]   (:213) */
-                const int32_t dp = (int32_t) (x_hi & 0x0FFFFF00u) - (int32_t) (c_hi & 0x0FFFFF00u);    /* < 0: penalty[carry] > penalty[x] */
-                const int32_t d = ((int32_t) usef < 0) ? df : dp;
-                const bool swap = active && d < 0;
-                swv |= (uint32_t) d & amask;
-                o_lo = swap ? x_lo : c_lo;          /* emitted: the smaller of the pair */
-                o_hi = swap ? x_hi : c_hi;
-                c_lo = swap ? c_lo : x_lo;          /* kept: the larger */
-                c_hi = swap ? c_hi : x_hi;
-                /* lane 63's outputs move down one lane per tick: after tick tb + 62 lane l holds output tb - 128 + l of the unit */
-                ob_lo = sr_dpp(o_lo, ob_lo, 1); ob_hi = sr_dpp(o_hi, ob_hi, 1);
-                {
-                    if (h == SR_STORE_AT / 32 && k == SR_STORE_AT % 32 && hold_base >= 0) {    /* (uniform) the block completed at the end of the previous one */
-                        if (hold_base + lane < ipop) sr_st(out + hold_base + lane, hold);
-                        pend_prog = hold_base + 64 < ipop ? hold_base + 64 : ipop;
-                        hold_base = -1;
-                    }
-                    if (h == SR_POLL_AT / 32 && k == SR_POLL_AT % 32 && tb + 64 < ipop) {      /* is the next block there already? */
-                        pre_prog = (lane == 0) ? __hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                        pre_polled = true;
-                    }
-                    if (h == SR_PUB_AT / 32 && k == SR_PUB_AT % 32 && pend_prog >= 0) {        /* the elements have landed before the count says so */
-                        SR_WAIT_VMCNT0();
-                        if (lane == 0) __hip_atomic_store(prog_out, pend_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pend_prog = -1;
-                    }
-                    if (h == SR_LOAD_AT / 32 && k == SR_LOAD_AT % 32 && pre_polled) {
-                        const int ntb = tb + 64, need1 = ntb + 64 < ipop ? ntb + 64 : ipop;
-                        if (__builtin_amdgcn_readfirstlane(pre_prog) >= need1) {               /* (uniform) the counter covers the block: load it */
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            pre_in = ((uint64_t) SR_PINF_HI << 32) | SR_PINF_LO;
-                            if (ntb + lane < ipop) pre_in = sr_ld(in + ntb + lane);
-                            pre_ok = true;
-                        }
-                    }
-                }
-                if (k == 30) {
-                    if (h == 1 && tb >= 128) {
-                        const int base = tb - 128;
-                        hold = ((uint64_t) ob_hi << 32) | ob_lo; hold_base = base;     /* stored SR_STORE_AT ticks into the next block */
-                    }
-                }
-            }
-        };
-        /* all 64 ticks straight-line: the compiler then waits for each load exactly where its value is first used — across the back
-         * edge of a loop over the two halves it waits for EVERYTHING at the loop's head, i.e. also for a store issued a few ticks earlier */
-        half_block(0);
-        half_block(1);
-    }
-    /* what the last two blocks left: a counter update, a held block */
-    if (pend_prog >= 0) {
-        SR_WAIT_VMCNT0();
-        if (lane == 0) __hip_atomic_store(prog_out, pend_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (hold_base >= 0) {
-        if (hold_base + lane < ipop) sr_st(out + hold_base + lane, hold);
-        SR_WAIT_VMCNT0();
-        if (lane == 0) __hip_atomic_store(prog_out, hold_base + 64 < ipop ? hold_base + 64 : ipop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (active) swapped_out[stage] = (uint8_t) (swv >> 31);
 }

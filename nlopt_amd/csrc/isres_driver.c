@@ -47,9 +47,7 @@ typedef struct {
     void *st, *ev0, *ev1;
     void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
     int gated;                      /* "amd_isres_gated" (default 1; one rank, generator on its own stream): the ranking pipeline starts while its bits are still produced */
-    int rank_flags;                 /* "amd_isres_rank_prefetch" (default 0): NLA_STOCHRANK_PREFETCH — the pipeline's units read ahead (isres_stochrank_pre_kernel) */
     int *d_gate; int gate_value;    /* ISRES_GATES flags: block c of the ranking bits is complete when d_gate[c] == gate_value (a new value every generation) */
-    int evolve_flags;               /* "amd_isres_fast_scan" (default 0): NLA_EVOLVE_FAST_SCAN — the evolve scan counts redraws with staged exp factors and a margin (hip/isres_scan_fast.h) */
     int evolve_serial;              /* "amd_isres_evolve_serial" != 0: the one-workgroup evolve kernel (the parallel one's reference in the tests) */
     int overlap;                    /* default; "amd_isres_overlap" = 0 / NLA_ISRES_OVERLAP=0 turn it off: generator work beside the latency-bound kernels */
     int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
@@ -254,8 +252,8 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         DCK(d, nla_memcpy_h2d(d->d_progress, d->h_progress, sizeof(int) * (size_t) (d->units + 1), d->st));
         DCK(d, nla_memset(d->d_ticket, 0, sizeof(int), d->st));
         if (d->ev0) nla_event_record(d->ev0, d->st);
-        DCK(d, nla_k_isres_stochrank_ex(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank,
-                                        gated ? d->d_gate : NULL, (int) rows_per_gate, d->gate_value, d->rank_flags, d->st));
+        DCK(d, nla_k_isres_stochrank_gated(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank,
+                                           gated ? d->d_gate : NULL, (int) rows_per_gate, d->gate_value, d->st));
         if (d->ev1) nla_event_record(d->ev1, d->st);
         DCK(d, nla_memcpy_d2h(d->h_swapped, d->d_swapped, (size_t) nsweeps, d->st));
         if (d->overlap && nsweeps == pop && !d->spec_valid) {
@@ -386,9 +384,8 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
                 const int64_t left = kend - state[0];
                 int rounds = (int) (left / 96) + 1;
                 if (rounds > 24) rounds = 24;
-                DCK(d, nla_k_isres_evolve_rounds_ex(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z,
-                                                    d->d_irank, d->d_inv, d->d_X, d->d_S, d->d_scratch, d->d_state, d->d_rho, d->d_ws, rounds,
-                                                    d->evolve_flags, d->st));
+                DCK(d, nla_k_isres_evolve_rounds(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z,
+                                                 d->d_irank, d->d_inv, d->d_X, d->d_S, d->d_scratch, d->d_state, d->d_rho, d->d_ws, rounds, d->st));
                 d->ev_rounds += (uint64_t) rounds;
                 if (d->overlap && !reserved) {
                     /* beside the rounds: the segment states behind the NEXT ranking's words (those of this phase's deviates generated
@@ -519,8 +516,6 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     D.comm = opt ? opt->comm : NULL;
     D.evolve_serial = opt ? nlopt_get_param(opt, "amd_isres_evolve_serial", 0) != 0 : 0;
     D.gated = opt ? nlopt_get_param(opt, "amd_isres_gated", 1) != 0 : 1;
-    D.rank_flags = (opt && nlopt_get_param(opt, "amd_isres_rank_prefetch", 0) != 0) ? NLA_STOCHRANK_PREFETCH : 0;
-    D.evolve_flags = (opt && nlopt_get_param(opt, "amd_isres_fast_scan", 0) != 0) ? NLA_EVOLVE_FAST_SCAN : 0;
     D.overlap = opt ? nlopt_get_param(opt, "amd_isres_overlap", 1) != 0 : 1;            /* 0: the one-stream generation */
     D.overlap = nla_dbg_int("NLA_ISRES_OVERLAP", D.overlap) > 0;     /* A/B switch for the bench */
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */

@@ -37,6 +37,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#define NLA_MLSL_SEG_REGENS 64          /* segment length (in regenerations of 624 words) of an MLSL run's MT19937 device stream */
 
 #define K2PI (6.2831853071795864769252867665590057683943388)
 #define MLSL_SIGMA 2.
@@ -50,7 +51,7 @@ typedef struct {
     nla_evaluator ev;
     double *h_rows;                 /* host objective: the iteration's samples, pinned (N x ld) */
     void *rs;                       /* the generator's stream: st itself, or (prefetch) a second one */
-    int prefetch; uint64_t prefetched_at;   /* opt-in: the next iteration's sample words generated beside the local phase; stream position they were generated for */
+    int prefetch; uint64_t prefetched_at;   /* device objectives: the next iteration's sample words generated beside the local phase; stream position they were generated for */
     void *st;
     nla_mtstream *mts;
     uint64_t words_used;
@@ -308,19 +309,21 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.st = nla_stream_create();
     /* several ranks: set-up ends with an exchange of "ready" (comm.c, nla_comm_agree_ready) — a rank that fails below says so there
      * instead of leaving the others in the run's first collective */
-    /* PREFETCH (opt-in, "amd_mlsl_prefetch" / NLA_MLSL_PREFETCH=1, until it has been measured): pseudo-random sampling (every MLSL
+    /* PREFETCH (always, with a device objective; measured on the MI355X in round 5 together with the short segments below: config 4
+     * 15.9 -> 13.9 ms per iteration, profiles/r05_staged_ab.txt): pseudo-random sampling (every MLSL
      * variant at n > 1111, where the reference has no Sobol generator either) costs a generator pass per iteration that is bound by
      * latency, not throughput — 2 n N words are 13 segments = 13 wavefronts at config 4, 1.9 ms + 0.5-1 ms of segment jumps of the
      * 7.5 ms sampling phase.  Nothing between two sampling phases draws random numbers (the local optimisers are deterministic), so
      * the NEXT iteration's words are generated on a stream of their own beside the distance pass and the local searches.  Hand-over
      * = a host synchronisation of that stream before the sampling kernel reads them. */
-    D.prefetch = !host && ((opt && nlopt_get_param(opt, "amd_mlsl_prefetch", 0) != 0) || nla_dbg_int("NLA_MLSL_PREFETCH", 0) > 0);
+    D.prefetch = !host;
     D.prefetched_at = ~0ULL;
     D.rs = (D.st && D.prefetch) ? nla_stream_create() : D.st;
     {
-        /* "amd_mlsl_seg_regens" (default NLA_MT_SEG_REGENS = 1024: the stream layout every other algorithm uses; NOT YET RUN ON A DEVICE with
-         * another value): the segment length of this run's stream — 64 makes 205 wavefronts of the 13 above.  The words are the same. */
-        int seg = opt ? (int) nlopt_get_param(opt, "amd_mlsl_seg_regens", NLA_MT_SEG_REGENS) : NLA_MT_SEG_REGENS;
+        /* "amd_mlsl_seg_regens": the segment length of this run's stream (NLA_MT_SEG_REGENS = 1024 is the layout every other algorithm
+         * uses) — 64 makes 205 wavefronts of the 13 above; measured at config 4 (MI355X, round 5): 15.9 ms per iteration at 1024, 14.7 at
+         * 256, 14.4 at 64, 14.3 at 16.  The words are the same. */
+        int seg = opt ? (int) nlopt_get_param(opt, "amd_mlsl_seg_regens", NLA_MLSL_SEG_REGENS) : NLA_MLSL_SEG_REGENS;
         if (seg < 1 || seg > NLA_MT_SEG_REGENS || (seg & (seg - 1))) seg = NLA_MT_SEG_REGENS;
         if (D.st && D.rs) D.mts = seg == NLA_MT_SEG_REGENS ? nla_mtstream_create(D.rs) : nla_mtstream_create_seg(D.rs, seg);
     }

@@ -497,13 +497,6 @@ int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams,
     if (gate) for (int64_t r = 0; r < nsweeps; r += rows_per_gate) if (gate[r / rows_per_gate] != gate_value) return 1;
     return nla_k_isres_stochrank(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, st);
 }
-/* the launch flags change when a unit issues its loads and stores on the device, not what comes out */
-int nla_k_isres_stochrank_ex(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket, uint8_t *swapped,
-                             int32_t *irank, const int *gate, int rows_per_gate, int gate_value, int flags, void *st)
-{
-    if (flags & ~1) return EMU_ERR;
-    return nla_k_isres_stochrank_gated(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, gate, rows_per_gate, gate_value, st);
-}
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                           uint8_t *swapped, int32_t *irank, void *st)
 {
@@ -620,12 +613,11 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
 int nla_isres_evolve2_supported(int n) { return getenv("NLA_EMU_EVOLVE2") != NULL && n <= 1150; }
 size_t nla_isres_evolve2_ws_bytes(int n) { (void) n; return 16; }
 static int emu_forced_handover(int64_t k, int phase) { return (((uint32_t) k * 2654435761u + (uint32_t) phase * 977u) >> 7) % 53u == 0; }
-int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
-                                 const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
-                                 double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, int flags, void *st)
+int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
+                              const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
+                              double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
 {
     EMU_LAUNCH();
-    if (flags & ~NLA_EVOLVE_FAST_SCAN) return 1;              /* (the flag changes how the device counts, not what: nothing to emulate) */
     const int64_t kend = phase == 0 ? pop : survivors;
     (void) inv; (void) rho; (void) ws;
     for (int r = 0; r < rounds; ++r) {
@@ -642,12 +634,6 @@ int nla_k_isres_evolve_rounds_ex(int n, int ld, int phase, int64_t pop, int64_t 
         state[9] = state[0] - first;
     }
     return 0;
-}
-int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
-                              const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
-                              double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
-{
-    return nla_k_isres_evolve_rounds_ex(n, ld, phase, pop, survivors, zcount, taup, tau, lb, ub, z, irank, inv, X, S, x0c, state, rho, ws, rounds, 0, st);
 }
 
 /* ---- CRS2_LM (hip/crs_kernels.hip): the per-kernel CPU references of port_kernels.c behind the launchers' ring / slot addressing,
@@ -803,17 +789,7 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
                     TX, TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL, NULL);
     return 0;
 }
-/* the launch flags change who advances the chain on the device, not what comes out */
-uint32_t nla_crs_chain_tickets(int n, int ld, int K, int flags) { return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + (uint32_t) (flags & 1); }
-int nla_k_crs_chain_ex(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
-                       const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W,
-                       const double *Wf, int nW, int w_on_host, int slot_mask, const double *lb, const double *ub, double *TX, double *TM, void *ctrl,
-                       uint32_t ticket_base, nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int flags, void *st)
-{
-    if (flags & ~1) return EMU_ERR;
-    return nla_k_crs_chain(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host, slot_mask,
-                           lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, st);
-}
+uint32_t nla_crs_chain_tickets(int n, int ld, int K) { return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + 1u; }
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
                      uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
                      const double *lb, const double *ub, double *fT_ring, double *fM_ring, nla_crs_slot_status *status, void *st)

@@ -11,10 +11,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-# tests/staged/: GPU tests of opt-in code that has not run on a device yet (see the file headers) — collected only when named
-collect_ignore_glob = ["staged/*"]
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     lib = os.path.join(ROOT, "nlopt_amd", "lib", "libnlopt_amd.so")
@@ -35,7 +31,7 @@ def pytest_configure(config):
 # full size are the first 30 tests, then the kernel-level tests, the other algorithms of the path, and the periphery (host
 # algorithms, client programs) last — so that with `-x` a surprise in the periphery cannot hide the hot path from whoever reads
 # the log (round-2 verdict, item 2).  Files not listed (the CPU suite) keep their alphabetical order in front.
-GPU_ORDER = ["test_gpu_crs", "test_gpu_fullsize", "test_gpu_kernels", "test_gpu_chain_resolver", "test_gpu_isres", "test_gpu_mlsl", "test_gpu_lbfgs",
+GPU_ORDER = ["test_gpu_crs", "test_gpu_fullsize", "test_gpu_kernels", "test_gpu_crs_windows", "test_gpu_isres", "test_gpu_mlsl", "test_gpu_lbfgs",
              "test_gpu_exact_local", "test_gpu_mma", "test_gpu_esch", "test_gpu_stops", "test_gpu_fixed_dims", "test_gpu_userobj",
              "test_gpu_maximise", "test_gpu_nan", "test_gpu_host_callbacks", "test_gpu_multiproc", "test_gpu_cobyla", "test_gpu_dropin",
              "test_gpu_cpp_client", "test_gpu_testopt_cli", "test_gpu_zz_clients"]

@@ -63,6 +63,33 @@ def crs_case(name, obj, n, N, extra, seed=42, with_ref=True):
          trial_accepted=tr["accepted"][N:].copy(), trial_xhash=p["xhash"][N:].copy())
 
 
+def crs_long_case(name, obj, n, N, extra, seed=42):
+    """CRS2_LM deep into the trial loop (the steady regime of rejections and mutation blocks the benchmark times, not the
+    all-accept start of a fresh population): the REAL reference and the port, bit for bit over every evaluation; stored: the
+    whole trial phase (f, row, kind, accepted), the hash of x of every 16th evaluation, the best-f sequence (evaluation number
+    and value of every improvement of the minimum — what bench.py compares its own stopping point with) and the running count
+    of accepted trials.  bench.py --steps 20 --warmup 5 stops about 51 000 evaluations into the trial loop."""
+    me = N + extra
+    t0 = time.time()
+    p = O.run_port_crs(obj, n, N, seed, maxeval=me, trace_cap=me + 1000, record=True)
+    print(name, "port: ret", p["ret"], "nevals", p["nevals"], "minf", p["minf"], "%.0f s" % (time.time() - t0), flush=True)
+    tr = p["trace"]
+    assert len(tr) == p["nevals"] == len(p["fseq"]) and np.array_equal(tr["f"], p["fseq"])
+    t0 = time.time()
+    r = O.run_ref(19, obj, n, N, seed, maxeval=me)
+    print(name, "reference: ret", r["ret"], "nevals", r["nevals"], "minf", r["minf"], "%.0f s" % (time.time() - t0), flush=True)
+    assert r["ret"] == p["ret"] and r["nevals"] == p["nevals"] and r["minf"] == p["minf"]
+    assert np.array_equal(r["fseq"], p["fseq"]) and np.array_equal(r["xhash"], p["xhash"]) and np.array_equal(r["x"], p["x"])
+    f = tr["f"]
+    run_min = np.minimum.accumulate(f)
+    imp = np.flatnonzero(np.concatenate(([True], run_min[1:] < run_min[:-1])))       # 0-based evaluation index of every new minimum
+    save(name, obj=obj, n=n, N=N, seed=seed, maxeval=me, ret=p["ret"], nevals=p["nevals"], minf=p["minf"], x=p["x"],
+         words=np.uint64(p["words"]), ref_checked=1, init_f_every16=f[:N:16].copy(), init_f_blocksum64=block_sums(f[:N], 64),
+         trial_f=f[N:].copy(), trial_row=tr["row"][N:].astype(np.int32), trial_kind=tr["kind"][N:].astype(np.int8),
+         trial_accepted=tr["accepted"][N:].astype(np.int8), trial_xhash_every16=p["xhash"][N::16].copy(),
+         best_eval=imp.astype(np.int64) + 1, best_f=run_min[imp].copy())
+
+
 def isres_case(name, obj, n, pop, nineq, gens=2, seed=42):
     """ISRES: `gens` generations' evaluations (one full generation incl. ranking + evolve, then the next generation's
     evaluations — every candidate of generation 2 is a function of generation 1's ranking and of the evolve step)."""
@@ -106,6 +133,8 @@ def mlsl_case(name, obj, n, nsamp, maxeval, seed=42, local_ftol_rel=1e-8):
 CASES = {
     # the metric configuration (BASELINE.json "metric"; SURVEY.md §8d config 5 at pop = 1e5)
     "crs_griewank_n4096_pop1e5": lambda: crs_case("crs_griewank_n4096_pop1e5", "griewank", 4096, 100000, 500),
+    # the metric configuration over the evaluations bench.py's default run times (warm-up + 20 steps of 2000 = about N + 51 000)
+    "crs_griewank_n4096_pop1e5_long": lambda: crs_long_case("crs_griewank_n4096_pop1e5_long", "griewank", 4096, 100000, 60000),
     # config 2
     "crs_rastrigin_n512_pop1e5": lambda: crs_case("crs_rastrigin_n512_pop1e5", "rastrigin", 512, 100000, 5000),
     # n = 64 line of the bench

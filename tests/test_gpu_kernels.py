@@ -174,18 +174,18 @@ class SlotStatus(C.Structure):
                                           ("griewank", 4096, 4200, 24, 4199), ("sphere", 2, 9, 8, 4), ("griewank", 2048, 2100, 20, 77),
                                           ("ackley", 300, 320, 30, 5), ("ackley", 9000, 9100, 6, 5), ("rastrigin", 1000, 1100, 200, 1)])
 def test_chain_kernel_resolves_the_window_like_the_sequential_statement(L, obj, n, N, K, i0):
-    chain_kernel_case(L, obj, n, N, K, i0, 0)
+    chain_kernel_case(L, obj, n, N, K, i0)
 
 
-def chain_kernel_case(L, obj, n, N, K, i0, flags):
+def chain_kernel_case(L, obj, n, N, K, i0):
     """nla_k_crs_chain (hip/crs_chain.hip): one launch computes every slot of the window, evaluates it, replays the accept / reject
     chain on the window's worst rows and lets later slots read what the chain says a worst row holds at their turn.  Against the
     sequential statement orc_k_crs_chain: bit-exact trial points and mutations, f within 1e-10, the same records of what every
     slot read from where.  Small populations (N barely above n) make every slot depend on MANY earlier slots of the same launch:
     the in-kernel waiting, evaluation and resolution are what is tested.  The objective values of the rows are random, so the
-    chain has rejections, accepted mutations and values landing among the worst rows again.
-    flags != 0: the same launch through nla_k_crs_chain_ex (NLA_CHAIN_RESOLVER = 1: the chain advanced by a dedicated wavefront,
-    hip/crs_chain_resolver.h) — same outputs, same control-block words."""
+    chain has rejections, accepted mutations and values landing among the worst rows again.  The chain is advanced by the launch's
+    resolver wavefront (hip/crs_chain_resolver.h); a trial that becomes the new best point ends the window (control word `halt` =
+    2 | (slot + 1) << 8): later slots may come back "not computed" (status.t = 0), never with a wrong point."""
     P = O.port()
     ring = 2 * K + 3
     first = 3 * ring + 2
@@ -228,18 +228,19 @@ def chain_kernel_case(L, obj, n, N, K, i0, flags):
     dst = DevBuf(C.sizeof(St) * K)
     dcnt, drec = DevBuf.from_array(np.zeros(K, np.uint32)), DevBuf.from_array(np.zeros(K * fwcap, np.uint32))
     for rep in range(2):                        # twice on the same control block: the ticket base carries over
-        if flags:
-            assert L.nla_k_crs_chain_ex(oid, n, ld, dX.ptr, i0, fbest, dj.ptr, dp.ptr, dl.ptr, dw.ptr, ring, first, K, dW.ptr, dWf.ptr, nW, 0, mask,
-                                        dlb.ptr, dub.ptr, dTX.ptr, dTM.ptr, dctrl.ptr, rep * L.nla_crs_chain_tickets(n, ld, K, flags), dst.ptr, dcnt.ptr,
-                                        drec.ptr, fwcap, flags, None) == 0
-        else:
-            assert L.nla_k_crs_chain(oid, n, ld, dX.ptr, i0, fbest, dj.ptr, dp.ptr, dl.ptr, dw.ptr, ring, first, K, dW.ptr, dWf.ptr, nW, 0, mask,
-                                     dlb.ptr, dub.ptr, dTX.ptr, dTM.ptr, dctrl.ptr, rep * K * L.nla_crs_chain_chunks(n, ld), dst.ptr, dcnt.ptr,
-                                     drec.ptr, fwcap, None) == 0
+        assert L.nla_memset(dst.ptr, 0, C.sizeof(St) * K, None) == 0
+        assert L.nla_k_crs_chain(oid, n, ld, dX.ptr, i0, fbest, dj.ptr, dp.ptr, dl.ptr, dw.ptr, ring, first, K, dW.ptr, dWf.ptr, nW, 0, mask,
+                                 dlb.ptr, dub.ptr, dTX.ptr, dTM.ptr, dctrl.ptr, rep * L.nla_crs_chain_tickets(n, ld, K), dst.ptr, dcnt.ptr,
+                                 drec.ptr, fwcap, None) == 0
         assert L.nla_stream_sync(None) == 0
         raw = dst.to_array(np.uint8, C.sizeof(St) * K)
         st = np.frombuffer(raw.tobytes(), dtype=[("fT", "f8"), ("fM", "f8"), ("t", "i4"), ("pad", "i4")])
-        assert np.all(st["t"] == n)
+        craw = dctrl.to_array(np.uint8, cb)
+        chead = np.frombuffer(craw[:32].tobytes(), np.uint32)
+        # every slot up to a new best point is computed; behind it a slot is either computed in full or not at all
+        live = int(chead[3] >> 8) if (chead[3] & 2) else K
+        assert np.all(st["t"][:live] == n) and np.all((st["t"] == n) | (st["t"] == 0))
+        done = st["t"] == n
         # the sequential statement, its accept / reject decisions taken on the DEVICE's f values (they differ from the host's in the
         # last bits; with N barely above n the trial points are nearly equal and so are their f: a comparison could go either way)
         dev_status = (St * K)()
@@ -251,9 +252,7 @@ def chain_kernel_case(L, obj, n, N, K, i0, flags):
         P.orc_k_crs_chain(oid, n, ld, X.ctypes.data, i0, fbest, jn.ctypes.data, pos.ctypes.data, last.ctypes.data, w.ctypes.data, ring, first, K,
                           W.ctypes.data, Wf.ctypes.data, nW, mask, lb.ctypes.data, ub.ctypes.data, TXr.ctypes.data, TMr.ctypes.data,
                           C.addressof(str_), cntr.ctypes.data, recr.ctypes.data, fwcap, C.addressof(dev_status), dbg.ctypes.data)
-        # the chain as the device resolved it (control block: 8 u32, 32 f64 + 32 i64 of landed values, fv[2K], done[K], evald[K], rowstate[nW])
-        craw = dctrl.to_array(np.uint8, cb)
-        chead = np.frombuffer(craw[:32].tobytes(), np.uint32)
+        # the chain as the device resolved it (control block: 8 u32, 32 f64 + 32 i64 of landed values, 2K record words, done[K], K unused words, rowstate[nW])
         rs_dev = np.frombuffer(craw[32 + 512 + 16 * K + 8 * K: 32 + 512 + 16 * K + 8 * K + 4 * nW].tobytes(), np.uint32)
         assert np.array_equal(rs_dev, dbg[8:8 + nW]), ("who overwrote which worst row", "device next/halt/naccept/wp/nextra", chead[2:7].tolist(),
                                                      "statement next/halt/wp/nextra", dbg[:4].tolist(),
@@ -267,13 +266,15 @@ def chain_kernel_case(L, obj, n, N, K, i0, flags):
         TM = dTM.to_array(np.float64, nslot * ld).reshape(nslot, ld)
         for a in range(K):
             qa = (first + a) & mask
+            if not done[a]:
+                continue
             assert cnt[a] == cntr[a], (a, cnt[a], cntr[a])
             if cnt[a] <= fwcap:                  # (beyond the capacity which records survive is arbitrary; the caller discards such a slot)
                 k = int(cnt[a])
                 assert sorted(rec[a, :k].tolist()) == sorted(recr.reshape(K, fwcap)[a, :k].tolist()), a
             assert np.array_equal(TX[qa, :n], TXr[qa, :n]), a
             assert np.array_equal(TM[qa, :n], TMr[qa, :n]), a
-        assert close(st["fT"], fTr, scale) and close(st["fM"], fMr, scale)
+        assert close(st["fT"][done], fTr[done], scale) and close(st["fM"][done], fMr[done], scale)
     kinds = (recr >> 16) & 3
     assert K < 8 or (cntr.sum() > 0 and (kinds[recr > 0] > 0).any())      # the case does exercise reading from producers
 

@@ -1,13 +1,9 @@
-"""STAGED (-m gpu, NOT collected by `pytest tests/`): an MT19937 device stream cut into SHORTER segments than the default 1024 regenerations
-(mtstream.c: nla_mtstream_create_seg; hip/mt_kernels.hip: mt_generate_seg_kernel, nla_k_mt_generate_seg) and MLSL on such a stream
-(`nlopt_set_param(opt, "amd_mlsl_seg_regens", 64)`: 205 wavefronts generate an iteration's 8 M words at config 4 instead of 13).
-
-Written at the end of round 4 with no GPU minutes left.  The words a stream delivers do not depend on how it is cut — that is the whole
-contract, and the CPU twin of this file (tests/test_mt_segments_emulated.py: the same tests over the emulated device, whose jump-ahead
-is the host's GF(2) arithmetic) checks the segment arithmetic of mtstream.c — but mt_generate_seg_kernel HAS NOT RUN ON AN MI355X.  Default
-segment length unchanged; these tests stay out of the driver's `pytest tests/ -m gpu` run (tests/conftest.py: collect_ignore_glob) until
-they have been green on a device once.
-    python -m pytest tests/staged/test_gpu_mlsl_short_segments.py -q -m gpu           (tools/r05_first_call.sh does)"""
+"""-m gpu: an MT19937 device stream cut into SHORTER segments than the 1024 regenerations the other algorithms use (mtstream.c:
+nla_mtstream_create_seg; hip/mt_kernels.hip: mt_generate_seg_kernel, nla_k_mt_generate_seg) and MLSL on such a stream
+(`nlopt_set_param(opt, "amd_mlsl_seg_regens", s)`; MLSL's default is 64 since round 5: 205 wavefronts generate an iteration's 8 M words
+at config 4 instead of 13 — 15.9 -> 14.4 ms per iteration on the MI355X, profiles/r05_staged_ab.txt).  The words a stream delivers do not
+depend on how it is cut — that is the whole contract; tests/test_mt_segments_emulated.py is the CPU twin (segment arithmetic of
+mtstream.c over the emulated device)."""
 import ctypes as C
 
 import numpy as np

@@ -194,13 +194,13 @@ def test_host_callbacks_are_bit_identical_to_the_oracles():
             assert np.array_equal(ga, gb)
 
 
-def test_dedicated_chain_resolver_takes_the_lock_versions_decisions():
-    """hip/crs_chain_resolver.h ("amd_chain_resolver": the accept / reject chain of a device-resolved window advanced by one wavefront
+def test_chain_resolver_wavefront_takes_the_sequential_decisions():
+    """hip/crs_chain_resolver.h (the accept / reject chain of a device-resolved window advanced by one wavefront
     out of registers) compiled by g++ with the wavefront primitives emulated — 64 threads in lockstep, a feeder thread publishing the
     slots' records out of order and partly only after the chain has passed an earlier slot: the rowstate words, next / pk and the final
-    counters equal the sequential statement of chain_resolve() (crs_chain.hip) for drawn windows with ties, NaNs, values landing among
+    counters equal the sequential statement of crs_trial's decisions (crs.c:125-156) for drawn windows with ties, NaNs, values landing among
     the worst rows, new bests and lists shorter than the window; the watchdog halts a window nobody evaluates
-    (tools/chain_resolver_check.cpp).  The device's memory model is not what this checks: tests/test_gpu_chain_resolver.py."""
+    (tools/chain_resolver_check.cpp).  The device's memory model is not what this checks: tests/test_gpu_kernels.py, tests/test_gpu_crs_windows.py."""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -245,36 +245,11 @@ def test_ordered_set_and_list_of_worst_rows_against_a_plain_array():
         os.remove(exe)
 
 
-def test_fast_evolve_scan_counts_what_the_exact_scan_counts():
-    """hip/isres_scan_fast.h — the lane walk of ev2_scan_fast_kernel (opt-in "amd_isres_fast_scan", not yet run on a device): sigma' from
-    staged factors and a decision with a margin, the exact expressions inside the margin — compiled by g++ against the exact scan's lane
-    walk: the same E entry and T column for every candidate start of drawn individuals, with the fast path's exps off by up to 6 ulp,
-    bounds planted 0-3 ulp from draws, parents on their bounds, empty boxes, sigma = 0, windows that end early; and on ordinary
-    individuals not one draw needs the exact path (tools/scan_fast_check.cpp)."""
-    import shutil
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not shutil.which("g++"):
-        pytest.skip("no g++ here")
-    out = os.path.join(root, "tools", "_build")
-    os.makedirs(out, exist_ok=True)
-    exe = os.path.join(out, "scan_fast_check.%d" % os.getpid())
-    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "nlopt_amd", "csrc", "hip"),
-                    os.path.join(root, "tools", "scan_fast_check.cpp"), "-o", exe], check=True)
-    try:
-        for args in (["1500", "1"], ["1500", "2"], ["1500", "3", "plain"]):
-            r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0 and r.stdout.startswith("ok 1500"), r.stdout + r.stderr
-    finally:
-        os.remove(exe)
-
-
 def test_stochastic_ranking_kernels_in_lockstep_emulation():
-    """hip/isres_stochrank.h — isres_stochrank_kernel (the default) and isres_stochrank_pre_kernel (its read-ahead variant, opt-in
-    "amd_isres_rank_prefetch", not yet run on a device) — compiled by g++ with the wavefront primitives emulated: the 64 lanes of a unit
-    are threads in lockstep (DPP wave shifts, v_readfirstlane), all units of the pipeline run at once, some of them slowed down so that
-    the read-ahead kernel's prefetches both hit and miss.  Both kernels reproduce the reference's double loop (isres.c:206-228): final
-    order, per-sweep "swapped" flags, every unit's counter at pop (tools/stochrank_check.cpp)."""
+    """hip/isres_stochrank.h — isres_stochrank_kernel compiled by g++ with the wavefront primitives emulated: the 64 lanes of a unit
+    are threads in lockstep (DPP wave shifts, v_readfirstlane), all units of the pipeline run at once, some of them slowed down.  The
+    kernel reproduces the reference's double loop (isres.c:206-228): final order, per-sweep "swapped" flags, every unit's counter at
+    pop (tools/stochrank_check.cpp)."""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

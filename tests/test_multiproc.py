@@ -363,11 +363,11 @@ def test_isres_overlap_mode_changes_nothing(world, env, obj, n, pop, seed, ncon,
 @pytest.mark.parametrize("obj,n,ns,seed,local,maxeval", [("rastrigin", 5, 12, 5, "lbfgs", 1500), ("griewank", 6, 40, 3, "lbfgs", 3000),
                                                           ("ackley", 8, 0, 9, "mma", 2500), ("rastrigin", 6, 20, 11, "default", 3000)])
 def test_mlsl_prefetch_of_the_next_samples_changes_nothing(world, obj, n, ns, seed, local, maxeval):
-    """MLSL with "amd_mlsl_prefetch" = 1 (opt-in, mlsl_driver.c): pseudo-random sampling's stream words of the NEXT iteration are
+    """MLSL's sample prefetch (mlsl_driver.c, always on with a device objective): pseudo-random sampling's stream words of the NEXT iteration are
     generated on a second stream while the distance pass and the local searches of this one run (nothing in between draws random
     numbers).  Same samples, same local searches, same final generator position as the oracle — incl. the run's last iteration, whose
     prefetched words are never used.  (The emulated device is synchronous: what this cannot see is a missing synchronisation.)"""
-    a = dict(obj=obj, n=n, pop=ns, seed=seed, maxeval=maxeval, local=local, lds=False, params={"amd_mlsl_prefetch": 1})
+    a = dict(obj=obj, n=n, pop=ns, seed=seed, maxeval=maxeval, local=local, lds=False)
     p = O.run_port_mlsl(obj, n, ns, seed, maxeval=maxeval, local="mma" if local == "default" else local, lds=False)
     for d in run_world("gpu_mlsl", a, world=world, extra_env=EMU):
         _check_against_oracle(d, p)

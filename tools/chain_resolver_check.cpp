@@ -1,10 +1,10 @@
 /* tools/chain_resolver_check.cpp — CPU check of hip/crs_chain_resolver.h (development tooling; tests/test_host_logic.py builds and
- * runs it): the SAME SOURCE that hipcc compiles into crs_chain_kernel<..., RES = 1> is compiled here by g++ with the wavefront
+ * runs it): the SAME SOURCE that hipcc compiles into crs_chain_kernel is compiled here by g++ with the wavefront
  * primitives replaced — 64 threads play the lanes in lockstep (ballot / readlane exchange through an array between barriers, as
  * tools/simt_emu does for shuffles), one more thread plays the evaluating workgroups: it publishes the slots' records out of order,
  * some of them only after the chain has got past an earlier slot (a slot waiting for a hazard row).  The published rowstate words,
- * next / pk and the final counters must equal the sequential statement of chain_resolve() (crs_chain.hip) below, whatever the
- * interleaving.  Says nothing about the device's memory model — only that the register walk takes chain_resolve's decisions.
+ * next / pk and the final counters must equal the sequential statement of crs_trial's decisions (crs.c:125-156) below, whatever the
+ * interleaving.  Says nothing about the device's memory model — only that the register walk takes the sequential statement's decisions.
  *
  *   g++ -O1 -std=c++17 -pthread -I nlopt_amd/csrc/hip tools/chain_resolver_check.cpp -o tools/_build/chain_resolver_check
  *   tools/_build/chain_resolver_check [cases] [seed]      -> prints "ok <cases>" or the first difference, exit code 0 / 1 */
@@ -100,7 +100,7 @@ static Outcome reference(int K, int nW, const std::vector<int64_t> &W, const std
                 if (o.nextra == CH_EXTRA) o.halt = 1;
                 else { xf[o.nextra] = fnew; xrow[o.nextra] = rw; ++o.nextra; }
             }
-            if (fnew < f_best || (fnew == f_best && rw < i0)) o.halt = 1;
+            if (fnew < f_best || (fnew == f_best && rw < i0)) o.halt = 2u | ((j + 1u) << 8);     /* new best at slot j (crs_chain.hip: later slots are not gathered) */
         }
         j += (kind == 1) ? 1u : 2u;
         if (!o.halt) { o.next = j; o.pk = j | ((j - o.wp) << 16); }
@@ -144,7 +144,7 @@ int main(int argc, char **argv)
             fT[a] = draw(); fM[a] = draw();
         }
         const Outcome ref = reference(K, nW, W, Wf, fT, fM, f_best, i0);
-        seen_halt += ref.halt; seen_extra += ref.nextra > 0; seen_accept += ref.naccept; seen_slots += K; seen_full += !ref.halt;
+        seen_halt += ref.halt != 0; seen_extra += ref.nextra > 0; seen_accept += ref.naccept; seen_slots += K; seen_full += !ref.halt;
 
         /* device-side memory: ctrl words, records, rowstate */
         std::vector<uint32_t> ctrl(8, 0), rowstate(nW + 1, 0);

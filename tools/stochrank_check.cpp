@@ -1,13 +1,12 @@
 /* tools/stochrank_check.cpp — CPU check of hip/isres_stochrank.h (development tooling; tests/test_host_logic.py builds and runs it): the
- * SAME SOURCE that hipcc compiles into isres_stochrank_kernel and isres_stochrank_pre_kernel, compiled by g++ with the wavefront
+ * SAME SOURCE that hipcc compiles into isres_stochrank_kernel, compiled by g++ with the wavefront
  * primitives replaced: the 64 lanes of a unit are threads in lockstep (DPP wave shifts and v_readfirstlane are exchanges through an
  * array between barriers), every unit of a small pipeline runs at once (ticket order as on the device), global memory is ordinary
- * memory behind acquire / release atomics.  Both kernels must produce the ranking of the reference's double loop (isres.c:206-228)
+ * memory behind acquire / release atomics.  The kernel must produce the ranking of the reference's double loop (isres.c:206-228)
  * and the same per-sweep "swapped" flags, and every unit's progress counter must end at pop — for populations of one lane, of one
- * unit exactly, of several blocks per unit and of several units.  The read-ahead kernel's units are slowed down at random (a delay in
- * front of a unit's polls) so that its prefetches meet both outcomes: the block is there already / it is not and the blocking poll
- * takes over.  What this does NOT check is the device's memory model or timing — only that the kernels' logic, incl. the order in which
- * the read-ahead kernel issues its loads, stores and counter updates, computes the reference's result.
+ * unit exactly, of several blocks per unit and of several units, with all units at speed and with units slowed down at random (a delay
+ * in front of a unit's polls).  What this does NOT check is the device's memory model or timing — only that the kernel's logic computes
+ * the reference's result.
  *
  *   g++ -O1 -std=c++17 -pthread -I nlopt_amd/csrc/hip tools/stochrank_check.cpp -o tools/_build/stochrank_check
  *   tools/_build/stochrank_check [seed]        -> "ok ..." / the first difference; exit code 0 / 1 */
@@ -109,7 +108,7 @@ static int run_case(int pop, unsigned seed, int *n_cases)
             const bool byf = ((bits[(size_t) i * roww + j / 64] >> (j % 64)) & 1) || (pen[a] == 0 && pen[b] == 0);
             if (byf ? f[a] > f[b] : pen[a] > pen[b]) { ref[j] = b; ref[j + 1] = a; ref_sw[i] = 1; }
         }
-    for (int variant = 0; variant < 3; ++variant) {           /* plain kernel; read-ahead kernel; read-ahead kernel with slow units */
+    for (int variant = 0; variant < 2; ++variant) {           /* all units at speed; some units slowed down */
         std::vector<uint64_t> streams((size_t) (units + 1) * pop, 0);
         for (int i = 0; i < pop; ++i) streams[i] = pack((uint32_t) i, dense(f, i), dense(pen, i), pen[i] == 0);
         std::vector<int> progress(units + 1, 0);
@@ -117,13 +116,13 @@ static int run_case(int pop, unsigned seed, int *n_cases)
         int ticket = 0;
         std::vector<uint8_t> swapped(pop, 7);
         std::vector<emu::Unit> U(units);
-        const kernel_t K = variant == 0 ? isres_stochrank_kernel : isres_stochrank_pre_kernel;
+        const kernel_t K = isres_stochrank_kernel;
         std::vector<std::thread> th;
         for (int u = 0; u < units; ++u)
             for (int l = 0; l < 64; ++l)
                 th.emplace_back([&, u, l]() {
                     emu::unit = &U[u]; emu::which = 0; threadIdx.x = (unsigned) l;
-                    emu::jitter = (variant == 2) ? (unsigned) ((u * 2654435761u >> 28) % 4) * 3u : 0u;
+                    emu::jitter = (variant == 1) ? (unsigned) ((u * 2654435761u >> 28) % 4) * 3u : 0u;
                     K(pop, nsweeps, streams.data(), progress.data(), bits.data(), roww, &ticket, swapped.data(), nullptr, 1, 0);
                 });
         for (auto &t : th) t.join();
@@ -145,6 +144,6 @@ int main(int argc, char **argv)
     int n = 0;
     for (int pop : {2, 5, 64, 65, 130, 200, 300, 520})
         if (run_case(pop, seed, &n)) return 1;
-    printf("ok %d runs (plain kernel, read-ahead kernel, read-ahead kernel with slow units; populations 2 .. 520)\n", n);
+    printf("ok %d runs (all units at speed, some units slowed down; populations 2 .. 520)\n", n);
     return 0;
 }
