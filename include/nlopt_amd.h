@@ -186,6 +186,14 @@ int nla_k_mt_generate_seg(const uint32_t *seg_states, uint64_t seg_first, int ns
  * seg_states: block arrays of segments seg_first .. seg_first + nseg - 1 as for nla_k_mt_generate. */
 int nla_k_mt_rankbits(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_rank0, uint64_t g_first,
                       uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *bits, void *stream);
+/* the same with IN-ORDER GATES: segments are claimed front first through *ticket (0 before the launch) and a wavefront that has produced
+ * everything it owes to the block of sweeps 64 c .. 64 c + 63 adds 1 to gate[c] (zero before the launch; its stores landed first):
+ * block c is complete when gate[c] == nla_rankbits_gate_target(g_rank0, popm1, nrows, c), nrows = the sweeps [g_first, g_first + count)
+ * covers counted from g_rank0.  waves_per_cu > 0 bounds the wavefronts a CU holds at a time (the segments are then worked off front
+ * to back in waves of that size and the first blocks complete early); 0: as many as fit. */
+int nla_k_mt_rankbits_gated(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_rank0, uint64_t g_first, uint64_t count,
+                            int64_t popm1, int64_t rowwords, uint64_t *bits, int *gate, int *ticket, int waves_per_cu, void *stream);
+int nla_rankbits_gate_target(uint64_t g_rank0, int64_t popm1, int64_t nrows, int64_t c);
 
 /* replaces: crs_init's row loop, src/algs/crs/crs.c:211-226 (K1+K2 of SURVEY.md §2.3).
  * rows row_first .. row_first+nrows-1 of X (leading dimension ld) := lb + (ub-lb)*res53(words),
@@ -364,12 +372,10 @@ int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_
  * Out: swapped[i] = sweep i exchanged something; irank[pos] = individual. */
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                           int *ticket, uint8_t *swapped, int32_t *irank, void *stream);
-/* the same with the rows of `bits` still being produced by launches on another stream, in blocks of rows_per_gate sweeps: unit u (sweeps
- * 64u .. 64u+63) waits until gate[block of its last sweep] == gate_value before it reads a row; nla_k_set_flag(gate + c, gate_value,
- * that stream) behind block c's launches opens it.  gate == NULL: no waiting. */
+/* the same with the rows of `bits` still being produced by nla_k_mt_rankbits_gated on another stream: unit u (sweeps 64u .. 64u+63) waits
+ * until gate[u] has reached nla_rankbits_gate_target(gate_g_rank0, pop - 1, gate_nrows, u) before it reads a row.  gate == NULL: no waiting. */
 int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
-                                uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream);
-int nla_k_set_flag(int *d_flag, int value, void *stream);
+                                uint8_t *swapped, int32_t *irank, const int *gate, uint64_t gate_g_rank0, int64_t gate_nrows, void *stream);
 
 /* replaces: nlopt_nrand(0,1), mt19937ar.c:216-232, for a run of 4-word attempts: appends the
  * accepted deviates of attempts [attempt_base, attempt_base+nattempts) (words = their words) to

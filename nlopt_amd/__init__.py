@@ -202,7 +202,7 @@ def lib():
     L.nla_k_isres_rank_count.argtypes = [C.c_int64, vp, vp, vp, vp, vp]
     L.nla_k_isres_bits.argtypes = [vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     L.nla_k_isres_stochrank.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
-    L.nla_k_isres_stochrank_gated.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]   # ..., gate, rows_per_gate, gate_value, stream
+    L.nla_k_isres_stochrank_gated.argtypes = [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int64, vp]   # ..., gate, gate_g_rank0, gate_nrows, stream
     L.nla_isres_evolve2_ws_bytes.restype = C.c_size_t
     L.nla_isres_evolve2_ws_bytes.argtypes = [C.c_int]
     L.nla_k_isres_inverse.argtypes = [C.c_int64, vp, vp, vp]

@@ -109,28 +109,40 @@ __global__ __launch_bounds__(256) void isres_eval_kernel(int n, int ld, const do
  * the all-feasible ranking of isres.c:204 (glibc's qsort_r is a stable merge sort, qsort_r.c:190).
  * Outputs: elems[k] = packed element of individual k; sorted[ps] = k.
  * ---------------------------------------------------------------------------------------------- */
-#define RC_TILE 2048
-__global__ __launch_bounds__(256) void isres_rank_count_kernel(int64_t pop, const double *__restrict__ F, const double *__restrict__ PEN,
-                                                                uint64_t *__restrict__ elems, int32_t *__restrict__ sorted)
+#define RC_W 8                           /* wavefronts per workgroup: wavefront w counts over the tiles w, w + 8, ... of the population */
+#define RC_T 256                         /* individuals per tile (each wavefront stages its own: no workgroup barrier inside the loop) */
+/* lane = individual (64 per workgroup), the j range dealt over the workgroup's 8 wavefronts, partial counts summed through LDS: 782
+ * workgroups / 6256 wavefronts at pop = 5e4 where one thread per individual and 256 per workgroup gave 196 / 784 — the kernel sits in
+ * front of the ranking pipeline on the generation's critical path (4.8 ms at config 3 in that shape, rounds 1-4) */
+__global__ __launch_bounds__(RC_W * 64) void isres_rank_count_kernel(int64_t pop, const double *__restrict__ F, const double *__restrict__ PEN,
+                                                                     uint64_t *__restrict__ elems, int32_t *__restrict__ sorted)
 {
-    __shared__ double sf[RC_TILE], sp[RC_TILE];
-    const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    __shared__ double sf[RC_W][RC_T], sp[RC_W][RC_T];
+    __shared__ uint32_t part[3][RC_W][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t k = (int64_t) blockIdx.x * 64 + lane;
     const bool live = k < pop;
     const double fk = live ? F[k] : 0.0, pk = live ? PEN[k] : 0.0;
     uint32_t rf = 0, rp = 0, ps = 0;
-    for (int64_t j0 = 0; j0 < pop; j0 += RC_TILE) {
-        const int cnt = (int) (pop - j0 < RC_TILE ? pop - j0 : RC_TILE);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += 256) { sf[i] = F[j0 + i]; sp[i] = PEN[j0 + i]; }
-        __syncthreads();
+    for (int64_t j0 = (int64_t) wave * RC_T; j0 < pop; j0 += (int64_t) RC_W * RC_T) {
+        const int cnt = (int) (pop - j0 < RC_T ? pop - j0 : RC_T);
+        /* a wavefront's LDS operations execute in the order they were issued: the reads below see the writes of its own lanes
+         * without a barrier; the waits only keep the previous tile's reads ahead of this tile's writes in the instruction stream */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < cnt; i += 64) { sf[wave][i] = F[j0 + i]; sp[wave][i] = PEN[j0 + i]; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         for (int i = 0; i < cnt; ++i) {
-            const double fj = sf[i], pj = sp[i];
+            const double fj = sf[wave][i], pj = sp[wave][i];
             rf += fj < fk;
             rp += pj < pk;
             ps += (fj < fk) || (fj == fk && j0 + i < k);
         }
     }
-    if (live) {
+    part[0][wave][lane] = rf; part[1][wave][lane] = rp; part[2][wave][lane] = ps;
+    __syncthreads();
+    if (wave == 0 && live) {
+        rf = rp = ps = 0;
+        for (int w = 0; w < RC_W; ++w) { rf += part[0][w][lane]; rp += part[1][w][lane]; ps += part[2][w][lane]; }
         if (pop <= (1 << ISRES_IDX_BITS)) elems[k] = isres_pack((uint32_t) k, rf, rp, pk == 0);
         sorted[ps] = (int32_t) k;
     }
@@ -654,7 +666,7 @@ extern "C" int nla_k_isres_rank_count(int64_t pop, const double *F, const double
     if (pop <= 0) return 0;
     /* above 2^20 individuals only `sorted` (the stable sort by f: all a generation without penalties needs, isres.c:203-204) is
      * meaningful: the packed elements have 20 bits per field, and the driver admits such populations only without constraints */
-    hipLaunchKernelGGL(isres_rank_count_kernel, dim3((unsigned) ((pop + 255) / 256)), dim3(256), 0, (hipStream_t) stream, pop, F, PEN, elems, sorted);
+    hipLaunchKernelGGL(isres_rank_count_kernel, dim3((unsigned) ((pop + 63) / 64)), dim3(RC_W * 64), 0, (hipStream_t) stream, pop, F, PEN, elems, sorted);
     NLA_LAUNCH_CHECK();
     return 0;
 }
@@ -669,32 +681,26 @@ extern "C" int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nr
     return 0;
 }
 
-__global__ void isres_set_flag_kernel(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-/* *d_flag := value, in stream order (the gate of a block of ranking bits: everything enqueued before it on the stream is complete) */
-extern "C" int nla_k_set_flag(int *d_flag, int value, void *stream)
-{
-    hipLaunchKernelGGL(isres_set_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t) stream, d_flag, value);
-    NLA_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
-                                           int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream);
+                                           int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, uint64_t gate_g_rank0, int64_t gate_nrows,
+                                           void *stream);
 extern "C" int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                                      int *ticket, uint8_t *swapped, int32_t *irank, void *stream)
 {
-    return nla_k_isres_stochrank_gated(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, NULL, 1, 0, stream);
+    return nla_k_isres_stochrank_gated(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, NULL, 0, 0, stream);
 }
 extern "C" int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
-                                           int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *stream)
+                                           int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, uint64_t gate_g_rank0, int64_t gate_nrows,
+                                           void *stream)
 {
+    static_assert(SR_SEG_WORDS == NLA_MT_SEG_WORDS, "the pipeline's gate targets count the generator's segments");
     hipStream_t st = (hipStream_t) stream;
     if (pop <= 0) return 0;
     const int64_t units = (nsweeps + 63) / 64;
     const int64_t rowwords = (pop - 1 + 63) / 64;
     if (units > 0 && pop > 1) {
         hipLaunchKernelGGL(isres_stochrank_kernel, dim3((unsigned) units), dim3(64), 0, st, pop, nsweeps, streams, progress, bits, rowwords, ticket,
-                           swapped, gate, rows_per_gate > 0 ? rows_per_gate : 1, gate_value);
+                           swapped, gate, gate_g_rank0, gate_nrows);
         NLA_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(isres_unpack_kernel, dim3((unsigned) ((pop + 255) / 256)), dim3(256), 0, st, pop,

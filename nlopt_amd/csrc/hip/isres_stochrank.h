@@ -13,6 +13,12 @@
 #define SR_SHARED_INT(name) __shared__ int name
 #define SR_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+#ifndef SR_SEG_WORDS
+#define SR_SEG_WORDS 638976ull           /* = NLA_MT_SEG_WORDS (include/nlopt_amd.h): 1024 regenerations of 624 words per segment of the device stream */
+#endif
+#ifndef SR_SETPRIO_HIGH
+#define SR_SETPRIO_HIGH() __builtin_amdgcn_s_setprio(3)
+#endif
 
 #define SR_DPP_SHL1 0x130               /* wave_shl:1 — lane i reads lane i+1 */
 #define SR_DPP_SHR1 0x138               /* wave_shr:1 — lane i reads lane i-1 */
@@ -29,10 +35,11 @@ __device__ __forceinline__ void sr_st(uint64_t *p, uint64_t v) { __hip_atomic_st
 SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__restrict__ streams,
                                                               int *__restrict__ progress, const uint64_t *__restrict__ bits,
                                                               int64_t rowwords, int *__restrict__ ticket, uint8_t *__restrict__ swapped_out,
-                                                              const int *__restrict__ gate, int rows_per_gate, int gate_value)
+                                                              const int *__restrict__ gate, uint64_t gate_g_rank0, int64_t gate_nrows)
 {
     SR_SHARED_INT(s_unit);
     const int lane = threadIdx.x;
+    SR_SETPRIO_HIGH();                          /* every tick is on the pipeline's serial path; whatever shares the SIMD (the generator of the bits) takes the slots left over */
     if (lane == 0) s_unit = atomicAdd(ticket, 1);
     __syncthreads();
     const int64_t unit = s_unit;
@@ -51,15 +58,18 @@ SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__
     const uint32_t amask = active ? 0x80000000u : 0u;
     auto clampw = [&](int w) { return w < 0 ? 0 : (w > rw1 ? rw1 : w); };
     if (gate) {
-        /* the rows of uniform bits are still being produced, in blocks of rows_per_gate sweeps, by launches on another stream
-         * (isres_driver.c, "amd_isres_gated"): gate[c] == gate_value once block c is complete.  This unit reads rows 64 unit ..
-         * 64 unit + 63: wait for the block of the last one BEFORE the first load of a row (a load ahead of the flag could leave a
-         * stale line in this CU's cache), then make the other stream's stores visible */
-        int64_t lastrow = unit * 64 + 63;
-        if (lastrow > nsweeps - 1) lastrow = nsweeps - 1;
-        if (lastrow < 0) lastrow = 0;
-        const int *g = gate + lastrow / rows_per_gate;
-        if (lane == 0) while (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate_value) __builtin_amdgcn_s_sleep(8);
+        /* the rows of uniform bits are still being produced by mt_rankbits_kernel on another stream (isres_driver.c, "amd_isres_gated"): the
+         * generator's wavefronts each add 1 to gate[c] when they have written all they owe to sweeps 64 c .. 64 c + 63 — this unit's rows —
+         * and block c is complete when as many have done so as segments of the stream intersect the block's words (the formula of
+         * nla_rankbits_gate_target, hip/mt_kernels.hip; gate_g_rank0 = stream index of the ranking's first word, gate_nrows = sweeps the
+         * generator was asked for).  Wait BEFORE the first load of a row (a load ahead of the count could leave a stale line in this CU's
+         * cache), then make the other stream's stores visible */
+        const int *g = gate + unit;
+        const uint64_t gb0 = gate_g_rank0 + 128ull * (uint64_t) (pop - 1) * (uint64_t) unit;
+        const int64_t gr1 = 64 * (unit + 1) < gate_nrows ? 64 * (unit + 1) : gate_nrows;
+        const uint64_t gb1 = gate_g_rank0 + 2ull * (uint64_t) (pop - 1) * (uint64_t) gr1;
+        const int want = gb1 > gb0 ? (int) ((gb1 - 1) / SR_SEG_WORDS - gb0 / SR_SEG_WORDS + 1) : 0;
+        if (lane == 0) while (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(8);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     uint64_t wa = brow[clampw(-1 - half)], wb = brow[clampw(0 - half)], wp = brow[clampw(1 - half)];

@@ -47,7 +47,10 @@ typedef struct {
     void *st, *ev0, *ev1;
     void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
     int gated;                      /* "amd_isres_gated" (default 1; one rank, generator on its own stream): the ranking pipeline starts while its bits are still produced */
-    int *d_gate; int gate_value;    /* ISRES_GATES flags: block c of the ranking bits is complete when d_gate[c] == gate_value (a new value every generation) */
+    int *d_gate;                    /* units + 1 counters (+ the generator's ticket): block c of the ranking bits (sweeps 64 c .. 64 c + 63) is complete when d_gate[c] has
+                                     * reached its target (hip/mt_kernels.hip: nla_k_mt_rankbits_gated; zeroed on the generator's stream before every launch) */
+    void *ev_gate;                  /* recorded behind that zeroing: the pipeline's launch on the main stream waits for it */
+    int gen_waves_per_cu;           /* "amd_isres_gen_waves": wavefronts of the gated generator a CU holds at a time (0 = as many as fit) */
     int evolve_serial;              /* "amd_isres_evolve_serial" != 0: the one-workgroup evolve kernel (the parallel one's reference in the tests) */
     int overlap;                    /* default; "amd_isres_overlap" = 0 / NLA_ISRES_OVERLAP=0 turn it off: generator work beside the latency-bound kernels */
     int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
@@ -73,7 +76,6 @@ typedef struct {
     char err[200];
 } isres_dev;
 
-#define ISRES_GATES 4                    /* blocks of sweeps the ranking bits are produced in when the pipeline starts beside them */
 #define DFAIL(d, ...) do { snprintf((d)->err, sizeof (d)->err, __VA_ARGS__); return -1; } while (0)
 #define DCK(d, call) do { int rc_ = (call); if (rc_) DFAIL(d, "%.90s failed: %.60s", #call, nla_dev_error_string(rc_)); } while (0)
 
@@ -90,7 +92,7 @@ static void dev_free_all(isres_dev *d)
     nla_dev_free(d->d_inv); nla_dev_free(d->d_rho); nla_dev_free(d->d_ws);
     nla_host_free(d->h_F); nla_host_free(d->h_PEN); nla_host_free(d->h_GPEN); nla_host_free(d->h_X); nla_host_free(d->h_FEAS);
     nla_host_free(d->h_swapped); nla_host_free(d->h_progress);
-    nla_event_destroy(d->ev0); nla_event_destroy(d->ev1);
+    nla_event_destroy(d->ev0); nla_event_destroy(d->ev1); nla_event_destroy(d->ev_gate);
     if (d->rs && d->rs != d->st) nla_stream_destroy(d->rs);
     if (d->st) nla_stream_destroy(d->st);
 }
@@ -141,8 +143,9 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     A(d_words, uint32_t, d->wchunk); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
     A(d_counts, int32_t, d->wchunk / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
     A(d_con, nla_dev_constraint, d->m + d->p + 1);
-    A(d_gate, int, ISRES_GATES);
-    if (d->d_gate && nla_memset(d->d_gate, 0, sizeof(int) * ISRES_GATES, d->st)) ok = 0;
+    A(d_gate, int, d->units + 2);
+    d->ev_gate = nla_event_create();
+    if (!d->ev_gate) ok = 0;
     d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !d->evolve_serial && !NLA_DBG_ENV("NLA_ISRES_EVOLVE_SERIAL");
     if (d->parallel_evolve) {
         A(d_inv, int32_t, pop); A(d_rho, double, 4);
@@ -190,13 +193,15 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
     const int64_t pop = d->pop, popm1 = pop - 1;
     int64_t nsweeps = pop, rows_per, r0, i;
     double t0;
-    /* GATED (round 4): the bits of the pop sweeps are produced in ISRES_GATES blocks of whole sweeps on the generator's stream, a flag
-     * behind each block; the ranking pipeline is launched at once on the main stream and each of its units waits for the block of its
-     * own rows (hip/isres_kernels.hip).  The pipeline's unit u starts ~190 ticks (14 us) after unit u - 1 and the generator makes 64 rows
-     * in ~12 us, so the bits stay just ahead of the units: the 9.6 ms of generation disappear behind the 15 ms of the pipeline
-     * (config 3).  One rank with the generator on its own stream only (several ranks all-gather the complete bits first). */
+    /* GATED (round 5: in-order gates inside ONE generator launch; round 4 had four launches with a flag kernel behind each): the bits of
+     * the pop sweeps are produced on the generator's stream by wavefronts that claim the stream's segments front first and count, per
+     * block of 64 sweeps, how many of them are through with it (hip/mt_kernels.hip, nla_k_mt_rankbits_gated); the ranking pipeline is
+     * launched at once on the main stream and its unit u — sweeps 64 u .. 64 u + 63 — waits until block u is complete
+     * (hip/isres_stochrank.h).  The pipeline's unit u starts ~15 us after unit u - 1, which is time enough for the ten segments of a
+     * block: the generation of the bits disappears behind the pipeline.  One rank with the generator on its own stream only (several
+     * ranks all-gather the complete bits first). */
     const int gated = d->gated && d->rs != d->st && nlopt_amd_comm_world(d->comm) == 1 && !d->bits_two_pass && d->d_gate != NULL;
-    const int64_t rows_per_gate = ((pop + ISRES_GATES - 1) / ISRES_GATES + 63) / 64 * 64;
+    uint64_t gate_g0 = 0;
     *sweeps_out = 0;
     DCK(d, nla_k_isres_rank_count(pop, d->d_F, d->d_PEN, d->d_streams, d->d_irank, d->st));
     if (all_feasible || popm1 <= 0) return 0;      /* irank = stable sort by f (or the single individual) */
@@ -213,15 +218,13 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         const int64_t first = world > 1 ? (d->per * rank < pop ? d->per * rank : pop) : 0;
         const int64_t last = world > 1 ? (first + d->per < pop ? first + d->per : pop) : pop;
         if (gated) {
-            ++d->gate_value;
             DCK(d, nla_memset(d->d_bits, 0, sizeof(uint64_t) * (size_t) pop * (size_t) d->rowwords, d->rs));
-            for (r0 = 0; r0 < pop; r0 += rows_per_gate) {
-                const int64_t nr = pop - r0 < rows_per_gate ? pop - r0 : rows_per_gate;
-                if (nla_mtstream_rankbits(d->mts, d->words_used, d->words_used + 2ULL * (uint64_t) popm1 * (uint64_t) r0,
-                                          2ULL * (uint64_t) popm1 * (uint64_t) nr, popm1, d->rowwords, d->d_bits))
-                    DFAIL(d, "MT stream ranking bits failed");
-                DCK(d, nla_k_set_flag(d->d_gate + r0 / rows_per_gate, d->gate_value, d->rs));
-            }
+            DCK(d, nla_memset(d->d_gate, 0, sizeof(int) * (size_t) (d->units + 2), d->rs));
+            DCK(d, nla_event_record(d->ev_gate, d->rs));
+            gate_g0 = nla_mtstream_origin(d->mts) + d->words_used;
+            if (nla_mtstream_rankbits_gated(d->mts, d->words_used, d->words_used, 2ULL * (uint64_t) popm1 * (uint64_t) pop, popm1, d->rowwords, d->d_bits,
+                                            d->d_gate, d->d_gate + d->units + 1, d->gen_waves_per_cu))
+                DFAIL(d, "MT stream ranking bits failed");
         } else if (!d->bits_two_pass) {
             /* words -> bits in one kernel, all of this rank's sweeps in one launch (hip/mt_kernels.hip, mt_rankbits_kernel):
              * the words are never written to memory */
@@ -252,8 +255,9 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         DCK(d, nla_memcpy_h2d(d->d_progress, d->h_progress, sizeof(int) * (size_t) (d->units + 1), d->st));
         DCK(d, nla_memset(d->d_ticket, 0, sizeof(int), d->st));
         if (d->ev0) nla_event_record(d->ev0, d->st);
+        if (gated && nsweeps == pop) DCK(d, nla_stream_wait_event(d->st, d->ev_gate));      /* the counters are zero before a unit looks at them */
         DCK(d, nla_k_isres_stochrank_gated(pop, nsweeps, d->d_streams, d->d_progress, d->d_bits, d->d_ticket, d->d_swapped, d->d_irank,
-                                           gated ? d->d_gate : NULL, (int) rows_per_gate, d->gate_value, d->st));
+                                           gated && nsweeps == pop ? d->d_gate : NULL, gate_g0, pop, d->st));
         if (d->ev1) nla_event_record(d->ev1, d->st);
         DCK(d, nla_memcpy_d2h(d->h_swapped, d->d_swapped, (size_t) nsweeps, d->st));
         if (d->overlap && nsweeps == pop && !d->spec_valid) {
@@ -516,6 +520,7 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     D.comm = opt ? opt->comm : NULL;
     D.evolve_serial = opt ? nlopt_get_param(opt, "amd_isres_evolve_serial", 0) != 0 : 0;
     D.gated = opt ? nlopt_get_param(opt, "amd_isres_gated", 1) != 0 : 1;
+    D.gen_waves_per_cu = opt ? (int) nlopt_get_param(opt, "amd_isres_gen_waves", 8) : 8;
     D.overlap = opt ? nlopt_get_param(opt, "amd_isres_overlap", 1) != 0 : 1;            /* 0: the one-stream generation */
     D.overlap = nla_dbg_int("NLA_ISRES_OVERLAP", D.overlap) > 0;     /* A/B switch for the bench */
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */

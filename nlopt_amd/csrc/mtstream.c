@@ -136,6 +136,20 @@ int nla_mtstream_reserve(nla_mtstream *s, uint64_t rel_last)
 
 /* the ranking bits of stream words [rel_first, rel_first + count) (relative to the run's first word, as nla_mtstream_fill),
  * rel_rank0 = the ranking's first word: see nla_k_mt_rankbits */
+int nla_mtstream_rankbits_gated(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords,
+                                uint64_t *d_bits, int *d_gate, int *d_ticket, int waves_per_cu)
+{
+    uint64_t g_first, seg0, seg1;
+    if (!count) return 0;
+    if (s->seg_regens != NLA_MT_SEG_REGENS) return -1;          /* (the fused kernel knows the default segment length only) */
+    g_first = (uint64_t) s->base_consumed + rel_first;
+    seg0 = g_first / NLA_MT_SEG_WORDS;
+    seg1 = (g_first + count - 1) / NLA_MT_SEG_WORDS;
+    if (ensure_states(s, seg1)) return -1;
+    return nla_k_mt_rankbits_gated(s->d_states + (size_t) seg0 * NLA_MT_N, seg0, (int) (seg1 - seg0 + 1), (uint64_t) s->base_consumed + rel_rank0,
+                                   g_first, count, popm1, rowwords, d_bits, d_gate, d_ticket, waves_per_cu, s->stream);
+}
+
 int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *d_bits)
 {
     uint64_t g_first, seg0, seg1;

@@ -162,6 +162,8 @@ uint64_t nla_mtstream_origin(const nla_mtstream *s); /* global index of the firs
 /* out[i] = stream word (origin + rel_first + i), i < count; device pointer, async on `stream` */
 int nla_mtstream_fill(nla_mtstream *s, uint64_t rel_first, uint64_t count, uint32_t *d_out);
 int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords, uint64_t *d_bits);
+int nla_mtstream_rankbits_gated(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords,
+                                uint64_t *d_bits, int *d_gate, int *d_ticket, int waves_per_cu);   /* in-order gates: nla_k_mt_rankbits_gated */
 int nla_mtstream_reserve(nla_mtstream *s, uint64_t rel_last);
 /* leave the calling thread's generator as if it had drawn `consumed` words since create */
 int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed);

@@ -131,6 +131,28 @@ int nla_k_mt_rankbits(const uint32_t *seg_states, uint64_t seg_first, int nseg, 
     return rc;
 }
 
+int nla_rankbits_gate_target(uint64_t g_rank0, int64_t popm1, int64_t nrows, int64_t c)
+{
+    const uint64_t b0 = g_rank0 + 128ULL * (uint64_t) popm1 * (uint64_t) c;
+    const int64_t r1 = 64 * (c + 1) < nrows ? 64 * (c + 1) : nrows;
+    const uint64_t b1 = g_rank0 + 2ULL * (uint64_t) popm1 * (uint64_t) r1;
+    if (b1 <= b0) return 0;
+    return (int) ((b1 - 1) / NLA_MT_SEG_WORDS - b0 / NLA_MT_SEG_WORDS + 1);
+}
+int nla_k_mt_rankbits_gated(const uint32_t *seg_states, uint64_t seg_first, int nseg, uint64_t g_rank0, uint64_t g_first, uint64_t count,
+                            int64_t popm1, int64_t rowwords, uint64_t *bits, int *gate, int *ticket, int waves_per_cu, void *st)
+{
+    /* the synchronous device: all bits, then every gate of the sweeps covered at its target */
+    int rc = nla_k_mt_rankbits(seg_states, seg_first, nseg, g_rank0, g_first, count, popm1, rowwords, bits, st);
+    (void) waves_per_cu;
+    if (!rc && ticket) *ticket += nseg;
+    if (!rc && gate && count) {
+        const int64_t r0 = (int64_t) ((g_first - g_rank0) / (2ULL * (uint64_t) popm1)), r1 = (int64_t) ((g_first + count - g_rank0) / (2ULL * (uint64_t) popm1));
+        for (int64_t c = r0 / 64; c <= (r1 - 1) / 64; ++c) gate[c] = nla_rankbits_gate_target(g_rank0, popm1, r1, c);
+    }
+    return rc;
+}
+
 /* ---- rows from the stream, evaluation (hip/crs_kernels.hip: crs_init_rows_kernel, eval_kernel) ------------------------------ */
 /* NLA_OBJ_NEGATE: the flag stripped from obj, the factor f is multiplied by */
 static double emu_obj_sign(int *obj)
@@ -487,14 +509,13 @@ int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_
     }
     return 0;
 }
-int nla_k_set_flag(int *d_flag, int value, void *st) { EMU_LAUNCH(); (void) st; *d_flag = value; return 0; }
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                           uint8_t *swapped, int32_t *irank, void *st);
 /* (launches run synchronously here: by the time the ranking is "launched", every block of bits enqueued before it is complete) */
 int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
-                                uint8_t *swapped, int32_t *irank, const int *gate, int rows_per_gate, int gate_value, void *st)
+                                uint8_t *swapped, int32_t *irank, const int *gate, uint64_t gate_g_rank0, int64_t gate_nrows, void *st)
 {
-    if (gate) for (int64_t r = 0; r < nsweeps; r += rows_per_gate) if (gate[r / rows_per_gate] != gate_value) return 1;
+    if (gate) for (int64_t u = 0; u < (nsweeps + 63) / 64; ++u) if (gate[u] < nla_rankbits_gate_target(gate_g_rank0, pop - 1, gate_nrows, u)) return 1;
     return nla_k_isres_stochrank(pop, nsweeps, streams, progress, bits, ticket, swapped, irank, st);
 }
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,

@@ -41,6 +41,7 @@ static thread_local emu::Idx threadIdx;
 #define SR_SHARED_INT(name) int &name = emu::unit->shared_int
 /* a wavefront executes in lockstep: when lane 0 stores a counter behind this wait, every lane's stores in front of it have been issued and
  * have landed; the threads that play the lanes meet at a barrier for that */
+#define SR_SETPRIO_HIGH() ((void) 0)
 #define SR_WAIT_VMCNT0() do { std::atomic_thread_fence(std::memory_order_seq_cst); emu::unit->bar.wait(); std::atomic_thread_fence(std::memory_order_seq_cst); } while (0)
 #define __restrict__
 #define __device__
@@ -86,7 +87,7 @@ static uint64_t pack(uint32_t idx, uint32_t rf, uint32_t rp, bool pzero)     /* 
 }
 static uint32_t unpack_idx(uint64_t e) { return ((uint32_t) e & 0xFFFu) | ((((uint32_t) (e >> 32)) & 0xFFu) << 12); }
 
-typedef void (*kernel_t)(int64_t, int64_t, uint64_t *, int *, const uint64_t *, int64_t, int *, uint8_t *, const int *, int, int);
+typedef void (*kernel_t)(int64_t, int64_t, uint64_t *, int *, const uint64_t *, int64_t, int *, uint8_t *, const int *, uint64_t, int64_t);
 
 static int run_case(int pop, unsigned seed, int *n_cases)
 {
@@ -123,7 +124,7 @@ static int run_case(int pop, unsigned seed, int *n_cases)
                 th.emplace_back([&, u, l]() {
                     emu::unit = &U[u]; emu::which = 0; threadIdx.x = (unsigned) l;
                     emu::jitter = (variant == 1) ? (unsigned) ((u * 2654435761u >> 28) % 4) * 3u : 0u;
-                    K(pop, nsweeps, streams.data(), progress.data(), bits.data(), roww, &ticket, swapped.data(), nullptr, 1, 0);
+                    K(pop, nsweeps, streams.data(), progress.data(), bits.data(), roww, &ticket, swapped.data(), nullptr, 0, 0);
                 });
         for (auto &t : th) t.join();
         ++*n_cases;
