@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--headline-only", action="store_true", help="crs: skip the other sizes / workloads / end-to-end call (tuning runs)")
     ap.add_argument("--cpu-sample-pop", type=int, default=0)
     ap.add_argument("--cpu-sample-trials", type=int, default=400)
+    ap.add_argument("--detail", default="", metavar="PATH",
+                    help="where the FULL record goes (host_split, phases, sample strings, latency models ...); default gpurun_out/bench_detail.json. "
+                         "The printed line is the compact form of it (kept below the 8 KB of stdout a driver record keeps)")
+    ap.add_argument("--full-line", action="store_true", help="print the full record as the JSON line (what rounds 1-4 printed)")
     a = ap.parse_args()
     dflt = {"crs": (4096, 100000, "griewank"), "isres": (256, 50000, "rastrigin"), "mlsl": (4096, 1000, "ackley")}[a.workload]
     a.n = a.n or dflt[0]
@@ -284,12 +288,78 @@ def main():
     else:
         out = bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        path = a.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            out["detail"] = os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+        print(json.dumps(out if a.full_line else compact_line(out)), flush=True)
     if STUCK:                              # a hung collective thread is still alive: no barrier, no orderly teardown
         os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# the printed line: every number the contract asks for and every measured value / fraction / speed-up, none of the prose
+# ------------------------------------------------------------------------------------------------
+LINE_BUDGET = 7000      # bytes: a driver record keeps the last 8 KB of stdout
+DROP_KEYS = ("host_split", "traffic_note", "traffic_source", "model", "peak_note", "init", "phases", "launches_timed_of_passes", "path",
+             "achievable", "frac_of_achievable", "avg_algorithmic_bytes_per_launch", "evals_per_step_requested", "setup_and_teardown_s",
+             "init_evals_per_s", "roofline_hbm_passes", "total_seconds_incl_setup", "reference_numevals", "reference_value", "wall_s",
+             "note", "mutations", "reference_mutations", "trial_evals", "estimate_at_benchmark_pop", "sample_pop")
+
+
+def _round(v):
+    if isinstance(v, float):
+        return float("%.6g" % v)
+    return v
+
+
+def _prune(v, depth=0):
+    if isinstance(v, dict):
+        return {k: _prune(x, depth + 1) for k, x in v.items() if k not in DROP_KEYS}
+    if isinstance(v, list):
+        return [_prune(x, depth + 1) for x in v]
+    if isinstance(v, str) and depth > 1 and len(v) > 96:
+        return v[:93] + "..."
+    return _round(v)
+
+
+def compact_line(full):
+    """the contract's keys untouched; nested records pruned of prose and of the second-order numbers (they are in the detail file).  What
+    stays per size / workload: value, ms per step, roofline (bound, kernel, achieved, peak, frac, traffic, avg launch), cpu_baseline value + kind,
+    the speed-up, identical_to_reference flags"""
+    out = {}
+    for k, v in full.items():
+        if k in ("host_split", "init"):
+            continue
+        if k == "config":
+            out[k] = v
+        elif k == "cpu_baseline":
+            out[k] = {kk: (_round(x) if not isinstance(x, str) or len(x) <= 200 else x[:197] + "...") for kk, x in v.items()} if isinstance(v, dict) else v
+        elif k == "roofline":
+            out[k] = _prune(v, 1)
+        else:
+            out[k] = _prune(v, 0)
+    for wl in (out.get("other_workloads") or {}).values():
+        if isinstance(wl, dict):
+            for kk in ("higher_is_better", "scaling", "vs_baseline", "data", "n_gpus", "metric", "final_result", "dtype"):
+                wl.pop(kk, None)
+    order = ["nlopt_optimize_end_to_end", "window", "gens_to_ftol"]          # what goes first if the line is still too long
+    while len(json.dumps(out)) > LINE_BUDGET and order:
+        k = order.pop(0)
+        if k == "gens_to_ftol" and isinstance(out.get(k), dict):
+            g = out[k]
+            out[k] = {"value": g.get("value"), "identical_to_reference": g.get("identical_to_reference"),
+                      "second_pin": {"value": (g.get("second_pin") or {}).get("value"), "identical_to_reference": (g.get("second_pin") or {}).get("identical_to_reference")}}
+        elif k in out:
+            out[k] = {kk: x for kk, x in out[k].items() if kk in ("value", "unit", "useful_frac", "slots_started", "slots_used")} if isinstance(out[k], dict) else out[k]
+    return out
 
 
 CRS_PARAMS = []        # --param NAME=VALUE of the command line (the library's A/B switches), applied to every CRS2_LM object of crs_measure
@@ -336,7 +406,27 @@ def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, 
     dt = time.perf_counter() - t0
     st1, ev1 = o.stats(), o.get_numevals()
     fret = L.nlopt_amd_crs_close(s)
-    return dict(dt=dt, evals=ev1 - ev0, st0=st0, st1=st1, t_init=t_init, fret=int(fret), minf=minf.value)
+    return dict(dt=dt, evals=ev1 - ev0, st0=st0, st1=st1, t_init=t_init, fret=int(fret), minf=minf.value, numevals=int(ev1))
+
+
+def pinned_to_reference(m, n, pop, obj, seed):
+    """the run bench.py has just timed against the REAL reference's run of the same problem (tests/golden/full_crs_griewank_n4096_pop1e5_long.npz:
+    N + 60 018 evaluations of oracle/_ref, written by tests/golden/make_fullsize.py): at the evaluation where this run stopped — the minimum
+    found, the number of accepted trials and the number of mutation evaluations must be the reference's at that evaluation (crs.c:125-156)"""
+    path = os.path.join(ROOT, "tests", "golden", "full_crs_griewank_n4096_pop1e5_long.npz")
+    if (n, pop, obj, seed) != (4096, 100000, "griewank", 42) or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    k = m["numevals"] - pop
+    if k < 0 or k > len(g["trial_f"]):
+        return {"numevals": m["numevals"], "identical_to_reference": None, "note": "the run stopped outside the fixture's %d trial evaluations" % len(g["trial_f"])}
+    ref_minf = float(g["best_f"][np.searchsorted(g["best_eval"], m["numevals"], side="right") - 1])
+    ref_acc = int(g["trial_accepted"][:k].sum())
+    ref_mut = int((g["trial_kind"][:k] == 2).sum())
+    st = m["st1"]
+    same = bool(abs(m["minf"] - ref_minf) <= 1e-10 * abs(ref_minf) and st["accepted"] == ref_acc and st["evals_mutation"] == ref_mut)
+    return {"numevals": m["numevals"], "trial_evals": k, "minf": m["minf"], "reference_minf": ref_minf, "accepted": int(st["accepted"]),
+            "reference_accepted": ref_acc, "mutations": int(st["evals_mutation"]), "reference_mutations": ref_mut, "identical_to_reference": same}
 
 
 def crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce):
@@ -553,6 +643,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         "init": {"evals": pop, "seconds": t_init, "init_evals_per_s": pop / t_init},
         "final_result": int(fret), "minf": m["minf"],
     }
+    if world == 1 or sharded:
+        pin = pinned_to_reference(m, n, pop, a.obj, a.seed)
+        if pin:
+            out["pinned_run"] = pin
     if world == 1 and (n, pop, a.obj) == (4096, 100000, "griewank") and not a.headline_only:
         # north_star asks for n in {64, 512, 4096}: the two smaller sizes (512 = BASELINE config 2), shorter runs, same contract
         out["other_sizes"] = {}

@@ -112,6 +112,9 @@ typedef struct {
      * and the time it took (seconds; the part beside the device is inside t_engine_s, the rest outside both) */
     uint64_t list_refreshes, list_refreshes_beside_device;
     double t_list_refresh_s;
+    /* ISRES gated ranking: launches of the pipeline in which a unit gave up waiting for its block of ranking bits (hip/isres_stochrank.h:
+     * 4 s) — the ranking was then redone without gates after the generator's stream had been waited for.  0 in a healthy run */
+    uint64_t isres_gate_timeouts;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 
@@ -139,8 +142,11 @@ nlopt_amd_comm *nlopt_amd_comm_create_rccl(int rank, int world, const void *id12
 nlopt_amd_comm *nlopt_amd_comm_create_host(int rank, int world, nlopt_amd_allgather_fn fn, void *ctx);
 /* ranks on ONE node without a collective library: a POSIX shared-memory segment `name` ("/...", the same on every rank, unique to the
  * job) with per-rank slots of slot_bytes (0: 16 MiB; larger contributions travel in pieces) and a barrier; device data are copied
- * straight into / out of the (registered) slots.  Rank 0 creates the segment, the others wait for it. */
+ * straight into / out of the (registered) slots.  Rank 0 creates the segment (removing one a crashed run left under the name), the
+ * others wait for it and attach only to a segment whose creating process is alive — the ranks may start in any order. */
 nlopt_amd_comm *nlopt_amd_comm_create_shm(int rank, int world, const char *name, size_t slot_bytes);
+/* shm transport: how long a rank waits in a barrier for the others before it reports an error (default 600 s) */
+void nlopt_amd_comm_set_timeout(nlopt_amd_comm *c, double seconds);
 void nlopt_amd_comm_destroy(nlopt_amd_comm *c);
 int nlopt_amd_comm_rank(const nlopt_amd_comm *c);
 int nlopt_amd_comm_world(const nlopt_amd_comm *c);
@@ -255,6 +261,16 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
                     uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                     const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
                     nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream);
+/* the same, leaner around the launch (round 5): ctrl_is_zero != 0 — the caller cleared the control block behind its ticket word on this
+ * stream already (nla_k_crs_commit_zero: no fill operations in front of the window); bell != NULL — status, fwcnt and fwrec are pinned
+ * host memory and the last workgroup to finish stores bell_seq into *bell (pinned) once every record is visible to the host, which
+ * spins on it instead of synchronising the stream; bell_count = a zeroed device word */
+int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                         const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                         uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                         const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                         nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
+                         uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *stream);
 /* workgroups one launch draws tickets for: K * nla_crs_chain_chunks + 1 (the resolver wavefront's workgroup, hip/crs_chain_resolver.h:
  * the chain — crs.c:135-156, the decisions between evaluations — is advanced by one dedicated wavefront out of registers) */
 uint32_t nla_crs_chain_tickets(int n, int ld, int K);
@@ -332,6 +348,11 @@ int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, c
  * X[row[c]] := (kind[c] == 1 ? TX : TM)[slot[c]];  rows must be distinct within one call. */
 int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *TM, int ncommit,
                      const int32_t *slot, const int32_t *kind, const int64_t *row, void *stream);
+
+/* nla_k_crs_commit (lists_on_host == 0) / nla_k_crs_commit_args (!= 0, ncommit <= 128) that also clear zero_bytes (a multiple of 4) at
+ * `zero`: the control block of the window launched next on the stream.  ncommit >= 1. */
+int nla_k_crs_commit_zero(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *slot,
+                          const int32_t *kind, const int64_t *row, int lists_on_host, void *zero, size_t zero_bytes, void *stream);
 
 /* single local mutation of one candidate in place (host-callback mode, crs.c:139-146) */
 int nla_k_crs_mutate(int n, const double *best, double *p, const uint32_t *words,

@@ -76,14 +76,27 @@ typedef struct {
     _Atomic uint32_t arrived, generation;
     _Atomic uint32_t attached, detached;
     _Atomic uint32_t aborted;           /* nla_comm_abort: a rank gave up in the middle of a job; every barrier from now on fails */
-    char pad[64 - 44];
+    /* who made the segment: rank 0's pid and the kernel's start time of that process (/proc/<pid>/stat field 22).  A segment left under the
+     * same name by a run that crashed carries a valid magic, world and slot size and garbage barrier words; what tells it from this job's
+     * is that its creator no longer exists — a rank > 0 attaches only to a segment whose creator is alive (shm_creator_alive) */
+    uint32_t creator_pid;
+    uint64_t creator_start;
+    char pad[64 - 56];
 } shm_header;
 #define SHM_MAGIC 0x6e6c6173u
 typedef struct {
     shm_header *h; char *slots; size_t bytes_mapped, slot;
     int owner, registered; unsigned parity;
+    double barrier_timeout_s;           /* nlopt_amd_comm_set_timeout; 600 s unless set */
     char name[96];
 } shm_state;
+#if defined(__x86_64__) || defined(__i386__)
+#define NLA_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define NLA_CPU_RELAX() __asm__ __volatile__("yield" ::: "memory")
+#else
+#define NLA_CPU_RELAX() ((void) 0)
+#endif
 
 struct nlopt_amd_comm_s {
     int rank, world;
@@ -147,12 +160,15 @@ static int shm_barrier(nlopt_amd_comm *c)
     }
     clock_gettime(CLOCK_MONOTONIC, &t0);
     while (atomic_load_explicit(&h->generation, memory_order_acquire) == g) {
-        if (++spins < 2000) { __builtin_ia32_pause(); continue; }
+        if (++spins < 2000) { NLA_CPU_RELAX(); continue; }
         if (atomic_load_explicit(&h->aborted, memory_order_acquire)) { snprintf(c->err, sizeof c->err, "shm transport: a rank aborted the job"); return -1; }
         sched_yield();
         if ((spins & 1023) == 0) {                       /* a rank that died must not hang the others for ever */
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (t1.tv_sec - t0.tv_sec > 600) { snprintf(c->err, sizeof c->err, "shm transport: a rank did not reach the barrier within 600 s"); return -1; }
+            if ((double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec) > c->shm->barrier_timeout_s) {
+                snprintf(c->err, sizeof c->err, "shm transport: a rank did not reach the barrier within %g s", c->shm->barrier_timeout_s);
+                return -1;
+            }
         }
     }
     return 0;
@@ -187,16 +203,47 @@ static void shm_close(shm_state *s)
     }
     free(s);
 }
+/* start time of process `pid` in clock ticks since boot (field 22 of /proc/<pid>/stat; the command name in field 2 may hold spaces and
+ * parentheses, so the fields are counted from the LAST ')'); 0 if the process does not exist */
+static uint64_t proc_start_time(uint32_t pid)
+{
+    char path[64], buf[1024], *p;
+    FILE *f;
+    size_t len;
+    int field;
+    snprintf(path, sizeof path, "/proc/%u/stat", (unsigned) pid);
+    f = fopen(path, "r");
+    if (!f) return 0;
+    len = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[len] = 0;
+    p = strrchr(buf, ')');
+    if (!p) return 0;
+    for (field = 2, ++p; *p && field < 22; ++p) if (*p == ' ' && p[1] != ' ') ++field;      /* p ends on the first digit of field 22 */
+    return *p ? (uint64_t) strtoull(p, NULL, 10) : 0;
+}
+static int shm_creator_alive(const shm_header *h)
+{
+    const uint64_t t = h->creator_pid ? proc_start_time(h->creator_pid) : 0;
+    return t != 0 && t == h->creator_start;
+}
+
 /* `name`: a POSIX shared-memory name ("/something") every rank of the job passes identically and no other job uses; slot_bytes: the
- * largest single contribution moved in one piece (larger ones are split; 0 = 16 MiB).  Rank 0 creates the segment, the others wait
- * for it (up to 120 s).  All ranks must live on one node. */
+ * largest single contribution moved in one piece (larger ones are split; 0 = 16 MiB).  All ranks must live on one node (and see the same
+ * /proc: one pid namespace).
+ * Start-up, safe against a segment that a crashed run left under the same name and against any order in which the ranks arrive:
+ * rank 0 removes the old name, builds the new segment under a private name ("<name>.<pid>"), initialises it completely — sizes, barrier
+ * words, its own pid + start time, the magic — and only then gives it the job's name (link(2) on /dev/shm: the name appears atomically
+ * and never points at a half-made segment).  A rank > 0 opens the name, maps it and attaches only if magic / world / slot size agree AND
+ * the creator recorded in the header is a live process; otherwise (the crashed run's segment: its creator is gone) it lets go and opens
+ * the name again, for up to 120 s. */
 nlopt_amd_comm *nlopt_amd_comm_create_shm(int rank, int world, const char *name, size_t slot_bytes)
 {
     nlopt_amd_comm *c;
     shm_state *s;
     size_t total;
     int fd = -1, tries;
-    if (world < 1 || rank < 0 || rank >= world || !name || name[0] != '/' || strlen(name) >= sizeof s->name) return NULL;
+    if (world < 1 || rank < 0 || rank >= world || !name || name[0] != '/' || strchr(name + 1, '/') || strlen(name) + 24 >= sizeof s->name) return NULL;
     if (!slot_bytes) slot_bytes = (size_t) 16 << 20;
     slot_bytes = (slot_bytes + 4095) & ~(size_t) 4095;
     total = sizeof(shm_header) + 2 * (size_t) world * slot_bytes;
@@ -206,42 +253,66 @@ nlopt_amd_comm *nlopt_amd_comm_create_shm(int rank, int world, const char *name,
     if (!c || !s) { free(c); free(s); return NULL; }
     c->rank = rank; c->world = world; c->shm = s; c->fn = shm_allgather; c->ctx = c;
     snprintf(s->name, sizeof s->name, "%s", name);
-    s->slot = slot_bytes; s->bytes_mapped = total; s->owner = rank == 0;
+    s->slot = slot_bytes; s->bytes_mapped = total; s->owner = rank == 0; s->barrier_timeout_s = 600.;
     if (rank == 0) {
+        char tmp[sizeof s->name], from[sizeof s->name + 16], to[sizeof s->name + 16];
+        shm_header *h;
+        snprintf(tmp, sizeof tmp, "%s.%ld", name, (long) getpid());
+        shm_unlink(tmp);
         shm_unlink(name);                                /* a stale segment of a run that crashed */
-        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, (off_t) total)) { if (fd >= 0) { close(fd); shm_unlink(name); } free(c); free(s); return NULL; }
+        fd = shm_open(tmp, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t) total)) { if (fd >= 0) { close(fd); shm_unlink(tmp); } free(c); free(s); return NULL; }
+        h = (shm_header *) mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (h == MAP_FAILED) { shm_unlink(tmp); free(c); free(s); return NULL; }
+        h->world = (uint32_t) world; h->slot = slot_bytes;
+        h->creator_pid = (uint32_t) getpid(); h->creator_start = proc_start_time((uint32_t) getpid());
+        atomic_store_explicit(&h->arrived, 0, memory_order_relaxed);
+        atomic_store_explicit(&h->generation, 0, memory_order_relaxed);
+        atomic_store_explicit(&h->attached, 0, memory_order_relaxed);
+        atomic_store_explicit(&h->detached, 0, memory_order_relaxed);
+        atomic_store_explicit(&h->aborted, 0, memory_order_relaxed);
+        atomic_store_explicit(&h->magic, SHM_MAGIC, memory_order_release);
+        /* complete: now it gets the job's name (POSIX shm objects are files under /dev/shm on Linux) */
+        snprintf(from, sizeof from, "/dev/shm%s", tmp);
+        snprintf(to, sizeof to, "/dev/shm%s", name);
+        if (!h->creator_start || link(from, to)) { munmap(h, total); shm_unlink(tmp); free(c); free(s); return NULL; }
+        shm_unlink(tmp);
+        s->h = h;
     } else {
-        for (tries = 0; tries < 120000 && fd < 0; ++tries) {
+        for (tries = 0; tries < 120000 && !s->h; ++tries) {
             struct stat sb;
+            shm_header *h;
             fd = shm_open(name, O_RDWR, 0600);
-            if (fd >= 0 && (fstat(fd, &sb) || (size_t) sb.st_size < total)) { close(fd); fd = -1; }      /* created, not sized yet */
-            if (fd < 0) usleep(1000);
+            if (fd < 0) { usleep(1000); continue; }
+            if (fstat(fd, &sb) || (size_t) sb.st_size < sizeof(shm_header)) { close(fd); usleep(1000); continue; }
+            h = (shm_header *) mmap(NULL, (size_t) sb.st_size < total ? (size_t) sb.st_size : total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (h == MAP_FAILED) { usleep(1000); continue; }
+            if (atomic_load_explicit(&h->magic, memory_order_acquire) == SHM_MAGIC && shm_creator_alive(h)) {
+                /* this job's segment (its creator lives): ranks that disagree about the job's shape are an error, not a reason to wait */
+                if (h->world != (uint32_t) world || h->slot != slot_bytes || (size_t) sb.st_size < total) { munmap(h, (size_t) sb.st_size < total ? (size_t) sb.st_size : total); break; }
+                s->h = h;
+                break;
+            }
+            munmap(h, (size_t) sb.st_size < total ? (size_t) sb.st_size : total);      /* a crashed run's segment: rank 0 will replace it */
+            usleep(1000);
         }
-        if (fd < 0) { free(c); free(s); return NULL; }
+        if (!s->h) { free(c); free(s); return NULL; }
     }
-    s->h = (shm_header *) mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (s->h == MAP_FAILED) { s->h = NULL; if (rank == 0) shm_unlink(name); free(c); free(s); return NULL; }
     s->slots = (char *) s->h + sizeof(shm_header);
-    if (rank == 0) {
-        s->h->world = (uint32_t) world; s->h->slot = slot_bytes;
-        atomic_store_explicit(&s->h->arrived, 0, memory_order_relaxed);
-        atomic_store_explicit(&s->h->generation, 0, memory_order_relaxed);
-        atomic_store_explicit(&s->h->attached, 0, memory_order_relaxed);
-        atomic_store_explicit(&s->h->detached, 0, memory_order_relaxed);
-        atomic_store_explicit(&s->h->magic, SHM_MAGIC, memory_order_release);
-    } else {
-        for (tries = 0; tries < 120000 && atomic_load_explicit(&s->h->magic, memory_order_acquire) != SHM_MAGIC; ++tries) usleep(1000);
-        if (atomic_load_explicit(&s->h->magic, memory_order_acquire) != SHM_MAGIC || s->h->world != (uint32_t) world || s->h->slot != slot_bytes) {
-            munmap(s->h, total); free(c); free(s); return NULL;                   /* another job's segment, or ranks that disagree */
-        }
-    }
     atomic_fetch_add_explicit(&s->h->attached, 1, memory_order_acq_rel);
     /* device copies straight into / out of the slots (no device: the transport still serves host data) */
     s->registered = nla_dev_count() > 0 && nla_host_register(s->h, total) == 0;
     if (shm_barrier(c)) { shm_close(s); free(c); return NULL; }                   /* everyone is attached before anyone may leave */
     return c;
+}
+
+/* how long a rank waits in a barrier of the shm transport for the others before it reports an error (default 600 s; the other transports
+ * have their own timeouts) */
+void nlopt_amd_comm_set_timeout(nlopt_amd_comm *c, double seconds)
+{
+    if (c && c->shm && seconds > 0) c->shm->barrier_timeout_s = seconds;
 }
 
 void nlopt_amd_comm_destroy(nlopt_amd_comm *c)

@@ -779,34 +779,64 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     const int on_host = nW <= NLA_KARG_MAX && !e->force_upload;
     const int64_t *d_W = W;
     const double *d_Wf = Wf;
+    int use_bell = 0;
+    uint32_t bell_seq = 0;
     if (e->obj < 0 || !e->d_ctrl) FAIL(e, "no device-resolved windows for a host objective");
     if (K < 1 || K > CHAIN_KMAX || nW < 0 || nW > CHAIN_KMAX || fwcap != CHAIN_FWCAP) FAIL(e, "bad window K=%d nW=%d", K, nW);
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
     if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
-    /* the commits of the previous pass, then (long lists only) W and its f values */
-    if (e->npending && e->npending <= NLA_KARG_MAX && !e->force_upload) {
-        CK(e, nla_k_crs_commit_args(n, e->ld, e->d_X, e->d_TX, e->d_TM, e->npending, e->pend_slot, e->pend_kind, e->pend_row, e->main));
-        e->npending = 0;
-    }
-    if (e->npending || !on_host) {
-        if (upload_and_commit(e, W, on_host ? 0 : nW, NULL, 0, &d_W, NULL, NULL, NULL)) return -1;
-        if (!on_host) { CK(e, nla_memcpy_h2d(e->d_Wf, Wf, sizeof(double) * (size_t) nW, e->main)); d_Wf = e->d_Wf; }
-        else { d_W = W; }
-    }
-    /* the event pair around the launch (the roofline figure of bench.py) on every window from n = 2048 on, on one window in
-     * TIME_EVERY_WINDOW below: two barrier packets and an elapsed-time query per ~200 us window are a few per cent there */
-    e->timed = (n >= 2048 || e->pass_log || (e->pass_no++ % TIME_EVERY_WINDOW) == 0) && e->stats;
-    if (e->timed) CK(e, nla_event_record(e->ev0, e->main));
+    /* what goes in front of the window on the stream (round 5, "lean windows": a 256-slot window used to be copy / commit / copy / fill /
+     * fill / chain — six operations with 4-7 us between any two, profiles/r05_n512_timeline.txt): ONE copy with everything the device
+     * needs (W, its f values, the commit lists — none at all when they fit the kernel arguments), the commit kernel of the previous
+     * window's accepted points, which also clears the control block, then the window */
     {
-        const int rc = nla_k_crs_chain(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W, d_Wf,
-                                       nW, on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status, e->h_fwcnt,
-                                       e->h_fwrec, fwcap, e->main);
-        if (rc) FAIL(e, "nla_k_crs_chain failed: %s", nla_dev_error_string(rc));
+        const size_t zero_bytes = nla_crs_chain_ctrl_bytes(K, nW) - sizeof(uint32_t);
+        void *zero = (char *) e->d_ctrl + sizeof(uint32_t);
+        int zeroed = 0;
+        if (e->npending && e->npending <= NLA_KARG_MAX && !e->force_upload) {
+            CK(e, nla_k_crs_commit_zero(n, e->ld, e->d_X, e->d_TX, e->d_TM, e->npending, e->pend_slot, e->pend_kind, e->pend_row, 1, zero, zero_bytes, e->main));
+            e->npending = 0; zeroed = 1;
+        }
+        if (e->npending || !on_host) {
+            const int nc = e->npending, nWu = on_host ? 0 : nW;
+            const size_t oW = 0, oF = oW + 8 * (size_t) nWu, oR = oF + 8 * (size_t) nWu, oS = oR + 8 * (size_t) nc, oK = oS + 4 * (size_t) nc;
+            const size_t total = oK + 4 * (size_t) nc;
+            if (nWu) { memcpy(e->h_up + oW, W, 8 * (size_t) nWu); memcpy(e->h_up + oF, Wf, 8 * (size_t) nWu); }
+            if (nc) {
+                memcpy(e->h_up + oR, e->pend_row, 8 * (size_t) nc);
+                memcpy(e->h_up + oS, e->pend_slot, 4 * (size_t) nc);
+                memcpy(e->h_up + oK, e->pend_kind, 4 * (size_t) nc);
+            }
+            CK(e, nla_memcpy_h2d(e->d_up, e->h_up, total, e->main));
+            if (nc) {
+                CK(e, nla_k_crs_commit_zero(e->ncopy, e->ld, e->d_X, e->d_TX, e->d_TM, nc, (const int32_t *) (e->d_up + oS), (const int32_t *) (e->d_up + oK),
+                                            (const int64_t *) (e->d_up + oR), 0, zero, zero_bytes, e->main));
+                e->npending = 0; zeroed = 1;
+            }
+            if (nWu) { d_W = (const int64_t *) (e->d_up + oW); d_Wf = (const double *) (e->d_up + oF); }
+        }
+        /* the event pair around the launch (the roofline figure of bench.py) on every window from n = 2048 on, on one window in
+         * TIME_EVERY_WINDOW below: two barrier packets and an elapsed-time query per ~200 us window are a few per cent there */
+        e->timed = (n >= 2048 || e->pass_log || (e->pass_no++ % TIME_EVERY_WINDOW) == 0) && e->stats;
+        /* the doorbell ("amd_doorbell", hip/crs_chain.hip): the last workgroup of the window rings a word in pinned memory and the host
+         * spins on it instead of sleeping in the stream synchronisation; not on the windows whose event pair is read afterwards */
+        use_bell = e->doorbell && !e->timed && e->h_bell && e->d_bellcount;
+        if (use_bell) bell_seq = ++e->bell_seq ? e->bell_seq : ++e->bell_seq;
+        if (e->timed) CK(e, nla_event_record(e->ev0, e->main));
+        {
+            const int rc = nla_k_crs_chain_lean(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W,
+                                                d_Wf, nW, on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status,
+                                                e->h_fwcnt, e->h_fwrec, fwcap, zeroed, use_bell ? e->d_bellcount : NULL, use_bell ? e->h_bell : NULL,
+                                                bell_seq, e->main);
+            if (rc) FAIL(e, "nla_k_crs_chain failed: %s", nla_dev_error_string(rc));
+        }
     }
     e->ticket_base += nla_crs_chain_tickets(n, e->ld, K);
     if (e->timed) CK(e, nla_event_record(e->ev1, e->main));
     if (e->idle_fn) e->idle_fn(e->idle_arg);      /* the window is with the device: the driver's upkeep of its ordered set runs beside it */
-    CK(e, nla_stream_sync(e->main));              /* status and records were written into pinned host memory by the kernel */
+    /* status and records were written into pinned host memory by the kernel; a bell that does not come within 20 ms falls back to the
+     * synchronisation, which reports what happened */
+    if (!use_bell || bell_wait(e, bell_seq)) CK(e, nla_stream_sync(e->main));
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
     memcpy(fwcnt, e->h_fwcnt, sizeof(uint32_t) * (size_t) K);
     /* only the records a slot wrote (most slots of a window read none or one of the window's worst rows): the buffer is pinned memory the

@@ -399,7 +399,9 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
      * part of a status record — makes it visible system-wide and counts itself; the last one resets the count and rings */
     if (bell && tid == 0) {
         __threadfence_system();
-        if (atomicAdd(bell_count, 1u) == gridDim.x - 1u) {
+        /* acquire-release on the count: the last workgroup's read of it happens-after every other workgroup's increment — and so after
+         * their status writes — and the release store of the bell below carries all of that to the host's acquire load */
+        if (__hip_atomic_fetch_add(bell_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
             atomicExch(bell_count, 0u);
             __hip_atomic_store(bell, bell_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -409,9 +411,13 @@ __global__ __launch_bounds__(NLA_FIN_WAVES * 64) void crs_finish_kernel(
 /* write accepted candidates back into the population (crs.c:153) */
 __global__ __launch_bounds__(256) void crs_commit_kernel(int n, int ld, double *__restrict__ X, const double *__restrict__ TX,
                                                           const double *__restrict__ TM, const int32_t *__restrict__ slot,
-                                                          const int32_t *__restrict__ kind, const int64_t *__restrict__ row, const crs_commits C)
+                                                          const int32_t *__restrict__ kind, const int64_t *__restrict__ row, const crs_commits C,
+                                                          uint32_t *__restrict__ zero, int zero_words)
 {
     const int c = blockIdx.x;
+    /* the control block of the window launched behind this kernel (hip/crs_chain.hip) starts from zero: cleared here by the first
+     * workgroup instead of by a fill operation of its own in front of every window (two fill kernels and their gaps per window) */
+    if (c == 0) for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0u;
     const int kc = C.inl ? C.kind[c] : kind[c], sc = C.inl ? C.slot[c] : slot[c];
     const int64_t rc = C.inl ? C.row[c] : row[c];
     const double *src = (kc == 1 ? TX : TM) + (size_t) sc * (size_t) ld;
@@ -481,7 +487,25 @@ extern "C" int nla_k_crs_commit(int n, int ld, double *X, const double *TX, cons
     crs_commits C;
     C.inl = 0;
     hipLaunchKernelGGL(crs_commit_kernel, dim3((unsigned) ncommit), dim3(256), 0, (hipStream_t) stream,
-                       n, ld, X, TX, TM, slot, kind, row, C);
+                       n, ld, X, TX, TM, slot, kind, row, C, nullptr, 0);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+/* nla_k_crs_commit / nla_k_crs_commit_args (lists_on_host != 0: at most 128 commits, as kernel arguments) that also clear `zero_bytes`
+ * (a multiple of 4) at `zero`: the control block of the device-resolved window launched next on the same stream */
+extern "C" int nla_k_crs_commit_zero(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *slot,
+                                     const int32_t *kind, const int64_t *row, int lists_on_host, void *zero, size_t zero_bytes, void *stream)
+{
+    if (ncommit <= 0 || (zero_bytes & 3u) || (lists_on_host && ncommit > NLA_KA_MAX)) return (int) hipErrorInvalidValue;
+    crs_commits C;
+    C.inl = lists_on_host ? 1 : 0;
+    if (lists_on_host) {
+        for (int c = 0; c < ncommit; ++c) { C.slot[c] = slot[c]; C.kind[c] = kind[c]; C.row[c] = row[c]; }
+        slot = nullptr; kind = nullptr; row = nullptr;
+    }
+    hipLaunchKernelGGL(crs_commit_kernel, dim3((unsigned) ncommit), dim3(256), 0, (hipStream_t) stream,
+                       n, ld, X, TX, TM, slot, kind, row, C, (uint32_t *) zero, (int) (zero_bytes / 4));
     NLA_LAUNCH_CHECK();
     return 0;
 }
@@ -496,7 +520,7 @@ extern "C" int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX,
     C.inl = 1;
     for (int c = 0; c < ncommit; ++c) { C.slot[c] = h_slot[c]; C.kind[c] = h_kind[c]; C.row[c] = h_row[c]; }
     hipLaunchKernelGGL(crs_commit_kernel, dim3((unsigned) ncommit), dim3(256), 0, (hipStream_t) stream,
-                       n, ld, X, TX, TM, nullptr, nullptr, nullptr, C);
+                       n, ld, X, TX, TM, nullptr, nullptr, nullptr, C, nullptr, 0);
     NLA_LAUNCH_CHECK();
     return 0;
 }

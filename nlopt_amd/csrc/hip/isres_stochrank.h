@@ -19,6 +19,10 @@
 #ifndef SR_SETPRIO_HIGH
 #define SR_SETPRIO_HIGH() __builtin_amdgcn_s_setprio(3)
 #endif
+#ifndef SR_CLOCK
+#define SR_CLOCK() ((uint64_t) wall_clock64())       /* 100 MHz */
+#endif
+#define SR_GATE_TIMEOUT 400000000ull    /* 4 s without the block's bits arriving: the generator's launch failed or never ran */
 
 #define SR_DPP_SHL1 0x130               /* wave_shl:1 — lane i reads lane i+1 */
 #define SR_DPP_SHR1 0x138               /* wave_shr:1 — lane i reads lane i-1 */
@@ -69,7 +73,21 @@ SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__
         const int64_t gr1 = 64 * (unit + 1) < gate_nrows ? 64 * (unit + 1) : gate_nrows;
         const uint64_t gb1 = gate_g_rank0 + 2ull * (uint64_t) (pop - 1) * (uint64_t) gr1;
         const int want = gb1 > gb0 ? (int) ((gb1 - 1) / SR_SEG_WORDS - gb0 / SR_SEG_WORDS + 1) : 0;
-        if (lane == 0) while (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(8);
+        /* bounded: a generator launch that faulted or never ran must not hang the device.  The unit that gives up says so in the word
+         * behind the generator's ticket (gate[units + 2]); it and every later unit then run through on whatever bits there are, and the
+         * host — which reads the word after the launch — waits for the generator's stream and ranks again without gates (isres_driver.c) */
+        int *gate_err = const_cast<int *>(gate) + (gate_nrows + 63) / 64 + 2;
+        if (lane == 0) {
+            const uint64_t t0 = SR_CLOCK();
+            unsigned spins = 0;
+            while (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((++spins & 1023u) == 0 && (__hip_atomic_load(gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || SR_CLOCK() - t0 > SR_GATE_TIMEOUT)) {
+                    __hip_atomic_store(gate_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     uint64_t wa = brow[clampw(-1 - half)], wb = brow[clampw(0 - half)], wp = brow[clampw(1 - half)];

@@ -47,7 +47,7 @@ typedef struct {
     void *st, *ev0, *ev1;
     void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
     int gated;                      /* "amd_isres_gated" (default 1; one rank, generator on its own stream): the ranking pipeline starts while its bits are still produced */
-    int *d_gate;                    /* units + 1 counters (+ the generator's ticket): block c of the ranking bits (sweeps 64 c .. 64 c + 63) is complete when d_gate[c] has
+    int *d_gate;                    /* units + 1 counters (+ the generator's ticket, + the pipeline's "gave up waiting" word): block c of the ranking bits (sweeps 64 c .. 64 c + 63) is complete when d_gate[c] has
                                      * reached its target (hip/mt_kernels.hip: nla_k_mt_rankbits_gated; zeroed on the generator's stream before every launch) */
     void *ev_gate;                  /* recorded behind that zeroing: the pipeline's launch on the main stream waits for it */
     int gen_waves_per_cu;           /* "amd_isres_gen_waves": wavefronts of the gated generator a CU holds at a time (0 = as many as fit) */
@@ -143,7 +143,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     A(d_words, uint32_t, d->wchunk); A(d_z, double, d->zcap); A(d_zatt, int64_t, d->zcap);
     A(d_counts, int32_t, d->wchunk / 4 / 1024 + 16); A(d_ztotal, int64_t, 1); A(d_state, int64_t, 16);
     A(d_con, nla_dev_constraint, d->m + d->p + 1);
-    A(d_gate, int, d->units + 2);
+    A(d_gate, int, d->units + 3);
     d->ev_gate = nla_event_create();
     if (!d->ev_gate) ok = 0;
     d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !d->evolve_serial && !NLA_DBG_ENV("NLA_ISRES_EVOLVE_SERIAL");
@@ -200,8 +200,9 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
      * (hip/isres_stochrank.h).  The pipeline's unit u starts ~15 us after unit u - 1, which is time enough for the ten segments of a
      * block: the generation of the bits disappears behind the pipeline.  One rank with the generator on its own stream only (several
      * ranks all-gather the complete bits first). */
-    const int gated = d->gated && d->rs != d->st && nlopt_amd_comm_world(d->comm) == 1 && !d->bits_two_pass && d->d_gate != NULL;
+    int gated = d->gated && d->rs != d->st && nlopt_amd_comm_world(d->comm) == 1 && !d->bits_two_pass && d->d_gate != NULL;
     uint64_t gate_g0 = 0;
+    int gate_err = 0;
     *sweeps_out = 0;
     DCK(d, nla_k_isres_rank_count(pop, d->d_F, d->d_PEN, d->d_streams, d->d_irank, d->st));
     if (all_feasible || popm1 <= 0) return 0;      /* irank = stable sort by f (or the single individual) */
@@ -219,7 +220,7 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         const int64_t last = world > 1 ? (first + d->per < pop ? first + d->per : pop) : pop;
         if (gated) {
             DCK(d, nla_memset(d->d_bits, 0, sizeof(uint64_t) * (size_t) pop * (size_t) d->rowwords, d->rs));
-            DCK(d, nla_memset(d->d_gate, 0, sizeof(int) * (size_t) (d->units + 2), d->rs));
+            DCK(d, nla_memset(d->d_gate, 0, sizeof(int) * (size_t) (d->units + 3), d->rs));
             DCK(d, nla_event_record(d->ev_gate, d->rs));
             gate_g0 = nla_mtstream_origin(d->mts) + d->words_used;
             if (nla_mtstream_rankbits_gated(d->mts, d->words_used, d->words_used, 2ULL * (uint64_t) popm1 * (uint64_t) pop, popm1, d->rowwords, d->d_bits,
@@ -271,7 +272,17 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
             d->spec_valid = 1; ++d->spec_made;
             *t_rng += nla_seconds() - t1;
         }
+        if (gated && nsweeps == pop) DCK(d, nla_memcpy_d2h(&gate_err, d->d_gate + d->units + 2, sizeof gate_err, d->st));
         DCK(d, nla_stream_sync(d->st));
+        if (gated && gate_err) {
+            /* a unit of the pipeline gave up waiting for its block of bits (hip/isres_stochrank.h: 4 s): the generator's launch is late
+             * beyond reason or failed.  Its stream's error, if any, comes out of the synchronisation; otherwise the bits are complete
+             * after it and the ranking is done again on them, without gates */
+            DCK(d, nla_stream_sync(d->rs));
+            gated = 0; gate_err = 0;
+            if (st) ++st->isres_gate_timeouts;
+            continue;
+        }
         if (st && d->ev0 && d->ev1) {
             const float ms = nla_event_elapsed_ms(d->ev0, d->ev1);
             if (ms >= 0) st->t_stochrank_ms += ms;

@@ -810,6 +810,19 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
                     TX, TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL, NULL);
     return 0;
 }
+int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
+                         const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W,
+                         const double *Wf, int nW, int w_on_host, int slot_mask, const double *lb, const double *ub, double *TX, double *TM, void *ctrl,
+                         uint32_t ticket_base, nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
+                         uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *st)
+{
+    /* (the synchronous device: the window is complete when the call returns, so the bell has rung) */
+    const int rc = nla_k_crs_chain(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host,
+                                   slot_mask, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, st);
+    (void) ctrl_is_zero; (void) bell_count;
+    if (!rc && bell) __atomic_store_n(bell, bell_seq, __ATOMIC_RELEASE);
+    return rc;
+}
 uint32_t nla_crs_chain_tickets(int n, int ld, int K) { return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + 1u; }
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,
                      uint32_t ring_blocks, uint64_t first_block, int K, const int32_t *t_in, const int32_t *t_out, int slot_mask,
@@ -862,6 +875,13 @@ int nla_k_crs_commit(int n, int ld, double *X, const double *TX, const double *T
     for (int c = 0; c < ncommit; ++c)                                                                  /* crs.c:153 */
         memmove(X + (size_t) row[c] * (size_t) ld, (kind[c] == 1 ? TX : TM) + (size_t) slot[c] * (size_t) ld, sizeof(double) * (size_t) n);
     return 0;
+}
+int nla_k_crs_commit_zero(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *slot, const int32_t *kind,
+                          const int64_t *row, int lists_on_host, void *zero, size_t zero_bytes, void *st)
+{
+    if (ncommit <= 0 || (zero_bytes & 3u) || (lists_on_host && ncommit > 128)) return EMU_ERR;
+    if (zero_bytes) memset(zero, 0, zero_bytes);
+    return nla_k_crs_commit(n, ld, X, TX, TM, ncommit, slot, kind, row, st);
 }
 int nla_k_crs_commit_args(int n, int ld, double *X, const double *TX, const double *TM, int ncommit, const int32_t *h_slot, const int32_t *h_kind,
                           const int64_t *h_row, void *st)

@@ -363,6 +363,8 @@ def main():
         res["rccl_calls"] = np.array(list(st))
     np.savez(out + ".rank%d.npz" % rank, **res)
     dist.barrier()
+    if os.environ.get("NLA_TEST_SHM"):
+        comm.destroy()                                # the last rank to leave removes the segment's name (comm.c shm_close)
     dist.destroy_process_group()
 
 

@@ -99,6 +99,37 @@ def test_metric_config_crs_griewank_n4096_pop1e5_against_the_reference():
     check_crs("crs_griewank_n4096_pop1e5")
 
 
+def test_metric_config_steady_regime_60000_trials_against_the_reference():
+    """the metric configuration DEEP into the trial loop — the evaluations bench.py's default run times (warm-up + 20 steps of
+    2000 end about N + 51 000): N + 60 018 evaluations of the REAL reference (crs.c:125-156), i.e. the steady regime of
+    rejections, mutation blocks and new best points, not the all-accept start of a fresh population.  Every trial: reflection /
+    mutation, accepted or not, the row it replaced — bit-exact; f to 1e-10; every improvement of the minimum at the reference's
+    evaluation number; the argmin x bit for bit."""
+    g = load("crs_griewank_n4096_pop1e5_long")
+    N = int(g["N"])
+    a = run_crs(g)
+    t = a["trace"]
+    assert a["ret"] == int(g["ret"]), (a["ret"], a["err"])
+    assert a["nevals"] == int(g["nevals"]) == len(t)
+    assert a["stats"]["mt_words"] == int(g["words"])
+    scale = np.abs(g["init_f_every16"]).mean()
+    assert close(t["f"][:N:16], g["init_f_every16"], scale)
+    tt = t[N:]
+    assert np.array_equal(tt["kind"], g["trial_kind"])
+    assert np.array_equal(tt["accepted"], g["trial_accepted"])
+    assert np.array_equal(tt["row"], g["trial_row"])
+    assert close(tt["f"], g["trial_f"], scale)
+    # the regime: the fixture must hold rejections and mutation blocks at their steady rate, or this test is the short one again
+    late = slice(len(tt) // 2, None)
+    assert (g["trial_accepted"][late] == 0).mean() > 0.02 and (g["trial_kind"][late] == 2).sum() > 100
+    run_min = np.minimum.accumulate(t["f"])
+    imp = np.flatnonzero(np.concatenate(([True], run_min[1:] < run_min[:-1])))
+    assert np.array_equal(imp + 1, g["best_eval"]) and close(run_min[imp], g["best_f"], scale)
+    assert abs(a["minf"] - float(g["minf"])) <= RTOL * max(abs(float(g["minf"])), scale)
+    assert np.array_equal(a["x"], g["x"])
+    assert int(g["ref_checked"]) == 1
+
+
 def test_config2_crs_rastrigin_n512_pop1e5_against_the_reference():
     """BASELINE.json config 2: CRS2_LM Rastrigin n=512 pop=1e5, N + 5000 evaluations"""
     check_crs("crs_rastrigin_n512_pop1e5")

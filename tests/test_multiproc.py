@@ -2,6 +2,9 @@
 product's CRS driver with the initial population produced in rank blocks and all-gathered (over the CPU
 emulation of the device engine — no GPU here; the device version of the same paths is tests/test_gpu_multiproc.py)."""
 import os
+import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -408,3 +411,59 @@ def test_isres_over_the_shm_transport_world3():
     p = O.run_port_isres(obj, n, pop, seed, nineq=ncon, maxeval=gens * pop)
     for d in res:
         _check_against_oracle(d, p)
+
+
+SHM_START_SNIPPET = r"""
+import ctypes as C, os, struct, sys, time
+rank, world, name, delay, lib = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], float(sys.argv[4]), sys.argv[5]
+L = C.CDLL(lib)
+L.nlopt_amd_comm_create_shm.restype = C.c_void_p
+L.nlopt_amd_comm_create_shm.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+L.nlopt_amd_comm_set_timeout.argtypes = [C.c_void_p, C.c_double]
+L.nla_comm_allgather_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+L.nlopt_amd_comm_destroy.argtypes = [C.c_void_p]
+time.sleep(delay)
+c = L.nlopt_amd_comm_create_shm(rank, world, name.encode(), 4096)
+if not c:
+    print("create failed"); sys.exit(3)
+L.nlopt_amd_comm_set_timeout(c, 30.0)
+send = struct.pack("q", 1000 + rank)
+recv = C.create_string_buffer(8 * world)
+rc = L.nla_comm_allgather_host(c, send, recv, 8, None)
+print("rc", rc, "got", struct.unpack("%dq" % world, recv.raw))
+L.nlopt_amd_comm_destroy(c)
+"""
+
+
+@pytest.mark.parametrize("late_rank0", [False, True])
+def test_shm_transport_start_up_ignores_the_segment_of_a_crashed_run(late_rank0):
+    """comm.c start-up: a segment a crashed run left under the job's name — valid magic, world and slot size, barrier words
+    holding garbage, creator dead — must not catch a rank > 0 that starts before rank 0 has replaced it.  The stale segment is planted
+    by hand; rank 0 arrives 0.7 s after the others (or first); every rank must finish one all-gather within seconds."""
+    import struct
+    world, slot = 3, 4096
+    name = "/nla_test_stale_%d_%d" % (os.getpid(), int(late_rank0))
+    path = "/dev/shm" + name
+    total = (64 + 2 * world * slot + 4095) & ~4095
+    # header layout of comm.c's shm_header: magic, world, slot (u64), arrived, generation, attached, detached, aborted, creator_pid, creator_start (u64)
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    hdr = struct.pack("<IIQIIIIIIQ", 0x6e6c6173, world, slot, 2, 7, world, 1, 0, dead.pid, 12345)
+    with open(path, "wb") as fh:
+        fh.write(hdr + b"\0" * (total - len(hdr)))
+    try:
+        procs = []
+        for r in range(world):
+            delay = (0.7 if r == 0 else 0.0) if late_rank0 else (0.0 if r == 0 else 0.3)
+            procs.append(subprocess.Popen([sys.executable, "-c", SHM_START_SNIPPET, str(r), str(world), name, str(delay), os.path.join(ROOT, "oracle", "libnlopt_amd_emu.so")],
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        t0 = time.time()
+        outs = [p.communicate(timeout=100) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, so + se
+            assert "rc 0 got (1000, 1001, 1002)" in so, so + se
+        assert time.time() - t0 < 60
+        assert not os.path.exists(path)                  # the last rank to leave removed the name
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)

@@ -42,6 +42,7 @@ static thread_local emu::Idx threadIdx;
 /* a wavefront executes in lockstep: when lane 0 stores a counter behind this wait, every lane's stores in front of it have been issued and
  * have landed; the threads that play the lanes meet at a barrier for that */
 #define SR_SETPRIO_HIGH() ((void) 0)
+#define SR_CLOCK() ((uint64_t) 0)
 #define SR_WAIT_VMCNT0() do { std::atomic_thread_fence(std::memory_order_seq_cst); emu::unit->bar.wait(); std::atomic_thread_fence(std::memory_order_seq_cst); } while (0)
 #define __restrict__
 #define __device__
