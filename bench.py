@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("crs", "isres", "mlsl"), default="crs")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
-                    help="nlopt_set_param on the optimiser (and on MLSL's local optimiser): the library's A/B switches, e.g. amd_mlsl_prefetch=1, amd_isres_gated=0")
+                    help="nlopt_set_param on the optimiser (and on MLSL's local optimiser): the library's switches, e.g. amd_forward=0, amd_isres_overlap=0")
     ap.add_argument("--exact", action="store_true",
                     help="mlsl: the local optimiser sums in the reference's order (\"amd_exact_dot\" = 1: iterates bit-identical to the reference's); default: workgroup tree sums")
     ap.add_argument("--local", choices=("lbfgs", "mma"), default="lbfgs",
@@ -74,7 +74,6 @@ def parse():
     ap.add_argument("--evals-per-step", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--max-spec", type=int, default=0)
-    ap.add_argument("--gather-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="crs: skip the other sizes / workloads / end-to-end call (tuning runs)")
     ap.add_argument("--cpu-sample-pop", type=int, default=0)
@@ -365,7 +364,7 @@ def compact_line(full):
 CRS_PARAMS = []        # --param NAME=VALUE of the command line (the library's A/B switches), applied to every CRS2_LM object of crs_measure
 
 
-def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, sync_all, max_spec=0, variant=0, comm=None):
+def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, sync_all, max_spec=0, comm=None):
     """open a CRS2_LM run (population initialisation untimed), W warm-up steps, K timed steps; returns the raw numbers.
     comm: ONE job over the communicator's ranks (population sharded by coordinate), every rank with the same seed"""
     import _oracle as O
@@ -377,8 +376,6 @@ def crs_measure(nlopt_amd, L, obj, n, pop, seed, warmup, steps, evals_per_step, 
     o.set_population(pop)
     if max_spec:
         o.set_param("amd_max_spec", max_spec)
-    if variant:
-        o.set_param("amd_gather_variant", variant)
     for kv in CRS_PARAMS:
         o.set_param(kv.split("=", 1)[0], float(kv.split("=", 1)[1]))
     if comm is not None:
@@ -507,7 +504,7 @@ def crs_end_to_end(nlopt_amd, obj, n, pop, seed, trial_evals):
 
 def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     n, pop = a.n, a.pop
-    m = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed + rank, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec, a.gather_variant)
+    m = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed + rank, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec)
     dt, st0, st1, t_init, fret = m["dt"], m["st0"], m["st1"], m["t_init"], m["fret"]
     dt_max, evals_all = reduce(dt, m["evals"], True)
     replicas = None
@@ -534,7 +531,7 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
                 except ImportError:
                     pass
                 comm = nlopt_amd.Comm.from_torch_distributed()
-                mm = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec, a.gather_variant, comm=comm)
+                mm = crs_measure(nlopt_amd, L, a.obj, n, pop, a.seed, a.warmup, a.steps, a.evals_per_step, sync_all, a.max_spec, comm=comm)
                 dtm, evm = reduce(mm["dt"], mm["evals"], False)
                 tim, _ = reduce(mm["t_init"], 0, False)
                 box1["r"] = dict(m=mm, dt=dtm, evals=evm, t_init=tim, ranks=comm.world, transport="rccl" if os.environ.get("NLA_BENCH_TRANSPORT", "") != "host" else "host")

@@ -261,16 +261,13 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
                     uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                     const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
                     nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream);
-/* the same, leaner around the launch (round 5): ctrl_is_zero != 0 — the caller cleared the control block behind its ticket word on this
- * stream already (nla_k_crs_commit_zero: no fill operations in front of the window); bell != NULL — status, fwcnt and fwrec are pinned
- * host memory and the last workgroup to finish stores bell_seq into *bell (pinned) once every record is visible to the host, which
- * spins on it instead of synchronising the stream; bell_count = a zeroed device word */
+/* the same; ctrl_is_zero != 0 — the caller cleared the control block behind its ticket word on this stream already
+ * (nla_k_crs_commit_zero: no fill operations in front of the window) */
 int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
                          const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
                          uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                          const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
-                         nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
-                         uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *stream);
+                         nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *stream);
 /* workgroups one launch draws tickets for: K * nla_crs_chain_chunks + 1 (the resolver wavefront's workgroup, hip/crs_chain_resolver.h:
  * the chain — crs.c:135-156, the decisions between evaluations — is advanced by one dedicated wavefront out of registers) */
 uint32_t nla_crs_chain_tickets(int n, int ld, int K);
@@ -424,8 +421,12 @@ int nla_isres_evolve2_supported(int n);
 int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *inv, void *stream);
 int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
                               const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
-                              double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
-                              void *stream);
+                              double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, const double *mu_rp,
+                              int rounds, void *stream);
+/* once per generation, before the mutation phase's rounds (phase 0 of nla_k_isres_evolve_rounds needs it): mu_rp[p], p < survivors =
+ * the redraws a child of the parent at rank position p is expected to make — what the rounds predict the children's starts with */
+int nla_k_isres_evolve_parent_mu(int n, int ld, int64_t survivors, const double *lb, const double *ub, const int32_t *irank,
+                                 const double *X, const double *S, double *mu_rp, void *stream);
 
 /* ---- the batched local optimisers: common pieces ---------------------------------------------------- */
 /* External evaluation: the objective of a local search is not one of the compiled-in device objectives but a host callback

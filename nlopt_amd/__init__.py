@@ -207,7 +207,7 @@ def lib():
     L.nla_isres_evolve2_ws_bytes.restype = C.c_size_t
     L.nla_isres_evolve2_ws_bytes.argtypes = [C.c_int]
     L.nla_k_isres_inverse.argtypes = [C.c_int64, vp, vp, vp]
-    L.nla_k_isres_evolve_rounds.argtypes = ([C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double] + [vp] * 11 +
+    L.nla_k_isres_evolve_rounds.argtypes = ([C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double] + [vp] * 12 +
                                             [C.c_int, vp])   # ..., lb, ub, z, irank, inv, X, S, x0c, state, rho, ws, rounds, stream
     L.nla_k_crs_commit.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.nla_k_crs_mutate.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]

@@ -61,7 +61,7 @@ struct nla_crs_hip_engine {
     nla_crs_slot_status *d_status, *h_status;
     int32_t h_t[KCAP];             /* picks summed so far, per slot (host-authoritative) */
     int npending;                  /* commits staged on the host, not yet written to X */
-    int fuse_commit;               /* "amd_fuse_commit" (default 1): staged commits done inside the next pass's advance launch */
+    int fuse_commit;               /* 1: staged commits done inside the next pass's advance launch */
     int32_t pend_slot[KCAP], pend_kind[KCAP];
     int64_t pend_row[KCAP];
     void *ev0, *ev1;
@@ -72,7 +72,7 @@ struct nla_crs_hip_engine {
     int uncached;                  /* TX / TM / ctrl are uncached memory (the chain kernel may run) */
     int direct_status;             /* the finish kernel writes the status records into pinned host memory itself */
     int doorbell;                  /* ... and rings a word there when the last record is visible: the host spins on it instead of sleeping in a
-                                    * stream synchronisation ("amd_doorbell", default 1) */
+                                    * stream synchronisation (conservative passes only) */
     uint32_t *h_bell, *d_bellcount, bell_seq;
     void (*idle_fn)(void *); void *idle_arg;   /* the driver's host work beside a pass (ops->set_idle) */
     /* device-resolved windows (hip/crs_chain.hip): control block, the walk's lists when they do not fit the kernel arguments,
@@ -779,8 +779,6 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     const int on_host = nW <= NLA_KARG_MAX && !e->force_upload;
     const int64_t *d_W = W;
     const double *d_Wf = Wf;
-    int use_bell = 0;
-    uint32_t bell_seq = 0;
     if (e->obj < 0 || !e->d_ctrl) FAIL(e, "no device-resolved windows for a host objective");
     if (K < 1 || K > CHAIN_KMAX || nW < 0 || nW > CHAIN_KMAX || fwcap != CHAIN_FWCAP) FAIL(e, "bad window K=%d nW=%d", K, nW);
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
@@ -818,25 +816,18 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
         /* the event pair around the launch (the roofline figure of bench.py) on every window from n = 2048 on, on one window in
          * TIME_EVERY_WINDOW below: two barrier packets and an elapsed-time query per ~200 us window are a few per cent there */
         e->timed = (n >= 2048 || e->pass_log || (e->pass_no++ % TIME_EVERY_WINDOW) == 0) && e->stats;
-        /* the doorbell ("amd_doorbell", hip/crs_chain.hip): the last workgroup of the window rings a word in pinned memory and the host
-         * spins on it instead of sleeping in the stream synchronisation; not on the windows whose event pair is read afterwards */
-        use_bell = e->doorbell && !e->timed && e->h_bell && e->d_bellcount;
-        if (use_bell) bell_seq = ++e->bell_seq ? e->bell_seq : ++e->bell_seq;
         if (e->timed) CK(e, nla_event_record(e->ev0, e->main));
         {
             const int rc = nla_k_crs_chain_lean(OBJK(e), n, e->ld, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K, d_W,
                                                 d_Wf, nW, on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status,
-                                                e->h_fwcnt, e->h_fwrec, fwcap, zeroed, use_bell ? e->d_bellcount : NULL, use_bell ? e->h_bell : NULL,
-                                                bell_seq, e->main);
+                                                e->h_fwcnt, e->h_fwrec, fwcap, zeroed, e->main);
             if (rc) FAIL(e, "nla_k_crs_chain failed: %s", nla_dev_error_string(rc));
         }
     }
     e->ticket_base += nla_crs_chain_tickets(n, e->ld, K);
     if (e->timed) CK(e, nla_event_record(e->ev1, e->main));
     if (e->idle_fn) e->idle_fn(e->idle_arg);      /* the window is with the device: the driver's upkeep of its ordered set runs beside it */
-    /* status and records were written into pinned host memory by the kernel; a bell that does not come within 20 ms falls back to the
-     * synchronisation, which reports what happened */
-    if (!use_bell || bell_wait(e, bell_seq)) CK(e, nla_stream_sync(e->main));
+    CK(e, nla_stream_sync(e->main));              /* status and records were written into pinned host memory by the kernel */
     memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
     memcpy(fwcnt, e->h_fwcnt, sizeof(uint32_t) * (size_t) K);
     /* only the records a slot wrote (most slots of a window read none or one of the window's worst rows): the buffer is pinned memory the
@@ -917,8 +908,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
                           (!opt || nlopt_get_param(opt, "amd_shard", 1) != 0);
         if (shard) { pb->forward = 0; pb->comm = comm; }
         *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
-        if (*eout) (*eout)->fuse_commit = !opt || nlopt_get_param(opt, "amd_fuse_commit", 1) != 0;
-        if (*eout) (*eout)->doorbell = !opt || nlopt_get_param(opt, "amd_doorbell", 1) != 0;
+        if (*eout) { (*eout)->fuse_commit = 1; (*eout)->doorbell = 1; }      /* (rounds 4-5 had A/B switches here: profiles/r04_crs_fuse_commit_ab.txt, r04_crs_doorbell_ab.txt) */
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */
     if (opt && nlopt_amd_comm_world(opt->comm) > 1) {
@@ -935,7 +925,7 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         return NLOPT_OUT_OF_MEMORY;
     }
     (*eout)->user = user; (*eout)->sign = sign;
-    if (opt) (*eout)->variant = (int) nlopt_get_param(opt, "amd_gather_variant", 0);
+    (*eout)->variant = 0;                          /* automatic tiling of the conservative passes' gather (nla_k_crs_advance) */
     return NLOPT_SUCCESS;
 }
 

@@ -86,9 +86,9 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_a
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int VEC, int U, int WAVES, int OBJ>
-__device__ __forceinline__ void crs_chain_body(
-    /* (the kernel's first argument, the chain_lists, is read through the kernarg segment below, never by name: indexing the by-value
-     * copy with a run-time j makes the compiler move all 1.5 KB of it to scratch memory) */
+__global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
+    const chain_lists L_first_kernel_argument,  /* read through the kernarg segment below, never by name: indexing the by-value copy
+                                                 * with a run-time j makes the compiler move all 1.5 KB of it to scratch memory */
     int n, int ld, const double *__restrict__ X, int64_t i0, double f_best, const int32_t *__restrict__ jn_ring,
     const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, const uint32_t *__restrict__ words_ring,
     uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *__restrict__ Wd, const double *__restrict__ Wfd, int nW,
@@ -98,6 +98,7 @@ __device__ __forceinline__ void crs_chain_body(
 {
     typedef const __attribute__((address_space(4))) chain_lists *kernarg_lists;
     const kernarg_lists Lk = (kernarg_lists) __builtin_amdgcn_kernarg_segment_ptr();       /* explicit arguments start at offset 0 */
+    (void) L_first_kernel_argument;
     typedef typename VecT<VEC>::T V;
     static_assert(U <= 64, "one lane per row of a batch");
     __shared__ V sacc[64];
@@ -307,39 +308,6 @@ __device__ __forceinline__ void crs_chain_body(
     }
 }
 
-/* The kernel: the body above, then the DOORBELL (bell != NULL).  status, fwcnt and fwrec are pinned host memory the host reads as soon as
- * the window is finished; instead of sleeping in a stream synchronisation (its wake-up is 10-20 us of a ~200 us window below n = 2048)
- * the host spins on *bell.  Every workgroup, on whatever path it leaves the body: all its wavefronts wait for their own stores to be
- * acknowledged (vmcnt) and meet at a barrier, thread 0 makes them visible system-wide and counts the workgroup with an
- * acquire-release increment; the workgroup that completes the count resets it and rings (system-scope release store) — the host's
- * acquire load of the bell then happens-after every workgroup's records.  (The resolver's workgroup arrives last or nearly: its other
- * wavefronts wait at the barrier while wavefront 0 advances the chain.) */
-template <int VEC, int U, int WAVES, int OBJ>
-__global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
-    const chain_lists L_first_kernel_argument,
-    int n, int ld, const double *__restrict__ X, int64_t i0, double f_best, const int32_t *__restrict__ jn_ring,
-    const int32_t *__restrict__ pos_ring, const int32_t *__restrict__ last_ring, const uint32_t *__restrict__ words_ring,
-    uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *__restrict__ Wd, const double *__restrict__ Wfd, int nW,
-    int slot_mask, int chunks, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX,
-    double *__restrict__ TM, chain_ctrl *__restrict__ ctrl, uint32_t ticket_base, nla_crs_slot_status *__restrict__ status,
-    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, double sign, uint64_t resolver_timeout,
-    uint32_t *__restrict__ bell_count, uint32_t *__restrict__ bell, uint32_t bell_seq)
-{
-    (void) L_first_kernel_argument;
-    crs_chain_body<VEC, U, WAVES, OBJ>(n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, Wd,
-                                       Wfd, nW, slot_mask, chunks, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, sign, resolver_timeout);
-    if (!bell) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        if (__hip_atomic_fetch_add(bell_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-            atomicExch(bell_count, 0u);
-            __hip_atomic_store(bell, bell_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
 extern "C" size_t nla_crs_chain_ctrl_bytes(int K, int nW)
 {
     return sizeof(chain_ctrl) + sizeof(double) * 2 * (size_t) K + sizeof(uint32_t) * (2 * (size_t) K + (size_t) nW + 8);
@@ -368,8 +336,7 @@ extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int
                                     const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
                                     uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                                     const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
-                                    nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
-                                    uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *stream);
+                                    nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *stream);
 extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
                                const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
                                uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
@@ -377,20 +344,20 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
                                nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, void *stream)
 {
     return nla_k_crs_chain_lean(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host,
-                                slot_mask, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, 0, nullptr, nullptr, 0, stream);
+                                slot_mask, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, 0, stream);
 }
 
-/* ctrl_is_zero != 0: the caller has cleared the control block behind its ticket word on this stream already (nla_k_crs_commit_zero);
- * bell != NULL: status / fwcnt / fwrec are pinned host memory and the last workgroup rings *bell = bell_seq (bell_count: a zeroed device word) */
+/* ctrl_is_zero != 0: the caller has cleared the control block behind its ticket word on this stream already (nla_k_crs_commit_zero).
+ * (A doorbell in pinned memory rung by the last workgroup, for a host that spins instead of synchronising the stream, was measured here
+ * in round 5 and removed: with a system-scope fence per workgroup n = 512 ran at 612 k evals/s against 687 k with the synchronisation,
+ * with one fence by the ringing workgroup 920 k against 980 k — profiles/r05_lean_windows_ab.txt.) */
 extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
                                     const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
                                     uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                                     const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
-                                    nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
-                                    uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *stream)
+                                    nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *stream)
 {
     if (K <= 0) return 0;
-    if (bell && !bell_count) return (int) hipErrorInvalidValue;
     if (K > 256 || nW > 256 || nW < 0 || obj < 0) return (int) hipErrorInvalidValue;
     const double sign = nla_obj_sign(&obj);
     /* rows of TX / TM start on a 128-byte line: a line that holds the end of one slot's row and the start of the next one's could
@@ -417,22 +384,27 @@ extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int
     }
 #define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
         pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
-        fwcnt, fwrec, fwcap, sign, res_timeout, bell_count, bell, bell_seq)
+        fwcnt, fwrec, fwcap, sign, res_timeout)
 /* rows in flight per workgroup = wavefronts x U (tuning builds override: NLOPT_AMD_VARIANT="name:-DNLA_CHAIN_MID_W=8 ...") */
+/* Measured on the MI355X, N = 1e5 (profiles/r05_lean_windows_ab.txt; was 4 x 16 from n = 512, 2 x 16 from 128, 1 x 16 below): the time of a
+ * window below n = 2048 is the DEPTH of its dependency chains (a slot that picked one of the worst rows ahead of it waits for the chain,
+ * then finishes its gather, is evaluated, and lets the next one go) times what one such step takes — so what counts is how fast ONE
+ * slot gets through its rows, not how many slots are resident: 8 x 32 rows in flight per workgroup from n = 512 (n = 512: 688 -> 798 k
+ * evals/s, n = 1024: 290 -> 378 k), 4 wavefronts below (n = 256: 1.03 -> 1.13 M, n = 64: 1.53 -> 1.70 M; 8 there: 1.10 / 1.55 M) */
 #ifndef NLA_CHAIN_MID_W
-#define NLA_CHAIN_MID_W 4
+#define NLA_CHAIN_MID_W 8
 #endif
 #ifndef NLA_CHAIN_MID_U
-#define NLA_CHAIN_MID_U 16
+#define NLA_CHAIN_MID_U 32
 #endif
 #ifndef NLA_CHAIN_LOW_W
-#define NLA_CHAIN_LOW_W 2
+#define NLA_CHAIN_LOW_W 4
 #endif
 #ifndef NLA_CHAIN_LOW_U
 #define NLA_CHAIN_LOW_U 16
 #endif
 #ifndef NLA_CHAIN_TINY_W
-#define NLA_CHAIN_TINY_W 1
+#define NLA_CHAIN_TINY_W 4
 #endif
 #define CHAIN_SHAPE(O)                                                                   \
     if (vec2) {                                                                          \

@@ -38,6 +38,13 @@ CH_DEV uint64_t ch_readlane_u64(uint64_t v, uint32_t l)
     const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, ls), hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), ls);
     return (uint64_t) lo | ((uint64_t) hi << 32);
 }
+/* every lane reads the value of the lane IT names (ds_bpermute: the LDS crossbar, no memory) */
+CH_DEV uint64_t ch_shuffle_u64(uint64_t v, uint32_t src)
+{
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) (uint32_t) v);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) (uint32_t) (v >> 32));
+    return (uint64_t) lo | ((uint64_t) hi << 32);
+}
 CH_DEV uint64_t ch_ld64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CH_DEV void ch_st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CH_DEV void ch_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
@@ -112,6 +119,39 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
         }
         uint32_t i = 0;
         while (i < run && !halt) {
+            /* FAST STEP (round 5): the common case — a reflection trial that beats the current worst row, which is simply the next entry
+             * of the list — decided for ALL evaluated slots of the run at once instead of one slot per trip round the scalar walk below
+             * (that walk is ~100 dependent scalar / cross-lane instructions per slot: at n = 64 a 256-slot window spent most of its
+             * ~140 us in it).  While no accepted value has landed among the worst rows (nextra == 0), slot next + l accepted as a trial
+             * point takes list entry wp + (l - i) PROVIDED every slot before it in the run did the same; so lane l tests its own f(T)
+             * against that entry, and the run's leading lanes that pass are exactly the sequential walk's next decisions.  A lane fails —
+             * and the scalar walk takes over at that slot — if its trial is not accepted (rejection: the mutation and a second block),
+             * if the list ends, or if the accepted value MIGHT land among the worst rows or be a new best point (tested conservatively,
+             * f >= the list's last / f <= the best, so that no row index is needed here; the scalar walk decides those exactly). */
+#ifndef NLA_CHAIN_NO_FASTSTEP            /* (A/B builds) */
+            if (nextra == 0 && wp < (uint32_t) nW) {
+                const uint32_t rel = (uint32_t) lane - i;
+                const bool in = (uint32_t) lane >= i && (uint32_t) lane < run && wp + rel < (uint32_t) nW;
+                const uint32_t idx = wp + (in ? rel : 0u);
+                const uint32_t q0 = wp >> 6;
+                const uint64_t va = q0 == 0 ? wfb[0] : q0 == 1 ? wfb[1] : q0 == 2 ? wfb[2] : wfb[3];
+                uint64_t fwb = ch_shuffle_u64(va, idx & 63u);
+                if ((wp & 63u) + (run - i) > 64u) {                /* (uniform) the run's entries straddle two of the list's registers */
+                    const uint64_t vb = q0 == 0 ? wfb[1] : q0 == 1 ? wfb[2] : wfb[3];
+                    const uint64_t fb2 = ch_shuffle_u64(vb, idx & 63u);
+                    if ((idx >> 6) != q0) fwb = fb2;
+                }
+                const double fw_l = ch_f_of_bits(~fwb), fT_l = ch_f_of_bits(rt);
+                const bool ok = in && fT_l < fw_l && !(fT_l >= f_last) && !(fT_l <= f_best);
+                const uint64_t m = ch_ballot(ok) >> i;
+                const uint32_t P = (m == ~0ull) ? 64u : (uint32_t) __builtin_ctzll(~m);
+                if (P) {
+                    if ((uint32_t) lane >= i && (uint32_t) lane < i + P) ch_st32(&rowstate[wp + rel], ch_rowstate_word(1, next + (uint32_t) lane));
+                    wp += P; naccept += P; i += P;
+                    if (i >= run) break;
+                }
+            }
+#endif
             const uint32_t j = next + i;
             const double fT = ch_f_of_bits(ch_readlane_u64(rt, i)), fM = ch_f_of_bits(ch_readlane_u64(rm, i));
             /* the current worst: the next untouched row of the list, or a value that landed among them */

@@ -46,7 +46,9 @@ struct ev2_args {
     const double *x0c;                  /* copy of physical row 0 taken before the variation loop (isres.c:253) */
     int64_t *state;                     /* [0] next individual, [1] next deviate, [2] deviates ran out, [9] resolved in the last round,
                                            [10] stuck (fallback needed), [11] rounds, [12] first individual of the last round */
-    double *rho;                        /* [2*phase] decayed redraw sum, [2*phase+1] decayed mutated-coordinate sum */
+    double *rho;                        /* [2*phase] decayed redraw sum, [2*phase+1] decayed sum of the redraws EXPECTED (ws_mu) of the same individuals */
+    double *ws_mu;                      /* per block slot: redraws the individual is expected to make (stage kernel; see the scan's prediction) */
+    const double *mu_rp;                /* mutation phase: the same per PARENT, by rank position p < survivors (ev2_parent_mu_kernel, once per generation) */
     int32_t *ws_nact, *ws_act;          /* per block slot: number of mutated coordinates (-1: past the end), their indices */
     double *ws_xi, *ws_sg, *ws_xpre;    /* parent x / sigma of the mutated coordinates (compacted); x of the others */
     int16_t *T;                         /* EVM x 64 x EVD: redraws before coordinate chunk c when starting at d */
@@ -69,13 +71,7 @@ __global__ __launch_bounds__(256) void ev2_stage_kernel(ev2_args A)
     const int64_t rk = A.irank[k];
     int32_t *act = A.ws_act + (size_t) i * n;
     double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n, *wpre = A.ws_xpre + (size_t) i * n;
-    if (A.phase == 0) {                                        /* standard mutation: child k from parent irank[k % survivors], every coordinate */
-        const int64_t ri = A.irank[k % A.survivors];
-        const double *xr = A.X + (size_t) ri * ld, *sr = A.S + (size_t) ri * ld;
-        for (int j = tid; j < n; j += 256) { wxi[j] = xr[j]; wsg[j] = sr[j]; act[j] = j; }
-        if (tid == 0) A.ws_nact[i] = n;
-        return;
-    }
+    /* (the mutation phase is not staged: its scan and write workgroups read the parent's rows themselves, ev2_scan0_kernel) */
     /* differential variation of survivor k, in place: x + 0.85 (x0 - physical row k+1) unless it is the last survivor;
      * coordinates that leave the box (or all of them, for the last survivor) are mutated from the survivor's own x, sigma */
     const double GAMMA = 0.85;
@@ -104,35 +100,50 @@ __global__ __launch_bounds__(256) void ev2_stage_kernel(ev2_args A)
         if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         __syncthreads();
     }
-    if (tid == 0) A.ws_nact[i] = s_base;
+    if (tid == 0) { A.ws_nact[i] = s_base; A.ws_mu[i] = (double) s_base; }       /* variation: no better guess than the running rate per mutated coordinate */
 }
 
 /* ---- scan -------------------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
+/* PH0 (mutation phase, isres.c:234-252): nothing is staged — every coordinate of child k mutates from the rows of its parent
+ * irank[k % survivors], which no child overwrites, so the workgroup reads them itself; the expectation of its predecessors' redraws comes
+ * from the per-parent table mu_rp.  !PH0 (variation): from the stage kernel's compacted workspace. */
+template <bool PH0>
+__device__ __forceinline__ void ev2_scan_body(const ev2_args &A, const int i, double *sm)
 {
-    extern __shared__ double sm[];
     __shared__ long long s_red[4];
+    __shared__ double s_mred[4];
     __shared__ long long s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = A.n;
-    const int64_t st1 = A.state[1], st2 = A.state[2], st10 = A.state[10];
-    const int na = A.ws_nact[i];
+    const int64_t st0 = A.state[0], st1 = A.state[1], st2 = A.state[2], st10 = A.state[10];
     const double rho_r = A.rho[2 * A.phase], rho_a = A.rho[2 * A.phase + 1];
     if (st2 || st10) return;
+    int na;
+    if (PH0) {
+        const int64_t k = st0 + i;
+        na = k < A.pop ? n : -1;
+        if (tid == 0) { A.ws_nact[i] = na; A.ws_mu[i] = na < 0 ? 0.0 : A.mu_rp[k % A.survivors]; }     /* (the chain kernel's inputs) */
+    } else
+        na = A.ws_nact[i];
     if (na < 0) return;
-    const double rhoc = rho_a > 0 ? rho_r / rho_a : 0.0;
+    /* observed / expected redraws of the individuals resolved lately (decayed sums kept by the chain kernel); before anything was
+     * resolved: the expectation as it is (mutation), nothing (variation: its "expectation" is the mutated-coordinate count) */
+    const double rhoc = rho_a > 0 ? rho_r / rho_a : (PH0 ? 1.0 : 0.0);
     /* predicted start: the exact start of the block + what the individuals before this one consume at least
-     * (1 + 2 per mutated coordinate) + the expected redraws */
+     * (1 + 2 per mutated coordinate) + the redraws expected of them */
     {
         long long acc = 0;
-        for (int q = tid; q < i; q += 256) acc += A.ws_nact[q];
+        double macc = 0;
+        if (PH0) { acc = (tid == 0) ? (long long) i * n : 0; for (int q = tid; q < i; q += 256) macc += A.mu_rp[(st0 + q) % A.survivors]; }
+        else for (int q = tid; q < i; q += 256) { acc += A.ws_nact[q]; macc += A.ws_mu[q]; }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-        if (lane == 0) s_red[wave] = acc;
+        for (int m = 32; m >= 1; m >>= 1) { acc += __shfl_xor(acc, m, 64); macc += __shfl_xor(macc, m, 64); }
+        if (lane == 0) { s_red[wave] = acc; s_mred[wave] = macc; }
         __syncthreads();
         if (tid == 0) {
             const long long ab = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-            s_base = st1 + i + 2 * ab + (long long) floor(rhoc * (double) ab) - EVD / 2;
+            const double mb = s_mred[0] + s_mred[1] + s_mred[2] + s_mred[3];
+            s_base = st1 + i + 2 * ab + (long long) floor(rhoc * mb) - EVD / 2;
             A.ws_base[i] = s_base;
         }
         __syncthreads();
@@ -140,11 +151,17 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
     const int64_t base = s_base;
     double *xi = sm, *sg = sm + n, *lo = sm + 2 * n, *hi = sm + 3 * n, *smax = sm + 4 * n, *zw = sm + 5 * n;
     const double sqn = sqrt((double) n);
-    const int32_t *act = A.ws_act + (size_t) i * n;
-    const double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n;
-    for (int a = tid; a < na; a += 256) {
-        const int j = act[a];
-        xi[a] = wxi[a]; sg[a] = wsg[a]; lo[a] = A.lb[j]; hi[a] = A.ub[j]; smax[a] = (A.ub[j] - A.lb[j]) / sqn;
+    if (PH0) {
+        const int64_t ri = A.irank[(st0 + i) % A.survivors];
+        const double *xr = A.X + (size_t) ri * A.ld, *sr = A.S + (size_t) ri * A.ld;
+        for (int a = tid; a < na; a += 256) { xi[a] = xr[a]; sg[a] = sr[a]; lo[a] = A.lb[a]; hi[a] = A.ub[a]; smax[a] = (A.ub[a] - A.lb[a]) / sqn; }
+    } else {
+        const int32_t *act = A.ws_act + (size_t) i * n;
+        const double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n;
+        for (int a = tid; a < na; a += 256) {
+            const int j = act[a];
+            xi[a] = wxi[a]; sg[a] = wsg[a]; lo[a] = A.lb[j]; hi[a] = A.ub[j]; smax[a] = (A.ub[j] - A.lb[j]) / sqn;
+        }
     }
     const int ZW = EVD + 3 * na + 65;
     const int64_t avail = A.zcount - base;
@@ -189,6 +206,12 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
     }
 }
 
+__global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
+{
+    extern __shared__ double sm[];
+    ev2_scan_body<false>(A, (int) blockIdx.x, sm);
+}
+
 /* One workgroup of 1024: all of it copies the E table into LDS (16 bytes per thread and step, everything in flight at once); wavefront 0
  * then walks the block.  The walk is one dependent chain — start of individual i -> its E entry -> start of i + 1 — and a lone wavefront
  * issues one instruction every four cycles, so what counts is the number of instructions per individual and that no memory latency sits
@@ -223,11 +246,12 @@ __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
     const long long pos0 = ev2_uniform64(st1);
     const int OUT = 0x40000000;                                /* a window origin no start of this block can be within EVD of */
     int na_v[4], b_v[4], st_v[4];
+    double mu_v[4];
     if (tid < 64) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int q = c * 64 + tid;
-            na_v[c] = A.ws_nact[q]; st_v[c] = 0;
+            na_v[c] = A.ws_nact[q]; st_v[c] = 0; mu_v[c] = A.ws_mu[q];
             const long long brel = A.ws_base[q] - pos0;
             /* the row isres.c:260 reads (physical row k + 1) must not be rewritten inside this block before k: the walk ends at a
              * survivor k whose row k + 1 belongs to an earlier survivor of the block (straight-line: the index is clamped, not guarded) */
@@ -272,12 +296,13 @@ __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
     }
 done:
     long long asum = 0;
+    double msum = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (c * 64 + tid < r) { A.ws_start[c * 64 + tid] = pos0 + st_v[c]; asum += na_v[c]; }
+        if (c * 64 + tid < r) { A.ws_start[c * 64 + tid] = pos0 + st_v[c]; asum += na_v[c]; msum += mu_v[c]; }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) asum += __shfl_xor(asum, m, 64);
+    for (int m = 32; m >= 1; m >>= 1) { asum += __shfl_xor(asum, m, 64); msum += __shfl_xor(msum, m, 64); }
     if (tid != 0) return;
     const long long rsum = (long long) pos - r - 2 * asum;     /* = sum over the resolved of (consumed - 1 - 2 mutated) = their redraws */
     A.state[12] = k0;
@@ -292,36 +317,45 @@ done:
     { long long a2 = 0; for (int i = 0; i < r; ++i) a2 += A.ws_nact[i]; A.state[13] += a2 != asum; A.state[15] += a2 - asum; }
 #endif
     A.rho[2 * A.phase] = 0.9 * rho_r + (double) rsum;
-    A.rho[2 * A.phase + 1] = 0.9 * rho_a + (double) asum;
+    A.rho[2 * A.phase + 1] = 0.9 * rho_a + msum;
 }
 
 /* ---- write ------------------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(64) void ev2_write_kernel(ev2_args A)
+/* (a workgroup of 64 or of 256 threads: the chunk walk is the first wavefront's, loads and stores are everybody's) */
+template <bool PH0>
+__device__ __forceinline__ void ev2_write_body(const ev2_args &A, const int i, double *sm)
 {
-    extern __shared__ double sm[];
-    const int lane = threadIdx.x, i = blockIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int n = A.n, ld = A.ld;
     /* state[9] / [12] were written by the chain kernel of this round; a round that was skipped leaves state[9] = 0 */
     const int64_t st9 = A.state[9], st12 = A.state[12];
-    const int na = A.ws_nact[i];
-    const int64_t start = A.ws_start[i], wbase = A.ws_base[i];
     if (i >= st9) return;
+    const int na = PH0 ? n : A.ws_nact[i];
+    const int64_t start = A.ws_start[i], wbase = A.ws_base[i];
     const int64_t k = st12 + i, rk = A.irank[k];
     double *xi = sm, *sg = sm + n, *lo = sm + 2 * n, *hi = sm + 3 * n, *smax = sm + 4 * n, *xo = sm + 5 * n, *so = sm + 6 * n, *zw = sm + 7 * n;
     const double sqn = sqrt((double) n);
     const int32_t *act = A.ws_act + (size_t) i * n;
-    const double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n, *wpre = A.ws_xpre + (size_t) i * n;
-    for (int a = lane; a < na; a += 64) {
-        const int j = act[a];
-        xi[a] = wxi[a]; sg[a] = wsg[a]; lo[a] = A.lb[j]; hi[a] = A.ub[j]; smax[a] = (A.ub[j] - A.lb[j]) / sqn;
+    const double *wpre = A.ws_xpre + (size_t) i * n;
+    if (PH0) {
+        const int64_t ri = A.irank[k % A.survivors];
+        const double *xr = A.X + (size_t) ri * ld, *sr = A.S + (size_t) ri * ld;
+        for (int a = tid; a < na; a += nthr) { xi[a] = xr[a]; sg[a] = sr[a]; lo[a] = A.lb[a]; hi[a] = A.ub[a]; smax[a] = (A.ub[a] - A.lb[a]) / sqn; }
+    } else {
+        const double *wxi = A.ws_xi + (size_t) i * n, *wsg = A.ws_sg + (size_t) i * n;
+        for (int a = tid; a < na; a += nthr) {
+            const int j = act[a];
+            xi[a] = wxi[a]; sg[a] = wsg[a]; lo[a] = A.lb[j]; hi[a] = A.ub[j]; smax[a] = (A.ub[j] - A.lb[j]) / sqn;
+        }
     }
     const int ZW = EVD + 3 * na + 65;                         /* as long as the longest window the scan had for this individual */
     const int64_t avail = A.zcount - start;
     const int zwlen = (int) (avail < ZW ? avail : ZW);
-    for (int q = lane; q < zwlen; q += 64) zw[q] = A.z[start + q];
+    for (int q = tid; q < zwlen; q += nthr) zw[q] = A.z[start + q];
     __syncthreads();
-    {
+    if (tid < 64) {
         /* the exact start is candidate dtrue of the scan's window: its lane left the redraw count before every chunk in T */
+        const int lane = tid;
         const double ALPHA = 0.2;
         const int dtrue = (int) (start - wbase);
         const int chunk = (na + 63) >> 6;
@@ -341,9 +375,68 @@ __global__ __launch_bounds__(64) void ev2_write_kernel(ev2_args A)
     }
     __syncthreads();
     double *xw = A.X + (size_t) rk * ld, *sw = A.S + (size_t) rk * ld;
-    if (A.phase == 1) for (int j = lane; j < n; j += 64) xw[j] = wpre[j];      /* coordinates that stayed inside the box; sigma unchanged */
+    if (PH0) {
+        for (int a = tid; a < na; a += nthr) { xw[a] = xo[a]; sw[a] = so[a]; }
+    } else {
+        for (int j = tid; j < n; j += nthr) xw[j] = wpre[j];      /* coordinates that stayed inside the box; sigma unchanged */
+        __syncthreads();
+        for (int a = tid; a < na; a += nthr) { const int j = act[a]; xw[j] = xo[a]; sw[j] = so[a]; }
+    }
+}
+
+__global__ __launch_bounds__(64) void ev2_write_kernel(ev2_args A)
+{
+    extern __shared__ double sm[];
+    ev2_write_body<false>(A, (int) blockIdx.x, sm);
+}
+__global__ __launch_bounds__(256) void ev2_write0_kernel(ev2_args A)
+{
+    extern __shared__ double sm[];
+    ev2_write_body<true>(A, (int) blockIdx.x, sm);
+}
+
+/* Mutation phase, one launch per round in front of the chain kernel: workgroups 0 .. EVM-1 scan the round's block (A: this round's
+ * tables), workgroups EVM .. 2 EVM-1 — only when a round went before it in the batch — WRITE the individuals the PREVIOUS round
+ * resolved (P: that round's tables; T, the window origins and the exact starts exist twice and alternate).  The children's rows and
+ * the parents' rows are disjoint in this phase, so the previous round's write needs nothing the scan touches and leaves the serial
+ * path: a round is scan -> chain instead of stage -> scan -> chain -> write (round 5; 4.8 + 8.1 us of kernels and two launch gaps of
+ * a ~125 us round). */
+__global__ __launch_bounds__(256) void ev2_scan0_kernel(ev2_args A, ev2_args P)
+{
+    extern __shared__ double sm[];
+    if (blockIdx.x < EVM) ev2_scan_body<true>(A, (int) blockIdx.x, sm);
+    else ev2_write_body<true>(P, (int) blockIdx.x - EVM, sm);
+}
+
+/* redraws a child of parent p (by rank position, p < survivors) is EXPECTED to make (isres.c:245-248 draws x again while it is outside
+ * the box): with sigma' ~ sigma a draw of coordinate j leaves the box with p_j = Q((x_j - lb_j) / sigma_j) + Q((ub_j - x_j) / sigma_j), and
+ * the draws are repeated p_j / (1 - p_j) times on average.  The parents differ (sd of the redraws per individual 5.8 at config 3, 5.1 of it
+ * NOT explained by this expectation = the draws' own noise), and over the 256 individuals of a round a single rate for all of them
+ * misses the true start by +-90 deviates: half of the rounds ended where the start left its +-128 window.  With the per-parent
+ * expectation: 226 -> 183 rounds for the 42 857 children of a generation (tools/evolve_predict.py on a dump of the emulated device
+ * reproduces the device's 226; 168 = every round a full block).  Once per generation, before the mutation phase. */
+__global__ __launch_bounds__(256) void ev2_parent_mu_kernel(int n, int ld, int64_t survivors, const double *__restrict__ lb, const double *__restrict__ ub,
+                                                             const int32_t *__restrict__ irank, const double *__restrict__ X, const double *__restrict__ S,
+                                                             double *__restrict__ mu_rp)
+{
+    __shared__ double s_mu[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t p = blockIdx.x;
+    if (p >= survivors) return;
+    const int64_t ri = irank[p];
+    const double *xr = X + (size_t) ri * ld, *sr = S + (size_t) ri * ld;
+    double mu = 0;
+    for (int j = tid; j < n; j += 256) {
+        const double xv = xr[j], sv = sr[j];
+        const double inv = 0.7071067811865476 / (sv > 1e-300 ? sv : 1e-300);
+        const double q = 0.5 * (erfc((xv - lb[j]) * inv) + erfc((ub[j] - xv) * inv));
+        mu += q < 0.999 ? q / (1.0 - q) : 999.0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mu += __shfl_xor(mu, m, 64);
+    if (lane == 0) s_mu[wave] = mu;
     __syncthreads();
-    for (int a = lane; a < na; a += 64) { const int j = act[a]; xw[j] = xo[a]; sw[j] = so[a]; }
+    if (tid == 0) mu_rp[p] = s_mu[0] + s_mu[1] + s_mu[2] + s_mu[3];
 }
 
 /* inverse of the ranking permutation (variation's dependency test) */
@@ -362,6 +455,8 @@ extern "C" size_t nla_isres_evolve2_ws_bytes(int n)
     add(sizeof(int32_t) * EVM); add(sizeof(int32_t) * EVM * (size_t) n);
     add(sizeof(double) * EVM * (size_t) n); add(sizeof(double) * EVM * (size_t) n); add(sizeof(double) * EVM * (size_t) n);
     add(sizeof(int16_t) * EVM * EVD); add(sizeof(int16_t) * EVM * 64 * EVD); add(sizeof(int64_t) * EVM); add(sizeof(int64_t) * EVM);
+    add(sizeof(double) * EVM);
+    add(sizeof(int16_t) * EVM * 64 * EVD); add(sizeof(int64_t) * EVM); add(sizeof(int64_t) * EVM);      /* the second set of T / base / start (mutation phase) */
     return b;
 }
 extern "C" int nla_isres_evolve2_supported(int n) { return n >= 1 && n <= EV2_MAXN; }
@@ -374,15 +469,26 @@ extern "C" int nla_k_isres_inverse(int64_t pop, const int32_t *irank, int32_t *i
     return 0;
 }
 
+/* once per generation, before the mutation phase's rounds: mu_rp[p], p < survivors (device memory, survivors doubles) */
+extern "C" int nla_k_isres_evolve_parent_mu(int n, int ld, int64_t survivors, const double *lb, const double *ub, const int32_t *irank,
+                                            const double *X, const double *S, double *mu_rp, void *stream)
+{
+    if (survivors <= 0) return 0;
+    hipLaunchKernelGGL(ev2_parent_mu_kernel, dim3((unsigned) survivors), dim3(256), 0, (hipStream_t) stream, n, ld, survivors, lb, ub, irank, X, S, mu_rp);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
                                             const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv,
-                                            double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds,
-                                            void *stream)
+                                            double *X, double *S, const double *x0c, int64_t *state, double *rho, void *ws, const double *mu_rp,
+                                            int rounds, void *stream)
 {
     if (!nla_isres_evolve2_supported(n)) return (int) hipErrorInvalidValue;
+    if (phase == 0 && !mu_rp) return (int) hipErrorInvalidValue;
     ev2_args A;
     A.n = n; A.ld = ld; A.phase = phase; A.pop = pop; A.survivors = survivors; A.zcount = zcount; A.taup = taup; A.tau = tau;
-    A.lb = lb; A.ub = ub; A.z = z; A.irank = irank; A.inv = inv; A.X = X; A.S = S; A.x0c = x0c; A.state = state; A.rho = rho;
+    A.lb = lb; A.ub = ub; A.z = z; A.irank = irank; A.inv = inv; A.X = X; A.S = S; A.x0c = x0c; A.state = state; A.rho = rho; A.mu_rp = mu_rp;
     char *p = (char *) ws;
     auto take = [&](size_t x) { char *q = p; p += (x + 255) & ~(size_t) 255; return q; };
     A.ws_nact = (int32_t *) take(sizeof(int32_t) * EVM);
@@ -394,18 +500,35 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
     A.T = (int16_t *) take(sizeof(int16_t) * EVM * 64 * EVD);
     A.ws_base = (int64_t *) take(sizeof(int64_t) * EVM);
     A.ws_start = (int64_t *) take(sizeof(int64_t) * EVM);
+    A.ws_mu = (double *) take(sizeof(double) * EVM);
+    ev2_args B = A;                                            /* the other set of what a round's write still needs while the next round scans */
+    B.T = (int16_t *) take(sizeof(int16_t) * EVM * 64 * EVD);
+    B.ws_base = (int64_t *) take(sizeof(int64_t) * EVM);
+    B.ws_start = (int64_t *) take(sizeof(int64_t) * EVM);
     const size_t lds_scan = sizeof(double) * (size_t) (5 * n + EV2_ZW(n));
     const size_t lds_write = sizeof(double) * (size_t) (7 * n + EV2_ZW(n));
     const size_t lds_chain = sizeof(int16_t) * EVM * EVD;
     static bool attr_set = false;
     if (!attr_set) {
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipGetLastError();
         attr_set = true;
     }
     hipStream_t st = (hipStream_t) stream;
+    if (phase == 0) {
+        /* round r works on set r & 1; its launch also writes what round r - 1 resolved (the other set); the batch ends with the last
+         * round's write, so every batch starts from a population that is up to date */
+        for (int r = 0; r < rounds; ++r) {
+            const ev2_args &C = (r & 1) ? B : A, &Pv = (r & 1) ? A : B;
+            hipLaunchKernelGGL(ev2_scan0_kernel, dim3(r ? 2 * EVM : EVM), dim3(EVD), lds_write, st, C, Pv);
+            hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(1024), lds_chain, st, C);
+        }
+        if (rounds > 0) hipLaunchKernelGGL(ev2_write0_kernel, dim3(EVM), dim3(256), lds_write, st, ((rounds - 1) & 1) ? B : A);
+    } else
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(ev2_stage_kernel, dim3(EVM), dim3(256), 0, st, A);
         hipLaunchKernelGGL(ev2_scan_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);

@@ -46,11 +46,11 @@ typedef struct {
     int bits_two_pass;              /* A/B switch: ranking words through a buffer + isres_bits_kernel instead of the fused kernel */
     void *st, *ev0, *ev1;
     void *rs;                       /* the stream the generator works on: st itself, or (overlap) a second stream — see "overlap" below */
-    int gated;                      /* "amd_isres_gated" (default 1; one rank, generator on its own stream): the ranking pipeline starts while its bits are still produced */
+    int gated;                      /* 1 (one rank, generator on its own stream): the ranking pipeline starts while its bits are still produced */
     int *d_gate;                    /* units + 1 counters (+ the generator's ticket, + the pipeline's "gave up waiting" word): block c of the ranking bits (sweeps 64 c .. 64 c + 63) is complete when d_gate[c] has
                                      * reached its target (hip/mt_kernels.hip: nla_k_mt_rankbits_gated; zeroed on the generator's stream before every launch) */
     void *ev_gate;                  /* recorded behind that zeroing: the pipeline's launch on the main stream waits for it */
-    int gen_waves_per_cu;           /* "amd_isres_gen_waves": wavefronts of the gated generator a CU holds at a time (0 = as many as fit) */
+    int gen_waves_per_cu;           /* wavefronts of the gated generator a CU holds at a time (0 = as many as fit) */
     int evolve_serial;              /* "amd_isres_evolve_serial" != 0: the one-workgroup evolve kernel (the parallel one's reference in the tests) */
     int overlap;                    /* default; "amd_isres_overlap" = 0 / NLA_ISRES_OVERLAP=0 turn it off: generator work beside the latency-bound kernels */
     int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
@@ -60,6 +60,7 @@ typedef struct {
     double *d_lb, *d_ub, *d_X, *d_S, *d_F, *d_PEN, *d_GPEN, *d_scratch, *d_z;
     int32_t *d_FEAS, *d_irank, *d_counts, *d_inv;
     double *d_rho; void *d_ws;           /* parallel evolve (hip/isres_evolve2.hip): redraw statistics, block workspace */
+    double *d_mu;                        /* ... and the redraws a child of each parent (by rank position) is expected to make: survivors doubles */
     int parallel_evolve;
     uint64_t ev_rounds, ev_fallbacks, ev_real;
     int *d_progress, *d_ticket;
@@ -89,7 +90,7 @@ static void dev_free_all(isres_dev *d)
     nla_dev_free(d->d_irank); nla_dev_free(d->d_counts); nla_dev_free(d->d_progress); nla_dev_free(d->d_ticket);
     nla_dev_free(d->d_swapped); nla_dev_free(d->d_streams); nla_dev_free(d->d_bits); nla_dev_free(d->d_zatt); nla_dev_free(d->d_gate);
     nla_dev_free(d->d_ztotal); nla_dev_free(d->d_state); nla_dev_free(d->d_words); nla_dev_free(d->d_con);
-    nla_dev_free(d->d_inv); nla_dev_free(d->d_rho); nla_dev_free(d->d_ws);
+    nla_dev_free(d->d_inv); nla_dev_free(d->d_rho); nla_dev_free(d->d_ws); nla_dev_free(d->d_mu);
     nla_host_free(d->h_F); nla_host_free(d->h_PEN); nla_host_free(d->h_GPEN); nla_host_free(d->h_X); nla_host_free(d->h_FEAS);
     nla_host_free(d->h_swapped); nla_host_free(d->h_progress);
     nla_event_destroy(d->ev0); nla_event_destroy(d->ev1); nla_event_destroy(d->ev_gate);
@@ -148,7 +149,7 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     if (!d->ev_gate) ok = 0;
     d->parallel_evolve = nla_isres_evolve2_supported(d->n) && !d->evolve_serial && !NLA_DBG_ENV("NLA_ISRES_EVOLVE_SERIAL");
     if (d->parallel_evolve) {
-        A(d_inv, int32_t, pop); A(d_rho, double, 4);
+        A(d_inv, int32_t, pop); A(d_rho, double, 4); A(d_mu, double, d->survivors > 0 ? d->survivors : 1);
         d->d_ws = nla_dev_malloc(nla_isres_evolve2_ws_bytes(d->n));
         if (!d->d_ws || (d->d_rho && nla_memset(d->d_rho, 0, sizeof(double) * 4, d->st))) ok = 0;
     }
@@ -384,7 +385,11 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
     }
     d->spec_valid = 0;
     *t_rng += nla_seconds() - t0;
-    if (d->parallel_evolve) DCK(d, nla_k_isres_inverse(d->pop, d->d_irank, d->d_inv, d->st));
+    if (d->parallel_evolve) {
+        DCK(d, nla_k_isres_inverse(d->pop, d->d_irank, d->d_inv, d->st));
+        /* what the mutation phase's rounds predict the children's starts with (the parents' rows do not change during that phase) */
+        DCK(d, nla_k_isres_evolve_parent_mu(d->n, d->ld, d->survivors, d->d_lb, d->d_ub, d->d_irank, d->d_X, d->d_S, d->d_mu, d->st));
+    }
     for (phase = 0; phase < 2; ++phase) {
         const int64_t kend = phase == 0 ? d->pop : d->survivors;
         state[0] = phase == 0 ? d->survivors : 0;
@@ -395,12 +400,15 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
         DCK(d, nla_stream_sync(d->st));
         for (;;) {
             if (d->parallel_evolve) {
-                /* a round resolves up to 256 individuals (fewer when the predicted windows are left): enqueue several, then look */
+                /* a round resolves up to 256 individuals (fewer when the predicted windows are left or a variation individual depends on an
+                 * earlier one of its block: 247 / 188 per round measured at config 3): enqueue what the phase should need, then look.  Every
+                 * look is a stream synchronisation, a copy of the state and a cold start of the next batch — some 50 us, and round 4's
+                 * batches of at most 24 rounds made ~28 of them per generation; a round enqueued in vain costs its launches (~10 us) */
                 const int64_t left = kend - state[0];
-                int rounds = (int) (left / 96) + 1;
-                if (rounds > 24) rounds = 24;
+                int rounds = (int) (left / (phase == 0 ? 230 : 170)) + 2;
+                if (rounds > 72) rounds = 72;
                 DCK(d, nla_k_isres_evolve_rounds(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z,
-                                                 d->d_irank, d->d_inv, d->d_X, d->d_S, d->d_scratch, d->d_state, d->d_rho, d->d_ws, rounds, d->st));
+                                                 d->d_irank, d->d_inv, d->d_X, d->d_S, d->d_scratch, d->d_state, d->d_rho, d->d_ws, d->d_mu, rounds, d->st));
                 d->ev_rounds += (uint64_t) rounds;
                 if (d->overlap && !reserved) {
                     /* beside the rounds: the segment states behind the NEXT ranking's words (those of this phase's deviates generated
@@ -530,8 +538,8 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
     D.n = n; D.ld = (n + 1) & ~1; D.m = m; D.p = p; D.pop = population; D.dev_eval = dev_eval;
     D.comm = opt ? opt->comm : NULL;
     D.evolve_serial = opt ? nlopt_get_param(opt, "amd_isres_evolve_serial", 0) != 0 : 0;
-    D.gated = opt ? nlopt_get_param(opt, "amd_isres_gated", 1) != 0 : 1;
-    D.gen_waves_per_cu = opt ? (int) nlopt_get_param(opt, "amd_isres_gen_waves", 8) : 8;
+    D.gated = 1;                     /* (A/B switches in round 5, profiles/r05_isres_steps.txt: gated 49.5 ms per generation, not gated 55.3) */
+    D.gen_waves_per_cu = 8;
     D.overlap = opt ? nlopt_get_param(opt, "amd_isres_overlap", 1) != 0 : 1;            /* 0: the one-stream generation */
     D.overlap = nla_dbg_int("NLA_ISRES_OVERLAP", D.overlap) > 0;     /* A/B switch for the bench */
     D.survivors = (int64_t) ceil(population * SURVIVOR);                               /* :93 */

@@ -177,7 +177,7 @@ static int grow_lms(mlsl_dev *d, size_t need)
 
 /* The distance scratch grows with the point set — N x npts doubles per sampling phase, npts larger by N every iteration — and it used
  * to be reallocated to the exact size EVERY iteration: a hipFree (which waits for every stream of the device: the generator's, when it
- * works ahead on a stream of its own — why "amd_mlsl_prefetch" never overlapped anything, profiles/r04_mlsl_prefetch_timeline.txt) and
+ * works ahead on a stream of its own — why round 4's sample prefetch never overlapped anything, profiles/r04_mlsl_prefetch_timeline.txt) and
  * a hipMalloc of tens of MB between the sampling kernel and the distance pass.  Now it doubles: a handful of reallocations per run. */
 static int need_D(mlsl_dev *d, size_t doubles)
 {
@@ -318,7 +318,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
      * = a host synchronisation of that stream before the sampling kernel reads them. */
     D.prefetch = !host;
     D.prefetched_at = ~0ULL;
-    D.rs = (D.st && D.prefetch) ? nla_stream_create() : D.st;
+    D.rs = (D.st && D.prefetch) ? nla_stream_create_background() : D.st;
     {
         /* "amd_mlsl_seg_regens": the segment length of this run's stream (NLA_MT_SEG_REGENS = 1024 is the layout every other algorithm
          * uses) — 64 makes 205 wavefronts of the 13 above; measured at config 4 (MI355X, round 5): 15.9 ms per iteration at 1024, 14.7 at
@@ -405,6 +405,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         if (all == 0) { nla_stop_msg(stop, "nlopt_amd: another rank could not set up its MLSL device state"); ret = NLOPT_FAILURE; goto done; }
     }
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
+#define PREFETCH_NOW() do { if (prefetch_due) { prefetch_due = 0; \
+        if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); } \
+        D.prefetched_at = D.words_used; } } while (0)
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
     /* several ranks: the clock and the force_stop flag are decided by all ranks together at the start of every phase (comm.c);
      * sp is what those two tests look at until the next agreement */
@@ -434,7 +437,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     while (ret == NLOPT_SUCCESS) {
         double R, t0 = nla_seconds();
         size_t old = D.npts, used = 0, idx;
-        int remaining;
+        int remaining, prefetch_due = 0;
         GET_MINF();                                                            /* mlsl.c:347 */
         AGREE();
         if (opt && opt->progress) { opt->progress(opt->progress_data, st ? (long) st->generations : 0, (long) *stop->nevals_p); t0 = nla_seconds(); }
@@ -472,11 +475,12 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         else D.words_used += 2ULL * (uint64_t) n * (uint64_t) used;
         if (host && (nla_memcpy_h2d(D.d_F + old, Fnew, sizeof(double) * used, D.st) || nla_stream_sync(D.st))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         if (ret != NLOPT_SUCCESS) break;
-        if (D.prefetch && !D.d_V) {
-            /* the sampling kernel has read the words (synchronised above): the next iteration's, beside everything that follows */
-            if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); }
-            D.prefetched_at = D.words_used;
-        }
+        /* the sampling kernel has read the words (synchronised above): the next iteration's can be generated.  NOT here (round 5,
+         * profiles/r05_mlsl_timeline.txt): enqueued now, the jump-ahead kernel — 33 k workgroups, 0.55 ms, once or twice per iteration —
+         * and the generator had the device to themselves and the distance pass queued up behind them, 0.9-1.8 ms of every iteration.
+         * They go out right in front of the local searches' launch instead (PREFETCH_NOW below), on a background-priority stream: the
+         * searches' 300 workgroups leave most of every compute unit free for 6 ms */
+        prefetch_due = D.prefetch && !D.d_V;
         {
             const int na = D.N, nb = (int) D.npts;
             if (need_D(&D, (size_t) na * (size_t) nb)) DEVFAIL();
@@ -566,6 +570,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                     res[0].nevals = 0; res[0].iterm = 0;                            /* the calls were counted one by one (mlsl_counted_f) */
                 }
             } else {
+            PREFETCH_NOW();
             if (mine > 0 && nla_local_ctx_run(D.lb, mine, &prm, res_mine, &lstop, NULL)) { snprintf(D.err, sizeof D.err, "local-search batch failed"); DEVFAIL(); }
             if (nla_comm_allgather_dev(D.comm, nla_local_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st) ||
                 nla_comm_allgather_host(D.comm, res_mine, res, sizeof *res * (size_t) per, D.st)) {
@@ -678,6 +683,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 idx = scan;
             }
         }
+        PREFETCH_NOW();                                                        /* (an iteration without a local search) */
         if (st) { st->t_evolve_s += nla_seconds() - t0; ++st->generations; }
     }
     GET_MINF();                                                                /* mlsl.c:431 */

@@ -582,6 +582,11 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
     if (!xo) return EMU_ERR;
     if (state[14] > 0 && state[14] < kend) kend = state[14];
     if (phase == 1 && k == 0) memcpy(scratch, X, sizeof(double) * (size_t) n);           /* memcpy(x0, xs, n), isres.c:253 */
+    /* NLA_EMU_EVOLVE_DUMP=<file> (analysis, tools/evolve_predict.py): per individual of the mutation phase the deviates it consumed and
+     * the analytic expectation of its redraws from the parent's x and sigma — what a start predictor could know in advance */
+    static FILE *dump = NULL;
+    static int dump_checked = 0;
+    if (!dump_checked) { const char *pth = getenv("NLA_EMU_EVOLVE_DUMP"); dump_checked = 1; if (pth) dump = fopen(pth, "ab"); }
     for (; k < kend; ++k) {
         const int64_t rk = irank[k], ri = phase == 0 ? irank[k % survivors] : rk;
         const int lastsurv = (k + 1 == survivors);
@@ -618,6 +623,17 @@ int nla_k_isres_evolve(int n, int ld, int phase, int64_t pop, int64_t survivors,
             xo[j] = xnew; so[j] = snew;
         }
         if (ranout) break;
+        if (dump && phase == 0) {
+            double rec[4] = { (double) k, (double) (cur - pos), 0., 0. };
+            for (int j = 0; j < n; ++j) {            /* P(out of the box) with sigma' ~ sigma, and with sigma' = sigma exp(taup_rand) (known once the first deviate is) */
+                const double s0 = si[j] > 0 ? si[j] : 1e-300, s1 = s0 * exp(taup_rand);
+                const double p0 = 0.5 * erfc((xi[j] - lb[j]) / (s0 * 1.4142135623730951)) + 0.5 * erfc((ub[j] - xi[j]) / (s0 * 1.4142135623730951));
+                const double p1 = 0.5 * erfc((xi[j] - lb[j]) / (s1 * 1.4142135623730951)) + 0.5 * erfc((ub[j] - xi[j]) / (s1 * 1.4142135623730951));
+                rec[2] += p0 / (1. - p0); rec[3] += p1 / (1. - p1);
+            }
+            fwrite(rec, sizeof rec, 1, dump);
+            if (k + 1 == kend) fflush(dump);
+        }
         memcpy(X + (size_t) rk * ld, xo, sizeof(double) * (size_t) n);
         memcpy(S + (size_t) rk * ld, so, sizeof(double) * (size_t) n);
         pos = cur;
@@ -636,11 +652,11 @@ size_t nla_isres_evolve2_ws_bytes(int n) { (void) n; return 16; }
 static int emu_forced_handover(int64_t k, int phase) { return (((uint32_t) k * 2654435761u + (uint32_t) phase * 977u) >> 7) % 53u == 0; }
 int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t survivors, int64_t zcount, double taup, double tau,
                               const double *lb, const double *ub, const double *z, const int32_t *irank, const int32_t *inv, double *X,
-                              double *S, const double *x0c, int64_t *state, double *rho, void *ws, int rounds, void *st)
+                              double *S, const double *x0c, int64_t *state, double *rho, void *ws, const double *mu_rp, int rounds, void *st)
 {
     EMU_LAUNCH();
     const int64_t kend = phase == 0 ? pop : survivors;
-    (void) inv; (void) rho; (void) ws;
+    (void) inv; (void) rho; (void) ws; (void) mu_rp;
     for (int r = 0; r < rounds; ++r) {
         int64_t first = state[0], limit, stop = first + 256 < kend ? first + 256 : kend;
         int rc;
@@ -654,6 +670,15 @@ int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, int64_t sur
         if (rc) return rc;
         state[9] = state[0] - first;
     }
+    return 0;
+}
+
+int nla_k_isres_evolve_parent_mu(int n, int ld, int64_t survivors, const double *lb, const double *ub, const int32_t *irank, const double *X,
+                                 const double *S, double *mu_rp, void *st)
+{
+    EMU_LAUNCH();            /* (a prediction aid of the device's look-up rounds: nothing here depends on it) */
+    (void) n; (void) ld; (void) lb; (void) ub; (void) irank; (void) X; (void) S; (void) st;
+    for (int64_t p = 0; p < survivors; ++p) mu_rp[p] = 0.;
     return 0;
 }
 
@@ -813,15 +838,11 @@ int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double 
 int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                          const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *W,
                          const double *Wf, int nW, int w_on_host, int slot_mask, const double *lb, const double *ub, double *TX, double *TM, void *ctrl,
-                         uint32_t ticket_base, nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
-                         uint32_t *bell_count, uint32_t *bell, uint32_t bell_seq, void *st)
+                         uint32_t ticket_base, nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *st)
 {
-    /* (the synchronous device: the window is complete when the call returns, so the bell has rung) */
-    const int rc = nla_k_crs_chain(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host,
-                                   slot_mask, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, st);
-    (void) ctrl_is_zero; (void) bell_count;
-    if (!rc && bell) __atomic_store_n(bell, bell_seq, __ATOMIC_RELEASE);
-    return rc;
+    (void) ctrl_is_zero;
+    return nla_k_crs_chain(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host,
+                           slot_mask, lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, st);
 }
 uint32_t nla_crs_chain_tickets(int n, int ld, int K) { return (uint32_t) nla_crs_chain_chunks(n, ld) * (uint32_t) K + 1u; }
 int nla_k_crs_finish(int obj, int n, int ld, const double *X, int64_t i0, const double *TX, double *TM, const uint32_t *words_ring,

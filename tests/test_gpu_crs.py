@@ -126,16 +126,6 @@ def test_speculation_depth_does_not_change_the_sequence():
     assert base["stats"]["slots_launched"] == base["stats"]["slots_used"]     # depth 1 never wastes a slot
 
 
-@pytest.mark.parametrize("params", [{"amd_doorbell": 0}, {"amd_fuse_commit": 0}, {"amd_doorbell": 0, "amd_fuse_commit": 0}], ids=["no_doorbell", "commit_launch", "neither"])
-def test_pass_plumbing_switches_do_not_change_the_sequence(params):
-    """how a conservative pass ends (the finish kernel's doorbell in pinned memory or a stream synchronisation) and how the staged commits
-    reach the population (inside the advance launch or in a launch of their own) are plumbing: same trials, same f, same result"""
-    a = run_amd("rastrigin", 64, 2000, 42, maxeval=9000, trace_cap=20000)
-    b = run_amd("rastrigin", 64, 2000, 42, maxeval=9000, trace_cap=20000, params=params)
-    assert np.array_equal(a["trace"]["row"], b["trace"]["row"]) and np.array_equal(a["trace"]["f"], b["trace"]["f"])
-    assert np.array_equal(a["x"], b["x"]) and a["minf"] == b["minf"] and a["nevals"] == b["nevals"]
-
-
 def test_rng_continues_where_the_reference_would():
     """after nlopt_optimize the thread's generator must stand where the serial reference's stands"""
     P, L = O.port(), nlopt_amd.lib()

@@ -7,7 +7,10 @@ so that the kernel's three regimes are timed apart:
   reject    nothing is accepted (Wf = -huge): a pick of W[j] waits until every block before the slot is resolved
 run on the GPU box:  python tools/chain_latency.py [n] [N]"""
 import ctypes as C
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 
@@ -63,7 +66,7 @@ L.nla_event_sync.argtypes = [C.c_void_p]
 ticket = 0
 bytes_per_trial = 8.0 * n * (n + 1) + 8.0 * n * 4          # the gather + the evaluation's passes over the point
 print("n = %d, N = %d, %d chunks per slot, %.1f MB per trial" % (n, N, chunks, bytes_per_trial / 1e6))
-for K in (8, 24, 48, 96, 192):
+for K in ((8, 24, 48, 96, 192) if n >= 2048 else (32, 64, 128, 256)):
     for mode in ("free", "accept", "reject"):
         nW = 0 if mode == "free" else min(K, 256)
         W = rng.choice(N - 2, max(nW, 1), replace=False).astype(np.int64) + 8
@@ -78,7 +81,7 @@ for K in (8, 24, 48, 96, 192):
             assert rc == 0, rc
             L.nla_event_record(e1, None)
             L.nla_event_sync(e1)
-            ticket = (ticket + K * chunks) & 0xffffffff
+            ticket = (ticket + L.nla_crs_chain_tickets(n, ld, K)) & 0xffffffff
             ms = L.nla_event_elapsed_ms(e0, e1)
             best = min(best, ms)
         cnt = dcnt.to_array(np.uint32, K)

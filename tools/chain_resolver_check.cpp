@@ -49,6 +49,7 @@ CH_DEV uint64_t ch_exchange(uint64_t v, uint32_t from)
     return r;
 }
 CH_DEV uint64_t ch_readlane_u64(uint64_t v, uint32_t l) { return ch_exchange(v, l); }
+CH_DEV uint64_t ch_shuffle_u64(uint64_t v, uint32_t src) { return ch_exchange(v, src); }     /* (ds_bpermute: each lane names its own source) */
 CH_DEV uint64_t ch_ballot(bool p)
 {
     uint64_t *b = emu::xch[emu::which];
