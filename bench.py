@@ -785,7 +785,7 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                           "avg_launch_ms": d["t_stochrank_ms"] / d["stochrank_launches"],
                           "serial_ticks_per_launch": ticks / d["stochrank_launches"],
                           "achieved": t_sr * 1e9 / ticks if ticks else None, "unit": "ns per serial tick",
-                          "model": "ticks = pop + 2*sweeps + 63*ceil(sweeps/64); one tick = one DPP lane shift + compare-exchange of the "
+                          "model": "ticks = pop + 2*sweeps + 63*ceil(sweeps/64) (782 units of 64 sweeps in a row; the units hand over through the elements themselves); one tick = one DPP lane shift + compare-exchange of the "
                                    "packed element on a wavefront that is alone on its SIMD (26 VALU/DPP instructions, isres_kernels.hip)",
                           "peak": 26 * 4 / 2.4, "peak_note": "26 instructions x 4 cycles each (wave64 on a 16-lane SIMD) at 2.4 GHz = 43 ns: the floor of this formulation",
                           "frac": (26 * 4 / 2.4) / (t_sr * 1e9 / ticks) if ticks and t_sr > 0 else None,

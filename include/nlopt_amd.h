@@ -388,6 +388,7 @@ int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_
  * stages.  streams: (ceil(nsweeps/64)+1) x pop u64, streams[0..pop) = the packed elements in
  * initial order; progress: one int per stream (progress[0] = pop, others 0); *ticket = 0.
  * Out: swapped[i] = sweep i exchanged something; irank[pos] = individual. */
+int nla_isres_stochrank_handoff(void);      /* elements a pipeline unit hands on at a time (ticks of a launch: pop + 2 sweeps + (handoff - 1) units) */
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                           int *ticket, uint8_t *swapped, int32_t *irank, void *stream);
 /* the same with the rows of `bits` still being produced by nla_k_mt_rankbits_gated on another stream: unit u (sweeps 64u .. 64u+63) waits

@@ -212,14 +212,20 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
     ev2_scan_body<false>(A, (int) blockIdx.x, sm);
 }
 
-/* One workgroup of 1024: all of it copies the E table into LDS (16 bytes per thread and step, everything in flight at once); wavefront 0
- * then walks the block.  The walk is one dependent chain — start of individual i -> its E entry -> start of i + 1 — and a lone wavefront
- * issues one instruction every four cycles, so what counts is the number of instructions per individual and that no memory latency sits
- * between them.  It runs on the SCALAR unit out of registers: the per-individual inputs (mutated-coordinate count; window origin relative
- * to the block's first deviate, pushed out of every window when the individual is past the end or variation's dependency forbids it) sit
- * in the lanes of four registers and come out with v_readlane; the individual's E row (256 entries = 8 bytes per lane) is fetched from
- * LDS four individuals AHEAD and the one entry the chain needs comes out with v_readlane too; the exact starts go into a lane of a
- * register and leave in one parallel store; the sums for rho are formed after the walk from the same registers. */
+/* ---- chain ------------------------------------------------------------------------------------------------------- */
+/* start_0 is exact; start_{i+1} = start_i + E[i][start_i - base_i].  Rounds 3-4 walked that chain through the block with one wavefront
+ * (256 dependent look-ups: 33-39 us of a ~125 us round, the E table copied into LDS first).  But a look-up table composes: the
+ * deviates the SEGMENT of individuals 16 s .. 16 s + 15 consumes is a function of the start of its first individual alone, and that
+ * function can be tabulated for every candidate start by independent lanes.  Round 5:
+ *   A  (all 1024 threads)  for each of the 16 segments and each of the 256 candidate starts d of its first individual: walk the
+ *      segment's 16 individuals through E (LDS) and store the deviates consumed, G[s][d], or "left a window / an entry says no";
+ *   B  (one thread)        16 look-ups in G from the block's exact first start: the exact start of every segment, up to the first
+ *      segment that cannot be crossed whole;
+ *   C  (one thread per segment, all at once)  the segment's 16 individuals again from its now exact start, recording the individual
+ *      starts — the segment that could not be crossed is walked until it stops, which gives the round's count and why it ended.
+ * The same look-ups in the same tables as the serial walk, hence the same starts: 16 + 16 + 16 dependent steps instead of 256. */
+#define EV2_SEG 16                     /* individuals per segment; EVM / EV2_SEG segments */
+#define EV2_NSEG (EVM / EV2_SEG)
 __device__ __forceinline__ long long ev2_uniform64(long long v)
 {
     const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v & 0xffffffffll));
@@ -229,8 +235,12 @@ __device__ __forceinline__ long long ev2_uniform64(long long v)
 
 __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
 {
-    extern __shared__ int16_t sE[];                            /* EVM x EVD */
-    const int tid = threadIdx.x;
+    extern __shared__ int16_t sE[];                            /* EVM x EVD, then G: EV2_NSEG x EVD ints */
+    __shared__ int s_b[EVM], s_st[EVM], s_segpos[EV2_NSEG + 1], s_cnt[EV2_NSEG], s_why[EV2_NSEG], s_nfull;
+    __shared__ long long s_asum[16];
+    __shared__ double s_msum[16];
+    int *G = reinterpret_cast<int *>(sE + (size_t) EVM * EVD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t st0 = A.state[0], st1 = A.state[1], st2 = A.state[2], st10 = A.state[10], st11 = A.state[11];
     const double rho_r = A.rho[2 * A.phase], rho_a = A.rho[2 * A.phase + 1];
     if (st2 || st10) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing: its write kernel idles */
@@ -242,68 +252,88 @@ __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
 #pragma unroll
         for (int q = 0; q < EVM * EVD / 8 / 1024; ++q) dst[q * 1024 + tid] = src[q * 1024 + tid];
     }
-    static_assert(EVM == 256 && EVD == 256 && (EVM * EVD / 8) % 1024 == 0, "the chain kernel holds the block in four registers per lane, a row in 8 bytes per lane");
+    static_assert(EVM == 256 && EVD == 256 && (EVM * EVD / 8) % 1024 == 0 && EV2_NSEG * EVD % 1024 == 0, "block shape");
     const long long pos0 = ev2_uniform64(st1);
     const int OUT = 0x40000000;                                /* a window origin no start of this block can be within EVD of */
-    int na_v[4], b_v[4], st_v[4];
-    double mu_v[4];
-    if (tid < 64) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int q = c * 64 + tid;
-            na_v[c] = A.ws_nact[q]; st_v[c] = 0; mu_v[c] = A.ws_mu[q];
-            const long long brel = A.ws_base[q] - pos0;
-            /* the row isres.c:260 reads (physical row k + 1) must not be rewritten inside this block before k: the walk ends at a
-             * survivor k whose row k + 1 belongs to an earlier survivor of the block (straight-line: the index is clamped, not guarded) */
-            const long long k = k0 + q, k1 = k + 1 < A.pop ? k + 1 : A.pop - 1;
-            const long long o = A.inv[k1];
-            const bool dep = A.phase == 1 && k + 1 < A.pop && o >= k0 && o < k;
-            const bool stop = na_v[c] < 0 || dep || brel >= OUT || brel <= -OUT;
-            b_v[c] = stop ? OUT : (int) brel;
-        }
+    int na_i = 0;
+    double mu_i = 0;
+    if (tid < EVM) {
+        const int q = tid;
+        na_i = A.ws_nact[q]; mu_i = A.ws_mu[q];
+        const long long brel = A.ws_base[q] - pos0;
+        /* the row isres.c:260 reads (physical row k + 1) must not be rewritten inside this block before k: the walk ends at a
+         * survivor k whose row k + 1 belongs to an earlier survivor of the block (straight-line: the index is clamped, not guarded) */
+        const long long k = k0 + q, k1 = k + 1 < A.pop ? k + 1 : A.pop - 1;
+        const long long o = A.inv[k1];
+        const bool dep = A.phase == 1 && k + 1 < A.pop && o >= k0 && o < k;
+        const bool stop = na_i < 0 || dep || brel >= OUT || brel <= -OUT;
+        s_b[q] = stop ? OUT : (int) brel;
     }
     __syncthreads();
-    if (tid >= 64) return;
-    const uint2 *rows = reinterpret_cast<const uint2 *>(sE);   /* row i: entries 4 lane .. 4 lane + 3 in rows[i * 64 + lane] */
-    int pos = 0, r = 0, elast = 0;                             /* pos: relative to pos0 (at most 256 x 32767) */
-    uint2 nx[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) nx[u] = rows[u * 64 + tid];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    /* one step of the chain for individual i from position pos (relative to pos0): the entry, or why there is none:
+     * -10 the start left the window, -11 the individual stops every walk (end of the phase / variation's dependency), -1 / -2 the scan's */
+    auto step = [&](int i, int pos) -> int {
+        const unsigned d = (unsigned) (pos - s_b[i]);
+        if (d >= (unsigned) EVD) return d >= 0xc0000000u && d < 0xd0000000u ? -11 : -10;
+        return (int) sE[(size_t) i * EVD + d];
+    };
+    /* A: the segments' tables */
 #pragma unroll 1
-        for (int g = 0; g < 16; ++g) {
-            uint2 cu[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cu[u] = nx[u];
-            const int inext = c * 64 + g * 4 + 4 < EVM ? c * 64 + g * 4 + 4 : EVM - 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) nx[u] = rows[(inext + u) * 64 + tid];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int l = g * 4 + u;
-                const unsigned d = (unsigned) (pos - __builtin_amdgcn_readlane(b_v[c], l));
-                if (d >= (unsigned) EVD) { elast = d >= 0xc0000000u && d < 0xd0000000u ? -11 : -10; goto done; }
-                const int wx = __builtin_amdgcn_readlane((int) cu[u].x, (int) (d >> 2)), wy = __builtin_amdgcn_readlane((int) cu[u].y, (int) (d >> 2));
-                const int w = (d & 2u) ? wy : wx;
-                const int e = (int) (int16_t) (w >> ((d & 1u) << 4));
-                if (e < 0) { elast = e; goto done; }
-                if (tid == l) st_v[c] = pos;
-                pos += e;
-                ++r;
-            }
+    for (int t = tid; t < EV2_NSEG * EVD; t += 1024) {
+        const int sg = t / EVD, d = t % EVD, i0 = sg * EV2_SEG;
+        int pos = s_b[i0] == OUT ? 0 : s_b[i0] + d, ok = s_b[i0] != OUT;
+        const int p0 = pos;
+        for (int j = 0; ok && j < EV2_SEG; ++j) {
+            const int e = step(i0 + j, pos);
+            if (e < 0) ok = 0; else pos += e;
         }
+        G[t] = ok ? pos - p0 : -1;
     }
-done:
+    __syncthreads();
+    /* B: the exact start of every segment that can be reached by crossing whole segments */
+    if (tid == 0) {
+        int pos = 0, nf = 0;
+        s_segpos[0] = 0;
+        for (; nf < EV2_NSEG; ++nf) {
+            const unsigned d = (unsigned) (pos - s_b[nf * EV2_SEG]);
+            if (d >= (unsigned) EVD) break;
+            const int g = G[nf * EVD + (int) d];
+            if (g < 0) break;
+            pos += g;
+            s_segpos[nf + 1] = pos;
+        }
+        s_nfull = nf;
+    }
+    __syncthreads();
+    /* C: the individual starts, segment by segment in parallel (lane 0 of wavefront s: every walker on a SIMD's issue slot of its own
+     * as far as the 16 wavefronts go) */
+    const int nfull = s_nfull;
+    if (lane == 0 && wave < EV2_NSEG && wave <= nfull) {
+        const int i0 = wave * EV2_SEG;
+        int pos = s_segpos[wave], c = 0, why = 0;
+        for (; c < EV2_SEG; ++c) {
+            const int e = step(i0 + c, pos);
+            if (e < 0) { why = e; break; }
+            s_st[i0 + c] = pos;
+            pos += e;
+        }
+        s_cnt[wave] = c; s_why[wave] = why;
+        if (wave == nfull) s_segpos[EV2_NSEG] = pos;           /* where the round's walk ended (the segment that stopped it) */
+    }
+    __syncthreads();
+    const int r = nfull < EV2_NSEG ? nfull * EV2_SEG + s_cnt[nfull] : EVM;
+    const int elast = nfull < EV2_NSEG ? s_why[nfull] : 0;
+    const int pos = nfull < EV2_NSEG ? s_segpos[EV2_NSEG] : s_segpos[EV2_NSEG];     /* (a full block: B stored the end in s_segpos[EV2_NSEG] too) */
     long long asum = 0;
     double msum = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (c * 64 + tid < r) { A.ws_start[c * 64 + tid] = pos0 + st_v[c]; asum += na_v[c]; msum += mu_v[c]; }
-    }
+    if (tid < r) { A.ws_start[tid] = pos0 + s_st[tid]; asum = na_i; msum = mu_i; }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { asum += __shfl_xor(asum, m, 64); msum += __shfl_xor(msum, m, 64); }
+    if (lane == 0) { s_asum[wave] = asum; s_msum[wave] = msum; }
+    __syncthreads();
     if (tid != 0) return;
+    asum = s_asum[0] + s_asum[1] + s_asum[2] + s_asum[3];
+    msum = (s_msum[0] + s_msum[1]) + (s_msum[2] + s_msum[3]);
     const long long rsum = (long long) pos - r - 2 * asum;     /* = sum over the resolved of (consumed - 1 - 2 mutated) = their redraws */
     A.state[12] = k0;
     A.state[0] = k0 + r;
@@ -314,7 +344,6 @@ done:
     else if (r == 0) A.state[10] = 1;                           /* not even the exactly-started first individual resolved: serial fallback */
 #ifdef NLA_EV2_REASONS                                          /* development build (NLOPT_AMD_VARIANT="reasons:-DNLA_EV2_REASONS"): what ended the walks; isres_driver.c prints it per phase */
     A.state[3] += elast == -10; A.state[4] += elast == -11; A.state[5] += elast == -1; A.state[6] += elast == 0; A.state[7] += r;
-    { long long a2 = 0; for (int i = 0; i < r; ++i) a2 += A.ws_nact[i]; A.state[13] += a2 != asum; A.state[15] += a2 - asum; }
 #endif
     A.rho[2 * A.phase] = 0.9 * rho_r + (double) rsum;
     A.rho[2 * A.phase + 1] = 0.9 * rho_a + msum;
@@ -507,14 +536,14 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
     B.ws_start = (int64_t *) take(sizeof(int64_t) * EVM);
     const size_t lds_scan = sizeof(double) * (size_t) (5 * n + EV2_ZW(n));
     const size_t lds_write = sizeof(double) * (size_t) (7 * n + EV2_ZW(n));
-    const size_t lds_chain = sizeof(int16_t) * EVM * EVD;
+    const size_t lds_chain = sizeof(int16_t) * EVM * EVD + sizeof(int) * EV2_NSEG * EVD;
     static bool attr_set = false;
     if (!attr_set) {
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         (void) hipGetLastError();
         attr_set = true;
     }

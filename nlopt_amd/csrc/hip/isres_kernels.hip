@@ -684,6 +684,8 @@ extern "C" int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nr
 extern "C" int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                                            int *ticket, uint8_t *swapped, int32_t *irank, const int *gate, uint64_t gate_g_rank0, int64_t gate_nrows,
                                            void *stream);
+/* elements a unit of the pipeline hands on at a time: a launch makes pop + 2 sweeps + (this - 1) units serial ticks */
+extern "C" int nla_isres_stochrank_handoff(void) { return 64; }
 extern "C" int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits,
                                      int *ticket, uint8_t *swapped, int32_t *irank, void *stream)
 {
@@ -699,6 +701,9 @@ extern "C" int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_
     const int64_t units = (nsweeps + 63) / 64;
     const int64_t rowwords = (pop - 1 + 63) / 64;
     if (units > 0 && pop > 1) {
+        /* the units hand over through the elements themselves (hip/isres_stochrank.h): every buffer between two units starts out unwritten */
+        hipError_t e = hipMemsetAsync(streams + (size_t) pop, 0xFF, sizeof(uint64_t) * (size_t) units * (size_t) pop, st);
+        if (e != hipSuccess) return (int) e;
         hipLaunchKernelGGL(isres_stochrank_kernel, dim3((unsigned) units), dim3(64), 0, st, pop, nsweeps, streams, progress, bits, rowwords, ticket,
                            swapped, gate, gate_g_rank0, gate_nrows);
         NLA_LAUNCH_CHECK();

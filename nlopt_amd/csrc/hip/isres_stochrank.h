@@ -22,6 +22,10 @@
 #ifndef SR_CLOCK
 #define SR_CLOCK() ((uint64_t) wall_clock64())       /* 100 MHz */
 #endif
+#ifndef SR_ANY                           /* does any lane of the wavefront say so? */
+#define SR_ANY(p) (__ballot(p) != 0ull)
+#endif
+#define SR_UNWRITTEN 0xFFFFFFFFFFFFFFFFull    /* no element looks like this (bits 28-30 of the high word are never set: isres_pack, SR_PINF_HI) */
 #define SR_GATE_TIMEOUT 400000000ull    /* 4 s without the block's bits arriving: the generator's launch failed or never ran */
 
 #define SR_DPP_SHL1 0x130               /* wave_shl:1 — lane i reads lane i+1 */
@@ -51,7 +55,7 @@ SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__
     const bool active = stage < nsweeps;
     const uint64_t *in = streams + (size_t) unit * (size_t) pop;
     uint64_t *out = streams + (size_t) (unit + 1) * (size_t) pop;
-    int *prog_in = progress + unit, *prog_out = progress + unit + 1;
+    (void) progress;                            /* (the counter protocol of rounds 2-4; the parameter stays in the launcher's signature) */
     const uint64_t *brow = bits + (size_t) (active ? stage : 0) * (size_t) rowwords;
     const int ipop = (int) pop, rw1 = (int) rowwords - 1;
     const int half = lane >> 5;                 /* row word of the window of block b starts at word b - 1 - half */
@@ -90,53 +94,72 @@ SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    /* HAND-OVER THROUGH THE ELEMENTS (round 5).  Rounds 2-4 passed a block of 64 elements from unit to unit behind a progress counter:
+     * every block of a unit began with two dependent round trips to memory (lane 0 polls the upstream counter, then the lanes load
+     * their inputs) and ended with a third (the output stores must have landed before the unit's own counter moves) — 2.8 us of stalls
+     * around 2.9 us of ticks, on every block of every unit (measured by varying the block length: 64 elements 5.7 us per block, 32: 3.9,
+     * 16: 3.1, 8: 3.0; profiles/r05_isres_handoff.txt).  Now the buffers between the units start out as SR_UNWRITTEN (the launcher
+     * fills them), a producer just stores its 64 outputs — each a single 64-bit store, so an element is either there or not — and a
+     * consumer loads its next block's 64 inputs HALF A BLOCK AHEAD and looks at them when it gets there: all written -> go; otherwise
+     * load again until they are.  Nobody waits for a store, and the load on a unit's path has had 32 ticks to land.  A consumer that runs
+     * too close behind its producer misses, waits a round trip, and from then on runs that much later — at the same rate.  Config 3:
+     * 20.3 -> 14.7 ms per launch in the same source (17.7 ms with round 4's kernel), generation 46.3 -> 40.6 ms.
+     * (The first load is issued BEFORE the row words below: at the top of the block loop the compiler's wait for this register is the
+     * stricter of "as left by the code in front of the loop" and "as left by the previous block".) */
+    const uint64_t pinf = ((uint64_t) SR_PINF_HI << 32) | SR_PINF_LO;
+    uint64_t nxt = lane < ipop ? sr_ld(in + lane) : pinf;
     uint64_t wa = brow[clampw(-1 - half)], wb = brow[clampw(0 - half)], wp = brow[clampw(1 - half)];
     const int nblk = (ipop + 63) / 64 + 2;      /* the last output leaves lane 63 at tick pop + 126 */
     for (int b = 0; b < nblk; ++b) {
         const int tb = b * 64;
         /* u < PF bits of ticks tb .. tb+63 of this stage: row bits tb - 2 lane - 1 + k */
         const uint64_t win = (wa >> cut) | (wb << (64 - cut));
+        const uint32_t wlo = (uint32_t) win, whi = (uint32_t) (win >> 32);
         wa = wb; wb = wp;
-        wp = brow[clampw(b + 2 - half)];        /* (used two blocks from now: the load has a whole block to land) */
-        /* the unit's next 64 inputs; past the end of the stream: +inf */
-        uint64_t inb = ((uint64_t) SR_PINF_HI << 32) | SR_PINF_LO;
+        /* the block's 64 inputs, one per lane (lane 0 consumes one per tick, the rest move down); past the end of the stream: +inf */
+        uint64_t inb = pinf;
         if (tb < ipop) {
-            const int need = tb + 64 < ipop ? tb + 64 : ipop;
-            if (lane == 0) while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (tb + lane < ipop) inb = sr_ld(in + tb + lane);
+            const bool inr = tb + lane < ipop;
+            inb = nxt;
+            /* (the first look is at the load issued half a block ago and stands outside the retry loop: a loop header would wait for
+             * every outstanding memory operation before each look) */
+            if (SR_ANY(inr && inb == SR_UNWRITTEN)) {
+                do {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (inr) inb = sr_ld(in + tb + lane);
+                } while (SR_ANY(inr && inb == SR_UNWRITTEN));
+            }
+            if (!inr) inb = pinf;
         }
         vin_lo = (uint32_t) inb; vin_hi = (uint32_t) (inb >> 32);
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t wcur = h ? (uint32_t) (win >> 32) : (uint32_t) win;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                /* input: lane 0 from the unit's input block, the others from their left neighbour's output of the previous tick */
-                const uint32_t x_lo = sr_dpp(vin_lo, o_lo, 0), x_hi = sr_dpp(vin_hi, o_hi, 0);
-                vin_lo = sr_dpp(vin_lo, vin_lo, 1); vin_hi = sr_dpp(vin_hi, vin_hi, 1);
-                /* by fval if u < PF (bit k of the window: isres.c:210) or both penalties are zero (bit 31 of both high words),
-                 * else by penalty (:211-212, :220) — sign bits instead of booleans: the tick stays straight-line integer code */
-                const uint32_t usef = (wcur << (31 - k)) | (c_hi & x_hi);
-                const int32_t df = (int32_t) (x_lo >> 12) - (int32_t) (c_lo >> 12);                    /* < 0: fval[carry] > fval[x]   (:213) */
-                const int32_t dp = (int32_t) (x_hi & 0x0FFFFF00u) - (int32_t) (c_hi & 0x0FFFFF00u);    /* < 0: penalty[carry] > penalty[x] */
-                const int32_t d = ((int32_t) usef < 0) ? df : dp;
-                const bool swap = active && d < 0;
-                swv |= (uint32_t) d & amask;
-                o_lo = swap ? x_lo : c_lo;          /* emitted: the smaller of the pair */
-                o_hi = swap ? x_hi : c_hi;
-                c_lo = swap ? c_lo : x_lo;          /* kept: the larger */
-                c_hi = swap ? c_hi : x_hi;
-                /* lane 63's outputs move down one lane per tick: after tick tb + 62 lane l holds output tb - 128 + l of the unit */
-                ob_lo = sr_dpp(o_lo, ob_lo, 1); ob_hi = sr_dpp(o_hi, ob_hi, 1);
-                if (k == 30) {
-                    if (h == 1 && tb >= 128) {
-                        const int base = tb - 128;
-                        if (base + lane < ipop) sr_st(out + base + lane, ((uint64_t) ob_hi << 32) | ob_lo);
-                        SR_WAIT_VMCNT0();         /* the elements have landed before the count says so */
-                        if (lane == 0) __hip_atomic_store(prog_out, base + 64 < ipop ? base + 64 : ipop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+        for (int k = 0; k < 64; ++k) {
+            /* input: lane 0 from the unit's input block, the others from their left neighbour's output of the previous tick */
+            const uint32_t x_lo = sr_dpp(vin_lo, o_lo, 0), x_hi = sr_dpp(vin_hi, o_hi, 0);
+            vin_lo = sr_dpp(vin_lo, vin_lo, 1); vin_hi = sr_dpp(vin_hi, vin_hi, 1);
+            /* by fval if u < PF (bit k of the window: isres.c:210) or both penalties are zero (bit 31 of both high words),
+             * else by penalty (:211-212, :220) — sign bits instead of booleans: the tick stays straight-line integer code */
+            const uint32_t usef = (((k & 32) ? whi : wlo) << (31 - (k & 31))) | (c_hi & x_hi);
+            const int32_t df = (int32_t) (x_lo >> 12) - (int32_t) (c_lo >> 12);                    /* < 0: fval[carry] > fval[x]   (:213) */
+            const int32_t dp = (int32_t) (x_hi & 0x0FFFFF00u) - (int32_t) (c_hi & 0x0FFFFF00u);    /* < 0: penalty[carry] > penalty[x] */
+            const int32_t d = ((int32_t) usef < 0) ? df : dp;
+            const bool swap = active && d < 0;
+            swv |= (uint32_t) d & amask;
+            o_lo = swap ? x_lo : c_lo;          /* emitted: the smaller of the pair */
+            o_hi = swap ? x_hi : c_hi;
+            c_lo = swap ? c_lo : x_lo;          /* kept: the larger */
+            c_hi = swap ? c_hi : x_hi;
+            /* lane 63's outputs move down one lane per tick: after tick tb + 62 lane l holds output tb - 128 + l of the unit */
+            ob_lo = sr_dpp(o_lo, ob_lo, 1); ob_hi = sr_dpp(o_hi, ob_hi, 1);
+            /* the row word used two blocks from now and, half a block ahead, the next block's inputs; the 64 outputs completed at
+             * tick 62 are stored there and nobody waits for the stores as such.  (Measured and dropped: keeping the outputs in two
+             * registers and storing them at tick 8 of the next block, so that the top of a block — which must drain the one counter
+             * loads and stores share before it can use a loaded value — never meets a young store: 14.8 against 14.7 ms per launch.) */
+            if (k == 12) wp = brow[clampw(b + 2 - half)];
+            if (k == 32) { if (tb + 64 < ipop) nxt = tb + 64 + lane < ipop ? sr_ld(in + tb + 64 + lane) : pinf; }
+            if (k == 62) {
+                const int base = tb - 128;
+                if (base >= 0 && base + lane < ipop) sr_st(out + base + lane, ((uint64_t) ob_hi << 32) | ob_lo);
             }
         }
     }

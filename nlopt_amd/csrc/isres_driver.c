@@ -288,7 +288,7 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
             const float ms = nla_event_elapsed_ms(d->ev0, d->ev1);
             if (ms >= 0) st->t_stochrank_ms += ms;
             ++st->stochrank_launches;
-            st->stochrank_ticks += (uint64_t) pop + 2ULL * (uint64_t) nsweeps + 63ULL * (uint64_t) ((nsweeps + 63) / 64);
+            st->stochrank_ticks += (uint64_t) pop + 2ULL * (uint64_t) nsweeps + (uint64_t) (nla_isres_stochrank_handoff() - 1) * (uint64_t) ((nsweeps + 63) / 64);     /* (hip/isres_stochrank.h) */
         }
         for (i = 0; i < nsweeps; ++i) if (!d->h_swapped[i]) break;      /* `if (!swapped) break;` isres.c:227 */
         if (i >= nsweeps - 1) break;               /* no early exit, or it was the last sweep anyway */

@@ -512,6 +512,7 @@ int nla_k_isres_bits(const uint32_t *words, int64_t row_first, int nrows, int64_
 int nla_k_isres_stochrank(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                           uint8_t *swapped, int32_t *irank, void *st);
 /* (launches run synchronously here: by the time the ranking is "launched", every block of bits enqueued before it is complete) */
+int nla_isres_stochrank_handoff(void) { return 32; }
 int nla_k_isres_stochrank_gated(int64_t pop, int64_t nsweeps, uint64_t *streams, int *progress, const uint64_t *bits, int *ticket,
                                 uint8_t *swapped, int32_t *irank, const int *gate, uint64_t gate_g_rank0, int64_t gate_nrows, void *st)
 {

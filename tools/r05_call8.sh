@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round 5, GPU call 8: ISRES — the evolve chain as composed segment tables (16 + 16 + 16 dependent look-ups instead of 256), the ranking
+# pipeline's units handing on 32 / 16 / 8 elements at a time instead of 64 (variant builds).  ISRES device tests, config 3 lines, kernel statistics.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05_c8; mkdir -p $O
+date +%s > $O/t0
+timeout -k 5 900 python -X faulthandler -m pytest tests/test_gpu_isres.py tests/test_gpu_nan.py tests/test_gpu_fullsize.py -x -q -m gpu -k "isres or nan or config3" -p no:cacheprovider > $O/tests.log 2>&1; echo "tests rc=$? $(tail -1 $O/tests.log)"
+for v in hb16 hb8; do
+  NLOPT_AMD_LIB=$PWD/nlopt_amd/lib/libnlopt_amd_$v.so timeout -k 5 600 python -m pytest tests/test_gpu_isres.py -x -q -m gpu -k "stochastic_ranking or golden or larger" -p no:cacheprovider > $O/tests_$v.log 2>&1; echo "tests $v rc=$? $(tail -1 $O/tests_$v.log)"
+done
+line() {   # line <label> <bench args...>
+    local label=$1; shift
+    timeout -k 5 150 python bench.py --detail $O/last_detail.json --full-line "$@" 2>/dev/null | tail -1 > $O/last.json
+    python - "$label" "$O/last.json" <<'PY' | tee -a $O/ab.log
+import json, sys
+try:
+    d = json.load(open(sys.argv[2]))
+    r = d.get("roofline") or {}
+    ph = d.get("phases") or {}
+    print("%-30s %9.0f evals/s  %8.3f ms/step  pipeline %.3f ms/launch %.1f ns/tick (%d ticks)  %s" % (sys.argv[1], d["value"], d["ms_per_step"], r.get("avg_launch_ms") or 0, r.get("achieved") or 0, r.get("serial_ticks_per_launch") or 0,
+          {k: (round(v * 1e3, 2) if k.endswith("_s_per_gen") or k.endswith("_s_per_iter") else v) for k, v in ph.items() if k.endswith("_s_per_gen") or "rounds" in k}))
+except Exception as e:
+    print(sys.argv[1], "FAILED", repr(e))
+PY
+}
+for rep in 1 2; do
+  line "isres config 3 handoff 32" --workload isres --no-cpu-baseline --steps 3 --warmup 1
+  NLOPT_AMD_LIB=$PWD/nlopt_amd/lib/libnlopt_amd_hb16.so line "isres config 3 handoff 16" --workload isres --no-cpu-baseline --steps 3 --warmup 1
+  NLOPT_AMD_LIB=$PWD/nlopt_amd/lib/libnlopt_amd_hb8.so line "isres config 3 handoff 8" --workload isres --no-cpu-baseline --steps 3 --warmup 1
+done
+timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/ki -o isres -- python bench.py --workload isres --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_isres_under_rocprof.json 2> $O/ki.err
+f=$(find $O/ki -name '*.db' | head -1); python profiles/summarize_rocpd.py $f > $O/isres_kernel_stats.csv; rm -rf $O/ki
+head -14 $O/isres_kernel_stats.csv
+echo "elapsed $(( $(date +%s) - $(cat $O/t0) )) s" | tee -a $O/ab.log

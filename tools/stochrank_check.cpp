@@ -78,6 +78,17 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
     return (int) emu_exchange((uint32_t) src, from, (uint32_t) old);
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return (int) emu_exchange((uint32_t) v, 0, 0u); }
+static inline bool emu_any(bool p)
+{
+    uint32_t *b = emu::unit->xch[emu::which];
+    b[threadIdx.x] = p ? 1u : 0u;
+    emu::unit->bar.wait();
+    bool r = false;
+    for (int l = 0; l < 64; ++l) r = r || b[l];
+    emu::which ^= 1;
+    return r;
+}
+#define SR_ANY(p) emu_any(p)
 
 #include "isres_stochrank.h"
 
@@ -111,7 +122,7 @@ static int run_case(int pop, unsigned seed, int *n_cases)
             if (byf ? f[a] > f[b] : pen[a] > pen[b]) { ref[j] = b; ref[j + 1] = a; ref_sw[i] = 1; }
         }
     for (int variant = 0; variant < 2; ++variant) {           /* all units at speed; some units slowed down */
-        std::vector<uint64_t> streams((size_t) (units + 1) * pop, 0);
+        std::vector<uint64_t> streams((size_t) (units + 1) * pop, ~0ull);       /* (the launcher's fill: SR_UNWRITTEN) */
         for (int i = 0; i < pop; ++i) streams[i] = pack((uint32_t) i, dense(f, i), dense(pen, i), pen[i] == 0);
         std::vector<int> progress(units + 1, 0);
         progress[0] = pop;
@@ -130,7 +141,7 @@ static int run_case(int pop, unsigned seed, int *n_cases)
         for (auto &t : th) t.join();
         ++*n_cases;
         for (int u = 0; u <= units; ++u)
-            if (progress[u] != pop) { printf("pop %d variant %d: progress[%d] = %d\n", pop, variant, u, progress[u]); return 1; }
+            if (0 && progress[u] != pop) {      /* (the counter protocol's; the hand-over through the elements keeps no counters) */ printf("pop %d variant %d: progress[%d] = %d\n", pop, variant, u, progress[u]); return 1; }
         const uint64_t *last = streams.data() + (size_t) units * pop;
         for (int k = 0; k < pop; ++k)
             if ((int) unpack_idx(last[k]) != ref[k]) { printf("pop %d variant %d: position %d holds %u, reference %d\n", pop, variant, k, unpack_idx(last[k]), ref[k]); return 1; }
