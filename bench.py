@@ -591,10 +591,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     passes = st1["rounds"] - st0["rounds"]
     timed_share = (g_launch / passes) if passes else 1.0
     useful_gbs = (used * timed_share * 8.0 * n * (n + 1) / (world if sharded else 1) / 1e9) / (g_ms / 1e3) if g_ms > 0 else None
-    # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) from n = 512 on, the conservative passes below
-    # (and always the conservative passes, on column slices, in a sharded job)
+    # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) at every dimension; the conservative passes with
+    # --param amd_forward=0 and, on column slices, in a sharded job
     fw = [kv.split("=", 1)[1] for kv in CRS_PARAMS if kv.split("=", 1)[0] == "amd_forward"]         # (--param amd_forward=0/1: the A/B switch)
-    chain = (float(fw[-1]) != 0 if fw else n >= 512) and not sharded
+    chain = (float(fw[-1]) != 0 if fw else True) and not sharded
     gkernel = "crs_chain_kernel" if chain else "crs_advance_kernel"
     traffic, traffic_src = pmc_traffic(gkernel) if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
     out = {
@@ -649,16 +649,15 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         out["other_sizes"] = {}
         for n2 in (512, 64):
             try:
-                m2 = crs_measure(nlopt_amd, L, "rastrigin", n2, 100000, a.seed, 1, 3, 20000, sync_all)
+                m2 = crs_measure(nlopt_amd, L, "rastrigin", n2, 100000, a.seed, 1, 6, 20000, sync_all)
                 s0, s1 = m2["st0"], m2["st1"]
                 gms, gb, gl = s1["t_gather_ms"] - s0["t_gather_ms"], s1["gather_bytes"] - s0["gather_bytes"], s1["gather_launches"] - s0["gather_launches"]
-                e2 = {"workload": "NLOPT_GN_CRS2_LM rastrigin n=%d pop=100000 seed=%d, 3 steps of 20000 evals" % (n2, a.seed),
+                e2 = {"workload": "NLOPT_GN_CRS2_LM rastrigin n=%d pop=100000 seed=%d, 6 steps of 20000 evals" % (n2, a.seed),
                       "value": m2["evals"] / m2["dt"], "unit": "evals/s",
                       "roofline_frac": (gb / 1e9) / (gms / 1e3) / HBM_PEAK_GBS if gms > 0 else None,
                       "avg_launch_ms": gms / gl if gl else None, "algorithmic_bytes_per_trial": 8 * n2 * (n2 + 1),
                       "init_evals_per_s": 100000 / m2["t_init"],
-                      "path": ("device-resolved windows (crs_chain_kernel), the chain advanced by the resolver wavefront: the default for 512 <= n < 2048"
-                               if n2 >= 512 else "conservative passes (crs_advance_kernel + crs_finish_kernel): the default below n = 512"),
+                      "path": "device-resolved windows (crs_chain_kernel, the chain advanced by the resolver wavefront): every dimension since round 5",
                       "trials_consumed_per_pass": (s1["slots_used"] - s0["slots_used"]) / max(1, s1["rounds"] - s0["rounds"]),
                       "host_split": {"trial_s": s1["t_trial_s"] - s0["t_trial_s"], "engine_s": s1["t_engine_s"] - s0["t_engine_s"],
                                      "walk_s": s1["t_walk_s"] - s0["t_walk_s"], "gather_kernel_s": gms / 1e3, "passes": int(s1["rounds"] - s0["rounds"]),
@@ -757,6 +756,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
             if gens_done == W + K:
                 o.force_stop()
     o.set_progress(hook)
+    if a.workload == "mlsl" and getattr(a, "exact", False):
+        o.enable_trace((W + K + 2) * (pop + 4096))          # per local search: its evaluation count (the latency model below)
     nlopt_amd.srand(a.seed)                                   # every rank: the same stream (one job)
     t_start = time.perf_counter()
     x, minf, ret = o.optimize_raw(xs)
@@ -812,6 +813,39 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
         wl = "NLOPT_%s(ftol_rel 1e-8) %s n=%d, %d samples/iteration, seed=%d; %s; step = 1 MLSL iteration" % (name.replace(" + ", " + NLOPT_").replace("default ", ""), a.obj, n, pop, a.seed, mode)
         phases = {"sampling_s_per_iter": d["t_eval_s"] / K, "local_phase_s_per_iter": d["t_evolve_s"] / K,
                   "local_searches": int(d["accepted"]), "sample_evals": int(d["evals_trial"]), "local_evals": int(d["evals_mutation"])}
+    if a.workload == "mlsl" and getattr(a, "exact", False) and a.local == "lbfgs":
+        # amd_exact_dot = 1 is not a bandwidth problem: every dot product of a search is ONE chain of n dependent fp64 additions in the
+        # reference's order (mssubs.c:601-641), and a launch lasts as long as its longest search.  Chain length of a search with E
+        # evaluations (one L-BFGS iteration per evaluation after the first; iteration i runs the two Strang recurrences over
+        # min(i, mf) columns: two dots each, plus ~6 ordered sums per iteration for norms / the directional derivative / the objective):
+        #   adds(E) = n * sum_{i < E} (2 min(i, mf) + 6)
+        # floor: one v_add_f64 of the chain every 4 cycles (a wave64 fp64 instruction on a 32-lane SIMD at half rate: its issue time, no
+        # dependency stall at all) at 2.4 GHz = 1.67 ns; measured in round 5: 2.5 ns = 6 cycles per addition.
+        try:
+            t = o.trace()
+            kinds = t["kind"]
+            it, prev, per_it = 0, 3, {}
+            for kk, ev in zip(kinds.tolist(), t["accepted"].tolist()):
+                if kk == 3 and prev == 4:
+                    it += 1
+                if kk == 4:
+                    per_it.setdefault(it, []).append(int(ev))
+                if kk in (3, 4):
+                    prev = kk
+            mf = max(10, 1310720 // n)      # plis.c:441-445, luksan.h:149 (MEMAVAIL / n)
+            def adds(E):
+                return n * sum(2 * min(i, mf) + 6 for i in range(int(E)))
+            longest = [max(adds(E) for E in per_it[i]) for i in range(W, W + K) if per_it.get(i)]
+            if longest and t_dom > 0:
+                ns = 1e9 * t_dom / float(sum(longest))
+                roof_extra = {"bound": "latency", "kernel": kern, "launches": launches, "avg_launch_ms": 1e3 * t_dom / launches if launches else None,
+                              "achieved": ns, "unit": "ns per sequential fp64 add on the launch's longest search",
+                              "peak": 4 / 2.4, "peak_note": "one v_add_f64 of the chain per 4 cycles (issue time of a wave64 fp64 instruction on a SIMD-32) at 2.4 GHz",
+                              "frac": (4 / 2.4) / ns, "sequential_adds_longest_search_per_launch": float(sum(longest)) / len(longest),
+                              "model": "adds(E) = n * sum_{i<E} (2 min(i, mf) + 6), E = evaluations of the search; launch time = its longest search",
+                              "traffic": None}
+        except Exception as e:
+            roof_extra = None
     achieved = (bytes_dom / 1e9) / t_dom if t_dom > 0 else None
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of the same command (BASELINE's shapes only)
     std = (a.workload == "isres" and (n, pop, a.obj) == (256, 50000, "rastrigin")) or (a.workload == "mlsl" and (n, pop, a.obj) == (4096, 1000, "ackley"))

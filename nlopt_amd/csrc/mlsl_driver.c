@@ -1,3 +1,4 @@
+#define _GNU_SOURCE            /* qsort_r */
 /* mlsl_driver.c — Multi-Level Single-Linkage behind the reference's entry point
  *   mlsl_minimize(n, f, f_data, lb, ub, x, minf, stop, local_opt, Nsamples, lds)   (mlsl.h:34-41),
  * host side: the point / local-minimum bookkeeping of mlsl.c:251-438 (ordered by f, the trees'
@@ -60,6 +61,7 @@ typedef struct {
     double *F, *cpd, *cld;          /* host */
     int32_t *minimized;
     size_t *ord;                    /* row ids sorted by f, equal keys newest first (redblack.c:120) */
+    int ord_has_nan;                /* a NaN key went in: from then on rows are inserted one by one (ord_insert_run) */
     size_t nlms, lcap;
     double *LF; size_t *lord;
     double *d_lb, *d_ub, *d_P, *d_F, *d_cpd, *d_LM, *d_LF, *d_D, *d_tmp;
@@ -123,6 +125,14 @@ static int grow_pts(mlsl_dev *d, size_t need)
     double *nP, *nF, *nC;
     int32_t *nM;
     if (need <= d->cap) return 0;
+    if (!d->cap) {
+        /* the first allocation holds 16 iterations' samples (within 2 GiB of rows; 524 MB at config 4 of 288 GB): growing costs a
+         * round of allocations, a copy of the whole point set and frees that wait for the device — 0.9 ms in the middle of one of
+         * the first iterations each time the set doubled (profiles/r05_mlsl_timeline.txt) */
+        const size_t want = 16 * (size_t) d->N + 1, budget = ((size_t) 2 << 30) / (sizeof(double) * (size_t) d->ld);
+        const size_t first = want < budget ? want : budget;
+        while (ncap < first) ncap *= 2;
+    }
     while (ncap < need) ncap *= 2;
     d->F = (double *) realloc(d->F, sizeof(double) * ncap);
     {
@@ -159,6 +169,11 @@ static int grow_lms(mlsl_dev *d, size_t need)
     size_t ncap = d->lcap ? d->lcap : 256;
     double *nL, *nF;
     if (need <= d->lcap) return 0;
+    if (!d->lcap) {           /* (as the point set: room for 8 iterations' worth of minima from the start, within 1 GiB) */
+        const size_t want = 8 * (size_t) d->N, budget = ((size_t) 1 << 30) / (sizeof(double) * (size_t) d->ld);
+        const size_t first = want < budget ? want : budget;
+        while (ncap < first) ncap *= 2;
+    }
     while (ncap < need) ncap *= 2;
     d->LF = (double *) realloc(d->LF, sizeof(double) * ncap);
     d->lord = (size_t *) realloc(d->lord, sizeof(size_t) * ncap);
@@ -183,6 +198,10 @@ static int need_D(mlsl_dev *d, size_t doubles)
 {
     if (doubles <= d->dcap) return 0;
     if (doubles < 2 * d->dcap) doubles = 2 * d->dcap;
+    if (!d->dcap) {            /* the first allocation: the pass of the 8th iteration (N x 8 N doubles, within 1 GiB) */
+        const size_t want = 8 * (size_t) d->N * (size_t) d->N, budget = ((size_t) 1 << 30) / sizeof(double);
+        if (doubles < (want < budget ? want : budget)) doubles = want < budget ? want : budget;
+    }
     nla_dev_free(d->d_D);
     d->d_D = (double *) nla_dev_malloc(sizeof(double) * doubles);
     d->dcap = d->d_D ? doubles : 0;
@@ -198,6 +217,41 @@ static void ord_insert(size_t *ord, size_t cnt, const double *F, size_t r)
     while (lo < hi) { size_t mid = (lo + hi) / 2; if (F[ord[mid]] < f) lo = mid + 1; else hi = mid; }
     memmove(ord + lo + 1, ord + lo, (cnt - lo) * sizeof *ord);
     ord[lo] = r;
+}
+
+/* the same for a run of nnew consecutive rows first .. first + nnew - 1 inserted one after the other (the sampling phase's 1000 points
+ * per iteration: a binary search through F and a memmove of half the array each — 1 ms per iteration at 3000 points, growing with the
+ * point set): sort the new rows, merge from the back.  The order is the one-by-one insertion's: an equal key goes in front of those
+ * already there, so among equals new rows come before old ones and later new rows before earlier ones.  (Keys that do not order —
+ * NaN — take the one-by-one path: the binary search's answer for them is whatever it happens to be, and that is what counts.) */
+static int ord_cmp_new(const void *a_, const void *b_, void *F_)
+{
+    const double *F = (const double *) F_;
+    const size_t a = *(const size_t *) a_, b = *(const size_t *) b_;
+    if (F[a] < F[b]) return -1;
+    if (F[a] > F[b]) return 1;
+    return a > b ? -1 : (a < b ? 1 : 0);                 /* the later row first */
+}
+static void ord_insert_run(size_t *ord, size_t cnt, const double *F, size_t first, size_t nnew, int any_nan)
+{
+    size_t k;
+    long i, j;
+    for (k = 0; k < nnew && !any_nan; ++k) if (F[first + k] != F[first + k]) any_nan = 1;
+    if (any_nan || nnew < 8) { for (k = 0; k < nnew; ++k) ord_insert(ord, cnt + k, F, first + k); return; }
+    for (k = 0; k < nnew; ++k) ord[cnt + k] = first + k;                      /* the tail of the array is the merge's scratch */
+    qsort_r(ord + cnt, nnew, sizeof *ord, ord_cmp_new, (void *) F);
+    {
+        /* merge in place from the back; the sorted new rows are first moved out of the way of the write position */
+        size_t *tmp = (size_t *) malloc(sizeof *tmp * nnew);
+        if (!tmp) { for (k = 0; k < nnew; ++k) ord[cnt + k] = 0; for (k = 0; k < nnew; ++k) ord_insert(ord, cnt + k, F, first + k); return; }
+        memcpy(tmp, ord + cnt, sizeof *tmp * nnew);
+        i = (long) cnt - 1; j = (long) nnew - 1;
+        for (k = cnt + nnew; k-- > 0 && j >= 0; ) {
+            if (i >= 0 && !(F[ord[i]] < F[tmp[j]])) ord[k] = ord[i--];       /* an old row with a key not smaller stays behind the new one */
+            else ord[k] = tmp[j--];
+        }
+        free(tmp);
+    }
 }
 
 /* v[k] = min over the ranks of their v[k] (each rank holds the minima over ITS rows of the distance matrix) */
@@ -408,6 +462,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 #define PREFETCH_NOW() do { if (prefetch_due) { prefetch_due = 0; \
         if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); } \
         D.prefetched_at = D.words_used; } } while (0)
+#define NEWPT_UNORDERED(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ++D.npts; } while (0)     /* (ord_insert_run follows) */
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
     /* several ranks: the clock and the force_stop flag are decided by all ranks together at the start of every phase (comm.c);
      * sp is what those two tests look at until the next agreement */
@@ -431,6 +486,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         nla_memcpy_d2h(D.F, D.d_F, sizeof(double), D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "first evaluation failed"); DEVFAIL(); }
     ++*stop->nevals_p;
     NEWPT(0);
+    if (D.F[0] != D.F[0]) D.ord_has_nan = 1;
     AGREE();
     STOPS(D.F[0]);
 
@@ -463,13 +519,18 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
             D.F[old + (size_t) i] = Fnew[i];
             ++*stop->nevals_p;
             if (st) ++st->evals_trial;
-            NEWPT(old + (size_t) i);
+            NEWPT_UNORDERED(old + (size_t) i);
             used = (size_t) i + 1;
             if (opt && opt->trace) {
                 if (opt->trace_len < opt->trace_cap) { nlopt_amd_trace_rec *tr = opt->trace + opt->trace_len; tr->f = Fnew[i]; tr->row = (int64_t) (old + (size_t) i); tr->kind = 3; tr->accepted = 0; }
                 ++opt->trace_len;
             }
             STOPS(Fnew[i]);
+        }
+        {
+            int any_nan = D.ord_has_nan;
+            ord_insert_run(D.ord, old, D.F, old, used, any_nan);
+            for (i = 0; i < (int) used && !D.ord_has_nan; ++i) if (D.F[old + (size_t) i] != D.F[old + (size_t) i]) D.ord_has_nan = 1;
         }
         if (D.d_V) D.sobol_next += (uint32_t) used;
         else D.words_used += 2ULL * (uint64_t) n * (uint64_t) used;
