@@ -25,6 +25,9 @@
 #ifndef SR_ANY                           /* does any lane of the wavefront say so? */
 #define SR_ANY(p) (__ballot(p) != 0ull)
 #endif
+#ifndef SR_PF_K
+#define SR_PF_K 32                       /* the tick of a block at which the next block's inputs are loaded (tuning builds: -DSR_PF_K=...) */
+#endif
 #define SR_UNWRITTEN 0xFFFFFFFFFFFFFFFFull    /* no element looks like this (bits 28-30 of the high word are never set: isres_pack, SR_PINF_HI) */
 #define SR_GATE_TIMEOUT 400000000ull    /* 4 s without the block's bits arriving: the generator's launch failed or never ran */
 
@@ -156,7 +159,7 @@ SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__
              * registers and storing them at tick 8 of the next block, so that the top of a block — which must drain the one counter
              * loads and stores share before it can use a loaded value — never meets a young store: 14.8 against 14.7 ms per launch.) */
             if (k == 12) wp = brow[clampw(b + 2 - half)];
-            if (k == 32) { if (tb + 64 < ipop) nxt = tb + 64 + lane < ipop ? sr_ld(in + tb + 64 + lane) : pinf; }
+            if (k == SR_PF_K) { if (tb + 64 < ipop) nxt = tb + 64 + lane < ipop ? sr_ld(in + tb + 64 + lane) : pinf; }
             if (k == 62) {
                 const int base = tb - 128;
                 if (base >= 0 && base + lane < ipop) sr_st(out + base + lane, ((uint64_t) ob_hi << 32) | ob_lo);
