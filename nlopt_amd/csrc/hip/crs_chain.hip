@@ -289,6 +289,12 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         double *m = TM + (size_t) q * (size_t) ld;
         auto getx = [&](int i) { return __builtin_nontemporal_load(x + i); };
         const double fT = sign * nla_block_objective_as<OBJ, WAVES, CH_FWAVES>(n, getx, scratch);
+        uint64_t *rec = reinterpret_cast<uint64_t *>(fv) + 2 * (size_t) a;
+        /* f(T) is published AT ONCE (the record's first word is its own flag; TX of the slot has landed: the chunks' waits above): the
+         * resolver accepts four trials in five on f(T) alone, and whoever waits for this slot need not wait for its mutation too */
+#ifndef NLA_CHAIN_LATE_FT                /* (A/B builds: both words at the end, as before round 5) */
+        if (tid == 0) __hip_atomic_store(rec, ch_bits_of_f(fT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         auto mut = [&](int i) {        /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
             const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
             const double wv = nla_urand_from(0., 1., ww.x, ww.y);
@@ -300,9 +306,10 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         __syncthreads();
         if (tid == 0) {
             status[a].fT = fT; status[a].fM = fM; status[a].t = n; status[a].pad = 0;
-            /* the record IS the flag (a word is nonzero once written); TX / TM of the slot have landed (the waits above) */
-            uint64_t *rec = reinterpret_cast<uint64_t *>(fv) + 2 * (size_t) a;
+            /* the record's second word: f(M) — TM of the slot has landed (the wait above) */
+#ifdef NLA_CHAIN_LATE_FT
             __hip_atomic_store(rec, ch_bits_of_f(fT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             __hip_atomic_store(rec + 1, ch_bits_of_f(fM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

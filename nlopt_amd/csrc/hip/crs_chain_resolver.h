@@ -110,7 +110,11 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
         const uint32_t s = next + (uint32_t) lane;
         uint64_t rt = 0, rm = 0;
         if (s < (uint32_t) K) { rt = ch_ld64(recs + 2 * (size_t) s); rm = ch_ld64(recs + 2 * (size_t) s + 1); }
-        const uint64_t ok = ch_ballot(rt != 0 && rm != 0);
+        /* a slot can be looked at as soon as f(T) is there: the evaluating workgroup publishes it BEFORE it forms and evaluates the
+         * mutation (round 5), and four trials in five are accepted on f(T) alone — the mutation's share of an evaluation leaves the
+         * critical path of every slot that waits for this one.  f(M) is asked for only behind a rejected trial; if it has not arrived
+         * the run ends in front of that slot */
+        const uint64_t ok = ch_ballot(rt != 0);
         const uint32_t run = (ok == ~0ull) ? 64u : (uint32_t) __builtin_ctzll(~ok);
         if (run == 0) {
             if ((++idle & 255u) == 0 && ch_clock() - t0 > timeout) { halt = 1; break; }
@@ -153,7 +157,9 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
             }
 #endif
             const uint32_t j = next + i;
-            const double fT = ch_f_of_bits(ch_readlane_u64(rt, i)), fM = ch_f_of_bits(ch_readlane_u64(rm, i));
+            const double fT = ch_f_of_bits(ch_readlane_u64(rt, i));
+            const uint64_t rmi = ch_readlane_u64(rm, i);
+            const double fM = ch_f_of_bits(rmi);
             /* the current worst: the next untouched row of the list, or a value that landed among them */
             double fw = -__builtin_huge_val();
             int64_t rw = -1;
@@ -168,6 +174,7 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
             int kind = 0;
             double fnew = 0;
             if (fT < fw) { kind = 1; fnew = fT; }               /* crs.c:135 */
+            else if (rmi == 0) break;                            /* rejected, and f(M) is still on its way: look again later */
             else if (fM < fw) { kind = 2; fnew = fM; }           /* the mutation of crs.c:139-146, accepted at :135 */
             if (kind) {
                 if (xi >= 0) {                                   /* entry xi leaves the list: the last one takes its place */
@@ -196,6 +203,11 @@ CH_DEV void chain_resolver_wave(uint32_t *ctrl_words, const uint64_t *recs, uint
                 }
             }
             i += (kind == 1) ? 1u : 2u;
+        }
+        if (i == 0 && !halt) {                                   /* the front slot waits for its f(M): nothing to publish */
+            if ((++idle & 255u) == 0 && ch_clock() - t0 > timeout) { halt = 1; break; }
+            ch_sleep();
+            continue;
         }
         next += i;
         idle = 0;

@@ -161,11 +161,19 @@ int main(int argc, char **argv)
                 int progressed = 0;
                 for (int t = 0; t < K; ++t) {
                     const int a = order[t];
-                    if (done[a]) continue;
+                    if (done[a] == 1) continue;
                     const uint32_t pk = reinterpret_cast<std::atomic<uint32_t> *>(&ctrl[CH_CTRL_PK])->load(std::memory_order_acquire);
                     if (dep[a] > 0 && (pk & 0xffffu) < (uint32_t) dep[a] && pk != 0xffffffffu) continue;
-                    reinterpret_cast<std::atomic<uint64_t> *>(&recs[2 * (size_t) a])->store(ch_bits_of_f(fT[a]), std::memory_order_release);
-                    if (U(0, 1)) std::this_thread::yield();
+                    /* f(T) first; f(M) at once, a moment later, or only on a later pass of the feeder (the evaluating workgroup publishes
+                     * f(T) before it forms the mutation: the resolver must get by without f(M) behind an accepted trial and wait for it
+                     * behind a rejected one) */
+                    if (done[a] == 0) {
+                        reinterpret_cast<std::atomic<uint64_t> *>(&recs[2 * (size_t) a])->store(ch_bits_of_f(fT[a]), std::memory_order_release);
+                        ++progressed;
+                        const int how = U(0, 3);
+                        if (how == 0) { done[a] = 2; continue; }       /* f(M) on a later pass */
+                        if (how == 1) std::this_thread::yield();
+                    }
                     reinterpret_cast<std::atomic<uint64_t> *>(&recs[2 * (size_t) a + 1])->store(ch_bits_of_f(fM[a]), std::memory_order_release);
                     done[a] = 1; --left; ++progressed;
                     if (U(0, 7) == 0) break;                    /* look at the chain's progress again */
