@@ -55,6 +55,7 @@ struct nla_local_ctx {
     double *h_x, *h_g, *h_f;       /* pinned: one point, one gradient, cap values */
     int32_t *h_list, *d_list;      /* user objective: indices of the waiting searches */
     double *d_ftrace; int64_t ftrace_cap;   /* optional per-evaluation f trace (nla_local_ctx_set_ftrace) */
+    int (*after_launch)(void *); void *after_arg;   /* one-shot: called right behind the next run's kernel launch (nla_local_ctx_after_launch) */
 };
 
 void nla_local_ctx_destroy(nla_local_ctx *c)
@@ -124,6 +125,10 @@ nla_local_ctx *nla_local_ctx_create_mma(const nla_evaluator *ev, int n, int cap,
     return c;
 }
 void nla_local_ctx_set_stats(nla_local_ctx *c, nlopt_amd_stats *stats) { if (c) c->stats = stats; }
+/* work the caller wants on the context's stream RIGHT BEHIND the searches' kernel — enqueued before the host waits for the kernel, so that
+ * it starts the moment the last search ends (MLSL: the minimisers' distances to the point set).  One-shot; device objectives only (a
+ * run that goes through host evaluations calls it before it returns, with the searches finished).  A nonzero return fails the run. */
+void nla_local_ctx_after_launch(nla_local_ctx *c, int (*fn)(void *), void *arg) { if (c) { c->after_launch = fn; c->after_arg = arg; } }
 int nla_local_ctx_alg(const nla_local_ctx *c) { return c->alg; }
 double *nla_local_ctx_X(nla_local_ctx *c) { return c->d_X; }
 
@@ -205,6 +210,7 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
     if (c->ev.kind == NLA_EVAL_DEVICE) {
         if ((rc = launch(c, count, prm, NULL))) return rc;
         nla_event_record(c->ev1, c->st);
+        if (c->after_launch) { int (*fn)(void *) = c->after_launch; c->after_launch = NULL; if ((rc = fn(c->after_arg))) return rc; }
         /* watch first, copy afterwards: a device-to-host copy into pageable memory (the caller's result record may live on its
          * stack) does not return before the kernel has finished, and nobody would raise the abort flag meanwhile */
         if ((rc = wait_watching(c, stop))) return rc;
@@ -246,6 +252,7 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
             E.resume = 1;
         }
         nla_event_record(c->ev1, c->st);
+        if (c->after_launch) { int (*fn)(void *) = c->after_launch; c->after_launch = NULL; if ((rc = fn(c->after_arg))) return rc; }
         if ((rc = nla_memcpy_d2h(h_res, c->d_res, sizeof(nla_lbfgs_result) * (size_t) count, c->st))) return rc;
         if ((rc = nla_stream_sync(c->st))) return rc;
     }

@@ -52,6 +52,7 @@ typedef struct {
     nla_evaluator ev;
     double *h_rows;                 /* host objective: the iteration's samples, pinned (N x ld) */
     void *rs;                       /* the generator's stream: st itself, or (prefetch) a second one */
+    void *ev_samples;               /* recorded behind the copy of the samples' values (the distance pass is enqueued behind it) */
     int prefetch; uint64_t prefetched_at;   /* device objectives: the next iteration's sample words generated beside the local phase; stream position they were generated for */
     void *st;
     nla_mtstream *mts;
@@ -105,6 +106,7 @@ static void mfree(mlsl_dev *d)
     nla_host_free(d->h_D); nla_host_free(d->h_idx); nla_host_free(d->h_lf); nla_host_free(d->h_flags);
     nla_host_free(d->h_S); nla_host_free(d->h_lfall); nla_host_free(d->h_gi);
     nla_dev_free(d->d_idx); nla_dev_free(d->d_flags); nla_dev_free(d->d_S); nla_dev_free(d->d_lfall); nla_dev_free(d->d_gi);
+    nla_event_destroy(d->ev_samples);
     if (d->rs && d->rs != d->st) nla_stream_destroy(d->rs);
     if (d->st) nla_stream_destroy(d->st);
 }
@@ -254,6 +256,20 @@ static void ord_insert_run(size_t *ord, size_t cnt, const double *F, size_t firs
     }
 }
 
+/* the distances of a batch's minimisers to every point + the nb x nb of them the commit walk reads, enqueued on the stream (MLSL's
+ * local phase; with a device objective on one rank: right behind the searches' kernel, nla_local_ctx_after_launch) */
+typedef struct { mlsl_dev *d; int n, nb; size_t na; const double *ctx_X; size_t lx_bytes; } mlsl_pairs_job;
+static int mlsl_enqueue_pairs(void *arg)
+{
+    mlsl_pairs_job *j = (mlsl_pairs_job *) arg;
+    mlsl_dev *d = j->d;
+    if (j->ctx_X && j->lx_bytes && nla_memcpy_d2d(d->d_LX, j->ctx_X, j->lx_bytes, d->st)) return -1;      /* (one rank: the all-gather of the minimisers is this copy) */
+    return nla_memcpy_h2d(d->d_gi, d->h_gi, sizeof(int64_t) * (size_t) j->nb, d->st) ||
+           nla_k_mlsl_dist2(j->n, d->ld, d->d_LX, (int) j->na, d->d_P, (int) d->npts, d->d_D, d->st) ||
+           nla_k_mlsl_gather_pairs(d->d_D, (int) d->npts, d->d_gi, j->nb, d->d_idx, j->nb, d->d_S, d->st) ||
+           nla_memcpy_d2h(d->h_S, d->d_S, sizeof(double) * (size_t) j->nb * (size_t) j->nb, d->st);
+}
+
 /* v[k] = min over the ranks of their v[k] (each rank holds the minima over ITS rows of the distance matrix) */
 static int min_over_ranks(mlsl_dev *d, double *v, size_t count)
 {
@@ -373,6 +389,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.prefetch = !host;
     D.prefetched_at = ~0ULL;
     D.rs = (D.st && D.prefetch) ? nla_stream_create_background() : D.st;
+    D.ev_samples = nla_event_create();
     {
         /* "amd_mlsl_seg_regens": the segment length of this run's stream (NLA_MT_SEG_REGENS = 1024 is the layout every other algorithm
          * uses) — 64 makes 205 wavefronts of the 13 above; measured at config 4 (MI355X, round 5): 15.9 ms per iteration at 1024, 14.7 at
@@ -403,7 +420,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
     cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
-    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !D.ev_samples || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         nla_comm_agree_ready(D.comm, 0);
@@ -462,7 +479,35 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 #define PREFETCH_NOW() do { if (prefetch_due) { prefetch_due = 0; \
         if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); } \
         D.prefetched_at = D.words_used; } } while (0)
-#define NEWPT_UNORDERED(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ++D.npts; } while (0)     /* (ord_insert_run follows) */
+/* the sampling phase's distance pass (find_closest_pt + pts_update_newpt, find_closest_lm) for the N new points in rows old .. old + N - 1:
+ * everything it needs is on the device once the sampling kernel has run — the points, their f, the old points' closest_pt_d and flags
+ * (uploaded here: the new rows' entries are set before) — so with a device objective on one rank it is ENQUEUED RIGHT BEHIND THE
+ * SAMPLING KERNEL and runs while the host walks the N values (counts, stop tests, the order array: 0.3 ms per iteration that used to
+ * stand between the sampling kernel and the distance kernel, profiles/r05_mlsl_timeline.txt).  A run that stops inside that walk
+ * leaves; what the pass wrote is not looked at again. */
+#define ENQUEUE_DISTANCES() do { \
+            const int na_ = D.N, nb_ = (int) (old + (size_t) D.N); \
+            const int per_r_ = (na_ + D.world - 1) / D.world; \
+            const int r0_ = per_r_ * D.rank < na_ ? per_r_ * D.rank : na_; \
+            const int mine_r_ = na_ - r0_ < per_r_ ? na_ - r0_ : per_r_; \
+            const double *A_ = D.d_P + (old + (size_t) r0_) * (size_t) D.ld, *FA_ = D.d_F + old + r0_; \
+            if (need_D(&D, (size_t) na_ * (size_t) nb_) || (D.nlms && need_D(&D, (size_t) na_ * D.nlms))) DEVFAIL(); \
+            /* closest_pt_d of the new points: over every point with smaller f; of the old, not yet minimised points: over the new points \
+             * with smaller f.  Several ranks: the ROWS of the new points are dealt in blocks over the ranks; every rank computes its rows' \
+             * minima and its rows' share of the column minima, combined by an element-wise min over an all-gather (exact) */ \
+            if (nla_memcpy_h2d(D.d_cpd, D.cpd, sizeof(double) * (size_t) nb_, D.st) || \
+                nla_memcpy_h2d(D.d_min, D.minimized, sizeof(int32_t) * (size_t) nb_, D.st) || \
+                (mine_r_ > 0 && (nla_k_mlsl_dist2(n, D.ld, A_, mine_r_, D.d_P, nb_, D.d_D, D.st) || \
+                                 nla_k_mlsl_rowmin(D.d_D, nb_, mine_r_, nb_, FA_, D.d_F, NULL, D.d_cpd + old + r0_, D.st) || \
+                                 nla_k_mlsl_colmin(D.d_D, nb_, mine_r_, (int) old, FA_, D.d_F, D.d_min, D.d_cpd, D.st))) || \
+                nla_memcpy_d2h(D.cpd, D.d_cpd, sizeof(double) * (size_t) nb_, D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); } \
+            if (D.nlms) {                                                      /* find_closest_lm */ \
+                if (mine_r_ > 0 && (nla_k_mlsl_dist2(n, D.ld, A_, mine_r_, D.d_LM, (int) D.nlms, D.d_D, D.st) || \
+                                    nla_k_mlsl_rowmin(D.d_D, (int) D.nlms, mine_r_, (int) D.nlms, FA_, D.d_LF, NULL, D.d_tmp, D.st) || \
+                                    nla_memcpy_d2h(D.cld + old + r0_, D.d_tmp, sizeof(double) * (size_t) mine_r_, D.st))) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); } \
+            } \
+            dist_enqueued = 1; } while (0)
+#define NEWPT_UNORDERED(row) do { (void) (row); ++D.npts; } while (0)     /* (entries initialised in front of the walk; ord_insert_run follows) */
 #define NEWPT(row) do { D.minimized[row] = 0; D.cpd[row] = HUGE_VAL; D.cld[row] = HUGE_VAL; ord_insert(D.ord, D.npts, D.F, row); ++D.npts; } while (0)
     /* several ranks: the clock and the force_stop flag are decided by all ranks together at the start of every phase (comm.c);
      * sp is what those two tests look at until the next agreement */
@@ -493,7 +538,8 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     while (ret == NLOPT_SUCCESS) {
         double R, t0 = nla_seconds();
         size_t old = D.npts, used = 0, idx;
-        int remaining, prefetch_due = 0;
+        int remaining, prefetch_due = 0, dist_enqueued = 0, pairs_enqueued = 0;
+        mlsl_pairs_job pairs_job;
         GET_MINF();                                                            /* mlsl.c:347 */
         AGREE();
         if (opt && opt->progress) { opt->progress(opt->progress_data, st ? (long) st->generations : 0, (long) *stop->nevals_p); t0 = nla_seconds(); }
@@ -512,8 +558,18 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 (D.ev.kind == NLA_EVAL_DEVICE && D.ev.sign < 0 && nla_k_mlsl_negate(D.d_F + old, D.N, D.st)) ||
                 (D.ev.kind == NLA_EVAL_USER && EVAL_ROWS(D.d_P + old * (size_t) D.ld, D.N, D.d_F + old))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         }
-        if ((host ? nla_memcpy_d2h(D.h_rows, D.d_P + old * (size_t) D.ld, sizeof(double) * (size_t) D.N * (size_t) D.ld, D.st)
-                  : nla_memcpy_d2h(Fnew, D.d_F + old, sizeof(double) * (size_t) D.N, D.st)) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+        /* the new rows' closest-distance entries and flags start as "none yet" (what NEWPT does per point; here for all N at once so
+         * that the distance pass can be enqueued before the host looks at a single value) */
+        for (i = 0; i < D.N; ++i) { D.minimized[old + (size_t) i] = 0; D.cpd[old + (size_t) i] = HUGE_VAL; D.cld[old + (size_t) i] = HUGE_VAL; }
+        dist_enqueued = 0;
+        if (host ? nla_memcpy_d2h(D.h_rows, D.d_P + old * (size_t) D.ld, sizeof(double) * (size_t) D.N * (size_t) D.ld, D.st)
+                 : nla_memcpy_d2h(Fnew, D.d_F + old, sizeof(double) * (size_t) D.N, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+        if (!host && D.world == 1) {
+            /* wait for the values only (an event behind their copy), with the distance pass already behind them on the stream */
+            if (nla_event_record(D.ev_samples, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+            ENQUEUE_DISTANCES();
+            if (nla_event_sync(D.ev_samples)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+        } else if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
         for (i = 0; i < D.N && ret == NLOPT_SUCCESS; ++i) {
             if (host) Fnew[i] = f((unsigned) n, D.h_rows + (size_t) i * (size_t) D.ld, NULL, f_data);   /* mlsl.c:360 */
             D.F[old + (size_t) i] = Fnew[i];
@@ -542,30 +598,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
          * They go out right in front of the local searches' launch instead (PREFETCH_NOW below), on a background-priority stream: the
          * searches' 300 workgroups leave most of every compute unit free for 6 ms */
         prefetch_due = D.prefetch && !D.d_V;
+        if (!dist_enqueued) ENQUEUE_DISTANCES();
         {
-            const int na = D.N, nb = (int) D.npts;
-            if (need_D(&D, (size_t) na * (size_t) nb)) DEVFAIL();
-            /* closest_pt_d of the new points: over every point with smaller f; of the old, not yet
-             * minimised points: over the new points with smaller f (find_closest_pt + pts_update_newpt).
-             * Several ranks: the ROWS of the new points are dealt in blocks over the ranks (the pair distances are the costly part
-             * of the sampling phase: 6.4 of its 9.3 ms at config 4); every rank computes its rows' minima and its rows' share of
-             * the column minima, and the ranks' vectors are combined by an element-wise min over an all-gather (exact) */
-            const int per_r = (na + D.world - 1) / D.world;
-            const int r0 = per_r * D.rank < na ? per_r * D.rank : na;
-            const int mine_r = na - r0 < per_r ? na - r0 : per_r;
-            const double *A = D.d_P + (old + (size_t) r0) * (size_t) D.ld, *FA = D.d_F + old + r0;
-            if (nla_memcpy_h2d(D.d_cpd, D.cpd, sizeof(double) * D.npts, D.st) ||
-                nla_memcpy_h2d(D.d_min, D.minimized, sizeof(int32_t) * D.npts, D.st) ||
-                (mine_r > 0 && (nla_k_mlsl_dist2(n, D.ld, A, mine_r, D.d_P, nb, D.d_D, D.st) ||
-                                nla_k_mlsl_rowmin(D.d_D, nb, mine_r, nb, FA, D.d_F, NULL, D.d_cpd + old + r0, D.st) ||
-                                nla_k_mlsl_colmin(D.d_D, nb, mine_r, (int) old, FA, D.d_F, D.d_min, D.d_cpd, D.st))) ||
-                nla_memcpy_d2h(D.cpd, D.d_cpd, sizeof(double) * D.npts, D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
-            if (D.nlms) {                                                      /* find_closest_lm */
-                if (need_D(&D, (size_t) na * D.nlms)) DEVFAIL();
-                if (mine_r > 0 && (nla_k_mlsl_dist2(n, D.ld, A, mine_r, D.d_LM, (int) D.nlms, D.d_D, D.st) ||
-                                   nla_k_mlsl_rowmin(D.d_D, (int) D.nlms, mine_r, (int) D.nlms, FA, D.d_LF, NULL, D.d_tmp, D.st) ||
-                                   nla_memcpy_d2h(D.cld + old + r0, D.d_tmp, sizeof(double) * (size_t) mine_r, D.st))) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
-            }
+            const int na = D.N;
             if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
             if (D.world > 1 && (min_over_ranks(&D, D.cpd, D.npts) || (D.nlms && min_over_ranks(&D, D.cld + old, (size_t) na)))) {
                 snprintf(D.err, sizeof D.err, "all-gather of the distance minima failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL();
@@ -632,8 +667,19 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 }
             } else {
             PREFETCH_NOW();
+            pairs_enqueued = 0;
+            if (!host && D.world == 1 && mine > 0) {
+                /* one rank, device objective: the minimisers' distances go out right behind the searches' kernel (they need nothing the
+                 * host decides), instead of after the host has woken up, copied the results and come back: 0.2 ms per iteration */
+                pairs_job.d = &D; pairs_job.n = n; pairs_job.nb = nb; pairs_job.na = (size_t) per; pairs_job.ctx_X = nla_local_ctx_X(D.lb);
+                pairs_job.lx_bytes = sizeof(double) * (size_t) per * (size_t) D.ld;
+                if (need_D(&D, (size_t) per * D.npts)) DEVFAIL();
+                for (c = 0; c < nb; ++c) D.h_gi[c] = (int64_t) GI(c);
+                nla_local_ctx_after_launch(D.lb, mlsl_enqueue_pairs, &pairs_job);
+                pairs_enqueued = 1;
+            }
             if (mine > 0 && nla_local_ctx_run(D.lb, mine, &prm, res_mine, &lstop, NULL)) { snprintf(D.err, sizeof D.err, "local-search batch failed"); DEVFAIL(); }
-            if (nla_comm_allgather_dev(D.comm, nla_local_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st) ||
+            if ((!pairs_enqueued && nla_comm_allgather_dev(D.comm, nla_local_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st)) ||
                 nla_comm_allgather_host(D.comm, res_mine, res, sizeof *res * (size_t) per, D.st)) {
                 snprintf(D.err, sizeof D.err, "all-gather of the local minima failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL();
             }
@@ -651,11 +697,12 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                     D.h_D = (double *) nla_host_malloc(sizeof(double) * D.hcap);
                     if (!D.h_D) { D.hcap = 0; snprintf(D.err, sizeof D.err, "out of pinned memory"); DEVFAIL(); }
                 }
-                for (c = 0; c < nb; ++c) D.h_gi[c] = (int64_t) GI(c);
-                if (nla_memcpy_h2d(D.d_gi, D.h_gi, sizeof(int64_t) * (size_t) nb, D.st) ||
-                    nla_k_mlsl_dist2(n, D.ld, D.d_LX, (int) na, D.d_P, (int) D.npts, D.d_D, D.st) ||
-                    nla_k_mlsl_gather_pairs(D.d_D, (int) D.npts, D.d_gi, nb, D.d_idx, nb, D.d_S, D.st) ||
-                    nla_memcpy_d2h(D.h_S, D.d_S, sizeof(double) * (size_t) nb * (size_t) nb, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+                if (!pairs_enqueued) {
+                    for (c = 0; c < nb; ++c) D.h_gi[c] = (int64_t) GI(c);
+                    pairs_job.d = &D; pairs_job.n = n; pairs_job.nb = nb; pairs_job.na = na; pairs_job.ctx_X = NULL; pairs_job.lx_bytes = 0;
+                    if (mlsl_enqueue_pairs(&pairs_job)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+                }
+                if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
                 for (c = 0; c < (int) na; ++c) D.h_lfall[c] = HUGE_VAL;
             }
             if (grow_lms(&D, D.nlms + (size_t) nb)) DEVFAIL();
