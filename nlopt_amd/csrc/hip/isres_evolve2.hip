@@ -433,6 +433,8 @@ __global__ __launch_bounds__(256) void ev2_write0_kernel(ev2_args A)
 __global__ __launch_bounds__(256) void ev2_scan0_kernel(ev2_args A, ev2_args P)
 {
     extern __shared__ double sm[];
+    /* (the launch takes what the scan and the stage took together — 84 us at config 3, of which the write workgroups cost nothing
+     * measurable: a build without them ran the same; profiles/r05_isres_handoff.txt) */
     if (blockIdx.x < EVM) ev2_scan_body<true>(A, (int) blockIdx.x, sm);
     else ev2_write_body<true>(P, (int) blockIdx.x - EVM, sm);
 }
