@@ -32,12 +32,17 @@
 #include "../../../include/nlopt_amd.h"
 
 #define EVD 256                 /* candidate starts per individual (window of stream positions) */
-#define EVM 256                 /* individuals per round */
+#define EVM 256                 /* individuals the chain kernel crosses at a time (one LDS load of E rows); a round's block is bm = 1 or 2 of these */
+#define EVMX 512                /* the largest block: the mutation phase's (round 5) */
+#ifndef EV2_MUT_BLOCK
+#define EV2_MUT_BLOCK EVMX      /* (A/B builds: -DEV2_MUT_BLOCK=256) */
+#endif
 #define EV2_MAXN 1150           /* LDS staging limit (same as the serial LDS kernel) */
 #define EV2_ZW(n) (EVD + 3 * (n) + 65)      /* deviates staged per individual: window + 1 + 2n + room for n + 64 redraws */
 
 struct ev2_args {
     int n, ld, phase;
+    int bm;                             /* individuals of this round's block: EVMX in the mutation phase, EVM in the variation phase */
     int64_t pop, survivors, zcount;
     double taup, tau;
     const double *lb, *ub, *z;
@@ -246,87 +251,97 @@ __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
     if (st2 || st10) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing: its write kernel idles */
     const int64_t k0 = ev2_uniform64(st0), kend = A.phase == 0 ? A.pop : A.survivors;
     if (k0 >= kend) { if (tid == 0) A.state[9] = 0; return; }
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(A.E);            /* (E is 256-byte aligned in the workspace) */
-        uint4 *dst = reinterpret_cast<uint4 *>(sE);
-#pragma unroll
-        for (int q = 0; q < EVM * EVD / 8 / 1024; ++q) dst[q * 1024 + tid] = src[q * 1024 + tid];
-    }
     static_assert(EVM == 256 && EVD == 256 && (EVM * EVD / 8) % 1024 == 0 && EV2_NSEG * EVD % 1024 == 0, "block shape");
     const long long pos0 = ev2_uniform64(st1);
     const int OUT = 0x40000000;                                /* a window origin no start of this block can be within EVD of */
-    int na_i = 0;
-    double mu_i = 0;
-    if (tid < EVM) {
-        const int q = tid;
-        na_i = A.ws_nact[q]; mu_i = A.ws_mu[q];
-        const long long brel = A.ws_base[q] - pos0;
-        /* the row isres.c:260 reads (physical row k + 1) must not be rewritten inside this block before k: the walk ends at a
-         * survivor k whose row k + 1 belongs to an earlier survivor of the block (straight-line: the index is clamped, not guarded) */
-        const long long k = k0 + q, k1 = k + 1 < A.pop ? k + 1 : A.pop - 1;
-        const long long o = A.inv[k1];
-        const bool dep = A.phase == 1 && k + 1 < A.pop && o >= k0 && o < k;
-        const bool stop = na_i < 0 || dep || brel >= OUT || brel <= -OUT;
-        s_b[q] = stop ? OUT : (int) brel;
-    }
-    __syncthreads();
-    /* one step of the chain for individual i from position pos (relative to pos0): the entry, or why there is none:
+    /* one step of the chain for individual i (of the EVM in LDS) from position pos (relative to pos0): the entry, or why there is none:
      * -10 the start left the window, -11 the individual stops every walk (end of the phase / variation's dependency), -1 / -2 the scan's */
     auto step = [&](int i, int pos) -> int {
         const unsigned d = (unsigned) (pos - s_b[i]);
         if (d >= (unsigned) EVD) return d >= 0xc0000000u && d < 0xd0000000u ? -11 : -10;
         return (int) sE[(size_t) i * EVD + d];
     };
-    /* A: the segments' tables */
-#pragma unroll 1
-    for (int t = tid; t < EV2_NSEG * EVD; t += 1024) {
-        const int sg = t / EVD, d = t % EVD, i0 = sg * EV2_SEG;
-        int pos = s_b[i0] == OUT ? 0 : s_b[i0] + d, ok = s_b[i0] != OUT;
-        const int p0 = pos;
-        for (int j = 0; ok && j < EV2_SEG; ++j) {
-            const int e = step(i0 + j, pos);
-            if (e < 0) ok = 0; else pos += e;
-        }
-        G[t] = ok ? pos - p0 : -1;
-    }
-    __syncthreads();
-    /* B: the exact start of every segment that can be reached by crossing whole segments */
-    if (tid == 0) {
-        int pos = 0, nf = 0;
-        s_segpos[0] = 0;
-        for (; nf < EV2_NSEG; ++nf) {
-            const unsigned d = (unsigned) (pos - s_b[nf * EV2_SEG]);
-            if (d >= (unsigned) EVD) break;
-            const int g = G[nf * EVD + (int) d];
-            if (g < 0) break;
-            pos += g;
-            s_segpos[nf + 1] = pos;
-        }
-        s_nfull = nf;
-    }
-    __syncthreads();
-    /* C: the individual starts, segment by segment in parallel (lane 0 of wavefront s: every walker on a SIMD's issue slot of its own
-     * as far as the 16 wavefronts go) */
-    const int nfull = s_nfull;
-    if (lane == 0 && wave < EV2_NSEG && wave <= nfull) {
-        const int i0 = wave * EV2_SEG;
-        int pos = s_segpos[wave], c = 0, why = 0;
-        for (; c < EV2_SEG; ++c) {
-            const int e = step(i0 + c, pos);
-            if (e < 0) { why = e; break; }
-            s_st[i0 + c] = pos;
-            pos += e;
-        }
-        s_cnt[wave] = c; s_why[wave] = why;
-        if (wave == nfull) s_segpos[EV2_NSEG] = pos;           /* where the round's walk ended (the segment that stopped it) */
-    }
-    __syncthreads();
-    const int r = nfull < EV2_NSEG ? nfull * EV2_SEG + s_cnt[nfull] : EVM;
-    const int elast = nfull < EV2_NSEG ? s_why[nfull] : 0;
-    const int pos = nfull < EV2_NSEG ? s_segpos[EV2_NSEG] : s_segpos[EV2_NSEG];     /* (a full block: B stored the end in s_segpos[EV2_NSEG] too) */
+    /* The block is crossed EVM individuals at a time (what fits the LDS): the mutation phase's block is two of them (round 5 — the scan of
+     * 512 individuals is two workgroups per compute unit, two wavefronts per SIMD, and takes little longer than that of 256, whose lone
+     * wavefronts left every SIMD idle most of the time; with the per-parent expectation the starts of ~430 of the 512 stay inside their
+     * windows: 100 rounds per mutation phase instead of 172, tools/evolve_predict.py), the second entered at the exact end of the first. */
+    int r = 0, elast = 0, pos = 0;
     long long asum = 0;
     double msum = 0;
-    if (tid < r) { A.ws_start[tid] = pos0 + s_st[tid]; asum = na_i; msum = mu_i; }
+    for (int h = 0; h < A.bm / EVM; ++h) {
+        __syncthreads();                                       /* (the previous part's tables are no longer read) */
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(A.E) + (size_t) h * (EVM * EVD / 8);      /* (E is 256-byte aligned in the workspace) */
+            uint4 *dst = reinterpret_cast<uint4 *>(sE);
+#pragma unroll
+            for (int q = 0; q < EVM * EVD / 8 / 1024; ++q) dst[q * 1024 + tid] = src[q * 1024 + tid];
+        }
+        int na_i = 0;
+        double mu_i = 0;
+        if (tid < EVM) {
+            const int q = h * EVM + tid;
+            na_i = A.ws_nact[q]; mu_i = A.ws_mu[q];
+            const long long brel = A.ws_base[q] - pos0;
+            /* the row isres.c:260 reads (physical row k + 1) must not be rewritten inside this block before k: the walk ends at a
+             * survivor k whose row k + 1 belongs to an earlier survivor of the block (straight-line: the index is clamped, not guarded) */
+            const long long k = k0 + q, k1 = k + 1 < A.pop ? k + 1 : A.pop - 1;
+            const long long o = A.inv[k1];
+            const bool dep = A.phase == 1 && k + 1 < A.pop && o >= k0 && o < k;
+            const bool stop = na_i < 0 || dep || brel >= OUT || brel <= -OUT;
+            s_b[tid] = stop ? OUT : (int) brel;
+        }
+        __syncthreads();
+        /* A: the segments' tables */
+#pragma unroll 1
+        for (int t = tid; t < EV2_NSEG * EVD; t += 1024) {
+            const int sg = t / EVD, d = t % EVD, i0 = sg * EV2_SEG;
+            int p = s_b[i0] == OUT ? 0 : s_b[i0] + d, ok = s_b[i0] != OUT;
+            const int p0 = p;
+            for (int j = 0; ok && j < EV2_SEG; ++j) {
+                const int e = step(i0 + j, p);
+                if (e < 0) ok = 0; else p += e;
+            }
+            G[t] = ok ? p - p0 : -1;
+        }
+        __syncthreads();
+        /* B: the exact start of every segment that can be reached by crossing whole segments */
+        if (tid == 0) {
+            int p = pos, nf = 0;
+            s_segpos[0] = p;
+            for (; nf < EV2_NSEG; ++nf) {
+                const unsigned d = (unsigned) (p - s_b[nf * EV2_SEG]);
+                if (d >= (unsigned) EVD) break;
+                const int g = G[nf * EVD + (int) d];
+                if (g < 0) break;
+                p += g;
+                s_segpos[nf + 1] = p;
+            }
+            s_nfull = nf;
+        }
+        __syncthreads();
+        /* C: the individual starts, segment by segment in parallel (lane 0 of wavefront s: every walker on a SIMD's issue slot of its own
+         * as far as the 16 wavefronts go) */
+        const int nfull = s_nfull;
+        if (lane == 0 && wave < EV2_NSEG && wave <= nfull) {
+            const int i0 = wave * EV2_SEG;
+            int p = s_segpos[wave], c = 0, why = 0;
+            for (; c < EV2_SEG; ++c) {
+                const int e = step(i0 + c, p);
+                if (e < 0) { why = e; break; }
+                s_st[i0 + c] = p;
+                p += e;
+            }
+            s_cnt[wave] = c; s_why[wave] = why;
+            if (wave == nfull) s_segpos[EV2_NSEG] = p;         /* where the walk ended (the segment that stopped it) */
+        }
+        __syncthreads();
+        const int rh = nfull < EV2_NSEG ? nfull * EV2_SEG + s_cnt[nfull] : EVM;
+        elast = nfull < EV2_NSEG ? s_why[nfull] : 0;
+        pos = s_segpos[EV2_NSEG];                              /* (a full part: B stored its end there) */
+        if (tid < rh) { A.ws_start[h * EVM + tid] = pos0 + s_st[tid]; asum += na_i; msum += mu_i; }
+        r += rh;
+        if (rh < EVM) break;
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { asum += __shfl_xor(asum, m, 64); msum += __shfl_xor(msum, m, 64); }
     if (lane == 0) { s_asum[wave] = asum; s_msum[wave] = msum; }
@@ -424,8 +439,8 @@ __global__ __launch_bounds__(256) void ev2_write0_kernel(ev2_args A)
     ev2_write_body<true>(A, (int) blockIdx.x, sm);
 }
 
-/* Mutation phase, one launch per round in front of the chain kernel: workgroups 0 .. EVM-1 scan the round's block (A: this round's
- * tables), workgroups EVM .. 2 EVM-1 — only when a round went before it in the batch — WRITE the individuals the PREVIOUS round
+/* Mutation phase, one launch per round in front of the chain kernel: workgroups 0 .. bm-1 scan the round's block (A: this round's
+ * tables), workgroups bm .. 2 bm-1 — only when a round went before it in the batch — WRITE the individuals the PREVIOUS round
  * resolved (P: that round's tables; T, the window origins and the exact starts exist twice and alternate).  The children's rows and
  * the parents' rows are disjoint in this phase, so the previous round's write needs nothing the scan touches and leaves the serial
  * path: a round is scan -> chain instead of stage -> scan -> chain -> write (round 5; 4.8 + 8.1 us of kernels and two launch gaps of
@@ -435,8 +450,8 @@ __global__ __launch_bounds__(256) void ev2_scan0_kernel(ev2_args A, ev2_args P)
     extern __shared__ double sm[];
     /* (the launch takes what the scan and the stage took together — 84 us at config 3, of which the write workgroups cost nothing
      * measurable: a build without them ran the same; profiles/r05_isres_handoff.txt) */
-    if (blockIdx.x < EVM) ev2_scan_body<true>(A, (int) blockIdx.x, sm);
-    else ev2_write_body<true>(P, (int) blockIdx.x - EVM, sm);
+    if ((int) blockIdx.x < A.bm) ev2_scan_body<true>(A, (int) blockIdx.x, sm);
+    else ev2_write_body<true>(P, (int) blockIdx.x - A.bm, sm);
 }
 
 /* redraws a child of parent p (by rank position, p < survivors) is EXPECTED to make (isres.c:245-248 draws x again while it is outside
@@ -483,11 +498,11 @@ extern "C" size_t nla_isres_evolve2_ws_bytes(int n)
     /* nact | act | xi | sg | xpre | E | T | base | start, each region 256-byte aligned */
     size_t b = 0;
     auto add = [&](size_t x) { b += (x + 255) & ~(size_t) 255; };
-    add(sizeof(int32_t) * EVM); add(sizeof(int32_t) * EVM * (size_t) n);
-    add(sizeof(double) * EVM * (size_t) n); add(sizeof(double) * EVM * (size_t) n); add(sizeof(double) * EVM * (size_t) n);
-    add(sizeof(int16_t) * EVM * EVD); add(sizeof(int16_t) * EVM * 64 * EVD); add(sizeof(int64_t) * EVM); add(sizeof(int64_t) * EVM);
-    add(sizeof(double) * EVM);
-    add(sizeof(int16_t) * EVM * 64 * EVD); add(sizeof(int64_t) * EVM); add(sizeof(int64_t) * EVM);      /* the second set of T / base / start (mutation phase) */
+    add(sizeof(int32_t) * EVMX); add(sizeof(int32_t) * EVMX * (size_t) n);
+    add(sizeof(double) * EVMX * (size_t) n); add(sizeof(double) * EVMX * (size_t) n); add(sizeof(double) * EVMX * (size_t) n);
+    add(sizeof(int16_t) * EVMX * EVD); add(sizeof(int16_t) * EVMX * 64 * EVD); add(sizeof(int64_t) * EVMX); add(sizeof(int64_t) * EVMX);
+    add(sizeof(double) * EVMX);
+    add(sizeof(int16_t) * EVMX * 64 * EVD); add(sizeof(int64_t) * EVMX); add(sizeof(int64_t) * EVMX);      /* the second set of T / base / start (mutation phase) */
     return b;
 }
 extern "C" int nla_isres_evolve2_supported(int n) { return n >= 1 && n <= EV2_MAXN; }
@@ -522,20 +537,20 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
     A.lb = lb; A.ub = ub; A.z = z; A.irank = irank; A.inv = inv; A.X = X; A.S = S; A.x0c = x0c; A.state = state; A.rho = rho; A.mu_rp = mu_rp;
     char *p = (char *) ws;
     auto take = [&](size_t x) { char *q = p; p += (x + 255) & ~(size_t) 255; return q; };
-    A.ws_nact = (int32_t *) take(sizeof(int32_t) * EVM);
-    A.ws_act = (int32_t *) take(sizeof(int32_t) * EVM * (size_t) n);
-    A.ws_xi = (double *) take(sizeof(double) * EVM * (size_t) n);
-    A.ws_sg = (double *) take(sizeof(double) * EVM * (size_t) n);
-    A.ws_xpre = (double *) take(sizeof(double) * EVM * (size_t) n);
-    A.E = (int16_t *) take(sizeof(int16_t) * EVM * EVD);
-    A.T = (int16_t *) take(sizeof(int16_t) * EVM * 64 * EVD);
-    A.ws_base = (int64_t *) take(sizeof(int64_t) * EVM);
-    A.ws_start = (int64_t *) take(sizeof(int64_t) * EVM);
-    A.ws_mu = (double *) take(sizeof(double) * EVM);
+    A.ws_nact = (int32_t *) take(sizeof(int32_t) * EVMX);
+    A.ws_act = (int32_t *) take(sizeof(int32_t) * EVMX * (size_t) n);
+    A.ws_xi = (double *) take(sizeof(double) * EVMX * (size_t) n);
+    A.ws_sg = (double *) take(sizeof(double) * EVMX * (size_t) n);
+    A.ws_xpre = (double *) take(sizeof(double) * EVMX * (size_t) n);
+    A.E = (int16_t *) take(sizeof(int16_t) * EVMX * EVD);
+    A.T = (int16_t *) take(sizeof(int16_t) * EVMX * 64 * EVD);
+    A.ws_base = (int64_t *) take(sizeof(int64_t) * EVMX);
+    A.ws_start = (int64_t *) take(sizeof(int64_t) * EVMX);
+    A.ws_mu = (double *) take(sizeof(double) * EVMX);
     ev2_args B = A;                                            /* the other set of what a round's write still needs while the next round scans */
-    B.T = (int16_t *) take(sizeof(int16_t) * EVM * 64 * EVD);
-    B.ws_base = (int64_t *) take(sizeof(int64_t) * EVM);
-    B.ws_start = (int64_t *) take(sizeof(int64_t) * EVM);
+    B.T = (int16_t *) take(sizeof(int16_t) * EVMX * 64 * EVD);
+    B.ws_base = (int64_t *) take(sizeof(int64_t) * EVMX);
+    B.ws_start = (int64_t *) take(sizeof(int64_t) * EVMX);
     const size_t lds_scan = sizeof(double) * (size_t) (5 * n + EV2_ZW(n));
     const size_t lds_write = sizeof(double) * (size_t) (7 * n + EV2_ZW(n));
     const size_t lds_chain = sizeof(int16_t) * EVM * EVD + sizeof(int) * EV2_NSEG * EVD;
@@ -550,15 +565,16 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
         attr_set = true;
     }
     hipStream_t st = (hipStream_t) stream;
+    A.bm = B.bm = phase == 0 ? EV2_MUT_BLOCK : EVM;
     if (phase == 0) {
         /* round r works on set r & 1; its launch also writes what round r - 1 resolved (the other set); the batch ends with the last
          * round's write, so every batch starts from a population that is up to date */
         for (int r = 0; r < rounds; ++r) {
             const ev2_args &C = (r & 1) ? B : A, &Pv = (r & 1) ? A : B;
-            hipLaunchKernelGGL(ev2_scan0_kernel, dim3(r ? 2 * EVM : EVM), dim3(EVD), lds_write, st, C, Pv);
+            hipLaunchKernelGGL(ev2_scan0_kernel, dim3(r ? 2 * EV2_MUT_BLOCK : EV2_MUT_BLOCK), dim3(EVD), lds_write, st, C, Pv);
             hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(1024), lds_chain, st, C);
         }
-        if (rounds > 0) hipLaunchKernelGGL(ev2_write0_kernel, dim3(EVM), dim3(256), lds_write, st, ((rounds - 1) & 1) ? B : A);
+        if (rounds > 0) hipLaunchKernelGGL(ev2_write0_kernel, dim3(EV2_MUT_BLOCK), dim3(256), lds_write, st, ((rounds - 1) & 1) ? B : A);
     } else
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(ev2_stage_kernel, dim3(EVM), dim3(256), 0, st, A);
