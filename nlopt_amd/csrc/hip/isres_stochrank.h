@@ -158,6 +158,8 @@ SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__
              * tick 62 are stored there and nobody waits for the stores as such.  (Measured and dropped: keeping the outputs in two
              * registers and storing them at tick 8 of the next block, so that the top of a block — which must drain the one counter
              * loads and stores share before it can use a loaded value — never meets a young store: 14.8 against 14.7 ms per launch.) */
+            /* (also measured and dropped, call 18: a unit that missed its look-ahead falling back by s_sleep(24 .. 96) so that the next
+             * ones hit — 14.3-15.9 against 14.1-14.3 ms per launch; the look-ahead's tick, 16 .. 48: no difference) */
             if (k == 12) wp = brow[clampw(b + 2 - half)];
             if (k == SR_PF_K) { if (tb + 64 < ipop) nxt = tb + 64 + lane < ipop ? sr_ld(in + tb + 64 + lane) : pinf; }
             if (k == 62) {
