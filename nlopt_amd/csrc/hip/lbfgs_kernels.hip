@@ -159,8 +159,11 @@ __device__ __attribute__((noinline)) double lb_strang_in_registers(int n, int k,
 
 /* two workgroups per CU (<= 256 registers per lane): what does not fit is spilled in the scalar outer logic, once per iteration —
  * the per-column loops live in lb_strang_in_registers and stay spill-free (checked in the ISA: only its prologue / epilogue touch scratch) */
+#ifndef LB_WAVES_PER_EU
+#define LB_WAVES_PER_EU 2
+#endif
 template <int OBJ>
-__global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbfgs_batch_kernel(int n, int ld, int mf, int count, const double *__restrict__ lb,
+__global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(LB_WAVES_PER_EU, LB_WAVES_PER_EU))) void lbfgs_batch_kernel(int n, int ld, int mf, int count, const double *__restrict__ lb,
                                                             const double *__restrict__ ub, double *__restrict__ X,
                                                             double *__restrict__ work, int *__restrict__ iwork,
                                                             double *__restrict__ hist, nla_lbfgs_params P,
