@@ -515,6 +515,7 @@ int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA
 int nla_k_mlsl_gather_rows(int n, int ld, const double *src, const int64_t *idx, int count, double *dst, void *stream);
 /* out[a * nc + b] = D[rows[a] * ldd + cols[b]] (a < nr, b < nc): the entries of a batch's distance matrix the commit walk reads */
 int nla_k_mlsl_gather_pairs(const double *D, int ldd, const int64_t *rows, int nr, const int64_t *cols, int nc, double *out, void *stream);
+int nla_k_mlsl_gather_pairs_t(const double *D, int ldd, const int64_t *rows, int nr, const int64_t *cols, int nc, double *out, void *stream);   /* transposed: out[b * nr + a] */
 /* replaces: the bound test of is_potential_minimizer (mlsl.c:211-218) for `count` points: flags[c] = 1 if row idx[c] of P has a
  * coordinate within thr (= dbound R) of a bound of a box side wider than thr */
 int nla_k_mlsl_near_bound(int n, int ld, const double *P, const int64_t *idx, int count, const double *lb, const double *ub,

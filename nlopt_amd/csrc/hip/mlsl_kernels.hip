@@ -160,6 +160,22 @@ __global__ __launch_bounds__(256) void mlsl_gather_pairs_kernel(const double *__
     const int b = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
     if (b < nc && a < nr) out[(size_t) a * nc + b] = D[(size_t) rows[a] * (size_t) ldd + (size_t) cols[b]];
 }
+/* the same transposed, out[b * nr + a]: the commit walk asks, for start point b, about the minimisers a < b one after the other — with the
+ * pairs in this order its inner loop reads consecutive memory instead of one cache line per question (0.45 -> 0.1 ms per iteration at
+ * config 4's 300-search batches) */
+__global__ __launch_bounds__(256) void mlsl_gather_pairs_t_kernel(const double *__restrict__ D, int ldd, const int64_t *__restrict__ rows, int nr,
+                                                                   const int64_t *__restrict__ cols, int nc, double *__restrict__ out)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
+    if (b < nc && a < nr) out[(size_t) b * nr + a] = D[(size_t) rows[a] * (size_t) ldd + (size_t) cols[b]];
+}
+extern "C" int nla_k_mlsl_gather_pairs_t(const double *D, int ldd, const int64_t *rows, int nr, const int64_t *cols, int nc, double *out, void *stream)
+{
+    if (nr <= 0 || nc <= 0) return 0;
+    hipLaunchKernelGGL(mlsl_gather_pairs_t_kernel, dim3((unsigned) ((nc + 255) / 256), (unsigned) nr), dim3(256), 0, (hipStream_t) stream, D, ldd, rows, nr, cols, nc, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int nla_k_mlsl_gather_pairs(const double *D, int ldd, const int64_t *rows, int nr, const int64_t *cols, int nc, double *out, void *stream)
 {
     if (nr <= 0 || nc <= 0) return 0;

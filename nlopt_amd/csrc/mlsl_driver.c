@@ -266,7 +266,7 @@ static int mlsl_enqueue_pairs(void *arg)
     if (j->ctx_X && j->lx_bytes && nla_memcpy_d2d(d->d_LX, j->ctx_X, j->lx_bytes, d->st)) return -1;      /* (one rank: the all-gather of the minimisers is this copy) */
     return nla_memcpy_h2d(d->d_gi, d->h_gi, sizeof(int64_t) * (size_t) j->nb, d->st) ||
            nla_k_mlsl_dist2(j->n, d->ld, d->d_LX, (int) j->na, d->d_P, (int) d->npts, d->d_D, d->st) ||
-           nla_k_mlsl_gather_pairs(d->d_D, (int) d->npts, d->d_gi, j->nb, d->d_idx, j->nb, d->d_S, d->st) ||
+           nla_k_mlsl_gather_pairs_t(d->d_D, (int) d->npts, d->d_gi, j->nb, d->d_idx, j->nb, d->d_S, d->st) ||
            nla_memcpy_d2h(d->h_S, d->d_S, sizeof(double) * (size_t) j->nb * (size_t) j->nb, d->st);
 }
 
@@ -716,7 +716,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 /* closest_lm_d of this start as the serial order would see it now: the minima committed earlier in this batch count
                  * (pts_update_newlm, mlsl.c:180-194: those with smaller f than the point's, if closer) */
                 for (cp = 0; cp < c; ++cp)
-                    if (D.h_lfall[GI(cp)] < D.F[r] && D.h_S[(size_t) cp * (size_t) nb + (size_t) c] < cl) cl = D.h_S[(size_t) cp * (size_t) nb + (size_t) c];
+                    if (D.h_lfall[GI(cp)] < D.F[r] && D.h_S[(size_t) c * (size_t) nb + (size_t) cp] < cl) cl = D.h_S[(size_t) c * (size_t) nb + (size_t) cp];      /* (h_S[c][cp] = distance of start c to minimiser cp: transposed on the device) */
                 pot = !(cl <= (dlm * R) * (dlm * R));
                 /* nodes between the previous candidate and this one were visited and skipped */
                 remaining -= (int) (cand[c] + 1 - idx);
@@ -743,7 +743,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                         nla_memcpy_d2d(D.d_LX + g * (size_t) D.ld, nla_local_ctx_X(D.lb), sizeof(double) * (size_t) n, D.st) ||
                         nla_k_mlsl_dist2(n, D.ld, D.d_LX + g * (size_t) D.ld, 1, D.d_P, (int) D.npts, D.d_D + g * D.npts, D.st) ||
                         nla_memcpy_d2h(D.h_D, D.d_D + g * D.npts, sizeof(double) * D.npts, D.st) || nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "local-search rerun failed"); DEVFAIL(); }
-                    for (cp = 0; cp < nb; ++cp) D.h_S[(size_t) c * (size_t) nb + (size_t) cp] = D.h_D[D.ord[cand[cp]]];     /* this minimiser moved: its row of the pairs */
+                    for (cp = 0; cp < nb; ++cp) D.h_S[(size_t) cp * (size_t) nb + (size_t) c] = D.h_D[D.ord[cand[cp]]];     /* this minimiser moved: its distances to the batch's start points */
                     res[g] = r1;
                 }
                 calls = use_mma ? res[g].iterm : res[g].nevals;                /* objective calls the search made (MMA: iterm) */

@@ -237,6 +237,13 @@ int nla_k_mlsl_colmin(const double *D, int ldd, int na, int nb, const double *FA
     }
     return 0;
 }
+int nla_k_mlsl_gather_pairs_t(const double *D, int ldd, const int64_t *rows, int nr, const int64_t *cols, int nc, double *out, void *st)
+{
+    EMU_LAUNCH();
+    (void) st;
+    for (int a = 0; a < nr; ++a) for (int b = 0; b < nc; ++b) out[(size_t) b * nr + a] = D[(size_t) rows[a] * (size_t) ldd + (size_t) cols[b]];
+    return 0;
+}
 int nla_k_mlsl_gather_pairs(const double *D, int ldd, const int64_t *rows, int nr, const int64_t *cols, int nc, double *out, void *st)
 {
     EMU_LAUNCH();
