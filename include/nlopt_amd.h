@@ -115,6 +115,9 @@ typedef struct {
     /* ISRES gated ranking: launches of the pipeline in which a unit gave up waiting for its block of ranking bits (hip/isres_stochrank.h:
      * 4 s) — the ranking was then redone without gates after the generator's stream had been waited for.  0 in a healthy run */
     uint64_t isres_gate_timeouts;
+    /* MLSL: iterations whose sampling phase (points, values, distances) had been computed beside the local phase before them
+     * (mlsl_driver.c, mlsl_enqueue_ahead): every iteration but the first of a one-rank run with a compiled-in objective */
+    uint64_t mlsl_sampled_ahead;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 

@@ -114,28 +114,44 @@ __global__ __launch_bounds__(256) void isres_eval_kernel(int n, int ld, const do
 /* lane = individual (64 per workgroup), the j range dealt over the workgroup's 8 wavefronts, partial counts summed through LDS: 782
  * workgroups / 6256 wavefronts at pop = 5e4 where one thread per individual and 256 per workgroup gave 196 / 784 — the kernel sits in
  * front of the ranking pipeline on the generation's critical path (4.8 ms at config 3 in that shape, rounds 1-4) */
+typedef double rc_d8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(RC_W * 64) void isres_rank_count_kernel(int64_t pop, const double *__restrict__ F, const double *__restrict__ PEN,
                                                                      uint64_t *__restrict__ elems, int32_t *__restrict__ sorted)
 {
-    __shared__ double sf[RC_W][RC_T], sp[RC_W][RC_T];
     __shared__ uint32_t part[3][RC_W][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int64_t k = (int64_t) blockIdx.x * 64 + lane;
     const bool live = k < pop;
     const double fk = live ? F[k] : 0.0, pk = live ? PEN[k] : 0.0;
     uint32_t rf = 0, rp = 0, ps = 0;
+    /* the values everybody is compared with come through the SCALAR unit (round 5; tiles staged in LDS before: two broadcast LDS reads per
+     * comparison kept the kernel at a fifth of its instruction rate): the index j is the same for the whole wavefront, so F[j], PEN[j] are
+     * scalar loads — 8 values per instruction out of the constant cache — and the comparisons take them as scalar operands */
     for (int64_t j0 = (int64_t) wave * RC_T; j0 < pop; j0 += (int64_t) RC_W * RC_T) {
         const int cnt = (int) (pop - j0 < RC_T ? pop - j0 : RC_T);
-        /* a wavefront's LDS operations execute in the order they were issued: the reads below see the writes of its own lanes
-         * without a barrier; the waits only keep the previous tile's reads ahead of this tile's writes in the instruction stream */
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int i = lane; i < cnt; i += 64) { sf[wave][i] = F[j0 + i]; sp[wave][i] = PEN[j0 + i]; }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        for (int i = 0; i < cnt; ++i) {
-            const double fj = sf[wave][i], pj = sp[wave][i];
+        const double *Fj = F + j0, *Pj = PEN + j0;
+        const int64_t kd = k - j0;                                      /* "j < k" inside the tile, in 32 bits */
+        const int kk = kd < 0 ? 0 : kd > RC_T ? RC_T : (int) kd;
+        int i = 0;
+        if ((j0 & 7) == 0) {       /* RC_T and the tile origin are multiples of 8: the wide loads are aligned */
+            rc_d8 fa = *(const rc_d8 *) (Fj), pa = *(const rc_d8 *) (Pj);
+            for (; i + 8 <= cnt; i += 8) {
+                const rc_d8 fv = fa, pv = pa;
+                if (i + 16 <= cnt) { fa = *(const rc_d8 *) (Fj + i + 8); pa = *(const rc_d8 *) (Pj + i + 8); }   /* the next 8, in flight */
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double fj = fv[u], pj = pv[u];
+                    rf += fj < fk;
+                    rp += pj < pk;
+                    ps += (uint32_t) (fj < fk) | ((uint32_t) (fj == fk) & (uint32_t) (i + u < kk));
+                }
+            }
+        }
+        for (; i < cnt; ++i) {
+            const double fj = Fj[i], pj = Pj[i];
             rf += fj < fk;
             rp += pj < pk;
-            ps += (fj < fk) || (fj == fk && j0 + i < k);
+            ps += (uint32_t) (fj < fk) | ((uint32_t) (fj == fk) & (uint32_t) (i < kk));
         }
     }
     part[0][wave][lane] = rf; part[1][wave][lane] = rp; part[2][wave][lane] = ps;

@@ -18,7 +18,11 @@
  * pairs.  (Rounds 1-3 ran one pair per thread on 16 x 16 tiles — two LDS reads per pair and coordinate, bound by LDS bandwidth:
  * 6.4 ms for 1000 x 3000 pairs at n = 4096; measured on the MI355X in round 4 (gpurun_out/r04_first): the sampling phase of
  * config 4 went 9.4 -> 7.6 ms per iteration, the direct bit-for-bit test and the MLSL files green, and the old kernel was deleted.)
- * Every pair is summed by ONE thread over k ascending, subtract / multiply / add unfused: bit-identical to distance2. */
+ * Every pair is summed by ONE thread over k ascending, subtract / multiply / add unfused: bit-identical to distance2.
+ * (Round 5 tried the rows of A through the SCALAR unit — a wavefront owning 8 rows, their coordinates scalar loads and scalar operands
+ * of the subtraction, 2 LDS reads per 16 pairs instead of 8: slower, 2.54 against 2.17 ms for 1000 x 4000 pairs at n = 4096 and 1.54
+ * against 1.21 ms for 1000 x 1800 (profiles/r05_mlsl_ahead_ab.txt) — scalar loads and LDS reads share one counter, every wait for
+ * either is a wait for both.  Deleted.) */
 #define DR 64          /* pairs tile edge of the register-tiled kernel */
 #define DKR 32         /* coordinates per LDS tile */
 __global__ __launch_bounds__(256) void mlsl_dist2_kernel(int n, int ld, const double *__restrict__ A, int na,
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(256) void mlsl_dist2_kernel(int n, int ld, const do
             if (i < na && j < nb) D[(size_t) i * nb + j] = d[r][c];
         }
 }
+#define DIST2_GRID(na, nb) dim3((unsigned) (((nb) + DR - 1) / DR), (unsigned) (((na) + DR - 1) / DR))
 
 /* out[i] = min(init[i], min_j { D[i][j] : FB[j] < FA[i] })        (one wavefront per row i) */
 __global__ __launch_bounds__(256) void mlsl_rowmin_kernel(const double *__restrict__ D, int ldd, int na, int nb, const double *__restrict__ FA,
@@ -132,8 +137,7 @@ extern "C" int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const doub
 extern "C" int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream)
 {
     if (na <= 0 || nb <= 0) return 0;
-    hipLaunchKernelGGL(mlsl_dist2_kernel, dim3((unsigned) ((nb + DR - 1) / DR), (unsigned) ((na + DR - 1) / DR)), dim3(256), 0,
-                       (hipStream_t) stream, n, ld, A, na, B, nb, D);
+    hipLaunchKernelGGL(mlsl_dist2_kernel, DIST2_GRID(na, nb), dim3(256), 0, (hipStream_t) stream, n, ld, A, na, B, nb, D);
     NLA_LAUNCH_CHECK();
     return 0;
 }

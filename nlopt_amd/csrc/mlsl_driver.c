@@ -85,6 +85,20 @@ typedef struct {
     int64_t *h_idx, *d_idx;
     double *h_lf;
     int32_t *h_flags, *d_flags;
+    /* THE NEXT ITERATION'S SAMPLING PHASE, AHEAD (round 5; one rank, compiled-in objective): nothing of a sampling phase but the distances to the
+     * minima of the local phase before it depends on that local phase — not the sample points (the local optimisers draw no random
+     * numbers), not their values, not their distances to the points and to the minima known so far.  All of it is enqueued on the
+     * generator's background stream right in front of the local searches' launch (mlsl_enqueue_ahead) and runs beside it: the searches
+     * are bound by memory latency on a quarter of the chip's wavefront slots, the distance pass by fp64 arithmetic.  The results wait in
+     * buffers of their own (closest-point minima in d_cpd2 / h_cpd2, closest-minimum distances in h_cld2) and are merged by `min` —
+     * which is what both updates are (mlsl.c:155-194) — when the iteration they belong to starts. */
+    int ahead, ahead_valid;
+    size_t ahead_old, ahead_nlms;    /* rows old .. old + N - 1 were sampled for a point set of `old` rows; minima 0 .. ahead_nlms - 1 are accounted for */
+    uint64_t ahead_words; uint32_t ahead_sobol;
+    void *ev_ahead;
+    double *Fnew2, *h_cld2;          /* pinned, N each */
+    double *d_D2; size_t dcap2;
+    double *d_cpd2, *h_cpd2, *h_inf, *d_cld2; size_t cap2;
     char err[200];
 } mlsl_dev;
 
@@ -106,7 +120,9 @@ static void mfree(mlsl_dev *d)
     nla_host_free(d->h_D); nla_host_free(d->h_idx); nla_host_free(d->h_lf); nla_host_free(d->h_flags);
     nla_host_free(d->h_S); nla_host_free(d->h_lfall); nla_host_free(d->h_gi);
     nla_dev_free(d->d_idx); nla_dev_free(d->d_flags); nla_dev_free(d->d_S); nla_dev_free(d->d_lfall); nla_dev_free(d->d_gi);
-    nla_event_destroy(d->ev_samples);
+    nla_event_destroy(d->ev_samples); nla_event_destroy(d->ev_ahead);
+    nla_host_free(d->Fnew2); nla_host_free(d->h_cld2); nla_host_free(d->h_cpd2); nla_host_free(d->h_inf);
+    nla_dev_free(d->d_D2); nla_dev_free(d->d_cpd2); nla_dev_free(d->d_cld2);
     if (d->rs && d->rs != d->st) nla_stream_destroy(d->rs);
     if (d->st) nla_stream_destroy(d->st);
 }
@@ -208,6 +224,73 @@ static int need_D(mlsl_dev *d, size_t doubles)
     d->d_D = (double *) nla_dev_malloc(sizeof(double) * doubles);
     d->dcap = d->d_D ? doubles : 0;
     if (!d->d_D) MFAIL(d, "out of device memory (distance matrix)");
+    return 0;
+}
+
+/* ---- the next iteration's sampling phase, ahead (see mlsl_dev) ---- */
+static int ahead_buffers(mlsl_dev *d, size_t doubles)
+{
+    if (d->cap2 < d->cap) {
+        size_t i;
+        nla_host_free(d->h_cpd2); nla_host_free(d->h_inf); nla_dev_free(d->d_cpd2);
+        d->h_cpd2 = (double *) nla_host_malloc(sizeof(double) * d->cap);
+        d->h_inf = (double *) nla_host_malloc(sizeof(double) * d->cap);
+        d->d_cpd2 = (double *) nla_dev_malloc(sizeof(double) * d->cap);
+        d->cap2 = (d->h_cpd2 && d->h_inf && d->d_cpd2) ? d->cap : 0;
+        if (!d->cap2) MFAIL(d, "out of memory (sampling ahead)");
+        for (i = 0; i < d->cap; ++i) d->h_inf[i] = HUGE_VAL;
+    }
+    if (!d->Fnew2) d->Fnew2 = (double *) nla_host_malloc(sizeof(double) * (size_t) d->N);
+    if (!d->h_cld2) d->h_cld2 = (double *) nla_host_malloc(sizeof(double) * (size_t) d->N);
+    if (!d->d_cld2) d->d_cld2 = (double *) nla_dev_malloc(sizeof(double) * (size_t) d->N);
+    if (!d->Fnew2 || !d->h_cld2 || !d->d_cld2) MFAIL(d, "out of memory (sampling ahead)");
+    if (doubles > d->dcap2) {
+        if (doubles < 2 * d->dcap2) doubles = 2 * d->dcap2;
+        if (!d->dcap2) {       /* as need_D: the pass of the 8th iteration from the start, within 1 GiB */
+            const size_t want = 8 * (size_t) d->N * (size_t) d->N, budget = ((size_t) 1 << 30) / sizeof(double);
+            if (doubles < (want < budget ? want : budget)) doubles = want < budget ? want : budget;
+        }
+        nla_dev_free(d->d_D2);
+        d->d_D2 = (double *) nla_dev_malloc(sizeof(double) * doubles);
+        d->dcap2 = d->d_D2 ? doubles : 0;
+        if (!d->d_D2) MFAIL(d, "out of device memory (distance matrix of the samples ahead)");
+    }
+    return 0;
+}
+
+/* enqueue, on the generator's stream, the sampling of the iteration AFTER the current one: rows npts .. npts + N - 1 (the current
+ * iteration's sampling is complete, its local phase adds no points), their values, closest_pt_d of and through them (find_closest_pt,
+ * pts_update_newpt: mlsl.c:155-178) and their closest_lm_d over the minima known now (find_closest_lm, :139-153).  Called in front of
+ * the local searches' launch, behind the generator's fill of the words these rows are made of.  Every allocation it may need is
+ * made here, before anything is enqueued (freeing device memory waits for the whole device). */
+static int mlsl_enqueue_ahead(mlsl_dev *d, int n)
+{
+    const size_t old = d->npts, nlms = d->nlms;
+    const int N = d->N, nb = (int) (old + (size_t) N);
+    const size_t cols = (size_t) nb > nlms ? (size_t) nb : nlms;
+    const double *A, *FA;
+    d->ahead_valid = 0;
+    if (d->d_V && (uint64_t) d->sobol_next + (uint64_t) N >= 4294967295ULL) return 0;     /* (the iteration itself reports the exhausted sequence) */
+    if (grow_pts(d, old + (size_t) N) || ahead_buffers(d, (size_t) N * cols)) return -1;
+    A = d->d_P + old * (size_t) d->ld; FA = d->d_F + old;
+    if (d->d_V) {
+        if (nla_k_mlsl_sobol_rows(n, d->ld, d->d_lb, d->d_ub, d->d_V, d->sobol_next, N, d->d_P + old * (size_t) d->ld, d->rs) ||
+            nla_k_eval(d->obj, n, d->ld, A, N, d->d_F + old, d->rs) ||
+            (d->ev.sign < 0 && nla_k_mlsl_negate(d->d_F + old, N, d->rs))) MFAIL(d, "sampling ahead failed");
+    } else if (nla_k_crs_init_rows(d->obj, n, d->ld, d->d_lb, d->d_ub, d->d_words, (int64_t) old, N, d->d_P, d->d_F, d->rs) ||
+               (d->ev.sign < 0 && nla_k_mlsl_negate(d->d_F + old, N, d->rs))) MFAIL(d, "sampling ahead failed");
+    if (nla_memcpy_d2h(d->Fnew2, d->d_F + old, sizeof(double) * (size_t) N, d->rs) ||
+        nla_memcpy_h2d(d->d_cpd2, d->h_inf, sizeof(double) * (size_t) nb, d->rs) ||
+        nla_k_mlsl_dist2(n, d->ld, A, N, d->d_P, nb, d->d_D2, d->rs) ||
+        nla_k_mlsl_rowmin(d->d_D2, nb, N, nb, FA, d->d_F, NULL, d->d_cpd2 + old, d->rs) ||
+        nla_k_mlsl_colmin(d->d_D2, nb, N, (int) old, FA, d->d_F, NULL, d->d_cpd2, d->rs) ||
+        nla_memcpy_d2h(d->h_cpd2, d->d_cpd2, sizeof(double) * (size_t) nb, d->rs)) MFAIL(d, "distance pass ahead failed");
+    if (nlms && (nla_k_mlsl_dist2(n, d->ld, A, N, d->d_LM, (int) nlms, d->d_D2, d->rs) ||
+                 nla_k_mlsl_rowmin(d->d_D2, (int) nlms, N, (int) nlms, FA, d->d_LF, NULL, d->d_cld2, d->rs) ||
+                 nla_memcpy_d2h(d->h_cld2, d->d_cld2, sizeof(double) * (size_t) N, d->rs))) MFAIL(d, "distance pass ahead failed");
+    if (nla_event_record(d->ev_ahead, d->rs)) MFAIL(d, "distance pass ahead failed");
+    d->ahead_old = old; d->ahead_nlms = nlms; d->ahead_words = d->words_used; d->ahead_sobol = d->sobol_next;
+    d->ahead_valid = 1;
     return 0;
 }
 
@@ -387,9 +470,13 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
      * the NEXT iteration's words are generated on a stream of their own beside the distance pass and the local searches.  Hand-over
      * = a host synchronisation of that stream before the sampling kernel reads them. */
     D.prefetch = !host;
+#ifndef NLA_MLSL_NO_AHEAD
+    D.ahead = !host && D.world == 1 && D.ev.kind == NLA_EVAL_DEVICE;
+#endif
     D.prefetched_at = ~0ULL;
     D.rs = (D.st && D.prefetch) ? nla_stream_create_background() : D.st;
     D.ev_samples = nla_event_create();
+    D.ev_ahead = nla_event_create();
     {
         /* "amd_mlsl_seg_regens": the segment length of this run's stream (NLA_MT_SEG_REGENS = 1024 is the layout every other algorithm
          * uses) — 64 makes 205 wavefronts of the 13 above; measured at config 4 (MI355X, round 5): 15.9 ms per iteration at 1024, 14.7 at
@@ -420,7 +507,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
     cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
-    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !D.ev_samples || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !D.ev_samples || !D.ev_ahead || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         nla_comm_agree_ready(D.comm, 0);
@@ -478,7 +565,8 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 #define DEVFAIL() do { nla_stop_msg(stop, "device engine: %s", D.err); ret = NLOPT_FAILURE; goto done; } while (0)
 #define PREFETCH_NOW() do { if (prefetch_due) { prefetch_due = 0; \
         if (nla_mtstream_fill(D.mts, D.words_used, 2ULL * (uint64_t) n * (uint64_t) D.N, D.d_words)) { snprintf(D.err, sizeof D.err, "MT stream fill failed"); DEVFAIL(); } \
-        D.prefetched_at = D.words_used; } } while (0)
+        D.prefetched_at = D.words_used; } \
+    if (ahead_due) { ahead_due = 0; if (mlsl_enqueue_ahead(&D, n)) DEVFAIL(); } } while (0)
 /* the sampling phase's distance pass (find_closest_pt + pts_update_newpt, find_closest_lm) for the N new points in rows old .. old + N - 1:
  * everything it needs is on the device once the sampling kernel has run — the points, their f, the old points' closest_pt_d and flags
  * (uploaded here: the new rows' entries are set before) — so with a device objective on one rank it is ENQUEUED RIGHT BEHIND THE
@@ -538,7 +626,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     while (ret == NLOPT_SUCCESS) {
         double R, t0 = nla_seconds();
         size_t old = D.npts, used = 0, idx;
-        int remaining, prefetch_due = 0, dist_enqueued = 0, pairs_enqueued = 0;
+        int remaining, prefetch_due = 0, ahead_due = 0, dist_enqueued = 0, pairs_enqueued = 0, ahead_hit;
         mlsl_pairs_job pairs_job;
         GET_MINF();                                                            /* mlsl.c:347 */
         AGREE();
@@ -546,7 +634,11 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 
         /* ---- sampling phase (mlsl.c:349-374) ---- */
         if (grow_pts(&D, old + (size_t) D.N)) DEVFAIL();
-        if (D.d_V) {                                                           /* nlopt_sobol_next, mlsl.c:355 */
+        ahead_hit = D.ahead_valid && D.ahead_old == old && (D.d_V ? D.ahead_sobol == D.sobol_next : D.ahead_words == D.words_used);
+        D.ahead_valid = 0;
+        if (ahead_hit) {
+            /* the samples were made beside the last local phase (mlsl_enqueue_ahead): nothing to launch for them */
+        } else if (D.d_V) {                                                    /* nlopt_sobol_next, mlsl.c:355 */
             if ((uint64_t) D.sobol_next + (uint64_t) D.N >= 4294967295ULL) { snprintf(D.err, sizeof D.err, "Sobol sequence exhausted (2^32-1 points)"); DEVFAIL(); }
             if (nla_k_mlsl_sobol_rows(n, D.ld, D.d_lb, D.d_ub, D.d_V, D.sobol_next, D.N, D.d_P + old * (size_t) D.ld, D.st) ||
                 (!host && EVAL_ROWS(D.d_P + old * (size_t) D.ld, D.N, D.d_F + old))) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
@@ -562,9 +654,26 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
          * that the distance pass can be enqueued before the host looks at a single value) */
         for (i = 0; i < D.N; ++i) { D.minimized[old + (size_t) i] = 0; D.cpd[old + (size_t) i] = HUGE_VAL; D.cld[old + (size_t) i] = HUGE_VAL; }
         dist_enqueued = 0;
+        if (ahead_hit) {
+            /* what is left of the distance pass: the new rows against the minima found since (this stream's work waits for the rows) */
+            const size_t l0 = D.ahead_nlms, lc = D.nlms - D.ahead_nlms;
+            size_t j;
+            if (nla_stream_wait_event(D.st, D.ev_ahead)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+            if (lc && (need_D(&D, (size_t) D.N * lc) ||
+                       nla_k_mlsl_dist2(n, D.ld, D.d_P + old * (size_t) D.ld, D.N, D.d_LM + l0 * (size_t) D.ld, (int) lc, D.d_D, D.st) ||
+                       nla_k_mlsl_rowmin(D.d_D, (int) lc, D.N, (int) lc, D.d_F + old, D.d_LF + l0, NULL, D.d_tmp, D.st) ||
+                       nla_memcpy_d2h(D.cld + old, D.d_tmp, sizeof(double) * (size_t) D.N, D.st))) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+            if (nla_event_sync(D.ev_ahead)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
+            memcpy(Fnew, D.Fnew2, sizeof(double) * (size_t) D.N);
+            if (st) ++st->mlsl_sampled_ahead;
+            for (j = 0; j < old + (size_t) D.N; ++j) if (D.h_cpd2[j] < D.cpd[j]) D.cpd[j] = D.h_cpd2[j];
+            dist_enqueued = 1;
+        } else
         if (host ? nla_memcpy_d2h(D.h_rows, D.d_P + old * (size_t) D.ld, sizeof(double) * (size_t) D.N * (size_t) D.ld, D.st)
                  : nla_memcpy_d2h(Fnew, D.d_F + old, sizeof(double) * (size_t) D.N, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
-        if (!host && D.world == 1) {
+        if (ahead_hit) {
+            /* (everything is enqueued or done) */
+        } else if (!host && D.world == 1) {
             /* wait for the values only (an event behind their copy), with the distance pass already behind them on the stream */
             if (nla_event_record(D.ev_samples, D.st)) { snprintf(D.err, sizeof D.err, "sampling failed"); DEVFAIL(); }
             ENQUEUE_DISTANCES();
@@ -598,10 +707,13 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
          * They go out right in front of the local searches' launch instead (PREFETCH_NOW below), on a background-priority stream: the
          * searches' 300 workgroups leave most of every compute unit free for 6 ms */
         prefetch_due = D.prefetch && !D.d_V;
+        ahead_due = D.ahead;
         if (!dist_enqueued) ENQUEUE_DISTANCES();
         {
             const int na = D.N;
             if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
+            if (ahead_hit && D.ahead_nlms)                                      /* closest_lm_d: the minima known when the rows were made | those found since */
+                for (i = 0; i < na; ++i) if (D.h_cld2[i] < D.cld[old + (size_t) i]) D.cld[old + (size_t) i] = D.h_cld2[i];
             if (D.world > 1 && (min_over_ranks(&D, D.cpd, D.npts) || (D.nlms && min_over_ranks(&D, D.cld + old, (size_t) na)))) {
                 snprintf(D.err, sizeof D.err, "all-gather of the distance minima failed: %s", nlopt_amd_comm_error(D.comm)); DEVFAIL();
             }

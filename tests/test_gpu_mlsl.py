@@ -65,6 +65,9 @@ def test_mlsl_reaches_the_oracles_result(obj, n, ns, seed, kw, rugged):
     a = run_amd(obj, n, ns, seed, **kw)
     p = O.run_port_mlsl(obj, n, ns, seed, **kw)
     assert a["ret"] == p["ret"], (a, p["ret"])
+    # every sampling phase but the first was computed beside the local phase before it (mlsl_driver.c, mlsl_enqueue_ahead)
+    its = a["stats"]["generations"]
+    assert max(its - 1, 0) <= a["stats"]["mlsl_sampled_ahead"] <= its, a["stats"]
     nloc = len(p["floc"])
     assert abs(a["minf"] - p["minf"]) <= 1e-7 * max(abs(p["minf"]), 1.0)
     assert np.allclose(a["x"], p["x"], rtol=1e-5, atol=1e-6 * max(np.abs(p["x"]).max(), 1.0))
@@ -149,6 +152,7 @@ def test_mlsl_lds_sobol_sampling_matches_the_oracle(obj, n, ns, seed, kw):
     p = O.run_port_mlsl(obj, n, ns, seed, lds=True, **kw)
     assert a["ret"] == p["ret"], (a["err"], p["ret"])
     assert a["stats"]["mt_words"] == 0 and p["words"] == 0
+    assert max(a["stats"]["generations"] - 1, 0) <= a["stats"]["mlsl_sampled_ahead"] <= a["stats"]["generations"], a["stats"]   # (Sobol rows ahead too)
     assert abs(a["minf"] - p["minf"]) <= 1e-7 * max(abs(p["minf"]), 1.0)
     fs = a["trace"][a["trace"]["kind"] == 3]["f"]
     if p["ret"] != nlopt_amd.MAXEVAL_REACHED:
@@ -166,16 +170,18 @@ def _dist2_reference(A, B):
     return d
 
 
-@pytest.mark.parametrize("n,na,nb", [(4096, 70, 130), (257, 64, 64), (5, 1, 3), (33, 129, 65), (512, 200, 1000), (1, 1, 1), (64, 63, 193)])
+@pytest.mark.parametrize("n,na,nb", [(4096, 70, 130), (257, 64, 64), (5, 1, 3), (33, 129, 65), (512, 200, 1000), (1, 1, 1), (64, 63, 193),
+                                     (31, 33, 129), (34, 9, 257), (2, 40, 128), (63, 8, 127), (96, 31, 1)])
 def test_pair_distance_kernel_is_the_sequential_sum(n, na, nb):
     """mlsl_dist2_kernel (hip/mlsl_kernels.hip): the squared distance of every (new point, point) pair, bit for bit the serial sum of
     mlsl.c:119-125 — what the closest-point tests (`cpd <= R*R`, mlsl.c:208-209) are decided on.  Ragged tile edges, n not a multiple
-    of the coordinate tile (round 4: ran on the device, the register-tiled kernel became the only one)."""
+    of the coordinate tile (round 4: ran on the device, the register-tiled kernel became the only one; round 5: the rows of A through the
+    scalar unit, coordinates in pairs — odd n, a single coordinate, and the rows' padding poisoned with NaN: it must not be read)."""
     L = nlopt_amd.lib()
     L.nla_k_mlsl_dist2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(n * 1000 + na)
     ld = (n + 1) & ~1
-    A = np.zeros((na, ld)); B = np.zeros((nb, ld))
+    A = np.full((na, ld), np.nan); B = np.full((nb, ld), np.nan)
     A[:, :n] = rng.uniform(-32.768, 32.768, (na, n)); B[:, :n] = rng.uniform(-32.768, 32.768, (nb, n))
     B[0, :n] = A[0, :n]                                   # a zero distance
     dA, dB, dD = nlopt_amd.DevBuf.from_array(A), nlopt_amd.DevBuf.from_array(B), nlopt_amd.DevBuf(8 * na * nb)
