@@ -23,21 +23,26 @@
  * of the subtraction, 2 LDS reads per 16 pairs instead of 8: slower, 2.54 against 2.17 ms for 1000 x 4000 pairs at n = 4096 and 1.54
  * against 1.21 ms for 1000 x 1800 (profiles/r05_mlsl_ahead_ab.txt) — scalar loads and LDS reads share one counter, every wait for
  * either is a wait for both.  Deleted.) */
-#define DR 64          /* pairs tile edge of the register-tiled kernel */
 #define DKR 32         /* coordinates per LDS tile */
+/* T = pairs per thread and direction: the workgroup's tile is 16 T x 16 T pairs (T = 4: 64 x 64, the throughput shape; T = 2: 32 x 32 — a
+ * quarter of the work per workgroup for the calls that have few pairs: a workgroup walks all n coordinates of its tile alone, 1.1 ms at
+ * n = 4096 for a 64 x 64 tile whatever the number of tiles — the 1000 x 300 pairs of new samples against new minima, 80 tiles, took
+ * those 1.1 ms (profiles/r05_mlsl_timeline_ahead.txt) */
+template <int T>
 __global__ __launch_bounds__(256) void mlsl_dist2_kernel(int n, int ld, const double *__restrict__ A, int na,
                                                          const double *__restrict__ B, int nb, double *__restrict__ D)
 {
+    constexpr int DR = 16 * T;
     __shared__ double sa[DR][DKR + 1], sb[DR][DKR + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i0 = blockIdx.y * DR, j0 = blockIdx.x * DR;
-    double d[4][4];
+    double d[T][T];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < T; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[r][c] = 0.;
+        for (int c = 0; c < T; ++c) d[r][c] = 0.;
     /* the NEXT coordinate tile travels from global memory into registers while this one is being summed out of LDS (a thread stages
-     * 8 + 8 values per tile: element q * 256 + tid of the 64 x 32 tile, row = e / 32 — a wavefront reads two 256-byte row pieces) */
+     * 2 T + 2 T values per tile: element q * 256 + tid of the DR x 32 tile, row = e / 32 — a wavefront reads two 256-byte row pieces) */
     constexpr int PER = DR * DKR / 256;
     double pa[PER], pb[PER];
     auto fetch = [&](int k0) {
@@ -61,24 +66,23 @@ __global__ __launch_bounds__(256) void mlsl_dist2_kernel(int n, int ld, const do
         __syncthreads();
         if (k0 + DKR < n) fetch(k0 + DKR);
         for (int k = 0; k < kc; ++k) {
-            double a[4], b[4];
+            double a[T], b[T];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = sa[ty + 16 * r][k]; b[r] = sb[tx + 16 * r][k]; }
+            for (int r = 0; r < T; ++r) { a[r] = sa[ty + 16 * r][k]; b[r] = sb[tx + 16 * r][k]; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < T; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { const double dx = a[r] - b[c]; d[r][c] += dx * dx; }
+                for (int c = 0; c < T; ++c) { const double dx = a[r] - b[c]; d[r][c] += dx * dx; }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < T; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < T; ++c) {
             const int i = i0 + ty + 16 * r, j = j0 + tx + 16 * c;
             if (i < na && j < nb) D[(size_t) i * nb + j] = d[r][c];
         }
 }
-#define DIST2_GRID(na, nb) dim3((unsigned) (((nb) + DR - 1) / DR), (unsigned) (((na) + DR - 1) / DR))
 
 /* out[i] = min(init[i], min_j { D[i][j] : FB[j] < FA[i] })        (one wavefront per row i) */
 __global__ __launch_bounds__(256) void mlsl_rowmin_kernel(const double *__restrict__ D, int ldd, int na, int nb, const double *__restrict__ FA,
@@ -134,10 +138,18 @@ extern "C" int nla_k_mlsl_sobol_rows(int n, int ld, const double *lb, const doub
     return 0;
 }
 
+#ifndef NLA_DIST2_SMALL_BELOW
+#define NLA_DIST2_SMALL_BELOW 400
+#endif
 extern "C" int nla_k_mlsl_dist2(int n, int ld, const double *A, int na, const double *B, int nb, double *D, void *stream)
 {
     if (na <= 0 || nb <= 0) return 0;
-    hipLaunchKernelGGL(mlsl_dist2_kernel, DIST2_GRID(na, nb), dim3(256), 0, (hipStream_t) stream, n, ld, A, na, B, nb, D);
+    /* few 64 x 64 tiles: the small tile (measured alone, MI355X, n = 4096, profiles/r05_mlsl_ahead_ab.txt: 1000 x 300 pairs 0.38 against
+     * 0.71 ms, 305 x 4000 0.91 against 1.09 — but 1000 x 1800, 464 tiles, 1.30 against 1.21 and 305 x 8000 1.63 against 1.58) */
+    if ((long) ((na + 63) / 64) * (long) ((nb + 63) / 64) <= NLA_DIST2_SMALL_BELOW)
+        hipLaunchKernelGGL(mlsl_dist2_kernel<2>, dim3((unsigned) ((nb + 31) / 32), (unsigned) ((na + 31) / 32)), dim3(256), 0, (hipStream_t) stream, n, ld, A, na, B, nb, D);
+    else
+        hipLaunchKernelGGL(mlsl_dist2_kernel<4>, dim3((unsigned) ((nb + 63) / 64), (unsigned) ((na + 63) / 64)), dim3(256), 0, (hipStream_t) stream, n, ld, A, na, B, nb, D);
     NLA_LAUNCH_CHECK();
     return 0;
 }

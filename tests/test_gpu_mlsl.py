@@ -171,7 +171,8 @@ def _dist2_reference(A, B):
 
 
 @pytest.mark.parametrize("n,na,nb", [(4096, 70, 130), (257, 64, 64), (5, 1, 3), (33, 129, 65), (512, 200, 1000), (1, 1, 1), (64, 63, 193),
-                                     (31, 33, 129), (34, 9, 257), (2, 40, 128), (63, 8, 127), (96, 31, 1)])
+                                     (31, 33, 129), (34, 9, 257), (2, 40, 128), (63, 8, 127), (96, 31, 1),
+                                     (33, 1025, 2049), (40, 1100, 2000)])      # (more than 400 tiles of 64 x 64: the large-tile instance)
 def test_pair_distance_kernel_is_the_sequential_sum(n, na, nb):
     """mlsl_dist2_kernel (hip/mlsl_kernels.hip): the squared distance of every (new point, point) pair, bit for bit the serial sum of
     mlsl.c:119-125 — what the closest-point tests (`cpd <= R*R`, mlsl.c:208-209) are decided on.  Ragged tile edges, n not a multiple

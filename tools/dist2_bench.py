@@ -21,7 +21,7 @@ L.nla_stream_sync.argtypes = [C.c_void_p]
 st = L.nla_stream_create()
 e0, e1 = L.nla_event_create(), L.nla_event_create()
 rng = np.random.default_rng(1)
-for n, na, nb in [(4096, 1000, 4000), (4096, 1000, 8000), (4096, 305, 4000), (4096, 1000, 1800), (512, 1000, 4000), (64, 1000, 16000)]:
+for n, na, nb in [(4096, 1000, 300), (4096, 305, 300), (4096, 305, 4000), (4096, 1000, 1800), (4096, 305, 8000), (4096, 1000, 4000), (4096, 1000, 8000), (512, 1000, 4000), (64, 1000, 16000)]:
     ld = (n + 1) & ~1
     dA = nlopt_amd.DevBuf.from_array(rng.uniform(-30, 30, (na, ld)))
     dB = nlopt_amd.DevBuf.from_array(rng.uniform(-30, 30, (nb, ld)))
