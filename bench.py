@@ -868,6 +868,11 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                      "avg_algorithmic_bytes_per_launch": bytes_dom / launches if launches else None},
         "phases": phases, "total_seconds_incl_setup": t_total, "final_result": int(ret), "minf": minf,
     }
+    if a.workload == "mlsl" and d.get("mlsl_sampled_ahead"):
+        # round 5: the next iteration's sampling phase (points, values, pair distances: fp64-arithmetic-bound) runs BESIDE the searches' launch
+        # (mlsl_driver.c, mlsl_enqueue_ahead): the iteration is shorter, the launch itself longer than alone (6.0 -> 7.4 ms on one box)
+        out["roofline"]["co_running"] = "next iteration's mlsl_dist2_kernel (fp64-bound); alone: frac 0.25-0.29, r05_mlsl_ahead_ab.txt"
+        out["phases"]["iterations_sampled_ahead"] = int(d["mlsl_sampled_ahead"])
     if roof_extra is not None:
         # the line's `roofline` names the dominant kernel; the HBM-side figure of the passes that do move data is kept beside it
         out["roofline_hbm_passes"] = out["roofline"]

@@ -271,6 +271,7 @@ static int mlsl_enqueue_ahead(mlsl_dev *d, int n)
     const double *A, *FA;
     d->ahead_valid = 0;
     if (d->d_V && (uint64_t) d->sobol_next + (uint64_t) N >= 4294967295ULL) return 0;     /* (the iteration itself reports the exhausted sequence) */
+    if ((size_t) N * cols > ((size_t) 1 << 29)) { d->ahead = 0; return 0; }               /* a second distance matrix above 4 GiB: not worth the memory */
     if (grow_pts(d, old + (size_t) N) || ahead_buffers(d, (size_t) N * cols)) return -1;
     A = d->d_P + old * (size_t) d->ld; FA = d->d_F + old;
     if (d->d_V) {
@@ -470,9 +471,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
      * the NEXT iteration's words are generated on a stream of their own beside the distance pass and the local searches.  Hand-over
      * = a host synchronisation of that stream before the sampling kernel reads them. */
     D.prefetch = !host;
-#ifndef NLA_MLSL_NO_AHEAD
-    D.ahead = !host && D.world == 1 && D.ev.kind == NLA_EVAL_DEVICE;
-#endif
+    /* (not with the sums in the reference's order, amd_exact_dot = 1: that launch is one chain of dependent fp64 additions per search,
+     * every issue slot the distance pass takes on its SIMD delays the chain — measured: 103 -> 117 ms per launch, round 5) */
+    D.ahead = !host && D.world == 1 && D.ev.kind == NLA_EVAL_DEVICE && !use_cobyla && !nla_exact_mode_for(opt, local_opt, &D.ev);
     D.prefetched_at = ~0ULL;
     D.rs = (D.st && D.prefetch) ? nla_stream_create_background() : D.st;
     D.ev_samples = nla_event_create();

@@ -19,4 +19,9 @@ print("gens_to_ftol", d["gens_to_ftol"]["identical_to_reference"], d["gens_to_ft
 PY
 timeout -k 5 300 python bench.py --steps 20 --warmup 5 --headline-only --no-cpu-baseline --detail $O/bench_driver_steps_detail.json > $O/bench_driver_steps.json 2>/dev/null; python -c "
 import json; d=json.load(open('$O/bench_driver_steps_detail.json')); print('headline with the driver\'s --steps 20 --warmup 5: %.0f evals/s frac %.3f useful %.3f pinned %s' % (d['value'], d['roofline']['frac'], d['roofline']['frac_useful'], d['pinned_run']['identical_to_reference']))"
+for w in mlsl isres; do
+  timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $O/k_$w -o $w -- python bench.py --workload $w --steps $([ $w = mlsl ] && echo 2 || echo 3) --warmup 1 --no-cpu-baseline > $O/bench_${w}_under_rocprof.json 2> $O/k_$w.err
+  f=$(find $O/k_$w -name '*.db' | head -1); python profiles/summarize_rocpd.py $f > $O/${w}_kernel_stats.csv; [ $w = mlsl ] && python profiles/summarize_rocpd.py $f --timeline 0 400 > $O/mlsl_timeline.txt; rm -rf $O/k_$w
+  head -6 $O/${w}_kernel_stats.csv | cut -c1-110
+done
 echo "elapsed $(( $(date +%s) - $(cat $O/t0) )) s"
