@@ -464,6 +464,8 @@ typedef struct {
 typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, tolg; int32_t maxeval, exact; double sign;
                  const double *xtol_abs, *x_weights; const int32_t *abort;
                  double *ftrace; int64_t ftrace_cap;     /* NULL, or count x ftrace_cap doubles: f of every evaluation of search i, in order */
+                 int32_t *done;                          /* NULL, or a device counter every search adds 1 to when it ends (agent-scope atomic; never reset: the
+                                                            reader keeps the count it started from) — what nla_k_gate waits on, see nla_local_ctx_finished_counter */
                } nla_lbfgs_params;
 typedef struct { double f; int32_t ret, nevals, iterm, cols; } nla_lbfgs_result;   /* cols = history columns streamed: sum over iterations of k */
 size_t nla_lbfgs_work_doubles(int ld, int mf, int count);     /* doubles of `work` */
@@ -489,6 +491,7 @@ typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, rho_init, sigma_
                  int32_t maxeval, inner_maxeval, inner_gradients, always_improve; int32_t exact, pad; double sign;
                  const double *xtol_abs, *x_weights; const int32_t *abort;
                  double *ftrace; int64_t ftrace_cap;     /* as for LD_LBFGS; indexed by objective calls (the uncounted call included) */
+                 int32_t *done;                          /* as for LD_LBFGS */
                } nla_mma_params;
 size_t nla_mma_work_doubles(int ld, int count);               /* doubles of `work` */
 size_t nla_mma_save_bytes(void);
@@ -577,6 +580,10 @@ int nla_event_record(void *ev, void *stream);
 int nla_event_sync(void *ev);
 float nla_event_elapsed_ms(void *ev0, void *ev1);
 int nla_stream_wait_event(void *stream, void *ev);
+/* one wavefront that holds the stream's following work back until *counter - from >= need (agent-scope loads; counter in
+ * nla_dev_malloc_uncached memory) or timeout_ms have passed — how work enqueued BESIDE a batch of local searches starts when part of
+ * them have finished (mlsl_driver.c).  The emulated device returns at once. */
+int nla_k_gate(const int32_t *counter, int32_t from, int32_t need, double timeout_ms, void *stream);
 const char *nla_dev_error_string(int err);
 /* code objects loaded at run time (user device objectives) */
 void *nla_module_load_file(const char *path);

@@ -428,6 +428,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(LB_WAVES_P
     }
     if (tid == 0) {
         out[inst].f = fval; out[inst].ret = lb_result_of_iterm(c.iterm); out[inst].nevals = nevals; out[inst].iterm = c.iterm; out[inst].cols = cols;
+        if (P.done) __hip_atomic_fetch_add(P.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (EXT) E.req[inst].state = 2;
     }
 #undef MDOT

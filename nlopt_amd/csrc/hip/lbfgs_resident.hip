@@ -837,6 +837,7 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     PROF_STORE;
     if (tid == 0) {
         out[inst].f = C.fval; out[inst].ret = lb_result_of_iterm(C.c.iterm); out[inst].nevals = C.nevals; out[inst].iterm = C.c.iterm; out[inst].cols = C.cols;
+        if (P.done) __hip_atomic_fetch_add(P.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef COLX
 #undef COLG

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(LB_T) void mma_batch_kernel(int n, int ld, int coun
     /* iterm: objective calls made (what MLSL's counting wrapper sees, mlsl.c:246-251); cols: outer iterations */
     if (tid == 0) {
         out[inst].f = minf; out[inst].ret = ret; out[inst].nevals = nevals; out[inst].iterm = fcalls; out[inst].cols = k;
+        if (P.done) __hip_atomic_fetch_add(P.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (EXT) E.req[inst].state = 2;
     }
 #undef MMA_EVAL

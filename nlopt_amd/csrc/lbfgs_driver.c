@@ -56,6 +56,7 @@ struct nla_local_ctx {
     int32_t *h_list, *d_list;      /* user objective: indices of the waiting searches */
     double *d_ftrace; int64_t ftrace_cap;   /* optional per-evaluation f trace (nla_local_ctx_set_ftrace) */
     int (*after_launch)(void *); void *after_arg;   /* one-shot: called right behind the next run's kernel launch (nla_local_ctx_after_launch) */
+    int32_t *d_done; int32_t done_expected;         /* optional (nla_local_ctx_finished_counter): searches ended so far, on the device / launched so far */
 };
 
 void nla_local_ctx_destroy(nla_local_ctx *c)
@@ -65,6 +66,7 @@ void nla_local_ctx_destroy(nla_local_ctx *c)
     nla_dev_free(c->d_xtol_abs); nla_dev_free(c->d_x_weights);
     nla_dev_free(c->ext.req); nla_dev_free(c->ext.EX); nla_dev_free(c->ext.EG); nla_dev_free(c->ext.EF); nla_dev_free(c->ext.save);
     nla_dev_free(c->d_list); nla_dev_free(c->d_ftrace);
+    if (c->d_done) nla_dev_free_uncached(c->d_done);
     nla_host_free(c->h_abort); nla_host_free(c->h_req); nla_host_free(c->h_x); nla_host_free(c->h_g); nla_host_free(c->h_f);
     nla_host_free(c->h_list);
     nla_event_destroy(c->ev0); nla_event_destroy(c->ev1);
@@ -129,6 +131,26 @@ void nla_local_ctx_set_stats(nla_local_ctx *c, nlopt_amd_stats *stats) { if (c) 
  * it starts the moment the last search ends (MLSL: the minimisers' distances to the point set).  One-shot; device objectives only (a
  * run that goes through host evaluations calls it before it returns, with the searches finished).  A nonzero return fails the run. */
 void nla_local_ctx_after_launch(nla_local_ctx *c, int (*fn)(void *), void *arg) { if (c) { c->after_launch = fn; c->after_arg = arg; } }
+
+/* device objectives: a counter on the device that every search of this context's launches adds 1 to when it ends (never reset).
+ * nla_local_ctx_count_finished switches it on (0, or -1: no memory / searches that evaluate on the host); nla_local_ctx_finished_counter
+ * returns it (NULL: not switched on) and in *from its value once everything launched so far has ended. */
+int nla_local_ctx_count_finished(nla_local_ctx *c)
+{
+    if (!c || c->ev.kind != NLA_EVAL_DEVICE) return -1;
+    if (c->d_done) return 0;
+    c->d_done = (int32_t *) nla_dev_malloc_uncached(sizeof(int32_t));
+    if (!c->d_done) return -1;
+    if (nla_memset(c->d_done, 0, sizeof(int32_t), c->st) || nla_stream_sync(c->st)) { nla_dev_free_uncached(c->d_done); c->d_done = NULL; return -1; }
+    c->done_expected = 0;
+    return 0;
+}
+const int32_t *nla_local_ctx_finished_counter(nla_local_ctx *c, int32_t *from)
+{
+    if (!c || !c->d_done) return NULL;
+    *from = c->done_expected;
+    return c->d_done;
+}
 int nla_local_ctx_alg(const nla_local_ctx *c) { return c->alg; }
 double *nla_local_ctx_X(nla_local_ctx *c) { return c->d_X; }
 
@@ -174,12 +196,12 @@ static int launch(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, cons
         nla_mma_params P = c->mma;
         P.minf_max = prm->minf_max; P.ftol_rel = prm->ftol_rel; P.ftol_abs = prm->ftol_abs; P.xtol_rel = prm->xtol_rel; P.maxeval = prm->maxeval;
         P.exact = (c->exact & 1); P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.x_weights = c->d_x_weights; P.abort = c->h_abort;
-        P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap;
+        P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap; P.done = ext ? NULL : c->d_done;
         return nla_k_mma_batch(obj, c->n, c->ld, count, c->d_lb, c->d_ub, c->d_sigma_init, c->d_X, c->d_work, &P, c->d_res, ext, c->st);
     } else {
         nla_lbfgs_params P = *prm;
         P.exact = c->exact; P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.x_weights = c->d_x_weights; P.abort = c->h_abort;
-        P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap;
+        P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap; P.done = ext ? NULL : c->d_done;
         return nla_k_lbfgs_batch(obj, c->n, c->ld, c->mf, count, c->d_lb, c->d_ub, c->d_X, c->d_work, c->d_iwork, c->d_hist, &P, c->d_res, ext, c->st);
     }
 }
@@ -209,6 +231,7 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
     nla_event_record(c->ev0, c->st);
     if (c->ev.kind == NLA_EVAL_DEVICE) {
         if ((rc = launch(c, count, prm, NULL))) return rc;
+        if (c->d_done) c->done_expected = (int32_t) ((uint32_t) c->done_expected + (uint32_t) count);
         nla_event_record(c->ev1, c->st);
         if (c->after_launch) { int (*fn)(void *) = c->after_launch; c->after_launch = NULL; if ((rc = fn(c->after_arg))) return rc; }
         /* watch first, copy afterwards: a device-to-host copy into pageable memory (the caller's result record may live on its

@@ -99,9 +99,17 @@ typedef struct {
     double *Fnew2, *h_cld2;          /* pinned, N each */
     double *d_D2; size_t dcap2;
     double *d_cpd2, *h_cpd2, *h_inf, *d_cld2; size_t cap2;
+    /* ... and it STARTS when half of the searches it runs beside have ended (nla_k_gate on the searches' counter of finished ones): a
+     * launch lasts as long as its longest search (2.2 - 6.0 ms at config 4, 3.7 on average), and whatever else the device works on
+     * slows the searches by a quarter while it runs — on other compute units too (CU-masked streams: same loss), so no question of issue
+     * slots or LDS — behind the gate that is the launch's thinning second half, not all of it (config 4: 9.7 -> 9.4 ms per iteration) */
+    const int32_t *gate_counter; int32_t gate_from, gate_need;
     char err[200];
 } mlsl_dev;
 
+#ifndef NLA_MLSL_GATE_PCT
+#define NLA_MLSL_GATE_PCT 50        /* the sampling phase enqueued ahead starts when this share of the batch's searches have ended (0: at once) */
+#endif
 #define MFAIL(d, ...) do { snprintf((d)->err, sizeof (d)->err, __VA_ARGS__); return -1; } while (0)
 #define MCK(d, call) do { int rc_ = (call); if (rc_) MFAIL(d, "%s failed: %s", #call, nla_dev_error_string(rc_)); } while (0)
 
@@ -274,6 +282,7 @@ static int mlsl_enqueue_ahead(mlsl_dev *d, int n)
     if ((size_t) N * cols > ((size_t) 1 << 29)) { d->ahead = 0; return 0; }               /* a second distance matrix above 4 GiB: not worth the memory */
     if (grow_pts(d, old + (size_t) N) || ahead_buffers(d, (size_t) N * cols)) return -1;
     A = d->d_P + old * (size_t) d->ld; FA = d->d_F + old;
+    if (d->gate_need > 0 && nla_k_gate(d->gate_counter, d->gate_from, d->gate_need, 50.0, d->rs)) MFAIL(d, "sampling ahead failed");
     if (d->d_V) {
         if (nla_k_mlsl_sobol_rows(n, d->ld, d->d_lb, d->d_ub, d->d_V, d->sobol_next, N, d->d_P + old * (size_t) d->ld, d->rs) ||
             nla_k_eval(d->obj, n, d->ld, A, N, d->d_F + old, d->rs) ||
@@ -555,6 +564,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
                    : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);
     if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode_for(opt, local_opt, &D.ev), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
+    /* (LD_LBFGS only: LD_MMA's launches are half as long as the distance pass beside them — behind a gate it ends after them and holds the
+     * next iteration up: config 4 with LD_MMA 8.0 -> 8.3 ms per iteration, profiles/r05_mlsl_ahead_ab.txt) */
+    if (D.lb && D.ahead && !use_mma && NLA_MLSL_GATE_PCT > 0 && nla_local_ctx_count_finished(D.lb)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
     if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); nla_comm_agree_ready(D.comm, 0); mfree(&D); nla_host_free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_local_ctx_set_stats(D.lb, st);
     }
@@ -779,7 +791,6 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                     res[0].nevals = 0; res[0].iterm = 0;                            /* the calls were counted one by one (mlsl_counted_f) */
                 }
             } else {
-            PREFETCH_NOW();
             pairs_enqueued = 0;
             if (!host && D.world == 1 && mine > 0) {
                 /* one rank, device objective: the minimisers' distances go out right behind the searches' kernel (they need nothing the
@@ -791,6 +802,11 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 nla_local_ctx_after_launch(D.lb, mlsl_enqueue_pairs, &pairs_job);
                 pairs_enqueued = 1;
             }
+            /* (in front of the launch, behind everything that may allocate: freeing device memory waits for every stream, the gate included) */
+            D.gate_need = 0;
+            if (D.ahead && mine > 0 && (D.gate_counter = nla_local_ctx_finished_counter(D.lb, &D.gate_from))) D.gate_need = (mine * NLA_MLSL_GATE_PCT + 99) / 100;
+            PREFETCH_NOW();
+            D.gate_need = 0;
             if (mine > 0 && nla_local_ctx_run(D.lb, mine, &prm, res_mine, &lstop, NULL)) { snprintf(D.err, sizeof D.err, "local-search batch failed"); DEVFAIL(); }
             if ((!pairs_enqueued && nla_comm_allgather_dev(D.comm, nla_local_ctx_X(D.lb), D.d_LX, sizeof(double) * (size_t) per * (size_t) D.ld, D.st)) ||
                 nla_comm_allgather_host(D.comm, res_mine, res, sizeof *res * (size_t) per, D.st)) {

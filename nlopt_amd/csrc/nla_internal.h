@@ -252,6 +252,8 @@ void nla_local_ctx_destroy(nla_local_ctx *c);
 double *nla_local_ctx_X(nla_local_ctx *c);
 void nla_local_ctx_set_stats(nla_local_ctx *c, nlopt_amd_stats *stats);
 void nla_local_ctx_after_launch(nla_local_ctx *c, int (*fn)(void *), void *arg);
+int nla_local_ctx_count_finished(nla_local_ctx *c);
+const int32_t *nla_local_ctx_finished_counter(nla_local_ctx *c, int32_t *from);
 int nla_local_ctx_set_options(nla_local_ctx *c, int exact, const double *xtol_abs, const double *x_weights);
 int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res, const nla_stopping *stop,
                       int *live_nevals);

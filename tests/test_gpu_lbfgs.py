@@ -101,7 +101,7 @@ def test_lbfgs_host_callback_is_served():
 class _Params(C.Structure):
     _fields_ = [("minf_max", C.c_double), ("ftol_rel", C.c_double), ("ftol_abs", C.c_double), ("xtol_rel", C.c_double), ("tolg", C.c_double),
                 ("maxeval", C.c_int32), ("exact", C.c_int32), ("sign", C.c_double), ("xtol_abs", C.c_void_p), ("x_weights", C.c_void_p),
-                ("abort", C.c_void_p), ("ftrace", C.c_void_p), ("ftrace_cap", C.c_int64)]
+                ("abort", C.c_void_p), ("ftrace", C.c_void_p), ("ftrace_cap", C.c_int64), ("done", C.c_void_p)]
 
 
 class _Result(C.Structure):
