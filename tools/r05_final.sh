@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, final evidence on an MI355X box: the driver's exact GPU suite command, smoke(), the default bench line (compact + detail).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05_final3; mkdir -p $O
+O=gpurun_out/r05_final; mkdir -p $O
 date +%s > $O/t0
 timeout -k 5 900 python -X faulthandler -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $O/gpu_suite.log 2>&1; echo "suite rc=$? $(tail -1 $O/gpu_suite.log)"; grep -v "^  File" $O/gpu_suite.log | grep -i "error\|fatal\|fault\|FAILED" | head -5
 timeout -k 5 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 $O/smoke.log | cut -c1-200)"
