@@ -78,6 +78,7 @@ typedef struct {
     size_t hcap;
     double *h_S, *d_S;              /* bmax x bmax: distance between minimiser c' and start point c of a batch — all the commit walk reads of the batch's matrix */
     double *h_lfall, *d_lfall;      /* bmax: f of the accepted minima by gathered row, +inf for the others (the device-side pts_update_newlm) */
+    double *lf_cand;                /* the same by CANDIDATE (what the commit walk's inner loop reads: no index arithmetic per question) */
     int64_t *h_gi, *d_gi;           /* bmax: gathered row of candidate c */
     double *h_gather; size_t gcap;  /* several ranks: world x count doubles for the element-wise min of the distance minima */
     /* per-batch lists, pinned host side + device side: [idx of all candidates: bmax][idx of this rank's: BATCH_MAX]
@@ -126,7 +127,7 @@ static void mfree(mlsl_dev *d)
     nla_host_free(d->h_rows);
     free(d->h_gather);
     nla_host_free(d->h_D); nla_host_free(d->h_idx); nla_host_free(d->h_lf); nla_host_free(d->h_flags);
-    nla_host_free(d->h_S); nla_host_free(d->h_lfall); nla_host_free(d->h_gi);
+    nla_host_free(d->h_S); nla_host_free(d->h_lfall); nla_host_free(d->h_gi); free(d->lf_cand);
     nla_dev_free(d->d_idx); nla_dev_free(d->d_flags); nla_dev_free(d->d_S); nla_dev_free(d->d_lfall); nla_dev_free(d->d_gi);
     nla_event_destroy(d->ev_samples); nla_event_destroy(d->ev_ahead);
     nla_host_free(d->Fnew2); nla_host_free(d->h_cld2); nla_host_free(d->h_cpd2); nla_host_free(d->h_inf);
@@ -170,6 +171,13 @@ static int grow_pts(mlsl_dev *d, size_t need)
         if (m1) d->minimized = m1;
         if (!c1 || !c2 || !m1) MFAIL(d, "out of pinned memory growing the point set");
     }
+    /* (with the point set, not in the local phase when a row of distances first exceeds it: freeing pinned memory waits for the device —
+     * 0.53 ms + 0.04 ms for the new block between the searches' results and the commit walk, in every iteration that crossed the old
+     * size; host-side API trace of config 4, round 5) */
+    nla_host_free(d->h_D);
+    d->h_D = (double *) nla_host_malloc(sizeof(double) * ncap);
+    d->hcap = d->h_D ? ncap : 0;
+    if (!d->h_D) MFAIL(d, "out of pinned memory growing the point set");
     d->ord = (size_t *) realloc(d->ord, sizeof(size_t) * ncap);
     nP = (double *) nla_dev_malloc(sizeof(double) * ncap * (size_t) d->ld);
     nF = (double *) nla_dev_malloc(sizeof(double) * ncap);
@@ -507,6 +515,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.h_S = (double *) nla_host_malloc(sizeof(double) * (size_t) bmax * (size_t) bmax);
     D.d_S = (double *) nla_dev_malloc(sizeof(double) * (size_t) bmax * (size_t) bmax);
     D.h_lfall = (double *) nla_host_malloc(sizeof(double) * (size_t) bmax);
+    D.lf_cand = (double *) malloc(sizeof(double) * (size_t) bmax);
     D.d_lfall = (double *) nla_dev_malloc(sizeof(double) * (size_t) bmax);
     D.h_gi = (int64_t *) nla_host_malloc(sizeof(int64_t) * (size_t) bmax);
     D.d_gi = (int64_t *) nla_dev_malloc(sizeof(int64_t) * (size_t) bmax);
@@ -517,7 +526,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
     cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
-    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !D.ev_samples || !D.ev_ahead || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.lf_cand || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !D.ev_samples || !D.ev_ahead || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         nla_comm_agree_ready(D.comm, 0);
@@ -820,12 +829,6 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                  * order-independent min that one launch computes once the accepted set is known */
                 const size_t na = (size_t) per * (size_t) D.world;
                 if (need_D(&D, na * D.npts)) DEVFAIL();
-                if (D.npts > D.hcap) {
-                    nla_host_free(D.h_D);
-                    D.hcap = 2 * D.npts;
-                    D.h_D = (double *) nla_host_malloc(sizeof(double) * D.hcap);
-                    if (!D.h_D) { D.hcap = 0; snprintf(D.err, sizeof D.err, "out of pinned memory"); DEVFAIL(); }
-                }
                 if (!pairs_enqueued) {
                     for (c = 0; c < nb; ++c) D.h_gi[c] = (int64_t) GI(c);
                     pairs_job.d = &D; pairs_job.n = n; pairs_job.nb = nb; pairs_job.na = na; pairs_job.ctx_X = NULL; pairs_job.lx_bytes = 0;
@@ -833,6 +836,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 }
                 if (nla_stream_sync(D.st)) { snprintf(D.err, sizeof D.err, "distance pass failed"); DEVFAIL(); }
                 for (c = 0; c < (int) na; ++c) D.h_lfall[c] = HUGE_VAL;
+                for (c = 0; c < nb; ++c) D.lf_cand[c] = HUGE_VAL;
             }
             if (grow_lms(&D, D.nlms + (size_t) nb)) DEVFAIL();
             nacc = 0; nlms0 = D.nlms;
@@ -844,8 +848,14 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 const size_t g = GI(c);
                 /* closest_lm_d of this start as the serial order would see it now: the minima committed earlier in this batch count
                  * (pts_update_newlm, mlsl.c:180-194: those with smaller f than the point's, if closer) */
-                for (cp = 0; cp < c; ++cp)
-                    if (D.h_lfall[GI(cp)] < D.F[r] && D.h_S[(size_t) c * (size_t) nb + (size_t) cp] < cl) cl = D.h_S[(size_t) c * (size_t) nb + (size_t) cp];      /* (h_S[c][cp] = distance of start c to minimiser cp: transposed on the device) */
+                /* (h_S[c][cp] = distance of start c to minimiser cp: transposed on the device.  nb^2 / 2 questions per batch — 46 k at config 4:
+                 * with the gathered-row index GI(cp), a division and a remainder, inside the loop they were the better part of the 0.6 ms the
+                 * device waited for this walk) */
+                {
+                    const double Fr = D.F[r], *Sc = D.h_S + (size_t) c * (size_t) nb, *lfc = D.lf_cand;
+                    for (cp = 0; cp < c; ++cp)
+                        if (lfc[cp] < Fr && Sc[cp] < cl) cl = Sc[cp];
+                }
                 pot = !(cl <= (dlm * R) * (dlm * R));
                 /* nodes between the previous candidate and this one were visited and skipped */
                 remaining -= (int) (cand[c] + 1 - idx);
@@ -890,6 +900,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 D.h_idx[bmax + BATCH_MAX + nacc] = (int64_t) g;
                 D.h_lf[nacc] = lf;
                 D.h_lfall[g] = lf;
+                D.lf_cand[c] = lf;
                 ++nacc;
                 D.LF[D.nlms] = lf;
                 ord_insert(D.lord, D.nlms, D.LF, D.nlms);
@@ -900,7 +911,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
                 else if (nla_stop_time(sp)) ret = NLOPT_MAXTIME_REACHED;
                 /* (pts_update_newlm for this minimum: with the batch's other accepted minima, in one launch below.  A minimum whose commit
                  * ends the run updated nothing in the reference either — the stop tests come first, mlsl.c:417-425 — so it is left out.) */
-                if (ret != NLOPT_SUCCESS) D.h_lfall[g] = HUGE_VAL;
+                if (ret != NLOPT_SUCCESS) { D.h_lfall[g] = HUGE_VAL; D.lf_cand[c] = HUGE_VAL; }
             }
             /* pts_update_newlm (mlsl.c:180-194) for every accepted minimum of the batch at once: closest_lm_d[k] = min over the accepted
              * minima with smaller f than point k of their distance to k — a min, so the order of the commits does not matter.  (The
