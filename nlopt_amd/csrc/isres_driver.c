@@ -133,6 +133,8 @@ static int dev_alloc(isres_dev *d, const double *lb, const double *ub, const nla
     if (!d->rs) return -1;
     d->mts = nla_mtstream_create(d->rs);
     if (!d->mts) return -1;
+    /* (room for 16 generations' stream from the start: 2 (pop - 1) pop words of ranking uniforms + about 4 pop (1 + 2 n) of deviates each) */
+    if (nla_mtstream_expect(d->mts, 16ULL * (2ULL * (uint64_t) (pop > 1 ? pop - 1 : 1) * (uint64_t) pop + 4ULL * (uint64_t) pop * (uint64_t) (1 + 2 * n)))) return -1;
 #define A(ptr, T, count) do { d->ptr = (T *) nla_dev_malloc(sizeof(T) * (size_t) (count)); if (!d->ptr) ok = 0; } while (0)
     A(d_lb, double, ld); A(d_ub, double, ld); A(d_X, double, pop * ld); A(d_S, double, pop * ld);
     A(d_F, double, d->popcap); A(d_PEN, double, d->popcap); A(d_GPEN, double, d->popcap); A(d_FEAS, int32_t, d->popcap);

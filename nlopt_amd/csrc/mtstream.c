@@ -54,6 +54,23 @@ nla_mtstream *nla_mtstream_create_seg(void *stream, int seg_regens)
 
 nla_mtstream *nla_mtstream_create(void *stream) { return nla_mtstream_create_seg(stream, NLA_MT_SEG_REGENS); }
 
+int nla_mtstream_expect(nla_mtstream *s, uint64_t words)
+{
+    uint64_t want = words / s->seg_words + 2;
+    int ncap = s->cap_states;
+    uint32_t *nd;
+    if (want > (1u << 17)) want = 1u << 17;
+    if (want <= (uint64_t) s->cap_states) return 0;
+    while ((uint64_t) ncap < want) ncap *= 2;
+    nd = (uint32_t *) nla_dev_malloc(sizeof(uint32_t) * NLA_MT_N * (size_t) ncap);
+    if (!nd) return -1;
+    if (nla_memcpy_d2d(nd, s->d_states, sizeof(uint32_t) * NLA_MT_N * (size_t) s->nstates, s->stream) || nla_stream_sync(s->stream)) { nla_dev_free(nd); return -1; }
+    nla_dev_free(s->d_states);
+    s->d_states = nd;
+    s->cap_states = ncap;
+    return 0;
+}
+
 void nla_mtstream_destroy(nla_mtstream *s)
 {
     if (!s) return;

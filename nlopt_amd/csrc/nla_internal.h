@@ -165,6 +165,10 @@ int nla_mtstream_rankbits(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_firs
 int nla_mtstream_rankbits_gated(nla_mtstream *s, uint64_t rel_rank0, uint64_t rel_first, uint64_t count, int64_t popm1, int64_t rowwords,
                                 uint64_t *d_bits, int *d_gate, int *d_ticket, int waves_per_cu);   /* in-order gates: nla_k_mt_rankbits_gated */
 int nla_mtstream_reserve(nla_mtstream *s, uint64_t rel_last);
+/* room for the segment states of `words` words of stream from the start (within 2^17 states = 330 MB): the array doubles as the run
+ * consumes its stream, and every doubling frees the old block — a device-wide wait in the middle of whatever runs (ISRES config 3: 3900
+ * states per generation, 1.8 ms per free: host-side API trace, round 5) */
+int nla_mtstream_expect(nla_mtstream *s, uint64_t words);
 /* leave the calling thread's generator as if it had drawn `consumed` words since create */
 int nla_mtstream_finish(nla_mtstream *s, uint64_t consumed);
 
