@@ -78,6 +78,18 @@ def test_isres_driver_over_emulated_device_matches_oracle(world, obj, n, pop, se
             assert 5 * gens <= c <= 6 * gens and (ncon > 0 or c == 5 * gens)
 
 
+def test_isres_generator_state_array_sized_up_front_over_the_emulated_device():
+    """a population large enough for nla_mtstream_expect (mtstream.c) to re-allocate the generator's segment-state array at set-up —
+    16 generations of 2 (pop - 1) pop ranking uniforms are more than the 64 states it starts with (round 5: the array's doublings used
+    to free device memory in the middle of generations) — and the run is still the oracle's, evaluation by evaluation"""
+    obj, n, pop, seed, ncon, gens = "rastrigin", 3, 1300, 4, 1, 2
+    a = dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=gens * pop, ncon=ncon)
+    p = O.run_port_isres(obj, n, pop, seed, nineq=ncon, maxeval=gens * pop)
+    for d in run_world("gpu_isres", a, world=1, extra_env=EMU):
+        _check_against_oracle(d, p)
+        assert np.array_equal(d["f"], p["ftrace"][:len(d["f"])]) and len(d["f"]) == len(p["ftrace"])
+
+
 @pytest.mark.parametrize("world", [1, 2])
 @pytest.mark.parametrize("obj,n,ns,seed,local,lds,maxeval", [
     ("rastrigin", 5, 12, 5, "lbfgs", False, 1500), ("griewank", 6, 40, 3, "lbfgs", False, 3000), ("ackley", 8, 0, 9, "mma", False, 2500),
