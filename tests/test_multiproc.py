@@ -94,7 +94,8 @@ def test_isres_generator_state_array_sized_up_front_over_the_emulated_device():
 @pytest.mark.parametrize("obj,n,ns,seed,local,lds,maxeval", [
     ("rastrigin", 5, 12, 5, "lbfgs", False, 1500), ("griewank", 6, 40, 3, "lbfgs", False, 3000), ("ackley", 8, 0, 9, "mma", False, 2500),
     ("levy", 4, 16, 7, "mma", True, 1200), ("rosenbrock", 4, 12, 9, "lbfgs", True, 2000), ("rastrigin", 6, 20, 11, "default", False, 3000),
-    ("sphere", 5, 6, 2, "default", True, 400)])
+    ("sphere", 5, 6, 2, "default", True, 400),
+    ("ackley", 40, 500, 6, "lbfgs", False, 1600)])      # (n N large enough for the generator's state array to be re-allocated at set-up, nla_mtstream_expect)
 def test_mlsl_driver_over_emulated_device_matches_oracle(world, obj, n, ns, seed, local, lds, maxeval):
     """MLSL with LD_LBFGS / LD_MMA, pseudo-random and Sobol sampling, local searches dealt over the ranks and all-gathered: the
     batched, speculative walk of mlsl_driver.c commits exactly what the serial reference commits — same samples, same local
