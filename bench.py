@@ -426,6 +426,60 @@ def pinned_to_reference(m, n, pop, obj, seed):
             "reference_accepted": ref_acc, "mutations": int(st["evals_mutation"]), "reference_mutations": ref_mut, "identical_to_reference": same}
 
 
+def pinned_isres(n, pop, obj, seed, ncon, numevals, minf, mt_words):
+    """the ISRES run bench.py has just timed against the REAL reference stopped at the same evaluation (tests/golden/
+    full_isres_rastrigin_n256_pop5e4_4ineq.npz `stop_*`: oracle/_ref run with maxeval = g pop + 1 — where the hook's force_stop ends this
+    run, isres.c:195-198): the minimum and the position of the MT19937 stream (every ranking step, every Box-Muller attempt)"""
+    path = os.path.join(ROOT, "tests", "golden", "full_isres_rastrigin_n256_pop5e4_4ineq.npz")
+    if (n, pop, obj, seed, ncon) != (256, 50000, "rastrigin", 42, 4) or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if "stop_evals" not in g.files:
+        return None
+    hit = np.flatnonzero(g["stop_evals"] == numevals)
+    if len(hit) == 0:
+        return {"numevals": int(numevals), "identical_to_reference": None, "note": "the run stopped at an evaluation the fixture has no reference stop for (%s)" % g["stop_evals"].tolist()}
+    k = int(hit[0])
+    ref_minf, ref_words = float(g["stop_minf"][k]), int(g["stop_words"][k])
+    return {"numevals": int(numevals), "generations": k + 1, "minf": minf, "reference_minf": ref_minf, "mt_words": int(mt_words), "reference_mt_words": ref_words,
+            "identical_to_reference": bool(abs(minf - ref_minf) <= 1e-10 * abs(ref_minf) and int(mt_words) == ref_words)}
+
+
+def pinned_mlsl(n, pop, obj, seed, exact, iters_done, numevals, minf, trace):
+    """the MLSL run bench.py has just timed against the REAL reference's run (tests/golden/full_mlsl_ackley_n4096_N1000.npz `long_*`, `stop_*`):
+    every sample, which points were started from and in which order, each search's minimum and evaluation count, iteration by iteration
+    (mlsl.c:349-428).  amd_exact_dot = 1 (the reference's summation order) is the PARITY mode: its evaluation counts — hence numevals and
+    where maxeval would cut — are the reference's.  The default (tree-sum) mode takes the reference's decisions — same samples, same
+    starts in the same order, same searches per iteration, minima to 1e-8 — with evaluation counts that drift by a few per search;
+    the drift is reported."""
+    path = os.path.join(ROOT, "tests", "golden", "full_mlsl_ackley_n4096_N1000.npz")
+    if (n, pop, obj, seed) != (4096, 1000, "ackley", 42) or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if "long_sloc" not in g.files or iters_done < 1 or iters_done > len(g["long_it_nloc"]):
+        return None
+    nloc_ref, nev_ref = int(g["long_it_nloc"][iters_done - 1]), int(g["long_it_nevals"][iters_done - 1]) + 1
+    fs = trace[trace["kind"] == 3]["f"]
+    fl = trace[trace["kind"] == 4]
+    ns_ref = iters_done * pop
+    samples_same = bool(len(fs) >= ns_ref and np.all(np.abs(fs[:ns_ref] - g["long_fsamp"][:ns_ref]) <= 1e-10 * np.maximum(np.abs(g["long_fsamp"][:ns_ref]), 1.0)))
+    starts_same = bool(len(fl) == nloc_ref and np.array_equal(fl["row"], g["long_sloc"][:nloc_ref]))
+    k = min(len(fl), nloc_ref)
+    minima_same = bool(k > 0 and np.all(np.abs(fl["f"][:k] - g["long_floc"][:k]) <= 1e-8 * np.maximum(np.abs(g["long_floc"][:k]), 1.0)))
+    drift = np.abs(fl["accepted"][:k].astype(np.int64) - g["long_eloc"][:k].astype(np.int64))
+    hit = np.flatnonzero(g["stop_evals"] == nev_ref)
+    ref_minf = float(g["stop_minf"][int(hit[0])]) if len(hit) else None
+    minf_same = bool(ref_minf is not None and abs(minf - ref_minf) <= 1e-8 * abs(ref_minf))
+    decisions = samples_same and starts_same and minima_same and minf_same
+    out = {"mode": "amd_exact_dot=1 (parity mode: the reference's summation order)" if exact else "default (tree sums; decisions pinned, evaluation counts drift)",
+           "iterations": int(iters_done), "numevals": int(numevals), "reference_numevals": nev_ref, "local_searches": int(len(fl)), "reference_local_searches": nloc_ref,
+           "minf": minf, "reference_minf": ref_minf, "samples_identical": samples_same, "starts_identical_in_order": starts_same, "minima_within_1e-8": minima_same,
+           "evaluation_count_drift": {"max": int(drift.max()) if k else None, "mean": float(drift.mean()) if k else None, "searches_identical": int((drift == 0).sum())},
+           "decisions_identical_to_reference": bool(decisions),
+           "identical_to_reference": bool(decisions and int(numevals) == nev_ref and (k == 0 or int(drift.max()) == 0))}
+    return out
+
+
 def crs_config5_one_job(a, nlopt_amd, L, rank, world, sync_all, reduce):
     """BASELINE.json config 5 (CRS2_LM Griewank n=4096, pop=1e6) as ONE job over all ranks: the population is sharded BY COORDINATE
     (every rank keeps n/world columns of every row: 32.8 GB / world), each rank runs the gather-sum, mutation and row replacement on
@@ -760,8 +814,8 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
             if gens_done == W + K:
                 o.force_stop()
     o.set_progress(hook)
-    if a.workload == "mlsl" and getattr(a, "exact", False):
-        o.enable_trace((W + K + 2) * (pop + 4096))          # per local search: its evaluation count (the latency model below)
+    if a.workload == "mlsl":
+        o.enable_trace((W + K + 2) * (pop + 4096))          # per local search: its start, minimum and evaluation count (the pin against the reference; the latency model below)
     nlopt_amd.srand(a.seed)                                   # every rank: the same stream (one job)
     t_start = time.perf_counter()
     x, minf, ret = o.optimize_raw(xs)
@@ -868,6 +922,14 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                      "avg_algorithmic_bytes_per_launch": bytes_dom / launches if launches else None},
         "phases": phases, "total_seconds_incl_setup": t_total, "final_result": int(ret), "minf": minf,
     }
+    if world == 1:
+        try:
+            if a.workload == "isres":
+                out["pinned_run"] = pinned_isres(n, pop, a.obj, a.seed, ncon, o.get_numevals(), minf, o.stats()["mt_words"])
+            elif a.local == "lbfgs":
+                out["pinned_run"] = pinned_mlsl(n, pop, a.obj, a.seed, bool(getattr(a, "exact", False)), W + K, o.get_numevals(), minf, o.trace())
+        except Exception as e:
+            out["pinned_run"] = {"error": repr(e)}
     if a.workload == "mlsl" and d.get("mlsl_sampled_ahead"):
         # round 5: the next iteration's sampling phase (points, values, pair distances: fp64-arithmetic-bound) runs BESIDE the searches' launch
         # (mlsl_driver.c, mlsl_enqueue_ahead): the iteration is shorter, the launch itself longer than alone (6.0 -> 7.4 ms on one box)

@@ -271,6 +271,37 @@ int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int64_t i0, do
                          uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                          const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
                          nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *stream);
+/* ---- the same window on a COLUMN-SHARDED population, one rank per device (replaces crs.c:125-156 for a population
+ * dealt over several GPUs).  Rank r holds columns [c0, c0 + nc) of every row (X: N x ld); its launch forms ITS columns of every slot's
+ * trial point and stores them into the slot's row of EVERY rank's TX (rows of ldf >= n doubles; the peers' TX mapped with nla_ipc_open),
+ * raises per-chunk flag words on every rank, and evaluates / resolves exactly as the single-device launch does once a slot's chunks
+ * from all ranks are in: identical f, identical decisions on every rank, no collective call.
+ *   nla_crs_chain_sh_chunks      chunks a rank with `ncols` columns contributes per slot (ncols even where n >= 128: pad column zero)
+ *   nla_crs_chain_sh_table       host image (nla_crs_chain_sh_table_bytes) of the table the kernel reads: rank r's TX / flags / stop words
+ *                                as mapped HERE for every r (own entries: the own buffers), the whole best row, the whole bounds;
+ *                                flags: K_max x chunks_total u32, stop words: nla_crs_chain_sh_stop_bytes — both zero before the first
+ *                                launch, in the same peer-mapped allocation kind as TX
+ *   nla_k_crs_chain_sh           the launch; seq = 1, 2, ... identical on every rank; stopbits: bit 0 force_stop, bit 1 maxtime as this
+ *                                rank sees them; status[K] = (any rank forced, any rank timed, a rank's chunks never arrived);
+ *                                grid_cap >= 2: the launch's workgroups take ticket after ticket, at most that many resident (ranks that
+ *                                SHARE a device — a test box — must all fit the chip at once); 0: one workgroup per ticket
+ *   nla_k_crs_commit_sh          in front of it: accepted whole points -> rows of the slice, control block cleared, whole best row
+ *                                refreshed from a slot (best_slot >= 0) */
+int nla_crs_chain_sh_chunks(int n, int ncols);
+size_t nla_crs_chain_sh_table_bytes(void);
+size_t nla_crs_chain_sh_stop_bytes(void);
+int nla_crs_chain_sh_table(void *host_image, int world, int rank, int c0, int ldf, int chunks_total, int chunk0, void *const *peerTX,
+                           void *const *peerflags, void *const *peerstop, const double *xbest, const double *lbf, const double *ubf);
+int nla_k_crs_chain_sh(int obj, int n, int ncols, int ld, int ldf, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                       const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                       uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                       const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                       nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
+                       const void *table, uint32_t seq, uint32_t stopbits, int grid_cap, void *stream);
+uint32_t nla_crs_chain_sh_tickets(int n, int ncols, int K, int grid_cap);     /* tickets one launch draws (ticket_base of the next) */
+int nla_k_crs_commit_sh(int nc, int ld, int ldf, int c0, double *X, const double *TX, const double *TM, int ncommit,
+                        const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *zero, size_t zero_bytes,
+                        int n, int best_slot, int best_kind, double *xbest, void *stream);
 /* workgroups one launch draws tickets for: K * nla_crs_chain_chunks + 1 (the resolver wavefront's workgroup, hip/crs_chain_resolver.h:
  * the chain — crs.c:135-156, the decisions between evaluations — is advanced by one dedicated wavefront out of registers) */
 uint32_t nla_crs_chain_tickets(int n, int ld, int K);
@@ -570,6 +601,11 @@ int nla_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream);
 int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int nla_memset(void *dst, int value, size_t bytes, void *stream);
 void *nla_stream_create(void);
+void *nla_stream_create_cu_share(int part, int parts);   /* confined to the compute units i with i mod parts == part (hipExtStreamCreateWithCUMask): ranks sharing one device */
+#define NLA_IPC_BYTES 96
+int nla_ipc_export(const void *p, void *blob96);    /* device memory of this process made mappable by another (hipIpcGetMemHandle); 0 = ok */
+void *nla_ipc_open(const void *blob96);             /* ... mapped here (hipIpcOpenMemHandle); NULL = failed */
+void nla_ipc_close(void *p);
 void *nla_stream_create_background(void);       /* lowest dispatch priority of the device (hipStreamCreateWithPriority): gap-filling work */
 void nla_stream_destroy(void *stream);
 int nla_stream_sync(void *stream);

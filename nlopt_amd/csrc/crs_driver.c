@@ -573,6 +573,12 @@ nlopt_result nla_crs_advance(nla_crs_session *S, int64_t eval_budget)
             if (st && S->fresh_from > S->block) st->slots_invalid += S->fresh_from - S->block;
             S->fresh_from = S->block;
             if (ops->chain(e, S->block, K, rs->os.best, rs->F[rs->os.best], W, S->Wf, nW, status, S->fwcnt, S->fwrec, FWCAP)) { engine_failed(S); return S->ret; }
+            if (pb->comm && ops->stop_flags_in && ops->stop_flags_out) {      /* a column-sharded window: the ranks' stop bits crossed inside the launch */
+                int forced = 0, timed = 0;
+                ops->stop_flags_out(e, &forced, &timed);
+                nla_stop_view(stop, forced, timed, &S->view, &S->agreed_force);
+                rs->sp = &S->view;
+            }
         } else
         {
             if (!S->forward && ops->advance(e, S->block, K, S->fresh_from, rs->os.best, W, nW, status)) { engine_failed(S); return S->ret; }

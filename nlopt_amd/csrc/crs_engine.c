@@ -94,6 +94,19 @@ struct nla_crs_hip_engine {
     int stop_in[2], stop_out[2];   /* the per-process stop conditions: this rank's view into a pass, all ranks' OR out of it */
     double *d_gsend, *d_grecv, *h_g;   /* a whole point from its slices (read_row / read_slot): colper, world x colper */
     const double *h_lb_full, *h_ub_full;   /* the caller's bounds (valid for the engine's life: the run's own arrays) */
+    /* column-sharded population with the window resolved ON the device (hip/crs_chain.hip, SH instance; round 6): trial points are whole
+     * (rows of ldf doubles) on every rank — a rank's workgroups store their chunk of a slot into every rank's TX through peer-mapped
+     * memory — so every rank evaluates and resolves as a single device does and the 128-slot window survives the sharding */
+    int shchain, ldf, ncolp;       /* ncolp: columns gathered = nc, even-padded from n = 128 on (the pad column of X is zero) */
+    int sh_chunks, sh_chunk0, sh_chunks_total;
+    uint32_t sh_seq;
+    int sh_grid_cap;               /* ranks sharing one device ("amd_cu_share" = k): each rank's window kernel holds at most its k-th of the chip */
+    void *d_shared;                /* ONE peer-mapped block of uncached memory: TX | flags | stop words */
+    uint32_t *d_flags, *d_stopw;
+    void *peer_block[8];           /* the other ranks' blocks as mapped here (nla_ipc_open) */
+    void *d_table;                 /* what the kernel reads of all this (nla_crs_chain_sh_table) */
+    double *d_xbest, *d_lbf, *d_ubf;   /* the whole best row, the whole bounds */
+    int64_t xbest_row;             /* the row d_xbest is a copy of (-1: none yet) */
     char err[256];
 };
 
@@ -109,6 +122,15 @@ int nla_crs_can_shard(int n, int world)
 {
     if (world < 2) return 0;
     return (int64_t) (world - 1) * ((n + world - 1) / world) < n;
+}
+
+/* ... and for the device-resolved windows: equal blocks of whole 128-byte lines (no line of a trial point is written by two ranks),
+ * at most 8 ranks (the kernel's peer table) */
+static int shchain_colper(int n, int world) { return (((n + world - 1) / world) + 15) & ~15; }
+int nla_crs_can_shard_windows(int n, int world)
+{
+    if (world < 2 || world > 8) return 0;
+    return (int64_t) (world - 1) * shchain_colper(n, world) < n;
 }
 
 static uint64_t trial_word0(const nla_crs_hip_engine *e) { return 2ULL * (uint64_t) e->n * (uint64_t) (e->N - 1); }
@@ -153,6 +175,11 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     nla_dev_free(e->d_words); nla_dev_free(e->d_jn); nla_dev_free(e->d_pos); nla_dev_free(e->d_last);
     nla_dev_free(e->d_lb); nla_dev_free(e->d_ub); nla_dev_free(e->d_X); nla_dev_free(e->d_F);
     nla_dev_free(e->d_initwords);
+    if (e->shchain) {
+        for (int r = 0; r < 8; ++r) nla_ipc_close(e->peer_block[r]);
+        nla_dev_free_uncached(e->d_shared); nla_dev_free_uncached(e->d_TM); nla_dev_free_uncached(e->d_ctrl);
+        nla_dev_free(e->d_table); nla_dev_free(e->d_xbest); nla_dev_free(e->d_lbf); nla_dev_free(e->d_ubf);
+    } else
     if (e->uncached) { nla_dev_free_uncached(e->d_TX); nla_dev_free_uncached(e->d_TM); nla_dev_free_uncached(e->d_ctrl); }
     else { nla_dev_free(e->d_TX); nla_dev_free(e->d_TM); nla_dev_free(e->d_ctrl); }
     nla_dev_free(e->d_fT);   /* d_fM aliases d_fT + KCAP */
@@ -167,8 +194,12 @@ void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used)
     free(e);
 }
 
+static int shchain_setup(nla_crs_hip_engine *e);
+
+/* shard: 0 replicas / single process, 1 column-sharded with conservative passes, 2 column-sharded with device-resolved windows (cu_parts >= 2:
+ * the ranks share one device — a test box — and each confines its window kernels to its share of the compute units) */
 nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj, int forward,
-                                              nlopt_amd_comm *comm, int shard, nlopt_amd_stats *stats, char **errmsg)
+                                              nlopt_amd_comm *comm, int shard, int cu_parts, nlopt_amd_stats *stats, char **errmsg)
 {
     nla_crs_hip_engine *e;
     size_t B;
@@ -179,15 +210,23 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->n = n; e->N = N; e->obj = obj; e->stats = stats; e->comm = comm; e->h_lb_full = lb; e->h_ub_full = ub;
     e->world = nlopt_amd_comm_world(comm); e->rank = nlopt_amd_comm_rank(comm);
     e->sharded = shard && nla_crs_can_shard(n, e->world) && obj >= 0;
+    e->shchain = e->sharded && shard == 2 && nla_crs_can_shard_windows(n, e->world);
     e->c0 = 0; e->nc = e->ncopy = n; e->colper = n;
+    e->xbest_row = -1;
+    /* (measured on this pool, tools/cu_mask_probe.hip: a CU-masked stream still runs on all 256 compute units — so what keeps the kernels of
+     * ranks that share a device resident together is the cap on their workgroups: 224 of the chip's 256 one-workgroup-per-CU places dealt
+     * over the ranks, the rest left to the generator's kernels) */
+    e->sh_grid_cap = cu_parts >= 2 ? (224 / cu_parts >= 4 ? 224 / cu_parts : 4) : 0;
     if (e->sharded) {
-        e->colper = (n + e->world - 1) / e->world;
+        e->colper = e->shchain ? shchain_colper(n, e->world) : (n + e->world - 1) / e->world;
         e->c0 = e->rank * e->colper;
         e->nc = n - e->c0 < e->colper ? n - e->c0 : e->colper;
         e->ncopy = e->nc;
-        forward = 0;
+        forward = e->shchain;
     }
-    e->ld = (e->nc + 15) & ~15;      /* rows start on a 128-byte line (the chain kernel's contract; coalesced row reads everywhere) */
+    e->ld = (e->nc + 15) & ~15;
+    e->ldf = e->shchain ? ((n + 15) & ~15) : e->ld;
+    e->ncolp = (n >= 128 && (e->nc & 1)) ? e->nc + 1 : e->nc;      /* rows start on a 128-byte line (the chain kernel's contract; coalesced row reads everywhere) */
     e->bat[0].index = e->bat[1].index = -1;
     /* blocks digested per batch (the block ring holds two batches).  The Vitter kernel walks all N rows per block, one lane per
      * block (a serial fp64 chain): a launch takes the same 40-70 ms (N = 1e5) whether it digests 4096 blocks or 32768 — it is
@@ -204,7 +243,10 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     if (B < 2 * KCAP) B = 2 * KCAP;
     e->B = (int) B;
     if (NLA_DBG_ENV("NLA_CRS_PASS_LOG")) e->pass_log = fopen(NLA_DBG_ENV("NLA_CRS_PASS_LOG"), "a");
-    e->main = nla_stream_create();
+    /* "amd_cu_share" = k >= 2: this process's window kernels on every k-th compute unit (ranks that share a device; a single process
+     * asks for it to be measured on the same share, tools/shard_probe.py) */
+    e->main = cu_parts >= 2 ? nla_stream_create_cu_share(e->rank % cu_parts, cu_parts) : nla_stream_create();
+    if (!e->main && cu_parts >= 2) e->main = nla_stream_create();
     /* NLA_ONE_STREAM (A/B switch for debugging stream-ordering problems): the generator work on the main stream too */
     e->rng = NLA_DBG_ENV("NLA_ONE_STREAM") ? e->main : nla_stream_create();      /* (restricting this stream to a subset of the CUs — hipExtStreamCreateWithCUMask, every 4th / 16th CU — was measured:
                                         *  43.0 -> 43.1 k evals/s; what the digest kernels cost the gather is memory traffic, not CUs) */
@@ -226,8 +268,33 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     /* trial points and the chain kernel's control block: uncached memory where the workgroups of one launch read each other's
      * (device-resolved windows); ordinary memory for the conservative passes, whose kernels meet only at launch boundaries */
     e->uncached = (forward && obj >= 0) || NLA_DBG_ENV("NLA_UC_ALWAYS") != NULL;       /* (NLA_UC_ALWAYS: round 2's allocation pattern, A/B) */
+    if (e->shchain) {
+        /* whole trial points; TX, the chunk flags and the stop words in one block the other ranks map */
+        const size_t txb = sizeof(double) * (size_t) e->ldf * KCAP;
+        e->sh_chunks = nla_crs_chain_sh_chunks(n, e->ncolp);
+        e->sh_chunks_total = 0;
+        for (int r = 0; r < e->world; ++r) {
+            const int c0r = r * e->colper, ncr = n - c0r < e->colper ? n - c0r : e->colper;
+            if (r == e->rank) e->sh_chunk0 = e->sh_chunks_total;
+            e->sh_chunks_total += nla_crs_chain_sh_chunks(n, (n >= 128 && (ncr & 1)) ? ncr + 1 : ncr);
+        }
+        {
+            const size_t flb = (sizeof(uint32_t) * (size_t) CHAIN_KMAX * (size_t) e->sh_chunks_total + 127) & ~(size_t) 127;
+            e->d_shared = nla_dev_malloc_uncached(txb + flb + nla_crs_chain_sh_stop_bytes());
+            e->d_TX = (double *) e->d_shared;
+            e->d_flags = e->d_shared ? (uint32_t *) ((char *) e->d_shared + txb) : NULL;
+            e->d_stopw = e->d_shared ? (uint32_t *) ((char *) e->d_shared + txb + flb) : NULL;
+            if (e->d_shared && nla_memset(e->d_flags, 0, flb + nla_crs_chain_sh_stop_bytes(), e->main)) goto fail;
+        }
+        e->d_TM = (double *) nla_dev_malloc_uncached(txb);
+        e->d_table = nla_dev_malloc(nla_crs_chain_sh_table_bytes());
+        e->d_xbest = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ldf);
+        e->d_lbf = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ldf);
+        e->d_ubf = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->ldf);
+    } else {
     e->d_TX = (double *) (e->uncached ? nla_dev_malloc_uncached : nla_dev_malloc)(sizeof(double) * (size_t) e->ld * KCAP);
     e->d_TM = (double *) (e->uncached ? nla_dev_malloc_uncached : nla_dev_malloc)(sizeof(double) * (size_t) e->ld * KCAP);
+    }
     e->d_fT = (double *) nla_dev_malloc(sizeof(double) * 2 * KCAP);
     e->d_fM = e->d_fT ? e->d_fT + KCAP : NULL;
     e->d_up = (char *) nla_dev_malloc(UPLOAD_BYTES);
@@ -257,21 +324,27 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
     e->force_upload = NLA_DBG_ENV("NLA_CRS_UPLOAD") != NULL;
     if (!e->d_lb || !e->d_ub || !e->d_X || !e->d_F || !e->d_words || !e->d_jn || !e->d_last || !e->d_pos || !e->d_TX ||
         !e->d_TM || !e->d_fT || !e->d_up || !e->d_tout || !e->d_status || !e->h_up || !e->h_status || !e->h_bell || !e->d_bellcount || !e->ev0 || !e->ev1 ||
-        (e->uncached && obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) goto fail;
+        (e->uncached && obj >= 0 && (!e->d_ctrl || !e->d_Wf || !e->h_fwcnt || !e->h_fwrec))) {
+        /* (a window-mode rank still joins the handle exchange below, saying it failed: the others must not wait for it there) */
+        if (e->shchain) shchain_setup(e);
+        goto fail;
+    }
     if (e->sharded) {
-        e->d_csend = (double *) nla_dev_malloc(sizeof(double) * (2 * KCAP * (size_t) e->colper + 2));
-        e->d_crecv = (double *) nla_dev_malloc(sizeof(double) * (2 * KCAP * (size_t) e->colper + 2) * (size_t) e->world);
+        /* (the candidates' all-gather buffers serve the conservative passes only: a window-mode run exchanges nothing by collective) */
+        const size_t cslots = e->shchain ? 1 : 2 * KCAP;
+        e->d_csend = (double *) nla_dev_malloc(sizeof(double) * (cslots * (size_t) e->colper + 2));
+        e->d_crecv = (double *) nla_dev_malloc(sizeof(double) * (cslots * (size_t) e->colper + 2) * (size_t) e->world);
         e->d_gsend = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->colper);
         e->d_grecv = (double *) nla_dev_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
         e->h_g = (double *) nla_host_malloc(sizeof(double) * (size_t) e->colper * (size_t) e->world);
         if (!e->d_csend || !e->d_crecv || !e->d_gsend || !e->d_grecv || !e->h_g) goto fail;
         {   /* the communicator's staging for the largest exchange of the run — a pass's candidates, or a rank's share of the initial
              * values — now, while a failure can still be agreed on (the set-up's "ready" exchange), not inside a collective */
-            size_t big = sizeof(double) * (2 * KCAP * (size_t) e->colper + 2), ini = sizeof(double) * (size_t) ((e->N - 1 + e->world - 1) / e->world);
+            size_t big = sizeof(double) * (cslots * (size_t) e->colper + 2), ini = sizeof(double) * (size_t) ((e->N - 1 + e->world - 1) / e->world);
             if (nla_comm_reserve(comm, big > ini ? big : ini)) goto fail;
         }
         if (nla_memset(e->d_gsend, 0, sizeof(double) * (size_t) e->colper, e->main) ||
-            nla_memset(e->d_csend, 0, sizeof(double) * (2 * KCAP * (size_t) e->colper + 2), e->main)) goto fail;
+            nla_memset(e->d_csend, 0, sizeof(double) * (cslots * (size_t) e->colper + 2), e->main)) goto fail;
     }
     /* the slice's bounds (the whole vectors in a single-process run); pad entries are zero */
     *e->h_bell = 0;
@@ -280,10 +353,55 @@ nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb
         nla_memset(e->d_lb, 0, sizeof(double) * (size_t) e->ld, e->main) || nla_memset(e->d_ub, 0, sizeof(double) * (size_t) e->ld, e->main) ||
         nla_memcpy_h2d(e->d_lb, lb + e->c0, sizeof(double) * (size_t) e->nc, e->main) ||
         nla_memcpy_h2d(e->d_ub, ub + e->c0, sizeof(double) * (size_t) e->nc, e->main) || nla_stream_sync(e->main)) goto fail;
+    if (e->shchain && shchain_setup(e)) goto fail;
     return e;
 fail:
     nla_crs_hip_engine_destroy(e, 0);
     return NULL;
+}
+
+/* window-mode set-up: every rank exports its peer-mapped block, the handles are all-gathered (host data: 96 bytes per rank), every rank
+ * maps the others' blocks and writes its table.  A rank whose allocations failed takes part with an invalid handle, so that nobody waits
+ * for it; every rank then fails the set-up (the caller falls back to the conservative passes, on all ranks alike). */
+static int shchain_setup(nla_crs_hip_engine *e)
+{
+    unsigned char mine[NLA_IPC_BYTES], all[8 * NLA_IPC_BYTES];
+    void *ptx[8], *pfl[8], *pst[8];
+    char *img;
+    const size_t txb = sizeof(double) * (size_t) e->ldf * KCAP;
+    const size_t flb = (sizeof(uint32_t) * (size_t) CHAIN_KMAX * (size_t) e->sh_chunks_total + 127) & ~(size_t) 127;
+    int ok = e->d_shared && e->d_TM && e->d_table && e->d_xbest && e->d_lbf && e->d_ubf && e->d_ctrl && e->main, bad = 0;
+    memset(mine, 0, sizeof mine);
+    if (ok && (nla_stream_sync(e->main) || nla_ipc_export(e->d_shared, mine))) { ok = 0; memset(mine, 0, sizeof mine); }
+    if (nla_comm_allgather_host(e->comm, mine, all, NLA_IPC_BYTES, e->main)) FAIL(e, "exchange of the window buffers' handles failed: %s", nlopt_amd_comm_error(e->comm));
+    for (int r = 0; r < e->world; ++r) {
+        int zero = 1;
+        for (int i = 0; i < NLA_IPC_BYTES; ++i) if (all[r * NLA_IPC_BYTES + i]) { zero = 0; break; }
+        if (zero) bad = 1;
+    }
+    if (!ok || bad) FAIL(e, "%s", ok ? "another rank could not set up its window buffers" : "window buffers: allocation or export failed");
+    for (int r = 0; r < e->world; ++r) {
+        char *base;
+        if (r == e->rank) base = (char *) e->d_shared;
+        else {
+            e->peer_block[r] = nla_ipc_open(all + r * NLA_IPC_BYTES);
+            if (!e->peer_block[r]) { bad = 1; base = (char *) e->d_shared; }      /* (agreed below) */
+            else base = (char *) e->peer_block[r];
+        }
+        ptx[r] = base; pfl[r] = base + txb; pst[r] = base + txb + flb;
+    }
+    /* all ranks mapped all blocks, or none goes on */
+    if (!nla_comm_agree_ready(e->comm, !bad) || bad) FAIL(e, "%s", bad ? "mapping a peer's window buffers failed (hipIpcOpenMemHandle)" : "another rank could not map the window buffers");
+    img = (char *) malloc(nla_crs_chain_sh_table_bytes());
+    if (!img) FAIL(e, "out of memory");
+    if (nla_crs_chain_sh_table(img, e->world, e->rank, e->c0, e->ldf, e->sh_chunks_total, e->sh_chunk0, ptx, pfl, pst, e->d_xbest, e->d_lbf, e->d_ubf) ||
+        nla_memcpy_h2d(e->d_table, img, nla_crs_chain_sh_table_bytes(), e->main) ||
+        nla_memset(e->d_lbf, 0, sizeof(double) * (size_t) e->ldf, e->main) || nla_memset(e->d_ubf, 0, sizeof(double) * (size_t) e->ldf, e->main) ||
+        nla_memset(e->d_xbest, 0, sizeof(double) * (size_t) e->ldf, e->main) ||
+        nla_memcpy_h2d(e->d_lbf, e->h_lb_full, sizeof(double) * (size_t) e->n, e->main) ||
+        nla_memcpy_h2d(e->d_ubf, e->h_ub_full, sizeof(double) * (size_t) e->n, e->main) || nla_stream_sync(e->main)) { free(img); FAIL(e, "window table upload failed"); }
+    free(img);
+    return 0;
 }
 
 /* development aid (NLA_CRS_DEBUG_DIR=<dir>): what the init kernels saw and made — the stream words, the rows and their f — of the
@@ -540,9 +658,15 @@ static int upload_and_commit(nla_crs_hip_engine *e, const int64_t *W, int nW, co
 
 /* the pinned upload buffer is rewritten by the next pass: callers that do not synchronise
  * themselves must do so before the host touches it again (every pass ends with a sync) */
+static int commit_sh(nla_crs_hip_engine *e, void *zero, size_t zero_bytes, int best_slot, int best_kind);
 static int flush_commits(nla_crs_hip_engine *e)
 {
     if (!e->npending) return 0;
+    if (e->shchain) {
+        if (commit_sh(e, NULL, 0, -1, 0)) return -1;
+        CK(e, nla_stream_sync(e->main));
+        return 0;
+    }
     if (upload_and_commit(e, NULL, 0, NULL, 0, NULL, NULL, NULL, NULL)) return -1;
     CK(e, nla_stream_sync(e->main));
     return 0;
@@ -742,6 +866,12 @@ static int op_read_slot(void *ve, uint64_t block, int kind, double *x)
 {
     nla_crs_hip_engine *e = (nla_crs_hip_engine *) ve;
     const double *src = (kind == 1 ? e->d_TX : e->d_TM) + (size_t) (block & (KCAP - 1)) * (size_t) e->ld;
+    if (e->shchain) {                                   /* whole points on every rank: no exchange */
+        const double *whole = (kind == 1 ? e->d_TX : e->d_TM) + (size_t) (block & (KCAP - 1)) * (size_t) e->ldf;
+        CK(e, nla_memcpy_d2h(x, whole, sizeof(double) * (size_t) e->n, e->main));
+        CK(e, nla_stream_sync(e->main));
+        return 0;
+    }
     if (flush_commits(e)) return -1;
     if (e->sharded) return gather_point(e, src, x);
     CK(e, nla_memcpy_d2h(x, src, sizeof(double) * (size_t) e->n, e->main));
@@ -769,6 +899,88 @@ static int op_mutate_slot(void *ve, uint64_t block, int64_t i0)
     return 0;
 }
 
+/* window mode: the staged commits (whole points -> rows of the slice), in launches of at most NLA_KARG_MAX; the first one also clears
+ * `zero` and refreshes the whole best row from a slot */
+static int commit_sh(nla_crs_hip_engine *e, void *zero, size_t zero_bytes, int best_slot, int best_kind)
+{
+    int done = 0, first = 1;
+    while (first || done < e->npending) {
+        const int cnt = e->npending - done < NLA_KARG_MAX ? e->npending - done : NLA_KARG_MAX;
+        CK(e, nla_k_crs_commit_sh(e->nc, e->ld, e->ldf, e->c0, e->d_X, e->d_TX, e->d_TM, cnt, e->pend_slot + done, e->pend_kind + done, e->pend_row + done,
+                                  first ? zero : NULL, first ? zero_bytes : 0, e->n, first ? best_slot : -1, best_kind, e->d_xbest, e->main));
+        done += cnt; first = 0;
+    }
+    e->npending = 0;
+    return 0;
+}
+
+/* a whole window of a column-sharded population, resolved on the device: no collective call — the slices travel inside the launch */
+static int op_chain_sh(nla_crs_hip_engine *e, uint64_t first_block, int K, int64_t i0, double f_best, const int64_t *W, const double *Wf, int nW,
+                       nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap)
+{
+    const int n = e->n;
+    const uint32_t ring = 2u * (uint32_t) e->B;
+    const int on_host = nW <= NLA_KARG_MAX;
+    const int64_t *d_W = W;
+    const double *d_Wf = Wf;
+    const size_t zero_bytes = nla_crs_chain_ctrl_bytes(K, nW) - sizeof(uint32_t);
+    void *zero = (char *) e->d_ctrl + sizeof(uint32_t);
+    int best_slot = -1, best_kind = 0;
+    /* the whole best row: every trial starts from it (the slice in X serves that), every mutation is formed around it (that needs all of
+     * it).  A new best point is an accepted trial point or mutation of the window before — whole in this rank's TX / TM, named by the
+     * staged commits; only the first window's best (a row of the initial population) has to be put together from the ranks' slices */
+    if (i0 != e->xbest_row) {
+        for (int c = e->npending - 1; c >= 0; --c)
+            if (e->pend_row[c] == i0) { best_slot = e->pend_slot[c]; best_kind = e->pend_kind[c]; break; }
+        if (best_slot < 0) {
+            if (flush_commits(e)) return -1;
+            CK(e, nla_memcpy_d2d(e->d_gsend, e->d_X + (size_t) i0 * (size_t) e->ld, sizeof(double) * (size_t) e->nc, e->main));
+            if (nla_comm_allgather_dev(e->comm, e->d_gsend, e->d_grecv, sizeof(double) * (size_t) e->colper, e->main)) {
+                nla_comm_abort(e->comm);
+                FAIL(e, "all-gather of the best row's slices failed: %s", nlopt_amd_comm_error(e->comm));
+            }
+            CK(e, nla_memcpy_d2d(e->d_xbest, e->d_grecv, sizeof(double) * (size_t) n, e->main));     /* (rank r's colper columns sit at r * colper = c0 of rank r) */
+        }
+        e->xbest_row = i0;
+    }
+    if (!on_host) {
+        memcpy(e->h_up, W, 8 * (size_t) nW); memcpy(e->h_up + 8 * (size_t) nW, Wf, 8 * (size_t) nW);
+        CK(e, nla_memcpy_h2d(e->d_up, e->h_up, 16 * (size_t) nW, e->main));
+        d_W = (const int64_t *) e->d_up; d_Wf = (const double *) (e->d_up + 8 * (size_t) nW);
+    }
+    if (commit_sh(e, zero, zero_bytes, best_slot, best_kind)) return -1;
+    e->timed = e->stats != NULL;
+    if (e->timed) CK(e, nla_event_record(e->ev0, e->main));
+    ++e->sh_seq;
+    {
+        const int rc = nla_k_crs_chain_sh(OBJK(e), n, e->ncolp, e->ld, e->ldf, e->d_X, i0, f_best, e->d_jn, e->d_pos, e->d_last, e->d_words, ring, first_block, K,
+                                          d_W, d_Wf, nW, on_host, KCAP - 1, e->d_lb, e->d_ub, e->d_TX, e->d_TM, e->d_ctrl, e->ticket_base, e->h_status,
+                                          e->h_fwcnt, e->h_fwrec, fwcap, 1, e->d_table, e->sh_seq, (uint32_t) ((e->stop_in[0] ? 1 : 0) | (e->stop_in[1] ? 2 : 0)), e->sh_grid_cap, e->main);
+        if (rc) FAIL(e, "nla_k_crs_chain_sh failed: %s", nla_dev_error_string(rc));
+    }
+    e->ticket_base += nla_crs_chain_sh_tickets(n, e->ncolp, K, e->sh_grid_cap);
+    if (e->timed) CK(e, nla_event_record(e->ev1, e->main));
+    if (e->idle_fn) e->idle_fn(e->idle_arg);
+    CK(e, nla_stream_sync(e->main));
+    if (e->h_status[K].t != 0) FAIL(e, "a rank's share of a trial point did not arrive within 1.5 s (column-sharded window %u)", e->sh_seq);
+    e->stop_out[0] = e->h_status[K].fT != 0.; e->stop_out[1] = e->h_status[K].fM != 0.;
+    memcpy(status, e->h_status, sizeof(nla_crs_slot_status) * (size_t) K);
+    memcpy(fwcnt, e->h_fwcnt, sizeof(uint32_t) * (size_t) K);
+    for (int a = 0; a < K; ++a) {
+        const uint32_t c = e->h_fwcnt[a] < (uint32_t) fwcap ? e->h_fwcnt[a] : (uint32_t) fwcap;
+        if (c) memcpy(fwrec + (size_t) a * (size_t) fwcap, e->h_fwrec + (size_t) a * (size_t) fwcap, sizeof(uint32_t) * (size_t) c);
+    }
+    for (int a = 0; a < K; ++a) e->h_t[(first_block + (uint64_t) a) & (KCAP - 1)] = n;
+    if (e->timed) {
+        float ms = nla_event_elapsed_ms(e->ev0, e->ev1);
+        if (ms >= 0) e->stats->t_gather_ms += ms;
+        e->stats->gather_launches += 1;
+        /* what this rank pushed to the others inside the launch: its columns of every slot, to world - 1 ranks */
+        e->stats->allgather_bytes += (uint64_t) K * (uint64_t) (e->world - 1) * (uint64_t) e->ncolp * sizeof(double);
+    }
+    return 0;
+}
+
 /* a whole window in one launch with the chain resolved on the device (hip/crs_chain.hip) */
 static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_best, const int64_t *W, const double *Wf, int nW,
                     nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap)
@@ -783,6 +995,7 @@ static int op_chain(void *ve, uint64_t first_block, int K, int64_t i0, double f_
     if (K < 1 || K > CHAIN_KMAX || nW < 0 || nW > CHAIN_KMAX || fwcap != CHAIN_FWCAP) FAIL(e, "bad window K=%d nW=%d", K, nW);
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
     if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
+    if (e->shchain) return op_chain_sh(e, first_block, K, i0, f_best, W, Wf, nW, status, fwcnt, fwrec, fwcap);
     /* what goes in front of the window on the stream (round 5, "lean windows": a 256-slot window used to be copy / commit / copy / fill /
      * fill / chain — six operations with 4-7 us between any two, profiles/r05_n512_timeline.txt): ONE copy with everything the device
      * needs (W, its f values, the commit lists — none at all when they fit the kernel arguments), the commit kernel of the previous
@@ -906,8 +1119,24 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         nlopt_amd_comm *comm = opt ? opt->comm : NULL;
         const int shard = comm && nla_crs_can_shard(n, nlopt_amd_comm_world(comm)) && pb->obj >= 0 &&
                           (!opt || nlopt_get_param(opt, "amd_shard", 1) != 0);
-        if (shard) { pb->forward = 0; pb->comm = comm; }
-        *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, shard, pb->stats, NULL);
+        /* ... or, where the coordinates can be dealt in whole 128-byte lines over at most 8 ranks, as device-resolved windows whose slices
+         * cross between the ranks' kernels through peer-mapped memory ("amd_shard_windows" = 0: the conservative passes;
+         * "amd_cu_share" = k: k ranks share one device — each rank's windows run on its k-th of the compute units) */
+        const int windows = shard && pb->forward && nla_crs_can_shard_windows(n, nlopt_amd_comm_world(comm)) &&
+                            (!opt || nlopt_get_param(opt, "amd_shard_windows", 1) != 0);
+        const int cu_parts = opt ? (int) nlopt_get_param(opt, "amd_cu_share", 0) : 0;
+        if (shard) { pb->comm = comm; if (!windows) pb->forward = 0; }
+        *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, pb->forward, comm, windows ? 2 : shard, windows || !comm ? cu_parts : 0, pb->stats, NULL);
+        if (windows) {
+            /* all ranks run windows, or all fall back to the conservative passes (a rank that could not map a peer's buffers, an
+             * allocation that failed): the same decision everywhere */
+            const int all = nla_comm_agree_ready(comm, *eout != NULL);
+            if (!all) {
+                if (*eout) nla_crs_hip_engine_destroy(*eout, 0);
+                pb->forward = 0;
+                *eout = nla_crs_hip_engine_create(n, N, lb, ub, pb->obj, 0, comm, 1, 0, pb->stats, NULL);
+            }
+        }
         if (*eout) { (*eout)->fuse_commit = 1; (*eout)->doorbell = 1; }      /* (rounds 4-5 had A/B switches here: profiles/r04_crs_fuse_commit_ab.txt, r04_crs_doorbell_ab.txt) */
     }
     /* several ranks: all of them go on, or none (a rank that could not set up would leave the others in the first all-gather) */

@@ -64,6 +64,7 @@
 #define CH_FWAVES 8                      /* f is reduced as a workgroup of 8 wavefronts reduces it (= NLA_FIN_WAVES of crs_kernels.hip, SH_WAVES of crs_shard.hip):
                                           * windows, conservative passes and column-sharded jobs give the same f bit for bit at every n */
 #include <stddef.h>
+#include <string.h>
 
 /* control block of one launch (device memory, zeroed before the launch except `ticket`, which only grows) */
 struct chain_ctrl {
@@ -84,8 +85,41 @@ struct chain_lists { int inl; int64_t W[NLA_KA_MAX]; double Wf[NLA_KA_MAX]; };
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/* system scope (sc0 sc1): what crosses to / comes from ANOTHER device or process — the column-sharded instance below */
+__device__ __forceinline__ uint32_t ld_sys(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys_f64(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<uint64_t *>(p), (uint64_t) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
-template <int VEC, int U, int WAVES, int OBJ>
+/* ---- the window on a COLUMN-SHARDED population (SH = true): W ranks = W devices (or, on a test box, W processes sharing one), rank r
+ * holds columns [c0, c0 + nc) of every row.  Coordinates never mix in the gather-sum (crs.c:63-121), so a rank's workgroups form ITS
+ * columns of every slot's trial point — 1 / W of the rows' bytes — and store the finished chunk into the slot's row of EVERY rank's TX
+ * (peer-mapped memory: hipIpcOpenMemHandle; over xGMI between devices), then raise the chunk's flag word on every rank.  TX rows are
+ * full width on every rank.  The workgroup that completes a slot's LOCAL chunks waits for the flags of all the slot's chunks, then
+ * evaluates f(T), forms the mutation from the whole best row (a full-width copy every rank keeps) and evaluates it — the single-GPU
+ * reduction on the same numbers, so f is the same bits on every rank — and every rank's resolver takes the same decisions.  Nothing
+ * else crosses: 8 n bytes per slot and rank against 8 n (n + 1) / W gathered.
+ *   flags[a][c]      (seq << 2): chunk c (numbered across the ranks) of slot a of launch `seq` is in this rank's TX.  Never cleared: a
+ *                    waiter accepts any value >= its own launch's (a peer may be one launch ahead, never two: it cannot finish a
+ *                    launch without this rank's chunks)
+ *   stopw[seq & 1][r] (seq << 2) | rank r's stop bits for launch seq (force_stop, maxtime: per-process conditions every rank must act
+ *                    on together); the resolver's workgroup writes this rank's word to every peer when the launch starts and ORs
+ *                    all ranks' words into status[K] when the chain is done
+ * Every wait gives up: a slot behind a new best point is abandoned (ctrl->halt), and a chunk that does not arrive within 1.5 s sets
+ * the launch's failure word (status[K].t) — the host ends the run with an error instead of hanging the device. */
+#define NLA_SH_MAXW 8
+struct chain_shard {
+    int world, rank, c0, ldf, chunks_total, chunk0, pad0, pad1;
+    double *peerTX[NLA_SH_MAXW];
+    uint32_t *peerflags[NLA_SH_MAXW];
+    uint32_t *peerstop[NLA_SH_MAXW];
+    const double *xbest, *lbf, *ubf;
+};
+#define NLA_SH_WAIT_TICKS 150000000ull   /* 1.5 s of the 100 MHz clock (the resolver's own give-up is 2 s after the last arrival) */
+
+template <int VEC, int U, int WAVES, int OBJ, bool SH = false>
 __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     const chain_lists L_first_kernel_argument,  /* read through the kernarg segment below, never by name: indexing the by-value copy
                                                  * with a run-time j makes the compiler move all 1.5 KB of it to scratch memory */
@@ -94,7 +128,8 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     uint32_t ring_blocks, uint64_t first_block, int K, const int64_t *__restrict__ Wd, const double *__restrict__ Wfd, int nW,
     int slot_mask, int chunks, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ TX,
     double *__restrict__ TM, chain_ctrl *__restrict__ ctrl, uint32_t ticket_base, nla_crs_slot_status *__restrict__ status,
-    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, double sign, uint64_t resolver_timeout)
+    uint32_t *__restrict__ fwcnt, uint32_t *__restrict__ fwrec, int fwcap, double sign, uint64_t resolver_timeout,
+    int ncols, const chain_shard *__restrict__ S, uint32_t seq, uint32_t stopbits)
 {
     typedef const __attribute__((address_space(4))) chain_lists *kernarg_lists;
     const kernarg_lists Lk = (kernarg_lists) __builtin_amdgcn_kernarg_segment_ptr();       /* explicit arguments start at offset 0 */
@@ -103,7 +138,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     static_assert(U <= 64, "one lane per row of a batch");
     __shared__ V sacc[64];
     __shared__ int32_t srow[NLA_ADV_RCAP];
-    __shared__ int s_turn, s_ticket, s_last;
+    __shared__ int s_turn, s_ticket, s_last, s_state;
     __shared__ uint32_t s_nrec, s_halt;
     __shared__ double scratch[2 * CH_FWAVES];
     volatile __attribute__((address_space(3))) int *turn = (volatile __attribute__((address_space(3))) int *) &s_turn;
@@ -113,14 +148,43 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     uint32_t *done = reinterpret_cast<uint32_t *>(fv + 2 * (size_t) K), *rowstate = done + 2 * (size_t) K;     /* (done[K], K unused words, rowstate[nW]) */
     const int64_t *W = Lk->inl ? (const int64_t *) Lk->W : Wd;
     const double *Wf = Lk->inl ? (const double *) Lk->Wf : Wfd;
+    /* SH: a workgroup takes ticket after ticket until none is left (the launcher caps the grid: ranks that SHARE a device must both be
+     * resident — a rank's waiting workgroups may not fill the chip — and with the tickets handed out in order the holder of the earliest
+     * unfinished one is always running, whatever the cap).  Otherwise: one ticket per workgroup, as ever. */
+#define CH_NEXT do { if constexpr (SH) continue; else return; } while (0)
+    for (;;) {
+    if constexpr (SH) __syncthreads();    /* the previous ticket's LDS contents are done with */
     if (threadIdx.x == 0) { s_ticket = (int) (atomicAdd(&ctrl->ticket, 1u) - ticket_base); s_nrec = 0; s_halt = ld_agent(&ctrl->halt); }
     __syncthreads();
+    if constexpr (SH) { if (s_ticket > K * chunks) return; }
     /* the first workgroup to run is the resolver: wavefront 0 advances the chain for the whole launch, the others leave.  Every
      * slot's workgroups hold later tickets, so whatever they wait for is running already */
     if (s_ticket == 0) {
-        if (wave == 0)
+        if (wave == 0) {
+            if constexpr (SH) {          /* this rank's stop bits for the launch, to every rank (lane r: rank r) */
+                if (lane < S->world) st_sys(S->peerstop[lane] + (seq & 1u) * NLA_SH_MAXW + (uint32_t) S->rank, (seq << 2) | (stopbits & 3u));
+            }
             chain_resolver_wave(reinterpret_cast<uint32_t *>(ctrl), reinterpret_cast<const uint64_t *>(fv), rowstate, K, nW, W, Wf, f_best, i0,
                                 resolver_timeout);
+            if constexpr (SH) {
+                /* the chain is done, so every rank's kernel of this launch has started (slot 0 is never abandoned: its chunks came from
+                 * all of them): their stop words are there or on their way */
+                uint32_t bits = 0, bad = 0;
+                if (lane < S->world) {
+                    const uint32_t *wp_ = S->peerstop[S->rank] + (seq & 1u) * NLA_SH_MAXW + (uint32_t) lane;
+                    const uint64_t t0 = wall_clock64();
+                    uint32_t v;
+                    while (((v = ld_sys(wp_)) >> 2) != seq) {
+                        if (wall_clock64() - t0 > NLA_SH_WAIT_TICKS) { bad = 1; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    bits = v & 3u;
+                }
+                const uint32_t forced = __ballot((bits & 1u) != 0) != 0, timed = __ballot((bits & 2u) != 0) != 0;
+                const uint32_t failed = (__ballot(bad != 0) != 0 || ld_agent(&ctrl->lock) != 0) ? 1u : 0u;
+                if (lane == 0) { status[K].fT = forced ? 1. : 0.; status[K].fM = timed ? 1. : 0.; status[K].t = (int32_t) failed; status[K].pad = 0; }
+            }
+        }
         return;
     }
     const int wg = s_ticket - 1;
@@ -131,7 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         const uint32_t h = s_halt;
         if ((h & 2u) && (uint32_t) a >= (h >> 8)) {
             if (threadIdx.x == 0) { status[a].t = 0; if (chunk == 0) fwcnt[a] = 0; }
-            return;
+            CH_NEXT;
         }
     }
     const uint64_t block = first_block + (uint64_t) a;
@@ -172,10 +236,13 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
             if (hit[it] >= 0) srow[hit[it]] = -(it * 64 + lane + 1);
     };
     const int col = (chunk * 64 + lane) * VEC;
-    const bool active = col < n;
+    const bool active = col < (SH ? ncols : n);
     const size_t colc = active ? (size_t) col : 0;
     const double *Xc = X + colc;
-    double *accrow = TX + (size_t) q * (size_t) ld + colc;
+    /* rows of TX / TM: SH — full width (stride ldf), this rank's columns start at c0; otherwise the population's own layout */
+    const size_t tld = SH ? (size_t) S->ldf : (size_t) ld;
+    const size_t tc0 = SH ? (size_t) S->c0 : 0;
+    double *accrow = TX + (size_t) q * tld + tc0 + colc;
     if (wave == 0) sacc[lane] = ldv<VEC>(Xc + (size_t) i0 * (size_t) ld);       /* x := best (crs.c:69) */
     const double hneg = -(0.5 * n);         /* x -= xi*(0.5*n)  ==  x += xi*(-(0.5*n)), exactly */
     const uint32_t lane_off = (uint32_t) (colc * sizeof(double));
@@ -221,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
                     if (rs && (int) (rs >> 3) < a) {
                         pj = (int) (rs >> 3); kind = (int) ((rs >> 1) & 3u);
                         const int qk = (int) ((first_block + (uint64_t) pj) & (uint64_t) slot_mask);
-                        rowp = reinterpret_cast<const char *>((kind == 1 ? TX : TM) + (size_t) qk * (size_t) ld);
+                        rowp = reinterpret_cast<const char *>((kind == 1 ? TX : TM) + (size_t) qk * tld + tc0);
                     } else rowp = reinterpret_cast<const char *>(X + (size_t) W[j] * (size_t) ld);
                     if (chunk == 0 && lane == 0 && base + u < cnt) {     /* what was decided, for the host to verify */
                         const uint32_t k = atomicAdd(&s_nrec, 1u);
@@ -258,15 +325,27 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     if (wave == 0 && active) {              /* x[k] *= 2.0 / n, then clamp (crs.c:116-120) */
         V acc = sacc[lane];
         const double s = 2.0 / n;
+        double rx, ry = 0.;
         if constexpr (VEC == 1) {
             double a0 = *reinterpret_cast<double *>(&acc);
-            *accrow = nla_clamp_box(a0 * s, lb[col], ub[col]);
+            rx = nla_clamp_box(a0 * s, lb[col], ub[col]);
+            *accrow = rx;
         } else {
             double2 a2 = *reinterpret_cast<double2 *>(&acc), r2;
-            r2.x = nla_clamp_box(a2.x * s, lb[col], ub[col]);
-            r2.y = nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]);
+            r2.x = rx = nla_clamp_box(a2.x * s, lb[col], ub[col]);
+            r2.y = ry = nla_clamp_box(a2.y * s, lb[col + 1], ub[col + 1]);
             *reinterpret_cast<double2 *>(accrow) = r2;
         }
+        if constexpr (SH) {              /* the same chunk into the slot's row on every other rank */
+            const int me = S->rank, Wn = S->world;
+            for (int r = 0; r < Wn; ++r) {
+                if (r == me) continue;
+                double *dst = S->peerTX[r] + (size_t) q * tld + tc0 + colc;
+                st_sys_f64(dst, rx);
+                if constexpr (VEC == 2) st_sys_f64(dst + 1, ry);
+            }
+        }
+        (void) ry;
         /* the stores must have LANDED before this wave's lane 0 counts the chunk as done below (the barrier alone does not wait
          * for them: a workgroup-scope release drops vmcnt).  TX is uncached memory, so landed = visible to every CU: no L2
          * write-back, no agent-scope release */
@@ -274,19 +353,55 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
     }
     /* this chunk of the trial point is final; the workgroup that completes the slot evaluates it */
     __syncthreads();
+    if constexpr (SH) {                   /* the chunk has landed in every rank's TX (wave 0's wait above, then the barrier): raise its flag everywhere */
+        if (threadIdx.x < (unsigned) S->world)
+            st_sys(S->peerflags[threadIdx.x] + (size_t) a * (size_t) S->chunks_total + (size_t) (S->chunk0 + chunk), seq << 2);
+    }
     if (threadIdx.x == 0) {
         if (chunk == 0) fwcnt[a] = s_nrec;
         s_last = (atomicAdd(&done[a], 1u) == (uint32_t) (chunks - 1));
     }
     __syncthreads();
-    if (!s_last) return;
+    if (!s_last) CH_NEXT;
+    if constexpr (SH) {
+        /* the last LOCAL chunk of the slot: wait for the other ranks' (their workgroups hold tickets as early as this one's and never
+         * wait for this slot), unless the slot lies behind a new best point — then some rank may have left it alone */
+        if (wave == 0) {
+            const uint32_t *fl = S->peerflags[S->rank] + (size_t) a * (size_t) S->chunks_total;
+            const int nch = S->chunks_total;
+            const uint64_t t0 = wall_clock64();
+            int state = 0;
+            while (!state) {
+                bool all = true;
+                for (int c = lane; c < nch; c += 64) all = all && ((int32_t) (ld_sys(fl + c) - (seq << 2)) >= 0);
+                if (__ballot(!all) == 0) state = 1;
+                else {
+                    const uint32_t h = ld_agent(&ctrl->halt);
+                    if ((h & 2u) && (uint32_t) a >= (h >> 8)) state = 2;
+                    else if (wall_clock64() - t0 > NLA_SH_WAIT_TICKS) state = 3;
+                    else __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            if (lane == 0) s_state = state;
+        }
+        __syncthreads();
+        if (s_state != 1) {
+            if (threadIdx.x == 0) {
+                status[a].t = 0;
+                if (s_state == 3) st_agent(&ctrl->lock, 1u);          /* a peer's chunk never came: the launch has failed (status[K].t) */
+            }
+            CH_NEXT;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                 /* system scope: the peers' stores */
+    } else
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
         const int tid = threadIdx.x;
-        const double *x = TX + (size_t) q * (size_t) ld;
-        const double *xb = X + (size_t) i0 * (size_t) ld;
+        const double *x = TX + (size_t) q * tld;
+        const double *xb = SH ? S->xbest : X + (size_t) i0 * (size_t) ld;
+        const double *lbm = SH ? S->lbf : lb, *ubm = SH ? S->ubf : ub;      /* the mutation clamps whole points */
         const uint32_t *w = words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n;
-        double *m = TM + (size_t) q * (size_t) ld;
+        double *m = TM + (size_t) q * tld;
         auto getx = [&](int i) { return __builtin_nontemporal_load(x + i); };
         const double fT = sign * nla_block_objective_as<OBJ, WAVES, CH_FWAVES>(n, getx, scratch);
         uint64_t *rec = reinterpret_cast<uint64_t *>(fv) + 2 * (size_t) a;
@@ -298,7 +413,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         auto mut = [&](int i) {        /* p_i = best_i (1+w) - w p_i, clamp (crs.c:140-145) */
             const uint2 ww = *reinterpret_cast<const uint2 *>(w + 2 * i);
             const double wv = nla_urand_from(0., 1., ww.x, ww.y);
-            return nla_clamp_box(xb[i] * (1 + wv) - wv * getx(i), lb[i], ub[i]);
+            return nla_clamp_box(xb[i] * (1 + wv) - wv * getx(i), lbm[i], ubm[i]);
         };
         for (int i = tid; i < n; i += WAVES * 64) m[i] = mut(i);
         const double fM = sign * nla_block_objective_as<OBJ, WAVES, CH_FWAVES>(n, mut, scratch);
@@ -313,6 +428,9 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
             __hip_atomic_store(rec + 1, ch_bits_of_f(fM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if constexpr (!SH) return;
+    }
+#undef CH_NEXT
 }
 
 extern "C" size_t nla_crs_chain_ctrl_bytes(int K, int nW)
@@ -358,11 +476,79 @@ extern "C" int nla_k_crs_chain(int obj, int n, int ld, const double *X, int64_t 
  * (A doorbell in pinned memory rung by the last workgroup, for a host that spins instead of synchronising the stream, was measured here
  * in round 5 and removed: with a system-scope fence per workgroup n = 512 ran at 612 k evals/s against 687 k with the synchronisation,
  * with one fence by the ringing workgroup 920 k against 980 k — profiles/r05_lean_windows_ab.txt.) */
+static int chain_launch(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                        const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                        uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                        const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                        nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *stream,
+                        int ncols, const chain_shard *S, int ldf, uint32_t seq, uint32_t stopbits, int grid_cap);
 extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
                                     const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
                                     uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
                                     const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
                                     nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *stream)
+{
+    return chain_launch(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host, slot_mask,
+                        lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, ctrl_is_zero, stream, n, nullptr, ld, 0u, 0u, 0);
+}
+
+/* ---- column-sharded windows (SH instance of the kernel) ------------------------------------------------------ */
+/* chunks a rank with `ncols` columns (even-padded where n >= 128) contributes per slot */
+extern "C" int nla_crs_chain_sh_chunks(int n, int ncols)
+{
+    const int cpw = (n >= 128 && ncols % 2 == 0) ? 128 : 64;
+    return (ncols + cpw - 1) / cpw;
+}
+/* bytes of the per-rank table the kernel reads (device memory, filled by nla_crs_chain_sh_table) */
+extern "C" size_t nla_crs_chain_sh_table_bytes(void) { return sizeof(chain_shard); }
+/* fills the host image of that table: peerTX / peerflags / peerstop [r] = rank r's TX, flags, stop words AS MAPPED IN THIS PROCESS (the own
+ * entries: the own buffers); xbest / lbf / ubf: whole best row and whole bounds on this device */
+extern "C" int nla_crs_chain_sh_table(void *host_image, int world, int rank, int c0, int ldf, int chunks_total, int chunk0, void *const *peerTX,
+                                      void *const *peerflags, void *const *peerstop, const double *xbest, const double *lbf, const double *ubf)
+{
+    if (world < 2 || world > NLA_SH_MAXW || rank < 0 || rank >= world) return (int) hipErrorInvalidValue;
+    chain_shard t;
+    memset(&t, 0, sizeof t);
+    t.world = world; t.rank = rank; t.c0 = c0; t.ldf = ldf; t.chunks_total = chunks_total; t.chunk0 = chunk0;
+    for (int r = 0; r < world; ++r) { t.peerTX[r] = (double *) peerTX[r]; t.peerflags[r] = (uint32_t *) peerflags[r]; t.peerstop[r] = (uint32_t *) peerstop[r]; }
+    t.xbest = xbest; t.lbf = lbf; t.ubf = ubf;
+    memcpy(host_image, &t, sizeof t);
+    return 0;
+}
+extern "C" size_t nla_crs_chain_sh_stop_bytes(void) { return sizeof(uint32_t) * 2 * NLA_SH_MAXW; }
+/* one window on this rank's columns.  X: N x ld (the slice), ncols columns of it gathered (nc, even-padded); TX / TM: rows of ldf doubles
+ * (whole points), TX peer-mapped on every rank; lb / ub: the slice's bounds; table: device copy of the nla_crs_chain_sh_table image;
+ * seq: the launch's number (1, 2, ...: the same on every rank); stopbits: bit 0 force_stop, bit 1 maxtime as THIS rank sees them;
+ * grid_cap >= 2: at most that many workgroups (ranks sharing one device: all of them must fit the chip together), 0: one per ticket.
+ * status[K] comes back with (fT != 0: some rank's force_stop, fM != 0: some rank's clock, t != 0: a rank's chunks did not arrive). */
+extern "C" int nla_k_crs_chain_sh(int obj, int n, int ncols, int ld, int ldf, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                                  const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                                  uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                                  const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                                  nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
+                                  const void *table, uint32_t seq, uint32_t stopbits, int grid_cap, void *stream)
+{
+    if (!table || ncols < 1 || ncols > ld || ldf < n || ldf % 16 != 0) return (int) hipErrorInvalidValue;
+    return chain_launch(obj, n, ld, X, i0, f_best, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, w_on_host, slot_mask,
+                        lb, ub, TX, TM, ctrl, ticket_base, status, fwcnt, fwrec, fwcap, ctrl_is_zero, stream, ncols, (const chain_shard *) table, ldf, seq, stopbits, grid_cap);
+}
+/* workgroups of one launch and tickets they draw (every workgroup but the resolver's draws one ticket past the last) */
+static unsigned chain_sh_grid(int n, int ncols, int K, int grid_cap)
+{
+    const long total = (long) nla_crs_chain_sh_chunks(n, ncols) * K + 1;
+    return (unsigned) ((grid_cap >= 2 && grid_cap < total) ? grid_cap : total);
+}
+extern "C" uint32_t nla_crs_chain_sh_tickets(int n, int ncols, int K, int grid_cap)
+{
+    return (uint32_t) nla_crs_chain_sh_chunks(n, ncols) * (uint32_t) K + chain_sh_grid(n, ncols, K, grid_cap);
+}
+
+static int chain_launch(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                        const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                        uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                        const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                        nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero, void *stream,
+                        int ncols, const chain_shard *S, int ldf, uint32_t seq, uint32_t stopbits, int grid_cap)
 {
     if (K <= 0) return 0;
     if (K > 256 || nW > 256 || nW < 0 || obj < 0) return (int) hipErrorInvalidValue;
@@ -370,6 +556,7 @@ extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int
     /* rows of TX / TM start on a 128-byte line: a line that holds the end of one slot's row and the start of the next one's could
      * sit in a CU's vector L1 from the read of the first and serve a stale start of the second (consumers take no L1 invalidate) */
     if (ld % 16 != 0 || ((uintptr_t) TX | (uintptr_t) TM) % 128 != 0) return (int) hipErrorInvalidValue;
+    (void) ldf;
     hipStream_t st = (hipStream_t) stream;
     chain_lists L;
     L.inl = 0;
@@ -379,9 +566,11 @@ extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int
         for (int j = 0; j < nW; ++j) { L.W[j] = W[j]; L.Wf[j] = Wf[j]; }
         W = nullptr; Wf = nullptr;
     }
-    const bool vec2 = chain_vec2(n, ld);
-    const int chunks = nla_crs_chain_chunks(n, ld);
-    const dim3 grid((unsigned) ((long) chunks * K) + 1u);
+    const bool sh = S != nullptr;
+    const bool vec2 = sh ? (n >= 128 && ncols % 2 == 0 && ld % 2 == 0) : chain_vec2(n, ld);
+    const int chunks = sh ? nla_crs_chain_sh_chunks(n, ncols) : nla_crs_chain_chunks(n, ld);
+    if (sh && (ldf % 16 != 0)) return (int) hipErrorInvalidValue;
+    const dim3 grid(sh ? chain_sh_grid(n, ncols, K, grid_cap) : (unsigned) ((long) chunks * K) + 1u);
     const uint64_t res_timeout = 200000000ull;                /* 2 s of the 100 MHz clock without a single evaluation arriving */
     chain_ctrl *c = (chain_ctrl *) ctrl;
     /* everything but the ticket counter starts from zero */
@@ -391,7 +580,10 @@ extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int
     }
 #define CHAIN(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
         pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
-        fwcnt, fwrec, fwcap, sign, res_timeout)
+        fwcnt, fwrec, fwcap, sign, res_timeout, ncols, S, seq, stopbits)
+#define CHAIN_SH(VEC, UU, WV, O) hipLaunchKernelGGL((crs_chain_kernel<VEC, UU, WV, O, true>), grid, dim3(WV * 64), 0, st, L, n, ld, X, i0, f_best, jn_ring, \
+        pos_ring, last_ring, words_ring, ring_blocks, first_block, K, W, Wf, nW, slot_mask, chunks, lb, ub, TX, TM, c, ticket_base, status,         \
+        fwcnt, fwrec, fwcap, sign, res_timeout, ncols, S, seq, stopbits)
 /* rows in flight per workgroup = wavefronts x U (tuning builds override: NLOPT_AMD_VARIANT="name:-DNLA_CHAIN_MID_W=8 ...") */
 /* Measured on the MI355X, N = 1e5 (profiles/r05_lean_windows_ab.txt; was 4 x 16 from n = 512, 2 x 16 from 128, 1 x 16 below): the time of a
  * window below n = 2048 is the DEPTH of its dependency chains (a slot that picked one of the worst rows ahead of it waits for the chain,
@@ -419,7 +611,13 @@ extern "C" int nla_k_crs_chain_lean(int obj, int n, int ld, const double *X, int
     } else {                                                                             \
         if (n >= 2048) CHAIN(1, 32, 8, O); else if (n >= 512) CHAIN(1, NLA_CHAIN_MID_U, NLA_CHAIN_MID_W, O); else if (n >= 128) CHAIN(1, NLA_CHAIN_LOW_U, NLA_CHAIN_LOW_W, O); else CHAIN(1, 16, NLA_CHAIN_TINY_W, O); \
     }
-    NLA_OBJ_DISPATCH(obj, CHAIN_SHAPE)
+/* the sharded instance in three shapes (a rank's share of a row is short: the 8 x 32 tiling from n = 512 on, 4 x 16 below) */
+#define CHAIN_SHAPE_SH(O)                                                                \
+    if (vec2) { if (n >= 512) CHAIN_SH(2, 32, 8, O); else CHAIN_SH(2, 16, 4, O); } else CHAIN_SH(1, 16, 4, O);
+    if (sh) { NLA_OBJ_DISPATCH(obj, CHAIN_SHAPE_SH) }
+    else { NLA_OBJ_DISPATCH(obj, CHAIN_SHAPE) }
+#undef CHAIN_SHAPE_SH
+#undef CHAIN_SH
 #undef CHAIN_SHAPE
 #undef CHAIN
     NLA_LAUNCH_CHECK();

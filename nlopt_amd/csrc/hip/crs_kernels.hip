@@ -425,6 +425,29 @@ __global__ __launch_bounds__(256) void crs_commit_kernel(int n, int ld, double *
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+/* the same on a column-sharded population whose trial points are whole (hip/crs_chain.hip, SH instance): row `rc` of the slice X (stride
+ * ld, nc columns) := columns [c0, c0 + nc) of the slot's whole point in TX / TM (stride ldf).  Workgroup 0 also clears the next window's
+ * control block, and copies a whole point into `xbest` when asked (best_slot >= 0: the window's new best point, which every later trial
+ * starts from and every mutation is formed around — crs.c:69,141). */
+__global__ __launch_bounds__(256) void crs_commit_sh_kernel(int nc, int ld, int ldf, int c0, double *__restrict__ X, const double *__restrict__ TX,
+                                                             const double *__restrict__ TM, const crs_commits C, int ncommit,
+                                                             uint32_t *__restrict__ zero, int zero_words, int n, int best_slot, int best_kind,
+                                                             double *__restrict__ xbest)
+{
+    const int c = blockIdx.x;
+    if (c == 0) {
+        for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0u;
+        if (best_slot >= 0) {
+            const double *src = (best_kind == 1 ? TX : TM) + (size_t) best_slot * (size_t) ldf;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) xbest[i] = src[i];
+        }
+    }
+    if (c >= ncommit) return;
+    const double *src = (C.kind[c] == 1 ? TX : TM) + (size_t) C.slot[c] * (size_t) ldf + (size_t) c0;
+    double *dst = X + (size_t) C.row[c] * (size_t) ld;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) dst[i] = src[i];
+}
+
 /* one local mutation in place (host-callback mode): p := clamp(best(1+w) - w p) */
 __global__ __launch_bounds__(256) void crs_mutate_kernel(int n, const double *__restrict__ best, double *__restrict__ p,
                                                           const uint32_t *__restrict__ w, const double *__restrict__ lb,
@@ -506,6 +529,22 @@ extern "C" int nla_k_crs_commit_zero(int n, int ld, double *X, const double *TX,
     }
     hipLaunchKernelGGL(crs_commit_kernel, dim3((unsigned) ncommit), dim3(256), 0, (hipStream_t) stream,
                        n, ld, X, TX, TM, slot, kind, row, C, (uint32_t *) zero, (int) (zero_bytes / 4));
+    NLA_LAUNCH_CHECK();
+    return 0;
+}
+
+/* column-sharded windows: commits (host lists, ncommit <= 128, may be 0) from whole trial points into the slice, the control block
+ * cleared, the whole best row refreshed from a slot (best_slot < 0: left as it is) — one launch in front of the window */
+extern "C" int nla_k_crs_commit_sh(int nc, int ld, int ldf, int c0, double *X, const double *TX, const double *TM, int ncommit,
+                                   const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *zero, size_t zero_bytes,
+                                   int n, int best_slot, int best_kind, double *xbest, void *stream)
+{
+    if (ncommit < 0 || ncommit > NLA_KA_MAX || (zero_bytes & 3u)) return (int) hipErrorInvalidValue;
+    crs_commits C;
+    C.inl = 1;
+    for (int c = 0; c < ncommit; ++c) { C.slot[c] = h_slot[c]; C.kind[c] = h_kind[c]; C.row[c] = h_row[c]; }
+    hipLaunchKernelGGL(crs_commit_sh_kernel, dim3((unsigned) (ncommit > 0 ? ncommit : 1)), dim3(256), 0, (hipStream_t) stream,
+                       nc, ld, ldf, c0, X, TX, TM, C, ncommit, (uint32_t *) zero, (int) (zero_bytes / 4), n, best_slot, best_kind, xbest);
     NLA_LAUNCH_CHECK();
     return 0;
 }

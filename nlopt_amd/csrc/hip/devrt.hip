@@ -7,6 +7,7 @@
 #include "../nla_switches.h"
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../../../include/nlopt_amd.h"
 
 extern "C" int nla_dev_count(void)
@@ -221,6 +222,74 @@ extern "C" void *nla_stream_create(void)
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     return (void *) s;
 }
+/* a stream confined to a share of the compute units: CU i belongs to part (i mod parts).  For ranks that SHARE one device and whose
+ * kernels wait for each other inside a launch (the column-sharded CRS2_LM windows on a one-GPU test box): with disjoint shares both
+ * kernels are resident whatever their sizes.  parts < 2: an ordinary stream. */
+extern "C" void *nla_stream_create_cu_share(int part, int parts)
+{
+    if (parts < 2) return nla_stream_create();
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+    uint32_t mask[64];
+    if (words > 64 || part < 0 || part >= parts) return nullptr;
+    for (int w = 0; w < words; ++w) mask[w] = 0;
+    for (int i = 0; i < ncu; ++i) if (i % parts == part) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t) words, mask) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return (void *) s;
+}
+
+/* ---- device memory another PROCESS can map (hipIpc*): the column-sharded windows' TX / flag buffers ---------------------------------
+ * export: an opaque NLA_IPC_BYTES blob for a pointer obtained from nla_dev_malloc_uncached / nla_dev_malloc (blocks of the uncached pool
+ * lie inside a larger driver allocation: the blob carries the offset); open: the peer's pointer as mapped in this process; close. */
+struct nla_ipc_blob { hipIpcMemHandle_t h; uint64_t offset; uint64_t magic; };
+static_assert(sizeof(nla_ipc_blob) <= 96, "NLA_IPC_BYTES");
+struct ipc_open_rec { void *user, *base; };
+static std::mutex ipc_mu;
+static std::vector<ipc_open_rec> ipc_opened;
+extern "C" int nla_ipc_export(const void *p, void *blob96)
+{
+    nla_ipc_blob b;
+    memset(&b, 0, sizeof b);
+    const void *base = p;
+    {
+        std::lock_guard<std::mutex> g(uc_mu);
+        for (const uc_block &u : uc_pool) if (u.p == p) { base = u.raw; break; }
+    }
+    hipError_t e = hipIpcGetMemHandle(&b.h, const_cast<void *>(base));
+    if (e != hipSuccess) { (void) hipGetLastError(); return (int) e; }
+    b.offset = (uint64_t) ((const char *) p - (const char *) base);
+    b.magic = 0x6e6c61697063ull;
+    memset(blob96, 0, 96);
+    memcpy(blob96, &b, sizeof b);
+    return 0;
+}
+extern "C" void *nla_ipc_open(const void *blob96)
+{
+    nla_ipc_blob b;
+    memcpy(&b, blob96, sizeof b);
+    if (b.magic != 0x6e6c61697063ull) return nullptr;
+    void *base = nullptr;
+    if (hipIpcOpenMemHandle(&base, b.h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    void *user = (char *) base + b.offset;
+    std::lock_guard<std::mutex> g(ipc_mu);
+    ipc_opened.push_back(ipc_open_rec{user, base});
+    return user;
+}
+extern "C" void nla_ipc_close(void *user)
+{
+    if (!user) return;
+    void *base = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ipc_mu);
+        for (size_t i = 0; i < ipc_opened.size(); ++i)
+            if (ipc_opened[i].user == user) { base = ipc_opened[i].base; ipc_opened.erase(ipc_opened.begin() + (long) i); break; }
+    }
+    if (base && hipIpcCloseMemHandle(base) != hipSuccess) (void) hipGetLastError();
+}
+
 /* a stream whose kernels are dispatched after those of ordinary streams when both have work ready: for background work that
  * should fill the gaps another stream's latency-bound kernels leave, without taking compute units from its throughput-bound ones */
 extern "C" void *nla_stream_create_background(void)

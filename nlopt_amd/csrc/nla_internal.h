@@ -296,9 +296,10 @@ nlopt_result nla_esch_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
 /* HIP engine (crs_engine.c) */
 typedef struct nla_crs_hip_engine nla_crs_hip_engine;
 nla_crs_hip_engine *nla_crs_hip_engine_create(int n, int64_t N, const double *lb, const double *ub, int obj, int forward,
-                                              nlopt_amd_comm *comm, int shard, nlopt_amd_stats *stats, char **errmsg);
+                                              nlopt_amd_comm *comm, int shard, int cu_parts, nlopt_amd_stats *stats, char **errmsg);
 void nla_crs_hip_engine_destroy(nla_crs_hip_engine *e, uint64_t words_used);
 int nla_crs_can_shard(int n, int world);
+int nla_crs_can_shard_windows(int n, int world);
 extern const nla_crs_engine_ops nla_crs_hip_ops;
 
 /* reference-shaped entry (src/algs/crs/crs.h:34-40) */

@@ -61,6 +61,48 @@ int nla_memcpy_d2d(void *dst, const void *src, size_t bytes, void *st) { (void) 
 int nla_memset(void *dst, int value, size_t bytes, void *st) { (void) st; if (bytes) memset(dst, value, bytes); return 0; }
 void *nla_stream_create(void) { return emu_alloc(1); }
 void *nla_stream_create_background(void) { return emu_alloc(1); }
+void *nla_stream_create_cu_share(int part, int parts) { (void) part; (void) parts; return emu_alloc(1); }
+/* no peer-mapped memory between emulated devices: a column-sharded CRS2_LM job that asks for device-resolved windows finds out during
+ * its set-up and falls back — on every rank alike — to the conservative passes (crs_engine.c, crs_open_common) */
+int nla_ipc_export(const void *p, void *blob96) { (void) p; (void) blob96; return EMU_ERR; }
+void *nla_ipc_open(const void *blob96) { (void) blob96; return NULL; }
+void nla_ipc_close(void *p) { (void) p; }
+int nla_crs_chain_sh_chunks(int n, int ncols) { (void) n; return (ncols + 63) / 64; }
+size_t nla_crs_chain_sh_table_bytes(void) { return 64; }
+size_t nla_crs_chain_sh_stop_bytes(void) { return 64; }
+int nla_crs_chain_sh_table(void *host_image, int world, int rank, int c0, int ldf, int chunks_total, int chunk0, void *const *peerTX,
+                           void *const *peerflags, void *const *peerstop, const double *xbest, const double *lbf, const double *ubf)
+{
+    (void) host_image; (void) world; (void) rank; (void) c0; (void) ldf; (void) chunks_total; (void) chunk0; (void) peerTX; (void) peerflags; (void) peerstop;
+    (void) xbest; (void) lbf; (void) ubf;
+    return EMU_ERR;
+}
+uint32_t nla_crs_chain_sh_tickets(int n, int ncols, int K, int grid_cap) { (void) grid_cap; return (uint32_t) nla_crs_chain_sh_chunks(n, ncols) * (uint32_t) K + 1u; }
+int nla_k_crs_chain_sh(int obj, int n, int ncols, int ld, int ldf, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
+                       const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                       uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
+                       const double *lb, const double *ub, double *TX, double *TM, void *ctrl, uint32_t ticket_base,
+                       nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
+                       const void *table, uint32_t seq, uint32_t stopbits, int grid_cap, void *stream)
+{
+    (void) grid_cap; (void) obj; (void) n; (void) ncols; (void) ld; (void) ldf; (void) X; (void) i0; (void) f_best; (void) jn_ring; (void) pos_ring; (void) last_ring;
+    (void) words_ring; (void) ring_blocks; (void) first_block; (void) K; (void) W; (void) Wf; (void) nW; (void) w_on_host; (void) slot_mask; (void) lb;
+    (void) ub; (void) TX; (void) TM; (void) ctrl; (void) ticket_base; (void) status; (void) fwcnt; (void) fwrec; (void) fwcap; (void) ctrl_is_zero;
+    (void) table; (void) seq; (void) stopbits; (void) stream;
+    return EMU_ERR;
+}
+int nla_k_crs_commit_sh(int nc, int ld, int ldf, int c0, double *X, const double *TX, const double *TM, int ncommit,
+                        const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *zero, size_t zero_bytes,
+                        int n, int best_slot, int best_kind, double *xbest, void *stream)
+{
+    (void) stream;
+    EMU_LAUNCH();
+    if (zero && zero_bytes) memset(zero, 0, zero_bytes);
+    if (best_slot >= 0) memcpy(xbest, (best_kind == 1 ? TX : TM) + (size_t) best_slot * (size_t) ldf, sizeof(double) * (size_t) n);
+    for (int c = 0; c < ncommit; ++c)
+        memcpy(X + (size_t) h_row[c] * (size_t) ld, (h_kind[c] == 1 ? TX : TM) + (size_t) h_slot[c] * (size_t) ldf + (size_t) c0, sizeof(double) * (size_t) nc);
+    return 0;
+}
 void nla_stream_destroy(void *st) { emu_release(st); }
 int nla_stream_sync(void *st) { (void) st; return 0; }
 int nla_stream_query(void *st) { (void) st; return 0; }

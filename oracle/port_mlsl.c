@@ -13,7 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct { double f; int minimized; double closest_pt_d, closest_lm_d; double *x; } pt;
+typedef struct { double f; int minimized; double closest_pt_d, closest_lm_d; double *x; int id; } pt;
 typedef struct { double f; double *x; } lm_t;
 
 typedef struct {
@@ -51,6 +51,7 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
     lm_t *lms = NULL; size_t nlms = 0, caplms = 0;
     double R_prefactor;
     counted cnt;
+    int next_id = 0;
     orc_sobol *sob = mlsl_lds ? orc_sobol_create((unsigned) n) : NULL;
     if (N < 1) { orc_sobol_destroy(sob); return ORC_INVALID_ARGS; }
     cnt.n = n; cnt.f = f; cnt.f_data = f_data; cnt.stop = stop;
@@ -60,7 +61,7 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
 #define INSERT_PT(P) do { size_t pos_ = 0; if (npts == cappts) { cappts = cappts ? 2 * cappts : 1024; pts = (pt **) realloc(pts, cappts * sizeof *pts); } \
         while (pos_ < npts && pts[pos_]->f < (P)->f) ++pos_;   /* before the first element that is not smaller */ \
         memmove(pts + pos_ + 1, pts + pos_, (npts - pos_) * sizeof *pts); pts[pos_] = (P); ++npts; } while (0)
-#define NEWPT(P) do { (P) = (pt *) malloc(sizeof(pt)); (P)->x = (double *) malloc(sizeof(double) * (size_t) n); (P)->minimized = 0; \
+#define NEWPT(P) do { (P) = (pt *) malloc(sizeof(pt)); (P)->x = (double *) malloc(sizeof(double) * (size_t) n); (P)->minimized = 0; (P)->id = next_id++; \
         (P)->closest_pt_d = HUGE_VAL; (P)->closest_lm_d = HUGE_VAL; } while (0)
 #define STOPS(fv) do { if (stop->force_stop) ret = ORC_FORCED_STOP; else if (orc_stop_evals(stop)) ret = ORC_MAXEVAL_REACHED; \
         else if (orc_stop_time(stop)) ret = ORC_MAXTIME_REACHED; else if ((fv) < stop->minf_max) ret = ORC_STOPVAL_REACHED; } while (0)
@@ -137,7 +138,7 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
                 lret = loc->alg == 1 ? orc_mma_minimize(n, fcount, &cnt, lb, ub, lx, &lf, &ls, &loc->mma)
                                      : orc_lbfgs_minimize(n, fcount, &cnt, lb, ub, lx, &lf, &ls, loc->mf, loc->tolg);
                 p->minimized = 1;
-                if (trace && trace->nloc < trace->cap) { trace->floc[trace->nloc] = lf; trace->eloc[trace->nloc] = (int) ls.nevals; }
+                if (trace && trace->nloc < trace->cap) { trace->floc[trace->nloc] = lf; trace->eloc[trace->nloc] = (int) ls.nevals; if (trace->sloc) trace->sloc[trace->nloc] = p->id; }
                 if (trace) ++trace->nloc;
                 if (lret < 0) { free(lx); ret = lret; goto done; }
                 if (nlms == caplms) { caplms = caplms ? 2 * caplms : 256; lms = (lm_t *) realloc(lms, caplms * sizeof *lms); }
@@ -156,7 +157,13 @@ int orc_mlsl_minimize(int n, orc_func f, void *f_data, const double *lb, const d
                         }
             }
         }
-        if (trace) ++trace->iterations;
+        if (trace) {
+            if (trace->it_nloc && (size_t) trace->iterations < trace->it_cap) {
+                trace->it_nloc[trace->iterations] = (long) trace->nloc; trace->it_nevals[trace->iterations] = stop->nevals;
+                trace->it_words[trace->iterations] = orc_mt_words_drawn();
+            }
+            ++trace->iterations;
+        }
     }
     GET_MINF();
 done:

@@ -85,7 +85,10 @@ int orc_mma_minimize(int n, orc_func f, void *f_data, const double *lb, const do
 
 /* ---- MLSL (src/algs/mlsl/mlsl.c) with LD_LBFGS (alg 0) or LD_MMA (alg 1) as the local optimiser - */
 typedef struct { double ftol_rel, ftol_abs, xtol_rel, tolg; long maxeval; int mf; int alg; orc_mma_params mma; } orc_local_params;
-typedef struct { double *fsamp, *floc; int *eloc; size_t cap, nsamp, nloc; long iterations; } orc_mlsl_trace;
+typedef struct { double *fsamp, *floc; int *eloc; size_t cap, nsamp, nloc; long iterations;
+                 /* optional (NULL: not recorded): per local search the creation index of its start point (0 = the caller's x, 1.. = the samples
+                  * in the order drawn); per finished iteration the searches and evaluations so far and the stream words drawn so far */
+                 int *sloc; long *it_nloc, *it_nevals; unsigned long long *it_words; size_t it_cap; } orc_mlsl_trace;
 /* Sobol LDS (port_sobol.c; sobolseq.c:109-264) */
 typedef struct orc_sobol_s orc_sobol;
 orc_sobol *orc_sobol_create(unsigned sdim);

@@ -213,10 +213,10 @@ def main():
         s = L.nlopt_amd_crs_open(o._h, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(minf), C.byref(ret))
         t_init = time.perf_counter() - t0
         assert s and ret.value == 1, (ret.value, o.get_errmsg())
-        L.nlopt_amd_crs_step(s, args["evals"] // 4)
+        r1 = L.nlopt_amd_crs_step(s, args["evals"] // 4)
         dist.barrier()
         st0, ev0, t0 = o.stats(), o.get_numevals(), time.perf_counter()
-        L.nlopt_amd_crs_step(s, args["evals"])
+        r2 = L.nlopt_amd_crs_step(s, args["evals"])
         dist.barrier()
         dt = time.perf_counter() - t0
         st1, ev1 = o.stats(), o.get_numevals()
@@ -224,7 +224,8 @@ def main():
         res = dict(evals_per_s=np.array([(ev1 - ev0) / dt]), passes=np.array([st1["rounds"] - st0["rounds"]]), dt=np.array([dt]), t_init=np.array([t_init]),
                    evals=np.array([ev1 - ev0]), gather_ms=np.array([st1["t_gather_ms"] - st0["t_gather_ms"]]),
                    gather_launches=np.array([st1["gather_launches"] - st0["gather_launches"]]),
-                   allgather_bytes=np.array([st1["allgather_bytes"] - st0["allgather_bytes"]], dtype=np.uint64), minf=np.array([minf.value]))
+                   allgather_bytes=np.array([st1["allgather_bytes"] - st0["allgather_bytes"]], dtype=np.uint64), minf=np.array([minf.value]),
+                   step_ret=np.array([r1, r2]), errmsg=np.array(o.get_errmsg() or ""))
     elif case == "emu_sweep":
         # drawn configurations of the ISRES and MLSL host drivers over the emulated device, each checked against the oracle here
         # (every rank runs the same draws; the multi-rank runs shard them)

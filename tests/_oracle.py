@@ -444,7 +444,9 @@ class OrcLocal(C.Structure):
 
 class MlslTrace(C.Structure):
     _fields_ = [("fsamp", C.POINTER(C.c_double)), ("floc", C.POINTER(C.c_double)), ("eloc", C.POINTER(C.c_int)),
-                ("cap", C.c_size_t), ("nsamp", C.c_size_t), ("nloc", C.c_size_t), ("iterations", C.c_long)]
+                ("cap", C.c_size_t), ("nsamp", C.c_size_t), ("nloc", C.c_size_t), ("iterations", C.c_long),
+                ("sloc", C.POINTER(C.c_int)), ("it_nloc", C.POINTER(C.c_long)), ("it_nevals", C.POINTER(C.c_long)),
+                ("it_words", C.POINTER(C.c_ulonglong)), ("it_cap", C.c_size_t)]
 
 
 def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_rel=1e-8, local_xtol_rel=0.0, local_ftol_abs=0.0,
@@ -469,7 +471,9 @@ def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_re
     hbuf = np.zeros(cap, dtype=np.uint64)
     rec = Recorder(f, None, dptr(fbuf), hbuf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, 0)
     fs, fl, el = np.zeros(cap), np.zeros(cap), np.zeros(cap, dtype=np.int32)
-    tr = MlslTrace(dptr(fs), dptr(fl), el.ctypes.data_as(C.POINTER(C.c_int)), cap, 0, 0, 0)
+    sl, itl, ite, itw = np.zeros(cap, dtype=np.int32), np.zeros(4096, dtype=np.int64), np.zeros(4096, dtype=np.int64), np.zeros(4096, dtype=np.uint64)
+    tr = MlslTrace(dptr(fs), dptr(fl), el.ctypes.data_as(C.POINTER(C.c_int)), cap, 0, 0, 0, sl.ctypes.data_as(C.POINTER(C.c_int)),
+                   itl.ctypes.data_as(C.POINTER(C.c_long)), ite.ctypes.data_as(C.POINTER(C.c_long)), itw.ctypes.data_as(C.POINTER(C.c_ulonglong)), 4096)
     minf = C.c_double()
     L.orc_srand(seed)
     ret = L.orc_mlsl_minimize(n, C.cast(L.orc_recording_callback, C.c_void_p).value, C.cast(C.pointer(rec), C.c_void_p),
@@ -477,7 +481,8 @@ def run_port_mlsl(obj, n, nsamples, seed, maxeval=0, stopval=None, local_ftol_re
     L.orc_mlsl_set_lds(0)
     return dict(ret=ret, minf=minf.value, x=x, nevals=st.nevals, words=L.orc_mt_words_drawn(), fseq=fbuf[:rec.len].copy(),
                 xhash=hbuf[:rec.len].copy(), fsamp=fs[:tr.nsamp].copy(), floc=fl[:tr.nloc].copy(), eloc=el[:tr.nloc].copy(),
-                iterations=tr.iterations)
+                iterations=tr.iterations, sloc=sl[:tr.nloc].copy(), it_nloc=itl[:min(tr.iterations, 4096)].copy(),
+                it_nevals=ite[:min(tr.iterations, 4096)].copy(), it_words=itw[:min(tr.iterations, 4096)].copy())
 
 
 def port_sobol_points(sdim, skip_n, count, lb=None, ub=None):

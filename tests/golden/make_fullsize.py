@@ -90,10 +90,44 @@ def crs_long_case(name, obj, n, N, extra, seed=42):
          best_eval=imp.astype(np.int64) + 1, best_f=run_min[imp].copy())
 
 
-def isres_case(name, obj, n, pop, nineq, gens=2, seed=42):
-    """ISRES: `gens` generations' evaluations (one full generation incl. ranking + evolve, then the next generation's
-    evaluations — every candidate of generation 2 is a function of generation 1's ranking and of the evolve step)."""
+def isres_stops(ex, name, obj, n, pop, nineq, gens, seed=42):
+    """ISRES stopped one evaluation into generation g + 1 (maxeval = g pop + 1), g = 1 .. gens - 1: where bench.py's ISRES leg ends
+    (its hook raises force_stop when `warmup + steps` generations are done; the library sees the flag after the next generation's
+    first candidate, isres.c:195-198 — the reference stops on maxeval at the same evaluation with the same minimum and the same
+    stream position).  The REAL reference for every g; the port beside it for the stream position (asserted identical in what the
+    reference exposes: result, count, minimum, argmin)."""
+    evs = [g * pop + 1 for g in range(1, gens)]
+    futs = [ex.submit(_isres_stop_one, (obj, n, pop, seed, nineq, e)) for e in evs]      # beside the caller's own long run
+
+    def collect():
+        return _isres_stops_collect(name, evs, [f.result() for f in futs])
+    return collect
+
+
+def _isres_stops_collect(name, evs, refs):
+    for e, (r, p) in zip(evs, refs):
+        print(name, "stop at", e, "reference minf", r[1], "port words", p[3], flush=True)
+        assert r[0] == p[0] and r[1] == p[1] and r[2] == p[2] == e and np.array_equal(r[4], p[4])
+    return dict(stop_evals=np.array(evs, dtype=np.int64), stop_minf=np.array([r[1] for r, _ in refs]),
+                stop_ret=np.array([r[0] for r, _ in refs], dtype=np.int64),
+                stop_words=np.array([p[3] for _, p in refs], dtype=np.uint64), stop_x=np.array([r[4] for r, _ in refs]))
+
+
+def _isres_stop_one(a):
+    obj, n, pop, seed, nineq, e = a
+    r = O.run_ref_isres(obj, n, pop, seed, nineq, 0, maxeval=e, record=False)
+    p = O.run_port_isres(obj, n, pop, seed, nineq, 0, maxeval=e, record=False)
+    return (r["ret"], r["minf"], r["nevals"], 0, r["x"]), (p["ret"], p["minf"], p["nevals"], p["words"], p["x"])
+
+
+def isres_case(name, obj, n, pop, nineq, gens=5, seed=42):
+    """ISRES: `gens` generations' evaluations (gens - 1 full generations incl. ranking + evolve, then the last generation's
+    evaluations — every candidate of generation g + 1 is a function of generation g's ranking and of the evolve step): the
+    generations bench.py's ISRES leg times (1 warm-up + 3) and one more."""
+    from concurrent.futures import ProcessPoolExecutor
     me = gens * pop
+    ex = ProcessPoolExecutor(max_workers=4)
+    stops_later = isres_stops(ex, name, obj, n, pop, nineq, gens, seed)
     t0 = time.time()
     r = O.run_ref_isres(obj, n, pop, seed, nineq, 0, maxeval=me)
     print(name, "reference: ret", r["ret"], "nevals", r["nevals"], "minf", r["minf"], "%.0f s" % (time.time() - t0), flush=True)
@@ -105,16 +139,22 @@ def isres_case(name, obj, n, pop, nineq, gens=2, seed=42):
     assert np.array_equal(r["fseq"], p["fseq"]) and np.array_equal(r["xhash"], p["xhash"]) and np.array_equal(r["x"], p["x"])
     f, pen = p["ftrace"], p["pentrace"]
     assert len(f) == me
+    stops = stops_later()
+    ex.shutdown()
     save(name, obj=obj, n=n, pop=pop, nineq=nineq, seed=seed, maxeval=me, ret=p["ret"], nevals=p["nevals"], minf=p["minf"],
          x=p["x"], words=np.uint64(p["words"]), ref_checked=1,
          f_every8=f[::8].copy(), pen_every8=pen[::8].copy(), f_blocksum16=block_sums(f, 16), pen_blocksum16=block_sums(pen, 16),
          f_gen2_head=f[pop:pop + 2048].copy(), pen_gen2_head=pen[pop:pop + 2048].copy(),
-         xhash_gen2_every8=p["xhash"][pop::8].copy())
+         f_gen_heads=np.array([f[g * pop:g * pop + 512] for g in range(gens)]), pen_gen_heads=np.array([pen[g * pop:g * pop + 512] for g in range(gens)]),
+         xhash_gen2_every8=p["xhash"][pop:2 * pop:8].copy(), gens=gens, **stops)
 
 
-def mlsl_case(name, obj, n, nsamp, maxeval, seed=42, local_ftol_rel=1e-8):
+def mlsl_case(name, obj, n, nsamp, maxeval, seed=42, local_ftol_rel=1e-8, long_maxeval=100000):
     """G_MLSL_LDS + LD_LBFGS (n > 1111: the LDS variant samples pseudo-randomly, sobolseq.c:139): the run up to `maxeval`
-    evaluations: every sample's f, every local search's result and evaluation count, in order."""
+    evaluations: every sample's f, every local search's start, result and evaluation count, in order; the same over a longer run
+    (`long_*`: iterations 1-4 complete) with the iteration boundaries, and the REAL reference stopped one evaluation into iteration
+    k + 1 (maxeval = evaluations at the end of iteration k, + 1), k = 1..4: where bench.py's MLSL leg ends (its hook raises
+    force_stop when `warmup + steps` iterations are done; the library sees it at the next iteration's first sample, mlsl.c:366)."""
     t0 = time.time()
     r = O.run_ref_mlsl(obj, n, nsamp, seed, alg=39, local_ftol_rel=local_ftol_rel, maxeval=maxeval)
     print(name, "reference: ret", r["ret"], "nevals", r["nevals"], "minf", r["minf"], "%.0f s" % (time.time() - t0), flush=True)
@@ -124,10 +164,29 @@ def mlsl_case(name, obj, n, nsamp, maxeval, seed=42, local_ftol_rel=1e-8):
           "samples", len(p["fsamp"]), "local searches", len(p["floc"]), "%.0f s" % (time.time() - t0), flush=True)
     assert r["ret"] == p["ret"] and r["nevals"] == p["nevals"] and r["minf"] == p["minf"]
     assert np.array_equal(r["fseq"], p["fseq"]) and np.array_equal(r["xhash"], p["xhash"]) and np.array_equal(r["x"], p["x"])
+    # the longer run: reference == port evaluation by evaluation again, then the iteration boundaries from the port
+    rl = O.run_ref_mlsl(obj, n, nsamp, seed, alg=39, local_ftol_rel=local_ftol_rel, maxeval=long_maxeval)
+    pl = O.run_port_mlsl(obj, n, nsamp, seed, maxeval=long_maxeval, local_ftol_rel=local_ftol_rel, lds=True)
+    assert rl["ret"] == pl["ret"] and rl["nevals"] == pl["nevals"] and rl["minf"] == pl["minf"]
+    assert np.array_equal(rl["fseq"], pl["fseq"]) and np.array_equal(rl["xhash"], pl["xhash"]) and np.array_equal(rl["x"], pl["x"])
+    full = int(pl["iterations"]) - 1                   # the last iteration is the one maxeval cut
+    print(name, "long run: iterations", pl["iterations"], "searches by iteration", pl["it_nloc"], "evaluations", pl["it_nevals"], flush=True)
+    assert full >= 4
+    stops = []
+    for k in range(1, 5):
+        e = int(pl["it_nevals"][k - 1]) + 1
+        rs = O.run_ref_mlsl(obj, n, nsamp, seed, alg=39, local_ftol_rel=local_ftol_rel, maxeval=e)
+        assert rs["nevals"] == e and rs["ret"] == 5
+        stops.append((e, rs["minf"], rs["x"]))
+        print(name, "reference stopped at", e, "minf", rs["minf"], flush=True)
     save(name, obj=obj, n=n, nsamp=nsamp, seed=seed, maxeval=maxeval, local_ftol_rel=local_ftol_rel, ret=p["ret"],
          nevals=p["nevals"], minf=p["minf"], x=p["x"], words=np.uint64(p["words"]), ref_checked=1,
-         fsamp=p["fsamp"], floc=p["floc"], eloc=p["eloc"], iterations=p["iterations"],
-         fseq_every4=p["fseq"][::4].copy(), fseq_blocksum16=block_sums(p["fseq"], 16))
+         fsamp=p["fsamp"], floc=p["floc"], eloc=p["eloc"], sloc=p["sloc"], iterations=p["iterations"],
+         fseq_every4=p["fseq"][::4].copy(), fseq_blocksum16=block_sums(p["fseq"], 16),
+         long_maxeval=long_maxeval, long_fsamp=pl["fsamp"], long_floc=pl["floc"], long_eloc=pl["eloc"], long_sloc=pl["sloc"],
+         long_it_nloc=pl["it_nloc"][:full], long_it_nevals=pl["it_nevals"][:full], long_it_words=pl["it_words"][:full],
+         stop_evals=np.array([s_[0] for s_ in stops], dtype=np.int64), stop_minf=np.array([s_[1] for s_ in stops]),
+         stop_x=np.array([s_[2] for s_ in stops]))
 
 
 CASES = {

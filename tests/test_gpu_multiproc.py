@@ -66,9 +66,43 @@ def test_crs_column_sharded(world, a):
     single-process run of this device bit for bit (at n = 4096 that one resolves its windows in the chain kernel: same sequence)"""
     s = single("gpu_crs", a)
     assert s["ret"] == 5 and s["nevals"] >= a["maxeval"]             # a real run (MAXEVAL_REACHED), not an argument error
-    for d in run_world("gpu_crs", a, world=world):
+    for d in run_world("gpu_crs", dict(a, params={"amd_shard_windows": 0}), world=world):       # conservative passes + one all-gather per pass
         same(d, s)
         assert d["collectives"][0] >= d["rounds"][0] > 0 and d["stats_allgather_bytes"][0] > 0
+
+
+WINDOW_CASES = [(2, dict(obj="rastrigin", n=96, pop=1501, seed=11, maxeval=4000)),
+                (3, dict(obj="levy", n=257, pop=600, seed=5, maxeval=1500)),                 # odd n: the last rank's pad column; a coupled objective
+                (2, dict(obj="rastrigin", n=64, pop=2000, seed=42, maxeval=6000)),           # smoke()'s golden case
+                (2, dict(obj="rosenbrock", n=512, pop=5000, seed=7, maxeval=9000)),
+                (2, dict(obj="griewank", n=4096, pop=4200, seed=42, maxeval=4500)),
+                (4, dict(obj="griewank", n=4096, pop=4200, seed=42, maxeval=4500))]
+
+
+@pytest.mark.parametrize("world,a", WINDOW_CASES)
+def test_crs_column_sharded_windows(world, a):
+    """round 6: the column-sharded population with the window RESOLVED ON THE DEVICE (hip/crs_chain.hip, SH instance) — every rank's
+    kernel forms its columns of every slot's trial point and stores them into every rank's TX through peer-mapped memory
+    (hipIpcOpenMemHandle; the ranks here are processes sharing the one GPU, each on its share of the compute units:
+    "amd_cu_share"), evaluates the whole point and resolves the chain as a single device does.  No collective per window; the
+    run is the single-process run bit for bit: trace, result, stream position."""
+    s = single("gpu_crs", a)
+    assert s["ret"] == 5 and s["nevals"] >= a["maxeval"]
+    for d in run_world("gpu_crs", dict(a, params={"amd_cu_share": world}), world=world):
+        same(d, s)
+        # set-up exchanges only (fingerprint / ready agreements, the buffers' handles, the initial values, the first best row): none per window
+        assert d["collectives"][0] <= 12 and d["rounds"][0] > 3, (d["collectives"][0], d["rounds"][0])
+        assert d["stats_allgather_bytes"][0] > 0          # what crossed inside the launches
+
+
+def test_crs_column_sharded_windows_ranks_leave_together():
+    """force_stop raised on ONE rank only: its stop bit crosses inside the next window's launch, every rank returns
+    NLOPT_FORCED_STOP after the same evaluation"""
+    a = dict(obj="griewank", n=1024, pop=20000, seed=3, maxeval=4000000, force_stop_rank=1, force_stop_after=1.5)
+    res = run_world("gpu_crs", dict(a, params={"amd_cu_share": 2}), world=2)
+    assert res[0]["ret"][0] == res[1]["ret"][0] == -5
+    assert res[0]["nevals"][0] == res[1]["nevals"][0] > 20000
+    assert np.array_equal(res[0]["x"], res[1]["x"]) and res[0]["minf"][0] == res[1]["minf"][0]
 
 
 @pytest.mark.parametrize("world,ncon", [(2, 4), (3, 0)])
