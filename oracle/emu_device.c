@@ -19,6 +19,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
 
 #define EMU_ERR 999
 
@@ -48,8 +54,34 @@ static int emu_launch_fails(void) { return ++emu_launch_count == emu_launch_fail
 #define EMU_LAUNCH() do { if (emu_launch_fails()) return EMU_ERR; } while (0)
 void *nla_dev_malloc(size_t bytes) { return emu_alloc(bytes); }
 void nla_dev_free(void *p) { emu_release(p); }
-void *nla_dev_malloc_uncached(size_t bytes) { return emu_alloc(bytes); }
-void nla_dev_free_uncached(void *p) { nla_dev_free(p); }
+/* "uncached device memory" is what the workgroups of one launch — and, for a column-sharded CRS2_LM job, the launches of different
+ * RANKS — hand data to each other through: here an anonymous shared-memory file (memfd) mapped shared, so that another process can map
+ * the same pages (nla_ipc_export / nla_ipc_open below: the peer opens /proc/<pid>/fd/<fd>; nothing is left behind when a process dies) */
+#define EMU_UC_MAX 64
+static struct { void *p; size_t bytes; int fd; } emu_uc[EMU_UC_MAX];
+void *nla_dev_malloc_uncached(size_t bytes)
+{
+    int k, fd;
+    void *p;
+    if (++emu_alloc_count == emu_alloc_fail_at) return NULL;
+    if (!bytes) bytes = 1;
+    for (k = 0; k < EMU_UC_MAX && emu_uc[k].p; ++k) { }
+    if (k == EMU_UC_MAX) return NULL;
+    fd = (int) syscall(SYS_memfd_create, "nla_emu_uc", 0u);
+    if (fd < 0) return NULL;
+    if (ftruncate(fd, (off_t) bytes)) { close(fd); return NULL; }
+    p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (p == MAP_FAILED) { close(fd); return NULL; }
+    emu_uc[k].p = p; emu_uc[k].bytes = bytes; emu_uc[k].fd = fd;
+    ++emu_live;
+    return p;
+}
+void nla_dev_free_uncached(void *p)
+{
+    if (!p) return;
+    for (int k = 0; k < EMU_UC_MAX; ++k)
+        if (emu_uc[k].p == p) { munmap(p, emu_uc[k].bytes); close(emu_uc[k].fd); emu_uc[k].p = NULL; --emu_live; return; }
+}
 void nla_debug_uncached_stats(long out[4]) { out[0] = out[1] = out[2] = out[3] = 0; }
 void *nla_host_malloc(size_t bytes) { return emu_alloc(bytes); }
 void nla_host_free(void *p) { emu_release(p); }
@@ -62,22 +94,103 @@ int nla_memset(void *dst, int value, size_t bytes, void *st) { (void) st; if (by
 void *nla_stream_create(void) { return emu_alloc(1); }
 void *nla_stream_create_background(void) { return emu_alloc(1); }
 void *nla_stream_create_cu_share(int part, int parts) { (void) part; (void) parts; return emu_alloc(1); }
-/* no peer-mapped memory between emulated devices: a column-sharded CRS2_LM job that asks for device-resolved windows finds out during
- * its set-up and falls back — on every rank alike — to the conservative passes (crs_engine.c, crs_open_common) */
-int nla_ipc_export(const void *p, void *blob96) { (void) p; (void) blob96; return EMU_ERR; }
-void *nla_ipc_open(const void *blob96) { (void) blob96; return NULL; }
-void nla_ipc_close(void *p) { (void) p; }
+/* peer-mapped memory between emulated devices: the blob names the exporting process and its memfd */
+typedef struct { uint64_t magic; int64_t pid; int32_t fd; int32_t pad; uint64_t bytes; } emu_ipc_blob;
+static struct { void *p; size_t bytes; } emu_ipc_open[EMU_UC_MAX];
+int nla_ipc_export(const void *p, void *blob96)
+{
+    emu_ipc_blob b;
+    if (getenv("NLA_EMU_NO_IPC")) return EMU_ERR;                 /* (tests: the set-up falls back to the conservative passes, on every rank) */
+    for (int k = 0; k < EMU_UC_MAX; ++k)
+        if (emu_uc[k].p == p) {
+            memset(&b, 0, sizeof b);
+            b.magic = 0x656d75697063ull; b.pid = (int64_t) getpid(); b.fd = emu_uc[k].fd; b.bytes = emu_uc[k].bytes;
+            memset(blob96, 0, NLA_IPC_BYTES);
+            memcpy(blob96, &b, sizeof b);
+            return 0;
+        }
+    return EMU_ERR;
+}
+void *nla_ipc_open(const void *blob96)
+{
+    emu_ipc_blob b;
+    char path[64];
+    int fd, k;
+    void *p;
+    memcpy(&b, blob96, sizeof b);
+    if (b.magic != 0x656d75697063ull) return NULL;
+    for (k = 0; k < EMU_UC_MAX && emu_ipc_open[k].p; ++k) { }
+    if (k == EMU_UC_MAX) return NULL;
+    snprintf(path, sizeof path, "/proc/%lld/fd/%d", (long long) b.pid, (int) b.fd);
+    fd = open(path, O_RDWR);
+    if (fd < 0) return NULL;
+    p = mmap(NULL, (size_t) b.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return NULL;
+    emu_ipc_open[k].p = p; emu_ipc_open[k].bytes = (size_t) b.bytes;
+    ++emu_live;
+    return p;
+}
+void nla_ipc_close(void *p)
+{
+    if (!p) return;
+    for (int k = 0; k < EMU_UC_MAX; ++k)
+        if (emu_ipc_open[k].p == p) { munmap(p, emu_ipc_open[k].bytes); emu_ipc_open[k].p = NULL; --emu_live; return; }
+}
+/* the column-sharded window (hip/crs_chain.hip, SH instance), one emulated device per PROCESS: this rank's launcher walks the window's
+ * slots front to back (port_kernels.c, orc_k_crs_chain_cols), stores its columns of a slot into every rank's TX, raises its chunk flags
+ * everywhere and waits — really waits: the other ranks are other processes doing the same — until the slot's flags of all ranks show this
+ * launch, then evaluates and advances the chain as the single-process launcher does.  Same flag / stop-word protocol as the kernel. */
+#define EMU_SH_MAXW 8
+typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
+typedef struct { int world, rank, c0, ldf, chunks_total, chunk0; double *peerTX[EMU_SH_MAXW]; uint32_t *peerflags[EMU_SH_MAXW], *peerstop[EMU_SH_MAXW];
+                 const double *xbest, *lbf, *ubf; } emu_shard;
 int nla_crs_chain_sh_chunks(int n, int ncols) { (void) n; return (ncols + 63) / 64; }
-size_t nla_crs_chain_sh_table_bytes(void) { return 64; }
-size_t nla_crs_chain_sh_stop_bytes(void) { return 64; }
+size_t nla_crs_chain_sh_table_bytes(void) { return sizeof(emu_shard); }
+size_t nla_crs_chain_sh_stop_bytes(void) { return sizeof(uint32_t) * 2 * EMU_SH_MAXW; }
 int nla_crs_chain_sh_table(void *host_image, int world, int rank, int c0, int ldf, int chunks_total, int chunk0, void *const *peerTX,
                            void *const *peerflags, void *const *peerstop, const double *xbest, const double *lbf, const double *ubf)
 {
-    (void) host_image; (void) world; (void) rank; (void) c0; (void) ldf; (void) chunks_total; (void) chunk0; (void) peerTX; (void) peerflags; (void) peerstop;
-    (void) xbest; (void) lbf; (void) ubf;
-    return EMU_ERR;
+    emu_shard t;
+    if (world < 2 || world > EMU_SH_MAXW || rank < 0 || rank >= world) return EMU_ERR;
+    memset(&t, 0, sizeof t);
+    t.world = world; t.rank = rank; t.c0 = c0; t.ldf = ldf; t.chunks_total = chunks_total; t.chunk0 = chunk0;
+    for (int r = 0; r < world; ++r) { t.peerTX[r] = (double *) peerTX[r]; t.peerflags[r] = (uint32_t *) peerflags[r]; t.peerstop[r] = (uint32_t *) peerstop[r]; }
+    t.xbest = xbest; t.lbf = lbf; t.ubf = ubf;
+    memcpy(host_image, &t, sizeof t);
+    return 0;
 }
 uint32_t nla_crs_chain_sh_tickets(int n, int ncols, int K, int grid_cap) { (void) grid_cap; return (uint32_t) nla_crs_chain_sh_chunks(n, ncols) * (uint32_t) K + 1u; }
+typedef struct { const emu_shard *S; double *TX; int ncols, mychunks; uint32_t seq; int failed; } emu_sh_ctx;
+static double emu_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec; }
+static int emu_sh_wait(const uint32_t *word, uint32_t want, int exact)
+{
+    const double t0 = emu_now();
+    for (unsigned spin = 0;; ++spin) {
+        const uint32_t v = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if (exact ? (v >> 2) == (want >> 2) : (int32_t) (v - want) >= 0) return 0;
+        if ((spin & 63u) == 63u) { sched_yield(); if (emu_now() - t0 > 20.) return -1; }
+    }
+}
+static int emu_sh_exchange(void *vctx, int a, int q)
+{
+    emu_sh_ctx *c = (emu_sh_ctx *) vctx;
+    const emu_shard *S = c->S;
+    const double *mine = c->TX + (size_t) q * (size_t) S->ldf + S->c0;
+    for (int r = 0; r < S->world; ++r)
+        if (r != S->rank) memcpy(S->peerTX[r] + (size_t) q * (size_t) S->ldf + S->c0, mine, sizeof(double) * (size_t) c->ncols);
+    for (int r = 0; r < S->world; ++r)
+        for (int ch = 0; ch < c->mychunks; ++ch)
+            __atomic_store_n(S->peerflags[r] + (size_t) a * (size_t) S->chunks_total + (size_t) (S->chunk0 + ch), c->seq << 2, __ATOMIC_RELEASE);
+    for (int ch = 0; ch < S->chunks_total; ++ch)
+        if (emu_sh_wait(S->peerflags[S->rank] + (size_t) a * (size_t) S->chunks_total + (size_t) ch, c->seq << 2, 0)) { c->failed = 1; return -1; }
+    return 0;
+}
+int orc_k_crs_chain_cols(int obj, int n, int ncols, int c0, int ld, int ldf, const double *X, int64_t i0, double f_best, const double *xbest,
+                         const int32_t *jn_ring, const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                         uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub,
+                         const double *lbf, const double *ubf, double *TX, double *TM, orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec,
+                         int fwcap, const orc_slot_status *decide_with, uint32_t *dbg, int (*exchange)(void *, int, int), void *ctx);
 int nla_k_crs_chain_sh(int obj, int n, int ncols, int ld, int ldf, const double *X, int64_t i0, double f_best, const int32_t *jn_ring,
                        const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
                        uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int w_on_host, int slot_mask,
@@ -85,11 +198,27 @@ int nla_k_crs_chain_sh(int obj, int n, int ncols, int ld, int ldf, const double 
                        nla_crs_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, int ctrl_is_zero,
                        const void *table, uint32_t seq, uint32_t stopbits, int grid_cap, void *stream)
 {
-    (void) grid_cap; (void) obj; (void) n; (void) ncols; (void) ld; (void) ldf; (void) X; (void) i0; (void) f_best; (void) jn_ring; (void) pos_ring; (void) last_ring;
-    (void) words_ring; (void) ring_blocks; (void) first_block; (void) K; (void) W; (void) Wf; (void) nW; (void) w_on_host; (void) slot_mask; (void) lb;
-    (void) ub; (void) TX; (void) TM; (void) ctrl; (void) ticket_base; (void) status; (void) fwcnt; (void) fwrec; (void) fwcap; (void) ctrl_is_zero;
-    (void) table; (void) seq; (void) stopbits; (void) stream;
-    return EMU_ERR;
+    const emu_shard *S = (const emu_shard *) table;
+    emu_sh_ctx c;
+    uint32_t forced = 0, timed = 0;
+    int nc;
+    (void) w_on_host; (void) ctrl; (void) ticket_base; (void) ctrl_is_zero; (void) grid_cap; (void) stream;
+    EMU_LAUNCH();
+    if (!S || K > 256 || nW > 256 || obj < 0 || ldf != S->ldf) return EMU_ERR;
+    nc = n - S->c0 < ncols ? n - S->c0 : ncols;                     /* (the kernel's pad column is not needed here) */
+    c.S = S; c.TX = TX; c.ncols = nc; c.mychunks = nla_crs_chain_sh_chunks(n, ncols); c.seq = seq; c.failed = 0;
+    for (int r = 0; r < S->world; ++r)
+        __atomic_store_n(S->peerstop[r] + (seq & 1u) * EMU_SH_MAXW + (uint32_t) S->rank, (seq << 2) | (stopbits & 3u), __ATOMIC_RELEASE);
+    (void) orc_k_crs_chain_cols(obj, n, nc, S->c0, ld, ldf, X, i0, f_best, S->xbest, jn_ring, pos_ring, last_ring, words_ring, ring_blocks, first_block, K,
+                                W, Wf, nW, slot_mask, lb, ub, S->lbf, S->ubf, TX, TM, (orc_slot_status *) status, fwcnt, fwrec, fwcap, NULL, NULL,
+                                emu_sh_exchange, &c);
+    for (int r = 0; r < S->world && !c.failed; ++r) {
+        const uint32_t *w = S->peerstop[S->rank] + (seq & 1u) * EMU_SH_MAXW + (uint32_t) r;
+        if (emu_sh_wait(w, seq << 2, 1)) { c.failed = 1; break; }
+        forced |= __atomic_load_n(w, __ATOMIC_ACQUIRE) & 1u; timed |= (__atomic_load_n(w, __ATOMIC_ACQUIRE) >> 1) & 1u;
+    }
+    status[K].fT = forced ? 1. : 0.; status[K].fM = timed ? 1. : 0.; status[K].t = c.failed; status[K].pad = 0;
+    return 0;
 }
 int nla_k_crs_commit_sh(int nc, int ld, int ldf, int c0, double *X, const double *TX, const double *TM, int ncommit,
                         const int32_t *h_slot, const int32_t *h_kind, const int64_t *h_row, void *zero, size_t zero_bytes,
@@ -868,7 +997,6 @@ int nla_k_crs_sh_eval(int obj, int n, int colper, uint64_t first_block, int K, c
     return 0;
 }
 
-typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
 void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                      const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                      const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,

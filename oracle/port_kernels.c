@@ -147,10 +147,29 @@ int orc_k_advance_slot(int n, int ld, const double *X, int64_t i0, int32_t jn, c
  * concurrently; a slot there waits until the fate of the row it needs is known, so its reads are these.  Records as the kernel
  * writes them: j | producer slot << 8 | kind << 16. */
 typedef struct { double fT, fM; int32_t t, pad; } orc_slot_status;
+/* the same on a COLUMN SLICE (hip/crs_chain.hip, SH instance): X holds columns [c0, c0 + ncols) of every row (stride
+ * ld), TX / TM hold WHOLE points (stride ldf); the slot's slice is formed here, `exchange` (NULL: single process) hands it to the other
+ * ranks and returns when theirs are in this rank's TX; evaluation, mutation (around the whole best row `xbest`, clamped by the whole
+ * bounds lbf / ubf) and the chain are the single-process statements on the whole point.  lb / ub: the slice's bounds. */
+typedef int (*orc_chain_exchange_fn)(void *ctx, int a, int q);
+int orc_k_crs_chain_cols(int obj, int n, int ncols, int c0, int ld, int ldf, const double *X, int64_t i0, double f_best, const double *xbest,
+                         const int32_t *jn_ring, const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                         uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub,
+                         const double *lbf, const double *ubf, double *TX, double *TM, orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec,
+                         int fwcap, const orc_slot_status *decide_with, uint32_t *dbg, orc_chain_exchange_fn exchange, void *ctx);
 void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double f_best, const int32_t *jn_ring, const int32_t *pos_ring,
                      const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks, uint64_t first_block, int K,
                      const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub, double *TX, double *TM,
                      orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec, int fwcap, const orc_slot_status *decide_with, uint32_t *dbg)
+{
+    (void) orc_k_crs_chain_cols(obj, n, n, 0, ld, ld, X, i0, f_best, X + (size_t) i0 * (size_t) ld, jn_ring, pos_ring, last_ring, words_ring, ring_blocks,
+                                first_block, K, W, Wf, nW, slot_mask, lb, ub, lb, ub, TX, TM, status, fwcnt, fwrec, fwcap, decide_with, dbg, NULL, NULL);
+}
+int orc_k_crs_chain_cols(int obj, int n, int ncols, int c0, int ld, int ldf, const double *X, int64_t i0, double f_best, const double *xbest,
+                         const int32_t *jn_ring, const int32_t *pos_ring, const int32_t *last_ring, const uint32_t *words_ring, uint32_t ring_blocks,
+                         uint64_t first_block, int K, const int64_t *W, const double *Wf, int nW, int slot_mask, const double *lb, const double *ub,
+                         const double *lbf, const double *ubf, double *TX, double *TM, orc_slot_status *status, uint32_t *fwcnt, uint32_t *fwrec,
+                         int fwcap, const orc_slot_status *decide_with, uint32_t *dbg, orc_chain_exchange_fn exchange, void *ctx)
 {
     /* decide_with != NULL: the chain's decisions are taken on THESE f values (a device run's, which differ from this file's in the
      * last bits: enough to flip a comparison between two nearly equal values) — everything else is computed here as always */
@@ -163,9 +182,9 @@ void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double
         const uint32_t rb = (uint32_t) (block % ring_blocks);
         const int q = (int) (block & (uint64_t) slot_mask), nun = a < nW ? a : nW;
         const int32_t *pos = pos_ring + (size_t) rb * (size_t) n;
-        double *acc = TX + (size_t) q * (size_t) ld, *m = TM + (size_t) q * (size_t) ld;
+        double *whole = TX + (size_t) q * (size_t) ldf, *acc = whole + c0, *m = TM + (size_t) q * (size_t) ldf;
         uint32_t nrec = 0;
-        memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) n);
+        memcpy(acc, X + (size_t) i0 * (size_t) ld, sizeof(double) * (size_t) ncols);
         for (int t = 0; t < n; ++t) {
             const int64_t r = pick_row(n, pos, last_ring[rb], i0, t);
             const double *xi = X + (size_t) r * (size_t) ld;
@@ -175,24 +194,25 @@ void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double
                     uint32_t pj = 0, kind = 0;
                     if (rs && (int) (rs >> 3) < a) {
                         pj = rs >> 3; kind = (rs >> 1) & 3u;
-                        xi = (kind == 1 ? TX : TM) + (size_t) ((first_block + pj) & (uint64_t) slot_mask) * (size_t) ld;
+                        xi = (kind == 1 ? TX : TM) + (size_t) ((first_block + pj) & (uint64_t) slot_mask) * (size_t) ldf + c0;
                     }
                     if ((int) nrec < fwcap) fwrec[(size_t) a * (size_t) fwcap + nrec] = (uint32_t) j | (pj << 8) | (kind << 16);
                     ++nrec;
                     break;
                 }
-            if (t == jn_ring[rb]) for (int k = 0; k < n; ++k) acc[k] -= xi[k] * (0.5 * n);
-            else                  for (int k = 0; k < n; ++k) acc[k] += xi[k];
+            if (t == jn_ring[rb]) for (int k = 0; k < ncols; ++k) acc[k] -= xi[k] * (0.5 * n);
+            else                  for (int k = 0; k < ncols; ++k) acc[k] += xi[k];
         }
-        for (int k = 0; k < n; ++k) {
+        for (int k = 0; k < ncols; ++k) {
             acc[k] *= 2.0 / n;
             if (acc[k] > ub[k]) acc[k] = ub[k];
             else if (acc[k] < lb[k]) acc[k] = lb[k];
         }
         fwcnt[a] = nrec;
-        orc_k_eval(obj, n, ld, acc, 1, &status[a].fT);
-        orc_k_mutate(n, X + (size_t) i0 * (size_t) ld, acc, words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n, lb, ub, m);
-        orc_k_eval(obj, n, ld, m, 1, &status[a].fM);
+        if (exchange && exchange(ctx, a, q)) { free(rowstate); return -1; }
+        orc_k_eval(obj, n, ldf, whole, 1, &status[a].fT);
+        orc_k_mutate(n, xbest, whole, words_ring + (size_t) ((block + 1) % ring_blocks) * 2 * (size_t) n, lbf, ubf, m);
+        orc_k_eval(obj, n, ldf, m, 1, &status[a].fM);
         status[a].t = n; status[a].pad = 0;
         /* the chain: every block up to this one can be decided now */
         while (!halt && next < (uint32_t) K && next <= (uint32_t) a) {
@@ -224,4 +244,5 @@ void orc_k_crs_chain(int obj, int n, int ld, const double *X, int64_t i0, double
         for (int j = 0; j < nW; ++j) dbg[8 + j] = rowstate[j];
     }
     free(rowstate);
+    return 0;
 }

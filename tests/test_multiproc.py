@@ -135,8 +135,57 @@ SHARDED_CRS = [
 ]
 
 
+def _no_windows(extra):
+    """the conservative passes + one all-gather per pass (round 3's sharded path; since round 6 the fallback where the coordinates cannot
+    be dealt in whole cache lines, where a rank cannot map its peers' buffers, or on request)"""
+    return dict(extra, params=dict(extra.get("params") or {}, amd_shard_windows=0))
+
+
+SHARDED_WINDOWS = [
+    # world, obj, n, pop, seed, maxeval, extra
+    (2, "ackley", 64, 300, 7, 1500, {}),                                   # 32 + 32 columns
+    (2, "griewank", 257, 600, 5, 1100, {}),                                # 144 + 113 columns, odd n
+    (3, "griewank", 257, 600, 5, 1100, {}),                                # 96 + 96 + 65
+    (3, "levy", 130, 400, 12345, 1300, {}),                                # coupled across slice boundaries (48 + 48 + 34)
+    (2, "rosenbrock", 48, 200, 9, 2500, dict(xtol_rel=1e-3)),              # x needed on the host: whole points are local in this mode
+    (4, "rastrigin", 128, 2000, 42, 4000, dict(params={"amd_window_factor": 3.0})),
+    (2, "sphere", 40, 300, 3, 4000, dict(ftol_rel=1e-6)),
+]
+
+
+@pytest.mark.parametrize("world,obj,n,pop,seed,maxeval,extra", SHARDED_WINDOWS)
+def test_crs_column_sharded_windows_are_the_oracles_run(world, obj, n, pop, seed, maxeval, extra):
+    """round 6: the column-sharded population with the window resolved on the device — over the emulated device every rank's launcher forms
+    its columns of a slot, stores them into every rank's TX (shared memory mapped through the library's nla_ipc_* layer, as the HIP build
+    maps peer device memory), raises its chunk flags and waits for the other PROCESSES' flags before it evaluates: the engine's set-up
+    (handle exchange, table), the per-window protocol (launch numbers, flags that are never cleared, stop words) and the driver above it
+    are the product's.  The run is the single-process oracle's bit for bit on every rank, with no collective per window."""
+    kw = {k: v for k, v in extra.items() if k in ("ftol_rel", "xtol_rel")}
+    res = run_world("gpu_crs", dict(obj=obj, n=n, pop=pop, seed=seed, maxeval=maxeval, **extra), world=world, extra_env=EMU)
+    p = O.run_port_crs(obj, n, pop, seed, maxeval=maxeval, trace_cap=maxeval + 4096, **kw)
+    for d in res:
+        assert d["ret"][0] == p["ret"] and d["nevals"][0] == p["nevals"] and d["minf"][0] == p["minf"]
+        assert np.array_equal(d["x"], p["x"])
+        for key in ("f", "row", "kind", "accepted"):
+            assert np.array_equal(d[key], p["trace"][key]), key
+        assert d["after"][0] == res[0]["after"][0]
+        assert d["collectives"][0] <= 12 and d["rounds"][0] >= 3, (d["collectives"][0], d["rounds"][0])       # set-up exchanges only
+        assert d["stats_allgather_bytes"][0] > 0
+
+
+def test_crs_column_sharded_windows_fall_back_together_when_a_peer_cannot_be_mapped():
+    """NLA_EMU_NO_IPC: exporting the window buffers fails (on every rank here; one failing rank takes the same path: the handle exchange
+    carries an invalid handle) -> all ranks agree and run the conservative passes: same run, a collective per pass"""
+    a = dict(obj="ackley", n=64, pop=300, seed=7, maxeval=1500)
+    res = run_world("gpu_crs", a, world=2, extra_env=dict(EMU, NLA_EMU_NO_IPC="1"))
+    p = O.run_port_crs("ackley", 64, 300, 7, maxeval=1500, trace_cap=6000)
+    for d in res:
+        assert d["ret"][0] == p["ret"] and np.array_equal(d["f"], p["trace"]["f"]) and np.array_equal(d["x"], p["x"])
+        assert d["collectives"][0] >= d["rounds"][0]
+
+
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("obj,n,pop,seed,maxeval,extra", SHARDED_CRS)
+@pytest.mark.parametrize("obj,n,pop,seed,maxeval,extra", [(o_, n_, p_, s_, m_, _no_windows(e_)) for o_, n_, p_, s_, m_, e_ in SHARDED_CRS])
 def test_crs_column_sharded_over_the_ranks_is_the_oracles_run(world, obj, n, pop, seed, maxeval, extra):
     """every rank keeps 1/world of the COLUMNS of the population, runs the gather-sum, mutation and row replacement on its slice, the
     candidates of a pass are all-gathered and evaluated by every rank: the run — every f, every decision, the result, the stream
@@ -172,7 +221,7 @@ def test_crs_column_sharded_large_n_prefix_world3():
     n = 2050 over 3 ranks (684 + 684 + 682 columns), a prefix of the trial chain.  (The device twin, tests/test_gpu_multiproc.py, runs
     the metric's own n = 4096; here that costs 40 s of emulation.)"""
     n, pop, seed, me = 2050, 2100, 42, 2230
-    res = run_world("gpu_crs", dict(obj="griewank", n=n, pop=pop, seed=seed, maxeval=me), world=3, extra_env=EMU, timeout=1200)
+    res = run_world("gpu_crs", dict(obj="griewank", n=n, pop=pop, seed=seed, maxeval=me, params={"amd_shard_windows": 0}), world=3, extra_env=EMU, timeout=1200)
     p = O.run_port_crs("griewank", n, pop, seed, maxeval=me, trace_cap=me + 64)
     for d in res:
         assert d["ret"][0] == p["ret"] and d["nevals"][0] == p["nevals"]
@@ -203,11 +252,12 @@ def test_crs_column_sharded_variants_equal_the_single_process_run(a):
             assert not np.array_equal(d["x1"], d["x"])
 
 
+@pytest.mark.parametrize("windows", [0, 1], ids=["passes", "windows"])
 @pytest.mark.parametrize("a", [dict(force_stop_rank=1, force_stop_after=0.3), dict(maxtime_rank=0, maxtime=4.0)], ids=["force_stop_on_one_rank", "maxtime_on_one_rank"])
-def test_crs_column_sharded_ranks_leave_together(a):
+def test_crs_column_sharded_ranks_leave_together(a, windows):
     """a stop condition only ONE rank sees (its user's force_stop, its own clock) is agreed by all ranks once per pass: every rank
     returns the same result after the same number of evaluations — nobody is left waiting in an all-gather"""
-    cfg = dict(obj="rastrigin", n=64, pop=400, seed=7, maxeval=2000000, **a)
+    cfg = dict(obj="rastrigin", n=64, pop=400, seed=7, maxeval=2000000, params={"amd_shard_windows": windows}, **a)      # (windows: the stop bits cross inside the launch)
     res = run_world("gpu_crs", cfg, world=2, extra_env=EMU, timeout=300)
     want = -5 if "force_stop_rank" in a else 6                  # NLOPT_FORCED_STOP / NLOPT_MAXTIME_REACHED
     assert res[0]["ret"][0] == want and res[1]["ret"][0] == want
@@ -405,7 +455,7 @@ def test_shm_transport_allgather(world, slot):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("obj,n,pop,seed,maxeval,extra", [SHARDED_CRS[0], SHARDED_CRS[3]])
+@pytest.mark.parametrize("obj,n,pop,seed,maxeval,extra", [SHARDED_CRS[0][:5] + (_no_windows(SHARDED_CRS[0][5]),), SHARDED_CRS[3][:5] + (_no_windows(SHARDED_CRS[3][5]),)])
 def test_crs_column_sharded_over_the_shm_transport(world, obj, n, pop, seed, maxeval, extra):
     """the column-sharded CRS2_LM run with the candidates exchanged through the shared-memory transport: the oracle's run bit for bit"""
     kw = {k: v for k, v in extra.items() if k in ("ftol_rel", "xtol_rel")}
