@@ -648,7 +648,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
     # the gather kernel of this run: device-resolved windows (hip/crs_chain.hip) at every dimension; the conservative passes with
     # --param amd_forward=0 and, on column slices, in a sharded job
     fw = [kv.split("=", 1)[1] for kv in CRS_PARAMS if kv.split("=", 1)[0] == "amd_forward"]         # (--param amd_forward=0/1: the A/B switch)
-    chain = (float(fw[-1]) != 0 if fw else True) and not sharded
+    # a sharded job runs device-resolved windows too since round 6 (the slices cross between the ranks' kernels through peer-mapped memory);
+    # it falls back to conservative passes + one all-gather per pass where that cannot be set up: told apart by the slots a pass starts
+    sh_windows = sharded and passes > 0 and slots / passes > 32
+    chain = (float(fw[-1]) != 0 if fw else True) and (not sharded or sh_windows)
     gkernel = "crs_chain_kernel" if chain else "crs_advance_kernel"
     traffic, traffic_src = pmc_traffic(gkernel) if (n, pop, a.obj) == (4096, 100000, "griewank") else (None, None)
     out = {
@@ -658,8 +661,10 @@ def bench_crs(a, nlopt_amd, L, rank, world, sync_all, reduce):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "NLOPT_GN_CRS2_LM %s n=%d pop=%d seed=%d, %d candidate evals per step, population resident in HBM%s"
                                % (a.obj, n, pop, a.seed, a.evals_per_step,
-                                  "" if world == 1 else ("; ONE job over %d ranks: population sharded by coordinate (%d columns per rank), candidates of a pass "
-                                                         "all-gathered over RCCL (communicator ranks: %d)" % (world, (n + world - 1) // world, headline_one_job["ranks"])
+                                  "" if world == 1 else ("; ONE job over %d ranks: population sharded by coordinate (%d columns per rank), %s (communicator ranks: %d)"
+                                                         % (world, (n + world - 1) // world,
+                                                            "windows resolved on every device, each rank's columns of every trial point stored into all ranks' buffers inside the launch (peer-mapped memory over xGMI, no collective per window)"
+                                                            if sh_windows else "candidates of a pass all-gathered over RCCL", headline_one_job["ranks"])
                                                          if sharded else "; %d independent replicas (seed+rank)" % world)),
                    "evals_timed": int(evals_all), "evals_per_step_requested": a.evals_per_step},
         "roofline": {"bound": "hbm", "kernel": gkernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -14,6 +14,7 @@ _VAR = os.environ.get("NLOPT_AMD_VARIANT", "")
 _VNAME, _VFLAGS = (_VAR.split(":", 1) + [""])[:2] if _VAR else ("", "")
 OBJ = os.path.join(HERE, "lib", "obj" + ("_" + _VNAME if _VNAME else ""))
 LIB = os.path.join(HERE, "lib", "libnlopt_amd" + ("_" + _VNAME if _VNAME else "") + ".so")
+SHIM = os.path.join(HERE, "lib", "libnlopt_algs_amd" + ("_" + _VNAME if _VNAME else "") + ".so")
 
 HIP_SRC = ["hip/devrt.hip", "hip/mt_kernels.hip", "hip/crs_kernels.hip", "hip/crs_chain.hip", "hip/crs_shard.hip", "hip/isres_kernels.hip", "hip/isres_evolve2.hip", "hip/lbfgs_kernels.hip", "hip/lbfgs_resident.hip", "hip/mma_kernels.hip", "hip/mlsl_kernels.hip", "hip/esch_kernels.hip"]
 C_SRC = ["mt_host.c", "mtstream.c", "stopping.c", "objfuncs.c", "api_general.c", "api_options.c", "api_optimize.c",
@@ -66,6 +67,15 @@ def build(force=False, verbose=False):
             list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lm", "-ldl"])
+    # the secondary boundary (csrc/shim/algs_shim.c): crs_minimize / isres_minimize / mlsl_minimize with the reference's signatures over the
+    # same objects — a library of its own, -Bsymbolic, exporting those names (and the generator's entry points) only: what goes in front of
+    # an unmodified libnlopt.so with LD_PRELOAD
+    shim_src, shim_map = os.path.join(CSRC, "shim", "algs_shim.c"), os.path.join(CSRC, "shim", "shim.map")
+    shim_obj = os.path.join(OBJ, "algs_shim.o")
+    if force or _newer(shim_src, shim_obj, hdrs):
+        run(["gcc"] + C_FLAGS + ["-c", shim_src, "-o", shim_obj])
+    if jobs or force or not os.path.exists(SHIM) or _newer(shim_obj, SHIM, (shim_map,)):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-Wl,--version-script=" + shim_map, "-o", SHIM] + objs + [shim_obj] + ["-lpthread", "-lm", "-ldl"])
     return LIB
 
 

@@ -68,6 +68,12 @@ void nlopt_srand(unsigned long seed)                                /* general.c
     t_mti = NLA_MT_N;
 }
 
+void nla_init_genrand(unsigned long seed)                           /* mt19937ar.c:80-95 as a call of its own (the shim's nlopt_init_genrand) */
+{
+    nla_mt_seed_array(t_mt, seed);
+    t_mti = NLA_MT_N;
+}
+
 void nlopt_srand_time(void)                                         /* general.c:237-240 */
 {
     nlopt_srand(nla_time_seed() + (unsigned long) nla_thread_id() * 314159);

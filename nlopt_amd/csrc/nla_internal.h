@@ -44,6 +44,7 @@ int nla_isinf(double x);
 int nla_istiny(double x);
 double nla_seconds(void);
 unsigned long nla_time_seed(void);
+void nla_init_genrand(unsigned long seed);
 long nla_thread_id(void);
 
 /* ---- constraints (reference: nlopt-util.h:119-126) ------------------------------------------- */
