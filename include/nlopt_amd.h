@@ -118,8 +118,12 @@ typedef struct {
     /* MLSL: iterations whose sampling phase (points, values, distances) had been computed beside the local phase before them
      * (mlsl_driver.c, mlsl_enqueue_ahead): every iteration but the first of a one-rank run with a compiled-in objective */
     uint64_t mlsl_sampled_ahead;
+    uint64_t cobyla_host_searches;   /* GN_MLSL + LN_COBYLA on a device objective: searches of batches too small for the device, run by the host algorithm */
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
+/* ... for a client that may have been built against an older or newer header: writes at most `bytes` bytes of the structure (fields are
+ * only ever appended) and returns the library's sizeof(nlopt_amd_stats); 0 = invalid arguments */
+size_t nlopt_amd_get_stats_sized(const nlopt_opt opt, void *out, size_t bytes);
 
 /* generation hook: called on the caller's thread by ISRES at the start of every generation (isres.c:130) and by
  * MLSL at the start of every iteration (mlsl.c:345) — the device is idle at those points — with the number of
@@ -526,6 +530,22 @@ typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel, rho_init, sigma_
                } nla_mma_params;
 size_t nla_mma_work_doubles(int ld, int count);               /* doubles of `work` */
 size_t nla_mma_save_bytes(void);
+
+/* ---- LN_COBYLA with bound constraints only (src/algs/cobyla/cobyla.c), batched: the default local optimiser of NLOPT_GN_MLSL(_LDS)
+ * (optimize.c:763-768; MLSL strips its local optimiser's nonlinear constraints, options.c:824-846) ------------------------------------ */
+/* stopping values as nlopt_stopping holds them; exact / sign / xtol_abs / abort / done as for LD_LBFGS */
+typedef struct { double minf_max, ftol_rel, ftol_abs, xtol_rel; int32_t maxeval, exact; double sign;
+                 const double *xtol_abs; const int32_t *abort; int32_t *done; } nla_cobyla_params;
+size_t nla_cobyla_work_doubles(int n, int ld, int count);      /* doubles of `work` (a search's state is in LDS: a token size) */
+size_t nla_cobyla_work_ints(int n, int count);                 /* ints of `iwork` (the same) */
+size_t nla_cobyla_lds_bytes(int n);                            /* LDS one search of n variables in a finite box takes (simplex, inverse, models, LP basis) */
+int nla_cobyla_fits(int n);                                    /* 1: that fits a compute unit's 160 KB (n <= 51) — beyond, the caller runs the host algorithm */
+/* replaces: cobyla_minimize (cobyla.c:181-271) as nlopt_optimize(LN_COBYLA) reaches it (optimize.c:836-851, with the memoized best
+ * point of :450-508,1064-1071) for `count` independent starts at once, one WAVEFRONT per start, compiled-in device objectives only.
+ * X: count x ld, starts in, results out; dx: the initial step (n, device) or NULL = nlopt_set_default_initial_step per start
+ * (options.c:921-946); out[i] = (f, nlopt_result, objective calls, the same, 0).  Fails (hipErrorInvalidValue) when !nla_cobyla_fits(n). */
+int nla_k_cobyla_batch(int obj, int n, int ld, int count, const double *lb, const double *ub, const double *dx, double *X,
+                       double *work, int *iwork, const nla_cobyla_params *params, nla_lbfgs_result *out, void *stream);
 
 /* replaces: mma_minimize (mma.c:146-449) with m = 0 for `count` independent starts at once, one workgroup per start, outer
  * and inner iterations on the device (the 0-dimensional dual "solve" is dual_func's closed form, mma.c:58-137).  X: count x

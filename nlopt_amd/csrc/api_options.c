@@ -147,6 +147,15 @@ nlopt_result nlopt_set_param(nlopt_opt opt, const char *name, double val)
     if (!name) return fail_msg(opt, NLOPT_INVALID_ARGS, "invalid NULL parameter name");
     len = strnlen(name, 1024) + 1;
     if (len > 1024) return fail_msg(opt, NLOPT_INVALID_ARGS, "parameter name must be < 1024 bytes");
+    if (!strncmp(name, "amd_", 4)) {
+        /* this library's own switches: a name it does not (or no longer) read is refused instead of being stored and silently ignored — an
+         * A/B script written for a switch that has since been removed would otherwise compare two identical runs (advisor, round 5) */
+        static const char *const known[] = { "amd_forward", "amd_shard", "amd_shard_windows", "amd_cu_share", "amd_max_spec", "amd_window_factor", "amd_host_eval",
+                                             "amd_exact_dot", "amd_isres_evolve_serial", "amd_isres_overlap", "amd_lbfgs_streaming", "amd_mlsl_seg_regens", "amd_cobyla_host", "amd_cobyla_min_batch", NULL };
+        int k;
+        for (k = 0; known[k] && strcmp(name, known[k]); ++k) { }
+        if (!known[k]) return fail_msg(opt, NLOPT_INVALID_ARGS, "nlopt_amd: no such switch (the amd_* names this build reads: include/nlopt_amd.h, INTEGRATION.md E)");
+    }
     for (i = 0; i < opt->nparams; ++i) if (!strcmp(name, opt->params[i].name)) break;
     if (i == opt->nparams) {
         nla_param *np = (nla_param *) realloc(opt->params, sizeof(nla_param) * (opt->nparams + 1));
@@ -539,4 +548,12 @@ nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out)
     if (!opt || !out) return NLOPT_INVALID_ARGS;
     *out = opt->stats;
     return NLOPT_SUCCESS;
+}
+/* the same for a caller built against another version of the header: at most `bytes` bytes are written (the struct only ever grows at
+ * its end), and the library's own size comes back so that the caller can tell */
+size_t nlopt_amd_get_stats_sized(const nlopt_opt opt, void *out, size_t bytes)
+{
+    if (!opt || !out) return 0;
+    memcpy(out, &opt->stats, bytes < sizeof opt->stats ? bytes : sizeof opt->stats);
+    return sizeof opt->stats;
 }

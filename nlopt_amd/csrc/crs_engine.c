@@ -700,6 +700,7 @@ static int op_advance(void *ve, uint64_t first_block, int K, uint64_t fresh_from
     const int64_t *d_W = NULL;
     const int32_t *d_tin = NULL;
     if (K < 1 || K > KCAP || nW > KCAP || nW < 0) FAIL(e, "bad window K=%d nW=%d", K, nW);
+    if (e->shchain) FAIL(e, "this engine was set up for device-resolved windows on a column-sharded population: no conservative passes");
     if (K > op_max_slots(ve, first_block)) FAIL(e, "window reaches past the prepared batches");
     if (ensure_blocks(e, first_block, first_block + (uint64_t) K)) { if (!e->err[0]) snprintf(e->err, sizeof e->err, "batch preparation failed"); return -1; }
     e->timed = (e->n >= 2048 || e->pass_log || (e->pass_no++ % TIME_EVERY) == 0) && e->stats;
@@ -1122,7 +1123,8 @@ static nlopt_result crs_open_common(nlopt_opt opt, int n, nlopt_func f, void *f_
         /* ... or, where the coordinates can be dealt in whole 128-byte lines over at most 8 ranks, as device-resolved windows whose slices
          * cross between the ranks' kernels through peer-mapped memory ("amd_shard_windows" = 0: the conservative passes;
          * "amd_cu_share" = k: k ranks share one device — each rank's windows run on its k-th of the compute units) */
-        const int windows = shard && pb->forward && nla_crs_can_shard_windows(n, nlopt_amd_comm_world(comm)) &&
+        const int windows = shard && pb->forward && pb->max_spec != 1 /* (a window of one slot: the driver runs conservative passes) */ &&
+                            nla_crs_can_shard_windows(n, nlopt_amd_comm_world(comm)) &&
                             (!opt || nlopt_get_param(opt, "amd_shard_windows", 1) != 0);
         const int cu_parts = opt ? (int) nlopt_get_param(opt, "amd_cu_share", 0) : 0;
         if (shard) { pb->comm = comm; if (!windows) pb->forward = 0; }

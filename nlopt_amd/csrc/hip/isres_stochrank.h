@@ -44,7 +44,8 @@ __device__ __forceinline__ uint64_t sr_ld(const uint64_t *p) { return __hip_atom
 __device__ __forceinline__ void sr_st(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 SR_KERNEL void isres_stochrank_kernel(int64_t pop, int64_t nsweeps, uint64_t *__restrict__ streams,
-                                                              int *__restrict__ progress, const uint64_t *__restrict__ bits,
+                                                              int *__restrict__ progress, const uint64_t *bits /* written by mt_rankbits_kernel on another stream WHILE this kernel runs: neither
+                                                                                                                 * read-only nor unaliased for the compiler, or it may lift a row's loads above the gate's acquire fence */,
                                                               int64_t rowwords, int *__restrict__ ticket, uint8_t *__restrict__ swapped_out,
                                                               const int *__restrict__ gate, uint64_t gate_g_rank0, int64_t gate_nrows)
 {

@@ -64,7 +64,9 @@ __device__ __forceinline__ int lb_block_isum(int v, lb_shared &S)
  * are formed in parallel into LDS and then added in that order by every thread redundantly (LDS broadcast reads), so all
  * threads hold the bit-identical sum the sequential host loop produces.  A verification mode: n serial additions per
  * reduction instead of log2(256) + n/256. */
-#define LB_XCH 1024
+#ifndef LB_XCH
+#define LB_XCH 1024                 /* (cobyla_kernels.hip: 64 — its searches have n <= 64 and want the LDS for their own state) */
+#endif
 struct lb_exact_buf { double a[LB_XCH]; double b[LB_XCH]; };
 
 template <class Term>

@@ -16,6 +16,8 @@
  *             the same coroutine, the evaluations of all waiting searches of a batch made by one launch of the user's
  *             kernel. */
 #include "nla_internal.h"
+#include "objfuncs.h"
+#include <math.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,7 +34,7 @@ int nla_lbfgs_default_mf(int n, int mf, int maxeval)        /* plis.c:441-445 */
     return mf;
 }
 
-/* a reusable batch: device buffers for up to `cap` simultaneous local searches by LD_LBFGS (alg 0) or LD_MMA (alg 1) */
+/* a reusable batch: device buffers for up to `cap` simultaneous local searches by LD_LBFGS (alg 0), LD_MMA (alg 1) or LN_COBYLA (alg 2) */
 struct nla_local_ctx {
     int alg, n, ld, cap, mf;
     nla_evaluator ev;
@@ -57,6 +59,9 @@ struct nla_local_ctx {
     double *d_ftrace; int64_t ftrace_cap;   /* optional per-evaluation f trace (nla_local_ctx_set_ftrace) */
     int (*after_launch)(void *); void *after_arg;   /* one-shot: called right behind the next run's kernel launch (nla_local_ctx_after_launch) */
     int32_t *d_done; int32_t done_expected;         /* optional (nla_local_ctx_finished_counter): searches ended so far, on the device / launched so far */
+    /* alg 2: batches too small to fill the device go through the host algorithm (cobyla_small_batch_on_host) */
+    int cob_min_batch;
+    double *h_lb, *h_ub, *h_dx, *h_xtol_abs, *h_rows;
 };
 
 void nla_local_ctx_destroy(nla_local_ctx *c)
@@ -69,6 +74,7 @@ void nla_local_ctx_destroy(nla_local_ctx *c)
     if (c->d_done) nla_dev_free_uncached(c->d_done);
     nla_host_free(c->h_abort); nla_host_free(c->h_req); nla_host_free(c->h_x); nla_host_free(c->h_g); nla_host_free(c->h_f);
     nla_host_free(c->h_list);
+    free(c->h_lb); free(c->h_ub); free(c->h_dx); free(c->h_xtol_abs); free(c->h_rows);
     nla_event_destroy(c->ev0); nla_event_destroy(c->ev1);
     free(c);
 }
@@ -113,6 +119,34 @@ nla_local_ctx *nla_local_ctx_create(const nla_evaluator *ev, int n, int cap, int
     if (!c->d_work || !c->d_iwork || !c->d_hist) { nla_local_ctx_destroy(c); return NULL; }
     return c;
 }
+/* the same for LN_COBYLA with bound constraints only (alg 2; hip/cobyla_kernels.hip: GN_MLSL's default local optimiser, compiled-in device
+ * objectives only): d_dx = the initial step on the device, or NULL = the default step of every start (options.c:921-946) */
+nla_local_ctx *nla_local_ctx_create_cobyla(const nla_evaluator *ev, int n, int cap, const double *d_dx, const double *d_lb, const double *d_ub, void *stream)
+{
+    nla_local_ctx *c;
+    if (ev->kind != NLA_EVAL_DEVICE) return NULL;
+    c = (nla_local_ctx *) calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->alg = 2;
+    c->d_sigma_init = d_dx;
+    if (ctx_common(c, ev, n, cap, d_lb, d_ub, stream)) { nla_local_ctx_destroy(c); return NULL; }
+    c->d_work = (double *) nla_dev_malloc(sizeof(double) * nla_cobyla_work_doubles(n, c->ld, cap));
+    c->d_iwork = (int *) nla_dev_malloc(sizeof(int) * nla_cobyla_work_ints(n, cap));
+    c->h_lb = (double *) malloc(sizeof(double) * (size_t) n); c->h_ub = (double *) malloc(sizeof(double) * (size_t) n);
+    c->h_rows = (double *) malloc(sizeof(double) * (size_t) c->ld * (size_t) cap);
+    if (d_dx) c->h_dx = (double *) malloc(sizeof(double) * (size_t) n);
+    if (!c->d_work || !c->d_iwork || !c->h_lb || !c->h_ub || !c->h_rows || (d_dx && !c->h_dx) ||
+        nla_memcpy_d2h(c->h_lb, d_lb, sizeof(double) * (size_t) n, stream) || nla_memcpy_d2h(c->h_ub, d_ub, sizeof(double) * (size_t) n, stream) ||
+        (d_dx && nla_memcpy_d2h(c->h_dx, d_dx, sizeof(double) * (size_t) n, stream)) || nla_stream_sync(stream)) { nla_local_ctx_destroy(c); return NULL; }
+    /* One wavefront walks a search's serial chain 4 - 20 times slower than a host core (measured per evaluation of ONE search, device
+     * against the reference on the same box, profiles/r06_cobyla_batched.txt: n = 8 21.7 us against 1.0, n = 16 40.6 against 4.2,
+     * n = 32 133 against 26, n = 48 380 against 88) and hundreds of them run side by side (2048 searches: 56x / 104x one core at n = 8 / 16):
+     * the device is the faster place from about that many concurrent searches on, the host below */
+    c->cob_min_batch = n < 12 ? 24 : n < 24 ? 12 : 6;
+    return c;
+}
+/* ... the threshold can be set: 1 = every batch on the device, 0 / negative = the default above ("amd_cobyla_min_batch") */
+void nla_local_ctx_set_cobyla_min_batch(nla_local_ctx *c, int min_batch) { if (c && c->alg == 2 && min_batch > 0) c->cob_min_batch = min_batch; }
 /* the same for LD_MMA (mma_driver.c reads the parameters; sigma_init: device copy of the initial step or NULL) */
 nla_local_ctx *nla_local_ctx_create_mma(const nla_evaluator *ev, int n, int cap, const nla_mma_params *alg_params, const double *d_sigma_init,
                                         const double *d_lb, const double *d_ub, void *stream)
@@ -160,6 +194,12 @@ int nla_local_ctx_set_options(nla_local_ctx *c, int exact, const double *xtol_ab
     c->exact = exact;
     nla_dev_free(c->d_xtol_abs); nla_dev_free(c->d_x_weights);
     c->d_xtol_abs = c->d_x_weights = NULL;
+    free(c->h_xtol_abs); c->h_xtol_abs = NULL;
+    if (xtol_abs && c->alg == 2) {
+        c->h_xtol_abs = (double *) malloc(sizeof(double) * (size_t) c->n);
+        if (!c->h_xtol_abs) return -1;
+        memcpy(c->h_xtol_abs, xtol_abs, sizeof(double) * (size_t) c->n);
+    }
     if (xtol_abs) {
         c->d_xtol_abs = (double *) nla_dev_malloc(sizeof(double) * (size_t) c->ld);
         if (!c->d_xtol_abs || nla_memcpy_h2d(c->d_xtol_abs, xtol_abs, sizeof(double) * (size_t) c->n, c->st)) return -1;
@@ -192,7 +232,14 @@ int nla_local_ctx_read_ftrace(nla_local_ctx *c, int inst, int64_t count, double 
 static int launch(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, const nla_local_ext *ext)
 {
     const int obj = c->ev.kind == NLA_EVAL_DEVICE ? c->ev.obj : NLA_OBJ_EXTERNAL;
-    if (c->alg == 1) {
+    if (c->alg == 2) {
+        nla_cobyla_params P;
+        memset(&P, 0, sizeof P);
+        P.minf_max = prm->minf_max; P.ftol_rel = prm->ftol_rel; P.ftol_abs = prm->ftol_abs; P.xtol_rel = prm->xtol_rel; P.maxeval = prm->maxeval;
+        P.exact = (c->exact & 1); P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.abort = c->h_abort; P.done = c->d_done;
+        if (ext) return -1;
+        return nla_k_cobyla_batch(obj, c->n, c->ld, count, c->d_lb, c->d_ub, c->d_sigma_init, c->d_X, c->d_work, c->d_iwork, &P, c->d_res, c->st);
+    } else if (c->alg == 1) {
         nla_mma_params P = c->mma;
         P.minf_max = prm->minf_max; P.ftol_rel = prm->ftol_rel; P.ftol_abs = prm->ftol_abs; P.xtol_rel = prm->xtol_rel; P.maxeval = prm->maxeval;
         P.exact = (c->exact & 1); P.sign = c->ev.sign; P.xtol_abs = c->d_xtol_abs; P.x_weights = c->d_x_weights; P.abort = c->h_abort;
@@ -204,6 +251,51 @@ static int launch(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, cons
         P.ftrace = c->d_ftrace; P.ftrace_cap = c->ftrace_cap; P.done = ext ? NULL : c->d_done;
         return nla_k_lbfgs_batch(obj, c->n, c->ld, c->mf, count, c->d_lb, c->d_ub, c->d_X, c->d_work, c->d_iwork, c->d_hist, &P, c->d_res, ext, c->st);
     }
+}
+
+/* LN_COBYLA, a batch of fewer searches than the device needs to beat a host core (cob_min_batch): the rows come to the host, each search
+ * runs through the library's own nlopt_optimize(LN_COBYLA) (cobyla_host.c: the reference's run evaluation by evaluation) on the
+ * objective's host twin, the results go back to where the kernel would have left them.  In exact-order mode the twin's values ARE the
+ * kernel's (same summation order, IEEE arithmetic), so where a batch runs changes nothing; in the default mode they differ by the
+ * rounding of the tree sum. */
+typedef struct { int obj; double sign; const nla_stopping *stop; nlopt_opt loc; int timed; } cob_host_obj;
+static double cob_host_f(unsigned n, const double *x, double *g, void *p)
+{
+    cob_host_obj *o = (cob_host_obj *) p;
+    (void) g;
+    if (o->stop) {
+        if (nla_stop_forced(o->stop)) nlopt_force_stop(o->loc);
+        else if (nla_stop_time(o->stop)) { o->timed = 1; nlopt_force_stop(o->loc); }
+    }
+    return o->sign * nla_obj_eval_seq(o->obj, n, x, NULL);
+}
+static int cobyla_small_batch_on_host(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, nla_lbfgs_result *h_res, const nla_stopping *stop)
+{
+    const size_t rows = sizeof(double) * (size_t) c->ld * (size_t) count;
+    int rc, i;
+    if ((rc = nla_memcpy_d2h(c->h_rows, c->d_X, rows, c->st)) || (rc = nla_stream_sync(c->st))) return rc;
+    for (i = 0; i < count; ++i) {
+        cob_host_obj o = { c->ev.obj & 0xff, (c->ev.sign == 0. ? 1. : c->ev.sign) * ((c->ev.obj & 0x100) ? -1. : 1.), stop, NULL, 0 };
+        nlopt_opt loc = nlopt_create(NLOPT_LN_COBYLA, (unsigned) c->n);
+        double minf = HUGE_VAL;
+        if (!loc) return -1;
+        o.loc = loc;
+        nlopt_set_min_objective(loc, cob_host_f, &o);
+        nlopt_set_lower_bounds(loc, c->h_lb); nlopt_set_upper_bounds(loc, c->h_ub);
+        nlopt_set_stopval(loc, prm->minf_max); nlopt_set_ftol_rel(loc, prm->ftol_rel); nlopt_set_ftol_abs(loc, prm->ftol_abs); nlopt_set_xtol_rel(loc, prm->xtol_rel);
+        if (c->h_xtol_abs) nlopt_set_xtol_abs(loc, c->h_xtol_abs);
+        nlopt_set_maxeval(loc, prm->maxeval);
+        if (c->h_dx) nlopt_set_initial_step(loc, c->h_dx);
+        h_res[i].ret = nlopt_optimize(loc, c->h_rows + (size_t) i * (size_t) c->ld, &minf);
+        if (o.timed && h_res[i].ret == NLOPT_FORCED_STOP) h_res[i].ret = NLOPT_MAXTIME_REACHED;
+        h_res[i].f = minf; h_res[i].nevals = h_res[i].iterm = nlopt_get_numevals(loc); h_res[i].cols = 0;
+        nlopt_destroy(loc);
+    }
+    if ((rc = nla_memcpy_h2d(c->d_X, c->h_rows, rows, c->st))) return rc;
+    if (c->after_launch) { int (*fn)(void *) = c->after_launch; c->after_launch = NULL; if ((rc = fn(c->after_arg))) return rc; }
+    if ((rc = nla_stream_sync(c->st))) return rc;
+    if (c->stats) c->stats->cobyla_host_searches += (uint64_t) count;
+    return 0;
 }
 
 /* wait for the stream; meanwhile forward the caller's force_stop flag and maxtime to the kernel's abort flag */
@@ -227,6 +319,7 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
 {
     int rc, i;
     if (count > c->cap) return -1;
+    if (c->alg == 2 && count < c->cob_min_batch) return cobyla_small_batch_on_host(c, count, prm, h_res, stop);
     *c->h_abort = 0;
     nla_event_record(c->ev0, c->st);
     if (c->ev.kind == NLA_EVAL_DEVICE) {
@@ -283,7 +376,8 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
         ++c->stats->lbfgs_launches;
         c->stats->t_lbfgs_ms += (double) nla_event_elapsed_ms(c->ev0, c->ev1);
         for (i = 0; i < count; ++i)
-            c->stats->lbfgs_bytes += c->alg == 1 ? (uint64_t) c->n * 64ULL * (uint64_t) h_res[i].nevals    /* mma_kernels.hip header */
+            c->stats->lbfgs_bytes += c->alg == 2 ? (uint64_t) c->n * 16ULL * (uint64_t) h_res[i].nevals    /* (the point written and read once per evaluation) */
+                                   : c->alg == 1 ? (uint64_t) c->n * 64ULL * (uint64_t) h_res[i].nevals    /* mma_kernels.hip header */
                                                  : (uint64_t) c->n * (32ULL * (uint64_t) h_res[i].cols + 16ULL * (uint64_t) h_res[i].nevals);
     }
     return 0;

@@ -158,7 +158,7 @@ static int grow_pts(mlsl_dev *d, size_t need)
          * the first iterations each time the set doubled (profiles/r05_mlsl_timeline.txt) */
         const size_t want = 16 * (size_t) d->N + 1, budget = ((size_t) 2 << 30) / (sizeof(double) * (size_t) d->ld);
         const size_t first = want < budget ? want : budget;
-        while (ncap < first) ncap *= 2;
+        if (first > ncap) ncap = first;          /* exactly the budgeted rows: rounding up to a power of two could double the 2 GiB (advisor, round 5) */
     }
     while (ncap < need) ncap *= 2;
     d->F = (double *) realloc(d->F, sizeof(double) * ncap);
@@ -206,7 +206,7 @@ static int grow_lms(mlsl_dev *d, size_t need)
     if (!d->lcap) {           /* (as the point set: room for 8 iterations' worth of minima from the start, within 1 GiB) */
         const size_t want = 8 * (size_t) d->N, budget = ((size_t) 1 << 30) / (sizeof(double) * (size_t) d->ld);
         const size_t first = want < budget ? want : budget;
-        while (ncap < first) ncap *= 2;
+        if (first > ncap) ncap = first;
     }
     while (ncap < need) ncap *= 2;
     d->LF = (double *) realloc(d->LF, sizeof(double) * ncap);
@@ -421,7 +421,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     double R_prefactor, *Fnew = NULL, best_f = HUGE_VAL;
     const double dlm = 1.0, dbound = 1e-6;
     const double *lbh = lb, *ubh = ub;
-    int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0, use_cobyla = 0, host, batch;
+    int i, mf, best_is_lm = 0, loc_maxeval, use_mma = 0, use_cobyla = 0, cob_dev = 0, host, batch;
     mlsl_count_wrap cw, sw;
     nlopt_func lo_f = NULL; void *lo_fdata = NULL;
     nla_mma_params mma;
@@ -440,9 +440,12 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         return NLOPT_INVALID_ARGS;
     }
     use_mma = local_opt->algorithm == NLOPT_LD_MMA;
-    /* LN_COBYLA (GN_MLSL's default, optimize.c:763-768) is a HOST algorithm (cobyla_host.c): the searches run one at a time on the
-     * caller's thread through the library's own nlopt_optimize, exactly as mlsl.c:404-407 runs them; samples, distances and the
-     * bookkeeping stay on the device.  The whole run then takes the host-callback path, also for a device objective (its host twin). */
+    /* LN_COBYLA (GN_MLSL's default, optimize.c:763-768).  With a compiled-in device objective (round 6) the searches of a batch run
+     * CONCURRENTLY on the device, one wavefront per start with the search's whole state in LDS (hip/cobyla_kernels.hip), like
+     * LD_LBFGS / LD_MMA: `cob_dev`.  Otherwise — a host callback, a user kernel, a dimension whose simplex, inverse, models and LP
+     * basis no longer fit a compute unit's LDS (n > 51), or "amd_cobyla_host" = 1 — it is a HOST algorithm (cobyla_host.c): the
+     * searches run one at a time on the caller's thread through the library's own nlopt_optimize, exactly as mlsl.c:404-407 runs them;
+     * samples, distances and the bookkeeping stay on the device, and the run takes the host-callback path throughout. */
     use_cobyla = local_opt->algorithm == NLOPT_LN_COBYLA;
     if (use_mma && (i = nla_mma_read_params(local_opt, &mma))) {
         nla_stop_msg(stop, "%s", local_opt->errmsg ? local_opt->errmsg : "invalid LD_MMA parameter");
@@ -455,6 +458,9 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     }
     nla_evaluator_resolve(&D.ev, opt, f, f_data);
     D.obj = D.ev.kind == NLA_EVAL_DEVICE ? D.ev.obj : -1;
+    cob_dev = use_cobyla && D.ev.kind == NLA_EVAL_DEVICE && nla_cobyla_fits(n) && !(opt && nlopt_get_param(opt, "amd_cobyla_host", 0) != 0) &&
+              !nlopt_get_param(local_opt, "amd_cobyla_host", 0);
+    if (cob_dev) use_cobyla = 0;              /* from here on `use_cobyla` means: the host algorithm */
     host = D.ev.kind == NLA_EVAL_HOST || use_cobyla;
     sw.f = f; sw.f_data = f_data; sw.sign = -1.; sw.nevals_p = NULL;
     if (use_cobyla && D.ev.kind != NLA_EVAL_HOST && D.ev.sign < 0) { f = mlsl_signed_f; f_data = &sw; }   /* a maximisation the dispatcher left unflipped (dev_sign): flip here */
@@ -490,7 +496,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     D.prefetch = !host;
     /* (not with the sums in the reference's order, amd_exact_dot = 1: that launch is one chain of dependent fp64 additions per search,
      * every issue slot the distance pass takes on its SIMD delays the chain — measured: 103 -> 117 ms per launch, round 5) */
-    D.ahead = !host && D.world == 1 && D.ev.kind == NLA_EVAL_DEVICE && !use_cobyla && !nla_exact_mode_for(opt, local_opt, &D.ev);
+    D.ahead = !host && D.world == 1 && D.ev.kind == NLA_EVAL_DEVICE && !use_cobyla && !cob_dev && !nla_exact_mode_for(opt, local_opt, &D.ev);
     D.prefetched_at = ~0ULL;
     D.rs = (D.st && D.prefetch) ? nla_stream_create_background() : D.st;
     D.ev_samples = nla_event_create();
@@ -547,7 +553,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         }                                                                      /* else: NULL generator -> nlopt_urand, as the reference */
         free(V);
     }
-    if (use_mma && local_opt->dx) {                                            /* the initial step = MMA's sigma_init, optimize.c:829 */
+    if ((use_mma || cob_dev) && local_opt->dx) {                                            /* the initial step = MMA's sigma_init, optimize.c:829 */
         D.d_dx = (double *) nla_dev_malloc(sizeof(double) * (size_t) D.ld);
         if (!D.d_dx || nla_memcpy_h2d(D.d_dx, local_opt->dx, sizeof(double) * (size_t) n, D.st) || nla_stream_sync(D.st)) {
             nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
@@ -570,7 +576,8 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
         cob_x = (double *) nla_host_malloc(sizeof(double) * (size_t) n);
         if (!cob_x) { nla_stop_msg(stop, "nlopt_amd: out of pinned memory"); ret = NLOPT_OUT_OF_MEMORY; goto done; }
     } else {
-    D.lb = use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
+    D.lb = cob_dev ? nla_local_ctx_create_cobyla(&D.ev, n, batch, D.d_dx, D.d_lb, D.d_ub, D.st)
+         : use_mma ? nla_local_ctx_create_mma(&D.ev, n, batch, &mma, D.d_dx, D.d_lb, D.d_ub, D.st)
                    : nla_local_ctx_create(&D.ev, n, batch, mf, D.d_lb, D.d_ub, D.st);
     if (D.lb && nla_local_ctx_set_options(D.lb, nla_exact_mode_for(opt, local_opt, &D.ev), local_opt->xtol_abs, local_opt->x_weights)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
     /* (LD_LBFGS only: LD_MMA's launches are half as long as the distance pass beside them — behind a gate it ends after them and holds the
@@ -578,6 +585,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     if (D.lb && D.ahead && !use_mma && NLA_MLSL_GATE_PCT > 0 && nla_local_ctx_count_finished(D.lb)) { nla_local_ctx_destroy(D.lb); D.lb = NULL; }
     if (!D.lb) { nla_stop_msg(stop, "nlopt_amd: out of device memory (local-search batch)"); nla_comm_agree_ready(D.comm, 0); mfree(&D); nla_host_free(Fnew); free(res); free(res_mine); free(cand); return NLOPT_OUT_OF_MEMORY; }
     nla_local_ctx_set_stats(D.lb, st);
+    if (cob_dev) nla_local_ctx_set_cobyla_min_batch(D.lb, (int) nlopt_get_param(opt ? opt : local_opt, "amd_cobyla_min_batch", nlopt_get_param(local_opt, "amd_cobyla_min_batch", 0)));
     }
     if (D.world > 1) {
         const int all = nla_comm_agree_same(D.comm, 1, nla_problem_fingerprint(lds ? NLOPT_G_MLSL_LDS : NLOPT_G_MLSL, n, D.N, D.obj + 100 * (int) local_opt->algorithm, lb, ub, x, stop) + nla_params_fingerprint(opt) + nla_params_fingerprint(local_opt));

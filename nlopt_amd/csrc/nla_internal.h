@@ -252,6 +252,8 @@ typedef struct nla_local_ctx nla_local_ctx;
 nla_local_ctx *nla_local_ctx_create(const nla_evaluator *ev, int n, int cap, int mf, const double *d_lb, const double *d_ub, void *stream);
 nla_local_ctx *nla_local_ctx_create_mma(const nla_evaluator *ev, int n, int cap, const nla_mma_params *alg_params, const double *d_sigma_init,
                                         const double *d_lb, const double *d_ub, void *stream);
+nla_local_ctx *nla_local_ctx_create_cobyla(const nla_evaluator *ev, int n, int cap, const double *d_dx, const double *d_lb, const double *d_ub, void *stream);
+void nla_local_ctx_set_cobyla_min_batch(nla_local_ctx *c, int min_batch);
 int nla_local_ctx_alg(const nla_local_ctx *c);
 void nla_local_ctx_destroy(nla_local_ctx *c);
 double *nla_local_ctx_X(nla_local_ctx *c);

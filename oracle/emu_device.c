@@ -605,6 +605,45 @@ int nla_k_mma_batch(int obj, int n, int ld, int count, const double *lb, const d
 }
 
 /* ---- code objects (hip/devrt.hip): none on the emulated device ------------------------------------------------------------- */
+/* LN_COBYLA batched (hip/cobyla_kernels.hip): every start through the product's own host COBYLA as nlopt_optimize reaches it (default
+ * initial step, memoized best point), the objective in the host callback's summation order */
+typedef struct { int obj; double sign; } emu_cob_obj;
+static double emu_cob_f(unsigned n, const double *x, double *g, void *p) { emu_cob_obj *o = (emu_cob_obj *) p; (void) g; return o->sign * nla_obj_eval_seq(o->obj, n, x, NULL); }
+size_t nla_cobyla_work_doubles(int n, int ld, int count) { (void) n; (void) ld; (void) count; return 8; }
+size_t nla_cobyla_work_ints(int n, int count) { (void) n; (void) count; return 8; }
+/* (the device kernel's LDS budget, hip/cobyla_kernels.hip cw_lds_doubles with m = 2n: the host logic must take the same decisions here) */
+size_t nla_cobyla_lds_bytes(int n)
+{
+    const size_t m = 2 * (size_t) n, ldn = (size_t) (n | 1), ldd = (m + 2) | 1, v = m + 2 > (size_t) n + 1 ? m + 2 : (size_t) n + 1;
+    return 8 * (ldn * (size_t) (n + 1) + ldn * (size_t) n + ldd * (size_t) (n + 1) + ldn * (m + 1) + ldn * (size_t) n + 14 * (size_t) n + 6 * v + (m + 2 + (size_t) n + 1) / 2 + 1) + 2048;
+}
+int nla_cobyla_fits(int n) { return n >= 1 && nla_cobyla_lds_bytes(n) <= 160 * 1024; }
+int nla_k_cobyla_batch(int obj, int n, int ld, int count, const double *lb, const double *ub, const double *dx, double *X,
+                       double *work, int *iwork, const nla_cobyla_params *P, nla_lbfgs_result *out, void *st)
+{
+    EMU_LAUNCH();
+    (void) work; (void) iwork; (void) st;
+    if (!nla_cobyla_fits(n)) return EMU_ERR;                 /* (as the kernel: the state of a search must fit the LDS) */
+    nla_emu_last_exact = P->exact;
+    for (int i = 0; i < count; ++i) {
+        emu_cob_obj o = { obj & 0xff, (P->sign == 0. ? 1. : P->sign) * ((obj & 0x100) ? -1. : 1.) };
+        nlopt_opt loc = nlopt_create(NLOPT_LN_COBYLA, (unsigned) n);
+        double minf = HUGE_VAL;
+        if (!loc) return EMU_ERR;
+        nlopt_set_min_objective(loc, emu_cob_f, &o);
+        nlopt_set_lower_bounds(loc, lb); nlopt_set_upper_bounds(loc, ub);
+        nlopt_set_stopval(loc, P->minf_max); nlopt_set_ftol_rel(loc, P->ftol_rel); nlopt_set_ftol_abs(loc, P->ftol_abs); nlopt_set_xtol_rel(loc, P->xtol_rel);
+        if (P->xtol_abs) nlopt_set_xtol_abs(loc, P->xtol_abs);
+        nlopt_set_maxeval(loc, P->maxeval);
+        if (dx) nlopt_set_initial_step(loc, dx);
+        if (P->abort && *P->abort == -999) { out[i].ret = NLOPT_FORCED_STOP; out[i].f = minf; out[i].nevals = out[i].iterm = 0; out[i].cols = 0; nlopt_destroy(loc); continue; }
+        out[i].ret = nlopt_optimize(loc, X + (size_t) i * (size_t) ld, &minf);
+        out[i].f = minf; out[i].nevals = out[i].iterm = nlopt_get_numevals(loc); out[i].cols = 0;
+        nlopt_destroy(loc);
+    }
+    return 0;
+}
+
 void *nla_module_load_file(const char *path) { (void) path; return NULL; }
 void *nla_module_load_data(const void *image) { (void) image; return NULL; }
 void nla_module_unload(void *module) { (void) module; }

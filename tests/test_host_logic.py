@@ -219,6 +219,22 @@ def test_chain_resolver_wavefront_takes_the_sequential_decisions():
         os.remove(exe)
 
 
+def test_cobyla_wavefront_kernel_on_lockstep_cpu_threads_is_the_host_algorithm():
+    """hip/cobyla_kernels.hip (one wavefront per LN_COBYLA search: independent sums one per lane, deciding sums by every lane, rotation chains
+    one row of Z per lane) compiled by g++ over tools/simt_emu — 64 threads, barriers where the kernel has them — against the host
+    algorithm (cobyla_host.c, itself the reference's run evaluation by evaluation: tests/test_cobyla_differential.py): result code,
+    evaluation count, f and minimiser identical for starts inside the box, on its bounds, with infinite bounds and with a caller's step
+    (tools/cobyla_emu_check.py tiny).  The device run against the real reference: tests/test_gpu_cobyla.py."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++") or not os.path.exists(os.path.join(root, "oracle", "libnlopt_amd_emu.so")):
+        pytest.skip("no g++ / no emulated library here")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cobyla_emu_check.py"), "tiny"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "cobyla emu check: ok" in r.stdout and "DIFFERENT" not in r.stdout, r.stdout + r.stderr
+
+
 def test_ordered_set_and_list_of_worst_rows_against_a_plain_array():
     """crs_driver.c's ordered set (4-ary max-heap, keys in the nodes, batch repair) and the sorted list of worst rows the walk follows
     between two looks at the heap (redrawn beside the device) — the file is #included by tools/ordset_check.c, so these are the product's

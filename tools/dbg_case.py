@@ -9,8 +9,7 @@ obj, n, pop, seed, me = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys
 loops = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 p = O.run_port_crs(obj, n, pop, seed, trace_cap=me + 5000, maxeval=me)
 tp = p["trace"]
-SETS = [("default", {}), ("forward+resolver", {"amd_forward": 1, "amd_chain_resolver": 1}), ("forward+lock", {"amd_forward": 1, "amd_chain_resolver": 0}),
-        ("forward+resolver K=8", {"amd_forward": 1, "amd_chain_resolver": 1, "amd_max_spec": 8}), ("conservative", {"amd_forward": 0})]
+SETS = [("default", {}), ("windows", {"amd_forward": 1}), ("windows K=8", {"amd_forward": 1, "amd_max_spec": 8}), ("conservative", {"amd_forward": 0})]
 for name, params in SETS:
     for it in range(loops):
         a = T.run_amd(obj, n, pop, seed, trace_cap=me + 5000, params=params, maxeval=me)

@@ -84,6 +84,8 @@ static inline bool simt_wave_all(bool p)
     which ^= 1;
     return all;
 }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
 static inline unsigned long long wall_clock64() { return 0; }
 static inline unsigned __smid() { return 0; }
 
