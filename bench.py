@@ -870,7 +870,7 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
         t_dom = d["t_lbfgs_ms"] / 1e3
         bytes_dom = float(d["lbfgs_bytes"])
         # the kernel the searches run on: the resident one up to n = 4096 with a device objective (hip/lbfgs_resident.hip), else the streaming one
-        kern, launches = ("mma_batch_kernel" if a.local == "mma" else ("lbfgs_resident_kernel" if n <= 4096 else "lbfgs_batch_kernel")), int(d["lbfgs_launches"])
+        kern, launches = ("mma_batch_kernel" if a.local == "mma" else ("lbfgs_batch_kernel" if (n > 8192 or any(q.startswith("amd_lbfgs_streaming=") and float(q.split("=", 1)[1]) != 0 for q in a.param)) else ("lbfgs_resident_kernel" if n <= 4096 else "lbfgs_resident32_kernel"))), int(d["lbfgs_launches"])
         name = "GD_MLSL_LDS + default LD_MMA" if a.local == "mma" else "G_MLSL_LDS + LD_LBFGS"
         metric = "candidate-evals/sec, %s n=%d, %d samples per iteration" % (name, n, pop)
         mode = ("amd_exact_dot=1: every sum of the local search in the reference's sequential order, iterates bit-identical to the reference's"

@@ -16,13 +16,13 @@ OBJ = os.path.join(HERE, "lib", "obj" + ("_" + _VNAME if _VNAME else ""))
 LIB = os.path.join(HERE, "lib", "libnlopt_amd" + ("_" + _VNAME if _VNAME else "") + ".so")
 SHIM = os.path.join(HERE, "lib", "libnlopt_algs_amd" + ("_" + _VNAME if _VNAME else "") + ".so")
 
-HIP_SRC = ["hip/devrt.hip", "hip/mt_kernels.hip", "hip/crs_kernels.hip", "hip/crs_chain.hip", "hip/crs_shard.hip", "hip/isres_kernels.hip", "hip/isres_evolve2.hip", "hip/lbfgs_kernels.hip", "hip/lbfgs_resident.hip", "hip/mma_kernels.hip", "hip/cobyla_kernels.hip", "hip/mlsl_kernels.hip", "hip/esch_kernels.hip"]
+HIP_SRC = ["hip/devrt.hip", "hip/mt_kernels.hip", "hip/crs_kernels.hip", "hip/crs_chain.hip", "hip/crs_shard.hip", "hip/isres_kernels.hip", "hip/isres_evolve2.hip", "hip/lbfgs_kernels.hip", "hip/lbfgs_resident.hip", "hip/lbfgs_resident32.hip", "hip/mma_kernels.hip", "hip/cobyla_kernels.hip", "hip/mlsl_kernels.hip", "hip/esch_kernels.hip"]
 C_SRC = ["mt_host.c", "mtstream.c", "stopping.c", "objfuncs.c", "api_general.c", "api_options.c", "api_optimize.c",
          "comm.c", "sobol.c", "userobj.c", "crs_driver.c", "crs_engine.c", "isres_driver.c", "lbfgs_driver.c", "mma_driver.c", "mlsl_driver.c", "esch_driver.c", "cobyla_host.c", "mma_host.c", "auglag_host.c"]
 # per-source flags.  lbfgs_resident.hip: without machine-level loop-invariant code motion — the pass hoists ~40 VGPRs of literal
 # constants (the sin / cos polynomials of the objectives, small integers) out of the search loop and keeps them alive across the
 # Strang recurrences, which then spill; with it off the kernel needs 226 VGPRs and no scratch (tools/kernel_resources.py)
-EXTRA_FLAGS = {"hip/lbfgs_resident.hip": ["-mllvm", "-disable-machine-licm"]}
+EXTRA_FLAGS = {"hip/lbfgs_resident.hip": ["-mllvm", "-disable-machine-licm"], "hip/lbfgs_resident32.hip": ["-mllvm", "-disable-machine-licm"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off everywhere: population rows and trial points must be bit-identical to the
 # reference, which is built with it (CMakeLists.txt:280-284).

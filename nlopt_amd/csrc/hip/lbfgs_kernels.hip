@@ -446,6 +446,9 @@ extern "C" size_t nla_lbfgs_save_bytes(void) { return sizeof(lb_saved); }
 extern "C" int nla_lbfgs_resident_supported(int obj, int n, const nla_lbfgs_params *params);
 extern "C" int nla_k_lbfgs_batch_resident(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X, double *work,
                                           double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out, void *stream);
+extern "C" int nla_lbfgs_resident32_supported(int obj, int n, const nla_lbfgs_params *params);                      /* 4096 < n <= 8192 (lbfgs_resident32.hip) */
+extern "C" int nla_k_lbfgs_batch_resident32(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X, double *work,
+                                            double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out, void *stream);
 
 extern "C" int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
                                  double *work, int *iwork, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out,
@@ -459,6 +462,7 @@ extern "C" int nla_k_lbfgs_batch(int obj, int n, int ld, int mf, int count, cons
     /* a device objective, n <= 4096, tree sums: the resident kernel (lbfgs_resident.hip) — the same search bit for bit;
      * exact == 2 / 3 ("amd_lbfgs_streaming"): tree sums / the reference's order on THIS kernel, for the tests that compare the two */
     if (nla_lbfgs_resident_supported(obj, n, &P)) return nla_k_lbfgs_batch_resident(obj, n, ld, mf, count, lb, ub, X, work, hist, &P, out, stream);
+    if (nla_lbfgs_resident32_supported(obj, n, &P)) return nla_k_lbfgs_batch_resident32(obj, n, ld, mf, count, lb, ub, X, work, hist, &P, out, stream);
     if (P.exact == 2) P.exact = 0;
     if (P.exact == 3) P.exact = 1;                 /* the reference's summation order on THIS kernel */
     if (obj == NLA_OBJ_EXTERNAL) {

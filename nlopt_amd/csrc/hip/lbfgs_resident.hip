@@ -29,8 +29,25 @@
 #include "../lbfgs_scalar.h"
 #include "../../../include/nlopt_amd.h"
 
+/* The file is compiled twice: as itself with 16 coordinates per thread (n <= 4096, two workgroups per compute unit — config 4's kernel), and
+ * through lbfgs_resident32.hip with 32 (LR_WIDE: 4096 < n <= 8192, x and the gradient 2 x 64 KB of LDS, ONE workgroup per compute unit, the
+ * direction 64 VGPRs) — the same source, the same sums, so the same search bit for bit as the streaming kernel there too. */
+#ifdef LR_WIDE
+#define LR_E 32
+#define LR_PER_EU 1
+#define LR_KERNEL lbfgs_resident32_kernel
+#define LR_SUPPORTED nla_lbfgs_resident32_supported
+#define LR_BATCH nla_k_lbfgs_batch_resident32
+#else
 #define LR_E 16                        /* coordinates per thread */
-#define LR_NMAX (LB_T * LR_E)          /* 4096 */
+#define LR_PER_EU 2
+#define LR_KERNEL lbfgs_resident_kernel
+#define LR_SUPPORTED nla_lbfgs_resident_supported
+#define LR_BATCH nla_k_lbfgs_batch_resident
+#endif
+#define LR_NMAX (LB_T * LR_E)          /* 4096 (8192) */
+
+namespace {                            /* (the two builds of this file define the same names with different LR_E: internal linkage) */
 
 /* the one copy of a search's scalar state (LDS) */
 struct lr_ctl {
@@ -41,7 +58,7 @@ struct lr_ctl {
 struct lr_red { double v[2][LB_W][2]; int iv[2][LB_W]; };
 enum { LR_EXIT = 1, LR_RELEASE, LR_CONTINUE, LR_STRANG, LR_STEEPEST, LR_AGAIN, LR_LS_EVAL, LR_RESTORE, LR_PYTRCD, LR_NO_STEP, LR_XTOL_ABS };
 
-#ifdef NLA_LB_PROF     /* tools/lbfgs_prof.py: per-phase device time of every search (10 ns ticks); the shipped library has none of this */
+#if defined(NLA_LB_PROF) && !defined(LR_WIDE)     /* tools/lbfgs_prof.py: per-phase device time of every search (10 ns ticks); the shipped library has none of this */
 #define LB_PROF_PHASES 12
 #define LB_PROF_CAP 4096
 __device__ unsigned long long nla_lb_prof[LB_PROF_CAP][LB_PROF_PHASES + 4];
@@ -51,11 +68,13 @@ __device__ unsigned long long nla_lb_prof[LB_PROF_CAP][LB_PROF_PHASES + 4];
 #define PROF_STORE do { if (tid == 0 && inst < LB_PROF_CAP) { for (int pf_i = 0; pf_i < LB_PROF_PHASES; ++pf_i) nla_lb_prof[inst][pf_i] = pf_acc[pf_i]; \
         nla_lb_prof[inst][LB_PROF_PHASES] = pf_iters; nla_lb_prof[inst][LB_PROF_PHASES + 1] = C.nevals; nla_lb_prof[inst][LB_PROF_PHASES + 2] = C.cols; \
         nla_lb_prof[inst][LB_PROF_PHASES + 3] = 0; } } while (0)
+}
 extern "C" int nla_lbfgs_prof_read(unsigned long long *out, int count)
 {
     if (count > LB_PROF_CAP) count = LB_PROF_CAP;
     return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(nla_lb_prof), sizeof(unsigned long long) * (LB_PROF_PHASES + 4) * (size_t) count);
 }
+namespace {
 #else
 #define PROF_DECL
 #define PROF(i)
@@ -315,6 +334,8 @@ __device__ __forceinline__ double lr_objgrad(int n, const double *x, double *g, 
     return f;
 }
 
+}
+#ifndef LR_WIDE
 /* development / test aid: sin, cos and sincos of the device library for n arguments (tests/test_gpu_lbfgs.py) */
 __global__ void lr_debug_sincos_kernel(int n, const double *a, double *out)
 {
@@ -331,6 +352,8 @@ extern "C" int nla_k_debug_sincos(int n, const double *a, double *out, void *str
     NLA_LAUNCH_CHECK();
     return 0;
 }
+#endif
+namespace {
 
 /* thread 0, when PS1L01 reports the line search finished (q.isys == 0): take its results over (plis.c:395-403) */
 __device__ __forceinline__ int lr_line_search_finished(lr_ctl &C)
@@ -373,7 +396,7 @@ __device__ __forceinline__ void lr_bstore(double v, lr_buf b, unsigned voff, uns
 #define LR_ST(v, buf, e) lr_bstore(v, buf, voff, (unsigned) (e) * (LB_T * 8u))
 
 template <int OBJ, bool EXACT>
-__global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbfgs_resident_kernel(
+__global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(LR_PER_EU, LR_PER_EU))) void LR_KERNEL(
     int n, int ld, int mf, int count, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ X,
     double *__restrict__ work, double *__restrict__ hist, nla_lbfgs_params P, nla_lbfgs_result *__restrict__ out)
 {
@@ -845,21 +868,23 @@ __global__ __launch_bounds__(LB_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #undef COLIDX
 }
 
-extern "C" int nla_lbfgs_resident_supported(int obj, int n, const nla_lbfgs_params *params)
+}   /* namespace */
+
+extern "C" int LR_SUPPORTED(int obj, int n, const nla_lbfgs_params *params)
 {
     return obj >= 0 && n <= LR_NMAX && (params->exact == 0 || params->exact == 1);       /* exact 2 / 3: the streaming kernel asked for by name */
 }
 
-extern "C" int nla_k_lbfgs_batch_resident(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
-                                          double *work, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out, void *stream)
+extern "C" int LR_BATCH(int obj, int n, int ld, int mf, int count, const double *lb, const double *ub, double *X,
+                        double *work, double *hist, const nla_lbfgs_params *params, nla_lbfgs_result *out, void *stream)
 {
     if (count <= 0) return 0;
     hipStream_t st = (hipStream_t) stream;
     nla_lbfgs_params P = *params;
     if (P.sign == 0.) P.sign = 1.;
-    if (!nla_lbfgs_resident_supported(obj, n, &P)) return (int) hipErrorInvalidValue;
-#define CALL(O) do { if (P.exact) hipLaunchKernelGGL((lbfgs_resident_kernel<O, true>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out); \
-                     else hipLaunchKernelGGL((lbfgs_resident_kernel<O, false>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out); } while (0)
+    if (!LR_SUPPORTED(obj, n, &P)) return (int) hipErrorInvalidValue;
+#define CALL(O) do { if (P.exact) hipLaunchKernelGGL((LR_KERNEL<O, true>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out); \
+                     else hipLaunchKernelGGL((LR_KERNEL<O, false>), dim3(count), dim3(LB_T), 0, st, n, ld, mf, count, lb, ub, X, work, hist, P, out); } while (0)
     NLA_OBJ_DISPATCH(obj, CALL)
 #undef CALL
     NLA_LAUNCH_CHECK();

@@ -142,6 +142,9 @@ def _batch(streaming, obj, n, starts, lov, hiv, mf, ftol_rel=1e-8, maxeval=0, si
     ("levy", 33, 2, 400, {}), ("sphere", 5, 2, 400, {}), ("rastrigin", 513, 2, 4, {}), ("rastrigin", 4095, 2, 7, {}),
     ("ackley", 600, 2, 400, dict(maxeval=9)), ("griewank", 64, 3, 50, dict(sign=-1.0, maxeval=40)),
     ("rastrigin", 100, 2, 30, dict(weights=True)), ("ackley", 77, 2, 30, dict(xtol_abs=True)),
+    # round 6: 4096 < n <= 8192 on the 32-coordinates-per-thread build (hip/lbfgs_resident32.hip: x and g 2 x 64 KB of LDS, one workgroup per CU)
+    ("ackley", 8192, 3, 160, dict(maxeval=60)), ("rastrigin", 4097, 2, 6, dict(maxeval=80)), ("griewank", 6000, 2, 12, dict(maxeval=50)),
+    ("rosenbrock", 5000, 2, 9, dict(maxeval=70)), ("levy", 7777, 2, 5, dict(maxeval=40, sign=-1.0)), ("sphere", 8191, 2, 3, dict(weights=True)),
 ])
 def test_resident_kernel_is_the_streaming_kernel(obj, n, count, mf, kw, exact):
     """lbfgs_resident_kernel (x / g in LDS, direction in registers, the scalar state advanced by thread 0) must be

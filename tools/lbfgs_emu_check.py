@@ -3,7 +3,9 @@ compiled by g++ over tools/simt_emu (one std::thread per work-item) and run on t
 reproduce the streaming kernel's tree-sum mode BIT FOR BIT (f of every evaluation, minimiser, result, counts), and both must
 agree with the oracle's sequential-order search (oracle/port_lbfgs.c) to rounding.  The GPU twin of this check is
 tests/test_gpu_lbfgs.py::test_resident_kernel_is_the_streaming_kernel; this one exists so that kernel LOGIC can be debugged
-without a GPU.       usage: python tools/lbfgs_emu_check.py [quick]"""
+without a GPU.       usage: python tools/lbfgs_emu_check.py [quick | wide]
+`wide`: workgroups of 64 threads, so that dimensions 1024 < n <= 2048 take the 32-coordinates-per-thread build of the resident kernel
+(hip/lbfgs_resident32.hip: 4096 < n <= 8192 on the device) — the same comparison there."""
 import ctypes as C
 import os
 import subprocess
@@ -16,7 +18,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _oracle as O          # noqa: E402
 
 HIP = os.path.join(ROOT, "nlopt_amd", "csrc", "hip")
-OUT = os.path.join(ROOT, "tools", "_build", "liblbfgs_emu.so")
+WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"
+LB_T = "64" if WIDE else os.environ.get("EMU_LB_T", "128")
+OUT = os.path.join(ROOT, "tools", "_build", "liblbfgs_emu%s.so" % ("_wide" if WIDE else ""))
 
 
 class Params(C.Structure):
@@ -31,10 +35,10 @@ class Result(C.Structure):
 
 def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    srcs = [os.path.join(HIP, "lbfgs_kernels.hip"), os.path.join(HIP, "lbfgs_resident.hip")]
+    srcs = [os.path.join(HIP, "lbfgs_kernels.hip"), os.path.join(HIP, "lbfgs_resident.hip"), os.path.join(HIP, "lbfgs_resident32.hip")]
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(s) for s in srcs + [os.path.join(HIP, "local_common.h")]):
         return
-    subprocess.run(["g++", "-O1", "-std=c++17", "-DLB_T=%s" % os.environ.get("EMU_LB_T", "128"), "-ffp-contract=off", "-fPIC", "-shared", "-x", "c++", "-w", "-I", os.path.join(ROOT, "tools", "simt_emu"),
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DLB_T=%s" % LB_T, "-ffp-contract=off", "-fPIC", "-shared", "-x", "c++", "-w", "-I", os.path.join(ROOT, "tools", "simt_emu"),
                     "-o", OUT] + srcs + ["-lpthread"], check=True)
 
 
@@ -66,6 +70,8 @@ def main():
              ("sphere", 5, 2, None, 0), ("ackley", 600, 2, None, 25), ("rastrigin", 513, 2, 4, 0)]
     if quick:
         cases = cases[:3]
+    if WIDE:
+        cases = [("sphere", 1100, 1, 3, 0), ("rastrigin", 1500, 2, 4, 14), ("ackley", 2048, 1, 3, 10), ("griewank", 1025, 1, 2, 8)]
     bad = 0
     for obj, n, count, mf, maxeval in cases:
         _, lo, hi = O.golden_x0(obj, n)
