@@ -2,7 +2,7 @@
  *
  * Wavefront = 64 lanes (CDNA4).  One wavefront evaluates one candidate: lane l owns coordinates
  * l, l+64, l+128, ... (coalesced 512-byte row segments), accumulates its partial in coordinate
- * order and the 64 partials are combined with a xor-butterfly (DPP/ds_swizzle shuffles, no LDS).
+ * order and the 64 partials are combined with a xor-butterfly (nla_xor_lane below: DPP moves and lane swaps, no LDS).
  * The per-element terms are the *same source* as the host callbacks (../objfuncs.h); only the
  * association order of the final reduction differs from the sequential host loop, which moves f
  * by O(1e-16) relative — inside the 1e-10 tolerance of the parity contract.
@@ -22,22 +22,63 @@
 
 #define NLA_WAVE 64
 
+/* ---- the value lane (l ^ M) holds, M = 1, 2, 4, 8, 16, 32: one step of every xor-butterfly in this library.  __shfl_xor compiles to
+ * ds_bpermute_b32 — an LDS-crossbar round trip per 32-bit half and step, ~12 of them in a row with a dependent fp64 add between two
+ * (round 6: 1992 ds_bpermute in lbfgs_resident.hip's code object; the Strang loops do one such reduction per history column).  The same
+ * lanes meet here through the VALU:   1, 2  quad permutes;  4  two row shifts under complementary bank masks;  8  a row rotation;
+ * 16 / 32  gfx950's v_permlane16_swap / v_permlane32_swap (rows / halves of two copies trade places, each lane keeps the copy that
+ * received its partner).  Same partner, same operands, same sum: bit for bit what the shuffle gave (tests/test_gpu_kernels.py
+ * compares the two on every lane; every kernel's parity tests sit on top). ---- */
+#ifdef NLA_SIMT_EMU
+template <int M> __device__ __forceinline__ double nla_xor_lane(double v) { return __shfl_xor(v, M, NLA_WAVE); }
+template <int M> __device__ __forceinline__ int nla_xor_lane(int v) { return __shfl_xor(v, M, NLA_WAVE); }
+#else
+typedef unsigned nla_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned nla_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <int M> __device__ __forceinline__ int nla_xor_lane(int v)
+{
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "a lane distance of the butterfly");
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false);
+    else if constexpr (M == 4) {
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x104 /* row_shl:4: lane l <- l + 4 */, 0xF, 0x5 /* quads 0, 2 of a row */, false);
+        return __builtin_amdgcn_update_dpp(t, v, 0x114 /* row_shr:4: lane l <- l - 4 */, 0xF, 0xA /* quads 1, 3 */, false);
+    } else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+    else if constexpr (M == 16) {
+        const nla_u2 r = __builtin_amdgcn_permlane16_swap((unsigned) v, (unsigned) v, false, false);      /* x: rows 1, 3 now hold rows 0, 2;  y: rows 0, 2 hold rows 1, 3 */
+        return (int) ((nla_lane_id() & 16u) ? r.x : r.y);
+    } else {
+        const nla_u2 r = __builtin_amdgcn_permlane32_swap((unsigned) v, (unsigned) v, false, false);      /* x: the upper half holds the lower;  y: the lower holds the upper */
+        return (int) ((nla_lane_id() & 32u) ? r.x : r.y);
+    }
+}
+template <int M> __device__ __forceinline__ double nla_xor_lane(double v)
+{
+    return __hiloint2double(nla_xor_lane<M>(__double2hiint(v)), nla_xor_lane<M>(__double2loint(v)));
+}
+#endif
+/* a whole butterfly: STEP(M) for M = 32, 16, 8, 4, 2, 1 — the order every reduction of the library has always used */
+#define NLA_BUTTERFLY(STEP) do { STEP(32); STEP(16); STEP(8); STEP(4); STEP(2); STEP(1); } while (0)
+
 __device__ __forceinline__ double nla_wave_sum(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, NLA_WAVE);
+#define NLA_S_(M) v += nla_xor_lane<M>(v)
+    NLA_BUTTERFLY(NLA_S_);
+#undef NLA_S_
     return v;
 }
 __device__ __forceinline__ double nla_wave_prod(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v *= __shfl_xor(v, m, NLA_WAVE);
+#define NLA_S_(M) v *= nla_xor_lane<M>(v)
+    NLA_BUTTERFLY(NLA_S_);
+#undef NLA_S_
     return v;
 }
 __device__ __forceinline__ int nla_wave_min_i32(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, NLA_WAVE); v = o < v ? o : v; }
+#define NLA_S_(M) { const int o = nla_xor_lane<M>(v); v = o < v ? o : v; }
+    NLA_BUTTERFLY(NLA_S_);
+#undef NLA_S_
     return v;
 }
 
@@ -117,13 +158,9 @@ __device__ __forceinline__ double nla_obj_finish(int n, nla_obj_part t, Get get)
 template <int OBJ>
 __device__ __forceinline__ nla_obj_part nla_obj_wave_reduce(nla_obj_part t)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        nla_obj_part o;
-        o.a = __shfl_xor(t.a, m, NLA_WAVE);
-        o.b = __shfl_xor(t.b, m, NLA_WAVE);
-        t = nla_obj_combine<OBJ>(t, o);
-    }
+#define NLA_S_(M) { nla_obj_part o; o.a = nla_xor_lane<M>(t.a); o.b = nla_xor_lane<M>(t.b); t = nla_obj_combine<OBJ>(t, o); }
+    NLA_BUTTERFLY(NLA_S_);
+#undef NLA_S_
     return t;
 }
 

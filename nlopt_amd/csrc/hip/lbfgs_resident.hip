@@ -89,12 +89,9 @@ namespace {
 template <bool MAX>
 __device__ __forceinline__ void lr_reduce2(double &a, double &b, lr_red &R, int &par)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double oa = __shfl_xor(a, m, 64), ob = __shfl_xor(b, m, 64);
-        if (MAX) { a = oa > a ? oa : a; b = ob > b ? ob : b; }
-        else { a += oa; b += ob; }
-    }
+#define LR_S_(M) { const double oa = nla_xor_lane<M>(a), ob = nla_xor_lane<M>(b); if (MAX) { a = oa > a ? oa : a; b = ob > b ? ob : b; } else { a += oa; b += ob; } }
+    NLA_BUTTERFLY(LR_S_);
+#undef LR_S_
     if ((threadIdx.x & 63) == 0) { R.v[par][threadIdx.x >> 6][0] = a; R.v[par][threadIdx.x >> 6][1] = b; }
     __syncthreads();
     a = R.v[par][0][0]; b = R.v[par][0][1];
@@ -109,8 +106,9 @@ __device__ __forceinline__ void lr_reduce2(double &a, double &b, lr_red &R, int 
 template <bool MAX>
 __device__ __forceinline__ double lr_reduce1(double a, lr_red &R, int &par)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const double oa = __shfl_xor(a, m, 64); if (MAX) a = oa > a ? oa : a; else a += oa; }
+#define LR_S_(M) { const double oa = nla_xor_lane<M>(a); if (MAX) a = oa > a ? oa : a; else a += oa; }
+    NLA_BUTTERFLY(LR_S_);
+#undef LR_S_
     if ((threadIdx.x & 63) == 0) R.v[par][threadIdx.x >> 6][0] = a;
     __syncthreads();
     a = R.v[par][0][0];
@@ -121,8 +119,9 @@ __device__ __forceinline__ double lr_reduce1(double a, lr_red &R, int &par)
 }
 __device__ __forceinline__ int lr_reduce_isum(int a, lr_red &R, int &par)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+#define LR_S_(M) a += nla_xor_lane<M>(a)
+    NLA_BUTTERFLY(LR_S_);
+#undef LR_S_
     if ((threadIdx.x & 63) == 0) R.iv[par][threadIdx.x >> 6] = a;
     __syncthreads();
     a = R.iv[par][0];
@@ -344,6 +343,25 @@ __global__ void lr_debug_sincos_kernel(int n, const double *a, double *out)
     double s2, c2;
     sincos(a[i], &s2, &c2);
     out[4 * (size_t) i] = sin(a[i]); out[4 * (size_t) i + 1] = cos(a[i]); out[4 * (size_t) i + 2] = s2; out[4 * (size_t) i + 3] = c2;
+}
+/* development / test aid: for every lane of 4 wavefronts and every distance of the butterfly, the partner's value by __shfl_xor and by
+ * nla_xor_lane (dev_common.h) — out[(2 s + which) * 256 + thread], s = 0 .. 5 for M = 32 .. 1; the int version behind them (12 * 256 on) */
+__global__ void lr_debug_xor_lane_kernel(const double *in, double *out)
+{
+    const int t = threadIdx.x;
+    const double v = in[t];
+    const int iv = (int) (long long) (in[t] * 1e6);
+    int s = 0;
+#define LR_D_(M) { out[(2 * s) * 256 + t] = __shfl_xor(v, M, 64); out[(2 * s + 1) * 256 + t] = nla_xor_lane<M>(v); \
+                   out[(12 + 2 * s) * 256 + t] = (double) __shfl_xor(iv, M, 64); out[(12 + 2 * s + 1) * 256 + t] = (double) nla_xor_lane<M>(iv); ++s; }
+    NLA_BUTTERFLY(LR_D_);
+#undef LR_D_
+}
+extern "C" int nla_k_debug_xor_lane(const double *in, double *out, void *stream)
+{
+    hipLaunchKernelGGL(lr_debug_xor_lane_kernel, dim3(1), dim3(256), 0, (hipStream_t) stream, in, out);
+    NLA_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int nla_k_debug_sincos(int n, const double *a, double *out, void *stream)
 {

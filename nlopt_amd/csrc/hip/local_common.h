@@ -17,8 +17,9 @@ struct lb_shared {
 
 __device__ __forceinline__ double lb_wave_sum(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+#define LB_S_(M) v += nla_xor_lane<M>(v)
+    NLA_BUTTERFLY(LB_S_);
+#undef LB_S_
     return v;
 }
 __device__ __forceinline__ double lb_block_sum(double v, lb_shared &S)
@@ -34,8 +35,9 @@ __device__ __forceinline__ double lb_block_sum(double v, lb_shared &S)
 }
 __device__ __forceinline__ double lb_block_max(double v, lb_shared &S)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+#define LB_S_(M) { const double o = nla_xor_lane<M>(v); v = o > v ? o : v; }
+    NLA_BUTTERFLY(LB_S_);
+#undef LB_S_
     __syncthreads();
     if ((threadIdx.x & 63) == 0) S.red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -47,8 +49,9 @@ __device__ __forceinline__ double lb_block_max(double v, lb_shared &S)
 __device__ __forceinline__ double lb_block_min(double v, lb_shared &S) { return -lb_block_max(-v, S); }
 __device__ __forceinline__ int lb_block_isum(int v, lb_shared &S)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+#define LB_S_(M) v += nla_xor_lane<M>(v)
+    NLA_BUTTERFLY(LB_S_);
+#undef LB_S_
     __syncthreads();
     if ((threadIdx.x & 63) == 0) S.ired[threadIdx.x >> 6] = v;
     __syncthreads();

@@ -172,6 +172,28 @@ def test_resident_kernel_is_the_streaming_kernel(obj, n, count, mf, kw, exact):
     assert (a["res"]["nevals"] > 1).all()
 
 
+def test_lane_exchange_through_the_valu_is_the_shuffle():
+    """dev_common.h nla_xor_lane<M> (DPP quad permutes / row shifts / row rotation, v_permlane16_swap, v_permlane32_swap) against
+    __shfl_xor (ds_bpermute) for every distance of the butterfly on every lane of four wavefronts, doubles (incl. NaN payloads,
+    infinities, -0.0, denormals) and ints: the same bits — so every reduction of the library sums what it always summed"""
+    L = nlopt_amd.lib()
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(256) * 10.0 ** rng.integers(-8, 8, 256)
+    v[[3, 70, 131, 255]] = [np.inf, -np.inf, -0.0, 5e-324]
+    raw = v.view(np.uint64).copy()
+    raw[17] = 0x7FF8000000ABCDEF; raw[200] = 0xFFF0000000000001          # NaNs with payloads
+    v = raw.view(np.float64)
+    dI, dO = nlopt_amd.DevBuf.from_array(v), nlopt_amd.DevBuf(8 * 24 * 256)
+    L.nla_k_debug_xor_lane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.nla_k_debug_xor_lane(dI.ptr, dO.ptr, None) == 0 and L.nla_stream_sync(None) == 0
+    o = dO.to_array(np.uint64, 24 * 256).reshape(12, 2, 256)
+    lanes = np.arange(256)
+    for s, m in enumerate((32, 16, 8, 4, 2, 1)):
+        assert np.array_equal(o[s, 0], raw[lanes ^ m]), m                     # the shuffle itself gives the partner's bits
+        assert np.array_equal(o[s, 1], o[s, 0]), m                             # ... and so does the VALU route
+        assert np.array_equal(o[6 + s, 1], o[6 + s, 0]), m                     # ints
+
+
 def test_device_sincos_is_sin_and_cos():
     """lbfgs_resident.hip computes Ackley's / Rastrigin's cos(2 pi x) (for f) and sin(2 pi x) (for the gradient) with ONE sincos call;
     the streaming kernel and the population kernels call cos and sin.  The device library must return the same bits either way:
