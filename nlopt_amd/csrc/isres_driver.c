@@ -273,6 +273,14 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
             DCK(d, nla_memset(d->d_ztotal, 0, sizeof(int64_t), d->rs));
             if (dev_more_deviates(d, d->spec_word0, &d->spec_attempts, (int64_t) (1.35 * (double) expect / 0.785) + 4096, &d->spec_zcount)) return -1;
             d->spec_valid = 1; ++d->spec_made;
+            /* ... and behind them the segment states the NEXT ranking's words start from (that ranking begins behind these deviates).  Round 3 put
+             * this beside the evolve rounds; but mt_jump_kernel's workgroups hold LDS on every compute unit while it runs, and the rounds' chain
+             * kernel — ONE workgroup with 147 of a compute unit's 160 KB of LDS — then finds none to run on: one 45 us launch per generation
+             * took 2.8-3.0 ms (every trace since round 4; understood in round 6, profiles/r06_isres_ahead.txt).  Here the main stream launches
+             * nothing until the pipeline has ended; what is left of the jump then delays the first round by that much at most. */
+            if (nla_dbg_int("NLA_ISRES_JUMP_IN_RANK", 1) && pop > 1 &&
+                nla_mtstream_reserve(d->mts, d->spec_word0 + 4ULL * (uint64_t) d->spec_attempts + 2ULL * (uint64_t) popm1 * (uint64_t) pop))
+                DFAIL(d, "MT stream reserve failed");
             *t_rng += nla_seconds() - t1;
         }
         if (gated && nsweeps == pop) DCK(d, nla_memcpy_d2h(&gate_err, d->d_gate + d->units + 2, sizeof gate_err, d->st));
