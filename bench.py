@@ -880,37 +880,22 @@ def bench_generational(a, nlopt_amd, L, rank, world, dist, sync_all, reduce):
                   "local_searches": int(d["accepted"]), "sample_evals": int(d["evals_trial"]), "local_evals": int(d["evals_mutation"])}
     if a.workload == "mlsl" and getattr(a, "exact", False) and a.local == "lbfgs":
         # amd_exact_dot = 1 is not a bandwidth problem: every dot product of a search is ONE chain of n dependent fp64 additions in the
-        # reference's order (mssubs.c:601-641), and a launch lasts as long as its longest search.  Chain length of a search with E
-        # evaluations (one L-BFGS iteration per evaluation after the first; iteration i runs the two Strang recurrences over
-        # min(i, mf) columns: two dots each, plus ~6 ordered sums per iteration for norms / the directional derivative / the objective):
-        #   adds(E) = n * sum_{i < E} (2 min(i, mf) + 6)
-        # floor: one v_add_f64 of the chain every 4 cycles (a wave64 fp64 instruction on a 32-lane SIMD at half rate: its issue time, no
-        # dependency stall at all) at 2.4 GHz = 1.67 ns; measured in round 5: 2.5 ns = 6 cycles per addition.
-        try:
-            t = o.trace()
-            kinds = t["kind"]
-            it, prev, per_it = 0, 3, {}
-            for kk, ev in zip(kinds.tolist(), t["accepted"].tolist()):
-                if kk == 3 and prev == 4:
-                    it += 1
-                if kk == 4:
-                    per_it.setdefault(it, []).append(int(ev))
-                if kk in (3, 4):
-                    prev = kk
-            mf = max(10, 1310720 // n)      # plis.c:441-445, luksan.h:149 (MEMAVAIL / n)
-            def adds(E):
-                return n * sum(2 * min(i, mf) + 6 for i in range(int(E)))
-            longest = [max(adds(E) for E in per_it[i]) for i in range(W, W + K) if per_it.get(i)]
-            if longest and t_dom > 0:
-                ns = 1e9 * t_dom / float(sum(longest))
-                roof_extra = {"bound": "latency", "kernel": kern, "launches": launches, "avg_launch_ms": 1e3 * t_dom / launches if launches else None,
-                              "achieved": ns, "unit": "ns per sequential fp64 add on the launch's longest search",
-                              "peak": 4 / 2.4, "peak_note": "one v_add_f64 of the chain per 4 cycles (issue time of a wave64 fp64 instruction on a SIMD-32) at 2.4 GHz",
-                              "frac": (4 / 2.4) / ns, "sequential_adds_longest_search_per_launch": float(sum(longest)) / len(longest),
-                              "model": "adds(E) = n * sum_{i<E} (2 min(i, mf) + 6), E = evaluations of the search; launch time = its longest search",
-                              "traffic": None}
-        except Exception as e:
-            roof_extra = None
+        # reference's order (mssubs.c:601-641), and a launch lasts as long as its longest search.  Steps of a search, counted by the library from
+        # what the kernel reports per search (include/nlopt_amd.h, lbfgs_longest_chain_steps): n (2 cols + 4 nevals) — two dot products per
+        # history column used, about four passes of ordered sums per evaluation.  (Rounds 2-5 modelled the steps from the evaluation counts
+        # alone — adds(E) = n sum_{i<E} (2 min(i, mf) + 6) — which counts 5 times the columns the searches really use: the "2.5 ns per
+        # addition" of those rounds was 9.6 ns of two v_readlane + v_add_f64 per step, tools/fmac_chain_probe.hip.)
+        # floor: one step of a chain of dependent v_fmac_f64 with a row_newbcast operand, one wavefront per SIMD, measured alone on this
+        # part: 3.2 ns (profiles/r06_fmac_chain_probe.txt; 4.9 ns with two such workgroups per compute unit, which 44 of 256 CUs carry).
+        steps = float(d.get("lbfgs_longest_chain_steps", 0))
+        if steps > 0 and t_dom > 0:
+            ns = 1e9 * t_dom / steps
+            roof_extra = {"bound": "latency", "kernel": kern, "launches": launches, "avg_launch_ms": 1e3 * t_dom / launches if launches else None,
+                          "achieved": ns, "unit": "ns per step of the longest search's chain of dependent fp64 additions",
+                          "peak": 3.2, "peak_note": "one dependent v_fmac_f64 (DPP row_newbcast operand) per step, one wavefront per SIMD, measured alone: tools/fmac_chain_probe.hip, profiles/r06_fmac_chain_probe.txt",
+                          "frac": 3.2 / ns, "chain_steps_longest_search_per_launch": steps / launches if launches else None,
+                          "model": "steps = n (2 cols + 4 nevals) of the launch's longest search (cols = history columns it streamed); launch time = its longest search",
+                          "traffic": None}
     achieved = (bytes_dom / 1e9) / t_dom if t_dom > 0 else None
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of the same command (BASELINE's shapes only)
     std = (a.workload == "isres" and (n, pop, a.obj) == (256, 50000, "rastrigin")) or (a.workload == "mlsl" and (n, pop, a.obj) == (4096, 1000, "ackley"))

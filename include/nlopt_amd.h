@@ -119,6 +119,10 @@ typedef struct {
      * (mlsl_driver.c, mlsl_enqueue_ahead): every iteration but the first of a one-rank run with a compiled-in objective */
     uint64_t mlsl_sampled_ahead;
     uint64_t cobyla_host_searches;   /* GN_MLSL + LN_COBYLA on a device objective: searches of batches too small for the device, run by the host algorithm */
+    /* batched L-BFGS: sum over its launches of the LONGEST search's ordered-sum steps, n (2 cols + 4 nevals) — two dot products per history
+     * column used, about four passes of ordered sums per evaluation (objective, g.s; per iteration the norms, p, the stop test's) —
+     * what a launch in the reference's summation order ("amd_exact_dot" = 1) lasts: one dependent addition per step (bench.py's model of that mode) */
+    uint64_t lbfgs_longest_chain_steps;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 /* ... for a client that may have been built against an older or newer header: writes at most `bytes` bytes of the structure (fields are

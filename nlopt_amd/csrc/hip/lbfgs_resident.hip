@@ -147,6 +147,31 @@ __device__ __forceinline__ double lr_lane(double v, int l)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 #endif
 }
+/* Sixteen terms of the chain in sixteen instructions (round 6; the readlane form above it is three per term — two v_readlane_b32 and the add —
+ * and measured 2.5 ns per term, which is what a search costs in this mode): v_fmac_f64 is the one double-precision VOP2 instruction, so it
+ * takes a DPP operand, and row_newbcast:j hands every lane lane j OF ITS ROW of 16 — with the same sixteen terms in each of the wavefront's
+ * four rows every lane accumulates a + t_0 + t_1 + ... in order.  fma(t, 1.0, a) rounds t + a once: the add, bit for bit.
+ * (s_nop: a VGPR written by a vector instruction may not be read through DPP by the next two.) */
+#ifndef NLA_SIMT_EMU
+#define LR_FD_(acc, v, J) "v_fmac_f64_dpp " acc ", " v ", %[one] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void lr_chain16(double &a, double va)
+{
+    const double one = 1.0;
+#define LR_C_(J) LR_FD_("%[a]", "%[va]", J)
+    asm volatile("s_nop 1\n\t" LR_C_(0) LR_C_(1) LR_C_(2) LR_C_(3) LR_C_(4) LR_C_(5) LR_C_(6) LR_C_(7) LR_C_(8) LR_C_(9) LR_C_(10) LR_C_(11) LR_C_(12) LR_C_(13) LR_C_(14) LR_C_(15)
+                 : [a] "+v"(a) : [va] "v"(va), [one] "v"(one));
+#undef LR_C_
+}
+/* two chains side by side (each one's next step waits for its last: the other fills the wait) */
+__device__ __forceinline__ void lr_chain16x2(double &a, double va, double &b, double vb)
+{
+    const double one = 1.0;
+#define LR_C_(J) LR_FD_("%[a]", "%[va]", J) LR_FD_("%[b]", "%[vb]", J)
+    asm volatile("s_nop 1\n\t" LR_C_(0) LR_C_(1) LR_C_(2) LR_C_(3) LR_C_(4) LR_C_(5) LR_C_(6) LR_C_(7) LR_C_(8) LR_C_(9) LR_C_(10) LR_C_(11) LR_C_(12) LR_C_(13) LR_C_(14) LR_C_(15)
+                 : [a] "+v"(a), [b] "+v"(b) : [va] "v"(va), [vb] "v"(vb), [one] "v"(one));
+#undef LR_C_
+}
+#endif
 template <bool PROD>
 __device__ __forceinline__ void lr_seq2(int nterms, double &ra, double &rb, const double (&ta)[LR_E], const double (&tb)[LR_E], lr_xbuf &XB, int &xpar)
 {
@@ -162,6 +187,14 @@ __device__ __forceinline__ void lr_seq2(int nterms, double &ra, double &rb, cons
 #ifdef NLA_SIMT_EMU
             for (int i = 0; i < mm; ++i) { a += XB.a[xpar][i]; if (PROD) b *= XB.b[xpar][i]; else b += XB.b[xpar][i]; }
 #else
+            if (!PROD && mm == LB_T) {
+                /* a whole block, two sums: sixteen LDS reads (the block's terms, sixteen at a time, the same in all four rows of the wavefront) in flight, then the chains */
+                double va[LB_T / 16], vb[LB_T / 16];
+#pragma unroll
+                for (int c = 0; c < LB_T / 16; ++c) { va[c] = XB.a[xpar][16 * c + (tid & 15)]; vb[c] = XB.b[xpar][16 * c + (tid & 15)]; }
+#pragma unroll
+                for (int c = 0; c < LB_T / 16; ++c) lr_chain16x2(a, va[c], b, vb[c]);
+            } else
             for (int c = 0; c < mm; c += 64) {
                 const double va = XB.a[xpar][c + (tid & 63)], vb = XB.b[xpar][c + (tid & 63)];
                 if (mm - c >= 64) {
@@ -191,6 +224,13 @@ __device__ __forceinline__ double lr_seq1(int nterms, const double (&ta)[LR_E], 
 #ifdef NLA_SIMT_EMU
             for (int i = 0; i < mm; ++i) a += XB.a[xpar][i];
 #else
+            if (mm == LB_T) {
+                double va[LB_T / 16];
+#pragma unroll
+                for (int c = 0; c < LB_T / 16; ++c) va[c] = XB.a[xpar][16 * c + (tid & 15)];
+#pragma unroll
+                for (int c = 0; c < LB_T / 16; ++c) lr_chain16(a, va[c]);
+            } else
             for (int c = 0; c < mm; c += 64) {
                 const double va = XB.a[xpar][c + (tid & 63)];
                 if (mm - c >= 64) {

@@ -379,6 +379,14 @@ int nla_local_ctx_run(nla_local_ctx *c, int count, const nla_lbfgs_params *prm, 
             c->stats->lbfgs_bytes += c->alg == 2 ? (uint64_t) c->n * 16ULL * (uint64_t) h_res[i].nevals    /* (the point written and read once per evaluation) */
                                    : c->alg == 1 ? (uint64_t) c->n * 64ULL * (uint64_t) h_res[i].nevals    /* mma_kernels.hip header */
                                                  : (uint64_t) c->n * (32ULL * (uint64_t) h_res[i].cols + 16ULL * (uint64_t) h_res[i].nevals);
+        if (c->alg == 0) {
+            uint64_t longest = 0;
+            for (i = 0; i < count; ++i) {
+                const uint64_t steps = (uint64_t) c->n * (2ULL * (uint64_t) h_res[i].cols + 4ULL * (uint64_t) h_res[i].nevals);
+                if (steps > longest) longest = steps;
+            }
+            c->stats->lbfgs_longest_chain_steps += longest;
+        }
     }
     return 0;
 }
