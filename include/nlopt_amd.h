@@ -123,6 +123,9 @@ typedef struct {
      * column used, about four passes of ordered sums per evaluation (objective, g.s; per iteration the norms, p, the stop test's) —
      * what a launch in the reference's summation order ("amd_exact_dot" = 1) lasts: one dependent addition per step (bench.py's model of that mode) */
     uint64_t lbfgs_longest_chain_steps;
+    /* MLSL: gates in front of the sampling phase enqueued ahead that gave up waiting (50 ms) for the searches they start behind — the two
+     * streams did not run beside each other; the run stops gating after the first.  0 in a healthy run */
+    uint64_t mlsl_gate_timeouts;
 } nlopt_amd_stats;
 nlopt_result nlopt_amd_get_stats(const nlopt_opt opt, nlopt_amd_stats *out);
 /* ... for a client that may have been built against an older or newer header: writes at most `bytes` bytes of the structure (fields are
@@ -643,7 +646,7 @@ int nla_stream_wait_event(void *stream, void *ev);
 /* one wavefront that holds the stream's following work back until *counter - from >= need (agent-scope loads; counter in
  * nla_dev_malloc_uncached memory) or timeout_ms have passed — how work enqueued BESIDE a batch of local searches starts when part of
  * them have finished (mlsl_driver.c).  The emulated device returns at once. */
-int nla_k_gate(const int32_t *counter, int32_t from, int32_t need, double timeout_ms, void *stream);
+int nla_k_gate(const int32_t *counter, int32_t from, int32_t need, double timeout_ms, int32_t *gave_up /* device-writable (pinned) word set to 1 when the gate times out; or NULL */, void *stream);
 const char *nla_dev_error_string(int err);
 /* code objects loaded at run time (user device objectives) */
 void *nla_module_load_file(const char *path);

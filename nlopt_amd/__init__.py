@@ -43,7 +43,7 @@ class Stats(C.Structure):
                 ("evolve_rounds_enqueued", C.c_uint64), ("evolve_rounds", C.c_uint64),
                 ("t_engine_s", C.c_double), ("t_walk_s", C.c_double),
                 ("list_refreshes", C.c_uint64), ("list_refreshes_beside_device", C.c_uint64), ("t_list_refresh_s", C.c_double),
-                ("isres_gate_timeouts", C.c_uint64), ("mlsl_sampled_ahead", C.c_uint64), ("cobyla_host_searches", C.c_uint64), ("lbfgs_longest_chain_steps", C.c_uint64)]
+                ("isres_gate_timeouts", C.c_uint64), ("mlsl_sampled_ahead", C.c_uint64), ("cobyla_host_searches", C.c_uint64), ("lbfgs_longest_chain_steps", C.c_uint64), ("mlsl_gate_timeouts", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -329,19 +329,24 @@ extern "C" float nla_event_elapsed_ms(void *ev0, void *ev1)
 extern "C" int nla_stream_wait_event(void *stream, void *ev) { return (int) hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) ev, 0); }
 
 /* a gate in a stream (nlopt_amd.h): one wavefront, one lane polling with an agent-scope load between sleeps; wall_clock64 ticks at 100 MHz */
-__global__ void nla_gate_kernel(const int32_t *counter, int32_t from, int32_t need, unsigned long long timeout_ticks)
+__global__ void nla_gate_kernel(const int32_t *counter, int32_t from, int32_t need, unsigned long long timeout_ticks, int32_t *gave_up)
 {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while ((int32_t) ((uint32_t) __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (uint32_t) from) < need) {
-        if (wall_clock64() - t0 > timeout_ticks) break;
+        if (wall_clock64() - t0 > timeout_ticks) {
+            /* what it waits for is not running beside it (streams that cannot overlap: a serialising profiler, one hardware queue): say so,
+             * the caller stops gating (round-5 advisor) */
+            if (gave_up) __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         __builtin_amdgcn_s_sleep(64);
     }
 }
-extern "C" int nla_k_gate(const int32_t *counter, int32_t from, int32_t need, double timeout_ms, void *stream)
+extern "C" int nla_k_gate(const int32_t *counter, int32_t from, int32_t need, double timeout_ms, int32_t *gave_up, void *stream)
 {
     if (!counter || need <= 0) return 0;
-    hipLaunchKernelGGL(nla_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, counter, from, need, (unsigned long long) (timeout_ms * 1e5));
+    hipLaunchKernelGGL(nla_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t) stream, counter, from, need, (unsigned long long) (timeout_ms * 1e5), gave_up);
     return (int) hipGetLastError();
 }
 extern "C" const char *nla_dev_error_string(int err) { return hipGetErrorString((hipError_t) err); }

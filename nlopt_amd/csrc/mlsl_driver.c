@@ -105,6 +105,8 @@ typedef struct {
      * slows the searches by a quarter while it runs — on other compute units too (CU-masked streams: same loss), so no question of issue
      * slots or LDS — behind the gate that is the launch's thinning second half, not all of it (config 4: 9.7 -> 9.4 ms per iteration) */
     const int32_t *gate_counter; int32_t gate_from, gate_need;
+    nlopt_amd_stats *stats;
+    int32_t *h_gate_gave_up; int gate_off;      /* pinned word a gate sets when it times out: no more gates in this run (nlopt_amd_stats.mlsl_gate_timeouts) */
     char err[200];
 } mlsl_dev;
 
@@ -130,7 +132,7 @@ static void mfree(mlsl_dev *d)
     nla_host_free(d->h_S); nla_host_free(d->h_lfall); nla_host_free(d->h_gi); free(d->lf_cand);
     nla_dev_free(d->d_idx); nla_dev_free(d->d_flags); nla_dev_free(d->d_S); nla_dev_free(d->d_lfall); nla_dev_free(d->d_gi);
     nla_event_destroy(d->ev_samples); nla_event_destroy(d->ev_ahead);
-    nla_host_free(d->Fnew2); nla_host_free(d->h_cld2); nla_host_free(d->h_cpd2); nla_host_free(d->h_inf);
+    nla_host_free(d->h_gate_gave_up); nla_host_free(d->Fnew2); nla_host_free(d->h_cld2); nla_host_free(d->h_cpd2); nla_host_free(d->h_inf);
     nla_dev_free(d->d_D2); nla_dev_free(d->d_cpd2); nla_dev_free(d->d_cld2);
     if (d->rs && d->rs != d->st) nla_stream_destroy(d->rs);
     if (d->st) nla_stream_destroy(d->st);
@@ -290,7 +292,11 @@ static int mlsl_enqueue_ahead(mlsl_dev *d, int n)
     if ((size_t) N * cols > ((size_t) 1 << 29)) { d->ahead = 0; return 0; }               /* a second distance matrix above 4 GiB: not worth the memory */
     if (grow_pts(d, old + (size_t) N) || ahead_buffers(d, (size_t) N * cols)) return -1;
     A = d->d_P + old * (size_t) d->ld; FA = d->d_F + old;
-    if (d->gate_need > 0 && nla_k_gate(d->gate_counter, d->gate_from, d->gate_need, 50.0, d->rs)) MFAIL(d, "sampling ahead failed");
+    if (d->h_gate_gave_up && *(volatile int32_t *) d->h_gate_gave_up) {     /* (the launch it belonged to has long ended) */
+        *(volatile int32_t *) d->h_gate_gave_up = 0; d->gate_off = 1;
+        if (d->stats) ++d->stats->mlsl_gate_timeouts;
+    }
+    if (d->gate_need > 0 && !d->gate_off && nla_k_gate(d->gate_counter, d->gate_from, d->gate_need, 50.0, d->h_gate_gave_up, d->rs)) MFAIL(d, "sampling ahead failed");
     if (d->d_V) {
         if (nla_k_mlsl_sobol_rows(n, d->ld, d->d_lb, d->d_ub, d->d_V, d->sobol_next, N, d->d_P + old * (size_t) d->ld, d->rs) ||
             nla_k_eval(d->obj, n, d->ld, A, N, d->d_F + old, d->rs) ||
@@ -498,6 +504,8 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
      * every issue slot the distance pass takes on its SIMD delays the chain — measured: 103 -> 117 ms per launch, round 5) */
     D.ahead = !host && D.world == 1 && D.ev.kind == NLA_EVAL_DEVICE && !use_cobyla && !cob_dev && !nla_exact_mode_for(opt, local_opt, &D.ev);
     D.prefetched_at = ~0ULL;
+    D.stats = st;
+    if (D.ahead) { D.h_gate_gave_up = (int32_t *) nla_host_malloc(sizeof(int32_t)); if (D.h_gate_gave_up) *D.h_gate_gave_up = 0; }     /* (its failure is the set-up's, below) */
     D.rs = (D.st && D.prefetch) ? nla_stream_create_background() : D.st;
     D.ev_samples = nla_event_create();
     D.ev_ahead = nla_event_create();
@@ -532,7 +540,7 @@ nlopt_result nla_mlsl_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data,
     res = (nla_lbfgs_result *) malloc(sizeof *res * (size_t) bmax);
     res_mine = (nla_lbfgs_result *) calloc(BATCH_MAX, sizeof *res_mine);
     cand = (size_t *) malloc(sizeof *cand * (size_t) bmax);
-    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.lf_cand || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !D.ev_samples || !D.ev_ahead || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
+    if ((host && !D.h_rows) || !D.h_idx || !D.d_idx || !D.h_lf || !D.h_S || !D.d_S || !D.h_lfall || !D.lf_cand || !D.d_lfall || !D.h_gi || !D.d_gi || !D.h_flags || !D.d_flags || !D.d_lb || !D.d_ub || !D.d_words || !D.d_tmp || !D.d_LX || !D.ev_samples || !D.ev_ahead || (D.ahead && !D.h_gate_gave_up) || !Fnew || !res || !res_mine || !cand || grow_pts(&D, (size_t) D.N + 1) || grow_lms(&D, 1) ||
         nla_memcpy_h2d(D.d_lb, lbh, sizeof(double) * (size_t) n, D.st) || nla_memcpy_h2d(D.d_ub, ubh, sizeof(double) * (size_t) n, D.st)) {
         nla_stop_msg(stop, "nlopt_amd: could not create the MLSL device state");
         nla_comm_agree_ready(D.comm, 0);

@@ -242,7 +242,13 @@ int nla_event_sync(void *ev) { (void) ev; return 0; }
 float nla_event_elapsed_ms(void *a, void *b) { (void) a; (void) b; return 0.f; }
 int nla_stream_wait_event(void *st, void *ev) { (void) st; (void) ev; return 0; }
 /* (the emulated device runs everything at once, in program order: what a gate would wait for has not been launched yet) */
-int nla_k_gate(const int32_t *counter, int32_t from, int32_t need, double timeout_ms, void *st) { (void) counter; (void) from; (void) timeout_ms; (void) st; if (need > 0) EMU_LAUNCH(); return 0; }
+int nla_k_gate(const int32_t *counter, int32_t from, int32_t need, double timeout_ms, int32_t *gave_up, void *st)
+{
+    (void) counter; (void) from; (void) timeout_ms; (void) st;
+    if (need > 0) EMU_LAUNCH();
+    if (need > 0 && gave_up && getenv("NLA_EMU_GATE_TIMEOUT")) *gave_up = 1;      /* (tests: a gate that gave up) */
+    return 0;
+}
 const char *nla_dev_error_string(int err) { return err == EMU_ERR ? "not provided by the emulated device" : "emulated device error"; }
 
 static double urand_from(double a, double b, uint32_t w0, uint32_t w1)       /* mt19937ar.c:186-206 */

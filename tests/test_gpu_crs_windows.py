@@ -41,6 +41,9 @@ def well_conditioned_prefix(p, pop, floor):
     return None if not idx.size else max(floor, int(idx[0]) - 4)
 
 
+CUTS = []          # (draw, compared up to, drawn budget) of the drawn configurations that were cut short
+
+
 @pytest.mark.parametrize("draw", range(24))
 def test_drawn_configurations(draw):
     """drawn objective / dimension / population (down to n + 1 rows) / seed / stopping rule / window depth / path: the run is the
@@ -65,11 +68,21 @@ def test_drawn_configurations(draw):
     p = O.run_port_crs(obj, n, pop, seed, trace_cap=20000, **kw)
     cut = well_conditioned_prefix(p, pop, pop + 20)
     if cut is not None and cut < kw["maxeval"]:
+        # (round-5 advisor: a cut must not hollow the case out silently — it is reported, and a draw whose comparison would shrink
+        # to the population's evaluations and a handful of trials fails instead of passing on nothing)
+        print("draw %d (%s n=%d pop=%d): compared up to evaluation %d of %d (the population has collapsed to within rounding there)" % (draw, obj, n, pop, cut, kw["maxeval"]))
+        assert cut >= pop + 20, (draw, cut, pop)
+        CUTS.append((draw, cut, kw["maxeval"]))
         kw["maxeval"] = cut
         p = O.run_port_crs(obj, n, pop, seed, trace_cap=20000, **kw)
     a = run_amd(obj, n, pop, seed, trace_cap=20000, params=params, **kw)
     assert_same_run(a, p)
     assert a["stats"]["slots_launched"] >= a["stats"]["slots_used"] > 0
+
+
+def test_few_drawn_configurations_were_cut_short():
+    """the drawn cases above are compared over their whole budget, bar a few toy populations that collapse onto one point"""
+    assert len(CUTS) <= 6, CUTS
 
 
 @pytest.mark.parametrize("obj,n,pop,maxeval", [("rastrigin", 512, 100000, 102500), ("rastrigin", 64, 2000, 9000), ("griewank", 4096, 4200, 5400),

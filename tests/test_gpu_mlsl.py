@@ -68,6 +68,7 @@ def test_mlsl_reaches_the_oracles_result(obj, n, ns, seed, kw, rugged):
     # every sampling phase but the first was computed beside the local phase before it (mlsl_driver.c, mlsl_enqueue_ahead)
     its = a["stats"]["generations"]
     assert max(its - 1, 0) <= a["stats"]["mlsl_sampled_ahead"] <= its, a["stats"]
+    assert a["stats"]["mlsl_gate_timeouts"] == 0, a["stats"]        # (every gate opened: the searches' stream ran beside the generator's)
     nloc = len(p["floc"])
     assert abs(a["minf"] - p["minf"]) <= 1e-7 * max(abs(p["minf"]), 1.0)
     assert np.allclose(a["x"], p["x"], rtol=1e-5, atol=1e-6 * max(np.abs(p["x"]).max(), 1.0))
@@ -176,8 +177,9 @@ def _dist2_reference(A, B):
 def test_pair_distance_kernel_is_the_sequential_sum(n, na, nb):
     """mlsl_dist2_kernel (hip/mlsl_kernels.hip): the squared distance of every (new point, point) pair, bit for bit the serial sum of
     mlsl.c:119-125 — what the closest-point tests (`cpd <= R*R`, mlsl.c:208-209) are decided on.  Ragged tile edges, n not a multiple
-    of the coordinate tile (round 4: ran on the device, the register-tiled kernel became the only one; round 5: the rows of A through the
-    scalar unit, coordinates in pairs — odd n, a single coordinate, and the rows' padding poisoned with NaN: it must not be read)."""
+    of the coordinate tile (round 4: ran on the device, the register-tiled kernel became the only one; round 5: both tile sizes — the
+    32 x 32 instance serves calls with few pairs — odd n, a single coordinate, and the rows' padding poisoned with NaN: it must not be
+    read.  A variant with the rows of A as scalar operands was measured slower in round 5 and is not in the tree)."""
     L = nlopt_amd.lib()
     L.nla_k_mlsl_dist2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(n * 1000 + na)

@@ -1,5 +1,5 @@
 """CPU twin of tests/test_gpu_mlsl_short_segments.py (an MT19937 device stream cut into shorter segments than the default; MLSL on such
-a stream — not yet run on a device): the same tests over the emulated device layer (oracle/libnlopt_amd_emu.so through tests/_emu_plugin.py,
+a stream — on the device since round 5: tests/test_gpu_mlsl_short_segments.py): the same tests over the emulated device layer (oracle/libnlopt_amd_emu.so through tests/_emu_plugin.py,
 in a pytest process of its own).  The emulated jump-ahead is the host's GF(2) arithmetic and the emulated generator regenerates block by
 block, so what is checked here is everything of the feature that is not the 30-line kernel: mtstream.c's segment arithmetic (which
 polynomial a doubling round applies, which state a fill starts from, where the host generator is left) and MLSL's plumbing of the option."""
