@@ -29,10 +29,11 @@
  * over EVM x EVD lanes per round.
  */
 #include "dev_common.h"
+#include <algorithm>
 #include "../../../include/nlopt_amd.h"
 
 #define EVD 256                 /* candidate starts per individual (window of stream positions) */
-#define EVM 256                 /* individuals the chain kernel crosses at a time (one LDS load of E rows); a round's block is bm = 1 or 2 of these */
+#define EVM 256                 /* a round's block is bm = 1 or 2 of these individuals (the variation phase's / the mutation phase's) */
 #define EVMX 512                /* the largest block: the mutation phase's (round 5) */
 #ifndef EV2_MUT_BLOCK
 #define EV2_MUT_BLOCK EVMX      /* (A/B builds: -DEV2_MUT_BLOCK=256) */
@@ -59,6 +60,12 @@ struct ev2_args {
     int16_t *T;                         /* EVM x 64 x EVD: redraws before coordinate chunk c when starting at d */
     int16_t *E;                         /* EVM x EVD: deviates consumed from candidate start d, -1 window exceeded, -2 deviates ran out */
     int64_t *ws_base, *ws_start;        /* window origin / exact start per slot */
+    /* segment tables (round 6): built by the scan launch itself — the LAST workgroup of a segment's 16 individuals to finish composes
+     * the segment's look-ups for every candidate start — so that the chain kernel only strings segments together */
+    uint32_t *segcnt;                   /* per segment: scan workgroups that have finished (zeroed by the chain kernel) */
+    int32_t *SG;                        /* EVMX/16 x EVD: deviates the whole segment consumes from start d of its first individual, -1 it cannot be crossed */
+    int2 *SC;                           /* ... {individuals resolved | (why it stopped & 0xff) << 8, deviates consumed by them} */
+    int32_t *SP;                        /* EVMX/16 x 16 x EVD: start of individual j of the segment, relative to the segment's start */
 };
 
 /* ---- stage ------------------------------------------------------------------------------------------------------- */
@@ -108,6 +115,75 @@ __global__ __launch_bounds__(256) void ev2_stage_kernel(ev2_args A)
     if (tid == 0) { A.ws_nact[i] = s_base; A.ws_mu[i] = (double) s_base; }       /* variation: no better guess than the running rate per mutated coordinate */
 }
 
+/* ---- segment tables (in the scan launch's tail) --------------------------------------------------------------------- */
+#define EV2_SEG 16                     /* individuals per segment */
+#define EV2_OUT 0x40000000             /* a window origin no start of a block can be within EVD of */
+/* does slot q of the block stop every walk (past the end of the phase; variation: isres.c:260 reads the CURRENT physical row k + 1,
+ * which must not be rewritten inside this block before k; a window origin out of all range)?  *base = its window origin otherwise */
+/* what one workgroup of a launch stores and another loads (E, the window origins, the counts): relaxed agent-scope accesses — they go past
+ * the caches that are not shared by all compute units, so the hand-over needs no release / acquire fence (a fence writes back and
+ * invalidates a whole L2: measured, +37 us per scan launch with 512 workgroups fencing) */
+__device__ __forceinline__ void ev2_st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ev2_st_agent64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ev2_ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ev2_ld_agent64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool ev2_slot_stops(const ev2_args &A, int q, int64_t st0, int64_t st1, long long *base)
+{
+    const int na = (int) ev2_ld_agent(reinterpret_cast<const uint32_t *>(A.ws_nact + q));
+    *base = 0;
+    if (na < 0) return true;
+    const long long k = st0 + q, k1 = k + 1 < A.pop ? k + 1 : A.pop - 1;
+    const long long o = A.inv ? A.inv[k1] : -1;
+    const bool dep = A.phase == 1 && k + 1 < A.pop && o >= st0 && o < k;
+    const long long b = (long long) ev2_ld_agent64(reinterpret_cast<const uint64_t *>(A.ws_base + q)), brel = b - st1;
+    if (dep || brel >= EV2_OUT || brel <= -EV2_OUT) return true;
+    *base = b;
+    return false;
+}
+/* Every scan workgroup of a round ends here (256 threads = EVD candidate starts).  The last of a segment's 16 to arrive walks the segment
+ * for every candidate start d of its first individual — start_{j+1} = start_j + E[j][start_j - base_j], the chain's own look-ups — and leaves
+ * what the chain kernel needs to cross the segment in ONE look-up: the deviates consumed (SG), and for a walk that stops inside, how far it got
+ * and why (SC); the individual starts along the way (SP) are what the chain kernel hands to the write pass.  (Rounds 3-5 did this in the chain
+ * kernel — ONE workgroup that first copied the block's 128 KB of E into LDS: 37-45 us per round on the serial path of ~135 rounds per
+ * generation, and a workgroup that needs a compute unit nobody else holds LDS on, §2.2.) */
+__device__ __forceinline__ void ev2_segment_tail(const ev2_args &A, const int i, const int64_t st0, const int64_t st1, double *sm)
+{
+    __shared__ int s_last, s_stop[EV2_SEG];
+    __shared__ long long s_sb[EV2_SEG];
+    const int tid = threadIdx.x, seg = i / EV2_SEG, i0 = seg * EV2_SEG;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           /* this workgroup's E row / window origin / count have landed before it is counted */
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&A.segcnt[seg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == EV2_SEG - 1;
+    __syncthreads();
+    if (!s_last) return;
+    int16_t *sE = reinterpret_cast<int16_t *>(sm);             /* 16 x EVD entries: 8 KB of the launch's dynamic LDS (its contents are done with) */
+    {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(A.E + (size_t) i0 * EVD);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(sE);
+#pragma unroll
+        for (int q = 0; q < EV2_SEG * EVD / 4 / 256; ++q) dst[q * 256 + tid] = ev2_ld_agent64(src + q * 256 + tid);
+    }
+    if (tid < EV2_SEG) { long long b; s_stop[tid] = ev2_slot_stops(A, i0 + tid, st0, st1, &b); s_sb[tid] = b; }
+    __syncthreads();
+    const int d = tid;
+    int cnt = 0, why = 0;
+    long long p = s_sb[0] + d;
+    const long long p0 = p;
+    int32_t *sp = A.SP + (size_t) seg * EV2_SEG * EVD + d;     /* [segment][individual][start]: a wavefront's stores are consecutive */
+#pragma unroll 1
+    for (int j = 0; j < EV2_SEG; ++j) {
+        const long long dj = p - s_sb[j];
+        if (s_stop[j]) { why = -11; break; }
+        if (dj < 0 || dj >= EVD) { why = -10; break; }
+        const int e = sE[j * EVD + (int) dj];
+        if (e < 0) { why = e; break; }
+        sp[j * EVD] = (int) (p - p0);
+        p += e; ++cnt;
+    }
+    A.SG[seg * EVD + d] = cnt == EV2_SEG ? (int) (p - p0) : -1;
+    A.SC[seg * EVD + d] = make_int2(cnt | ((why & 0xff) << 8), (int) (p - p0));
+}
+
 /* ---- scan -------------------------------------------------------------------------------------------------------- */
 /* PH0 (mutation phase, isres.c:234-252): nothing is staged — every coordinate of child k mutates from the rows of its parent
  * irank[k % survivors], which no child overwrites, so the workgroup reads them itself; the expectation of its predecessors' redraws comes
@@ -127,10 +203,10 @@ __device__ __forceinline__ void ev2_scan_body(const ev2_args &A, const int i, do
     if (PH0) {
         const int64_t k = st0 + i;
         na = k < A.pop ? n : -1;
-        if (tid == 0) { A.ws_nact[i] = na; A.ws_mu[i] = na < 0 ? 0.0 : A.mu_rp[k % A.survivors]; }     /* (the chain kernel's inputs) */
+        if (tid == 0) { ev2_st_agent(reinterpret_cast<uint32_t *>(A.ws_nact + i), (uint32_t) na); A.ws_mu[i] = na < 0 ? 0.0 : A.mu_rp[k % A.survivors]; }     /* (the chain kernel's inputs; the count also the segment tail's) */
     } else
         na = A.ws_nact[i];
-    if (na < 0) return;
+    if (na >= 0) {
     /* observed / expected redraws of the individuals resolved lately (decayed sums kept by the chain kernel); before anything was
      * resolved: the expectation as it is (mutation), nothing (variation: its "expectation" is the mutated-coordinate count) */
     const double rhoc = rho_a > 0 ? rho_r / rho_a : (PH0 ? 1.0 : 0.0);
@@ -149,7 +225,7 @@ __device__ __forceinline__ void ev2_scan_body(const ev2_args &A, const int i, do
             const long long ab = s_red[0] + s_red[1] + s_red[2] + s_red[3];
             const double mb = s_mred[0] + s_mred[1] + s_mred[2] + s_mred[3];
             s_base = st1 + i + 2 * ab + (long long) floor(rhoc * mb) - EVD / 2;
-            A.ws_base[i] = s_base;
+            ev2_st_agent64(reinterpret_cast<uint64_t *>(A.ws_base + i), (uint64_t) s_base);
         }
         __syncthreads();
     }
@@ -207,8 +283,13 @@ __device__ __forceinline__ void ev2_scan_body(const ev2_args &A, const int i, do
             cur += 1 + t; red += t - 1;
         }
         const int e = res != 0 ? res : 1 + 2 * na + red;
-        A.E[(size_t) i * EVD + d] = (int16_t) (e > 32767 ? -1 : e);
+        const int e16 = e > 32767 ? -1 : e;
+        /* read by another workgroup of this launch (the segment's tail): agent-scope stores, two entries a word */
+        const int eo = __shfl_down(e16, 1, 64);
+        if (!(d & 1)) ev2_st_agent(reinterpret_cast<uint32_t *>(A.E + (size_t) i * EVD + d), (uint32_t) (e16 & 0xffff) | ((uint32_t) eo << 16));
     }
+    }
+    ev2_segment_tail(A, i, st0, st1, sm);
 }
 
 __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
@@ -221,16 +302,13 @@ __global__ __launch_bounds__(256) void ev2_scan_kernel(ev2_args A)
 /* start_0 is exact; start_{i+1} = start_i + E[i][start_i - base_i].  Rounds 3-4 walked that chain through the block with one wavefront
  * (256 dependent look-ups: 33-39 us of a ~125 us round, the E table copied into LDS first).  But a look-up table composes: the
  * deviates the SEGMENT of individuals 16 s .. 16 s + 15 consumes is a function of the start of its first individual alone, and that
- * function can be tabulated for every candidate start by independent lanes.  Round 5:
- *   A  (all 1024 threads)  for each of the 16 segments and each of the 256 candidate starts d of its first individual: walk the
- *      segment's 16 individuals through E (LDS) and store the deviates consumed, G[s][d], or "left a window / an entry says no";
- *   B  (one thread)        16 look-ups in G from the block's exact first start: the exact start of every segment, up to the first
- *      segment that cannot be crossed whole;
- *   C  (one thread per segment, all at once)  the segment's 16 individuals again from its now exact start, recording the individual
- *      starts — the segment that could not be crossed is walked until it stops, which gives the round's count and why it ended.
- * The same look-ups in the same tables as the serial walk, hence the same starts: 16 + 16 + 16 dependent steps instead of 256. */
-#define EV2_SEG 16                     /* individuals per segment; EVM / EV2_SEG segments */
-#define EV2_NSEG (EVM / EV2_SEG)
+ * function can be tabulated for every candidate start by independent lanes (round 5: inside the chain kernel — ONE workgroup copying the
+ * block's 128 KB of E into LDS, 37-45 us per round; round 6: by the scan launch itself, ev2_segment_tail above).  What is left here:
+ *   B  (one thread)  strings the block's segments together from the block's exact first start, ONE look-up per segment in SG (32 KB in
+ *      LDS); a segment that cannot be crossed whole ends the walk where its own table says (SC);
+ *   C  (all at once)  every resolved individual's start is its segment's start + SP.
+ * The same look-ups in the same tables as the serial walk, hence the same starts (config 3: 7-10 us per round, the round 143 -> 118 us,
+ * 34.2 -> 32.3 ms per generation: profiles/r06_isres_segchain_ab.txt). */
 __device__ __forceinline__ long long ev2_uniform64(long long v)
 {
     const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v & 0xffffffffll));
@@ -238,109 +316,62 @@ __device__ __forceinline__ long long ev2_uniform64(long long v)
     return (long long) (((unsigned long long) hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
+__global__ __launch_bounds__(256) void ev2_chain_seg_kernel(ev2_args A)
 {
-    extern __shared__ int16_t sE[];                            /* EVM x EVD, then G: EV2_NSEG x EVD ints */
-    __shared__ int s_b[EVM], s_st[EVM], s_segpos[EV2_NSEG + 1], s_cnt[EV2_NSEG], s_why[EV2_NSEG], s_nfull;
-    __shared__ long long s_asum[16];
-    __shared__ double s_msum[16];
-    int *G = reinterpret_cast<int *>(sE + (size_t) EVM * EVD);
+    constexpr int NS = EVMX / EV2_SEG;
+    __shared__ int sG[NS * EVD];
+    __shared__ int s_segrel[NS], s_segstop[NS], s_segpos[NS + 1], s_r, s_why, s_end;
+    __shared__ long long s_asum[4];
+    __shared__ double s_msum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t st0 = A.state[0], st1 = A.state[1], st2 = A.state[2], st10 = A.state[10], st11 = A.state[11];
     const double rho_r = A.rho[2 * A.phase], rho_a = A.rho[2 * A.phase + 1];
-    if (st2 || st10) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing: its write kernel idles */
+    if (st2 || st10) { if (tid == 0) A.state[9] = 0; return; }     /* a skipped round resolves nothing (its scan counted nothing) */
+    const int nseg = A.bm / EV2_SEG;
+    if (tid < NS) A.segcnt[tid] = 0;                           /* for the next round's scan */
     const int64_t k0 = ev2_uniform64(st0), kend = A.phase == 0 ? A.pop : A.survivors;
     if (k0 >= kend) { if (tid == 0) A.state[9] = 0; return; }
-    static_assert(EVM == 256 && EVD == 256 && (EVM * EVD / 8) % 1024 == 0 && EV2_NSEG * EVD % 1024 == 0, "block shape");
     const long long pos0 = ev2_uniform64(st1);
-    const int OUT = 0x40000000;                                /* a window origin no start of this block can be within EVD of */
-    /* one step of the chain for individual i (of the EVM in LDS) from position pos (relative to pos0): the entry, or why there is none:
-     * -10 the start left the window, -11 the individual stops every walk (end of the phase / variation's dependency), -1 / -2 the scan's */
-    auto step = [&](int i, int pos) -> int {
-        const unsigned d = (unsigned) (pos - s_b[i]);
-        if (d >= (unsigned) EVD) return d >= 0xc0000000u && d < 0xd0000000u ? -11 : -10;
-        return (int) sE[(size_t) i * EVD + d];
-    };
-    /* The block is crossed EVM individuals at a time (what fits the LDS): the mutation phase's block is two of them (round 5 — the scan of
-     * 512 individuals is two workgroups per compute unit, two wavefronts per SIMD, and takes little longer than that of 256, whose lone
-     * wavefronts left every SIMD idle most of the time; with the per-parent expectation the starts of ~430 of the 512 stay inside their
-     * windows: 100 rounds per mutation phase instead of 172, tools/evolve_predict.py), the second entered at the exact end of the first. */
-    int r = 0, elast = 0, pos = 0;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.SG);
+        uint4 *dst = reinterpret_cast<uint4 *>(sG);
+        for (int q = tid; q < nseg * EVD / 4; q += 256) dst[q] = src[q];
+    }
+    if (tid < nseg) {
+        long long b;
+        const bool stop = ev2_slot_stops(A, tid * EV2_SEG, st0, st1, &b);
+        s_segstop[tid] = stop; s_segrel[tid] = stop ? 0 : (int) (b - pos0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int p = 0, nf = 0, cnt = 0, why = 0;
+        for (; nf < nseg; ++nf) {
+            s_segpos[nf] = p;
+            if (s_segstop[nf]) { why = -11; break; }
+            const int d = p - s_segrel[nf];
+            if (d < 0 || d >= EVD) { why = -10; break; }
+            const int g = sG[nf * EVD + d];
+            if (g < 0) {                                       /* the walk ends inside this segment: how far it got */
+                const int2 c = A.SC[nf * EVD + d];
+                cnt = c.x & 0xff; why = (int) (int8_t) ((c.x >> 8) & 0xff);
+                p += c.y;
+                break;
+            }
+            p += g;
+        }
+        s_r = nf * EV2_SEG + cnt; s_why = nf < nseg ? why : 0; s_end = p;
+    }
+    __syncthreads();
+    const int r = s_r, elast = s_why, pos = s_end;
     long long asum = 0;
     double msum = 0;
-    for (int h = 0; h < A.bm / EVM; ++h) {
-        __syncthreads();                                       /* (the previous part's tables are no longer read) */
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(A.E) + (size_t) h * (EVM * EVD / 8);      /* (E is 256-byte aligned in the workspace) */
-            uint4 *dst = reinterpret_cast<uint4 *>(sE);
-#pragma unroll
-            for (int q = 0; q < EVM * EVD / 8 / 1024; ++q) dst[q * 1024 + tid] = src[q * 1024 + tid];
+    {
+        for (int q = tid; q < r; q += EVM) {                   /* (thread t: individuals t and t + 256: the order the redraw statistics have been summed in since round 5) */
+            const int sg = q / EV2_SEG, j = q % EV2_SEG;
+            const int d = s_segpos[sg] - s_segrel[sg];
+            A.ws_start[q] = pos0 + s_segpos[sg] + A.SP[((size_t) sg * EV2_SEG + j) * EVD + d];
+            asum += A.ws_nact[q]; msum += A.ws_mu[q];
         }
-        int na_i = 0;
-        double mu_i = 0;
-        if (tid < EVM) {
-            const int q = h * EVM + tid;
-            na_i = A.ws_nact[q]; mu_i = A.ws_mu[q];
-            const long long brel = A.ws_base[q] - pos0;
-            /* the row isres.c:260 reads (physical row k + 1) must not be rewritten inside this block before k: the walk ends at a
-             * survivor k whose row k + 1 belongs to an earlier survivor of the block (straight-line: the index is clamped, not guarded) */
-            const long long k = k0 + q, k1 = k + 1 < A.pop ? k + 1 : A.pop - 1;
-            const long long o = A.inv[k1];
-            const bool dep = A.phase == 1 && k + 1 < A.pop && o >= k0 && o < k;
-            const bool stop = na_i < 0 || dep || brel >= OUT || brel <= -OUT;
-            s_b[tid] = stop ? OUT : (int) brel;
-        }
-        __syncthreads();
-        /* A: the segments' tables */
-#pragma unroll 1
-        for (int t = tid; t < EV2_NSEG * EVD; t += 1024) {
-            const int sg = t / EVD, d = t % EVD, i0 = sg * EV2_SEG;
-            int p = s_b[i0] == OUT ? 0 : s_b[i0] + d, ok = s_b[i0] != OUT;
-            const int p0 = p;
-            for (int j = 0; ok && j < EV2_SEG; ++j) {
-                const int e = step(i0 + j, p);
-                if (e < 0) ok = 0; else p += e;
-            }
-            G[t] = ok ? p - p0 : -1;
-        }
-        __syncthreads();
-        /* B: the exact start of every segment that can be reached by crossing whole segments */
-        if (tid == 0) {
-            int p = pos, nf = 0;
-            s_segpos[0] = p;
-            for (; nf < EV2_NSEG; ++nf) {
-                const unsigned d = (unsigned) (p - s_b[nf * EV2_SEG]);
-                if (d >= (unsigned) EVD) break;
-                const int g = G[nf * EVD + (int) d];
-                if (g < 0) break;
-                p += g;
-                s_segpos[nf + 1] = p;
-            }
-            s_nfull = nf;
-        }
-        __syncthreads();
-        /* C: the individual starts, segment by segment in parallel (lane 0 of wavefront s: every walker on a SIMD's issue slot of its own
-         * as far as the 16 wavefronts go) */
-        const int nfull = s_nfull;
-        if (lane == 0 && wave < EV2_NSEG && wave <= nfull) {
-            const int i0 = wave * EV2_SEG;
-            int p = s_segpos[wave], c = 0, why = 0;
-            for (; c < EV2_SEG; ++c) {
-                const int e = step(i0 + c, p);
-                if (e < 0) { why = e; break; }
-                s_st[i0 + c] = p;
-                p += e;
-            }
-            s_cnt[wave] = c; s_why[wave] = why;
-            if (wave == nfull) s_segpos[EV2_NSEG] = p;         /* where the walk ended (the segment that stopped it) */
-        }
-        __syncthreads();
-        const int rh = nfull < EV2_NSEG ? nfull * EV2_SEG + s_cnt[nfull] : EVM;
-        elast = nfull < EV2_NSEG ? s_why[nfull] : 0;
-        pos = s_segpos[EV2_NSEG];                              /* (a full part: B stored its end there) */
-        if (tid < rh) { A.ws_start[h * EVM + tid] = pos0 + s_st[tid]; asum += na_i; msum += mu_i; }
-        r += rh;
-        if (rh < EVM) break;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { asum += __shfl_xor(asum, m, 64); msum += __shfl_xor(msum, m, 64); }
@@ -357,7 +388,7 @@ __global__ __launch_bounds__(1024) void ev2_chain_kernel(ev2_args A)
     A.state[11] = st11 + 1;
     if (elast == -2) A.state[2] = 1;
     else if (r == 0) A.state[10] = 1;                           /* not even the exactly-started first individual resolved: serial fallback */
-#ifdef NLA_EV2_REASONS                                          /* development build (NLOPT_AMD_VARIANT="reasons:-DNLA_EV2_REASONS"): what ended the walks; isres_driver.c prints it per phase */
+#ifdef NLA_EV2_REASONS
     A.state[3] += elast == -10; A.state[4] += elast == -11; A.state[5] += elast == -1; A.state[6] += elast == 0; A.state[7] += r;
 #endif
     A.rho[2 * A.phase] = 0.9 * rho_r + (double) rsum;
@@ -503,6 +534,8 @@ extern "C" size_t nla_isres_evolve2_ws_bytes(int n)
     add(sizeof(int16_t) * EVMX * EVD); add(sizeof(int16_t) * EVMX * 64 * EVD); add(sizeof(int64_t) * EVMX); add(sizeof(int64_t) * EVMX);
     add(sizeof(double) * EVMX);
     add(sizeof(int16_t) * EVMX * 64 * EVD); add(sizeof(int64_t) * EVMX); add(sizeof(int64_t) * EVMX);      /* the second set of T / base / start (mutation phase) */
+    add(sizeof(uint32_t) * (EVMX / EV2_SEG)); add(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD); add(sizeof(int2) * (EVMX / EV2_SEG) * EVD);
+    add(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD * EV2_SEG);                                                /* the segment tables */
     return b;
 }
 extern "C" int nla_isres_evolve2_supported(int n) { return n >= 1 && n <= EV2_MAXN; }
@@ -547,24 +580,28 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
     A.ws_base = (int64_t *) take(sizeof(int64_t) * EVMX);
     A.ws_start = (int64_t *) take(sizeof(int64_t) * EVMX);
     A.ws_mu = (double *) take(sizeof(double) * EVMX);
+    int16_t *T2 = (int16_t *) take(sizeof(int16_t) * EVMX * 64 * EVD);
+    int64_t *base2 = (int64_t *) take(sizeof(int64_t) * EVMX), *start2 = (int64_t *) take(sizeof(int64_t) * EVMX);
+    A.segcnt = (uint32_t *) take(sizeof(uint32_t) * (EVMX / EV2_SEG));
+    A.SG = (int32_t *) take(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD);
+    A.SC = (int2 *) take(sizeof(int2) * (EVMX / EV2_SEG) * EVD);
+    A.SP = (int32_t *) take(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD * EV2_SEG);
+    hipStream_t st = (hipStream_t) stream;
+    if (hipMemsetAsync(A.segcnt, 0, sizeof(uint32_t) * (EVMX / EV2_SEG), st) != hipSuccess) return (int) hipGetLastError();
     ev2_args B = A;                                            /* the other set of what a round's write still needs while the next round scans */
-    B.T = (int16_t *) take(sizeof(int16_t) * EVMX * 64 * EVD);
-    B.ws_base = (int64_t *) take(sizeof(int64_t) * EVMX);
-    B.ws_start = (int64_t *) take(sizeof(int64_t) * EVMX);
-    const size_t lds_scan = sizeof(double) * (size_t) (5 * n + EV2_ZW(n));
-    const size_t lds_write = sizeof(double) * (size_t) (7 * n + EV2_ZW(n));
-    const size_t lds_chain = sizeof(int16_t) * EVM * EVD + sizeof(int) * EV2_NSEG * EVD;
+    B.T = T2; B.ws_base = base2; B.ws_start = start2;
+    const size_t lds_tail = sizeof(int16_t) * EV2_SEG * EVD;   /* (the segment tail of a scan workgroup re-uses the launch's dynamic LDS) */
+    const size_t lds_scan = std::max(sizeof(double) * (size_t) (5 * n + EV2_ZW(n)), lds_tail);
+    const size_t lds_write = std::max(sizeof(double) * (size_t) (7 * n + EV2_ZW(n)), lds_tail);
     static bool attr_set = false;
     if (!attr_set) {
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_write0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         (void) hipGetLastError();
         attr_set = true;
     }
-    hipStream_t st = (hipStream_t) stream;
     A.bm = B.bm = phase == 0 ? EV2_MUT_BLOCK : EVM;
     if (phase == 0) {
         /* round r works on set r & 1; its launch also writes what round r - 1 resolved (the other set); the batch ends with the last
@@ -572,14 +609,14 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
         for (int r = 0; r < rounds; ++r) {
             const ev2_args &C = (r & 1) ? B : A, &Pv = (r & 1) ? A : B;
             hipLaunchKernelGGL(ev2_scan0_kernel, dim3(r ? 2 * EV2_MUT_BLOCK : EV2_MUT_BLOCK), dim3(EVD), lds_write, st, C, Pv);
-            hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(1024), lds_chain, st, C);
+            hipLaunchKernelGGL(ev2_chain_seg_kernel, dim3(1), dim3(256), 0, st, C);
         }
         if (rounds > 0) hipLaunchKernelGGL(ev2_write0_kernel, dim3(EV2_MUT_BLOCK), dim3(256), lds_write, st, ((rounds - 1) & 1) ? B : A);
     } else
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(ev2_stage_kernel, dim3(EVM), dim3(256), 0, st, A);
         hipLaunchKernelGGL(ev2_scan_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);
-        hipLaunchKernelGGL(ev2_chain_kernel, dim3(1), dim3(1024), lds_chain, st, A);
+        hipLaunchKernelGGL(ev2_chain_seg_kernel, dim3(1), dim3(256), 0, st, A);
         hipLaunchKernelGGL(ev2_write_kernel, dim3(EVM), dim3(64), lds_write, st, A);
     }
     NLA_LAUNCH_CHECK();
