@@ -40,6 +40,7 @@
 #endif
 #define EV2_MAXN 1150           /* LDS staging limit (same as the serial LDS kernel) */
 #define EV2_ZW(n) (EVD + 3 * (n) + 65)      /* deviates staged per individual: window + 1 + 2n + room for n + 64 redraws */
+#define EV2_ZPAD 2                          /* doubles of LDS behind the staged deviates (the scan reads one deviate ahead) */
 
 struct ev2_args {
     int n, ld, phase;
@@ -269,16 +270,25 @@ __device__ __forceinline__ void ev2_scan_body(const ev2_args &A, const int i, do
              * only for draws inside the slack, was slower — 89 us against 70 us per round: with 5 % of the lanes redrawing every wavefront
              * goes round the draw loop twice, and the three-exit loop's mask bookkeeping costs more than the exp saves;
              * profiles/r04_isres_chain_walk.txt.) */
-            double zs = zw[cur], z1 = zw[cur + 1], sa = sg[a], sm_ = smax[a], xa = xi[a], l = lo[a], h = hi[a];
-            asm volatile("" : "+v"(zs), "+v"(z1), "+v"(sa), "+v"(sm_), "+v"(xa), "+v"(l), "+v"(h));   /* (all seven reads issued here: the compiler would sink z1 and the bounds below the exp) */
+            /* (z2, the first redraw's deviate, comes with them — the staging area has room for the read past a window's end: with 5 % of the
+             * draws outside the box nearly every step of a WAVEFRONT goes round the redraw loop once, and that round no longer waits for LDS) */
+            double zs = zw[cur], z1 = zw[cur + 1], z2 = zw[cur + 2], sa = sg[a], sm_ = smax[a], xa = xi[a], l = lo[a], h = hi[a];
+            asm volatile("" : "+v"(zs), "+v"(z1), "+v"(z2), "+v"(sa), "+v"(sm_), "+v"(xa), "+v"(l), "+v"(h));   /* (all eight reads issued here: the compiler would sink z1 and the bounds below the exp) */
             double s2 = sa * exp(taup_rand + A.tau * zs);
             if (s2 > sm_) s2 = sm_;
             int t = 1;
             double xn = xa + s2 * z1;
-            while (xn < l || xn > h) {
-                ++t;
-                if (cur + t >= zwlen) { res = zw_cut ? -2 : -1; break; }
-                xn = xa + s2 * zw[cur + t];
+            if (xn < l || xn > h) {
+                t = 2;
+                if (cur + 2 >= zwlen) res = zw_cut ? -2 : -1;
+                else {
+                    xn = xa + s2 * z2;
+                    while (xn < l || xn > h) {
+                        ++t;
+                        if (cur + t >= zwlen) { res = zw_cut ? -2 : -1; break; }
+                        xn = xa + s2 * zw[cur + t];
+                    }
+                }
             }
             cur += 1 + t; red += t - 1;
         }
@@ -591,8 +601,8 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
     ev2_args B = A;                                            /* the other set of what a round's write still needs while the next round scans */
     B.T = T2; B.ws_base = base2; B.ws_start = start2;
     const size_t lds_tail = sizeof(int16_t) * EV2_SEG * EVD;   /* (the segment tail of a scan workgroup re-uses the launch's dynamic LDS) */
-    const size_t lds_scan = std::max(sizeof(double) * (size_t) (5 * n + EV2_ZW(n)), lds_tail);
-    const size_t lds_write = std::max(sizeof(double) * (size_t) (7 * n + EV2_ZW(n)), lds_tail);
+    const size_t lds_scan = std::max(sizeof(double) * (size_t) (5 * n + EV2_ZW(n) + EV2_ZPAD), lds_tail);
+    const size_t lds_write = std::max(sizeof(double) * (size_t) (7 * n + EV2_ZW(n) + EV2_ZPAD), lds_tail);
     static bool attr_set = false;
     if (!attr_set) {
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(ev2_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
