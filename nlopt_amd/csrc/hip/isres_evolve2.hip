@@ -34,12 +34,20 @@
 
 #define EVD 256                 /* candidate starts per individual (window of stream positions) */
 #define EVM 256                 /* a round's block is bm = 1 or 2 of these individuals (the variation phase's / the mutation phase's) */
-#define EVMX 512                /* the largest block: the mutation phase's (round 5) */
+#ifndef EVMX
+#define EVMX 1024               /* the largest block: the mutation phase's (round 5: 512; round 6, with the chain kernel over segment tables: 768 / 1024 / 1536 measured,
+                                 * 63 rounds of ~680 individuals per mutation phase at config 3 instead of 96 of ~450: -0.8 ms per generation) */
+#endif
 #ifndef EV2_MUT_BLOCK
 #define EV2_MUT_BLOCK EVMX      /* (A/B builds: -DEV2_MUT_BLOCK=256) */
 #endif
+#ifndef EV2_VAR_BLOCK
+#define EV2_VAR_BLOCK EVM       /* the variation phase's block (512 measured at the end of round 6: 37 -> 31 rounds, no time gained — half of its
+                                 * rounds end at a row dependency, isres.c:260) */
+#endif
 #define EV2_MAXN 1150           /* LDS staging limit (same as the serial LDS kernel) */
 #define EV2_ZW(n) (EVD + 3 * (n) + 65)      /* deviates staged per individual: window + 1 + 2n + room for n + 64 redraws */
+static_assert(16 * EV2_ZW(EV2_MAXN) < 65535, "a segment's deviates fit the 16-bit segment table");
 #define EV2_ZPAD 2                          /* doubles of LDS behind the staged deviates (the scan reads one deviate ahead) */
 
 struct ev2_args {
@@ -64,7 +72,7 @@ struct ev2_args {
     /* segment tables (round 6): built by the scan launch itself — the LAST workgroup of a segment's 16 individuals to finish composes
      * the segment's look-ups for every candidate start — so that the chain kernel only strings segments together */
     uint32_t *segcnt;                   /* per segment: scan workgroups that have finished (zeroed by the chain kernel) */
-    int32_t *SG;                        /* EVMX/16 x EVD: deviates the whole segment consumes from start d of its first individual, -1 it cannot be crossed */
+    uint16_t *SG;                       /* EVMX/16 x EVD: deviates the whole segment consumes from start d of its first individual (<= 16 EV2_ZW(EV2_MAXN) < 65535), 0xffff it cannot be crossed */
     int2 *SC;                           /* ... {individuals resolved | (why it stopped & 0xff) << 8, deviates consumed by them} */
     int32_t *SP;                        /* EVMX/16 x 16 x EVD: start of individual j of the segment, relative to the segment's start */
 };
@@ -181,7 +189,7 @@ __device__ __forceinline__ void ev2_segment_tail(const ev2_args &A, const int i,
         sp[j * EVD] = (int) (p - p0);
         p += e; ++cnt;
     }
-    A.SG[seg * EVD + d] = cnt == EV2_SEG ? (int) (p - p0) : -1;
+    A.SG[seg * EVD + d] = cnt == EV2_SEG ? (uint16_t) (p - p0) : (uint16_t) 0xffffu;
     A.SC[seg * EVD + d] = make_int2(cnt | ((why & 0xff) << 8), (int) (p - p0));
 }
 
@@ -329,7 +337,7 @@ __device__ __forceinline__ long long ev2_uniform64(long long v)
 __global__ __launch_bounds__(256) void ev2_chain_seg_kernel(ev2_args A)
 {
     constexpr int NS = EVMX / EV2_SEG;
-    __shared__ int sG[NS * EVD];
+    __shared__ uint16_t sG[NS * EVD];
     __shared__ int s_segrel[NS], s_segstop[NS], s_segpos[NS + 1], s_r, s_why, s_end;
     __shared__ long long s_asum[4];
     __shared__ double s_msum[4];
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256) void ev2_chain_seg_kernel(ev2_args A)
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.SG);
         uint4 *dst = reinterpret_cast<uint4 *>(sG);
-        for (int q = tid; q < nseg * EVD / 4; q += 256) dst[q] = src[q];
+        for (int q = tid; q < nseg * EVD / 8; q += 256) dst[q] = src[q];
     }
     if (tid < nseg) {
         long long b;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256) void ev2_chain_seg_kernel(ev2_args A)
             const int d = p - s_segrel[nf];
             if (d < 0 || d >= EVD) { why = -10; break; }
             const int g = sG[nf * EVD + d];
-            if (g < 0) {                                       /* the walk ends inside this segment: how far it got */
+            if (g == 0xffff) {                                       /* the walk ends inside this segment: how far it got */
                 const int2 c = A.SC[nf * EVD + d];
                 cnt = c.x & 0xff; why = (int) (int8_t) ((c.x >> 8) & 0xff);
                 p += c.y;
@@ -544,7 +552,7 @@ extern "C" size_t nla_isres_evolve2_ws_bytes(int n)
     add(sizeof(int16_t) * EVMX * EVD); add(sizeof(int16_t) * EVMX * 64 * EVD); add(sizeof(int64_t) * EVMX); add(sizeof(int64_t) * EVMX);
     add(sizeof(double) * EVMX);
     add(sizeof(int16_t) * EVMX * 64 * EVD); add(sizeof(int64_t) * EVMX); add(sizeof(int64_t) * EVMX);      /* the second set of T / base / start (mutation phase) */
-    add(sizeof(uint32_t) * (EVMX / EV2_SEG)); add(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD); add(sizeof(int2) * (EVMX / EV2_SEG) * EVD);
+    add(sizeof(uint32_t) * (EVMX / EV2_SEG)); add(sizeof(uint16_t) * (EVMX / EV2_SEG) * EVD); add(sizeof(int2) * (EVMX / EV2_SEG) * EVD);
     add(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD * EV2_SEG);                                                /* the segment tables */
     return b;
 }
@@ -593,7 +601,7 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
     int16_t *T2 = (int16_t *) take(sizeof(int16_t) * EVMX * 64 * EVD);
     int64_t *base2 = (int64_t *) take(sizeof(int64_t) * EVMX), *start2 = (int64_t *) take(sizeof(int64_t) * EVMX);
     A.segcnt = (uint32_t *) take(sizeof(uint32_t) * (EVMX / EV2_SEG));
-    A.SG = (int32_t *) take(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD);
+    A.SG = (uint16_t *) take(sizeof(uint16_t) * (EVMX / EV2_SEG) * EVD);
     A.SC = (int2 *) take(sizeof(int2) * (EVMX / EV2_SEG) * EVD);
     A.SP = (int32_t *) take(sizeof(int32_t) * (EVMX / EV2_SEG) * EVD * EV2_SEG);
     hipStream_t st = (hipStream_t) stream;
@@ -612,7 +620,7 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
         (void) hipGetLastError();
         attr_set = true;
     }
-    A.bm = B.bm = phase == 0 ? EV2_MUT_BLOCK : EVM;
+    A.bm = B.bm = phase == 0 ? EV2_MUT_BLOCK : EV2_VAR_BLOCK;
     if (phase == 0) {
         /* round r works on set r & 1; its launch also writes what round r - 1 resolved (the other set); the batch ends with the last
          * round's write, so every batch starts from a population that is up to date */
@@ -624,10 +632,10 @@ extern "C" int nla_k_isres_evolve_rounds(int n, int ld, int phase, int64_t pop, 
         if (rounds > 0) hipLaunchKernelGGL(ev2_write0_kernel, dim3(EV2_MUT_BLOCK), dim3(256), lds_write, st, ((rounds - 1) & 1) ? B : A);
     } else
     for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(ev2_stage_kernel, dim3(EVM), dim3(256), 0, st, A);
-        hipLaunchKernelGGL(ev2_scan_kernel, dim3(EVM), dim3(EVD), lds_scan, st, A);
+        hipLaunchKernelGGL(ev2_stage_kernel, dim3(EV2_VAR_BLOCK), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(ev2_scan_kernel, dim3(EV2_VAR_BLOCK), dim3(EVD), lds_scan, st, A);
         hipLaunchKernelGGL(ev2_chain_seg_kernel, dim3(1), dim3(256), 0, st, A);
-        hipLaunchKernelGGL(ev2_write_kernel, dim3(EVM), dim3(64), lds_write, st, A);
+        hipLaunchKernelGGL(ev2_write_kernel, dim3(EV2_VAR_BLOCK), dim3(64), lds_write, st, A);
     }
     NLA_LAUNCH_CHECK();
     return 0;

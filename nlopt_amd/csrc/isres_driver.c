@@ -410,12 +410,12 @@ static int dev_evolve(isres_dev *d, double taup, double tau, double *t_rng)
         DCK(d, nla_stream_sync(d->st));
         for (;;) {
             if (d->parallel_evolve) {
-                /* a round resolves up to 256 individuals (fewer when the predicted windows are left or a variation individual depends on an
-                 * earlier one of its block: 430 of a mutation block's 512, 188 of a variation block's 256 per round at config 3): enqueue what the phase should need, then look.  Every
+                /* a round resolves up to a block of individuals (fewer when the predicted windows are left or a variation individual depends on an
+                 * earlier one of its block: 680 of a mutation block's 1024, 188 of a variation block's 256 per round at config 3): enqueue what the phase should need, then look.  Every
                  * look is a stream synchronisation, a copy of the state and a cold start of the next batch — some 50 us, and round 4's
                  * batches of at most 24 rounds made ~28 of them per generation; a round enqueued in vain costs its launches (~10 us) */
                 const int64_t left = kend - state[0];
-                int rounds = (int) (left / (phase == 0 ? 400 : 170)) + 2;
+                int rounds = (int) (left / (phase == 0 ? 680 : 170)) + 2;
                 if (rounds > 72) rounds = 72;
                 DCK(d, nla_k_isres_evolve_rounds(d->n, d->ld, phase, d->pop, d->survivors, zcount, taup, tau, d->d_lb, d->d_ub, d->d_z,
                                                  d->d_irank, d->d_inv, d->d_X, d->d_S, d->d_scratch, d->d_state, d->d_rho, d->d_ws, d->d_mu, rounds, d->st));
