@@ -60,6 +60,7 @@
 #include <stdlib.h>
 #include "../../../include/nlopt_amd.h"
 
+#define NLA_CHAIN_LIGHT_BELOW 2048        /* below: lighter fences around the resolver's turn and the evaluation (crs_chain_resolver.h, ch_landed) */
 #define CH_EXTRA 32                      /* accepted values that landed among the window's worst rows */
 #define CH_FWAVES 8                      /* f is reduced as a workgroup of 8 wavefronts reduces it (= NLA_FIN_WAVES of crs_kernels.hip, SH_WAVES of crs_shard.hip):
                                           * windows, conservative passes and column-sharded jobs give the same f bit for bit at every n */
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
                 if (lane < S->world) st_sys(S->peerstop[lane] + (seq & 1u) * NLA_SH_MAXW + (uint32_t) S->rank, (seq << 2) | (stopbits & 3u));
             }
             chain_resolver_wave(reinterpret_cast<uint32_t *>(ctrl), reinterpret_cast<const uint64_t *>(fv), rowstate, K, nW, W, Wf, f_best, i0,
-                                resolver_timeout);
+                                resolver_timeout, !SH && n < NLA_CHAIN_LIGHT_BELOW);
             if constexpr (SH) {
                 /* the chain is done, so every rank's kernel of this launch has started (slot 0 is never abandoned: its chunks came from
                  * all of them): their stop words are there or on their way */
@@ -394,7 +395,13 @@ __global__ __launch_bounds__(WAVES * 64) void crs_chain_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                 /* system scope: the peers' stores */
     } else
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+        /* TX is uncached memory and its chunks had landed before they were counted: nothing stale to drop.  Below n = 2048 — where the
+         * evaluation is a link of the window's dependency chains — the fence only orders the loads behind the count; from n = 2048 the
+         * agent-scope acquire stays (measured: the headline is 2.3 % faster WITH it; crs_chain_resolver.h, ch_landed) */
+        if (n < NLA_CHAIN_LIGHT_BELOW) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     {
         const int tid = threadIdx.x;
         const double *x = TX + (size_t) q * tld;
