@@ -153,7 +153,7 @@ def test_hot_kernels_use_no_scratch_memory():
     ks = kernel_resources.kernels()
     assert len(ks) > 100
     must = ("crs_advance_kernel", "crs_chain_kernel", "crs_finish_kernel", "crs_vitter_kernel", "lbfgs_resident_kernel", "mlsl_dist2_kernel",
-            "mma_batch_kernel", "ev2_scan_kernel", "ev2_chain_kernel", "ev2_write_kernel", "isres_stochrank_kernel",
+            "mma_batch_kernel", "ev2_scan_kernel", "ev2_chain_seg_kernel", "ev2_write_kernel", "isres_stochrank_kernel",
             "mt_rankbits_kernel")
     seen = set()
     for k in ks:
