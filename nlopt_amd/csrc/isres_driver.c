@@ -54,6 +54,7 @@ typedef struct {
     int evolve_serial;              /* "amd_isres_evolve_serial" != 0: the one-workgroup evolve kernel (the parallel one's reference in the tests) */
     int overlap;                    /* default; "amd_isres_overlap" = 0 / NLA_ISRES_OVERLAP=0 turn it off: generator work beside the latency-bound kernels */
     int spec_valid; uint64_t spec_word0; int64_t spec_attempts, spec_zcount;   /* deviates generated ahead of the evolve phase (overlap) */
+    int bits_pre; uint64_t bits_pre_g0;   /* the gated generator of this generation's ranking bits is already enqueued (in front of the host's bookkeeping loop) */
     uint64_t spec_made, spec_used;  /* ... how often, and how often the evolve phase could take them */
     nla_mtstream *mts;
     uint64_t words_used;
@@ -191,6 +192,26 @@ static int dev_init_population(isres_dev *d, const double *x0)
 /* selection (isres.c:202-229); *sweeps_out = ranking sweeps actually taken (0 on the sort path) */
 static int dev_more_deviates(isres_dev *d, uint64_t phase_word0, int64_t *attempts_done, int64_t nattempts, int64_t *zcount);
 
+/* can the ranking's bits be generated by the gated launch (in-order gates, the pipeline started beside it)? */
+static int dev_rank_is_gated(const isres_dev *d)
+{
+    return d->gated && d->rs != d->st && nlopt_amd_comm_world(d->comm) == 1 && !d->bits_two_pass && d->d_gate != NULL;
+}
+/* ... that launch, on the generator's stream: from where the stream stands (words_used).  Called by dev_rank, or — so that the generator, which
+ * bounds the ranking phase, does not wait for the host's pass over the generation's values (0.3 ms at pop = 5e4) — in front of that pass */
+static int dev_rank_bits_gated(isres_dev *d)
+{
+    const int64_t pop = d->pop, popm1 = pop - 1;
+    DCK(d, nla_memset(d->d_bits, 0, sizeof(uint64_t) * (size_t) pop * (size_t) d->rowwords, d->rs));
+    DCK(d, nla_memset(d->d_gate, 0, sizeof(int) * (size_t) (d->units + 3), d->rs));
+    DCK(d, nla_event_record(d->ev_gate, d->rs));
+    d->bits_pre_g0 = nla_mtstream_origin(d->mts) + d->words_used;
+    if (nla_mtstream_rankbits_gated(d->mts, d->words_used, d->words_used, 2ULL * (uint64_t) popm1 * (uint64_t) pop, popm1, d->rowwords, d->d_bits,
+                                    d->d_gate, d->d_gate + d->units + 1, d->gen_waves_per_cu))
+        DFAIL(d, "MT stream ranking bits failed");
+    return 0;
+}
+
 static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double *t_rng, nlopt_amd_stats *st)
 {
     const int64_t pop = d->pop, popm1 = pop - 1;
@@ -203,12 +224,12 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
      * (hip/isres_stochrank.h).  The pipeline's unit u starts ~15 us after unit u - 1, which is time enough for the ten segments of a
      * block: the generation of the bits disappears behind the pipeline.  One rank with the generator on its own stream only (several
      * ranks all-gather the complete bits first). */
-    int gated = d->gated && d->rs != d->st && nlopt_amd_comm_world(d->comm) == 1 && !d->bits_two_pass && d->d_gate != NULL;
+    int gated = dev_rank_is_gated(d);
     uint64_t gate_g0 = 0;
     int gate_err = 0;
     *sweeps_out = 0;
     DCK(d, nla_k_isres_rank_count(pop, d->d_F, d->d_PEN, d->d_streams, d->d_irank, d->st));
-    if (all_feasible || popm1 <= 0) return 0;      /* irank = stable sort by f (or the single individual) */
+    if (all_feasible || popm1 <= 0) { d->bits_pre = 0; return 0; }      /* irank = stable sort by f (or the single individual) */
     /* the uniforms of all pop sweeps, reduced to bits, generated in whole-sweep passes */
     t0 = nla_seconds();
     rows_per = (int64_t) (d->wchunk / (2ULL * (uint64_t) popm1));
@@ -222,13 +243,9 @@ static int dev_rank(isres_dev *d, int all_feasible, int64_t *sweeps_out, double 
         const int64_t first = world > 1 ? (d->per * rank < pop ? d->per * rank : pop) : 0;
         const int64_t last = world > 1 ? (first + d->per < pop ? first + d->per : pop) : pop;
         if (gated) {
-            DCK(d, nla_memset(d->d_bits, 0, sizeof(uint64_t) * (size_t) pop * (size_t) d->rowwords, d->rs));
-            DCK(d, nla_memset(d->d_gate, 0, sizeof(int) * (size_t) (d->units + 3), d->rs));
-            DCK(d, nla_event_record(d->ev_gate, d->rs));
-            gate_g0 = nla_mtstream_origin(d->mts) + d->words_used;
-            if (nla_mtstream_rankbits_gated(d->mts, d->words_used, d->words_used, 2ULL * (uint64_t) popm1 * (uint64_t) pop, popm1, d->rowwords, d->d_bits,
-                                            d->d_gate, d->d_gate + d->units + 1, d->gen_waves_per_cu))
-                DFAIL(d, "MT stream ranking bits failed");
+            if (!d->bits_pre && dev_rank_bits_gated(d)) return -1;
+            gate_g0 = d->bits_pre_g0;
+            d->bits_pre = 0;
         } else if (!d->bits_two_pass) {
             /* words -> bits in one kernel, all of this rank's sweeps in one launch (hip/mt_kernels.hip, mt_rankbits_kernel):
              * the words are never written to memory */
@@ -601,6 +618,14 @@ nlopt_result nla_isres_minimize(nlopt_opt opt, int n, nlopt_func f, void *f_data
         }
         if (st) st->t_eval_s += nla_seconds() - t0;
 
+        /* the generator of the ranking's bits goes out in front of the bookkeeping below when the generation will be ranked on the device with
+         * bits (some penalty positive, no NaN: the same two tests the ranking itself makes further down) */
+        D.bits_pre = 0;
+        if (dev_eval && D.pop > 1 && D.m + D.p > 0 && dev_rank_is_gated(&D) && !NLA_DBG_ENV("NLA_ISRES_NO_BITS_PRE")) {
+            int anypen = 0, nan = 0;
+            for (k = 0; k < D.pop; ++k) { anypen |= D.h_PEN[k] > 0; nan |= (D.h_F[k] != D.h_F[k]) || (D.h_PEN[k] != D.h_PEN[k]); }
+            if (anypen && !nan) { if (dev_rank_bits_gated(&D)) DEVFAIL(); D.bits_pre = 1; }
+        }
         /* the reference's per-candidate bookkeeping, in candidate order (isres.c:134-199) */
         /* several ranks: the clock and the force_stop flag are decided once per generation, by all ranks together (comm.c) */
         sp = nla_comm_agree_stop(D.comm, stop, &agreed_view, &agreed_force);
